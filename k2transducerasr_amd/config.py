@@ -1,0 +1,142 @@
+"""Model configuration contract for the k2hip engine.
+
+The reference's real configuration is the ONNX custom-metadata map
+(K2TransducerAsr/OfflineModel.cs:31-72: ``context_size``, ``vocab_size``,
+``joiner_dim``, ``model_type``, ``feature``; K2TransducerAsr/OnlineModel.cs:38-166
+adds ``encoder_dims``, ``num_encoder_layers``, ``cnn_module_kernels``,
+``left_context_len``, ``query_head_dims``, ``value_head_dims``, ``num_heads``,
+``decode_chunk_len``, ``T``).  All values are *strings*; lists are
+comma-separated integers, exactly as the reference parses them
+(OnlineModel.cs:60-110).  The ``.k2w`` weight file carries the same map, plus
+the per-stack hyper-parameters that an ONNX export bakes into the graph
+(``feedforward_dims``, ``downsampling_factors``, ``pos_dim``,
+``pos_head_dims``) and the fbank options that live inside the third-party
+SpeechFeatures package.
+"""
+from __future__ import annotations
+
+import copy
+
+# kaldi-native-fbank defaults, with the window the reference passes
+# (Model/FrontendConfEntity.cs:8 -> "hamming"; WavFrontend.cs:22-29).
+FBANK_DEFAULTS = {
+    "feature": "fbank",
+    "sample_rate": "16000",
+    "feature_dim": "80",
+    "frame_length_ms": "25",
+    "frame_shift_ms": "10",
+    "window_type": "hamming",
+    "dither": "0",
+    "snip_edges": "1",
+    "preemph_coeff": "0.97",
+    "remove_dc_offset": "1",
+    "low_freq": "20",
+    "high_freq": "0",
+    "input_scale": "1.0",
+}
+
+
+def _csv(xs):
+    return ",".join(str(int(x)) for x in xs)
+
+
+def make_zipformer2_meta(
+    *,
+    encoder_dims,
+    num_encoder_layers,
+    feedforward_dims,
+    num_heads,
+    cnn_module_kernels,
+    downsampling_factors,
+    query_head_dim=32,
+    value_head_dim=12,
+    pos_head_dim=4,
+    pos_dim=48,
+    joiner_dim=512,
+    decoder_dim=512,
+    vocab_size=500,
+    context_size=2,
+    comment="",
+):
+    n = len(encoder_dims)
+    assert all(
+        len(x) == n
+        for x in (num_encoder_layers, feedforward_dims, num_heads, cnn_module_kernels, downsampling_factors)
+    )
+    meta = dict(FBANK_DEFAULTS)
+    meta.update(
+        {
+            "model_type": "zipformer2",
+            "version": "1",
+            "model_author": "k2hip-synthetic",
+            "comment": comment,
+            "encoder_dims": _csv(encoder_dims),
+            "num_encoder_layers": _csv(num_encoder_layers),
+            "feedforward_dims": _csv(feedforward_dims),
+            "num_heads": _csv(num_heads),
+            "cnn_module_kernels": _csv(cnn_module_kernels),
+            "downsampling_factors": _csv(downsampling_factors),
+            "query_head_dims": _csv([query_head_dim] * n),
+            "value_head_dims": _csv([value_head_dim] * n),
+            "pos_head_dims": _csv([pos_head_dim] * n),
+            "pos_dim": str(pos_dim),
+            "joiner_dim": str(joiner_dim),
+            "decoder_dim": str(decoder_dim),
+            "vocab_size": str(vocab_size),
+            "context_size": str(context_size),
+        }
+    )
+    return meta
+
+
+# Architecture presets.  Dimensions are those of the public icefall recipes the
+# reference's model zoo was exported from (README.EN.md:8-35 lists the model
+# names; the dims themselves are external to the reference).
+PRESETS = {
+    # BASELINE.json configs[1]: the model the headline metric is quoted on.
+    "zipformer2-large-en": dict(
+        encoder_dims=[192, 256, 512, 768, 512, 256],
+        num_encoder_layers=[2, 2, 4, 5, 4, 2],
+        feedforward_dims=[512, 768, 1536, 2048, 1536, 768],
+        num_heads=[4, 4, 4, 8, 4, 4],
+        cnn_module_kernels=[31, 31, 15, 15, 15, 31],
+        downsampling_factors=[1, 2, 4, 8, 4, 2],
+        vocab_size=500,
+    ),
+    # BASELINE.json configs[0].
+    "zipformer2-small-en": dict(
+        encoder_dims=[192, 256, 256, 256, 256, 256],
+        num_encoder_layers=[2, 2, 2, 2, 2, 2],
+        feedforward_dims=[512, 768, 768, 768, 768, 768],
+        num_heads=[4, 4, 4, 8, 4, 4],
+        cnn_module_kernels=[31, 31, 15, 15, 15, 31],
+        downsampling_factors=[1, 2, 4, 8, 4, 2],
+        vocab_size=500,
+    ),
+    # Parity-test model: every structural feature of the big one (unequal
+    # stack dims -> channel pad/truncate + full-dim concat, three
+    # downsampling factors, odd lengths) at sizes the CPU oracle runs in
+    # well under a second.
+    "zipformer2-tiny-test": dict(
+        encoder_dims=[64, 96, 128, 64],
+        num_encoder_layers=[1, 2, 1, 1],
+        feedforward_dims=[128, 192, 256, 128],
+        num_heads=[2, 2, 4, 2],
+        cnn_module_kernels=[15, 7, 7, 15],
+        downsampling_factors=[1, 2, 4, 2],
+        vocab_size=37,
+        # the offline loops hard-code 512 (OfflineRecognizer.cs:103,136,201,219)
+        joiner_dim=512,
+        decoder_dim=64,
+    ),
+}
+
+
+def preset(name: str) -> dict:
+    if name not in PRESETS:
+        raise KeyError(f"unknown model preset {name!r}; have {sorted(PRESETS)}")
+    return make_zipformer2_meta(comment=name, **copy.deepcopy(PRESETS[name]))
+
+
+def ints(meta: dict, key: str):
+    return [int(x) for x in meta[key].split(",") if x != ""]

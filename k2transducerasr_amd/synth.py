@@ -1,0 +1,188 @@
+"""Seeded synthetic model weights and audio (there are no real checkpoints or
+wavs in this environment; SURVEY.md section 8d defines the recipe).
+
+Weights are N(0, 1/sqrt(fan_in)) f32 under icefall state-dict names.  The same
+``.k2w`` file is read by the CPU oracle and by the HIP engine, so parity never
+depends on the generator.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from .config import ints, preset
+from .k2w import write_k2w
+
+AUDIO_SEED_BASE = 0x2A50000
+
+# Joiner blank-bias per preset, frozen from tools/calibrate_blank_bias.py so that
+# roughly a quarter to a tenth of the frames emit a symbol on synth_utterance().
+BLANK_BIAS = {
+    "zipformer2-large-en": 3.656,
+    "zipformer2-small-en": 2.849,
+    "zipformer2-tiny-test": 1.033,
+}
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.default_rng([seed, zlib.crc32(name.encode())])
+
+
+def zipformer2_tensor_specs(meta: Dict[str, str]) -> List[Tuple[str, tuple, str]]:
+    """(name, shape, kind) for every tensor of an offline Zipformer2 transducer.
+
+    kind: "w" weight (fan_in = prod(shape[1:])), "b" bias, "bypass", "logscale",
+    "dsbias", "emb".
+    """
+    dims = ints(meta, "encoder_dims")
+    layers = ints(meta, "num_encoder_layers")
+    ffs = ints(meta, "feedforward_dims")
+    heads = ints(meta, "num_heads")
+    kernels = ints(meta, "cnn_module_kernels")
+    dss = ints(meta, "downsampling_factors")
+    qhd = ints(meta, "query_head_dims")
+    vhd = ints(meta, "value_head_dims")
+    phd = ints(meta, "pos_head_dims")
+    pos_dim = int(meta["pos_dim"])
+    J = int(meta["joiner_dim"])
+    DD = int(meta["decoder_dim"])
+    V = int(meta["vocab_size"])
+    ctx = int(meta["context_size"])
+    fdim = int(meta["feature_dim"])
+    out_width = (((fdim - 1) // 2) - 1) // 2
+
+    s: List[Tuple[str, tuple, str]] = []
+
+    def lin(prefix, out_f, in_f, bias=True):
+        s.append((prefix + ".weight", (out_f, in_f), "w"))
+        if bias:
+            s.append((prefix + ".bias", (out_f,), "b"))
+
+    e = "encoder_embed."
+    s += [
+        (e + "conv.0.weight", (8, 1, 3, 3), "w"),
+        (e + "conv.0.bias", (8,), "b"),
+        (e + "conv.4.weight", (32, 8, 3, 3), "w"),
+        (e + "conv.4.bias", (32,), "b"),
+        (e + "conv.7.weight", (128, 32, 3, 3), "w"),
+        (e + "conv.7.bias", (128,), "b"),
+        (e + "convnext.depthwise_conv.weight", (128, 1, 7, 7), "w"),
+        (e + "convnext.depthwise_conv.bias", (128,), "b"),
+        (e + "convnext.pointwise_conv1.weight", (384, 128, 1, 1), "w"),
+        (e + "convnext.pointwise_conv1.bias", (384,), "b"),
+        (e + "convnext.pointwise_conv2.weight", (128, 384, 1, 1), "w"),
+        (e + "convnext.pointwise_conv2.bias", (128,), "b"),
+    ]
+    lin(e + "out", dims[0], 128 * out_width)
+    s += [(e + "out_norm.log_scale", (1,), "logscale"), (e + "out_norm.bias", (dims[0],), "b")]
+
+    for i, (D, L, F, H, K, ds) in enumerate(zip(dims, layers, ffs, heads, kernels, dss)):
+        st = f"encoder.encoders.{i}."
+        if ds > 1:
+            s.append((st + "downsample.bias", (ds,), "dsbias"))
+            s.append((st + "out_combiner.bypass_scale", (D,), "bypass"))
+        for j in range(L):
+            p = st + f"layers.{j}."
+            lin(p + "self_attn_weights.in_proj", (2 * qhd[i] + phd[i]) * H, D)
+            lin(p + "self_attn_weights.linear_pos", phd[i] * H, pos_dim, bias=False)
+            for k, Fk in ((1, F * 3 // 4), (2, F), (3, F * 5 // 4)):
+                lin(p + f"feed_forward{k}.in_proj", Fk, D)
+                lin(p + f"feed_forward{k}.out_proj", D, Fk)
+            Hc = 3 * D // 4
+            lin(p + "nonlin_attention.in_proj", 3 * Hc, D)
+            lin(p + "nonlin_attention.out_proj", D, Hc)
+            for k in (1, 2):
+                lin(p + f"self_attn{k}.in_proj", vhd[i] * H, D)
+                lin(p + f"self_attn{k}.out_proj", D, vhd[i] * H)
+            for k in (1, 2):
+                lin(p + f"conv_module{k}.in_proj", 2 * D, D)
+                s.append((p + f"conv_module{k}.depthwise_conv.weight", (D, 1, K), "w"))
+                s.append((p + f"conv_module{k}.depthwise_conv.bias", (D,), "b"))
+                lin(p + f"conv_module{k}.out_proj", D, D)
+            s.append((p + "norm.log_scale", (1,), "logscale"))
+            s.append((p + "norm.bias", (D,), "b"))
+            s.append((p + "bypass.bypass_scale", (D,), "bypass"))
+            s.append((p + "bypass_mid.bypass_scale", (D,), "bypass"))
+    s.append(("encoder.downsample_output.bias", (2,), "dsbias"))
+    lin("joiner.encoder_proj", J, max(dims))
+    lin("joiner.decoder_proj", J, DD)
+    lin("joiner.output_linear", V, J)
+    s.append(("decoder.embedding.weight", (V, DD), "emb"))
+    s.append(("decoder.conv.weight", (DD, 4, ctx), "w"))
+    return s
+
+
+def _init(name: str, shape: tuple, kind: str, seed: int) -> np.ndarray:
+    g = _rng(seed, name)
+    if kind == "w":
+        fan_in = int(np.prod(shape[1:]))
+        return (g.standard_normal(shape) / np.sqrt(fan_in)).astype(np.float32)
+    if kind == "b":
+        return (0.1 * g.standard_normal(shape)).astype(np.float32)
+    if kind == "bypass":
+        # small per-layer bypass scales keep a random-weight stack close to the
+        # identity, so the input's temporal structure survives 19 layers
+        lo, hi = (0.3, 0.9) if "out_combiner" in name else (0.05, 0.25)
+        return g.uniform(lo, hi, shape).astype(np.float32)
+    if kind == "logscale":
+        return g.uniform(-0.2, 0.2, shape).astype(np.float32)
+    if kind == "dsbias":
+        return (0.5 * g.standard_normal(shape)).astype(np.float32)
+    if kind == "emb":
+        return g.standard_normal(shape).astype(np.float32)
+    raise ValueError(kind)
+
+
+def write_synthetic_model(path: str, preset_name: str, seed: int = 20231212, blank_bias: float | None = None,
+                          meta_overrides: Dict[str, str] | None = None) -> Dict[str, str]:
+    """Write a seeded random-weight Zipformer2 transducer.
+
+    ``blank_bias`` is added to the joiner's output bias at id 0 so that blank
+    wins most frames, as it does on speech; it is recorded in
+    the metadata for traceability only.
+    """
+    meta = preset(preset_name)
+    if blank_bias is None:
+        blank_bias = BLANK_BIAS.get(preset_name, 1.0)
+    if meta_overrides:
+        meta.update(meta_overrides)
+    meta["synthetic_seed"] = str(seed)
+    meta["synthetic_blank_bias"] = repr(float(blank_bias))
+
+    def gen():
+        for name, shape, kind in zipformer2_tensor_specs(meta):
+            a = _init(name, shape, kind, seed)
+            if name == "joiner.output_linear.bias":
+                a[0] += np.float32(blank_bias)
+            if name == "joiner.encoder_proj.weight":
+                a *= np.float32(4.0)  # let the (small) temporal variation reach the logits
+            if name == "encoder_embed.conv.0.weight":
+                # zero-sum along time: a constant-in-time input (the large DC of
+                # log-mel features) maps to 0, so that random-weight activations
+                # keep their temporal variation instead of collapsing to a bias.
+                a -= a.mean(axis=2, keepdims=True)
+                a *= np.float32(4.0)
+            yield name, a
+
+    write_k2w(path, meta, gen())
+    return meta
+
+
+def synth_utterance(u: int, seconds: float, sample_rate: int = 16000) -> np.ndarray:
+    """Deterministic speech-like test signal, float32 in [-0.99, 0.99], no exact zeros."""
+    g = np.random.default_rng(AUDIO_SEED_BASE + int(u))
+    n = int(round(seconds * sample_rate))
+    t = np.arange(n, dtype=np.float64) / sample_rate
+    x = np.zeros(n, dtype=np.float64)
+    for _ in range(8):
+        f = g.uniform(80.0, 7600.0)
+        a = g.uniform(0.01, 0.1)
+        ph = g.uniform(0.0, 2 * np.pi)
+        x += a * np.sin(2 * np.pi * f * t + ph)
+    env = 0.5 - 0.5 * np.cos(2 * np.pi * 3.0 * t + g.uniform(0.0, 2 * np.pi))
+    x = x * (0.15 + 0.85 * env) + 0.01 * g.standard_normal(n)
+    x = np.clip(x, -0.99, 0.99).astype(np.float32)
+    x[x == 0.0] = np.float32(1e-7)
+    return x

@@ -1,0 +1,93 @@
+/*
+ * k2_oracle.h -- CPU restatement ("oracle") of the K2TransducerAsr RNN-T decode
+ * hot path.  TEST INFRASTRUCTURE ONLY: nothing under oracle/ is linked, imported
+ * or executed by the product (k2transducerasr_amd/, libk2hip.so).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it, and only
+ * as the checker / the CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (C#) has no tests, golden vectors or fixtures
+ * for this path, cannot be built here (no dotnet/mono), and
+ * the arithmetic it runs lives in un-vendored third-party packages
+ * (Microsoft.ML.OnnxRuntime 1.22.1, ManySpeech.SpeechFeatures 1.1.6,
+ * K2TransducerAsr/K2TransducerAsr.csproj:12-14) over model files that are not in
+ * the tree.  What this oracle restates:
+ *   - from the reference itself (file:line cited at each function): padding
+ *     quirks, tensor layouts at the IOfflineProj boundary, the greedy-search
+ *     control flow, argmax tie-break, emit filters, context seeding;
+ *   - from the published algorithms the third-party pieces implement: kaldi
+ *     fbank, icefall Zipformer2 / stateless decoder / joiner inference graphs.
+ * It is pinned by hand-computed known-answer tests and by an independent torch
+ * restatement (tests/torch_twin.py) -- not by reference outputs.
+ */
+#ifndef K2_ORACLE_H
+#define K2_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct k2o_model k2o_model;
+
+/* ---- model ---------------------------------------------------------------- */
+k2o_model* k2o_model_load(const char* k2w_path);
+void k2o_model_free(k2o_model* m);
+const char* k2o_last_error(void);
+/* metadata lookup (NULL if absent) -- mirrors CustomMetadataMap[key] */
+const char* k2o_meta(const k2o_model* m, const char* key);
+int k2o_vocab_size(const k2o_model* m);
+int k2o_joiner_dim(const k2o_model* m);
+int k2o_context_size(const k2o_model* m);
+int k2o_feature_dim(const k2o_model* m);
+
+/* ---- F1: fbank (WavFrontend.GetFbank, WavFrontend.cs:32-36) ----------------- */
+/* number of frames for n samples (snip_edges) */
+int64_t k2o_fbank_num_frames(const k2o_model* m, int64_t n_samples);
+/* feats: [n_frames, feature_dim] frame-major; returns n_frames or <0 */
+int64_t k2o_fbank(const k2o_model* m, const float* samples, int64_t n_samples, float* feats, int64_t cap_frames);
+
+/* ---- F3: PadHelper.PadSequence (PadHelper.cs:14-60) ------------------------- */
+/* returns padded per-utterance float count (max_len + 80*tail_frames); out is
+ * [B, padded] flattened; out may be NULL to query the size. */
+int64_t k2o_pad_sequence(const float* const* speech, const int64_t* n_floats, int B, int tail_frames, float* out);
+
+/* ---- F4: offline encoder (OfflineProjOfTransducer.EncoderProj :48-92) ------- */
+/* T' for T input frames */
+int k2o_encoder_out_frames(const k2o_model* m, int T);
+/* x: [B,T,feat]; enc_out: [B,T',joiner_dim]. */
+int k2o_offline_encoder(const k2o_model* m, const float* x, int B, int T, float* enc_out);
+/* debug taps: tap 0 = encoder_embed output [B,T50,D0]; tap 1+i = output of
+ * stack i at 50 Hz [B,T50,D_i]; tap 100 = full-dim output before final
+ * downsample [B,T50,Dmax]. Returns number of floats written or <0. */
+int64_t k2o_offline_encoder_tap(const k2o_model* m, const float* x, int B, int T, int tap, float* out, int64_t cap);
+
+/* ---- F5/F6: decoder, joiner -------------------------------------------------- */
+/* y: [N, ctx] int64 (negative id -> zero embedding); dec_out: [N, joiner_dim] */
+int k2o_decoder(const k2o_model* m, const int64_t* y, int N, float* dec_out);
+/* logits: [N, vocab] = output_linear(tanh(enc + dec)) */
+int k2o_joiner(const k2o_model* m, const float* enc, const float* dec, int N, float* logits);
+
+/* ---- F7: greedy search -------------------------------------------------------- */
+/* Reference argmax (OfflineRecognizer.cs:151-154): later index wins ties/NaN. */
+int k2o_argmax_ref(const float* logits, int V);
+
+/* ForwardBatchGreedySearch (OfflineRecognizer.cs:189-303) on a precomputed
+ * encoder_out [B,T',J].  tokens/timestamps: [B, max_tokens] (real emitted
+ * tokens only, WITHOUT the 2*B blank prefix the reference seeds, Q10);
+ * n_tokens: [B].  margins (optional, [B*T']): top1-top2 logit gap per frame. */
+int k2o_greedy_batch(const k2o_model* m, const float* enc_out, int B, int Tp,
+                     int64_t* tokens, int32_t* timestamps, int32_t* n_tokens, int max_tokens,
+                     float* margins);
+/* ForwardGreedySearch (OfflineRecognizer.cs:93-187), B = 1. */
+int k2o_greedy_single(const k2o_model* m, const float* enc_out, int Tp,
+                      int64_t* tokens, int32_t* timestamps, int32_t* n_tokens, int max_tokens,
+                      float* margins);
+
+/* End to end: features -> pad -> encoder -> batch greedy (GetResults). */
+int k2o_offline_recognize_batch(const k2o_model* m, const float* const* feats, const int64_t* n_floats, int B,
+                                int64_t* tokens, int32_t* timestamps, int32_t* n_tokens, int max_tokens);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
