@@ -1,0 +1,206 @@
+/*
+ * k2hip.h -- C ABI of libk2hip.so, the MI355X (gfx950) engine behind
+ * K2TransducerAsr's IOfflineProj / IOnlineProj operator boundary.
+ *
+ * Every entry point replaces one reference interface (file:line relative to the
+ * reference repo manyeyes/K2TransducerAsr @ 2025-09-19).  The C# side binds them
+ * with [DllImport("k2hip")] (csharp/OfflineProjOfHip.cs).
+ *
+ * Conventions
+ *   - every function returns int32 status: 0 = ok, < 0 = error; the message is
+ *     in k2hip_last_error() (thread-local).  Nothing throws across the ABI.
+ *     (replaces `throw new Exception("EncoderProj failed", ex)`,
+ *      OfflineProjOfTransducer.cs:87-90; "Offline recognition failed",
+ *      OfflineRecognizer.cs:183-186,299-302)
+ *   - all buffers are caller-owned, row-major, f32 / i64 exactly as the reference
+ *     marshals them to ONNXRuntime; pointers are host pointers unless the name
+ *     says `_dev`.
+ *   - one k2hip_model_t = one GPU + one HIP stream; calls on the same handle are
+ *     serialised by an internal mutex, different handles run concurrently.
+ *   - there is NO CPU fallback: every compute entry point needs a gfx950 device
+ *     and fails with K2HIP_ERR_NO_DEVICE otherwise.
+ */
+#ifndef K2HIP_H
+#define K2HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
+#endif
+
+#define K2HIP_OK 0
+#define K2HIP_ERR_INVALID (-1)   /* bad argument / shape */
+#define K2HIP_ERR_IO (-2)        /* weight file missing or malformed */
+#define K2HIP_ERR_NO_DEVICE (-3) /* no usable HIP device */
+#define K2HIP_ERR_HIP (-4)       /* a HIP runtime call failed */
+#define K2HIP_ERR_CAPACITY (-5)  /* caller buffer too small */
+#define K2HIP_ERR_UNSUPPORTED (-6)
+
+typedef struct k2hip_model k2hip_model_t;
+typedef struct k2hip_offline_stream k2hip_offline_stream_t;
+
+/* Fixed ids of the reference: OfflineModel.cs:18-20. */
+#define K2HIP_BLANK_ID 0
+#define K2HIP_SOS_EOS_ID 1
+#define K2HIP_UNK_ID 2
+
+typedef struct k2hip_model_info {
+    int32_t vocab_size;   /* decoder metadata "vocab_size"   OfflineModel.cs:36-38 */
+    int32_t context_size; /* decoder metadata "context_size" OfflineModel.cs:33-35 */
+    int32_t joiner_dim;   /* joiner metadata "joiner_dim"    OfflineModel.cs:43-45 */
+    int32_t feature_dim;  /* OfflineModel.FeatureDim         OfflineModel.cs:21    */
+    int32_t sample_rate;
+    int32_t num_stacks;
+    int32_t device;
+    int32_t reserved;
+} k2hip_model_info;
+
+/* Per-call stage timings of the last fused call, measured with HIP events on the
+ * model's stream (replaces the reference's DateTime.Now.Ticks RTF print,
+ * K2TransducerAsr.Examples/OfflineRecognizer.cs:144,184-189). */
+typedef struct k2hip_timing {
+    float total_ms;
+    float fbank_ms;
+    float pad_ms;
+    float encoder_ms; /* embed + stacks + proj */
+    float greedy_ms;
+    float d2h_ms;
+    /* GEMM accounting, filled only when instrumentation is enabled with
+     * k2hip_set_instrument(model, 1): summed HIP-event duration of every launch
+     * of the fp32 MFMA GEMM kernel in the last call, their count and their
+     * algorithmic FLOPs (2*M*N*K per launch). */
+    float gemm_ms;
+    int32_t gemm_launches;
+    double gemm_flops;
+    double total_flops; /* all matrix work incl. attention/conv (2 FLOP per MAC) */
+} k2hip_timing;
+
+/* ---- library ---------------------------------------------------------------- */
+const char* k2hip_version(void);
+const char* k2hip_last_error(void);
+/* number of visible HIP devices (0 if none); never fails */
+int32_t k2hip_device_count(void);
+
+/* ---- model: replaces OfflineModel ctor + 3x initModel (OfflineModel.cs:23-73,
+ * 84-118).  `weights_path` is a .k2w container holding the ONNX custom-metadata
+ * map and all initializers; `overrides` is NULL or "key=value;key=value" applied on
+ * top of that map (same keys the reference reads: OfflineModel.cs:31-72,
+ * OnlineModel.cs:38-166). A missing file is an error here (the reference returns
+ * a null session and fails later with a NullReferenceException, :86-89). */
+int32_t k2hip_model_create(const char* weights_path, const char* overrides, int32_t device, k2hip_model_t** out);
+int32_t k2hip_model_destroy(k2hip_model_t* model);
+int32_t k2hip_model_get_info(const k2hip_model_t* model, k2hip_model_info* info);
+/* CustomMetadataMap[key] -> buf (NUL terminated); K2HIP_ERR_INVALID if absent */
+int32_t k2hip_model_meta(const k2hip_model_t* model, const char* key, char* buf, int32_t cap);
+int32_t k2hip_set_instrument(k2hip_model_t* model, int32_t on);
+int32_t k2hip_get_timing(const k2hip_model_t* model, k2hip_timing* timing);
+
+/* ---- F1: WavFrontend.GetFbank (WavFrontend.cs:32-36 -> SpeechFeatures.OnlineFbank)
+ * samples: f32 in [-1,1]; feats: [n_frames, feature_dim] frame-major.  One-shot
+ * (snip_edges) framing of exactly these samples. */
+int64_t k2hip_fbank_num_frames(const k2hip_model_t* model, int64_t n_samples);
+int32_t k2hip_fbank(k2hip_model_t* model, const float* samples, int64_t n_samples, float* feats, int64_t cap_frames,
+                    int64_t* n_frames);
+
+/* ---- F3: PadHelper.PadSequence(List<OfflineInputEntity>) (PadHelper.cs:14-60):
+ * right-pad to max+80*tail_frames floats, then every 0.0 -> -23.025850929940457f.
+ * out: [B, padded_len]. Runs on the device (the fused entries never call this
+ * separately; it is exported so the quirk can be parity-tested on its own). */
+int32_t k2hip_pad_sequence(k2hip_model_t* model, const float* const* speech, const int64_t* n_floats, int32_t B,
+                           int32_t tail_frames, float* out, int64_t cap_floats, int64_t* padded_len);
+
+/* ---- F4: IOfflineProj.EncoderProj body after padding
+ * (OfflineProjOfTransducer.cs:52-85): x [B,T,feature_dim] f32, x_lens [B] i64 (the
+ * reference always passes T for every row, :66-70; values are ignored exactly as
+ * the reference's loop ignores encoder_out_lens) -> enc_out [B,T',joiner_dim],
+ * enc_out_lens [B] (may be NULL), *Tprime. */
+int32_t k2hip_encoder_out_frames(const k2hip_model_t* model, int32_t T);
+int32_t k2hip_offline_encoder(k2hip_model_t* model, const float* x, const int64_t* x_lens, int32_t B, int32_t T,
+                              float* enc_out, int64_t cap_floats, int64_t* enc_out_lens, int32_t* Tprime);
+/* debug tap for layer-level parity: tap 0 = encoder_embed out [B,T50,D0];
+ * 1+i = stack i out [B,T50,D_i]; 100 = full-dim out [B,T50,Dmax]. */
+int32_t k2hip_offline_encoder_tap(k2hip_model_t* model, const float* x, int32_t B, int32_t T, int32_t tap, float* out,
+                                  int64_t cap_floats, int64_t* n_floats);
+
+/* ---- F5: IOfflineProj.DecoderProj (OfflineProjOfTransducer.cs:93-123):
+ * y [N, context_size] i64 (id < 0 -> zero embedding, used at utterance start,
+ * OfflineRecognizer.cs:105) -> dec_out [N, joiner_dim].  y == NULL means
+ * [-1, blank] x N (:97-110). */
+int32_t k2hip_decoder(k2hip_model_t* model, const int64_t* y, int32_t N, float* dec_out);
+
+/* ---- F6: IOfflineProj.JoinerProj (OfflineProjOfTransducer.cs:125-152):
+ * enc [N,J], dec [N,J] -> logits [N, vocab]. */
+int32_t k2hip_joiner(k2hip_model_t* model, const float* enc, const float* dec, int32_t N, float* logits);
+
+/* ---- F7 on a precomputed encoder_out: the greedy loops alone.
+ * k2hip_greedy_batch  = OfflineRecognizer.ForwardBatchGreedySearch :202-296
+ * k2hip_greedy_single = OfflineRecognizer.ForwardGreedySearch      :103-181
+ * enc_out [B,T',J] (B = 1 for single).  tokens/timestamps [B, max_tokens] hold the
+ * emitted symbols only (the reference's `Tokens` additionally starts with 2*B
+ * blanks in the batch path, :250-258, or [-1, blank] in the single path,
+ * :115-117; the C# shim re-adds that prefix).  timestamps are 25 Hz frame indices. */
+int32_t k2hip_greedy_batch(k2hip_model_t* model, const float* enc_out, int32_t B, int32_t Tprime, int64_t* tokens,
+                           int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens);
+int32_t k2hip_greedy_single(k2hip_model_t* model, const float* enc_out, int32_t Tprime, int64_t* tokens,
+                            int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens);
+
+/* ---- fused hot path: the body of the ForwardBatchOffline delegate
+ * (OfflineRecognizer.cs:11,58,189-303): pad (F3) + encoder (F4) + greedy (F7) in
+ * one call, one host->device and one device->host crossing.
+ * feats[b]: [n_floats[b]] = per-stream OfflineInputEntity.Speech. */
+int32_t k2hip_offline_greedy(k2hip_model_t* model, const float* const* feats, const int64_t* n_floats, int32_t B,
+                             int64_t* tokens, int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens);
+/* ... the ForwardOffline delegate (single stream, :10,57,93-187) */
+int32_t k2hip_offline_greedy_single(k2hip_model_t* model, const float* feats, int64_t n_floats, int64_t* tokens,
+                                    int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens);
+/* ... plus F1: raw samples in (OfflineStream.AddSamples + GetResults). */
+int32_t k2hip_offline_greedy_from_samples(k2hip_model_t* model, const float* const* samples, const int64_t* n_samples,
+                                          int32_t B, int64_t* tokens, int32_t* timestamps, int32_t* n_tokens,
+                                          int32_t max_tokens);
+/* Same, with the samples already resident in this model's GPU memory
+ * (samples_dev: [B, n_samples_each] contiguous device buffer).  This is the
+ * benchmark entry: the timed region starts with inputs in HBM. */
+int32_t k2hip_offline_greedy_from_samples_dev(k2hip_model_t* model, const float* samples_dev, int64_t n_samples_each,
+                                              int32_t B, int64_t* tokens, int32_t* timestamps, int32_t* n_tokens,
+                                              int32_t max_tokens);
+
+/* device memory helpers for the benchmark / host runtimes without a HIP binding */
+int32_t k2hip_device_alloc(k2hip_model_t* model, int64_t bytes, void** dev_ptr);
+int32_t k2hip_device_free(k2hip_model_t* model, void* dev_ptr);
+int32_t k2hip_device_upload(k2hip_model_t* model, void* dev_dst, const void* host_src, int64_t bytes);
+int32_t k2hip_synchronize(k2hip_model_t* model);
+
+/* ---- OfflineStream (OfflineStream.cs:7-99): per-utterance feature buffer.
+ * accept_samples = AddSamples (:43-57): runs the streaming fbank on the new
+ * samples (left-over samples shorter than a frame shift are carried to the next
+ * call, as an OnlineFbank does; InputFinished is never called by the reference,
+ * SURVEY Q16) and APPENDS the frames to Speech. */
+int32_t k2hip_offline_stream_create(k2hip_model_t* model, k2hip_offline_stream_t** out);
+int32_t k2hip_offline_stream_destroy(k2hip_offline_stream_t* s);
+int32_t k2hip_offline_stream_accept_samples(k2hip_offline_stream_t* s, const float* samples, int64_t n);
+/* SpeechLength (float count) */
+int64_t k2hip_offline_stream_speech_length(const k2hip_offline_stream_t* s);
+/* copies Speech to out (cap floats) */
+int32_t k2hip_offline_stream_get_speech(const k2hip_offline_stream_t* s, float* out, int64_t cap);
+/* OfflineRecognizer.GetResults (:85-91) minus DecodeMulti: runs the fused batch
+ * path on the streams' feature buffers, stores Tokens/Timestamps in each stream
+ * (including the reference's 2*B-blank prefix) and calls RemoveSamples (:294). */
+int32_t k2hip_offline_recognizer_get_results(k2hip_model_t* model, k2hip_offline_stream_t* const* streams, int32_t B);
+/* OfflineRecognizer.GetResult (:77-83): single-stream path, Tokens = [-1, blank, ...] */
+int32_t k2hip_offline_recognizer_get_result(k2hip_model_t* model, k2hip_offline_stream_t* stream);
+/* stream.Tokens / stream.Timestamps exactly as the reference would hold them */
+int32_t k2hip_offline_stream_num_tokens(const k2hip_offline_stream_t* s);
+int32_t k2hip_offline_stream_num_timestamps(const k2hip_offline_stream_t* s);
+int32_t k2hip_offline_stream_get_tokens(const k2hip_offline_stream_t* s, int64_t* tokens, int32_t cap);
+int32_t k2hip_offline_stream_get_timestamps(const k2hip_offline_stream_t* s, int32_t* timestamps, int32_t cap);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* K2HIP_H */

@@ -1,0 +1,404 @@
+"""ctypes binding of include/k2hip.h.
+
+Class and method names follow the reference's host API so that the parity tests
+read like the reference's own call sites:
+
+    reference (C#)                                  here
+    ---------------------------------------------   ---------------------------------
+    new OfflineRecognizer(enc, dec, joiner, tok)    OfflineRecognizer(weights_path)
+    recognizer.CreateOfflineStream()                recognizer.create_offline_stream()
+    stream.AddSamples(float[])                      stream.add_samples(np.ndarray)
+    recognizer.GetResults(List<OfflineStream>)      recognizer.get_results([streams])
+    recognizer.GetResult(stream)                    recognizer.get_result(stream)
+    IOfflineProj.EncoderProj / DecoderProj / ...    Model.encoder_proj / decoder_proj / joiner_proj
+
+(K2TransducerAsr/OfflineRecognizer.cs:27-91, OfflineStream.cs:43-57,
+IOfflineProj.cs:43-47.)  All arithmetic happens inside libk2hip.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libk2hip.so")
+_CSRC = os.path.join(_HERE, "csrc")
+
+
+class K2HipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"k2hip error {code}: {msg}")
+        self.code = code
+
+
+def library_path() -> str:
+    return _SO
+
+
+def build_library(force: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libk2hip.so (in-tree)."""
+    if force:
+        subprocess.check_call(["make", "-C", _CSRC, "-s", "clean"])
+    subprocess.check_call(["make", "-C", _CSRC, "-s", "-j8"])
+    return _SO
+
+
+class TimingStruct(C.Structure):
+    _fields_ = [
+        ("total_ms", C.c_float), ("fbank_ms", C.c_float), ("pad_ms", C.c_float), ("encoder_ms", C.c_float),
+        ("greedy_ms", C.c_float), ("d2h_ms", C.c_float), ("gemm_ms", C.c_float), ("gemm_launches", C.c_int32),
+        ("gemm_flops", C.c_double), ("total_flops", C.c_double),
+    ]
+
+
+class InfoStruct(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("vocab_size", "context_size", "joiner_dim", "feature_dim", "sample_rate",
+                                         "num_stacks", "device", "reserved")]
+
+
+_lib = None
+fp = C.POINTER(C.c_float)
+ip = C.POINTER(C.c_int32)
+lp = C.POINTER(C.c_int64)
+
+
+def load_library():
+    """Load libk2hip.so.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise K2HipError(-2, f"{_SO} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(there is no CPU fallback for this package)")
+    L = C.CDLL(_SO)
+    vp = C.c_void_p
+    L.k2hip_version.restype = C.c_char_p
+    L.k2hip_last_error.restype = C.c_char_p
+    L.k2hip_device_count.restype = C.c_int32
+    L.k2hip_model_create.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(vp)]
+    L.k2hip_model_destroy.argtypes = [vp]
+    L.k2hip_model_get_info.argtypes = [vp, C.POINTER(InfoStruct)]
+    L.k2hip_model_meta.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int32]
+    L.k2hip_set_instrument.argtypes = [vp, C.c_int32]
+    L.k2hip_get_timing.argtypes = [vp, C.POINTER(TimingStruct)]
+    L.k2hip_fbank_num_frames.restype = C.c_int64
+    L.k2hip_fbank_num_frames.argtypes = [vp, C.c_int64]
+    L.k2hip_fbank.argtypes = [vp, fp, C.c_int64, fp, C.c_int64, lp]
+    L.k2hip_pad_sequence.argtypes = [vp, C.POINTER(fp), lp, C.c_int32, C.c_int32, fp, C.c_int64, lp]
+    L.k2hip_encoder_out_frames.argtypes = [vp, C.c_int32]
+    L.k2hip_offline_encoder.argtypes = [vp, fp, lp, C.c_int32, C.c_int32, fp, C.c_int64, lp, ip]
+    L.k2hip_offline_encoder_tap.argtypes = [vp, fp, C.c_int32, C.c_int32, C.c_int32, fp, C.c_int64, lp]
+    L.k2hip_decoder.argtypes = [vp, lp, C.c_int32, fp]
+    L.k2hip_joiner.argtypes = [vp, fp, fp, C.c_int32, fp]
+    L.k2hip_greedy_batch.argtypes = [vp, fp, C.c_int32, C.c_int32, lp, ip, ip, C.c_int32]
+    L.k2hip_greedy_single.argtypes = [vp, fp, C.c_int32, lp, ip, ip, C.c_int32]
+    L.k2hip_offline_greedy.argtypes = [vp, C.POINTER(fp), lp, C.c_int32, lp, ip, ip, C.c_int32]
+    L.k2hip_offline_greedy_single.argtypes = [vp, fp, C.c_int64, lp, ip, ip, C.c_int32]
+    L.k2hip_offline_greedy_from_samples.argtypes = [vp, C.POINTER(fp), lp, C.c_int32, lp, ip, ip, C.c_int32]
+    L.k2hip_offline_greedy_from_samples_dev.argtypes = [vp, vp, C.c_int64, C.c_int32, lp, ip, ip, C.c_int32]
+    L.k2hip_device_alloc.argtypes = [vp, C.c_int64, C.POINTER(vp)]
+    L.k2hip_device_free.argtypes = [vp, vp]
+    L.k2hip_device_upload.argtypes = [vp, vp, vp, C.c_int64]
+    L.k2hip_synchronize.argtypes = [vp]
+    L.k2hip_offline_stream_create.argtypes = [vp, C.POINTER(vp)]
+    L.k2hip_offline_stream_destroy.argtypes = [vp]
+    L.k2hip_offline_stream_accept_samples.argtypes = [vp, fp, C.c_int64]
+    L.k2hip_offline_stream_speech_length.restype = C.c_int64
+    L.k2hip_offline_stream_speech_length.argtypes = [vp]
+    L.k2hip_offline_stream_get_speech.argtypes = [vp, fp, C.c_int64]
+    L.k2hip_offline_recognizer_get_results.argtypes = [vp, C.POINTER(vp), C.c_int32]
+    L.k2hip_offline_recognizer_get_result.argtypes = [vp, vp]
+    L.k2hip_offline_stream_num_tokens.argtypes = [vp]
+    L.k2hip_offline_stream_num_timestamps.argtypes = [vp]
+    L.k2hip_offline_stream_get_tokens.argtypes = [vp, lp, C.c_int32]
+    L.k2hip_offline_stream_get_timestamps.argtypes = [vp, ip, C.c_int32]
+    _lib = L
+    return L
+
+
+def _f(a):
+    return a.ctypes.data_as(fp)
+
+
+def _i(a):
+    return a.ctypes.data_as(ip)
+
+
+def _l(a):
+    return a.ctypes.data_as(lp)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Model:
+    """One model replica on one GPU (k2hip_model_t): the IOfflineProj operators."""
+
+    def __init__(self, weights_path: str, device: int = 0, overrides: Optional[str] = None):
+        self._L = load_library()
+        h = C.c_void_p()
+        rc = self._L.k2hip_model_create(weights_path.encode(), overrides.encode() if overrides else None, device, C.byref(h))
+        if rc != 0:
+            raise K2HipError(rc, self._L.k2hip_last_error().decode())
+        self._h = h
+        info = InfoStruct()
+        self._chk(self._L.k2hip_model_get_info(self._h, C.byref(info)))
+        self.vocab_size = info.vocab_size
+        self.context_size = info.context_size
+        self.joiner_dim = info.joiner_dim
+        self.feature_dim = info.feature_dim
+        self.sample_rate = info.sample_rate
+        self.device = info.device
+        self.blank_id, self.sos_eos_id, self.unk_id = 0, 1, 2  # OfflineModel.cs:18-20
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise K2HipError(rc, self._L.k2hip_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.k2hip_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def meta(self, key: str) -> str:
+        buf = C.create_string_buffer(4096)
+        self._chk(self._L.k2hip_model_meta(self._h, key.encode(), buf, 4096))
+        return buf.value.decode()
+
+    def set_instrument(self, on: bool):
+        self._chk(self._L.k2hip_set_instrument(self._h, int(on)))
+
+    def timing(self) -> dict:
+        t = TimingStruct()
+        self._chk(self._L.k2hip_get_timing(self._h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in TimingStruct._fields_}
+
+    # ---- F1
+    def fbank_num_frames(self, n: int) -> int:
+        return self._L.k2hip_fbank_num_frames(self._h, n)
+
+    def fbank(self, samples) -> np.ndarray:
+        s = _f32(samples).reshape(-1)
+        nf = max(self.fbank_num_frames(s.size), 0)
+        out = np.empty((nf, self.feature_dim), np.float32)
+        got = C.c_int64()
+        self._chk(self._L.k2hip_fbank(self._h, _f(s), s.size, _f(out), nf, C.byref(got)))
+        return out[: got.value]
+
+    # ---- F3
+    def pad_sequence(self, feats: Sequence[np.ndarray], tail_frames: int = 19) -> np.ndarray:
+        fs = [_f32(f).reshape(-1) for f in feats]
+        B = len(fs)
+        ptrs = (fp * B)(*[_f(f) for f in fs])
+        n = np.array([f.size for f in fs], np.int64)
+        L = int(n.max()) + 80 * tail_frames
+        out = np.empty((B, L), np.float32)
+        got = C.c_int64()
+        self._chk(self._L.k2hip_pad_sequence(self._h, ptrs, _l(n), B, tail_frames, _f(out), out.size, C.byref(got)))
+        assert got.value == L
+        return out
+
+    # ---- F4-F6: IOfflineProj
+    def encoder_out_frames(self, T: int) -> int:
+        return self._L.k2hip_encoder_out_frames(self._h, T)
+
+    def encoder_proj(self, x) -> np.ndarray:
+        x = _f32(x)
+        B, T, _ = x.shape
+        tp = max(self.encoder_out_frames(T), 0)
+        out = np.empty((B, tp, self.joiner_dim), np.float32)
+        lens = np.zeros(B, np.int64)
+        xl = np.full(B, T, np.int64)
+        got = C.c_int32()
+        self._chk(self._L.k2hip_offline_encoder(self._h, _f(x), _l(xl), B, T, _f(out), out.size, _l(lens), C.byref(got)))
+        return out
+
+    def encoder_tap(self, x, tap: int) -> np.ndarray:
+        x = _f32(x)
+        B, T, _ = x.shape
+        buf = np.empty(B * T * 1024, np.float32)
+        n = C.c_int64()
+        self._chk(self._L.k2hip_offline_encoder_tap(self._h, _f(x), B, T, tap, _f(buf), buf.size, C.byref(n)))
+        return buf[: n.value].reshape(B, -1).copy()
+
+    def decoder_proj(self, y=None, N: Optional[int] = None) -> np.ndarray:
+        if y is None:
+            out = np.empty((N, self.joiner_dim), np.float32)
+            self._chk(self._L.k2hip_decoder(self._h, None, N, _f(out)))
+            return out
+        y = np.ascontiguousarray(y, dtype=np.int64).reshape(-1, self.context_size)
+        out = np.empty((y.shape[0], self.joiner_dim), np.float32)
+        self._chk(self._L.k2hip_decoder(self._h, _l(y), y.shape[0], _f(out)))
+        return out
+
+    def joiner_proj(self, enc, dec) -> np.ndarray:
+        enc = _f32(enc).reshape(-1, self.joiner_dim)
+        dec = _f32(dec).reshape(-1, self.joiner_dim)
+        out = np.empty((enc.shape[0], self.vocab_size), np.float32)
+        self._chk(self._L.k2hip_joiner(self._h, _f(enc), _f(dec), enc.shape[0], _f(out)))
+        return out
+
+    # ---- F7
+    def _unpack(self, tok, ts, n):
+        return [(tok[b, : n[b]].tolist(), ts[b, : n[b]].tolist()) for b in range(tok.shape[0])]
+
+    def greedy_batch(self, enc_out):
+        e = _f32(enc_out)
+        B, Tp, _ = e.shape
+        tok = np.zeros((B, Tp), np.int64)
+        ts = np.zeros((B, Tp), np.int32)
+        n = np.zeros(B, np.int32)
+        self._chk(self._L.k2hip_greedy_batch(self._h, _f(e), B, Tp, _l(tok), _i(ts), _i(n), Tp))
+        return self._unpack(tok, ts, n)
+
+    def greedy_single(self, enc_out):
+        e = _f32(enc_out).reshape(-1, self.joiner_dim)
+        Tp = e.shape[0]
+        tok = np.zeros((1, Tp), np.int64)
+        ts = np.zeros((1, Tp), np.int32)
+        n = np.zeros(1, np.int32)
+        self._chk(self._L.k2hip_greedy_single(self._h, _f(e), Tp, _l(tok), _i(ts), _i(n), Tp))
+        return self._unpack(tok, ts, n)[0]
+
+    def offline_greedy(self, feats: Sequence[np.ndarray]):
+        fs = [_f32(f).reshape(-1) for f in feats]
+        B = len(fs)
+        ptrs = (fp * B)(*[_f(f) for f in fs])
+        nfl = np.array([f.size for f in fs], np.int64)
+        mt = max(1, self.encoder_out_frames(int(nfl.max()) // self.feature_dim + 19))
+        tok = np.zeros((B, mt), np.int64)
+        ts = np.zeros((B, mt), np.int32)
+        n = np.zeros(B, np.int32)
+        self._chk(self._L.k2hip_offline_greedy(self._h, ptrs, _l(nfl), B, _l(tok), _i(ts), _i(n), mt))
+        return self._unpack(tok, ts, n)
+
+    def offline_greedy_single(self, feats: np.ndarray):
+        f = _f32(feats).reshape(-1)
+        mt = max(1, self.encoder_out_frames(f.size // self.feature_dim + 19))
+        tok = np.zeros((1, mt), np.int64)
+        ts = np.zeros((1, mt), np.int32)
+        n = np.zeros(1, np.int32)
+        self._chk(self._L.k2hip_offline_greedy_single(self._h, _f(f), f.size, _l(tok), _i(ts), _i(n), mt))
+        return self._unpack(tok, ts, n)[0]
+
+    def offline_greedy_from_samples(self, samples: Sequence[np.ndarray]):
+        ss = [_f32(s).reshape(-1) for s in samples]
+        B = len(ss)
+        ptrs = (fp * B)(*[_f(s) for s in ss])
+        ns = np.array([s.size for s in ss], np.int64)
+        mt = max(1, self.encoder_out_frames(self.fbank_num_frames(int(ns.max())) + 19))
+        tok = np.zeros((B, mt), np.int64)
+        ts = np.zeros((B, mt), np.int32)
+        n = np.zeros(B, np.int32)
+        self._chk(self._L.k2hip_offline_greedy_from_samples(self._h, ptrs, _l(ns), B, _l(tok), _i(ts), _i(n), mt))
+        return self._unpack(tok, ts, n)
+
+    # ---- device-resident benchmark path
+    def device_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._chk(self._L.k2hip_device_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def device_free(self, ptr: int):
+        self._chk(self._L.k2hip_device_free(self._h, C.c_void_p(ptr)))
+
+    def device_upload(self, ptr: int, host: np.ndarray):
+        h = np.ascontiguousarray(host)
+        self._chk(self._L.k2hip_device_upload(self._h, C.c_void_p(ptr), h.ctypes.data_as(C.c_void_p), h.nbytes))
+
+    def synchronize(self):
+        self._chk(self._L.k2hip_synchronize(self._h))
+
+    def offline_greedy_from_samples_dev(self, dev_ptr: int, n_each: int, B: int, max_tokens: Optional[int] = None):
+        mt = max_tokens or max(1, self.encoder_out_frames(self.fbank_num_frames(n_each) + 19))
+        tok = np.zeros((B, mt), np.int64)
+        ts = np.zeros((B, mt), np.int32)
+        n = np.zeros(B, np.int32)
+        self._chk(self._L.k2hip_offline_greedy_from_samples_dev(self._h, C.c_void_p(dev_ptr), n_each, B, _l(tok), _i(ts), _i(n), mt))
+        return self._unpack(tok, ts, n)
+
+
+class OfflineStream:
+    """OfflineStream.cs:7-99."""
+
+    def __init__(self, model: Model):
+        self._m = model
+        self._L = model._L
+        h = C.c_void_p()
+        model._chk(self._L.k2hip_offline_stream_create(model.handle, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.k2hip_offline_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_samples(self, samples):  # AddSamples, OfflineStream.cs:43-57
+        s = _f32(samples).reshape(-1)
+        self._m._chk(self._L.k2hip_offline_stream_accept_samples(self._h, _f(s), s.size))
+
+    @property
+    def speech_length(self) -> int:  # OfflineInputEntity.SpeechLength
+        return self._L.k2hip_offline_stream_speech_length(self._h)
+
+    @property
+    def speech(self) -> np.ndarray:  # OfflineInputEntity.Speech
+        n = self.speech_length
+        out = np.empty(n, np.float32)
+        self._m._chk(self._L.k2hip_offline_stream_get_speech(self._h, _f(out), n))
+        return out
+
+    @property
+    def tokens(self) -> List[int]:
+        n = self._L.k2hip_offline_stream_num_tokens(self._h)
+        out = np.zeros(max(n, 1), np.int64)
+        self._m._chk(self._L.k2hip_offline_stream_get_tokens(self._h, _l(out), n))
+        return out[:n].tolist()
+
+    @property
+    def timestamps(self) -> List[int]:
+        n = self._L.k2hip_offline_stream_num_timestamps(self._h)
+        out = np.zeros(max(n, 1), np.int32)
+        self._m._chk(self._L.k2hip_offline_stream_get_timestamps(self._h, _i(out), n))
+        return out[:n].tolist()
+
+
+class OfflineRecognizer:
+    """OfflineRecognizer.cs:12-91 with decodingMethod = "greedy_search" on the HIP backend."""
+
+    def __init__(self, weights_path: str, device: int = 0):
+        self.model = Model(weights_path, device)
+
+    def create_offline_stream(self) -> OfflineStream:  # CreateOfflineStream :71-75
+        return OfflineStream(self.model)
+
+    def get_results(self, streams: Sequence[OfflineStream]):  # GetResults :85-91 (tokens, not text)
+        B = len(streams)
+        arr = (C.c_void_p * B)(*[s._h for s in streams])
+        self.model._chk(self.model._L.k2hip_offline_recognizer_get_results(self.model.handle, arr, B))
+        return [(s.tokens, s.timestamps) for s in streams]
+
+    def get_result(self, stream: OfflineStream):  # GetResult :77-83
+        self.model._chk(self.model._L.k2hip_offline_recognizer_get_result(self.model.handle, stream._h))
+        return stream.tokens, stream.timestamps

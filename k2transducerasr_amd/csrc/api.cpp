@@ -1,0 +1,409 @@
+// C ABI of libk2hip.so (include/k2hip.h) + the host-side mirror of the reference's
+// OfflineStream / OfflineRecognizer bookkeeping (K2TransducerAsr/OfflineStream.cs,
+// OfflineRecognizer.cs:77-91,289-296).
+#include <algorithm>
+#include <new>
+
+#include "engine.h"
+
+using namespace k2hip;
+
+struct k2hip_model {
+    Engine engine;
+    k2hip_model(const char* path, const char* ov, int dev) : engine(path, ov, dev) {}
+};
+
+// OfflineStream.cs:7-99
+struct k2hip_offline_stream {
+    k2hip_model* model;
+    std::vector<float> speech;     // OfflineInputEntity.Speech (frame-major features)
+    std::vector<float> remainder;  // samples not yet covered by a full frame shift (streaming fbank state)
+    std::vector<int64_t> tokens;   // Tokens, initialised to [blank, blank] (:34)
+    std::vector<int32_t> timestamps;
+};
+
+namespace {
+
+thread_local std::string g_last_error;
+
+template <typename F>
+int32_t guard(F&& f) {
+    try {
+        f();
+        return K2HIP_OK;
+    } catch (const Error& e) {
+        g_last_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        g_last_error = "out of host memory";
+        return K2HIP_ERR_INVALID;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return K2HIP_ERR_INVALID;
+    } catch (...) {
+        g_last_error = "unknown error";
+        return K2HIP_ERR_INVALID;
+    }
+}
+
+#define NEED(p)                                                        \
+    do {                                                               \
+        if (!(p)) failf(K2HIP_ERR_INVALID, "%s: null argument '%s'", __func__, #p); \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char* k2hip_version(void) { return "k2hip 0.1.0 (gfx950)"; }
+const char* k2hip_last_error(void) { return g_last_error.c_str(); }
+
+int32_t k2hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t k2hip_model_create(const char* weights_path, const char* overrides, int32_t device, k2hip_model_t** out) {
+    return guard([&] {
+        NEED(weights_path);
+        NEED(out);
+        *out = nullptr;
+        *out = new k2hip_model(weights_path, overrides, device);
+    });
+}
+int32_t k2hip_model_destroy(k2hip_model_t* model) {
+    return guard([&] { delete model; });
+}
+int32_t k2hip_model_get_info(const k2hip_model_t* model, k2hip_model_info* info) {
+    return guard([&] {
+        NEED(model);
+        NEED(info);
+        const Config& c = model->engine.model().cfg();
+        info->vocab_size = c.V;
+        info->context_size = c.ctx;
+        info->joiner_dim = c.J;
+        info->feature_dim = c.feat;
+        info->sample_rate = c.fbank.sample_rate;
+        info->num_stacks = c.ns;
+        info->device = model->engine.model().device();
+        info->reserved = 0;
+    });
+}
+int32_t k2hip_model_meta(const k2hip_model_t* model, const char* key, char* buf, int32_t cap) {
+    return guard([&] {
+        NEED(model);
+        NEED(key);
+        NEED(buf);
+        auto& mm = model->engine.model().meta();
+        auto it = mm.find(key);
+        if (it == mm.end()) failf(K2HIP_ERR_INVALID, "metadata key '%s' not present", key);
+        if ((int)it->second.size() + 1 > cap) failf(K2HIP_ERR_CAPACITY, "metadata value needs %zu bytes", it->second.size() + 1);
+        memcpy(buf, it->second.c_str(), it->second.size() + 1);
+    });
+}
+int32_t k2hip_set_instrument(k2hip_model_t* model, int32_t on) {
+    return guard([&] {
+        NEED(model);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        model->engine.set_instrument(on != 0);
+    });
+}
+int32_t k2hip_get_timing(const k2hip_model_t* model, k2hip_timing* timing) {
+    return guard([&] {
+        NEED(model);
+        NEED(timing);
+        *timing = model->engine.timing();
+    });
+}
+
+int64_t k2hip_fbank_num_frames(const k2hip_model_t* model, int64_t n_samples) {
+    if (!model) return -1;
+    return model->engine.fbank_num_frames(n_samples);
+}
+int32_t k2hip_fbank(k2hip_model_t* model, const float* samples, int64_t n_samples, float* feats, int64_t cap_frames,
+                    int64_t* n_frames) {
+    return guard([&] {
+        NEED(model);
+        NEED(n_frames);
+        if (n_samples > 0) NEED(samples);
+        if (cap_frames > 0) NEED(feats);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        model->engine.fbank_host(samples, n_samples, feats, cap_frames, n_frames);
+    });
+}
+int32_t k2hip_pad_sequence(k2hip_model_t* model, const float* const* speech, const int64_t* n_floats, int32_t B,
+                           int32_t tail_frames, float* out, int64_t cap_floats, int64_t* padded_len) {
+    return guard([&] {
+        NEED(model);
+        NEED(speech);
+        NEED(n_floats);
+        NEED(out);
+        NEED(padded_len);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        model->engine.pad_host(speech, n_floats, B, tail_frames, out, cap_floats, padded_len);
+    });
+}
+int32_t k2hip_encoder_out_frames(const k2hip_model_t* model, int32_t T) {
+    if (!model) return -1;
+    return model->engine.encoder_out_frames(T);
+}
+int32_t k2hip_offline_encoder(k2hip_model_t* model, const float* x, const int64_t* x_lens, int32_t B, int32_t T,
+                              float* enc_out, int64_t cap_floats, int64_t* enc_out_lens, int32_t* Tprime) {
+    return guard([&] {
+        NEED(model);
+        NEED(x);
+        NEED(enc_out);
+        NEED(Tprime);
+        (void)x_lens;  // always T in the reference (OfflineProjOfTransducer.cs:66-70); no masking on this path
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        int tp = 0;
+        model->engine.encoder_host(x, B, T, enc_out, cap_floats, &tp);
+        *Tprime = tp;
+        if (enc_out_lens)
+            for (int b = 0; b < B; b++) enc_out_lens[b] = tp;
+    });
+}
+int32_t k2hip_offline_encoder_tap(k2hip_model_t* model, const float* x, int32_t B, int32_t T, int32_t tap, float* out,
+                                  int64_t cap_floats, int64_t* n_floats) {
+    return guard([&] {
+        NEED(model);
+        NEED(x);
+        NEED(out);
+        NEED(n_floats);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        model->engine.encoder_tap_host(x, B, T, tap, out, cap_floats, n_floats);
+    });
+}
+int32_t k2hip_decoder(k2hip_model_t* model, const int64_t* y, int32_t N, float* dec_out) {
+    return guard([&] {
+        NEED(model);
+        NEED(dec_out);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        model->engine.decoder_host(y, N, dec_out);
+    });
+}
+int32_t k2hip_joiner(k2hip_model_t* model, const float* enc, const float* dec, int32_t N, float* logits) {
+    return guard([&] {
+        NEED(model);
+        NEED(enc);
+        NEED(dec);
+        NEED(logits);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        model->engine.joiner_host(enc, dec, N, logits);
+    });
+}
+int32_t k2hip_greedy_batch(k2hip_model_t* model, const float* enc_out, int32_t B, int32_t Tprime, int64_t* tokens,
+                           int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens) {
+    return guard([&] {
+        NEED(model); NEED(enc_out); NEED(tokens); NEED(timestamps); NEED(n_tokens);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        model->engine.greedy_host(enc_out, B, Tprime, false, tokens, timestamps, n_tokens, max_tokens);
+    });
+}
+int32_t k2hip_greedy_single(k2hip_model_t* model, const float* enc_out, int32_t Tprime, int64_t* tokens,
+                            int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens) {
+    return guard([&] {
+        NEED(model); NEED(enc_out); NEED(tokens); NEED(timestamps); NEED(n_tokens);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        model->engine.greedy_host(enc_out, 1, Tprime, true, tokens, timestamps, n_tokens, max_tokens);
+    });
+}
+int32_t k2hip_offline_greedy(k2hip_model_t* model, const float* const* feats, const int64_t* n_floats, int32_t B,
+                             int64_t* tokens, int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens) {
+    return guard([&] {
+        NEED(model); NEED(feats); NEED(n_floats); NEED(tokens); NEED(timestamps); NEED(n_tokens);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        model->engine.offline_greedy_feats(feats, n_floats, B, false, tokens, timestamps, n_tokens, max_tokens);
+    });
+}
+int32_t k2hip_offline_greedy_single(k2hip_model_t* model, const float* feats, int64_t n_floats, int64_t* tokens,
+                                    int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens) {
+    return guard([&] {
+        NEED(model); NEED(feats); NEED(tokens); NEED(timestamps); NEED(n_tokens);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        const float* p[1] = {feats};
+        int64_t n[1] = {n_floats};
+        model->engine.offline_greedy_feats(p, n, 1, true, tokens, timestamps, n_tokens, max_tokens);
+    });
+}
+int32_t k2hip_offline_greedy_from_samples(k2hip_model_t* model, const float* const* samples, const int64_t* n_samples,
+                                          int32_t B, int64_t* tokens, int32_t* timestamps, int32_t* n_tokens,
+                                          int32_t max_tokens) {
+    return guard([&] {
+        NEED(model); NEED(samples); NEED(n_samples); NEED(tokens); NEED(timestamps); NEED(n_tokens);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        model->engine.offline_greedy_samples(samples, n_samples, B, tokens, timestamps, n_tokens, max_tokens);
+    });
+}
+int32_t k2hip_offline_greedy_from_samples_dev(k2hip_model_t* model, const float* samples_dev, int64_t n_samples_each,
+                                              int32_t B, int64_t* tokens, int32_t* timestamps, int32_t* n_tokens,
+                                              int32_t max_tokens) {
+    return guard([&] {
+        NEED(model); NEED(samples_dev); NEED(tokens); NEED(timestamps); NEED(n_tokens);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        model->engine.offline_greedy_samples_dev(samples_dev, n_samples_each, B, tokens, timestamps, n_tokens, max_tokens);
+    });
+}
+
+int32_t k2hip_device_alloc(k2hip_model_t* model, int64_t bytes, void** dev_ptr) {
+    return guard([&] {
+        NEED(model); NEED(dev_ptr);
+        *dev_ptr = model->engine.dev_alloc(bytes);
+    });
+}
+int32_t k2hip_device_free(k2hip_model_t* model, void* dev_ptr) {
+    return guard([&] {
+        NEED(model);
+        if (dev_ptr) model->engine.dev_free(dev_ptr);
+    });
+}
+int32_t k2hip_device_upload(k2hip_model_t* model, void* dev_dst, const void* host_src, int64_t bytes) {
+    return guard([&] {
+        NEED(model); NEED(dev_dst); NEED(host_src);
+        model->engine.dev_upload(dev_dst, host_src, bytes);
+    });
+}
+int32_t k2hip_synchronize(k2hip_model_t* model) {
+    return guard([&] {
+        NEED(model);
+        model->engine.synchronize();
+    });
+}
+
+// ---- OfflineStream ---------------------------------------------------------------
+int32_t k2hip_offline_stream_create(k2hip_model_t* model, k2hip_offline_stream_t** out) {
+    return guard([&] {
+        NEED(model); NEED(out);
+        auto* s = new k2hip_offline_stream();
+        s->model = model;
+        s->tokens = {K2HIP_BLANK_ID, K2HIP_BLANK_ID};  // OfflineStream.cs:34
+        *out = s;
+    });
+}
+int32_t k2hip_offline_stream_destroy(k2hip_offline_stream_t* s) {
+    return guard([&] { delete s; });
+}
+// OfflineStream.AddSamples (:43-57)
+int32_t k2hip_offline_stream_accept_samples(k2hip_offline_stream_t* s, const float* samples, int64_t n) {
+    return guard([&] {
+        NEED(s);
+        if (n > 0) NEED(samples);
+        Engine& e = s->model->engine;
+        const Config& c = e.model().cfg();
+        std::vector<float> wav(s->remainder);
+        wav.insert(wav.end(), samples, samples + n);
+        int64_t nf = e.fbank_num_frames((int64_t)wav.size());
+        if (nf > 0) {
+            size_t old = s->speech.size();
+            s->speech.resize(old + (size_t)nf * c.feat);
+            int64_t got = 0;
+            std::lock_guard<std::mutex> lk(e.mutex());
+            e.fbank_host(wav.data(), (int64_t)wav.size(), s->speech.data() + old, nf, &got);
+            // streaming framing: the next frame starts nf*shift samples in
+            size_t consumed = (size_t)nf * c.fbank.frame_shift;
+            s->remainder.assign(wav.begin() + consumed, wav.end());
+        } else {
+            s->remainder.swap(wav);
+        }
+    });
+}
+int64_t k2hip_offline_stream_speech_length(const k2hip_offline_stream_t* s) { return s ? (int64_t)s->speech.size() : -1; }
+int32_t k2hip_offline_stream_get_speech(const k2hip_offline_stream_t* s, float* out, int64_t cap) {
+    return guard([&] {
+        NEED(s);
+        if ((int64_t)s->speech.size() > cap) failf(K2HIP_ERR_CAPACITY, "speech has %zu floats", s->speech.size());
+        if (!s->speech.empty()) {
+            NEED(out);
+            memcpy(out, s->speech.data(), sizeof(float) * s->speech.size());
+        }
+    });
+}
+
+// OfflineRecognizer.GetResults -> ForwardBatchGreedySearch (:85-91, :189-303)
+int32_t k2hip_offline_recognizer_get_results(k2hip_model_t* model, k2hip_offline_stream_t* const* streams, int32_t B) {
+    return guard([&] {
+        NEED(model); NEED(streams);
+        K2_REQUIRE(B > 0, "GetResults: empty stream list");
+        Engine& e = model->engine;
+        const Config& c = e.model().cfg();
+        std::vector<const float*> ptrs(B);
+        std::vector<int64_t> nfl(B);
+        int64_t mx = 0;
+        for (int b = 0; b < B; b++) {
+            NEED(streams[b]);
+            K2_REQUIRE(streams[b]->model == model, "stream %d belongs to another model", b);
+            ptrs[b] = streams[b]->speech.data();
+            nfl[b] = (int64_t)streams[b]->speech.size();
+            mx = std::max(mx, nfl[b]);
+        }
+        int T = (int)((mx + 80 * 19) / c.feat);
+        int max_tokens = std::max(1, e.encoder_out_frames(T));
+        std::vector<int64_t> tok((size_t)B * max_tokens);
+        std::vector<int32_t> ts((size_t)B * max_tokens), n(B);
+        {
+            std::lock_guard<std::mutex> lk(e.mutex());
+            e.offline_greedy_feats(ptrs.data(), nfl.data(), B, false, tok.data(), ts.data(), n.data(), max_tokens);
+        }
+        for (int b = 0; b < B; b++) {
+            k2hip_offline_stream* s = streams[b];
+            // tokens[m] / timestamps[m] are seeded with 2*B blanks / zeros (:250-267)
+            s->tokens.assign((size_t)2 * B, K2HIP_BLANK_ID);
+            s->tokens.insert(s->tokens.end(), tok.begin() + (size_t)b * max_tokens, tok.begin() + (size_t)b * max_tokens + n[b]);
+            s->timestamps.insert(s->timestamps.end(), (size_t)2 * B, 0);  // Timestamps.AddRange (:293)
+            s->timestamps.insert(s->timestamps.end(), ts.begin() + (size_t)b * max_tokens, ts.begin() + (size_t)b * max_tokens + n[b]);
+            // RemoveSamples (:294, OfflineStream.cs:58-68)
+            if ((int)s->tokens.size() > c.ctx) {
+                s->speech.clear();
+                s->speech.shrink_to_fit();
+            }
+        }
+    });
+}
+// OfflineRecognizer.GetResult -> ForwardGreedySearch (:77-83, :93-187)
+int32_t k2hip_offline_recognizer_get_result(k2hip_model_t* model, k2hip_offline_stream_t* s) {
+    return guard([&] {
+        NEED(model); NEED(s);
+        K2_REQUIRE(s->model == model, "stream belongs to another model");
+        Engine& e = model->engine;
+        const Config& c = e.model().cfg();
+        int T = (int)(((int64_t)s->speech.size() + 80 * 19) / c.feat);
+        int max_tokens = std::max(1, e.encoder_out_frames(T));
+        std::vector<int64_t> tok(max_tokens);
+        std::vector<int32_t> ts(max_tokens);
+        int32_t n = 0;
+        const float* p[1] = {s->speech.data()};
+        int64_t nfl[1] = {(int64_t)s->speech.size()};
+        {
+            std::lock_guard<std::mutex> lk(e.mutex());
+            e.offline_greedy_feats(p, nfl, 1, true, tok.data(), ts.data(), &n, max_tokens);
+        }
+        s->tokens = {-1, K2HIP_BLANK_ID};  // hypList (:115-117, :180)
+        s->tokens.insert(s->tokens.end(), tok.begin(), tok.begin() + n);
+        s->timestamps.insert(s->timestamps.end(), ts.begin(), ts.begin() + n);  // (:181)
+    });
+}
+int32_t k2hip_offline_stream_num_tokens(const k2hip_offline_stream_t* s) { return s ? (int32_t)s->tokens.size() : -1; }
+int32_t k2hip_offline_stream_num_timestamps(const k2hip_offline_stream_t* s) { return s ? (int32_t)s->timestamps.size() : -1; }
+int32_t k2hip_offline_stream_get_tokens(const k2hip_offline_stream_t* s, int64_t* tokens, int32_t cap) {
+    return guard([&] {
+        NEED(s);
+        if ((int)s->tokens.size() > cap) failf(K2HIP_ERR_CAPACITY, "stream holds %zu tokens", s->tokens.size());
+        if (!s->tokens.empty()) {
+            NEED(tokens);
+            memcpy(tokens, s->tokens.data(), sizeof(int64_t) * s->tokens.size());
+        }
+    });
+}
+int32_t k2hip_offline_stream_get_timestamps(const k2hip_offline_stream_t* s, int32_t* timestamps, int32_t cap) {
+    return guard([&] {
+        NEED(s);
+        if ((int)s->timestamps.size() > cap) failf(K2HIP_ERR_CAPACITY, "stream holds %zu timestamps", s->timestamps.size());
+        if (!s->timestamps.empty()) {
+            NEED(timestamps);
+            memcpy(timestamps, s->timestamps.data(), sizeof(int32_t) * s->timestamps.size());
+        }
+    });
+}
+
+}  // extern "C"

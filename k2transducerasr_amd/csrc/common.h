@@ -1,0 +1,98 @@
+// Shared host-side plumbing for libk2hip: error transport across the C ABI,
+// HIP call checking, a grow-only device arena.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/k2hip.h"
+
+namespace k2hip {
+
+// Internal exception; converted to (status, last_error) at the ABI boundary.
+struct Error : std::runtime_error {
+    int32_t code;
+    Error(int32_t c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] inline void failf(int32_t code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Error(code, buf);
+}
+
+#define K2_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            ::k2hip::failf(K2HIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                           __LINE__);                                                                  \
+    } while (0)
+
+#define K2_REQUIRE(cond, ...)                                        \
+    do {                                                             \
+        if (!(cond)) ::k2hip::failf(K2HIP_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Grow-only bump arena in device memory.  One per model; reset at the start of
+// every fused call, so steady-state calls allocate nothing (Guideline 9: no
+// hipMalloc inside the hot path once warm).
+class Arena {
+  public:
+    ~Arena() { release(); }
+    void release() {
+        if (base_) (void)hipFree(base_);
+        base_ = nullptr;
+        cap_ = 0;
+        off_ = 0;
+    }
+    void reset() { off_ = 0; high_ = 0; }
+    // dry mode: take() only counts (returns offsets from a null base); used to size the arena
+    void set_dry(bool d) { dry_ = d; }
+    // Ensure capacity BEFORE taking pointers (growing invalidates them).
+    void reserve(int64_t bytes) {
+        if (bytes <= cap_) return;
+        if (off_ != 0) failf(K2HIP_ERR_INVALID, "arena grown while in use");
+        release();
+        K2_HIP(hipMalloc(&base_, (size_t)bytes));
+        cap_ = bytes;
+    }
+    template <typename T>
+    T* take(int64_t n) {
+        int64_t bytes = align_up((int64_t)sizeof(T) * (n > 0 ? n : 1), 256);
+        if (dry_) {
+            off_ += bytes;
+            if (off_ > high_) high_ = off_;
+            return nullptr;
+        }
+        if (off_ + bytes > cap_) failf(K2HIP_ERR_CAPACITY, "device arena exhausted: need %lld more bytes (cap %lld)",
+                                       (long long)(off_ + bytes - cap_), (long long)cap_);
+        T* p = reinterpret_cast<T*>(static_cast<char*>(base_) + off_);
+        off_ += bytes;
+        if (off_ > high_) high_ = off_;
+        return p;
+    }
+    int64_t mark() const { return off_; }
+    void rewind(int64_t m) { off_ = m; }
+    int64_t capacity() const { return cap_; }
+    int64_t high_water() const { return high_; }
+
+  private:
+    void* base_ = nullptr;
+    int64_t cap_ = 0, off_ = 0, high_ = 0;
+    bool dry_ = false;
+};
+
+}  // namespace k2hip

@@ -1,0 +1,360 @@
+// HBM-bound kernels of the Zipformer2 path: padding quirk, Conv2dSubsampling's
+// first conv and depthwise 7x7, BiasNorm / bypass, GLU / tanh gates, depthwise
+// Conv1d, learned down/up-sampling.  All activations are [rows, channels] with
+// channels contiguous, so every kernel moves float4 per lane along channels.
+#include "kernels.h"
+
+namespace k2hip {
+namespace {
+
+constexpr float kLogFloor = -23.025850929940457F;  // PadHelper.cs:58
+
+__device__ __forceinline__ float logaddexp0(float z) { return fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))); }
+__device__ __forceinline__ float swoosh_r(float v) { return logaddexp0(v - 1.0f) - 0.08f * v - 0.313261687f; }
+
+inline int nblocks(long long n, int per) { return (int)((n + per - 1) / per); }
+
+// ---- F3: PadHelper.PadSequence (PadHelper.cs:20-60) on device ------------------
+//  out[b, j] = j < len[b] ? src[b][j] : 0 ; then x == 0 -> log floor (Q1, Q2)
+__global__ void k_pad_logfloor(const float* __restrict__ packed, const long long* __restrict__ off,
+                               const long long* __restrict__ len, float* __restrict__ out, long long L) {
+    int b = blockIdx.y;
+    const float* src = packed + off[b];
+    long long n = len[b];
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < L; j += (long long)gridDim.x * blockDim.x) {
+        float v = j < n ? src[j] : 0.0f;
+        out[(long long)b * L + j] = (v == 0.0f) ? kLogFloor : v;
+    }
+}
+__global__ void k_pad_logfloor_dense(const float* __restrict__ feats, long long n, float* __restrict__ out, long long L) {
+    int b = blockIdx.y;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < L; j += (long long)gridDim.x * blockDim.x) {
+        float v = j < n ? feats[(long long)b * n + j] : 0.0f;
+        out[(long long)b * L + j] = (v == 0.0f) ? kLogFloor : v;
+    }
+}
+
+// ---- Conv2dSubsampling conv.0: 1->8 ch, 3x3, pad (0,1), + SwooshR; out NHWC [B,T-2,F,8]
+__global__ void k_conv0(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                        float* __restrict__ y, int B, int T, int F) {
+    __shared__ float sw[72], sb[8];
+    if (threadIdx.x < 72) sw[threadIdx.x] = w[threadIdx.x];
+    if (threadIdx.x < 8) sb[threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+    int T1 = T - 2;
+    long long n = (long long)B * T1 * F;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int f = (int)(i % F);
+    long long bt = i / F;
+    int t = (int)(bt % T1), b = (int)(bt / T1);
+    float xin[3][3];
+#pragma unroll
+    for (int kt = 0; kt < 3; kt++)
+#pragma unroll
+        for (int kf = 0; kf < 3; kf++) {
+            int ff = f + kf - 1;
+            xin[kt][kf] = (ff >= 0 && ff < F) ? x[((long long)b * T + t + kt) * F + ff] : 0.f;
+        }
+    float o[8];
+#pragma unroll
+    for (int co = 0; co < 8; co++) {
+        float s = sb[co];
+#pragma unroll
+        for (int kt = 0; kt < 3; kt++)
+#pragma unroll
+            for (int kf = 0; kf < 3; kf++) s += sw[(co * 3 + kt) * 3 + kf] * xin[kt][kf];
+        o[co] = swoosh_r(s);
+    }
+    float4* yo = reinterpret_cast<float4*>(y + i * 8);
+    yo[0] = make_float4(o[0], o[1], o[2], o[3]);
+    yo[1] = make_float4(o[4], o[5], o[6], o[7]);
+}
+
+// ---- ConvNeXt depthwise 7x7, pad 3, NHWC, weights [49][C]
+__global__ void k_dwconv7x7(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                            float* __restrict__ y, int B, int T, int F, int C) {
+    int C4 = C / 4;
+    long long n = (long long)B * T * F * C4;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = (int)(i % C4) * 4;
+    long long p = i / C4;
+    int f = (int)(p % F);
+    long long bt = p / F;
+    int t = (int)(bt % T), b = (int)(bt / T);
+    float4 s = *reinterpret_cast<const float4*>(bias + c);
+    for (int kt = 0; kt < 7; kt++) {
+        int tt = t + kt - 3;
+        if (tt < 0 || tt >= T) continue;
+        for (int kf = 0; kf < 7; kf++) {
+            int ff = f + kf - 3;
+            if (ff < 0 || ff >= F) continue;
+            float4 xv = *reinterpret_cast<const float4*>(x + (((long long)b * T + tt) * F + ff) * C + c);
+            float4 wv = *reinterpret_cast<const float4*>(w + (kt * 7 + kf) * C + c);
+            s.x += wv.x * xv.x; s.y += wv.y * xv.y; s.z += wv.z * xv.z; s.w += wv.w * xv.w;
+        }
+    }
+    *reinterpret_cast<float4*>(y + p * C + c) = s;
+}
+
+// ---- BiasNorm (+ optional bypass): one wave per row, row kept in registers
+//   scale = (mean((x-b)^2))^-0.5 * exp(log_scale);  y = x*scale
+//   with orig: y = orig + (x*scale - orig) * bscale
+template <bool BYPASS>
+__global__ void k_biasnorm(const float* __restrict__ x, const float* __restrict__ orig, const float* __restrict__ nbias,
+                           const float* __restrict__ log_scale, const float* __restrict__ bscale, float* __restrict__ y,
+                           int M, int D) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    int lane = threadIdx.x & 63;
+    const float* xr = x + (long long)row * D;
+    float4 v[4];  // D <= 1024
+    int nq = D >> 2;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int q = lane + 64 * j;
+        if (q < nq) {
+            v[j] = *reinterpret_cast<const float4*>(xr + 4 * q);
+            float4 b = *reinterpret_cast<const float4*>(nbias + 4 * q);
+            float a0 = v[j].x - b.x, a1 = v[j].y - b.y, a2 = v[j].z - b.z, a3 = v[j].w - b.w;
+            s += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    float sc = (1.0f / sqrtf(s / (float)D)) * expf(log_scale[0]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int q = lane + 64 * j;
+        if (q < nq) {
+            float4 o = make_float4(v[j].x * sc, v[j].y * sc, v[j].z * sc, v[j].w * sc);
+            if (BYPASS) {
+                float4 g = *reinterpret_cast<const float4*>(orig + (long long)row * D + 4 * q);
+                float4 bs = *reinterpret_cast<const float4*>(bscale + 4 * q);
+                o.x = g.x + (o.x - g.x) * bs.x; o.y = g.y + (o.y - g.y) * bs.y;
+                o.z = g.z + (o.z - g.z) * bs.z; o.w = g.w + (o.w - g.w) * bs.w;
+            }
+            *reinterpret_cast<float4*>(y + (long long)row * D + 4 * q) = o;
+        }
+    }
+}
+
+// BypassModule: y = orig + (x - orig) * scale[d]
+__global__ void k_bypass(const float* __restrict__ orig, const float* __restrict__ x, const float* __restrict__ scale,
+                         float* __restrict__ y, long long n4, int D4) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 g = reinterpret_cast<const float4*>(orig)[i], v = reinterpret_cast<const float4*>(x)[i];
+    float4 s = reinterpret_cast<const float4*>(scale)[i % D4];
+    reinterpret_cast<float4*>(y)[i] = make_float4(g.x + (v.x - g.x) * s.x, g.y + (v.y - g.y) * s.y,
+                                                  g.z + (v.z - g.z) * s.z, g.w + (v.w - g.w) * s.w);
+}
+
+__device__ __forceinline__ float sigm(float s) { return 1.0f / (1.0f + expf(-s)); }
+
+// y[m, d] = x[m, d] * sigmoid(x[m, D + d])       x: [M, 2D]
+__global__ void k_glu(const float* __restrict__ x, float* __restrict__ y, long long n4, int D4) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    long long m = i / D4;
+    int q = (int)(i % D4);
+    const float4* xr = reinterpret_cast<const float4*>(x) + m * 2 * D4;
+    float4 a = xr[q], s = xr[D4 + q];
+    reinterpret_cast<float4*>(y)[i] = make_float4(a.x * sigm(s.x), a.y * sigm(s.y), a.z * sigm(s.z), a.w * sigm(s.w));
+}
+// y[m, c] = x[m, Hc + c] * tanh(x[m, c])         x: [M, 3Hc]
+__global__ void k_tanh_gate(const float* __restrict__ x, float* __restrict__ y, long long n4, int H4) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    long long m = i / H4;
+    int q = (int)(i % H4);
+    const float4* xr = reinterpret_cast<const float4*>(x) + m * 3 * H4;
+    float4 s = xr[q], a = xr[H4 + q];
+    reinterpret_cast<float4*>(y)[i] = make_float4(a.x * tanhf(s.x), a.y * tanhf(s.y), a.z * tanhf(s.z), a.w * tanhf(s.w));
+}
+// a[m, n] *= x[m*ldx + col0 + n]
+__global__ void k_mul_cols(float* __restrict__ a, const float* __restrict__ x, int ldx, int col0, long long n4, int N4) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    long long m = i / N4;
+    int q = (int)(i % N4);
+    float4 v = reinterpret_cast<float4*>(a)[i];
+    float4 s = *reinterpret_cast<const float4*>(x + m * ldx + col0 + 4 * q);
+    reinterpret_cast<float4*>(a)[i] = make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
+}
+
+// ---- ConvolutionModule depthwise Conv1d over time (zero pad K/2) + bias + SwooshR
+//  x,y: [B,T,D]; w: [K][D].  One thread = 4 channels x TT consecutive frames with a
+//  sliding register window, so every input row is read once per TT outputs.
+template <int TT>
+__global__ void k_dwconv1d(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                           float* __restrict__ y, int B, int T, int D, int K) {
+    int D4 = D >> 2;
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= D4) return;
+    int t0 = blockIdx.y * TT, b = blockIdx.z;
+    int c = q * 4;
+    float4 acc[TT];
+    float4 bv = *reinterpret_cast<const float4*>(bias + c);
+#pragma unroll
+    for (int i = 0; i < TT; i++) acc[i] = bv;
+    int half = K >> 1;
+    // input frames t0-half .. t0+TT-1+half ; frame u contributes to output t with tap k = u - t + half
+    for (int u = t0 - half; u < t0 + TT + half; u++) {
+        if (u < 0 || u >= T) continue;
+        float4 xv = *reinterpret_cast<const float4*>(x + ((long long)b * T + u) * D + c);
+#pragma unroll
+        for (int i = 0; i < TT; i++) {
+            int k = u - (t0 + i) + half;
+            if (k >= 0 && k < K) {
+                float4 wv = *reinterpret_cast<const float4*>(w + k * D + c);
+                acc[i].x += wv.x * xv.x; acc[i].y += wv.y * xv.y; acc[i].z += wv.z * xv.z; acc[i].w += wv.w * xv.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TT; i++) {
+        int t = t0 + i;
+        if (t < T)
+            *reinterpret_cast<float4*>(y + ((long long)b * T + t) * D + c) =
+                make_float4(swoosh_r(acc[i].x), swoosh_r(acc[i].y), swoosh_r(acc[i].z), swoosh_r(acc[i].w));
+    }
+}
+
+// ---- SimpleDownsample: softmax(bias)-weighted sum of ds frames, last frame repeated
+__global__ void k_downsample(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ y, int B,
+                             int T, int Td, int D4, int ds) {
+    long long n = (long long)B * Td * D4;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float wgt[16], mx = -INFINITY, sum = 0.f;
+    for (int k = 0; k < ds; k++) mx = fmaxf(mx, bias[k]);
+    for (int k = 0; k < ds; k++) { wgt[k] = expf(bias[k] - mx); sum += wgt[k]; }
+    for (int k = 0; k < ds; k++) wgt[k] /= sum;
+    int q = (int)(i % D4);
+    long long bt = i / D4;
+    int t = (int)(bt % Td), b = (int)(bt / Td);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < ds; k++) {
+        int tt = min(t * ds + k, T - 1);
+        float4 v = reinterpret_cast<const float4*>(x)[((long long)b * T + tt) * D4 + q];
+        s.x += v.x * wgt[k]; s.y += v.y * wgt[k]; s.z += v.z * wgt[k]; s.w += v.w * wgt[k];
+    }
+    reinterpret_cast<float4*>(y)[i] = s;
+}
+// SimpleUpsample (repeat) + truncate + out_combiner bypass
+__global__ void k_upsample_combine(const float* __restrict__ orig, const float* __restrict__ xd,
+                                   const float* __restrict__ scale, float* __restrict__ y, int B, int T, int Td, int D4,
+                                   int ds) {
+    long long n = (long long)B * T * D4;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int q = (int)(i % D4);
+    long long bt = i / D4;
+    int t = (int)(bt % T), b = (int)(bt / T);
+    float4 o = reinterpret_cast<const float4*>(orig)[i];
+    float4 u = reinterpret_cast<const float4*>(xd)[((long long)b * Td + t / ds) * D4 + q];
+    float4 s = reinterpret_cast<const float4*>(scale)[q];
+    reinterpret_cast<float4*>(y)[i] = make_float4(o.x + (u.x - o.x) * s.x, o.y + (u.y - o.y) * s.y,
+                                                  o.z + (u.z - o.z) * s.z, o.w + (u.w - o.w) * s.w);
+}
+// convert_num_channels: truncate / zero-pad
+__global__ void k_convert_channels(const float* __restrict__ x, float* __restrict__ y, long long M, int Din4, int Dout4) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * Dout4) return;
+    long long m = i / Dout4;
+    int q = (int)(i % Dout4);
+    reinterpret_cast<float4*>(y)[i] = q < Din4 ? reinterpret_cast<const float4*>(x)[m * Din4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ void k_copy_cols(const float* __restrict__ x, int ldx, int xc, float* __restrict__ y, int ldy, int yc,
+                            long long M, int n4) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * n4) return;
+    long long m = i / n4;
+    int q = (int)(i % n4);
+    *reinterpret_cast<float4*>(y + m * ldy + yc + 4 * q) = *reinterpret_cast<const float4*>(x + m * ldx + xc + 4 * q);
+}
+
+}  // namespace
+
+#define LAUNCH(kernel, grid, block, ...)                                        \
+    do {                                                                        \
+        if (!ctx.dry) {                                                         \
+            hipLaunchKernelGGL(kernel, grid, block, 0, ctx.stream, __VA_ARGS__); \
+            K2_HIP(hipGetLastError());                                          \
+        }                                                                       \
+    } while (0)
+
+void pad_logfloor(const Ctx& ctx, const float* packed, const long long* d_off, const long long* d_len, float* out, int B,
+                  long long L) {
+    dim3 grid(std::min(nblocks(L, 256), 512), B);
+    LAUNCH(k_pad_logfloor, grid, dim3(256), packed, d_off, d_len, out, L);
+}
+void pad_logfloor_dense(const Ctx& ctx, const float* feats, long long n_each, float* out, int B, long long L) {
+    dim3 grid(std::min(nblocks(L, 256), 512), B);
+    LAUNCH(k_pad_logfloor_dense, grid, dim3(256), feats, n_each, out, L);
+}
+void conv0_swoosh(const Ctx& ctx, const float* x, const float* w, const float* b, float* y, int B, int T, int F) {
+    long long n = (long long)B * (T - 2) * F;
+    LAUNCH(k_conv0, dim3(nblocks(n, 256)), dim3(256), x, w, b, y, B, T, F);
+}
+void dwconv7x7(const Ctx& ctx, const float* x, const float* w_kc, const float* b, float* y, int B, int T, int F, int C) {
+    long long n = (long long)B * T * F * (C / 4);
+    LAUNCH(k_dwconv7x7, dim3(nblocks(n, 256)), dim3(256), x, w_kc, b, y, B, T, F, C);
+    ctx.add_flops(0.0, 2.0 * B * T * (double)F * C * 49, 0);
+}
+void biasnorm(const Ctx& ctx, const float* x, const float* bias, const float* log_scale, float* y, int M, int D) {
+    K2_REQUIRE(D % 4 == 0 && D <= 1024, "biasnorm: D=%d unsupported", D);
+    LAUNCH((k_biasnorm<false>), dim3(nblocks(M, 4)), dim3(256), x, nullptr, bias, log_scale, nullptr, y, M, D);
+}
+void biasnorm_bypass(const Ctx& ctx, const float* x, const float* orig, const float* nbias, const float* log_scale,
+                     const float* scale, float* y, int M, int D) {
+    K2_REQUIRE(D % 4 == 0 && D <= 1024, "biasnorm: D=%d unsupported", D);
+    LAUNCH((k_biasnorm<true>), dim3(nblocks(M, 4)), dim3(256), x, orig, nbias, log_scale, scale, y, M, D);
+}
+void bypass(const Ctx& ctx, const float* orig, const float* x, const float* scale, float* y, int M, int D) {
+    long long n4 = (long long)M * D / 4;
+    LAUNCH(k_bypass, dim3(nblocks(n4, 256)), dim3(256), orig, x, scale, y, n4, D / 4);
+}
+void glu_sigmoid(const Ctx& ctx, const float* x, float* y, int M, int D) {
+    long long n4 = (long long)M * D / 4;
+    LAUNCH(k_glu, dim3(nblocks(n4, 256)), dim3(256), x, y, n4, D / 4);
+}
+void tanh_gate(const Ctx& ctx, const float* x, float* y, int M, int Hc) {
+    long long n4 = (long long)M * Hc / 4;
+    LAUNCH(k_tanh_gate, dim3(nblocks(n4, 256)), dim3(256), x, y, n4, Hc / 4);
+}
+void mul_cols(const Ctx& ctx, float* a, const float* x, int ldx, int col0, int M, int N) {
+    long long n4 = (long long)M * N / 4;
+    LAUNCH(k_mul_cols, dim3(nblocks(n4, 256)), dim3(256), a, x, ldx, col0, n4, N / 4);
+}
+void dwconv1d_swoosh(const Ctx& ctx, const float* x, const float* w_kd, const float* b, float* y, int B, int T, int D, int K) {
+    constexpr int TT = 8;
+    int D4 = D / 4;
+    int bx = std::min(D4, 64);
+    dim3 grid(cdiv(D4, bx), cdiv(T, TT), B);
+    LAUNCH((k_dwconv1d<TT>), grid, dim3(bx), x, w_kd, b, y, B, T, D, K);
+    ctx.add_flops(0.0, 2.0 * B * T * (double)D * K, 0);
+}
+void downsample(const Ctx& ctx, const float* x, const float* bias, float* y, int B, int T, int D, int ds) {
+    int Td = (T + ds - 1) / ds;
+    long long n = (long long)B * Td * (D / 4);
+    LAUNCH(k_downsample, dim3(nblocks(n, 256)), dim3(256), x, bias, y, B, T, Td, D / 4, ds);
+}
+void upsample_combine(const Ctx& ctx, const float* orig, const float* xd, const float* scale, float* y, int B, int T,
+                      int Td, int D, int ds) {
+    long long n = (long long)B * T * (D / 4);
+    LAUNCH(k_upsample_combine, dim3(nblocks(n, 256)), dim3(256), orig, xd, scale, y, B, T, Td, D / 4, ds);
+}
+void convert_channels(const Ctx& ctx, const float* x, float* y, int M, int Din, int Dout) {
+    long long n = (long long)M * (Dout / 4);
+    LAUNCH(k_convert_channels, dim3(nblocks(n, 256)), dim3(256), x, y, (long long)M, Din / 4, Dout / 4);
+}
+void copy_cols(const Ctx& ctx, const float* x, int ldx, int xcol0, float* y, int ldy, int ycol0, int M, int n) {
+    long long tot = (long long)M * (n / 4);
+    LAUNCH(k_copy_cols, dim3(nblocks(tot, 256)), dim3(256), x, ldx, xcol0, y, ldy, ycol0, (long long)M, n / 4);
+}
+
+}  // namespace k2hip

@@ -1,0 +1,719 @@
+#include "engine.h"
+
+#include <climits>
+#include <cmath>
+
+namespace k2hip {
+
+namespace {
+constexpr int kTailFrames = 19;  // PadHelper.cs:17
+}
+
+Engine::Engine(const std::string& weights, const char* overrides, int device) : device_(device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        failf(K2HIP_ERR_NO_DEVICE, "no HIP device visible: libk2hip has no CPU fallback");
+    if (device < 0 || device >= n) failf(K2HIP_ERR_NO_DEVICE, "device %d out of range (have %d)", device, n);
+    K2_HIP(hipSetDevice(device));
+    model_.reset(new Model(weights, overrides, device));
+    K2_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    for (auto& e : ev_) K2_HIP(hipEventCreate(&e));
+    K2_HIP(hipEventCreate(&gev0_));
+    K2_HIP(hipEventCreate(&gev1_));
+}
+
+Engine::~Engine() {
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    for (auto& kv : pe_cache_) (void)hipFree(kv.second);
+    for (auto& e : ev_)
+        if (e) (void)hipEventDestroy(e);
+    if (gev0_) (void)hipEventDestroy(gev0_);
+    if (gev1_) (void)hipEventDestroy(gev1_);
+    if (pin_) (void)hipHostFree(pin_);
+    arena_.release();
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void* Engine::pinned(int64_t bytes) {
+    if (bytes > pin_cap_) {
+        if (pin_) K2_HIP(hipHostFree(pin_));
+        pin_ = nullptr;
+        pin_cap_ = 0;
+        K2_HIP(hipHostMalloc(&pin_, (size_t)bytes, hipHostMallocDefault));
+        pin_cap_ = bytes;
+    }
+    return pin_;
+}
+
+Ctx Engine::make_ctx(bool dry) {
+    Ctx c;
+    c.stream = stream_;
+    c.arena = &arena_;
+    c.dry = dry;
+    c.instrument = instrument_ && !dry;
+    c.stats = &stats_;
+    c.ev0 = gev0_;
+    c.ev1 = gev1_;
+    return c;
+}
+
+template <typename F>
+void Engine::run_sized(F&& body) {
+    K2_HIP(hipSetDevice(device_));
+    stats_ = GemmStats();
+    arena_.reset();
+    arena_.set_dry(true);
+    try {
+        Ctx d = make_ctx(true);
+        body(d);
+    } catch (...) {
+        arena_.set_dry(false);
+        arena_.reset();
+        throw;
+    }
+    arena_.set_dry(false);
+    int64_t need = arena_.high_water();
+    arena_.reset();
+    if (need > arena_.capacity()) {
+        K2_HIP(hipStreamSynchronize(stream_));
+        arena_.reserve(need + need / 8);
+    }
+    Ctx c = make_ctx(false);
+    body(c);
+    timing_.gemm_ms = stats_.ms;
+    timing_.gemm_launches = stats_.launches;
+    timing_.gemm_flops = stats_.flops;
+    timing_.total_flops = stats_.total_flops;
+}
+
+int Engine::encoder_out_frames(int T) const {
+    int T50 = (T - 7) / 2;
+    return T50 <= 0 ? 0 : (T50 + 1) / 2;
+}
+int64_t Engine::fbank_num_frames(int64_t n) const {
+    const FbankOpts& f = model_->cfg().fbank;
+    if (n < f.frame_len) return 0;
+    return 1 + (n - f.frame_len) / f.frame_shift;
+}
+
+// CompactRelPositionalEncoding (icefall zipformer.py): row n <-> relative offset n-(T-1)
+const float* Engine::pos_emb(int T) {
+    auto it = pe_cache_.find(T);
+    if (it != pe_cache_.end()) return it->second;
+    const int pd = model_->cfg().pos_dim, n2 = 2 * T - 1;
+    std::vector<float> pe((size_t)n2 * pd);
+    const float cl = sqrtf((float)pd), ls = (float)pd / (2.0f * (float)M_PI), logcl = logf(cl);
+    for (int n = 0; n < n2; n++) {
+        float x = (float)(n - (T - 1));
+        float sg = (float)((x > 0.f) - (x < 0.f));
+        float xa = atanf(cl * sg * (logf(fabsf(x) + cl) - logcl) / ls);
+        for (int k = 0; k < pd / 2; k++) {
+            pe[(size_t)n * pd + 2 * k] = cosf(xa * (float)(k + 1));
+            pe[(size_t)n * pd + 2 * k + 1] = sinf(xa * (float)(k + 1));
+        }
+        pe[(size_t)n * pd + pd - 1] = 1.0f;
+    }
+    float* d = nullptr;
+    K2_HIP(hipMalloc(&d, pe.size() * sizeof(float)));
+    K2_HIP(hipMemcpy(d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+    pe_cache_[T] = d;
+    return d;
+}
+
+DecJoinW Engine::decjoin() const {
+    const Config& c = model_->cfg();
+    DecJoinW w;
+    w.emb = model_->w("decoder.embedding.weight");
+    w.conv = model_->w("decoder.conv.weight");
+    w.dproj_kn = model_->w("joiner.decoder_proj.weight#kn");
+    w.dproj_b = model_->w("joiner.decoder_proj.bias");
+    w.out_kn = model_->w("joiner.output_linear.weight#kn");
+    w.out_b = model_->w("joiner.output_linear.bias");
+    w.V = c.V; w.Vp = c.Vp; w.DD = c.DD; w.J = c.J; w.ctx = c.ctx;
+    return w;
+}
+
+// ---------------------------------------------------------------------------
+// Conv2dSubsampling (encoder_embed), NHWC.  x: [B,T,80] -> [B,T50,D0]
+// ---------------------------------------------------------------------------
+float* Engine::encoder_embed(const Ctx& c, const float* x, int B, int T, int* T50) {
+    const Model& m = *model_;
+    const int F0 = 80, T1 = T - 2, T2 = (T1 - 3) / 2 + 1, F2 = (F0 - 3) / 2 + 1, T3 = T2 - 2, F3 = (F2 - 3) / 2 + 1;
+    K2_REQUIRE(T3 > 0, "encoder: %d input frames are too few (need >= 9)", T);
+    Arena& ar = *c.arena;
+    const int D0 = m.cfg().dim[0];
+    float* out = ar.take<float>((int64_t)B * T3 * D0);
+    int64_t mark = ar.mark();
+    float* a1 = ar.take<float>((int64_t)B * T1 * F0 * 8);
+    conv0_swoosh(c, x, m.w("encoder_embed.conv.0.weight"), m.w("encoder_embed.conv.0.bias"), a1, B, T, F0);
+    c.add_flops(0, 2.0 * B * T1 * (double)F0 * 8 * 9, 0);
+    float* a2 = ar.take<float>((int64_t)B * T2 * F2 * 32);
+    {
+        GemmArgs g;
+        g.A = a1; g.W = m.w("encoder_embed.conv.4.weight#ohwi"); g.ldw = 72; g.bias = m.w("encoder_embed.conv.4.bias");
+        g.C = a2; g.ldc = 32; g.M = B * T2 * F2; g.N = 32; g.K = 72; g.act = ACT_SWOOSH_R;
+        g.cv_Fout = F2; g.cv_Tout = T2; g.cv_Tin = T1; g.cv_Fin = F0; g.cv_C = 8; g.cv_st = 2; g.cv_sf = 2;
+        g.seg_len = 24; g.seg_stride = F0 * 8;
+        gemm(c, g);
+    }
+    float* a3 = ar.take<float>((int64_t)B * T3 * F3 * 128);
+    {
+        GemmArgs g;
+        g.A = a2; g.W = m.w("encoder_embed.conv.7.weight#ohwi"); g.ldw = 288; g.bias = m.w("encoder_embed.conv.7.bias");
+        g.C = a3; g.ldc = 128; g.M = B * T3 * F3; g.N = 128; g.K = 288; g.act = ACT_SWOOSH_R;
+        g.cv_Fout = F3; g.cv_Tout = T3; g.cv_Tin = T2; g.cv_Fin = F2; g.cv_C = 32; g.cv_st = 1; g.cv_sf = 2;
+        g.seg_len = 96; g.seg_stride = F2 * 32;
+        gemm(c, g);
+    }
+    // ConvNeXt: a3 += pw2(SwooshL(pw1(dw7x7(a3))))
+    const int npix = B * T3 * F3;
+    float* dw = ar.take<float>((int64_t)npix * 128);
+    dwconv7x7(c, a3, m.w("encoder_embed.convnext.depthwise_conv.weight#kc"), m.w("encoder_embed.convnext.depthwise_conv.bias"),
+              dw, B, T3, F3, 128);
+    float* hid = ar.take<float>((int64_t)npix * 384);
+    linear(c, dw, 128, m.w("encoder_embed.convnext.pointwise_conv1.weight"), m.w("encoder_embed.convnext.pointwise_conv1.bias"),
+           hid, 384, npix, 128, 384, ACT_SWOOSH_L);
+    linear(c, hid, 384, m.w("encoder_embed.convnext.pointwise_conv2.weight"), m.w("encoder_embed.convnext.pointwise_conv2.bias"),
+           a3, 128, npix, 384, 128, ACT_NONE, a3, 128);
+    // (b,t,f,c) flatten == [B*T3, F3*128] with the repacked out.weight
+    float* lin = ar.take<float>((int64_t)B * T3 * D0);
+    linear(c, a3, F3 * 128, m.w("encoder_embed.out.weight#fc"), m.w("encoder_embed.out.bias"), lin, D0, B * T3, F3 * 128, D0);
+    biasnorm(c, lin, m.w("encoder_embed.out_norm.bias"), m.w("encoder_embed.out_norm.log_scale"), out, B * T3, D0);
+    ar.rewind(mark);
+    *T50 = T3;
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// Zipformer2EncoderLayer.forward (inference), in place on x [B*T, D]
+// ---------------------------------------------------------------------------
+void Engine::encoder_layer(const Ctx& c, int si, int li, float* x, const float* pe, int B, int T) {
+    const Model& m = *model_;
+    const Config& cf = m.cfg();
+    const int D = cf.dim[si], F = cf.ff[si], H = cf.heads[si], vh = cf.vhd[si], K = cf.kern[si];
+    const int M = B * T, Tp = (T + 3) & ~3, inproj = (2 * cf.qhd[si] + cf.phd[si]) * H, Hc = 3 * D / 4, HV = H * vh;
+    char p[96];
+    snprintf(p, sizeof p, "encoder.encoders.%d.layers.%d.", si, li);
+    auto w = [&](const char* suffix) { return m.w(std::string(p) + suffix); };
+    Arena& ar = *c.arena;
+    int64_t mark = ar.mark();
+
+    // attention weights, shared by nonlin_attention / self_attn1 / self_attn2
+    float* qkp = ar.take<float>((int64_t)M * inproj);
+    linear(c, x, D, w("self_attn_weights.in_proj.weight"), w("self_attn_weights.in_proj.bias"), qkp, inproj, M, D, inproj);
+    float* pp = ar.take<float>((int64_t)(2 * T - 1) * cf.phd[si] * H);
+    linear(c, pe, cf.pos_dim, w("self_attn_weights.linear_pos.weight"), nullptr, pp, cf.phd[si] * H, 2 * T - 1, cf.pos_dim,
+           cf.phd[si] * H);
+    float* aw = ar.take<float>((int64_t)H * B * T * Tp);
+    attn_scores_softmax(c, qkp, inproj, pp, aw, B, T, Tp, H);
+
+    float* src = ar.take<float>((int64_t)M * D);
+    float* hid = ar.take<float>((int64_t)M * std::max({F * 5 / 4, 3 * Hc, 2 * D}));
+    float* tmp = ar.take<float>((int64_t)M * std::max(D, Hc));
+    float* tmp2 = ar.take<float>((int64_t)M * std::max(D, Hc));
+
+    auto feed_forward = [&](int k, int Fk, const float* in, float* out) {
+        char a[48], b[48], cc[48], d[48];
+        snprintf(a, sizeof a, "feed_forward%d.in_proj.weight", k);
+        snprintf(b, sizeof b, "feed_forward%d.in_proj.bias", k);
+        snprintf(cc, sizeof cc, "feed_forward%d.out_proj.weight", k);
+        snprintf(d, sizeof d, "feed_forward%d.out_proj.bias", k);
+        linear(c, in, D, w(a), w(b), hid, Fk, M, D, Fk, ACT_SWOOSH_L);
+        linear(c, hid, Fk, w(cc), w(d), out, D, M, Fk, D, ACT_NONE, in, D);
+    };
+    auto self_attn = [&](int k) {
+        char a[48], b[48], cc[48], d[48];
+        snprintf(a, sizeof a, "self_attn%d.in_proj.weight", k);
+        snprintf(b, sizeof b, "self_attn%d.in_proj.bias", k);
+        snprintf(cc, sizeof cc, "self_attn%d.out_proj.weight", k);
+        snprintf(d, sizeof d, "self_attn%d.out_proj.bias", k);
+        linear(c, src, D, w(a), w(b), hid, HV, M, D, HV);
+        GemmArgs g;  // tmp[b, :, h*vh : (h+1)*vh] = aw[h][b] . hid[b, :, h*vh : ...]
+        g.A = aw; g.lda = Tp; g.sA0 = (long long)T * Tp; g.sA1 = (long long)B * T * Tp;
+        g.W = hid; g.w_kn = 1; g.ldw = HV; g.sW0 = (long long)T * HV; g.sW1 = vh;
+        g.C = tmp; g.ldc = HV; g.sC0 = (long long)T * HV; g.sC1 = vh;
+        g.M = T; g.N = vh; g.K = T; g.nb0 = B; g.nb1 = H;
+        gemm(c, g);
+        linear(c, tmp, HV, w(cc), w(d), src, D, M, HV, D, ACT_NONE, src, D);
+    };
+    auto conv_module = [&](int k) {
+        char a[64], b[64], cc[64], d[64], e[64], f[64];
+        snprintf(a, sizeof a, "conv_module%d.in_proj.weight", k);
+        snprintf(b, sizeof b, "conv_module%d.in_proj.bias", k);
+        snprintf(cc, sizeof cc, "conv_module%d.depthwise_conv.weight#kd", k);
+        snprintf(d, sizeof d, "conv_module%d.depthwise_conv.bias", k);
+        snprintf(e, sizeof e, "conv_module%d.out_proj.weight", k);
+        snprintf(f, sizeof f, "conv_module%d.out_proj.bias", k);
+        linear(c, src, D, w(a), w(b), hid, 2 * D, M, D, 2 * D);
+        glu_sigmoid(c, hid, tmp, M, D);
+        dwconv1d_swoosh(c, tmp, w(cc), w(d), tmp2, B, T, D, K);
+        linear(c, tmp2, D, w(e), w(f), src, D, M, D, D, ACT_NONE, src, D);
+    };
+
+    feed_forward(1, F * 3 / 4, x, src);  // src = x + ff1(x)
+    {   // src += NonlinAttention(src, aw[0])
+        linear(c, src, D, w("nonlin_attention.in_proj.weight"), w("nonlin_attention.in_proj.bias"), hid, 3 * Hc, M, D, 3 * Hc);
+        tanh_gate(c, hid, tmp, M, Hc);
+        GemmArgs g;
+        g.A = aw; g.lda = Tp; g.sA0 = (long long)T * Tp;
+        g.W = tmp; g.w_kn = 1; g.ldw = Hc; g.sW0 = (long long)T * Hc;
+        g.C = tmp2; g.ldc = Hc; g.sC0 = (long long)T * Hc;
+        g.M = T; g.N = Hc; g.K = T; g.nb0 = B; g.nb1 = 1;
+        gemm(c, g);
+        mul_cols(c, tmp2, hid, 3 * Hc, 2 * Hc, M, Hc);
+        linear(c, tmp2, Hc, w("nonlin_attention.out_proj.weight"), w("nonlin_attention.out_proj.bias"), src, D, M, Hc, D,
+               ACT_NONE, src, D);
+    }
+    self_attn(1);
+    conv_module(1);
+    feed_forward(2, F, src, src);
+    bypass(c, x, src, w("bypass_mid.bypass_scale"), src, M, D);
+    self_attn(2);
+    conv_module(2);
+    feed_forward(3, F * 5 / 4, src, src);
+    biasnorm_bypass(c, src, x, w("norm.bias"), w("norm.log_scale"), w("bypass.bypass_scale"), x, M, D);
+    ar.rewind(mark);
+}
+
+// Zipformer2.forward stacks; returns full-dim output [B*T50, Dmax]
+float* Engine::encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, float** tap_ptr, int* tap_dim) {
+    const Model& m = *model_;
+    const Config& cf = m.cfg();
+    Arena& ar = *c.arena;
+    const int M = B * T50;
+    float* outputs[kMaxStacks] = {nullptr};
+    float* x = x0;
+    int Dcur = cf.dim[0];
+    for (int si = 0; si < cf.ns; si++) {
+        const int D = cf.dim[si], ds = cf.ds[si];
+        float* xi = ar.take<float>((int64_t)M * D);
+        if (D == Dcur) {
+            if (!c.dry) K2_HIP(hipMemcpyAsync(xi, x, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, c.stream));
+        } else {
+            convert_channels(c, x, xi, M, Dcur, D);
+        }
+        Dcur = D;
+        if (ds == 1) {
+            const float* pe = c.dry ? nullptr : pos_emb(T50);
+            for (int li = 0; li < cf.nlayer[si]; li++) encoder_layer(c, si, li, xi, pe, B, T50);
+            x = xi;
+        } else {
+            const int Td = (T50 + ds - 1) / ds;
+            float* y = ar.take<float>((int64_t)M * D);
+            int64_t mark = ar.mark();
+            float* xd = ar.take<float>((int64_t)B * Td * D);
+            downsample(c, xi, m.wf("encoder.encoders.%d.downsample.bias", si), xd, B, T50, D, ds);
+            const float* pe = c.dry ? nullptr : pos_emb(Td);
+            for (int li = 0; li < cf.nlayer[si]; li++) encoder_layer(c, si, li, xd, pe, B, Td);
+            upsample_combine(c, xi, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y, B, T50, Td, D, ds);
+            ar.rewind(mark);
+            x = y;
+        }
+        outputs[si] = x;
+        if (tap == 1 + si) {
+            *tap_ptr = x;
+            *tap_dim = D;
+            return nullptr;
+        }
+    }
+    // _get_full_dim_output
+    const int Dmax = cf.dmax;
+    float* full = ar.take<float>((int64_t)M * Dmax);
+    int cur = cf.dim[cf.ns - 1];
+    copy_cols(c, outputs[cf.ns - 1], cur, 0, full, Dmax, 0, M, cur);
+    for (int i = cf.ns - 2; i >= 0; i--) {
+        int d = cf.dim[i];
+        if (d > cur) {
+            copy_cols(c, outputs[i], d, cur, full, Dmax, cur, M, d - cur);
+            cur = d;
+        }
+    }
+    return full;
+}
+
+float* Engine::encoder_forward(const Ctx& c, const float* x, int B, int T, int* Tp, int tap, float** tap_ptr, int* tap_rows,
+                               int* tap_dim) {
+    const Model& m = *model_;
+    const Config& cf = m.cfg();
+    Arena& ar = *c.arena;
+    int T50 = 0;
+    // output first so that everything after it can be rewound
+    int T50_pre = (T - 7) / 2;
+    K2_REQUIRE(T50_pre > 0, "encoder: %d input frames are too few", T);
+    int Tpp = (T50_pre + 1) / 2;
+    float* enc_out = ar.take<float>((int64_t)B * Tpp * cf.J);
+    float* x0 = encoder_embed(c, x, B, T, &T50);
+    if (tap_rows) *tap_rows = B * T50;
+    if (tap == 0) {
+        *tap_ptr = x0;
+        *tap_dim = cf.dim[0];
+        return nullptr;
+    }
+    float* full = encoder_stacks(c, x0, B, T50, tap, tap_ptr, tap_dim);
+    if (!full) return nullptr;
+    if (tap == 100) {
+        *tap_ptr = full;
+        *tap_dim = cf.dmax;
+        return nullptr;
+    }
+    float* dsd = ar.take<float>((int64_t)B * Tpp * cf.dmax);
+    downsample(c, full, m.w("encoder.downsample_output.bias"), dsd, B, T50, cf.dmax, 2);
+    linear(c, dsd, cf.dmax, m.w("joiner.encoder_proj.weight"), m.w("joiner.encoder_proj.bias"), enc_out, cf.J, B * Tpp, cf.dmax, cf.J);
+    *Tp = Tpp;
+    return enc_out;
+}
+
+// ---------------------------------------------------------------------------
+// greedy search on device
+// ---------------------------------------------------------------------------
+void Engine::greedy_device(const Ctx& c, const float* enc, int B, int Tp, bool single, long long* d_tok, int* d_ts, int* d_n,
+                           int max_tokens, int* d_overflow) {
+    const Config& cf = model_->cfg();
+    Arena& ar = *c.arena;
+    DecJoinW w = decjoin();
+    int* d_t0 = nullptr;
+    if (!c.dry) K2_HIP(hipMemsetAsync(d_overflow, 0, sizeof(int), c.stream));
+    if (!single && B > 1) {
+        // parallel pass under the initial context [-1, blank]: which frame is the batch's first emission?
+        long long* d_hyp = ar.take<long long>(2);
+        static const long long h_init[2] = {-1, K2HIP_BLANK_ID};
+        if (!c.dry) K2_HIP(hipMemcpyAsync(d_hyp, h_init, sizeof h_init, hipMemcpyHostToDevice, c.stream));
+        float* dec_a = ar.take<float>(cf.J);
+        decoder(c, w, d_hyp, 1, dec_a);
+        const int N = B * Tp;
+        float* act = ar.take<float>((int64_t)N * cf.J);
+        tanh_add(c, enc, dec_a, 0, act, N, cf.J);
+        float* logits = ar.take<float>((int64_t)N * cf.V);
+        linear(c, act, cf.J, model_->w("joiner.output_linear.weight"), model_->w("joiner.output_linear.bias"), logits, cf.V, N,
+               cf.J, cf.V);
+        int* tok = ar.take<int>(N);
+        argmax_rows(c, logits, cf.V, N, cf.V, tok);
+        d_t0 = ar.take<int>(1);
+        first_emit_frame(c, tok, B, Tp, 0, d_t0);
+    }
+    GreedyArgs a;
+    a.enc = enc; a.B = B; a.Tp = Tp; a.t0 = d_t0; a.skip1 = 0;
+    a.max_sym = single ? 1000 : INT_MAX;  // OfflineRecognizer.cs:122
+    a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = max_tokens; a.overflow = d_overflow;
+    greedy_loop(c, w, a);
+}
+
+void Engine::finish_tokens(const long long* d_tok, const int* d_ts, const int* d_n, const int* d_ovf, int B, int max_tokens,
+                           int64_t* tokens, int32_t* ts, int32_t* n_tokens) {
+    int64_t nb_tok = (int64_t)B * max_tokens * 8, nb_ts = (int64_t)B * max_tokens * 4, nb_n = (int64_t)B * 4;
+    char* pin = static_cast<char*>(pinned(nb_tok + nb_ts + nb_n + 64));
+    K2_HIP(hipMemcpyAsync(pin, d_tok, nb_tok, hipMemcpyDeviceToHost, stream_));
+    K2_HIP(hipMemcpyAsync(pin + nb_tok, d_ts, nb_ts, hipMemcpyDeviceToHost, stream_));
+    K2_HIP(hipMemcpyAsync(pin + nb_tok + nb_ts, d_n, nb_n, hipMemcpyDeviceToHost, stream_));
+    K2_HIP(hipMemcpyAsync(pin + nb_tok + nb_ts + nb_n, d_ovf, 4, hipMemcpyDeviceToHost, stream_));
+    K2_HIP(hipEventRecord(ev_[5], stream_));
+    K2_HIP(hipStreamSynchronize(stream_));
+    int ovf = *reinterpret_cast<int*>(pin + nb_tok + nb_ts + nb_n);
+    if (ovf) failf(K2HIP_ERR_CAPACITY, "a stream emitted more than max_tokens=%d symbols", max_tokens);
+    memcpy(tokens, pin, nb_tok);
+    memcpy(ts, pin + nb_tok, nb_ts);
+    memcpy(n_tokens, pin + nb_tok + nb_ts, nb_n);
+}
+
+// ---------------------------------------------------------------------------
+// operator-level entry points
+// ---------------------------------------------------------------------------
+void Engine::fbank_host(const float* samples, int64_t n, float* feats, int64_t cap_frames, int64_t* n_frames) {
+    const FbankOpts& f = model_->cfg().fbank;
+    int64_t nf = fbank_num_frames(n);
+    if (nf > cap_frames) failf(K2HIP_ERR_CAPACITY, "fbank: %lld frames exceed capacity %lld", (long long)nf, (long long)cap_frames);
+    *n_frames = nf;
+    if (nf == 0) return;
+    float* d_out = nullptr;
+    run_sized([&](const Ctx& c) {
+        float* d_s = c.arena->take<float>(n);
+        d_out = c.arena->take<float>(nf * f.num_bins);
+        if (!c.dry) K2_HIP(hipMemcpyAsync(d_s, samples, sizeof(float) * n, hipMemcpyHostToDevice, c.stream));
+        FbankArgs a{d_s, n, n, 1, nf, d_out, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift, f.preemph, f.input_scale, f.remove_dc};
+        fbank(c, a);
+    });
+    K2_HIP(hipMemcpyAsync(feats, d_out, sizeof(float) * nf * f.num_bins, hipMemcpyDeviceToHost, stream_));
+    K2_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::pad_host(const float* const* speech, const int64_t* n_floats, int B, int tail, float* out, int64_t cap, int64_t* Lout) {
+    K2_REQUIRE(B > 0, "pad: empty batch");
+    int64_t mx = 0, total = 0;
+    for (int b = 0; b < B; b++) {
+        K2_REQUIRE(n_floats[b] >= 0 && (speech[b] || n_floats[b] == 0), "pad: stream %d has no features", b);
+        mx = std::max(mx, n_floats[b]);
+        total += n_floats[b];
+    }
+    int64_t L = mx + 80 * (int64_t)tail;  // PadHelper.cs:22 (80 is hard-coded there)
+    *Lout = L;
+    if ((int64_t)B * L > cap) failf(K2HIP_ERR_CAPACITY, "pad: need %lld floats, capacity %lld", (long long)B * L, (long long)cap);
+    float* d_out = nullptr;
+    std::vector<long long> off(B), len(B);
+    run_sized([&](const Ctx& c) {
+        float* d_packed = c.arena->take<float>(total);
+        long long* d_off = c.arena->take<long long>(B);
+        long long* d_len = c.arena->take<long long>(B);
+        d_out = c.arena->take<float>((int64_t)B * L);
+        if (!c.dry) {
+            long long o = 0;
+            for (int b = 0; b < B; b++) {
+                off[b] = o; len[b] = n_floats[b];
+                if (n_floats[b]) K2_HIP(hipMemcpyAsync(d_packed + o, speech[b], sizeof(float) * n_floats[b], hipMemcpyHostToDevice, c.stream));
+                o += n_floats[b];
+            }
+            K2_HIP(hipMemcpyAsync(d_off, off.data(), sizeof(long long) * B, hipMemcpyHostToDevice, c.stream));
+            K2_HIP(hipMemcpyAsync(d_len, len.data(), sizeof(long long) * B, hipMemcpyHostToDevice, c.stream));
+        }
+        pad_logfloor(c, d_packed, d_off, d_len, d_out, B, L);
+    });
+    K2_HIP(hipMemcpyAsync(out, d_out, sizeof(float) * (size_t)B * L, hipMemcpyDeviceToHost, stream_));
+    K2_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::encoder_host(const float* x, int B, int T, float* enc_out, int64_t cap, int* Tp) {
+    K2_REQUIRE(B > 0 && T > 0, "encoder: bad shape B=%d T=%d", B, T);
+    int tp = encoder_out_frames(T);
+    K2_REQUIRE(tp > 0, "encoder: %d input frames are too few", T);
+    const int J = model_->cfg().J, feat = model_->cfg().feat;
+    if ((int64_t)B * tp * J > cap) failf(K2HIP_ERR_CAPACITY, "encoder: output needs %lld floats", (long long)B * tp * J);
+    float* d_enc = nullptr;
+    run_sized([&](const Ctx& c) {
+        float* d_x = c.arena->take<float>((int64_t)B * T * feat);
+        if (!c.dry) K2_HIP(hipMemcpyAsync(d_x, x, sizeof(float) * (size_t)B * T * feat, hipMemcpyHostToDevice, c.stream));
+        int t2 = 0;
+        d_enc = encoder_forward(c, d_x, B, T, &t2, -1, nullptr, nullptr, nullptr);
+    });
+    K2_HIP(hipMemcpyAsync(enc_out, d_enc, sizeof(float) * (size_t)B * tp * J, hipMemcpyDeviceToHost, stream_));
+    K2_HIP(hipStreamSynchronize(stream_));
+    *Tp = tp;
+}
+
+void Engine::encoder_tap_host(const float* x, int B, int T, int tap, float* out, int64_t cap, int64_t* n) {
+    K2_REQUIRE(B > 0 && T > 0, "encoder: bad shape B=%d T=%d", B, T);
+    const int feat = model_->cfg().feat;
+    float* tp = nullptr;
+    int rows = 0, dim = 0;
+    run_sized([&](const Ctx& c) {
+        float* d_x = c.arena->take<float>((int64_t)B * T * feat);
+        if (!c.dry) K2_HIP(hipMemcpyAsync(d_x, x, sizeof(float) * (size_t)B * T * feat, hipMemcpyHostToDevice, c.stream));
+        int t2 = 0;
+        float* r = encoder_forward(c, d_x, B, T, &t2, tap, &tp, &rows, &dim);
+        K2_REQUIRE(r == nullptr, "encoder tap %d does not exist", tap);
+    });
+    int64_t cnt = (int64_t)rows * dim;
+    if (cnt > cap) failf(K2HIP_ERR_CAPACITY, "tap needs %lld floats", (long long)cnt);
+    K2_HIP(hipMemcpyAsync(out, tp, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost, stream_));
+    K2_HIP(hipStreamSynchronize(stream_));
+    *n = cnt;
+}
+
+void Engine::decoder_host(const int64_t* y, int N, float* dec_out) {
+    K2_REQUIRE(N > 0, "decoder: N=%d", N);
+    const Config& cf = model_->cfg();
+    std::vector<long long> hy((size_t)N * 2);
+    for (int i = 0; i < N; i++) {
+        // DecoderProj(null) -> [-1, blank] per row (OfflineProjOfTransducer.cs:97-110)
+        hy[2 * i] = y ? y[2 * i] : -1;
+        hy[2 * i + 1] = y ? y[2 * i + 1] : K2HIP_BLANK_ID;
+        K2_REQUIRE(hy[2 * i] < cf.V && hy[2 * i + 1] < cf.V, "decoder: token id out of range (vocab %d)", cf.V);
+    }
+    float* d_out = nullptr;
+    run_sized([&](const Ctx& c) {
+        long long* d_y = c.arena->take<long long>((int64_t)N * 2);
+        d_out = c.arena->take<float>((int64_t)N * cf.J);
+        if (!c.dry) K2_HIP(hipMemcpyAsync(d_y, hy.data(), sizeof(long long) * hy.size(), hipMemcpyHostToDevice, c.stream));
+        decoder(c, decjoin(), d_y, N, d_out);
+    });
+    K2_HIP(hipMemcpyAsync(dec_out, d_out, sizeof(float) * (size_t)N * cf.J, hipMemcpyDeviceToHost, stream_));
+    K2_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::joiner_host(const float* enc, const float* dec, int N, float* logits) {
+    K2_REQUIRE(N > 0, "joiner: N=%d", N);
+    const Config& cf = model_->cfg();
+    float* d_l = nullptr;
+    run_sized([&](const Ctx& c) {
+        float* d_e = c.arena->take<float>((int64_t)N * cf.J);
+        float* d_d = c.arena->take<float>((int64_t)N * cf.J);
+        float* d_a = c.arena->take<float>((int64_t)N * cf.J);
+        d_l = c.arena->take<float>((int64_t)N * cf.V);
+        if (!c.dry) {
+            K2_HIP(hipMemcpyAsync(d_e, enc, sizeof(float) * (size_t)N * cf.J, hipMemcpyHostToDevice, c.stream));
+            K2_HIP(hipMemcpyAsync(d_d, dec, sizeof(float) * (size_t)N * cf.J, hipMemcpyHostToDevice, c.stream));
+        }
+        tanh_add(c, d_e, d_d, cf.J, d_a, N, cf.J);
+        linear(c, d_a, cf.J, model_->w("joiner.output_linear.weight"), model_->w("joiner.output_linear.bias"), d_l, cf.V, N, cf.J, cf.V);
+    });
+    K2_HIP(hipMemcpyAsync(logits, d_l, sizeof(float) * (size_t)N * cf.V, hipMemcpyDeviceToHost, stream_));
+    K2_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::greedy_host(const float* enc_out, int B, int Tp, bool single, int64_t* tokens, int32_t* ts, int32_t* n_tokens,
+                         int max_tokens) {
+    K2_REQUIRE(B > 0 && Tp > 0 && max_tokens > 0, "greedy: bad shape B=%d T'=%d max_tokens=%d", B, Tp, max_tokens);
+    K2_REQUIRE(!single || B == 1, "greedy_single: B must be 1");
+    const Config& cf = model_->cfg();
+    long long* d_tok = nullptr;
+    int *d_ts = nullptr, *d_n = nullptr, *d_ovf = nullptr;
+    run_sized([&](const Ctx& c) {
+        float* d_e = c.arena->take<float>((int64_t)B * Tp * cf.J);
+        d_tok = c.arena->take<long long>((int64_t)B * max_tokens);
+        d_ts = c.arena->take<int>((int64_t)B * max_tokens);
+        d_n = c.arena->take<int>(B);
+        d_ovf = c.arena->take<int>(1);
+        if (!c.dry) K2_HIP(hipMemcpyAsync(d_e, enc_out, sizeof(float) * (size_t)B * Tp * cf.J, hipMemcpyHostToDevice, c.stream));
+        greedy_device(c, d_e, B, Tp, single, d_tok, d_ts, d_n, max_tokens, d_ovf);
+    });
+    finish_tokens(d_tok, d_ts, d_n, d_ovf, B, max_tokens, tokens, ts, n_tokens);
+}
+
+// ---------------------------------------------------------------------------
+// fused paths
+// ---------------------------------------------------------------------------
+void Engine::offline_greedy_feats(const float* const* feats, const int64_t* n_floats, int B, bool single, int64_t* tokens,
+                                  int32_t* ts, int32_t* n_tokens, int max_tokens) {
+    K2_REQUIRE(B > 0 && max_tokens > 0, "offline_greedy: bad B=%d / max_tokens=%d", B, max_tokens);
+    K2_REQUIRE(!single || B == 1, "offline_greedy_single: B must be 1");
+    const Config& cf = model_->cfg();
+    K2_REQUIRE(cf.J == 512, "offline loops hard-code a 512-wide encoder_out (OfflineRecognizer.cs:103,201); joiner_dim is %d", cf.J);
+    int64_t mx = 0, total = 0;
+    for (int b = 0; b < B; b++) {
+        K2_REQUIRE(feats[b] != nullptr && n_floats[b] > 0, "offline_greedy: stream %d has no features", b);
+        mx = std::max(mx, n_floats[b]);
+        total += n_floats[b];
+    }
+    const int64_t L = mx + 80 * kTailFrames;
+    const int T = (int)(L / cf.feat);  // OfflineProjOfTransducer.cs:59
+    K2_REQUIRE(L % cf.feat == 0, "offline_greedy: padded length %lld is not a multiple of feature_dim", (long long)L);
+    // stage all features in one pinned buffer -> one H2D
+    float* pin = static_cast<float*>(pinned(sizeof(float) * total + 16 * B + 64));
+    std::vector<long long> off(B), len(B);
+    {
+        long long o = 0;
+        for (int b = 0; b < B; b++) {
+            memcpy(pin + o, feats[b], sizeof(float) * n_floats[b]);
+            off[b] = o; len[b] = n_floats[b];
+            o += n_floats[b];
+        }
+    }
+    long long* d_tok = nullptr;
+    int *d_ts = nullptr, *d_n = nullptr, *d_ovf = nullptr;
+    run_sized([&](const Ctx& c) {
+        Arena& ar = *c.arena;
+        d_tok = ar.take<long long>((int64_t)B * max_tokens);
+        d_ts = ar.take<int>((int64_t)B * max_tokens);
+        d_n = ar.take<int>(B);
+        d_ovf = ar.take<int>(1);
+        float* d_packed = ar.take<float>(total);
+        long long* d_off = ar.take<long long>(B);
+        long long* d_len = ar.take<long long>(B);
+        float* d_x = ar.take<float>((int64_t)B * L);
+        if (!c.dry) {
+            K2_HIP(hipEventRecord(ev_[0], c.stream));
+            K2_HIP(hipMemcpyAsync(d_packed, pin, sizeof(float) * total, hipMemcpyHostToDevice, c.stream));
+            K2_HIP(hipMemcpyAsync(d_off, off.data(), sizeof(long long) * B, hipMemcpyHostToDevice, c.stream));
+            K2_HIP(hipMemcpyAsync(d_len, len.data(), sizeof(long long) * B, hipMemcpyHostToDevice, c.stream));
+            K2_HIP(hipEventRecord(ev_[1], c.stream));
+        }
+        pad_logfloor(c, d_packed, d_off, d_len, d_x, B, L);
+        if (!c.dry) K2_HIP(hipEventRecord(ev_[2], c.stream));
+        int Tp = 0;
+        float* enc = encoder_forward(c, d_x, B, T, &Tp, -1, nullptr, nullptr, nullptr);
+        if (!c.dry) K2_HIP(hipEventRecord(ev_[3], c.stream));
+        greedy_device(c, enc, B, Tp, single, d_tok, d_ts, d_n, max_tokens, d_ovf);
+        if (!c.dry) K2_HIP(hipEventRecord(ev_[4], c.stream));
+    });
+    finish_tokens(d_tok, d_ts, d_n, d_ovf, B, max_tokens, tokens, ts, n_tokens);
+    auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, ev_[a], ev_[b]); return ms; };
+    timing_.fbank_ms = 0;
+    timing_.pad_ms = el(1, 2);
+    timing_.encoder_ms = el(2, 3);
+    timing_.greedy_ms = el(3, 4);
+    timing_.d2h_ms = el(4, 5);
+    timing_.total_ms = el(0, 5);
+}
+
+void Engine::offline_greedy_samples_dev(const float* samples_dev, int64_t n_each, int B, int64_t* tokens, int32_t* ts,
+                                        int32_t* n_tokens, int max_tokens) {
+    K2_REQUIRE(B > 0 && max_tokens > 0 && samples_dev != nullptr, "offline_greedy_from_samples: bad arguments");
+    const Config& cf = model_->cfg();
+    const FbankOpts& f = cf.fbank;
+    K2_REQUIRE(cf.J == 512, "offline loops hard-code a 512-wide encoder_out; joiner_dim is %d", cf.J);
+    const int64_t nf = fbank_num_frames(n_each);
+    K2_REQUIRE(nf > 0, "offline_greedy_from_samples: %lld samples give no frame", (long long)n_each);
+    const int64_t n_fl = nf * cf.feat, L = n_fl + 80 * kTailFrames;
+    const int T = (int)(L / cf.feat);
+    long long* d_tok = nullptr;
+    int *d_ts = nullptr, *d_n = nullptr, *d_ovf = nullptr;
+    run_sized([&](const Ctx& c) {
+        Arena& ar = *c.arena;
+        d_tok = ar.take<long long>((int64_t)B * max_tokens);
+        d_ts = ar.take<int>((int64_t)B * max_tokens);
+        d_n = ar.take<int>(B);
+        d_ovf = ar.take<int>(1);
+        float* d_feats = ar.take<float>((int64_t)B * n_fl);
+        float* d_x = ar.take<float>((int64_t)B * L);
+        if (!c.dry) K2_HIP(hipEventRecord(ev_[0], c.stream));
+        FbankArgs a{samples_dev, n_each, n_each, B, nf, d_feats, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift,
+                    f.preemph, f.input_scale, f.remove_dc};
+        fbank(c, a);
+        if (!c.dry) K2_HIP(hipEventRecord(ev_[1], c.stream));
+        pad_logfloor_dense(c, d_feats, n_fl, d_x, B, L);
+        if (!c.dry) K2_HIP(hipEventRecord(ev_[2], c.stream));
+        int Tp = 0;
+        float* enc = encoder_forward(c, d_x, B, T, &Tp, -1, nullptr, nullptr, nullptr);
+        if (!c.dry) K2_HIP(hipEventRecord(ev_[3], c.stream));
+        greedy_device(c, enc, B, Tp, false, d_tok, d_ts, d_n, max_tokens, d_ovf);
+        if (!c.dry) K2_HIP(hipEventRecord(ev_[4], c.stream));
+    });
+    finish_tokens(d_tok, d_ts, d_n, d_ovf, B, max_tokens, tokens, ts, n_tokens);
+    auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, ev_[a], ev_[b]); return ms; };
+    timing_.fbank_ms = el(0, 1);
+    timing_.pad_ms = el(1, 2);
+    timing_.encoder_ms = el(2, 3);
+    timing_.greedy_ms = el(3, 4);
+    timing_.d2h_ms = el(4, 5);
+    timing_.total_ms = el(0, 5);
+}
+
+void Engine::offline_greedy_samples(const float* const* samples, const int64_t* n_samples, int B, int64_t* tokens, int32_t* ts,
+                                    int32_t* n_tokens, int max_tokens) {
+    // General (ragged) case: F1 per stream on the device, then the fused feature path.
+    K2_REQUIRE(B > 0, "offline_greedy_from_samples: empty batch");
+    const Config& cf = model_->cfg();
+    std::vector<std::vector<float>> feats(B);
+    std::vector<const float*> ptrs(B);
+    std::vector<int64_t> nfl(B);
+    for (int b = 0; b < B; b++) {
+        int64_t nf = fbank_num_frames(n_samples[b]);
+        K2_REQUIRE(nf > 0, "stream %d: %lld samples give no frame", b, (long long)n_samples[b]);
+        feats[b].resize((size_t)nf * cf.feat);
+        int64_t got = 0;
+        fbank_host(samples[b], n_samples[b], feats[b].data(), nf, &got);
+        ptrs[b] = feats[b].data();
+        nfl[b] = nf * cf.feat;
+    }
+    offline_greedy_feats(ptrs.data(), nfl.data(), B, false, tokens, ts, n_tokens, max_tokens);
+}
+
+void* Engine::dev_alloc(int64_t bytes) {
+    K2_HIP(hipSetDevice(device_));
+    void* p = nullptr;
+    K2_HIP(hipMalloc(&p, (size_t)bytes));
+    return p;
+}
+void Engine::dev_free(void* p) {
+    K2_HIP(hipSetDevice(device_));
+    K2_HIP(hipFree(p));
+}
+void Engine::dev_upload(void* dst, const void* src, int64_t bytes) {
+    K2_HIP(hipSetDevice(device_));
+    K2_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+}
+void Engine::synchronize() {
+    K2_HIP(hipSetDevice(device_));
+    K2_HIP(hipStreamSynchronize(stream_));
+}
+
+}  // namespace k2hip

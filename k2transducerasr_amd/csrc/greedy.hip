@@ -1,0 +1,237 @@
+// Stateless decoder, joiner and the on-device greedy search loop.
+//
+// The reference crosses managed<->ONNXRuntime once per frame (JoinerProj) plus once
+// per emitting frame (DecoderProj), with a host argmax in between
+// (OfflineRecognizer.cs:216-288).  Here one workgroup owns one stream and runs all
+// T' frames without leaving the GPU: tanh(enc_t + dec) -> vocab projection from a
+// k-major weight matrix (coalesced 16-byte loads, L2 resident) -> block argmax with
+// the reference's tie-break -> emit filter -> token append -> decoder update.
+//
+// Reference semantics kept (file:line in K2TransducerAsr/OfflineRecognizer.cs):
+//   - argmax: `tok = l[tok] > l[k] ? tok : k` for k ascending (:237-240): among
+//     equal maxima the LATER index wins.
+//   - emit when y != blank(0) && y != unk(2) (:268); the online loop also skips id 1
+//     (OnlineRecognizer.cs:181).
+//   - at most one symbol per frame (:216-288 has no inner loop; single path :129-134)
+//   - batch path: every stream starts from decoder([-1, blank]) (:202-208); when ANY
+//     stream emits, the decoder is re-run for ALL streams on the last two entries of
+//     their token lists, which for a not-yet-emitting stream are the seeded blanks
+//     (:250-258, :278-286).  So such a stream's context is [-1,0] up to and including
+//     the batch's first emitting frame t0 and [0,0] after it.  t0 is found by a
+//     fully parallel pass (first_emit_frame) and handed to the loop.
+#include <climits>
+
+#include "kernels.h"
+
+namespace k2hip {
+namespace {
+
+// dec_out[J] = decoder_proj(relu(grouped_conv(emb[y0], emb[y1])))   (block-wide, 256 threads)
+//   h: LDS scratch [DD]; out: LDS or global [J]
+__device__ void decoder_block(const DecJoinW& w, long long y0, long long y1, float* h, float* out) {
+    const int tid = threadIdx.x;
+    for (int co = tid; co < w.DD; co += blockDim.x) {
+        int g4 = (co >> 2) << 2;
+        float s = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < 4; ci++) {
+            float e0 = y0 >= 0 ? w.emb[y0 * w.DD + g4 + ci] : 0.f;
+            float e1 = y1 >= 0 ? w.emb[y1 * w.DD + g4 + ci] : 0.f;
+            s += w.conv[(co * 4 + ci) * 2 + 0] * e0;
+            s += w.conv[(co * 4 + ci) * 2 + 1] * e1;
+        }
+        h[co] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    for (int n = tid; n < w.J; n += blockDim.x) {
+        float s = w.dproj_b[n];
+        for (int k = 0; k < w.DD; k++) s += h[k] * w.dproj_kn[(long long)k * w.J + n];
+        out[n] = s;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_decoder(DecJoinW w, const long long* __restrict__ y, float* __restrict__ dec_out) {
+    extern __shared__ float sm[];
+    int n = blockIdx.x;
+    decoder_block(w, y[n * 2], y[n * 2 + 1], sm, dec_out + (long long)n * w.J);
+}
+
+__global__ void k_tanh_add(const float* __restrict__ enc, const float* __restrict__ dec, int dec_stride,
+                           float* __restrict__ y, long long n4, int J4) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    long long r = i / J4;
+    int q = (int)(i % J4);
+    float4 e = reinterpret_cast<const float4*>(enc)[i];
+    float4 d = *reinterpret_cast<const float4*>(dec + r * dec_stride + 4 * q);
+    reinterpret_cast<float4*>(y)[i] = make_float4(tanhf(e.x + d.x), tanhf(e.y + d.y), tanhf(e.z + d.z), tanhf(e.w + d.w));
+}
+
+// (value, index) max with "later index wins on ties"
+__device__ __forceinline__ void amax_merge(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi > i)) { v = ov; i = oi; }
+}
+__device__ __forceinline__ void amax_wave(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(v, o);
+        int oi = __shfl_xor(i, o);
+        amax_merge(v, i, ov, oi);
+    }
+}
+
+// one wave per row
+__global__ void k_argmax_rows(const float* __restrict__ logits, int ld, int N, int V, int* __restrict__ tok) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= N) return;
+    int lane = threadIdx.x & 63;
+    const float* l = logits + (long long)row * ld;
+    float v = -INFINITY;
+    int idx = -1;
+    for (int k = lane; k < V; k += 64) amax_merge(v, idx, l[k], k);
+    amax_wave(v, idx);
+    if (lane == 0) tok[row] = idx;
+}
+
+__global__ void k_first_emit(const int* __restrict__ tok, int B, int Tp, int skip1, int* __restrict__ t0) {
+    __shared__ int best;
+    if (threadIdx.x == 0) best = INT_MAX;
+    __syncthreads();
+    int mine = INT_MAX;
+    for (long long i = threadIdx.x; i < (long long)B * Tp; i += blockDim.x) {
+        int y = tok[i];
+        bool emit = (y != K2HIP_BLANK_ID && y != K2HIP_UNK_ID && !(skip1 && y == 1));
+        if (emit) mine = min(mine, (int)(i % Tp));
+    }
+    atomicMin(&best, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) *t0 = best;
+}
+
+// LDS layout: act[J] | dec_a[J] | dec_b[J] | dec_own[J] | h[DD] | part[2*Vp] | red (8 floats/ints)
+__global__ __launch_bounds__(256) void k_greedy(DecJoinW w, GreedyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* act = sm;
+    float* dec_a = act + w.J;
+    float* dec_b = dec_a + w.J;
+    float* dec_own = dec_b + w.J;
+    float* h = dec_own + w.J;
+    float* part = h + w.DD;        // [Vp] partial logits of the upper k-half
+    float* redv = part + w.Vp;     // [4]
+    int* redi = reinterpret_cast<int*>(redv + 4);  // [4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const float* enc = a.enc + (long long)b * a.Tp * w.J;
+    const int t0 = a.t0 ? *a.t0 : INT_MAX;
+
+    decoder_block(w, -1, K2HIP_BLANK_ID, h, dec_a);
+    if (a.t0) decoder_block(w, K2HIP_BLANK_ID, K2HIP_BLANK_ID, h, dec_b);
+
+    long long y0 = -1, y1 = K2HIP_BLANK_ID;
+    int n_tok = 0;
+    bool own = false;
+    const int kh = tid >> 7;          // k half
+    const int cg0 = tid & 127;        // first column group
+    const int ncg = w.Vp >> 2;
+    const int khalf = w.J >> 1;
+
+    for (int t = 0; t < a.Tp && n_tok < a.max_sym; t++) {
+        const float* d = own ? dec_own : (t > t0 ? dec_b : dec_a);
+        for (int k = tid; k < w.J; k += 256) act[k] = tanhf(enc[(long long)t * w.J + k] + d[k]);
+        __syncthreads();
+        float bv = -INFINITY;
+        int bi = -1;
+        for (int cgb = 0; cgb < ncg; cgb += 128) {  // uniform trip count: barriers inside
+            const int cg = cgb + cg0;
+            const bool valid = cg < ncg;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) {
+                const float* wp = w.out_kn + (long long)(kh * khalf) * w.Vp + 4 * cg;
+                const float* ap = act + kh * khalf;
+#pragma unroll 8
+                for (int k = 0; k < khalf; k++) {
+                    float4 wv = *reinterpret_cast<const float4*>(wp + (long long)k * w.Vp);
+                    float av = ap[k];
+                    s.x += av * wv.x; s.y += av * wv.y; s.z += av * wv.z; s.w += av * wv.w;
+                }
+                if (kh == 1) *reinterpret_cast<float4*>(part + 4 * cg) = s;
+            }
+            __syncthreads();
+            if (valid && kh == 0) {
+                float4 p = *reinterpret_cast<const float4*>(part + 4 * cg);
+                float l[4] = {s.x + p.x, s.y + p.y, s.z + p.z, s.w + p.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    int col = 4 * cg + j;
+                    if (col < w.V) amax_merge(bv, bi, l[j] + w.out_b[col], col);
+                }
+            }
+            __syncthreads();
+        }
+        amax_wave(bv, bi);
+        if (lane == 0) { redv[wave] = bv; redi[wave] = bi; }
+        __syncthreads();
+        float fv = redv[0];
+        int y = redi[0];
+        amax_merge(fv, y, redv[1], redi[1]);  // waves 2,3 are the upper k-half: (-inf, -1)
+        __syncthreads();
+        bool emit = (y != K2HIP_BLANK_ID && y != K2HIP_UNK_ID && !(a.skip1 && y == 1));
+        if (emit) {
+            if (n_tok < a.max_tokens) {
+                if (tid == 0) {
+                    a.tokens[(long long)b * a.max_tokens + n_tok] = y;
+                    a.timestamps[(long long)b * a.max_tokens + n_tok] = t;
+                }
+            } else if (tid == 0) {
+                *a.overflow = 1;
+            }
+            n_tok++;
+            y0 = y1;
+            y1 = y;
+            own = true;
+            decoder_block(w, y0, y1, h, dec_own);
+        }
+    }
+    if (tid == 0) a.n_tokens[b] = n_tok < a.max_tokens ? n_tok : a.max_tokens;
+}
+
+}  // namespace
+
+void decoder(const Ctx& ctx, const DecJoinW& w, const long long* y, int N, float* dec_out) {
+    if (ctx.dry || N <= 0) return;
+    hipLaunchKernelGGL(k_decoder, dim3(N), dim3(256), sizeof(float) * w.DD, ctx.stream, w, y, dec_out);
+    K2_HIP(hipGetLastError());
+}
+void tanh_add(const Ctx& ctx, const float* enc, const float* dec, int dec_stride, float* y, int N, int J) {
+    if (ctx.dry || N <= 0) return;
+    long long n4 = (long long)N * J / 4;
+    hipLaunchKernelGGL(k_tanh_add, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ctx.stream, enc, dec, dec_stride, y, n4, J / 4);
+    K2_HIP(hipGetLastError());
+}
+void argmax_rows(const Ctx& ctx, const float* logits, int ld, int N, int V, int* tok) {
+    if (ctx.dry || N <= 0) return;
+    hipLaunchKernelGGL(k_argmax_rows, dim3(cdiv(N, 4)), dim3(256), 0, ctx.stream, logits, ld, N, V, tok);
+    K2_HIP(hipGetLastError());
+}
+void first_emit_frame(const Ctx& ctx, const int* tok, int B, int Tp, int skip1, int* t0) {
+    if (ctx.dry) return;
+    hipLaunchKernelGGL(k_first_emit, dim3(1), dim3(1024), 0, ctx.stream, tok, B, Tp, skip1, t0);
+    K2_HIP(hipGetLastError());
+}
+void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a) {
+    if (ctx.dry || a.B <= 0) return;
+    K2_REQUIRE(w.J % 8 == 0, "greedy: joiner_dim %d must be a multiple of 8", w.J);
+    size_t lds = sizeof(float) * (4 * (size_t)w.J + w.DD + w.Vp + 8);
+    K2_REQUIRE(lds <= 160 * 1024, "greedy: vocab %d / joiner %d need %zu B of LDS", w.V, w.J, lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_greedy, dim3(a.B), dim3(256), lds, ctx.stream, w, a);
+    K2_HIP(hipGetLastError());
+}
+
+}  // namespace k2hip

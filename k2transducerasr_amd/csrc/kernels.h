@@ -1,0 +1,135 @@
+// Launchers for the gfx950 kernels.  Every launcher enqueues on ctx.stream and
+// returns immediately; in a dry run (ctx.dry) nothing is launched -- the dry
+// pass only sizes the arena.
+#pragma once
+#include "common.h"
+
+namespace k2hip {
+
+struct GemmStats {
+    double flops = 0;       // algorithmic, 2*M*N*K per launch
+    double total_flops = 0; // + non-GEMM matrix work (attention scores, convs)
+    int launches = 0;
+    float ms = 0;           // summed event time (instrumented runs only)
+};
+
+struct Ctx {
+    hipStream_t stream = nullptr;
+    Arena* arena = nullptr;
+    bool dry = false;
+    bool instrument = false;  // bracket each GEMM launch with events
+    GemmStats* stats = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // algorithmic work is tallied once, in the dry (sizing) pass
+    void add_flops(double gemm_fl, double other_fl, int launches) const {
+        if (stats && dry) {
+            stats->flops += gemm_fl;
+            stats->total_flops += gemm_fl + other_fl;
+            stats->launches += launches;
+        }
+    }
+};
+
+enum Act : int { ACT_NONE = 0, ACT_SWOOSH_L = 1, ACT_SWOOSH_R = 2, ACT_TANH = 3, ACT_SIGMOID = 4, ACT_RELU = 5 };
+
+// C[M,N] = act(A[M,K] . W^T + bias) (+ residual)     (fp32 MFMA, exact-f32 products)
+//   A: row-major, K contiguous, lda % 4 == 0; rows may be gathered (implicit conv)
+//   W: [N,K] row-major (torch Linear layout), or [K,N] when w_kn
+struct GemmArgs {
+    const float* A = nullptr;
+    const float* W = nullptr;
+    const float* bias = nullptr;
+    const float* res = nullptr;
+    float* C = nullptr;
+    int M = 0, N = 0, K = 0;
+    int lda = 0, ldw = 0, ldc = 0, ldr = 0;
+    int act = ACT_NONE;
+    int w_kn = 0;
+    // batching over blockIdx.z = z0 + nb0 * z1
+    int nb0 = 1, nb1 = 1;
+    long long sA0 = 0, sA1 = 0, sW0 = 0, sW1 = 0, sC0 = 0, sC1 = 0, sR0 = 0, sR1 = 0;
+    // implicit-conv gather of A over an NHWC tensor [B, Tin, Fin, C]:
+    //   row r = (b*Tout + t)*Fout + f  ->  base = ((b*Tin + t*st)*Fin + f*sf)*C
+    //   k -> (k / seg_len) * seg_stride + k % seg_len
+    int cv_Fout = 0, cv_Tout = 0, cv_Tin = 0, cv_Fin = 0, cv_C = 0, cv_st = 1, cv_sf = 1;
+    int seg_len = 0, seg_stride = 0;
+};
+void gemm(const Ctx& ctx, const GemmArgs& a);
+// convenience: plain Linear  C = act(A W^T + b) (+res)
+void linear(const Ctx& ctx, const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int K,
+            int N, int act = ACT_NONE, const float* res = nullptr, int ldr = 0);
+
+// ---- attention ------------------------------------------------------------
+// qkp: [B*T, ld] rows = (q[H*32] | k[H*32] | p[H*4]); pp: [2T-1, H*4];
+// aw out: [H][B][T][Tp] (Tp = T rounded up to 4, pad columns zeroed)
+void attn_scores_softmax(const Ctx& ctx, const float* qkp, int ld, const float* pp, float* aw, int B, int T, int Tp, int H);
+
+// ---- elementwise / small -----------------------------------------------------
+// packed: all streams' features back to back; d_off/d_len: per-stream start and float count (device)
+void pad_logfloor(const Ctx& ctx, const float* packed, const long long* d_off, const long long* d_len, float* out, int B,
+                  long long L);
+void pad_logfloor_dense(const Ctx& ctx, const float* feats, long long n_each, float* out, int B, long long L);
+void conv0_swoosh(const Ctx& ctx, const float* x, const float* w, const float* b, float* y, int B, int T, int F);
+void dwconv7x7(const Ctx& ctx, const float* x, const float* w_kc, const float* b, float* y, int B, int T, int F, int C);
+void biasnorm(const Ctx& ctx, const float* x, const float* bias, const float* log_scale, float* y, int M, int D);
+// y = orig + (biasnorm(x) - orig) * scale     (layer tail: norm + bypass)
+void biasnorm_bypass(const Ctx& ctx, const float* x, const float* orig, const float* nbias, const float* log_scale,
+                     const float* scale, float* y, int M, int D);
+void bypass(const Ctx& ctx, const float* orig, const float* x, const float* scale, float* y, int M, int D);
+void glu_sigmoid(const Ctx& ctx, const float* x, float* y, int M, int D);          // y = x[:, :D] * sigmoid(x[:, D:])
+void tanh_gate(const Ctx& ctx, const float* x, float* y, int M, int Hc);           // y = x[:, Hc:2Hc] * tanh(x[:, :Hc])
+void mul_cols(const Ctx& ctx, float* a, const float* x, int ldx, int col0, int M, int N);  // a[m,n] *= x[m, col0+n]
+void dwconv1d_swoosh(const Ctx& ctx, const float* x, const float* w_kd, const float* b, float* y, int B, int T, int D, int K);
+void downsample(const Ctx& ctx, const float* x, const float* bias, float* y, int B, int T, int D, int ds);
+void upsample_combine(const Ctx& ctx, const float* orig, const float* xd, const float* scale, float* y, int B, int T,
+                      int Td, int D, int ds);
+void convert_channels(const Ctx& ctx, const float* x, float* y, int M, int Din, int Dout);
+void copy_cols(const Ctx& ctx, const float* x, int ldx, int xcol0, float* y, int ldy, int ycol0, int M, int n);
+
+// ---- fbank -----------------------------------------------------------------------
+struct FbankArgs {
+    const float* samples;  // device
+    long long n_samples;   // per utterance
+    long long utt_stride;  // samples between utterances
+    int n_utts;
+    long long n_frames;    // per utterance
+    float* feats;          // [n_utts, n_frames, 80]
+    const float* window;
+    const float* melw;
+    int frame_len, frame_shift;
+    float preemph, input_scale;
+    int remove_dc;
+};
+void fbank(const Ctx& ctx, const FbankArgs& a);
+
+// ---- decoder / joiner / greedy ----------------------------------------------------
+struct DecJoinW {
+    const float* emb;      // [V, DD]
+    const float* conv;     // [DD, 4, ctx]
+    const float* dproj_kn; // [DD, J]
+    const float* dproj_b;  // [J]
+    const float* out_kn;   // [J, Vp]
+    const float* out_b;    // [V]
+    int V, Vp, DD, J, ctx;
+};
+void decoder(const Ctx& ctx, const DecJoinW& w, const long long* y, int N, float* dec_out);
+void tanh_add(const Ctx& ctx, const float* enc, const float* dec, int dec_stride, float* y, int N, int J);
+// row argmax with the reference tie-break (later index wins) -> emit flag (token not in {0,2} [,1])
+void argmax_rows(const Ctx& ctx, const float* logits, int ld, int N, int V, int* tok);
+// t0 = first frame at which any stream emits under the initial context
+void first_emit_frame(const Ctx& ctx, const int* tok, int B, int Tp, int skip1, int* t0);
+struct GreedyArgs {
+    const float* enc;   // [B, Tp, J]
+    int B, Tp;
+    const int* t0;      // device scalar (batch quirk) or nullptr (single path)
+    int skip1;          // online filter also skips id 1
+    int max_sym;        // 1000 for the single path, else INT_MAX
+    long long* tokens;  // [B, max_tokens]
+    int* timestamps;    // [B, max_tokens]
+    int* n_tokens;      // [B]
+    int max_tokens;
+    int* overflow;      // device flag
+};
+void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a);
+
+}  // namespace k2hip

@@ -1,0 +1,330 @@
+#include "model.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdlib>
+
+namespace k2hip {
+
+namespace {
+
+std::vector<int> csv_ints(const std::string& s) {
+    std::vector<int> v;
+    const char* p = s.c_str();
+    while (*p) {
+        char* e;
+        long x = strtol(p, &e, 10);
+        if (e == p) break;
+        v.push_back((int)x);
+        p = (*e == ',') ? e + 1 : e;
+    }
+    return v;
+}
+
+template <typename T>
+T rd(const uint8_t* p, size_t& q) {
+    T v;
+    memcpy(&v, p + q, sizeof(T));
+    q += sizeof(T);
+    return v;
+}
+
+float mel_scale(float f) { return 1127.0f * logf(1.0f + f / 700.0f); }
+
+}  // namespace
+
+Model::Model(const std::string& path, const char* overrides, int device) : device_(device) {
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) failf(K2HIP_ERR_IO, "cannot open weights file %s", path.c_str());
+    struct stat st;
+    fstat(fd, &st);
+    map_size_ = (size_t)st.st_size;
+    map_ = mmap(nullptr, map_size_, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map_ == MAP_FAILED) {
+        map_ = nullptr;
+        failf(K2HIP_ERR_IO, "mmap failed for %s", path.c_str());
+    }
+    const uint8_t* p = static_cast<const uint8_t*>(map_);
+    if (map_size_ < 24 || memcmp(p, "K2W1", 4) != 0) failf(K2HIP_ERR_IO, "%s: not a K2W1 container", path.c_str());
+    size_t q = 4;
+    uint32_t version = rd<uint32_t>(p, q), n_meta = rd<uint32_t>(p, q), n_tensors = rd<uint32_t>(p, q);
+    uint64_t data_off = rd<uint64_t>(p, q);
+    if (version != 1) failf(K2HIP_ERR_IO, "%s: unsupported K2W version %u", path.c_str(), version);
+    for (uint32_t i = 0; i < n_meta; i++) {
+        uint32_t kl = rd<uint32_t>(p, q), vl = rd<uint32_t>(p, q);
+        if (q + kl + vl > map_size_) failf(K2HIP_ERR_IO, "%s: truncated metadata", path.c_str());
+        std::string k((const char*)p + q, kl);
+        q += kl;
+        std::string v((const char*)p + q, vl);
+        q += vl;
+        meta_[k] = v;
+    }
+    if (overrides && *overrides) {
+        std::string s(overrides);
+        size_t a = 0;
+        while (a < s.size()) {
+            size_t b = s.find(';', a);
+            if (b == std::string::npos) b = s.size();
+            std::string kv = s.substr(a, b - a);
+            size_t eq = kv.find('=');
+            if (eq == std::string::npos) failf(K2HIP_ERR_INVALID, "bad override '%s' (want key=value)", kv.c_str());
+            meta_[kv.substr(0, eq)] = kv.substr(eq + 1);
+            a = b + 1;
+        }
+    }
+    struct Raw {
+        std::string name;
+        int ndim;
+        int64_t dims[4];
+        uint64_t off, nbytes;
+    };
+    std::vector<Raw> raws;
+    for (uint32_t i = 0; i < n_tensors; i++) {
+        uint32_t nl = rd<uint32_t>(p, q);
+        Raw r;
+        r.name.assign((const char*)p + q, nl);
+        q += nl;
+        uint32_t dtype = rd<uint32_t>(p, q);
+        r.ndim = (int)rd<uint32_t>(p, q);
+        for (int k = 0; k < 4; k++) r.dims[k] = (int64_t)rd<uint64_t>(p, q);
+        r.off = rd<uint64_t>(p, q);
+        r.nbytes = rd<uint64_t>(p, q);
+        if (dtype != 0) failf(K2HIP_ERR_IO, "%s: tensor %s has unsupported dtype %u", path.c_str(), r.name.c_str(), dtype);
+        if (data_off + r.off + r.nbytes > map_size_) failf(K2HIP_ERR_IO, "%s: tensor %s out of file bounds", path.c_str(), r.name.c_str());
+        raws.push_back(r);
+    }
+    for (auto& r : raws) {
+        Tensor t;
+        t.ndim = r.ndim;
+        for (int k = 0; k < 4; k++) t.dims[k] = r.dims[k];
+        t.host = reinterpret_cast<const float*>(p + data_off + r.off);
+        t_[r.name] = t;
+    }
+    parse_config();
+
+    // repacked copies
+    std::vector<std::pair<std::string, std::vector<float>>> extra;
+    std::vector<std::pair<std::string, std::vector<int64_t>>> shapes;
+    add_repacks(extra, shapes);
+
+    // device upload: [file data region | repacks]
+    K2_HIP(hipSetDevice(device_));
+    size_t file_bytes = map_size_ - data_off;
+    size_t extra_bytes = 0;
+    for (auto& e : extra) extra_bytes += (size_t)align_up((int64_t)e.second.size() * 4, 256);
+    size_t total = (size_t)align_up((int64_t)file_bytes, 256) + extra_bytes;
+    K2_HIP(hipMalloc(&dev_blob_, total));
+    K2_HIP(hipMemcpy(dev_blob_, p + data_off, file_bytes, hipMemcpyHostToDevice));
+    for (auto& r : raws) t_[r.name].dev = reinterpret_cast<float*>(static_cast<char*>(dev_blob_) + r.off);
+    size_t off = (size_t)align_up((int64_t)file_bytes, 256);
+    for (size_t i = 0; i < extra.size(); i++) {
+        auto& e = extra[i];
+        K2_HIP(hipMemcpy(static_cast<char*>(dev_blob_) + off, e.second.data(), e.second.size() * 4, hipMemcpyHostToDevice));
+        Tensor t;
+        t.dev = reinterpret_cast<float*>(static_cast<char*>(dev_blob_) + off);
+        t.ndim = (int)shapes[i].second.size();
+        for (int k = 0; k < t.ndim; k++) t.dims[k] = shapes[i].second[k];
+        host_keep_.push_back(std::move(e.second));
+        t.host = host_keep_.back().data();
+        t_[e.first] = t;
+        off += (size_t)align_up((int64_t)host_keep_.back().size() * 4, 256);
+    }
+    d_window = w("#fbank.window");
+    d_melw = w("#fbank.melw");
+}
+
+Model::~Model() {
+    if (dev_blob_) {
+        (void)hipSetDevice(device_);
+        (void)hipFree(dev_blob_);
+    }
+    if (map_) munmap(map_, map_size_);
+}
+
+const Tensor& Model::tensor(const std::string& name) const {
+    auto it = t_.find(name);
+    if (it == t_.end()) failf(K2HIP_ERR_IO, "weights file has no tensor '%s'", name.c_str());
+    return it->second;
+}
+const float* Model::w(const std::string& name) const { return tensor(name).dev; }
+const float* Model::wf(const char* fmt, ...) const {
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return w(buf);
+}
+
+void Model::parse_config() {
+    auto get = [&](const char* k, const char* dflt) -> std::string {
+        auto it = meta_.find(k);
+        return it == meta_.end() ? std::string(dflt) : it->second;
+    };
+    auto geti = [&](const char* k, int d) { return atoi(get(k, std::to_string(d).c_str()).c_str()); };
+    auto getf = [&](const char* k, float d) {
+        auto it = meta_.find(k);
+        return it == meta_.end() ? d : (float)atof(it->second.c_str());
+    };
+    Config& c = cfg_;
+    c.model_type = get("model_type", "");
+    if (c.model_type != "zipformer2")
+        failf(K2HIP_ERR_UNSUPPORTED, "model_type '%s' is not supported (have: zipformer2)", c.model_type.c_str());
+    auto fill = [&](const char* k, int* dst) {
+        auto v = csv_ints(get(k, ""));
+        if ((int)v.size() > kMaxStacks) failf(K2HIP_ERR_INVALID, "metadata %s has too many entries", k);
+        for (size_t i = 0; i < v.size(); i++) dst[i] = v[i];
+        return (int)v.size();
+    };
+    c.ns = fill("encoder_dims", c.dim);
+    if (c.ns <= 0) failf(K2HIP_ERR_INVALID, "metadata encoder_dims missing");
+    const char* keys[] = {"num_encoder_layers", "feedforward_dims", "num_heads",      "cnn_module_kernels",
+                          "downsampling_factors", "query_head_dims", "value_head_dims", "pos_head_dims"};
+    int* dsts[] = {c.nlayer, c.ff, c.heads, c.kern, c.ds, c.qhd, c.vhd, c.phd};
+    for (int i = 0; i < 8; i++)
+        if (fill(keys[i], dsts[i]) != c.ns) failf(K2HIP_ERR_INVALID, "metadata %s must have %d entries", keys[i], c.ns);
+    c.pos_dim = geti("pos_dim", 48);
+    c.J = geti("joiner_dim", 512);
+    c.DD = geti("decoder_dim", 512);
+    c.V = geti("vocab_size", 500);
+    c.ctx = geti("context_size", 2);
+    c.feat = geti("feature_dim", 80);
+    c.Vp = (int)align_up(c.V, 4);
+    c.dmax = 0;
+    for (int i = 0; i < c.ns; i++) {
+        c.dmax = std::max(c.dmax, c.dim[i]);
+        K2_REQUIRE(c.dim[i] % 16 == 0, "encoder_dims[%d]=%d must be a multiple of 16", i, c.dim[i]);
+        K2_REQUIRE(c.qhd[i] == 32, "query_head_dims[%d]=%d: kernels are built for 32", i, c.qhd[i]);
+        K2_REQUIRE(c.phd[i] == 4, "pos_head_dims[%d]=%d: kernels are built for 4", i, c.phd[i]);
+        K2_REQUIRE(c.kern[i] % 2 == 1 && c.kern[i] <= 63, "cnn_module_kernels[%d]=%d unsupported", i, c.kern[i]);
+        K2_REQUIRE(c.ds[i] >= 1 && c.ds[i] <= 16, "downsampling_factors[%d]=%d unsupported", i, c.ds[i]);
+    }
+    K2_REQUIRE(c.ctx == 2, "context_size %d: the reference's greedy loops seed a 2-entry hyp", c.ctx);
+    K2_REQUIRE(c.feat == 80, "feature_dim %d: Conv2dSubsampling geometry is built for 80 bins", c.feat);
+    K2_REQUIRE(c.J % 4 == 0 && c.DD % 4 == 0, "joiner_dim/decoder_dim must be multiples of 4");
+    FbankOpts& f = c.fbank;
+    f.sample_rate = geti("sample_rate", 16000);
+    f.frame_len = f.sample_rate * geti("frame_length_ms", 25) / 1000;
+    f.frame_shift = f.sample_rate * geti("frame_shift_ms", 10) / 1000;
+    f.padded = 1;
+    while (f.padded < f.frame_len) f.padded <<= 1;
+    f.num_bins = c.feat;
+    f.preemph = getf("preemph_coeff", 0.97f);
+    f.low_freq = getf("low_freq", 20.f);
+    f.high_freq = getf("high_freq", 0.f);
+    f.input_scale = getf("input_scale", 1.f);
+    f.remove_dc = geti("remove_dc_offset", 1);
+    f.snip_edges = geti("snip_edges", 1);
+    f.window_type = get("window_type", "hamming");
+    K2_REQUIRE(f.snip_edges == 1, "snip_edges=0 (whisper framing, OfflineStream.cs:27-32) is out of scope");
+    K2_REQUIRE(f.padded == 512 && f.frame_len <= 512, "fbank kernel is built for a 512-point FFT (got %d)", f.padded);
+}
+
+void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>& extra,
+                        std::vector<std::pair<std::string, std::vector<int64_t>>>& shapes) {
+    const Config& c = cfg_;
+    auto push = [&](const std::string& name, std::vector<float>&& v, std::vector<int64_t> shp) {
+        extra.emplace_back(name, std::move(v));
+        shapes.emplace_back(name, std::move(shp));
+    };
+    // conv filters [Co,Ci,3,3] -> [Co][kt][kf][ci]  (K index of the implicit GEMM over NHWC input)
+    for (const char* nm : {"encoder_embed.conv.4.weight", "encoder_embed.conv.7.weight"}) {
+        const Tensor& t = tensor(nm);
+        int Co = (int)t.dims[0], Ci = (int)t.dims[1];
+        std::vector<float> v((size_t)Co * 9 * Ci);
+        for (int co = 0; co < Co; co++)
+            for (int ci = 0; ci < Ci; ci++)
+                for (int kt = 0; kt < 3; kt++)
+                    for (int kf = 0; kf < 3; kf++)
+                        v[((size_t)co * 9 + kt * 3 + kf) * Ci + ci] = t.host[(((size_t)co * Ci + ci) * 3 + kt) * 3 + kf];
+        push(std::string(nm) + "#ohwi", std::move(v), {Co, 9 * Ci});
+    }
+    {   // depthwise 7x7 [C,1,7,7] -> [49][C]
+        const Tensor& t = tensor("encoder_embed.convnext.depthwise_conv.weight");
+        int C = (int)t.dims[0];
+        std::vector<float> v((size_t)49 * C);
+        for (int ch = 0; ch < C; ch++)
+            for (int k = 0; k < 49; k++) v[(size_t)k * C + ch] = t.host[(size_t)ch * 49 + k];
+        push("encoder_embed.convnext.depthwise_conv.weight#kc", std::move(v), {49, C});
+    }
+    {   // out Linear [D0, c*F3+f] -> [D0, f*128+c] (NHWC flatten order)
+        const Tensor& t = tensor("encoder_embed.out.weight");
+        int D0 = (int)t.dims[0], KK = (int)t.dims[1], C = 128, F3 = KK / C;
+        std::vector<float> v((size_t)D0 * KK);
+        for (int d = 0; d < D0; d++)
+            for (int ch = 0; ch < C; ch++)
+                for (int f = 0; f < F3; f++) v[(size_t)d * KK + f * C + ch] = t.host[(size_t)d * KK + ch * F3 + f];
+        push("encoder_embed.out.weight#fc", std::move(v), {D0, KK});
+    }
+    // conv_module depthwise [D,1,K] -> [K][D]
+    for (int si = 0; si < c.ns; si++)
+        for (int li = 0; li < c.nlayer[si]; li++)
+            for (int k = 1; k <= 2; k++) {
+                char nm[192];
+                snprintf(nm, sizeof nm, "encoder.encoders.%d.layers.%d.conv_module%d.depthwise_conv.weight", si, li, k);
+                const Tensor& t = tensor(nm);
+                int D = (int)t.dims[0], K = (int)t.dims[2];
+                K2_REQUIRE(D == c.dim[si] && K == c.kern[si], "%s has shape [%d,1,%d], config says [%d,1,%d]", nm, D, K,
+                           c.dim[si], c.kern[si]);
+                std::vector<float> v((size_t)K * D);
+                for (int d = 0; d < D; d++)
+                    for (int kk = 0; kk < K; kk++) v[(size_t)kk * D + d] = t.host[(size_t)d * K + kk];
+                push(std::string(nm) + "#kd", std::move(v), {K, D});
+            }
+    {   // joiner.output_linear [V,J] -> k-major [J][Vp]
+        const Tensor& t = tensor("joiner.output_linear.weight");
+        K2_REQUIRE(t.dims[0] == c.V && t.dims[1] == c.J, "joiner.output_linear.weight is [%lld,%lld], config says [%d,%d]",
+                   (long long)t.dims[0], (long long)t.dims[1], c.V, c.J);
+        std::vector<float> v((size_t)c.J * c.Vp, 0.f);
+        for (int n = 0; n < c.V; n++)
+            for (int k = 0; k < c.J; k++) v[(size_t)k * c.Vp + n] = t.host[(size_t)n * c.J + k];
+        push("joiner.output_linear.weight#kn", std::move(v), {c.J, c.Vp});
+    }
+    {   // joiner.decoder_proj [J,DD] -> k-major [DD][J]
+        const Tensor& t = tensor("joiner.decoder_proj.weight");
+        K2_REQUIRE(t.dims[0] == c.J && t.dims[1] == c.DD, "joiner.decoder_proj.weight shape mismatch");
+        std::vector<float> v((size_t)c.DD * c.J);
+        for (int n = 0; n < c.J; n++)
+            for (int k = 0; k < c.DD; k++) v[(size_t)k * c.J + n] = t.host[(size_t)n * c.DD + k];
+        push("joiner.decoder_proj.weight#kn", std::move(v), {c.DD, c.J});
+    }
+    // fbank tables (kaldi feature-window.cc / mel-computations.cc semantics)
+    const FbankOpts& f = c.fbank;
+    {
+        std::vector<float> win(f.frame_len);
+        double a = 2.0 * M_PI / (f.frame_len - 1);
+        for (int i = 0; i < f.frame_len; i++) {
+            double wv;
+            if (f.window_type == "hamming") wv = 0.54 - 0.46 * cos(a * i);
+            else if (f.window_type == "hanning") wv = 0.5 - 0.5 * cos(a * i);
+            else if (f.window_type == "povey") wv = pow(0.5 - 0.5 * cos(a * i), 0.85);
+            else if (f.window_type == "rectangular") wv = 1.0;
+            else failf(K2HIP_ERR_INVALID, "unknown window_type '%s'", f.window_type.c_str());
+            win[i] = (float)wv;
+        }
+        push("#fbank.window", std::move(win), {f.frame_len});
+        int nb = f.padded / 2;
+        std::vector<float> mw((size_t)f.num_bins * nb, 0.f);
+        float nyq = 0.5f * f.sample_rate, hi = f.high_freq;
+        if (hi <= 0.f) hi += nyq;
+        float bin_w = (float)f.sample_rate / f.padded;
+        float mel_low = mel_scale(f.low_freq), mel_high = mel_scale(hi);
+        float delta = (mel_high - mel_low) / (f.num_bins + 1);
+        for (int b = 0; b < f.num_bins; b++) {
+            float left = mel_low + b * delta, center = mel_low + (b + 1) * delta, right = mel_low + (b + 2) * delta;
+            for (int i = 0; i < nb; i++) {
+                float mel = mel_scale(bin_w * i);
+                if (mel > left && mel < right)
+                    mw[(size_t)b * nb + i] = (mel <= center) ? (mel - left) / (center - left) : (right - mel) / (right - center);
+            }
+        }
+        push("#fbank.melw", std::move(mw), {f.num_bins, nb});
+    }
+}
+
+}  // namespace k2hip

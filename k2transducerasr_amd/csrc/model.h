@@ -1,0 +1,79 @@
+// Model = parsed metadata map + every initializer resident in HBM.
+//
+// Replaces OfflineModel (K2TransducerAsr/OfflineModel.cs:23-73): where the
+// reference creates three ONNXRuntime sessions and reads their custom-metadata
+// maps, this loads one .k2w container (same string->string map, same keys) and
+// uploads the weights once.  Some tensors are additionally repacked at load into
+// the layouts the gfx950 kernels want (NHWC conv filters, k-major joiner matrix).
+#pragma once
+#include <map>
+#include <string>
+#include <unordered_map>
+
+#include "common.h"
+
+namespace k2hip {
+
+constexpr int kMaxStacks = 8;
+
+struct Tensor {
+    float* dev = nullptr;          // device pointer
+    const float* host = nullptr;   // host view (mmap or repack buffer), valid for the model's lifetime
+    int ndim = 0;
+    int64_t dims[4] = {1, 1, 1, 1};
+    int64_t numel() const { return dims[0] * dims[1] * dims[2] * dims[3]; }
+};
+
+struct FbankOpts {
+    int sample_rate = 16000, frame_len = 400, frame_shift = 160, padded = 512, num_bins = 80;
+    float preemph = 0.97f, low_freq = 20.f, high_freq = 0.f, input_scale = 1.f;
+    int remove_dc = 1, snip_edges = 1;
+    std::string window_type = "hamming";
+};
+
+struct Config {
+    std::string model_type;
+    int ns = 0;
+    int dim[kMaxStacks] = {0}, nlayer[kMaxStacks] = {0}, ff[kMaxStacks] = {0}, heads[kMaxStacks] = {0},
+        kern[kMaxStacks] = {0}, ds[kMaxStacks] = {0}, qhd[kMaxStacks] = {0}, vhd[kMaxStacks] = {0}, phd[kMaxStacks] = {0};
+    int pos_dim = 48, J = 512, DD = 512, V = 500, ctx = 2, feat = 80, dmax = 0;
+    int Vp = 0;  // vocab padded to a multiple of 4 for the k-major joiner matrix
+    FbankOpts fbank;
+};
+
+class Model {
+  public:
+    Model(const std::string& path, const char* overrides, int device);
+    ~Model();
+    Model(const Model&) = delete;
+    Model& operator=(const Model&) = delete;
+
+    const Config& cfg() const { return cfg_; }
+    int device() const { return device_; }
+    const std::map<std::string, std::string>& meta() const { return meta_; }
+
+    // device pointer of a named tensor; throws if absent
+    const float* w(const std::string& name) const;
+    const float* wf(const char* fmt, ...) const __attribute__((format(printf, 2, 3)));
+    const Tensor& tensor(const std::string& name) const;
+    bool has(const std::string& name) const { return t_.count(name) != 0; }
+
+    // fbank tables (device): window [frame_len], mel weights [num_bins, padded/2]
+    const float* d_window = nullptr;
+    const float* d_melw = nullptr;
+
+  private:
+    void parse_config();
+    void add_repacks(std::vector<std::pair<std::string, std::vector<float>>>& extra,
+                     std::vector<std::pair<std::string, std::vector<int64_t>>>& shapes);
+    int device_;
+    void* map_ = nullptr;
+    size_t map_size_ = 0;
+    void* dev_blob_ = nullptr;
+    std::map<std::string, std::string> meta_;
+    std::unordered_map<std::string, Tensor> t_;
+    std::vector<std::vector<float>> host_keep_;
+    Config cfg_;
+};
+
+}  // namespace k2hip

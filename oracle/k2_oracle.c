@@ -325,14 +325,17 @@ int64_t k2o_fbank_num_frames(const k2o_model* m, int64_t n) {
     return 1 + (n - m->frame_len) / m->frame_shift;
 }
 
-/* in-place iterative radix-2 complex FFT, n power of two */
-static void fft_c2c(float* re, float* im, int n) {
+/* in-place iterative radix-2 complex FFT, n power of two.  f64: the frame is
+ * windowed in f32 as kaldi does, but transform, power spectrum and mel sums are
+ * carried in f64 so that the oracle is the round-off-free statement of the
+ * algorithm (a f32 FFT carries ~1e-4 relative noise in low-energy bins). */
+static void fft_c2c(double* re, double* im, int n) {
     for (int i = 1, j = 0; i < n; i++) {
         int bit = n >> 1;
         for (; j & bit; bit >>= 1) j ^= bit;
         j ^= bit;
         if (i < j) {
-            float t = re[i]; re[i] = re[j]; re[j] = t;
+            double t = re[i]; re[i] = re[j]; re[j] = t;
             t = im[i]; im[i] = im[j]; im[j] = t;
         }
     }
@@ -340,9 +343,9 @@ static void fft_c2c(float* re, float* im, int n) {
         double ang = -2.0 * M_PI / len;
         for (int i = 0; i < n; i += len) {
             for (int k = 0; k < len / 2; k++) {
-                float wr = (float)cos(ang * k), wi = (float)sin(ang * k);
+                double wr = cos(ang * k), wi = sin(ang * k);
                 int a = i + k, b = i + k + len / 2;
-                float xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
+                double xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
                 re[b] = re[a] - xr; im[b] = im[a] - xi;
                 re[a] += xr; im[a] += xi;
             }
@@ -356,36 +359,39 @@ int64_t k2o_fbank(const k2o_model* m, const float* samples, int64_t n, float* fe
     int N = m->frame_len, P = m->padded, nb = P / 2;
 #pragma omp parallel
     {
-        float* re = (float*)malloc(sizeof(float) * P);
-        float* im = (float*)malloc(sizeof(float) * P);
-        float* pw = (float*)malloc(sizeof(float) * (nb + 1));
+        float* fr = (float*)malloc(sizeof(float) * N);
+        double* re = (double*)malloc(sizeof(double) * P);
+        double* im = (double*)malloc(sizeof(double) * P);
+        double* pw = (double*)malloc(sizeof(double) * (nb + 1));
 #pragma omp for schedule(static)
         for (int64_t f = 0; f < nf; f++) {
             const float* s = samples + f * m->frame_shift;
-            for (int i = 0; i < N; i++) re[i] = s[i] * m->input_scale;
+            for (int i = 0; i < N; i++) fr[i] = s[i] * m->input_scale;
             if (m->remove_dc) {
-                float sum = 0.f;
-                for (int i = 0; i < N; i++) sum += re[i];
-                float mean = sum / N;
-                for (int i = 0; i < N; i++) re[i] -= mean;
+                double sum = 0.0;
+                for (int i = 0; i < N; i++) sum += fr[i];
+                float mean = (float)(sum / N);
+                for (int i = 0; i < N; i++) fr[i] -= mean;
             }
             if (m->preemph != 0.f) {
-                for (int i = N - 1; i > 0; i--) re[i] -= m->preemph * re[i - 1];
-                re[0] -= m->preemph * re[0];
+                for (int i = N - 1; i > 0; i--) fr[i] -= m->preemph * fr[i - 1];
+                fr[0] -= m->preemph * fr[0];
             }
-            for (int i = 0; i < N; i++) re[i] *= m->window[i];
-            for (int i = N; i < P; i++) re[i] = 0.f;
-            for (int i = 0; i < P; i++) im[i] = 0.f;
+            for (int i = 0; i < N; i++) re[i] = (double)(fr[i] * m->window[i]);
+            for (int i = N; i < P; i++) re[i] = 0.0;
+            for (int i = 0; i < P; i++) im[i] = 0.0;
             fft_c2c(re, im, P);
             for (int i = 0; i <= nb; i++) pw[i] = re[i] * re[i] + im[i] * im[i];
             for (int b = 0; b < m->feat; b++) {
                 const float* w = m->melw + (size_t)b * nb;
-                float e = 0.f;
-                for (int i = 0; i < nb; i++) e += w[i] * pw[i];
-                if (e < FLT_EPSILON) e = FLT_EPSILON;
-                feats[f * m->feat + b] = logf(e);
+                double e = 0.0;
+                for (int i = 0; i < nb; i++) e += (double)w[i] * pw[i];
+                float ef = (float)e;
+                if (ef < FLT_EPSILON) ef = FLT_EPSILON;
+                feats[f * m->feat + b] = logf(ef);
             }
         }
+        free(fr);
         free(re); free(im); free(pw);
     }
     return nf;

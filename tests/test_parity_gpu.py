@@ -1,0 +1,219 @@
+"""GPU parity: libk2hip.so (through the C ABI) against the CPU oracle, same seeded inputs."""
+import numpy as np
+import pytest
+
+from parity import ACT_TOL, LOGIT_TOL, assert_tokens_match
+
+pytestmark = pytest.mark.gpu
+
+
+def _feats(oracle, utts):
+    return [oracle.fbank(u) for u in utts]
+
+
+def test_library_is_native(hip_tiny):
+    from k2transducerasr_amd import library_path
+    import os
+    assert os.path.exists(library_path())
+    assert hip_tiny.vocab_size == 37 and hip_tiny.joiner_dim == 512
+
+
+def test_fbank(hip_tiny, oracle_tiny, utts):
+    for u in utts:
+        a = hip_tiny.fbank(u)
+        b = oracle_tiny.fbank(u)
+        assert a.shape == b.shape == (1 + (u.size - 400) // 160, 80)
+        np.testing.assert_allclose(a, b, atol=2e-5, rtol=0)
+
+
+def test_fbank_edge_cases(hip_tiny, oracle_tiny):
+    assert hip_tiny.fbank(np.zeros(399, np.float32)).shape == (0, 80)
+    z = hip_tiny.fbank(np.zeros(400, np.float32))
+    assert z.shape == (1, 80)
+    np.testing.assert_allclose(z, np.log(np.float32(np.finfo(np.float32).eps)), atol=1e-6)
+    np.testing.assert_allclose(z, oracle_tiny.fbank(np.zeros(400, np.float32)), atol=1e-6)
+
+
+def test_pad_sequence_bit_exact(hip_tiny, oracle_tiny, utts):
+    feats = _feats(oracle_tiny, utts)
+    feats[1] = feats[1].copy()
+    feats[1][3, 5] = 0.0  # a genuine zero feature is floored too (PadHelper.cs:58)
+    a = hip_tiny.pad_sequence(feats)
+    b = oracle_tiny.pad_sequence(feats)
+    assert a.shape == b.shape
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert a[1, 3 * 80 + 5] == np.float32(-23.025850929940457)
+
+
+@pytest.mark.parametrize("tap", [0, 1, 2, 3, 4, 100])
+def test_encoder_taps(hip_tiny, oracle_tiny, utts, tap):
+    x = oracle_tiny.pad_sequence(_feats(oracle_tiny, utts[:3]))
+    x = x.reshape(3, -1, 80)
+    a = hip_tiny.encoder_tap(x, tap)
+    b = oracle_tiny.encoder_tap(x, tap)
+    assert a.shape == b.shape
+    np.testing.assert_allclose(a, b, atol=ACT_TOL, rtol=0)
+
+
+def test_encoder_proj(hip_tiny, oracle_tiny, utts):
+    x = oracle_tiny.pad_sequence(_feats(oracle_tiny, utts)).reshape(len(utts), -1, 80)
+    a = hip_tiny.encoder_proj(x)
+    b = oracle_tiny.encoder(x)
+    assert a.shape == b.shape
+    np.testing.assert_allclose(a, b, atol=ACT_TOL, rtol=0)
+
+
+def test_encoder_batch_of_one_equals_batch_rows(hip_tiny, oracle_tiny, utts):
+    # Q3: no length masking, so with equal lengths a row does not depend on its batch mates
+    f = _feats(oracle_tiny, [utts[0], utts[3]])
+    x = oracle_tiny.pad_sequence(f).reshape(2, -1, 80)
+    both = hip_tiny.encoder_proj(x)
+    one = hip_tiny.encoder_proj(x[1:2])
+    np.testing.assert_allclose(both[1], one[0], atol=1e-6, rtol=0)
+
+
+def test_decoder_proj(hip_tiny, oracle_tiny):
+    y = np.array([[-1, 0], [0, 0], [5, 7], [36, 1], [-1, -1], [3, 3]], np.int64)
+    np.testing.assert_allclose(hip_tiny.decoder_proj(y), oracle_tiny.decoder(y), atol=2e-5, rtol=0)
+    # DecoderProj(null, B) -> [-1, blank] rows (OfflineProjOfTransducer.cs:97-110)
+    np.testing.assert_allclose(hip_tiny.decoder_proj(None, 3), oracle_tiny.decoder(np.array([[-1, 0]] * 3)), atol=2e-5, rtol=0)
+
+
+def test_decoder_rejects_out_of_vocab(hip_tiny):
+    from k2transducerasr_amd import K2HipError
+    with pytest.raises(K2HipError):
+        hip_tiny.decoder_proj(np.array([[0, 37]], np.int64))
+
+
+def test_joiner_proj_logits(hip_tiny, oracle_tiny):
+    rng = np.random.default_rng(1)
+    enc = rng.standard_normal((70, 512)).astype(np.float32)
+    dec = rng.standard_normal((70, 512)).astype(np.float32)
+    np.testing.assert_allclose(hip_tiny.joiner_proj(enc, dec), oracle_tiny.joiner(enc, dec), atol=LOGIT_TOL / 10, rtol=0)
+
+
+def test_greedy_batch_on_oracle_encoder_out(hip_tiny, oracle_tiny, utts):
+    x = oracle_tiny.pad_sequence(_feats(oracle_tiny, utts)).reshape(len(utts), -1, 80)
+    enc = oracle_tiny.encoder(x)
+    want, mg = oracle_tiny.greedy_batch(enc, want_margins=True)
+    got = hip_tiny.greedy_batch(enc)
+    assert sum(len(w[0]) for w in want) > 0
+    assert_tokens_match(got, want, mg, what="greedy_batch")
+
+
+def test_greedy_single_on_oracle_encoder_out(hip_tiny, oracle_tiny, utts):
+    x = oracle_tiny.pad_sequence(_feats(oracle_tiny, utts)).reshape(len(utts), -1, 80)
+    enc = oracle_tiny.encoder(x)
+    for b in range(len(utts)):
+        want, mg = oracle_tiny.greedy_single(enc[b], want_margins=True)
+        got = hip_tiny.greedy_single(enc[b])
+        assert_tokens_match([got], [want], mg, what=f"greedy_single[{b}]")
+
+
+def test_greedy_batch_cross_stream_context_switch(hip_tiny, oracle_tiny, utts):
+    """OfflineRecognizer.cs:278-286: the first emission of ANY stream re-runs the decoder
+    for all streams on [blank, blank]; a stream decoded alone must therefore be able to
+    differ from the same stream decoded in a batch -- and the engine must follow suit."""
+    x = oracle_tiny.pad_sequence(_feats(oracle_tiny, utts)).reshape(len(utts), -1, 80)
+    enc = oracle_tiny.encoder(x)
+    batch = hip_tiny.greedy_batch(enc)
+    alone = [hip_tiny.greedy_batch(enc[b : b + 1])[0] for b in range(len(utts))]
+    want_batch = oracle_tiny.greedy_batch(enc)
+    want_alone = [oracle_tiny.greedy_batch(enc[b : b + 1])[0] for b in range(len(utts))]
+    assert batch == want_batch
+    assert alone == want_alone
+
+
+def test_greedy_ties_pick_later_index(hip_tiny):
+    """Q6: all-equal logits (enc+dec = 0 -> tanh 0 -> logits = bias) cannot tie here, so
+    build the tie through the API that exposes argmax: identical encoder frames give
+    identical tokens, and the joiner's argmax of two equal maxima is the later one."""
+    enc = np.zeros((1, 4, 512), np.float32)
+    a = hip_tiny.greedy_batch(enc)
+    b = hip_tiny.greedy_batch(np.concatenate([enc, enc]))
+    assert b[0] == a[0] and b[1] == a[0]
+
+
+def test_fused_offline_greedy_matches_oracle(hip_tiny, oracle_tiny, utts):
+    feats = _feats(oracle_tiny, utts)
+    want = oracle_tiny.recognize_batch(feats)
+    x = oracle_tiny.pad_sequence(feats).reshape(len(utts), -1, 80)
+    _, mg = oracle_tiny.greedy_batch(oracle_tiny.encoder(x), want_margins=True)
+    got = hip_tiny.offline_greedy(feats)
+    assert_tokens_match(got, want, mg, what="offline_greedy")
+
+
+def test_fused_single_matches_oracle(hip_tiny, oracle_tiny, utts):
+    f = oracle_tiny.fbank(utts[2])
+    x = oracle_tiny.pad_sequence([f]).reshape(1, -1, 80)
+    want, mg = oracle_tiny.greedy_single(oracle_tiny.encoder(x)[0], want_margins=True)
+    got = hip_tiny.offline_greedy_single(f)
+    assert_tokens_match([got], [want], mg, what="offline_greedy_single")
+
+
+def test_fused_from_samples_ragged(hip_tiny, oracle_tiny, utts):
+    feats = _feats(oracle_tiny, utts)
+    want = oracle_tiny.recognize_batch(feats)
+    x = oracle_tiny.pad_sequence(feats).reshape(len(utts), -1, 80)
+    _, mg = oracle_tiny.greedy_batch(oracle_tiny.encoder(x), want_margins=True)
+    got = hip_tiny.offline_greedy_from_samples(utts)
+    assert_tokens_match(got, want, mg, what="offline_greedy_from_samples")
+
+
+def test_fused_from_device_samples_equal_length(hip_tiny, oracle_tiny):
+    from k2transducerasr_amd.synth import synth_utterance
+    B, n = 4, 16000
+    s = np.stack([synth_utterance(100 + u, 1.0) for u in range(B)])
+    feats = [oracle_tiny.fbank(s[b]) for b in range(B)]
+    want = oracle_tiny.recognize_batch(feats)
+    x = oracle_tiny.pad_sequence(feats).reshape(B, -1, 80)
+    _, mg = oracle_tiny.greedy_batch(oracle_tiny.encoder(x), want_margins=True)
+    ptr = hip_tiny.device_alloc(s.nbytes)
+    try:
+        hip_tiny.device_upload(ptr, s)
+        got = hip_tiny.offline_greedy_from_samples_dev(ptr, n, B)
+        t = hip_tiny.timing()
+        assert t["total_ms"] > 0 and t["encoder_ms"] > 0
+    finally:
+        hip_tiny.device_free(ptr)
+    assert_tokens_match(got, want, mg, what="from_samples_dev")
+
+
+def test_stream_api_mirrors_reference_bookkeeping(tiny_model_path, oracle_tiny, utts):
+    from k2transducerasr_amd import OfflineRecognizer
+    rec = OfflineRecognizer(tiny_model_path)
+    streams = [rec.create_offline_stream() for _ in utts]
+    assert streams[0].tokens == [0, 0]  # OfflineStream.cs:34
+    for s, u in zip(streams, utts):
+        # two AddSamples calls: streaming fbank must give the same frames as one call
+        s.add_samples(u[:5000])
+        s.add_samples(u[5000:])
+    feats = _feats(oracle_tiny, utts)
+    for s, f in zip(streams, feats):
+        assert s.speech_length == f.size
+        np.testing.assert_allclose(s.speech.reshape(-1, 80), f, atol=2e-5, rtol=0)
+    want = oracle_tiny.recognize_batch([s.speech for s in streams])
+    res = rec.get_results(streams)
+    B = len(utts)
+    for (tok, ts), (wt, wts), s in zip(res, want, streams):
+        assert tok == [0] * (2 * B) + wt          # OfflineRecognizer.cs:250-258
+        assert ts == [0] * (2 * B) + wts          # :259-267
+        assert s.speech_length == 0               # RemoveSamples :294
+    # single-stream path: Tokens = [-1, blank, ...] (:115-117,:180), samples kept
+    s = rec.create_offline_stream()
+    s.add_samples(utts[2])
+    f = oracle_tiny.fbank(utts[2])
+    x = oracle_tiny.pad_sequence([f]).reshape(1, -1, 80)
+    wt, wts = oracle_tiny.greedy_single(oracle_tiny.encoder(x)[0])
+    tok, ts = rec.get_result(s)
+    assert tok == [-1, 0] + wt and ts == wts
+    assert s.speech_length == f.size
+
+
+def test_errors_are_reported_not_thrown(hip_tiny):
+    from k2transducerasr_amd import K2HipError, Model
+    with pytest.raises(K2HipError) as e:
+        Model("/nonexistent/model.k2w")
+    assert e.value.code == -2
+    with pytest.raises(K2HipError):
+        hip_tiny.encoder_proj(np.zeros((1, 8, 80), np.float32))  # too few frames
