@@ -277,7 +277,7 @@ void Engine::encoder_layer(const Ctx& c, int si, int li, float* x, const float* 
 }
 
 // Zipformer2.forward stacks; returns full-dim output [B*T50, Dmax]
-float* Engine::encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, float** tap_ptr, int* tap_dim) {
+float* Engine::encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, float** tap_ptr, int* tap_dim, bool* tapped) {
     const Model& m = *model_;
     const Config& cf = m.cfg();
     Arena& ar = *c.arena;
@@ -314,6 +314,7 @@ float* Engine::encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, 
         if (tap == 1 + si) {
             *tap_ptr = x;
             *tap_dim = D;
+            *tapped = true;
             return nullptr;
         }
     }
@@ -350,8 +351,9 @@ float* Engine::encoder_forward(const Ctx& c, const float* x, int B, int T, int* 
         *tap_dim = cf.dim[0];
         return nullptr;
     }
-    float* full = encoder_stacks(c, x0, B, T50, tap, tap_ptr, tap_dim);
-    if (!full) return nullptr;
+    bool tapped = false;  // NB: pointers are all null in a dry run, so never test them
+    float* full = encoder_stacks(c, x0, B, T50, tap, tap_ptr, tap_dim, &tapped);
+    if (tapped) return nullptr;
     if (tap == 100) {
         *tap_ptr = full;
         *tap_dim = cf.dmax;
@@ -498,8 +500,10 @@ void Engine::encoder_tap_host(const float* x, int B, int T, int tap, float* out,
         float* d_x = c.arena->take<float>((int64_t)B * T * feat);
         if (!c.dry) K2_HIP(hipMemcpyAsync(d_x, x, sizeof(float) * (size_t)B * T * feat, hipMemcpyHostToDevice, c.stream));
         int t2 = 0;
-        float* r = encoder_forward(c, d_x, B, T, &t2, tap, &tp, &rows, &dim);
-        K2_REQUIRE(r == nullptr, "encoder tap %d does not exist", tap);
+        tp = nullptr;
+        dim = 0;
+        encoder_forward(c, d_x, B, T, &t2, tap, &tp, &rows, &dim);
+        K2_REQUIRE(dim > 0, "encoder tap %d does not exist", tap);
     });
     int64_t cnt = (int64_t)rows * dim;
     if (cnt > cap) failf(K2HIP_ERR_CAPACITY, "tap needs %lld floats", (long long)cnt);

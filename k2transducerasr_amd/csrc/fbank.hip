@@ -1,12 +1,13 @@
 // F1: kaldi-style log-mel filterbank on gfx950 (replaces WavFrontend.GetFbank ->
 // SpeechFeatures.OnlineFbank.GetFbank, K2TransducerAsr/WavFrontend.cs:32-36).
 //
-// One workgroup (256 threads) per 25 ms frame: remove DC, pre-emphasis, window
-// (f32, as kaldi), 512-point radix-2 FFT in LDS, power spectrum, 80 triangular mel
-// filters, floor at FLT_EPSILON, log.  The FFT, power and mel sums run in f64: the
-// whole front-end is ~1.5 GFLOP per 32 x 10 s batch, so f64 costs nothing and it
-// removes the f32-FFT round-off (1e-4 relative in low-energy bins) that would
-// otherwise be the largest difference between two correct implementations.
+// One workgroup (256 threads) per 25 ms frame: remove DC, pre-emphasis, window,
+// 512-point radix-2 FFT in LDS, power spectrum, 80 triangular mel filters, floor at
+// FLT_EPSILON, log.  Everything up to the log runs in f64: the whole front-end is
+// ~1.5 GFLOP per 32 x 10 s batch, so f64 costs nothing, and it removes the f32
+// round-off (a one-ulp difference in pre-processing moves low-energy mel bins by
+// ~1e-4) that would otherwise be the largest difference between two correct
+// implementations of the same front-end.
 #include <cfloat>
 
 #include "kernels.h"
@@ -25,30 +26,31 @@ __global__ __launch_bounds__(256) void k_fbank(FbankArgs a, const double2* __res
     const float* s = a.samples + (long long)u * a.utt_stride + f * a.frame_shift;
     const int N = a.frame_len;
 
-    // two samples per thread: i0 = tid, i1 = tid + 256
-    float x0 = 0.f, x1 = 0.f, p0 = 0.f, p1 = 0.f;  // p = previous sample (for pre-emphasis)
+    // two samples per thread: i0 = tid, i1 = tid + 256 (p = previous sample, for pre-emphasis)
+    double x0 = 0.0, x1 = 0.0, p0 = 0.0, p1 = 0.0;
+    const double scale = (double)a.input_scale;
     int i0 = tid, i1 = tid + 256;
-    if (i0 < N) { x0 = s[i0] * a.input_scale; p0 = s[i0 > 0 ? i0 - 1 : 0] * a.input_scale; }
-    if (i1 < N) { x1 = s[i1] * a.input_scale; p1 = s[i1 - 1] * a.input_scale; }
+    if (i0 < N) { x0 = (double)s[i0] * scale; p0 = (double)s[i0 > 0 ? i0 - 1 : 0] * scale; }
+    if (i1 < N) { x1 = (double)s[i1] * scale; p1 = (double)s[i1 - 1] * scale; }
     if (a.remove_dc) {
-        double part = (double)x0 + (double)x1;
+        double part = x0 + x1;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
         if (lane == 0) red[wave] = part;
         __syncthreads();
-        float mean = (float)((red[0] + red[1] + red[2] + red[3]) / (double)N);
+        double mean = (red[0] + red[1] + red[2] + red[3]) / (double)N;
         x0 -= mean; x1 -= mean; p0 -= mean; p1 -= mean;
     }
     if (a.preemph != 0.f) {
         // kaldi: w[i] -= c*w[i-1] (i = N-1..1), w[0] -= c*w[0]
-        x0 = x0 - a.preemph * p0;
-        x1 = x1 - a.preemph * p1;
+        x0 = x0 - (double)a.preemph * p0;
+        x1 = x1 - (double)a.preemph * p1;
     }
-    if (i0 < N) x0 *= a.window[i0]; else x0 = 0.f;
-    if (i1 < N) x1 *= a.window[i1]; else x1 = 0.f;
+    if (i0 < N) x0 *= (double)a.window[i0]; else x0 = 0.0;
+    if (i1 < N) x1 *= (double)a.window[i1]; else x1 = 0.0;
     // bit-reversed scatter
-    re[__brev((unsigned)i0) >> (32 - LOG2N)] = (double)x0;
-    re[__brev((unsigned)i1) >> (32 - LOG2N)] = (double)x1;
+    re[__brev((unsigned)i0) >> (32 - LOG2N)] = x0;
+    re[__brev((unsigned)i1) >> (32 - LOG2N)] = x1;
     im[i0] = 0.0;
     im[i1] = 0.0;
     __syncthreads();

@@ -33,7 +33,8 @@ T rd(const uint8_t* p, size_t& q) {
     return v;
 }
 
-float mel_scale(float f) { return 1127.0f * logf(1.0f + f / 700.0f); }
+// MelScale in f64 (rounded once to f32 below): see add_repacks
+double mel_scale(double f) { return 1127.0 * log(1.0 + f / 700.0); }
 
 }  // namespace
 
@@ -310,17 +311,19 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
         push("#fbank.window", std::move(win), {f.frame_len});
         int nb = f.padded / 2;
         std::vector<float> mw((size_t)f.num_bins * nb, 0.f);
-        float nyq = 0.5f * f.sample_rate, hi = f.high_freq;
-        if (hi <= 0.f) hi += nyq;
-        float bin_w = (float)f.sample_rate / f.padded;
-        float mel_low = mel_scale(f.low_freq), mel_high = mel_scale(hi);
-        float delta = (mel_high - mel_low) / (f.num_bins + 1);
+        // kaldi mel-computations.cc triangles, evaluated in f64: mel - left cancels ~4
+        // digits in f32, which would make the table depend on contraction choices.
+        double nyq = 0.5 * f.sample_rate, hi = f.high_freq;
+        if (hi <= 0.0) hi += nyq;
+        double bin_w = (double)f.sample_rate / f.padded;
+        double mel_low = mel_scale(f.low_freq), mel_high = mel_scale(hi);
+        double delta = (mel_high - mel_low) / (f.num_bins + 1);
         for (int b = 0; b < f.num_bins; b++) {
-            float left = mel_low + b * delta, center = mel_low + (b + 1) * delta, right = mel_low + (b + 2) * delta;
+            double left = mel_low + b * delta, center = mel_low + (b + 1) * delta, right = mel_low + (b + 2) * delta;
             for (int i = 0; i < nb; i++) {
-                float mel = mel_scale(bin_w * i);
+                double mel = mel_scale(bin_w * i);
                 if (mel > left && mel < right)
-                    mw[(size_t)b * nb + i] = (mel <= center) ? (mel - left) / (center - left) : (right - mel) / (right - center);
+                    mw[(size_t)b * nb + i] = (float)((mel <= center) ? (mel - left) / (center - left) : (right - mel) / (right - center));
             }
         }
         push("#fbank.melw", std::move(mw), {f.num_bins, nb});

@@ -25,11 +25,23 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _cap_omp_threads():
+    """The GPU box shows all host cores but gives this job a share of them; an
+    uncapped OpenMP team oversubscribes and every parallel region crawls."""
+    if "OMP_NUM_THREADS" not in os.environ:
+        try:
+            n = len(os.sched_getaffinity(0))
+        except AttributeError:
+            n = os.cpu_count() or 1
+        os.environ["OMP_NUM_THREADS"] = str(max(1, min(n, 16)))
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_SO):
             build()
+        _cap_omp_threads()
         L = C.CDLL(_SO)
         fp, ip, lp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
         L.k2o_model_load.restype = C.c_void_p

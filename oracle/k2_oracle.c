@@ -285,7 +285,11 @@ void k2o_model_free(k2o_model* m) {
 /* published kaldi / kaldi-native-fbank algorithm (feature-window.cc,         */
 /* mel-computations.cc, feature-fbank.cc) with its defaults.                  */
 /* ------------------------------------------------------------------------- */
-static float mel_scale(float f) { return 1127.0f * logf(1.0f + f / 700.0f); }
+/* kaldi MelBanks uses MelScale(f) = 1127 ln(1 + f/700) and triangular filters in the
+ * mel domain.  Evaluated in f64 and rounded once to f32: in f32 the subtraction
+ * mel - left cancels ~4 digits, so the weights would depend on the compiler's
+ * contraction choices at the 1e-6 level. */
+static double mel_scale(double f) { return 1127.0 * log(1.0 + f / 700.0); }
 
 static void build_fbank_tables(k2o_model* m) {
     int N = m->frame_len;
@@ -302,19 +306,19 @@ static void build_fbank_tables(k2o_model* m) {
     }
     int nb = m->padded / 2;
     m->melw = (float*)calloc((size_t)m->feat * nb, sizeof(float));
-    float nyq = 0.5f * m->sample_rate;
-    float hi = m->high_freq;
-    if (hi <= 0.f) hi += nyq;
-    float fft_bin_width = (float)m->sample_rate / m->padded;
-    float mel_low = mel_scale(m->low_freq), mel_high = mel_scale(hi);
-    float delta = (mel_high - mel_low) / (m->feat + 1);
+    double nyq = 0.5 * m->sample_rate;
+    double hi = m->high_freq;
+    if (hi <= 0.0) hi += nyq;
+    double fft_bin_width = (double)m->sample_rate / m->padded;
+    double mel_low = mel_scale(m->low_freq), mel_high = mel_scale(hi);
+    double delta = (mel_high - mel_low) / (m->feat + 1);
     for (int b = 0; b < m->feat; b++) {
-        float left = mel_low + b * delta, center = mel_low + (b + 1) * delta, right = mel_low + (b + 2) * delta;
+        double left = mel_low + b * delta, center = mel_low + (b + 1) * delta, right = mel_low + (b + 2) * delta;
         for (int i = 0; i < nb; i++) {
-            float mel = mel_scale(fft_bin_width * i);
+            double mel = mel_scale(fft_bin_width * i);
             if (mel > left && mel < right) {
-                float w = (mel <= center) ? (mel - left) / (center - left) : (right - mel) / (right - center);
-                m->melw[(size_t)b * nb + i] = w;
+                double w = (mel <= center) ? (mel - left) / (center - left) : (right - mel) / (right - center);
+                m->melw[(size_t)b * nb + i] = (float)w;
             }
         }
     }
@@ -359,25 +363,25 @@ int64_t k2o_fbank(const k2o_model* m, const float* samples, int64_t n, float* fe
     int N = m->frame_len, P = m->padded, nb = P / 2;
 #pragma omp parallel
     {
-        float* fr = (float*)malloc(sizeof(float) * N);
         double* re = (double*)malloc(sizeof(double) * P);
         double* im = (double*)malloc(sizeof(double) * P);
         double* pw = (double*)malloc(sizeof(double) * (nb + 1));
 #pragma omp for schedule(static)
         for (int64_t f = 0; f < nf; f++) {
             const float* s = samples + f * m->frame_shift;
-            for (int i = 0; i < N; i++) fr[i] = s[i] * m->input_scale;
+            /* kaldi ProcessWindow order (remove DC, pre-emphasis, window), carried in f64 */
+            for (int i = 0; i < N; i++) re[i] = (double)s[i] * (double)m->input_scale;
             if (m->remove_dc) {
                 double sum = 0.0;
-                for (int i = 0; i < N; i++) sum += fr[i];
-                float mean = (float)(sum / N);
-                for (int i = 0; i < N; i++) fr[i] -= mean;
+                for (int i = 0; i < N; i++) sum += re[i];
+                double mean = sum / N;
+                for (int i = 0; i < N; i++) re[i] -= mean;
             }
             if (m->preemph != 0.f) {
-                for (int i = N - 1; i > 0; i--) fr[i] -= m->preemph * fr[i - 1];
-                fr[0] -= m->preemph * fr[0];
+                for (int i = N - 1; i > 0; i--) re[i] -= (double)m->preemph * re[i - 1];
+                re[0] -= (double)m->preemph * re[0];
             }
-            for (int i = 0; i < N; i++) re[i] = (double)(fr[i] * m->window[i]);
+            for (int i = 0; i < N; i++) re[i] *= (double)m->window[i];
             for (int i = N; i < P; i++) re[i] = 0.0;
             for (int i = 0; i < P; i++) im[i] = 0.0;
             fft_c2c(re, im, P);
@@ -391,7 +395,6 @@ int64_t k2o_fbank(const k2o_model* m, const float* samples, int64_t n, float* fe
                 feats[f * m->feat + b] = logf(ef);
             }
         }
-        free(fr);
         free(re); free(im); free(pw);
     }
     return nf;
