@@ -18,8 +18,6 @@ Engine::Engine(const std::string& weights, const char* overrides, int device) : 
     model_.reset(new Model(weights, overrides, device));
     K2_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     for (auto& e : ev_) K2_HIP(hipEventCreate(&e));
-    K2_HIP(hipEventCreate(&gev0_));
-    K2_HIP(hipEventCreate(&gev1_));
 }
 
 Engine::~Engine() {
@@ -28,8 +26,7 @@ Engine::~Engine() {
     for (auto& kv : pe_cache_) (void)hipFree(kv.second);
     for (auto& e : ev_)
         if (e) (void)hipEventDestroy(e);
-    if (gev0_) (void)hipEventDestroy(gev0_);
-    if (gev1_) (void)hipEventDestroy(gev1_);
+    for (auto& e : evpool_) (void)hipEventDestroy(e);
     if (pin_) (void)hipHostFree(pin_);
     arena_.release();
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -53,8 +50,8 @@ Ctx Engine::make_ctx(bool dry) {
     c.dry = dry;
     c.instrument = instrument_ && !dry;
     c.stats = &stats_;
-    c.ev0 = gev0_;
-    c.ev1 = gev1_;
+    c.evpool = &evpool_;
+    c.evused = &evused_;
     return c;
 }
 
@@ -80,7 +77,16 @@ void Engine::run_sized(F&& body) {
         arena_.reserve(need + need / 8);
     }
     Ctx c = make_ctx(false);
+    evused_ = 0;
     body(c);
+    if (instrument_) {
+        K2_HIP(hipStreamSynchronize(stream_));
+        for (int i = 0; i + 1 < evused_; i += 2) {
+            float ms = 0;
+            K2_HIP(hipEventElapsedTime(&ms, evpool_[i], evpool_[i + 1]));
+            stats_.ms += ms;
+        }
+    }
     timing_.gemm_ms = stats_.ms;
     timing_.gemm_launches = stats_.launches;
     timing_.gemm_flops = stats_.flops;

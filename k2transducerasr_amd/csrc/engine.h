@@ -81,7 +81,8 @@ class Engine {
     GemmStats stats_;
     k2hip_timing timing_{};
     hipEvent_t ev_[8] = {nullptr};
-    hipEvent_t gev0_ = nullptr, gev1_ = nullptr;
+    std::vector<hipEvent_t> evpool_;
+    int evused_ = 0;
     // pinned staging for results
     void* pin_ = nullptr;
     int64_t pin_cap_ = 0;

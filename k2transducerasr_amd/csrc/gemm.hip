@@ -227,19 +227,13 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     const double fl = 2.0 * a.M * (double)a.N * a.K * a.nb0 * a.nb1;
     ctx.add_flops(fl, 0.0, 1);
     if (ctx.dry) return;
-    if (ctx.instrument) K2_HIP(hipEventRecord(ctx.ev0, ctx.stream));
+    if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
     // tile choice: big tiles when they still give every CU >= 2 workgroups
     long long blocks128 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.nb0 * a.nb1;
     if (a.N > 64 && blocks128 >= 512) launch<128, 128, 64, 64>(ctx, a);
     else launch<64, 64, 32, 32>(ctx, a);
     K2_HIP(hipGetLastError());
-    if (ctx.instrument) {
-        K2_HIP(hipEventRecord(ctx.ev1, ctx.stream));
-        K2_HIP(hipEventSynchronize(ctx.ev1));
-        float ms = 0;
-        K2_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
-        if (ctx.stats) ctx.stats->ms += ms;
-    }
+    if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
 }
 
 void linear(const Ctx& ctx, const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int K,

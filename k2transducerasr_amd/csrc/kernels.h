@@ -19,7 +19,19 @@ struct Ctx {
     bool dry = false;
     bool instrument = false;  // bracket each GEMM launch with events
     GemmStats* stats = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // instrumented runs: each GEMM launch records a (start, stop) pair from this pool
+    // WITHOUT synchronising; the engine reads the pairs after the call has drained,
+    // so the launches run back to back exactly as in an un-instrumented call.
+    std::vector<hipEvent_t>* evpool = nullptr;
+    int* evused = nullptr;
+    hipEvent_t next_event() const {
+        if ((size_t)*evused == evpool->size()) {
+            hipEvent_t e;
+            K2_HIP(hipEventCreate(&e));
+            evpool->push_back(e);
+        }
+        return (*evpool)[(*evused)++];
+    }
     // algorithmic work is tallied once, in the dry (sizing) pass
     void add_flops(double gemm_fl, double other_fl, int launches) const {
         if (stats && dry) {
