@@ -134,12 +134,9 @@ def main():
     model.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
+    from k2transducerasr_amd.shard import max_over_ranks
 
-        t = torch.tensor([elapsed], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(dist, elapsed, device="cuda" if dist is not None else None)
     stages = model.timing()
 
     # roofline of the dominant kernel (fp32 MFMA GEMM): one extra instrumented pass

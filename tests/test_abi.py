@@ -1,0 +1,90 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/k2hip.h declares, and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "k2hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(k2hip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_surface():
+    syms = declared_symbols()
+    for s in ("k2hip_model_create", "k2hip_fbank", "k2hip_pad_sequence", "k2hip_offline_encoder", "k2hip_decoder",
+              "k2hip_joiner", "k2hip_offline_greedy", "k2hip_offline_greedy_single", "k2hip_offline_greedy_from_samples",
+              "k2hip_offline_stream_accept_samples", "k2hip_offline_recognizer_get_results", "k2hip_last_error",
+              "k2hip_get_timing"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from k2transducerasr_amd import library_path, load_library
+    load_library()
+    lib = ctypes.CDLL(library_path())
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, f"declared in include/k2hip.h but not exported: {missing}"
+
+
+def test_every_header_entry_cites_the_reference():
+    src = open(os.path.join(ROOT, "include", "k2hip.h")).read()
+    assert len(re.findall(r"\.cs:\d+", src)) >= 15
+
+
+def test_version_and_error_strings():
+    from k2transducerasr_amd import load_library
+    L = load_library()
+    assert L.k2hip_version().decode().startswith("k2hip")
+    assert isinstance(L.k2hip_last_error(), bytes)
+
+
+def test_no_cpu_fallback(tiny_model_path):
+    """Without a HIP device model creation must fail loudly (K2HIP_ERR_NO_DEVICE)."""
+    from k2transducerasr_amd import K2HipError, Model, load_library
+    if load_library().k2hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(K2HipError) as e:
+        Model(tiny_model_path, 0)
+    assert e.value.code == -3 and "no CPU fallback" in str(e.value)
+
+
+def test_null_arguments_are_errors_not_crashes():
+    from k2transducerasr_amd import load_library
+    L = load_library()
+    assert L.k2hip_model_create(None, None, 0, None) == -1
+    assert L.k2hip_fbank(None, None, 0, None, 0, None) == -1
+    assert L.k2hip_offline_greedy(None, None, None, 0, None, None, None, 0) == -1
+    assert b"null argument" in L.k2hip_last_error()
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under k2transducerasr_amd/ may import,
+    link or load it."""
+    pkg = os.path.join(ROOT, "k2transducerasr_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "k2_oracle" not in txt and "libk2oracle" not in txt, f
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_k2w_roundtrip(tmp_path):
+    import numpy as np
+    from k2transducerasr_amd.k2w import read_k2w, write_k2w
+    rng = np.random.default_rng(0)
+    tensors = [("a.weight", rng.standard_normal((3, 5)).astype(np.float32)), ("b", np.arange(7, dtype=np.float32)),
+               ("c.d", rng.standard_normal((2, 1, 3, 3)).astype(np.float32))]
+    meta = {"model_type": "zipformer2", "encoder_dims": "1,2,3", "comment": ""}
+    p = str(tmp_path / "x.k2w")
+    write_k2w(p, meta, tensors)
+    m2, t2 = read_k2w(p)
+    assert m2 == meta
+    for n, a in tensors:
+        np.testing.assert_array_equal(t2[n], a)

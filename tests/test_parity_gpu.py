@@ -217,3 +217,47 @@ def test_errors_are_reported_not_thrown(hip_tiny):
     assert e.value.code == -2
     with pytest.raises(K2HipError):
         hip_tiny.encoder_proj(np.zeros((1, 8, 80), np.float32))  # too few frames
+
+
+# ---- hand-derived greedy known-answer tests, through the HIP engine -----------------
+@pytest.fixture(scope="module")
+def kat_hip(tmp_path_factory):
+    from k2transducerasr_amd import Model
+    from kat_model import write_kat_model
+    p = str(tmp_path_factory.mktemp("kat") / "kat.k2w")
+    write_kat_model(p)
+    return Model(p, 0)
+
+
+def test_kat_decoder_by_hand(kat_hip):
+    d = kat_hip.decoder_proj(np.array([[-1, 0], [0, 0], [0, 4], [4, 3], [-1, -1]], np.int64))
+    np.testing.assert_allclose(d[:, 3], [0.05, 0.1, 0.45, 0.7, 0.0], rtol=1e-6)  # Q9: id < 0 -> zero embedding
+    assert (np.delete(d, 3, axis=1) == 0).all()
+
+
+def test_greedy_known_answers(kat_hip):
+    from kat_model import CASES
+    for name, case in sorted(CASES.items()):
+        enc = np.stack(case["streams"])
+        assert kat_hip.greedy_batch(enc) == case["batch"], name
+        for b, s in enumerate(case["streams"]):
+            assert kat_hip.greedy_single(s) == case["single"][b], name
+
+
+def test_greedy_single_max_symbols(kat_hip):
+    from kat_model import frames
+    enc = frames([{5: 1.0}] * 1003)
+    tok, ts = kat_hip.greedy_single(enc)
+    assert len(tok) == 1000 and ts == list(range(1000))  # max_sym_per_utt (OfflineRecognizer.cs:122)
+    assert len(kat_hip.greedy_batch(enc[None])[0][0]) == 1003
+
+
+def test_hip_matches_committed_golden(hip_tiny):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_golden.npz"))
+    np.testing.assert_allclose(hip_tiny.fbank(g["samples"]), g["fbank"], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(hip_tiny.encoder_proj(g["x"]), g["encoder_out"], atol=ACT_TOL, rtol=0)
+    np.testing.assert_allclose(hip_tiny.decoder_proj(g["y"]), g["decoder_out"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(hip_tiny.joiner_proj(g["encoder_out"][0, :6], g["decoder_out"][:6]), g["logits"], atol=1e-4, rtol=0)
+    want = [(g[f"tok{b}"].tolist(), g[f"ts{b}"].tolist()) for b in range(g["x"].shape[0])]
+    assert hip_tiny.greedy_batch(g["encoder_out"]) == want
