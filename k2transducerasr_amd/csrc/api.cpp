@@ -271,6 +271,18 @@ int32_t k2hip_synchronize(k2hip_model_t* model) {
     });
 }
 
+// ---- tuning hook (not part of include/k2hip.h): time one GEMM shape/config on random data
+__attribute__((visibility("default"))) int32_t k2hip_debug_gemm(k2hip_model_t* model, int32_t M, int32_t N, int32_t K,
+                                                                 int32_t act, int32_t with_res, int32_t cfg, int32_t iters, float* ms) {
+    return guard([&] {
+        NEED(model); NEED(ms);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        debug_force_gemm_cfg(cfg);
+        *ms = model->engine.debug_gemm(M, N, K, act, with_res != 0, iters);
+        debug_force_gemm_cfg(-1);
+    });
+}
+
 // ---- OfflineStream ---------------------------------------------------------------
 int32_t k2hip_offline_stream_create(k2hip_model_t* model, k2hip_offline_stream_t** out) {
     return guard([&] {

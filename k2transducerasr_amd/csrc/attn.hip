@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_attn_scores_softmax(const float* __rest
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         float sum = 0.f;
         for (int j = lane; j < T; j += 64) {
-            float e = expf(srow[j] - mx);
+            float e = __expf(srow[j] - mx);
             srow[j] = e;
             sum += e;
         }

@@ -9,8 +9,14 @@ namespace {
 
 constexpr float kLogFloor = -23.025850929940457F;  // PadHelper.cs:58
 
-__device__ __forceinline__ float logaddexp0(float z) { return fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))); }
-__device__ __forceinline__ float swoosh_r(float v) { return logaddexp0(v - 1.0f) - 0.08f * v - 0.313261687f; }
+// hardware exp/log (v_exp_f32 / v_log_f32), ~1e-6 relative -- see gemm.hip apply_act
+__device__ __forceinline__ float fast_softplus(float z) { return z > 15.f ? z : __logf(1.0f + __expf(z)); }
+__device__ __forceinline__ float swoosh_r(float v) { return fast_softplus(v - 1.0f) - 0.08f * v - 0.313261687f; }
+__device__ __forceinline__ float fast_tanh(float v) {
+    float e = __expf(-2.0f * fabsf(v));
+    float t = (1.0f - e) / (1.0f + e);
+    return v < 0.f ? -t : t;
+}
 
 inline int nblocks(long long n, int per) { return (int)((n + per - 1) / per); }
 
@@ -152,7 +158,7 @@ __global__ void k_bypass(const float* __restrict__ orig, const float* __restrict
                                                   g.z + (v.z - g.z) * s.z, g.w + (v.w - g.w) * s.w);
 }
 
-__device__ __forceinline__ float sigm(float s) { return 1.0f / (1.0f + expf(-s)); }
+__device__ __forceinline__ float sigm(float s) { return 1.0f / (1.0f + __expf(-s)); }
 
 // y[m, d] = x[m, d] * sigmoid(x[m, D + d])       x: [M, 2D]
 __global__ void k_glu(const float* __restrict__ x, float* __restrict__ y, long long n4, int D4) {
@@ -172,7 +178,7 @@ __global__ void k_tanh_gate(const float* __restrict__ x, float* __restrict__ y, 
     int q = (int)(i % H4);
     const float4* xr = reinterpret_cast<const float4*>(x) + m * 3 * H4;
     float4 s = xr[q], a = xr[H4 + q];
-    reinterpret_cast<float4*>(y)[i] = make_float4(a.x * tanhf(s.x), a.y * tanhf(s.y), a.z * tanhf(s.z), a.w * tanhf(s.w));
+    reinterpret_cast<float4*>(y)[i] = make_float4(a.x * fast_tanh(s.x), a.y * fast_tanh(s.y), a.z * fast_tanh(s.z), a.w * fast_tanh(s.w));
 }
 // a[m, n] *= x[m*ldx + col0 + n]
 __global__ void k_mul_cols(float* __restrict__ a, const float* __restrict__ x, int ldx, int col0, long long n4, int N4) {

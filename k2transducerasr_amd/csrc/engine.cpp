@@ -707,6 +707,35 @@ void Engine::offline_greedy_samples(const float* const* samples, const int64_t* 
     offline_greedy_feats(ptrs.data(), nfl.data(), B, false, tokens, ts, n_tokens, max_tokens);
 }
 
+// tuning hook: average time of one Linear-shaped GEMM on uniform random data
+float Engine::debug_gemm(int M, int N, int K, int act, bool with_res, int iters) {
+    K2_HIP(hipSetDevice(device_));
+    std::vector<float> h((size_t)std::max((int64_t)M * K, std::max((int64_t)N * K, (int64_t)M * N)));
+    uint32_t s = 12345u;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) * (1.0f / 8388608.0f)) - 1.0f; }
+    float *A, *W, *C, *b;
+    K2_HIP(hipMalloc(&A, sizeof(float) * (size_t)M * K));
+    K2_HIP(hipMalloc(&W, sizeof(float) * (size_t)N * K));
+    K2_HIP(hipMalloc(&C, sizeof(float) * (size_t)M * N));
+    K2_HIP(hipMalloc(&b, sizeof(float) * (size_t)N));
+    K2_HIP(hipMemcpy(A, h.data(), sizeof(float) * (size_t)M * K, hipMemcpyHostToDevice));
+    K2_HIP(hipMemcpy(W, h.data(), sizeof(float) * (size_t)N * K, hipMemcpyHostToDevice));
+    K2_HIP(hipMemcpy(C, h.data(), sizeof(float) * (size_t)M * N, hipMemcpyHostToDevice));
+    K2_HIP(hipMemcpy(b, h.data(), sizeof(float) * (size_t)N, hipMemcpyHostToDevice));
+    Ctx c = make_ctx(false);
+    c.instrument = false;
+    c.stats = nullptr;
+    for (int i = 0; i < 3; i++) linear(c, A, K, W, b, C, N, M, K, N, act, with_res ? C : nullptr, N);
+    K2_HIP(hipEventRecord(ev_[6], stream_));
+    for (int i = 0; i < iters; i++) linear(c, A, K, W, b, C, N, M, K, N, act, with_res ? C : nullptr, N);
+    K2_HIP(hipEventRecord(ev_[7], stream_));
+    K2_HIP(hipStreamSynchronize(stream_));
+    float ms = 0;
+    K2_HIP(hipEventElapsedTime(&ms, ev_[6], ev_[7]));
+    (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipFree(b);
+    return ms / iters;
+}
+
 void* Engine::dev_alloc(int64_t bytes) {
     K2_HIP(hipSetDevice(device_));
     void* p = nullptr;

@@ -47,6 +47,7 @@ class Engine {
     void set_instrument(bool on) { instrument_ = on; }
     const k2hip_timing& timing() const { return timing_; }
 
+    float debug_gemm(int M, int N, int K, int act, bool with_res, int iters);
     void* dev_alloc(int64_t bytes);
     void dev_free(void* p);
     void dev_upload(void* dst, const void* src, int64_t bytes);

@@ -16,9 +16,16 @@
 //     in which k is summed is a permutation of 0..K-1, identical for A and W.
 //   - double-buffered LDS, next tile's global loads in flight during the MFMAs,
 //     one barrier per K step
-//   - epilogue straight from the accumulators: bias, activation, residual add
-//   - optional gathers: implicit-conv row/k mapping for A (NHWC), [K,N] B operand
-//     (transposed while staging) for attention-weights x values products.
+//   - loads are branch-free: out-of-range rows/columns are clamped to a valid row
+//     (their results are never stored), the K tail is clamped + zero-selected
+//   - epilogue straight from the accumulators: bias, activation (hardware exp/log),
+//     residual add
+//   - MODE_CONV: implicit-conv row/k mapping for A over an NHWC tensor;
+//     MODE_WKN: [K,N] B operand (transposed while staging) for attention-weights x
+//     values products.
+#include <cmath>
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace k2hip {
@@ -29,27 +36,46 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int LDSK = 36;  // padded row length (floats): 144-byte rows, 16-byte aligned
+enum { MODE_PLAIN = 0, MODE_CONV = 1, MODE_WKN = 2 };
 
-__device__ __forceinline__ float logaddexp0(float z) { return fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))); }
-
+// Activations with the hardware transcendental units (v_exp_f32 / v_log_f32, ~1e-6
+// relative): the accurate libm forms cost ~100 VALU instructions per element, which
+// for K <= 256 made the epilogue longer than the MFMA loop.
+__device__ __forceinline__ float fast_softplus(float z) {  // log(1 + e^z)
+    return z > 15.f ? z : __logf(1.0f + __expf(z));
+}
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
-        case ACT_SWOOSH_L: return logaddexp0(v - 4.0f) - 0.08f * v - 0.035f;
-        case ACT_SWOOSH_R: return logaddexp0(v - 1.0f) - 0.08f * v - 0.313261687f;
-        case ACT_TANH: return tanhf(v);
-        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        case ACT_SWOOSH_L: return fast_softplus(v - 4.0f) - 0.08f * v - 0.035f;
+        case ACT_SWOOSH_R: return fast_softplus(v - 1.0f) - 0.08f * v - 0.313261687f;
+        case ACT_TANH: {
+            float e = __expf(-2.0f * fabsf(v));
+            float t = (1.0f - e) / (1.0f + e);
+            return v < 0.f ? -t : t;
+        }
+        case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
         case ACT_RELU: return fmaxf(v, 0.f);
         default: return v;
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs g) {
+// component-wise select (`ok ? v : zero4` on a float4 is lowered through scratch memory by
+// hipcc).  Only the K-tail tile uses it: any VALU touching a loaded value makes hipcc wait
+// for the load right there, i.e. BEFORE the MFMAs it is supposed to overlap, so the loads
+// of full tiles are left completely untouched until the LDS write of the next iteration.
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) {
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(GemmArgs g) {
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WCOLS = BN / WN;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-    constexpr int PA = BM / 32;  // float4 loads per thread for the A tile
-    constexpr int PB = BN / 32;
+    constexpr int NTHR = 64 * (BM / WM) * (BN / WN);
+    constexpr int RPP = NTHR / 8;  // tile rows covered by one pass of float4 loads (8 float4 per 32-float row)
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile must be a whole number of load passes");
+    constexpr int PA = BM / RPP;  // float4 loads per thread for the A tile
+    constexpr int PB = BN / RPP;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                        // [2][BM][LDSK]
@@ -70,77 +96,78 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs g) {
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int Kp = (g.K + 3) & ~3;
 
-    // ---- per-thread global-load coordinates
-    const int ld_row = tid >> 3;       // 0..31
+    // ---- per-thread global-load coordinates (rows / columns clamped into range)
+    const int ld_row = tid >> 3;       // 0..RPP-1
     const int ld_kq = (tid & 7) * 4;   // k offset of this thread's float4
-    long long a_base[PA];
-    bool a_ok[PA];
+    const float* a_ptr[PA];
 #pragma unroll
     for (int p = 0; p < PA; p++) {
-        int row = m0 + ld_row + 32 * p;
-        a_ok[p] = row < g.M;
-        if (g.cv_Fout > 0) {
+        int row = min(m0 + ld_row + RPP * p, g.M - 1);
+        if (MODE == MODE_CONV) {
             int f = row % g.cv_Fout;
             int bt = row / g.cv_Fout;
             int t = bt % g.cv_Tout, b = bt / g.cv_Tout;
-            a_base[p] = (((long long)b * g.cv_Tin + (long long)t * g.cv_st) * g.cv_Fin + (long long)f * g.cv_sf) * g.cv_C;
+            a_ptr[p] = A + (((long long)b * g.cv_Tin + (long long)t * g.cv_st) * g.cv_Fin + (long long)f * g.cv_sf) * g.cv_C;
         } else {
-            a_base[p] = (long long)row * g.lda;
+            a_ptr[p] = A + (long long)row * g.lda;
         }
     }
-    float4 ra[PA], rb[PB];
+    constexpr int NQ = BN / 4;           // MODE_WKN: float4 per k row
+    constexpr int KR = NTHR / NQ;        //           k rows per pass
+    constexpr int PBK = MODE == MODE_WKN ? 32 / KR : PB;  // loads per thread for the B tile
+    static_assert(MODE != MODE_WKN || (KR <= 32 && 32 % KR == 0), "[K,N] staging needs KR | 32");
+    const float* w_ptr[PBK];
+#pragma unroll
+    for (int p = 0; p < PBK; p++) {
+        if (MODE == MODE_WKN) {
+            int col = min(n0 + (tid % NQ) * 4, g.N - 4);
+            w_ptr[p] = W + col;
+        } else {
+            int col = min(n0 + ld_row + RPP * p, g.N - 1);
+            w_ptr[p] = W + (long long)col * g.ldw;
+        }
+    }
+    // Staging registers.  Plain loops over constexpr bounds, no lambdas: captured arrays
+    // were placed in scratch memory by hipcc (16 scratch_load/store_dwordx4 per K step).
+    float4 ra[PA], rb[PBK];
 
-    auto load_tile = [&](int k0) {
-        int k = k0 + ld_kq;
-        long long koff = k;
-        if (g.seg_len > 0) koff = (long long)(k / g.seg_len) * g.seg_stride + (k % g.seg_len);
-#pragma unroll
-        for (int p = 0; p < PA; p++) {
-            ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_ok[p] && k < Kp) ra[p] = *reinterpret_cast<const float4*>(A + a_base[p] + koff);
-        }
-        if (!g.w_kn) {
-#pragma unroll
-            for (int p = 0; p < PB; p++) {
-                int col = n0 + ld_row + 32 * p;
-                rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (col < g.N && k < Kp) rb[p] = *reinterpret_cast<const float4*>(W + (long long)col * g.ldw + k);
-            }
-        } else {
-            // W is [K,N]: this thread loads 4 consecutive n of one k row
-            constexpr int NQ = BN / 4;           // float4 per k row
-            constexpr int KR = 256 / NQ;         // k rows per pass
-#pragma unroll
-            for (int p = 0; p < PB; p++) {
-                int kk = k0 + tid / NQ + KR * p;
-                int col = n0 + (tid % NQ) * 4;
-                rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kk < g.K && col < g.N) rb[p] = *reinterpret_cast<const float4*>(W + (long long)kk * g.ldw + col);
-            }
-        }
-    };
-    auto store_tile = [&](int buf) {
-        float* a = sA + buf * BM * LDSK;
-        float* b = sB + buf * BN * LDSK;
-#pragma unroll
-        for (int p = 0; p < PA; p++) *reinterpret_cast<float4*>(a + (ld_row + 32 * p) * LDSK + ld_kq) = ra[p];
-        if (!g.w_kn) {
-#pragma unroll
-            for (int p = 0; p < PB; p++) *reinterpret_cast<float4*>(b + (ld_row + 32 * p) * LDSK + ld_kq) = rb[p];
-        } else {
-            constexpr int NQ = BN / 4;
-            constexpr int KR = 256 / NQ;
-#pragma unroll
-            for (int p = 0; p < PB; p++) {
-                int kk = tid / NQ + KR * p;
-                int c = (tid % NQ) * 4;
-                b[(c + 0) * LDSK + kk] = rb[p].x;
-                b[(c + 1) * LDSK + kk] = rb[p].y;
-                b[(c + 2) * LDSK + kk] = rb[p].z;
-                b[(c + 3) * LDSK + kk] = rb[p].w;
-            }
-        }
-    };
+    // full K tile: unconditional loads, nothing consumes them before the next LDS write
+#define K2_LOAD_TILE(k0_)                                                                                         \
+    {                                                                                                             \
+        const int k = (k0_) + ld_kq;                                                                              \
+        long long koff = k;                                                                                       \
+        if (MODE == MODE_CONV) koff = (long long)(k / g.seg_len) * g.seg_stride + (k % g.seg_len);                \
+        _Pragma("unroll") for (int p = 0; p < PA; p++) ra[p] = *reinterpret_cast<const float4*>(a_ptr[p] + koff); \
+        if (MODE != MODE_WKN) {                                                                                   \
+            _Pragma("unroll") for (int p = 0; p < PB; p++) rb[p] = *reinterpret_cast<const float4*>(w_ptr[p] + k); \
+        } else {                                                                                                  \
+            _Pragma("unroll") for (int p = 0; p < PBK; p++) {                                                     \
+                const int kk = (k0_) + tid / NQ + KR * p;                                                         \
+                rb[p] = *reinterpret_cast<const float4*>(w_ptr[p] + (long long)kk * g.ldw);                       \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+    // last, partial K tile: clamp the address, zero what lies beyond K
+#define K2_LOAD_TAIL(k0_)                                                                                         \
+    {                                                                                                             \
+        const int k = (k0_) + ld_kq;                                                                              \
+        const bool kok = k < Kp;                                                                                  \
+        const int kc = kok ? k : Kp - 4;                                                                          \
+        long long koff = kc;                                                                                      \
+        if (MODE == MODE_CONV) koff = (long long)(kc / g.seg_len) * g.seg_stride + (kc % g.seg_len);              \
+        _Pragma("unroll") for (int p = 0; p < PA; p++)                                                            \
+            ra[p] = sel4(kok, *reinterpret_cast<const float4*>(a_ptr[p] + koff));                                 \
+        if (MODE != MODE_WKN) {                                                                                   \
+            _Pragma("unroll") for (int p = 0; p < PB; p++)                                                        \
+                rb[p] = sel4(kok, *reinterpret_cast<const float4*>(w_ptr[p] + kc));                               \
+        } else {                                                                                                  \
+            _Pragma("unroll") for (int p = 0; p < PBK; p++) {                                                     \
+                const int kk = (k0_) + tid / NQ + KR * p;                                                         \
+                const bool ok = kk < g.K;                                                                         \
+                rb[p] = sel4(ok, *reinterpret_cast<const float4*>(w_ptr[p] + (long long)(ok ? kk : g.K - 1) * g.ldw)); \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -151,14 +178,40 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs g) {
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     const int nk = (g.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    int cur = 0;
+    const int nfull = g.K / BK;  // tiles [0, nfull) are complete
+    if (nfull > 0) K2_LOAD_TILE(0) else K2_LOAD_TAIL(0)
     for (int kt = 0; kt < nk; kt++) {
-        if (kt + 1 < nk) load_tile((kt + 1) * BK);
-        const float* a = sA + cur * BM * LDSK + (wr * WM + li) * LDSK + 4 * lh;
-        const float* b = sB + cur * BN * LDSK + (wc * WN + li) * LDSK + 4 * lh;
+        // registers -> LDS buffer kt&1.  The buffer was last read in iteration kt-2's
+        // MFMA section, which every wave left before passing iteration kt-1's barrier.
+        {
+            float* a = sA + (kt & 1) * BM * LDSK;
+            float* b = sB + (kt & 1) * BN * LDSK;
+#pragma unroll
+            for (int p = 0; p < PA; p++) *reinterpret_cast<float4*>(a + (ld_row + RPP * p) * LDSK + ld_kq) = ra[p];
+            if (MODE != MODE_WKN) {
+#pragma unroll
+                for (int p = 0; p < PB; p++) *reinterpret_cast<float4*>(b + (ld_row + RPP * p) * LDSK + ld_kq) = rb[p];
+            } else {
+#pragma unroll
+                for (int p = 0; p < PBK; p++) {
+                    const int kk = tid / NQ + KR * p;
+                    const int c = (tid % NQ) * 4;
+                    // a clamped column group (n0 + c > N - 4) re-loads valid data; its outputs are never stored
+                    b[(c + 0) * LDSK + kk] = rb[p].x;
+                    b[(c + 1) * LDSK + kk] = rb[p].y;
+                    b[(c + 2) * LDSK + kk] = rb[p].z;
+                    b[(c + 3) * LDSK + kk] = rb[p].w;
+                }
+            }
+        }
+        __syncthreads();
+        if (!(g.ablate & 1)) {  // next tile's loads stay in flight during the MFMAs below
+            if (kt + 1 < nfull) K2_LOAD_TILE((kt + 1) * BK)
+            else if (kt + 1 < nk) K2_LOAD_TAIL((kt + 1) * BK)
+        }
+        const float* a = sA + (kt & 1) * BM * LDSK + (wr * WM + li) * LDSK + 4 * lh;
+        const float* b = sB + (kt & 1) * BN * LDSK + (wc * WN + li) * LDSK + 4 * lh;
+        if (!(g.ablate & 2))
 #pragma unroll
         for (int gk = 0; gk < 4; gk++) {
             float4 fa[MT], fb[NT];
@@ -166,20 +219,21 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs g) {
             for (int i = 0; i < MT; i++) fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDSK + gk * 8);
 #pragma unroll
             for (int j = 0; j < NT; j++) fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * LDSK + gk * 8);
+            // k-step outer, accumulator tile inner: consecutive MFMAs hit different accumulators
 #pragma unroll
-            for (int i = 0; i < MT; i++)
+            for (int e = 0; e < 4; e++)
 #pragma unroll
-                for (int j = 0; j < NT; j++) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int j = 0; j < NT; j++) {
+                        const float av = e == 0 ? fa[i].x : e == 1 ? fa[i].y : e == 2 ? fa[i].z : fa[i].w;
+                        const float bv = e == 0 ? fb[j].x : e == 1 ? fb[j].y : e == 2 ? fb[j].z : fb[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
     }
+#undef K2_LOAD_TILE
+#undef K2_LOAD_TAIL
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -192,7 +246,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int row = m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < g.M) {
+                if (row < g.M && !(g.ablate & 4)) {
                     float v = apply_act(acc[i][j][r] + bv, g.act);
                     if (R) v += R[(long long)row * g.ldr + col];
                     C[(long long)row * g.ldc + col] = v;
@@ -202,36 +256,73 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-void launch(const Ctx& ctx, const GemmArgs& a) {
+template <int BM, int BN, int WM, int WN, int MODE>
+void launch_cfg(const Ctx& ctx, const GemmArgs& a) {
     dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.nb0 * a.nb1);
     size_t lds = sizeof(float) * 2 * (BM + BN) * LDSK;
     static bool attr_set = false;
     if (!attr_set) {
-        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma<BM, BN, WM, WN>),
+        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma<BM, BN, WM, WN, MODE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN>), grid, dim3(256), lds, ctx.stream, a);
+    hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, MODE>), grid, dim3(64 * (BM / WM) * (BN / WN)), lds, ctx.stream, a);
+}
+
+template <int MODE>
+void launch_mode(const Ctx& ctx, const GemmArgs& a, int cfg) {
+    switch (cfg) {
+        case 0: launch_cfg<128, 128, 64, 32, MODE>(ctx, a); break;  // 8 waves
+        case 1: launch_cfg<128, 64, 64, 32, MODE>(ctx, a); break;   // 4 waves
+        case 3: launch_cfg<128, 128, 64, 64, MODE>(ctx, a); break;  // 4 waves
+        case 4: launch_cfg<256, 128, 64, 64, MODE>(ctx, a); break;  // 8 waves
+        case 5: launch_cfg<128, 64, 32, 32, MODE>(ctx, a); break;   // 8 waves
+        default: launch_cfg<64, 64, 32, 32, MODE>(ctx, a); break;   // 4 waves
+    }
+}
+
+int g_forced_cfg = getenv("K2HIP_GEMM_CFG") ? atoi(getenv("K2HIP_GEMM_CFG")) : -1;  // tuning only
+
+// Tile choice, from tools/gemm_tune.py on the benchmark's shapes (gpurun_out/gemm_tune_*.txt):
+// on this path K is short (192..2560), so a launch is dominated by how well the prologue /
+// epilogue of one workgroup overlaps the MFMA loop of its neighbours.  Small wave tiles
+// (32x32 per wave, 4-5 waves per SIMD) win almost everywhere; the 128x128 tile only pays
+// when the output is large enough to fill every CU several times over.
+//   cfg 0: 128x128, 8 waves (64x32 per wave)   cfg 5: 128x64, 8 waves (32x32 per wave)
+//   cfg 2:  64x64,  4 waves (32x32 per wave)
+int choose_cfg(const GemmArgs& a) {
+    if (g_forced_cfg >= 0) return g_forced_cfg;
+    if (a.N <= 64) return 2;
+    const double out = (double)a.M * a.N * a.nb0 * a.nb1;
+    if (out >= 7.0e6 && a.N >= 256) return 0;
+    return 5;
 }
 
 }  // namespace
 
+int g_ablate = 0;
+void debug_force_gemm_cfg(int cfg) { g_forced_cfg = cfg & 0xff; g_ablate = cfg < 0 ? 0 : (cfg >> 8); if (cfg < 0) g_forced_cfg = -1; }
+
 void gemm(const Ctx& ctx, const GemmArgs& a) {
     K2_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty shape %dx%dx%d", a.M, a.N, a.K);
     K2_REQUIRE(a.cv_Fout > 0 || a.lda % 4 == 0, "gemm: lda %d must be a multiple of 4", a.lda);
-    K2_REQUIRE(a.w_kn || a.K % 4 == 0 || a.lda >= ((a.K + 3) & ~3), "gemm: K %d needs zero-padded A rows", a.K);
+    K2_REQUIRE(a.K >= 4, "gemm: K=%d too small", a.K);
+    K2_REQUIRE(a.w_kn || a.K % 4 == 0, "gemm: K %d must be a multiple of 4", a.K);
+    K2_REQUIRE(!a.w_kn || a.lda >= ((a.K + 3) & ~3), "gemm: [K,N] form needs A rows zero-padded to a multiple of 4");
     K2_REQUIRE(a.ldw % 4 == 0, "gemm: ldw %d must be a multiple of 4", a.ldw);
-    K2_REQUIRE(!a.w_kn || a.N % 4 == 0, "gemm: [K,N] operand needs N %% 4 == 0 (N=%d)", a.N);
-    K2_REQUIRE(a.seg_len == 0 || a.seg_len % 4 == 0, "gemm: seg_len %d must be a multiple of 4", a.seg_len);
+    K2_REQUIRE(!a.w_kn || (a.N % 4 == 0 && a.N >= 4), "gemm: [K,N] operand needs N %% 4 == 0 (N=%d)", a.N);
+    K2_REQUIRE(!(a.w_kn && a.cv_Fout > 0), "gemm: conv gather and [K,N] operand cannot be combined");
+    K2_REQUIRE(a.cv_Fout == 0 || (a.seg_len > 0 && a.seg_len % 4 == 0), "gemm: conv gather needs seg_len %% 4 == 0");
     const double fl = 2.0 * a.M * (double)a.N * a.K * a.nb0 * a.nb1;
     ctx.add_flops(fl, 0.0, 1);
     if (ctx.dry) return;
     if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
-    // tile choice: big tiles when they still give every CU >= 2 workgroups
-    long long blocks128 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.nb0 * a.nb1;
-    if (a.N > 64 && blocks128 >= 512) launch<128, 128, 64, 64>(ctx, a);
-    else launch<64, 64, 32, 32>(ctx, a);
+    int cfg = choose_cfg(a);
+    GemmArgs b = a;
+    b.ablate = g_ablate;
+    if (a.cv_Fout > 0) launch_mode<MODE_CONV>(ctx, b, cfg);
+    else if (a.w_kn) launch_mode<MODE_WKN>(ctx, b, cfg);
+    else launch_mode<MODE_PLAIN>(ctx, b, cfg);
     K2_HIP(hipGetLastError());
     if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
 }

@@ -109,90 +109,179 @@ __global__ void k_first_emit(const int* __restrict__ tok, int B, int Tp, int ski
     if (threadIdx.x == 0) *t0 = best;
 }
 
-// LDS layout: act[J] | dec_a[J] | dec_b[J] | dec_own[J] | h[DD] | part[2*Vp] | red (8 floats/ints)
-__global__ __launch_bounds__(256) void k_greedy(DecJoinW w, GreedyArgs a) {
+// ---- multi-frame greedy loop ---------------------------------------------------------
+// One workgroup of 1024 threads per stream.  The joiner matrix (J x V f32, 1 MB for the
+// large-en model) does not fit in LDS and streaming it from L2 once per frame made the loop
+// latency-bound (~50 us / frame).  Blank wins most frames and the decoder context only
+// changes on an emission, so each ROUND evaluates the next GF frames against the CURRENT
+// context in one sweep of the matrix (every 16-byte weight load feeds GF x 4 FMAs), then
+// accepts frames in order up to and including the first one that emits.  Frames after an
+// emission are re-evaluated in the next round under the new context, so the result is
+// exactly the frame-by-frame loop of OfflineRecognizer.cs:216-288.
+constexpr int GF = 8;      // frames per round
+constexpr int GT = 1024;   // threads per workgroup (16 waves)
+
+// dec_out[J] = decoder_proj(relu(grouped_conv(emb[y0], emb[y1]))), GT threads, two per output
+__device__ void decoder_block_wide(const DecJoinW& w, long long y0, long long y1, float* h, float* out) {
+    const int tid = threadIdx.x;
+    for (int co = tid; co < w.DD; co += GT) {
+        int g4 = (co >> 2) << 2;
+        float s = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < 4; ci++) {
+            float e0 = y0 >= 0 ? w.emb[y0 * w.DD + g4 + ci] : 0.f;
+            float e1 = y1 >= 0 ? w.emb[y1 * w.DD + g4 + ci] : 0.f;
+            s += w.conv[(co * 4 + ci) * 2 + 0] * e0;
+            s += w.conv[(co * 4 + ci) * 2 + 1] * e1;
+        }
+        h[co] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    const int khalf = w.DD >> 1;
+    for (int n2 = tid; n2 < 2 * w.J; n2 += GT) {
+        const int n = n2 >> 1, half = n2 & 1;
+        const float* wp = w.dproj_kn + (long long)(half * khalf) * w.J + n;
+        const float* hp = h + half * khalf;
+        float s = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < khalf; k++) s += hp[k] * wp[(long long)k * w.J];
+        s += __shfl_xor(s, 1);
+        if (!half) out[n] = s + w.dproj_b[n];
+    }
+    __syncthreads();
+}
+
+// LDS: actT[J][GF] | dec_a[J] | dec_b[J] | dec_own[J] | h[DD] | redv[16][GF] | redi[16][GF] | fin[GF]
+__global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* act = sm;
-    float* dec_a = act + w.J;
+    float* actT = sm;
+    float* dec_a = actT + w.J * GF;
     float* dec_b = dec_a + w.J;
     float* dec_own = dec_b + w.J;
     float* h = dec_own + w.J;
-    float* part = h + w.DD;        // [Vp] partial logits of the upper k-half
-    float* redv = part + w.Vp;     // [4]
-    int* redi = reinterpret_cast<int*>(redv + 4);  // [4]
+    float* redv = h + w.DD;
+    int* redi = reinterpret_cast<int*>(redv + 16 * GF);
+    int* fin = redi + 16 * GF;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ks = lane >> 3, cgl = lane & 7;  // k slice (8 per wave), column group within the wave's 8
     const int b = blockIdx.x;
     const float* enc = a.enc + (long long)b * a.Tp * w.J;
     const int t0 = a.t0 ? *a.t0 : INT_MAX;
+    const int ncg = w.Vp >> 2, kper = w.J >> 3;
 
-    decoder_block(w, -1, K2HIP_BLANK_ID, h, dec_a);
-    if (a.t0) decoder_block(w, K2HIP_BLANK_ID, K2HIP_BLANK_ID, h, dec_b);
+    decoder_block_wide(w, -1, K2HIP_BLANK_ID, h, dec_a);
+    if (a.t0) decoder_block_wide(w, K2HIP_BLANK_ID, K2HIP_BLANK_ID, h, dec_b);
 
     long long y0 = -1, y1 = K2HIP_BLANK_ID;
-    int n_tok = 0;
+    int n_tok = 0, t = 0;
     bool own = false;
-    const int kh = tid >> 7;          // k half
-    const int cg0 = tid & 127;        // first column group
-    const int ncg = w.Vp >> 2;
-    const int khalf = w.J >> 1;
 
-    for (int t = 0; t < a.Tp && n_tok < a.max_sym; t++) {
-        const float* d = own ? dec_own : (t > t0 ? dec_b : dec_a);
-        for (int k = tid; k < w.J; k += 256) act[k] = tanhf(enc[(long long)t * w.J + k] + d[k]);
-        __syncthreads();
-        float bv = -INFINITY;
-        int bi = -1;
-        for (int cgb = 0; cgb < ncg; cgb += 128) {  // uniform trip count: barriers inside
-            const int cg = cgb + cg0;
-            const bool valid = cg < ncg;
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) {
-                const float* wp = w.out_kn + (long long)(kh * khalf) * w.Vp + 4 * cg;
-                const float* ap = act + kh * khalf;
-#pragma unroll 8
-                for (int k = 0; k < khalf; k++) {
-                    float4 wv = *reinterpret_cast<const float4*>(wp + (long long)k * w.Vp);
-                    float av = ap[k];
-                    s.x += av * wv.x; s.y += av * wv.y; s.z += av * wv.z; s.w += av * wv.w;
-                }
-                if (kh == 1) *reinterpret_cast<float4*>(part + 4 * cg) = s;
+    while (t < a.Tp && n_tok < a.max_sym) {
+        const int nf = min(GF, a.Tp - t);
+        // activations of the next GF frames under the current context
+        for (int idx = tid; idx < w.J * GF; idx += GT) {
+            const int f = idx / w.J, k = idx - f * w.J;
+            float v = 0.f;
+            if (f < nf) {
+                const float* d = own ? dec_own : ((t + f) > t0 ? dec_b : dec_a);
+                v = tanhf(enc[(long long)(t + f) * w.J + k] + d[k]);
             }
-            __syncthreads();
-            if (valid && kh == 0) {
-                float4 p = *reinterpret_cast<const float4*>(part + 4 * cg);
-                float l[4] = {s.x + p.x, s.y + p.y, s.z + p.z, s.w + p.w};
+            actT[k * GF + f] = v;
+        }
+        __syncthreads();
+        float bestv[GF];
+        int besti[GF];
+#pragma unroll
+        for (int f = 0; f < GF; f++) { bestv[f] = -INFINITY; besti[f] = -1; }
+        for (int cgb = 0; cgb < ncg; cgb += 128) {
+            const int cg = cgb + wave * 8 + cgl;
+            const bool valid = cg < ncg;
+            float acc[GF][4];
+#pragma unroll
+            for (int f = 0; f < GF; f++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[f][j] = 0.f;
+            if (valid) {
+                const float* wp = w.out_kn + (long long)(ks * kper) * w.Vp + 4 * cg;
+                const float* ap = actT + (ks * kper) * GF;
+#pragma unroll 4
+                for (int k = 0; k < kper; k++) {
+                    const float4 wv = *reinterpret_cast<const float4*>(wp + (long long)k * w.Vp);
+                    const float4 a0 = *reinterpret_cast<const float4*>(ap + k * GF);
+                    const float4 a1 = *reinterpret_cast<const float4*>(ap + k * GF + 4);
+                    const float av[GF] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                    for (int f = 0; f < GF; f++) {
+                        acc[f][0] += av[f] * wv.x;
+                        acc[f][1] += av[f] * wv.y;
+                        acc[f][2] += av[f] * wv.z;
+                        acc[f][3] += av[f] * wv.w;
+                    }
+                }
+            }
+            // sum the 8 k slices (lane bits 3..5)
+#pragma unroll
+            for (int f = 0; f < GF; f++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    int col = 4 * cg + j;
-                    if (col < w.V) amax_merge(bv, bi, l[j] + w.out_b[col], col);
+                    float v = acc[f][j];
+                    v += __shfl_xor(v, 8);
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    acc[f][j] = v;
+                }
+            if (valid && ks == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int col = 4 * cg + j;
+                    if (col < w.V) {
+                        const float bj = w.out_b[col];
+#pragma unroll
+                        for (int f = 0; f < GF; f++) amax_merge(bestv[f], besti[f], acc[f][j] + bj, col);
+                    }
                 }
             }
-            __syncthreads();
         }
-        amax_wave(bv, bi);
-        if (lane == 0) { redv[wave] = bv; redi[wave] = bi; }
+#pragma unroll
+        for (int f = 0; f < GF; f++) {
+            amax_wave(bestv[f], besti[f]);
+            if (lane == 0) { redv[wave * GF + f] = bestv[f]; redi[wave * GF + f] = besti[f]; }
+        }
         __syncthreads();
-        float fv = redv[0];
-        int y = redi[0];
-        amax_merge(fv, y, redv[1], redi[1]);  // waves 2,3 are the upper k-half: (-inf, -1)
+        if (tid < GF) {
+            float v = redv[tid];
+            int i = redi[tid];
+            for (int wv = 1; wv < GT / 64; wv++) amax_merge(v, i, redv[wv * GF + tid], redi[wv * GF + tid]);
+            fin[tid] = i;
+        }
         __syncthreads();
-        bool emit = (y != K2HIP_BLANK_ID && y != K2HIP_UNK_ID && !(a.skip1 && y == 1));
-        if (emit) {
-            if (n_tok < a.max_tokens) {
-                if (tid == 0) {
-                    a.tokens[(long long)b * a.max_tokens + n_tok] = y;
-                    a.timestamps[(long long)b * a.max_tokens + n_tok] = t;
+        // accept frames in order up to and including the first emission
+        int adv = nf;
+        bool emitted = false;
+        for (int f = 0; f < nf; f++) {
+            const int y = fin[f];
+            if (y != K2HIP_BLANK_ID && y != K2HIP_UNK_ID && !(a.skip1 && y == 1)) {
+                if (n_tok < a.max_tokens) {
+                    if (tid == 0) {
+                        a.tokens[(long long)b * a.max_tokens + n_tok] = y;
+                        a.timestamps[(long long)b * a.max_tokens + n_tok] = t + f;
+                    }
+                } else if (tid == 0) {
+                    *a.overflow = 1;
                 }
-            } else if (tid == 0) {
-                *a.overflow = 1;
+                n_tok++;
+                y0 = y1;
+                y1 = y;
+                own = true;
+                adv = f + 1;
+                emitted = true;
+                break;
             }
-            n_tok++;
-            y0 = y1;
-            y1 = y;
-            own = true;
-            decoder_block(w, y0, y1, h, dec_own);
         }
+        t += adv;
+        if (emitted) decoder_block_wide(w, y0, y1, h, dec_own);
+        else __syncthreads();  // actT / fin are rewritten by the next round
     }
     if (tid == 0) a.n_tokens[b] = n_tok < a.max_tokens ? n_tok : a.max_tokens;
 }
@@ -223,14 +312,14 @@ void first_emit_frame(const Ctx& ctx, const int* tok, int B, int Tp, int skip1, 
 void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a) {
     if (ctx.dry || a.B <= 0) return;
     K2_REQUIRE(w.J % 8 == 0, "greedy: joiner_dim %d must be a multiple of 8", w.J);
-    size_t lds = sizeof(float) * (4 * (size_t)w.J + w.DD + w.Vp + 8);
+    size_t lds = sizeof(float) * ((size_t)w.J * GF + 3 * (size_t)w.J + w.DD + 32 * GF + GF + 8);
     K2_REQUIRE(lds <= 160 * 1024, "greedy: vocab %d / joiner %d need %zu B of LDS", w.V, w.J, lds);
     static bool attr_set = false;
     if (!attr_set) {
         K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_greedy, dim3(a.B), dim3(256), lds, ctx.stream, w, a);
+    hipLaunchKernelGGL(k_greedy, dim3(a.B), dim3(GT), lds, ctx.stream, w, a);
     K2_HIP(hipGetLastError());
 }
 

@@ -34,7 +34,7 @@ struct Ctx {
     }
     // algorithmic work is tallied once, in the dry (sizing) pass
     void add_flops(double gemm_fl, double other_fl, int launches) const {
-        if (stats && dry) {
+        if (stats && dry) {  // stats may be null (tuning hook)
             stats->flops += gemm_fl;
             stats->total_flops += gemm_fl + other_fl;
             stats->launches += launches;
@@ -65,8 +65,10 @@ struct GemmArgs {
     //   k -> (k / seg_len) * seg_stride + k % seg_len
     int cv_Fout = 0, cv_Tout = 0, cv_Tin = 0, cv_Fin = 0, cv_C = 0, cv_st = 1, cv_sf = 1;
     int seg_len = 0, seg_stride = 0;
+    int ablate = 0;  // tuning only: 1 = skip in-loop global loads, 2 = skip MFMAs, 4 = skip epilogue stores
 };
 void gemm(const Ctx& ctx, const GemmArgs& a);
+void debug_force_gemm_cfg(int cfg);  // tuning hook: -1 = automatic
 // convenience: plain Linear  C = act(A W^T + b) (+res)
 void linear(const Ctx& ctx, const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int K,
             int N, int act = ACT_NONE, const float* res = nullptr, int ldr = 0);

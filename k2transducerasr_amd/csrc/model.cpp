@@ -233,6 +233,10 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
         extra.emplace_back(name, std::move(v));
         shapes.emplace_back(name, std::move(shp));
     };
+    // A container may hold the decoder + joiner only (the reference also loads three separate
+    // sessions, OfflineModel.cs:25-27); encoder entry points then fail with "no tensor ...".
+    const bool has_encoder = has("encoder_embed.conv.0.weight");
+    if (has_encoder) {
     // conv filters [Co,Ci,3,3] -> [Co][kt][kf][ci]  (K index of the implicit GEMM over NHWC input)
     for (const char* nm : {"encoder_embed.conv.4.weight", "encoder_embed.conv.7.weight"}) {
         const Tensor& t = tensor(nm);
@@ -277,6 +281,7 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
                     for (int kk = 0; kk < K; kk++) v[(size_t)kk * D + d] = t.host[(size_t)d * K + kk];
                 push(std::string(nm) + "#kd", std::move(v), {K, D});
             }
+    }  // has_encoder
     {   // joiner.output_linear [V,J] -> k-major [J][Vp]
         const Tensor& t = tensor("joiner.output_linear.weight");
         K2_REQUIRE(t.dims[0] == c.V && t.dims[1] == c.J, "joiner.output_linear.weight is [%lld,%lld], config says [%d,%d]",
