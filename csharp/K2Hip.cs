@@ -1,0 +1,40 @@
+// P/Invoke declarations for libk2hip.so (include/k2hip.h).
+// Source only: there is no dotnet toolchain in the build image, so this file is not compiled here.
+using System;
+using System.Runtime.InteropServices;
+
+namespace K2TransducerAsr.Hip
+{
+    [StructLayout(LayoutKind.Sequential)]
+    internal struct K2HipModelInfo
+    {
+        public int vocab_size, context_size, joiner_dim, feature_dim, sample_rate, num_stacks, device, reserved;
+    }
+
+    internal static class K2Hip
+    {
+        private const string Lib = "k2hip";
+
+        [DllImport(Lib)] internal static extern IntPtr k2hip_last_error();
+        [DllImport(Lib)] internal static extern int k2hip_model_create(string weightsPath, string overrides, int device, out IntPtr model);
+        [DllImport(Lib)] internal static extern int k2hip_model_destroy(IntPtr model);
+        [DllImport(Lib)] internal static extern int k2hip_model_get_info(IntPtr model, out K2HipModelInfo info);
+        [DllImport(Lib)] internal static extern long k2hip_fbank_num_frames(IntPtr model, long nSamples);
+        [DllImport(Lib)] internal static extern int k2hip_fbank(IntPtr model, float[] samples, long n, float[] feats, long capFrames, out long nFrames);
+        [DllImport(Lib)] internal static extern int k2hip_encoder_out_frames(IntPtr model, int T);
+        [DllImport(Lib)] internal static extern int k2hip_offline_encoder(IntPtr model, float[] x, long[] xLens, int B, int T,
+            float[] encOut, long capFloats, long[] encOutLens, out int Tprime);
+        [DllImport(Lib)] internal static extern int k2hip_decoder(IntPtr model, long[] y, int N, float[] decOut);
+        [DllImport(Lib)] internal static extern int k2hip_joiner(IntPtr model, float[] enc, float[] dec, int N, float[] logits);
+        [DllImport(Lib)] internal static extern int k2hip_offline_greedy(IntPtr model, IntPtr[] feats, long[] nFloats, int B,
+            long[] tokens, int[] timestamps, int[] nTokens, int maxTokens);
+        [DllImport(Lib)] internal static extern int k2hip_offline_greedy_single(IntPtr model, float[] feats, long nFloats,
+            long[] tokens, int[] timestamps, int[] nTokens, int maxTokens);
+
+        internal static void Check(int rc, string what)
+        {
+            if (rc != 0)
+                throw new Exception(what, new Exception(Marshal.PtrToStringAnsi(k2hip_last_error())));
+        }
+    }
+}

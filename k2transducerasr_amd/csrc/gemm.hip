@@ -34,8 +34,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDSK = 36;  // padded row length (floats): 144-byte rows, 16-byte aligned
+// K step BK (32 or 64) is a template parameter; LDS rows are padded to BK+4 floats (16-byte
+// aligned; 36- and 68-dword strides are both conflict-free for the ds_read_b128 fragment reads)
 enum { MODE_PLAIN = 0, MODE_CONV = 1, MODE_WKN = 2 };
 
 // Activations with the hardware transcendental units (v_exp_f32 / v_log_f32, ~1e-6
@@ -67,12 +67,14 @@ __device__ __forceinline__ float4 sel4(bool ok, float4 v) {
     return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int BK, int MODE>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(GemmArgs g) {
+    constexpr int LDSK = BK + 4;
+    constexpr int F4R = BK / 4;  // float4 per tile row
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WCOLS = BN / WN;
     constexpr int NTHR = 64 * (BM / WM) * (BN / WN);
-    constexpr int RPP = NTHR / 8;  // tile rows covered by one pass of float4 loads (8 float4 per 32-float row)
+    constexpr int RPP = NTHR / F4R;  // tile rows covered by one pass of float4 loads
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile must be a whole number of load passes");
     constexpr int PA = BM / RPP;  // float4 loads per thread for the A tile
     constexpr int PB = BN / RPP;
@@ -97,8 +99,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
     const int Kp = (g.K + 3) & ~3;
 
     // ---- per-thread global-load coordinates (rows / columns clamped into range)
-    const int ld_row = tid >> 3;       // 0..RPP-1
-    const int ld_kq = (tid & 7) * 4;   // k offset of this thread's float4
+    const int ld_row = tid / F4R;        // 0..RPP-1
+    const int ld_kq = (tid % F4R) * 4;   // k offset of this thread's float4
     const float* a_ptr[PA];
 #pragma unroll
     for (int p = 0; p < PA; p++) {
@@ -114,8 +116,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
     }
     constexpr int NQ = BN / 4;           // MODE_WKN: float4 per k row
     constexpr int KR = NTHR / NQ;        //           k rows per pass
-    constexpr int PBK = MODE == MODE_WKN ? 32 / KR : PB;  // loads per thread for the B tile
-    static_assert(MODE != MODE_WKN || (KR <= 32 && 32 % KR == 0), "[K,N] staging needs KR | 32");
+    constexpr int PBK = MODE == MODE_WKN ? BK / KR : PB;  // loads per thread for the B tile
+    static_assert(MODE != MODE_WKN || (KR <= BK && BK % KR == 0), "[K,N] staging needs KR | BK");
     const float* w_ptr[PBK];
 #pragma unroll
     for (int p = 0; p < PBK; p++) {
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
         const float* b = sB + (kt & 1) * BN * LDSK + (wc * WN + li) * LDSK + 4 * lh;
         if (!(g.ablate & 2))
 #pragma unroll
-        for (int gk = 0; gk < 4; gk++) {
+        for (int gk = 0; gk < BK / 8; gk++) {
             float4 fa[MT], fb[NT];
 #pragma unroll
             for (int i = 0; i < MT; i++) fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDSK + gk * 8);
@@ -256,28 +258,29 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
     }
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int BK, int MODE>
 void launch_cfg(const Ctx& ctx, const GemmArgs& a) {
+    constexpr int LDSK = BK + 4;
     dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.nb0 * a.nb1);
     size_t lds = sizeof(float) * 2 * (BM + BN) * LDSK;
     static bool attr_set = false;
     if (!attr_set) {
-        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma<BM, BN, WM, WN, MODE>),
+        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma<BM, BN, WM, WN, BK, MODE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, MODE>), grid, dim3(64 * (BM / WM) * (BN / WN)), lds, ctx.stream, a);
+    hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, BK, MODE>), grid, dim3(64 * (BM / WM) * (BN / WN)), lds, ctx.stream, a);
 }
 
 template <int MODE>
 void launch_mode(const Ctx& ctx, const GemmArgs& a, int cfg) {
     switch (cfg) {
-        case 0: launch_cfg<128, 128, 64, 32, MODE>(ctx, a); break;  // 8 waves
-        case 1: launch_cfg<128, 64, 64, 32, MODE>(ctx, a); break;   // 4 waves
-        case 3: launch_cfg<128, 128, 64, 64, MODE>(ctx, a); break;  // 4 waves
-        case 4: launch_cfg<256, 128, 64, 64, MODE>(ctx, a); break;  // 8 waves
-        case 5: launch_cfg<128, 64, 32, 32, MODE>(ctx, a); break;   // 8 waves
-        default: launch_cfg<64, 64, 32, 32, MODE>(ctx, a); break;   // 4 waves
+        case 0: launch_cfg<128, 128, 64, 32, 32, MODE>(ctx, a); break;  // 8 waves
+        case 1: launch_cfg<128, 128, 64, 32, 64, MODE>(ctx, a); break;  // 8 waves, BK 64
+        case 3: launch_cfg<64, 64, 32, 32, 64, MODE>(ctx, a); break;    // 4 waves, BK 64
+        case 4: launch_cfg<128, 64, 32, 32, 64, MODE>(ctx, a); break;   // 8 waves, BK 64
+        case 5: launch_cfg<128, 64, 32, 32, 32, MODE>(ctx, a); break;   // 8 waves
+        default: launch_cfg<64, 64, 32, 32, 32, MODE>(ctx, a); break;   // 4 waves
     }
 }
 
