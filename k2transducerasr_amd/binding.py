@@ -100,6 +100,8 @@ def load_library():
     L.k2hip_offline_greedy_single.argtypes = [vp, fp, C.c_int64, lp, ip, ip, C.c_int32]
     L.k2hip_offline_greedy_from_samples.argtypes = [vp, C.POINTER(fp), lp, C.c_int32, lp, ip, ip, C.c_int32]
     L.k2hip_offline_greedy_from_samples_dev.argtypes = [vp, vp, C.c_int64, C.c_int32, lp, ip, ip, C.c_int32]
+    L.k2hip_offline_submit_samples_dev.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int32, ip]
+    L.k2hip_offline_wait.argtypes = [vp, C.c_int32, lp, ip, ip]
     L.k2hip_device_alloc.argtypes = [vp, C.c_int64, C.POINTER(vp)]
     L.k2hip_device_free.argtypes = [vp, vp]
     L.k2hip_device_upload.argtypes = [vp, vp, vp, C.c_int64]
@@ -330,6 +332,22 @@ class Model:
         ts = np.zeros((B, mt), np.int32)
         n = np.zeros(B, np.int32)
         self._chk(self._L.k2hip_offline_greedy_from_samples_dev(self._h, C.c_void_p(dev_ptr), n_each, B, _l(tok), _i(ts), _i(n), mt))
+        return self._unpack(tok, ts, n)
+
+
+    # pipelined form: submit() returns a ticket, wait(ticket) returns that batch's results
+    def offline_submit_samples_dev(self, dev_ptr: int, n_each: int, B: int, max_tokens: Optional[int] = None):
+        mt = max_tokens or max(1, self.encoder_out_frames(self.fbank_num_frames(n_each) + 19))
+        t = C.c_int32()
+        self._chk(self._L.k2hip_offline_submit_samples_dev(self._h, C.c_void_p(dev_ptr), n_each, B, mt, C.byref(t)))
+        return (t.value, B, mt)
+
+    def offline_wait(self, ticket):
+        t, B, mt = ticket
+        tok = np.zeros((B, mt), np.int64)
+        ts = np.zeros((B, mt), np.int32)
+        n = np.zeros(B, np.int32)
+        self._chk(self._L.k2hip_offline_wait(self._h, t, _l(tok), _i(ts), _i(n)))
         return self._unpack(tok, ts, n)
 
 

@@ -246,6 +246,22 @@ int32_t k2hip_offline_greedy_from_samples_dev(k2hip_model_t* model, const float*
     });
 }
 
+int32_t k2hip_offline_submit_samples_dev(k2hip_model_t* model, const float* samples_dev, int64_t n_samples_each, int32_t B,
+                                         int32_t max_tokens, int32_t* ticket) {
+    return guard([&] {
+        NEED(model); NEED(samples_dev); NEED(ticket);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        *ticket = model->engine.submit_samples_dev(samples_dev, n_samples_each, B, max_tokens);
+    });
+}
+int32_t k2hip_offline_wait(k2hip_model_t* model, int32_t ticket, int64_t* tokens, int32_t* timestamps, int32_t* n_tokens) {
+    return guard([&] {
+        NEED(model); NEED(tokens); NEED(timestamps); NEED(n_tokens);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        model->engine.wait_ticket(ticket, tokens, timestamps, n_tokens);
+    });
+}
+
 int32_t k2hip_device_alloc(k2hip_model_t* model, int64_t bytes, void** dev_ptr) {
     return guard([&] {
         NEED(model); NEED(dev_ptr);

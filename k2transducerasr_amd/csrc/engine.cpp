@@ -17,12 +17,25 @@ Engine::Engine(const std::string& weights, const char* overrides, int device) : 
     K2_HIP(hipSetDevice(device));
     model_.reset(new Model(weights, overrides, device));
     K2_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    K2_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+    for (auto& sl : slots_) {
+        K2_HIP(hipEventCreateWithFlags(&sl.enc_done, hipEventDisableTiming));
+        K2_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
     for (auto& e : ev_) K2_HIP(hipEventCreate(&e));
 }
 
 Engine::~Engine() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
+    if (stream2_) (void)hipStreamSynchronize(stream2_);
+    for (auto& sl : slots_) {
+        if (sl.enc_done) (void)hipEventDestroy(sl.enc_done);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.pin) (void)hipHostFree(sl.pin);
+        sl.arena.release();
+    }
+    if (stream2_) (void)hipStreamDestroy(stream2_);
     for (auto& kv : pe_cache_) (void)hipFree(kv.second);
     for (auto& e : ev_)
         if (e) (void)hipEventDestroy(e);
@@ -46,7 +59,7 @@ void* Engine::pinned(int64_t bytes) {
 Ctx Engine::make_ctx(bool dry) {
     Ctx c;
     c.stream = stream_;
-    c.arena = &arena_;
+    c.arena = cur_arena_;
     c.dry = dry;
     c.instrument = instrument_ && !dry;
     c.stats = &stats_;
@@ -59,22 +72,22 @@ template <typename F>
 void Engine::run_sized(F&& body) {
     K2_HIP(hipSetDevice(device_));
     stats_ = GemmStats();
-    arena_.reset();
-    arena_.set_dry(true);
+    cur_arena_->reset();
+    cur_arena_->set_dry(true);
     try {
         Ctx d = make_ctx(true);
         body(d);
     } catch (...) {
-        arena_.set_dry(false);
-        arena_.reset();
+        cur_arena_->set_dry(false);
+        cur_arena_->reset();
         throw;
     }
-    arena_.set_dry(false);
-    int64_t need = arena_.high_water();
-    arena_.reset();
-    if (need > arena_.capacity()) {
+    cur_arena_->set_dry(false);
+    int64_t need = cur_arena_->high_water();
+    cur_arena_->reset();
+    if (need > cur_arena_->capacity()) {
         K2_HIP(hipStreamSynchronize(stream_));
-        arena_.reserve(need + need / 8);
+        cur_arena_->reserve(need + need / 8);
     }
     Ctx c = make_ctx(false);
     evused_ = 0;
@@ -707,6 +720,85 @@ void Engine::offline_greedy_samples(const float* const* samples, const int64_t* 
     offline_greedy_feats(ptrs.data(), nfl.data(), B, false, tokens, ts, n_tokens, max_tokens);
 }
 
+int Engine::submit_samples_dev(const float* samples_dev, int64_t n_each, int B, int max_tokens) {
+    K2_REQUIRE(B > 0 && max_tokens > 0 && samples_dev != nullptr, "offline_submit: bad arguments");
+    const Config& cf = model_->cfg();
+    const FbankOpts& f = cf.fbank;
+    K2_REQUIRE(cf.J == 512, "offline loops hard-code a 512-wide encoder_out; joiner_dim is %d", cf.J);
+    const int64_t nf = fbank_num_frames(n_each);
+    K2_REQUIRE(nf > 0, "offline_submit: %lld samples give no frame", (long long)n_each);
+    const int ticket = next_slot_;
+    Slot& sl = slots_[ticket];
+    if (sl.busy) failf(K2HIP_ERR_INVALID, "offline_submit: %d batches already in flight; wait for one first", kSlots);
+    const int64_t n_fl = nf * cf.feat, L = n_fl + 80 * kTailFrames;
+    const int T = (int)(L / cf.feat);
+    const int64_t nb = (int64_t)B * max_tokens * 12 + (int64_t)B * 4 + 64;
+    if (nb > sl.pin_cap) {
+        if (sl.pin) K2_HIP(hipHostFree(sl.pin));
+        sl.pin = nullptr;
+        sl.pin_cap = 0;
+        K2_HIP(hipHostMalloc(&sl.pin, (size_t)nb, hipHostMallocDefault));
+        sl.pin_cap = nb;
+    }
+    cur_arena_ = &sl.arena;
+    try {
+        run_sized([&](const Ctx& c) {
+            Arena& ar = *c.arena;
+            sl.d_tok = ar.take<long long>((int64_t)B * max_tokens);
+            sl.d_ts = ar.take<int>((int64_t)B * max_tokens);
+            sl.d_n = ar.take<int>(B);
+            sl.d_ovf = ar.take<int>(1);
+            float* d_feats = ar.take<float>((int64_t)B * n_fl);
+            float* d_x = ar.take<float>((int64_t)B * L);
+            FbankArgs a{samples_dev, n_each, n_each, B, nf, d_feats, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift,
+                        f.preemph, f.input_scale, f.remove_dc};
+            fbank(c, a);
+            pad_logfloor_dense(c, d_feats, n_fl, d_x, B, L);
+            int Tp = 0;
+            float* enc = encoder_forward(c, d_x, B, T, &Tp, -1, nullptr, nullptr, nullptr);
+            Ctx cd = c;
+            cd.stream = stream2_;
+            cd.instrument = false;
+            if (!c.dry) {
+                K2_HIP(hipEventRecord(sl.enc_done, c.stream));
+                K2_HIP(hipStreamWaitEvent(stream2_, sl.enc_done, 0));
+            }
+            greedy_device(cd, enc, B, Tp, false, sl.d_tok, sl.d_ts, sl.d_n, max_tokens, sl.d_ovf);
+        });
+    } catch (...) {
+        cur_arena_ = &arena_;
+        throw;
+    }
+    cur_arena_ = &arena_;
+    const int64_t nb_tok = (int64_t)B * max_tokens * 8, nb_ts = (int64_t)B * max_tokens * 4, nb_n = (int64_t)B * 4;
+    char* pin = static_cast<char*>(sl.pin);
+    K2_HIP(hipMemcpyAsync(pin, sl.d_tok, nb_tok, hipMemcpyDeviceToHost, stream2_));
+    K2_HIP(hipMemcpyAsync(pin + nb_tok, sl.d_ts, nb_ts, hipMemcpyDeviceToHost, stream2_));
+    K2_HIP(hipMemcpyAsync(pin + nb_tok + nb_ts, sl.d_n, nb_n, hipMemcpyDeviceToHost, stream2_));
+    K2_HIP(hipMemcpyAsync(pin + nb_tok + nb_ts + nb_n, sl.d_ovf, 4, hipMemcpyDeviceToHost, stream2_));
+    K2_HIP(hipEventRecord(sl.done, stream2_));
+    sl.B = B;
+    sl.max_tokens = max_tokens;
+    sl.busy = true;
+    next_slot_ = (next_slot_ + 1) % kSlots;
+    return ticket;
+}
+
+void Engine::wait_ticket(int ticket, int64_t* tokens, int32_t* ts, int32_t* n_tokens) {
+    K2_REQUIRE(ticket >= 0 && ticket < kSlots && slots_[ticket].busy, "offline_wait: ticket %d is not in flight", ticket);
+    K2_HIP(hipSetDevice(device_));
+    Slot& sl = slots_[ticket];
+    K2_HIP(hipEventSynchronize(sl.done));
+    sl.busy = false;
+    const int64_t nb_tok = (int64_t)sl.B * sl.max_tokens * 8, nb_ts = (int64_t)sl.B * sl.max_tokens * 4, nb_n = (int64_t)sl.B * 4;
+    const char* pin = static_cast<const char*>(sl.pin);
+    if (*reinterpret_cast<const int*>(pin + nb_tok + nb_ts + nb_n))
+        failf(K2HIP_ERR_CAPACITY, "a stream emitted more than max_tokens=%d symbols", sl.max_tokens);
+    memcpy(tokens, pin, nb_tok);
+    memcpy(ts, pin + nb_tok, nb_ts);
+    memcpy(n_tokens, pin + nb_tok + nb_ts, nb_n);
+}
+
 // tuning hook: average time of one Linear-shaped GEMM on uniform random data
 float Engine::debug_gemm(int M, int N, int K, int act, bool with_res, int iters) {
     K2_HIP(hipSetDevice(device_));
@@ -753,6 +845,7 @@ void Engine::dev_upload(void* dst, const void* src, int64_t bytes) {
 void Engine::synchronize() {
     K2_HIP(hipSetDevice(device_));
     K2_HIP(hipStreamSynchronize(stream_));
+    K2_HIP(hipStreamSynchronize(stream2_));
 }
 
 }  // namespace k2hip

@@ -44,6 +44,15 @@ class Engine {
     void offline_greedy_samples_dev(const float* samples_dev, int64_t n_each, int B, int64_t* tokens, int32_t* ts,
                                     int32_t* n_tokens, int max_tokens);
 
+    // ---- pipelined (asynchronous) form of offline_greedy_samples_dev ----
+    // submit() enqueues fbank + pad + encoder on the encoder stream and the greedy loop + D2H
+    // on a second stream, then returns; wait() blocks on that batch only.  With two batches in
+    // flight the latency-bound greedy loop (32 workgroups) of batch i overlaps the MFMA-bound
+    // encoder of batch i+1.  At most kSlots batches may be outstanding.
+    static constexpr int kSlots = 2;
+    int submit_samples_dev(const float* samples_dev, int64_t n_each, int B, int max_tokens);
+    void wait_ticket(int ticket, int64_t* tokens, int32_t* ts, int32_t* n_tokens);
+
     void set_instrument(bool on) { instrument_ = on; }
     const k2hip_timing& timing() const { return timing_; }
 
@@ -76,6 +85,19 @@ class Engine {
     int device_;
     hipStream_t stream_ = nullptr;
     Arena arena_;
+    Arena* cur_arena_ = &arena_;
+    struct Slot {
+        Arena arena;
+        hipEvent_t enc_done = nullptr, done = nullptr;
+        void* pin = nullptr;
+        int64_t pin_cap = 0;
+        long long* d_tok = nullptr;
+        int *d_ts = nullptr, *d_n = nullptr, *d_ovf = nullptr;
+        int B = 0, max_tokens = 0;
+        bool busy = false;
+    } slots_[kSlots];
+    int next_slot_ = 0;
+    hipStream_t stream2_ = nullptr;
     std::mutex mu_;
     std::map<int, float*> pe_cache_;
     bool instrument_ = false;

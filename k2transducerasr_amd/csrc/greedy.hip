@@ -120,9 +120,13 @@ __global__ void k_first_emit(const int* __restrict__ tok, int B, int Tp, int ski
 // exactly the frame-by-frame loop of OfflineRecognizer.cs:216-288.
 constexpr int GF = 8;      // frames per round
 constexpr int GT = 1024;   // threads per workgroup (16 waves)
+// the 8 k slices of a wave read actT rows kper*GF floats apart (a multiple of 64 dwords: the same
+// LDS banks, an 8-way conflict on every read); skew each slice by APAD floats
+constexpr int APAD = 8;
 
 // dec_out[J] = decoder_proj(relu(grouped_conv(emb[y0], emb[y1]))), GT threads, two per output
-__device__ void decoder_block_wide(const DecJoinW& w, long long y0, long long y1, float* h, float* out) {
+__device__ void decoder_block_wide(const DecJoinW& w, long long y0, long long y1, float* h, float* scratch /* >= 8*J floats */,
+                                   float* out) {
     const int tid = threadIdx.x;
     for (int co = tid; co < w.DD; co += GT) {
         int g4 = (co >> 2) << 2;
@@ -137,16 +141,34 @@ __device__ void decoder_block_wide(const DecJoinW& w, long long y0, long long y1
         h[co] = fmaxf(s, 0.f);
     }
     __syncthreads();
-    const int khalf = w.DD >> 1;
-    for (int n2 = tid; n2 < 2 * w.J; n2 += GT) {
-        const int n = n2 >> 1, half = n2 & 1;
-        const float* wp = w.dproj_kn + (long long)(half * khalf) * w.J + n;
-        const float* hp = h + half * khalf;
-        float s = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < khalf; k++) s += hp[k] * wp[(long long)k * w.J];
-        s += __shfl_xor(s, 1);
-        if (!half) out[n] = s + w.dproj_b[n];
+    // decoder_proj: 8 k slices x J/4 column groups; 8 float4 weight loads in flight per thread
+    // (a dependent load per FMA made this ~50 us per emission), partials combined through LDS
+    const int ncg = w.J >> 2, kslice = (w.DD + 7) >> 3;
+    for (int u = tid; u < 8 * ncg; u += GT) {
+        const int ks = u / ncg, cg = u - ks * ncg;
+        const int k0 = ks * kslice, k1 = min(k0 + kslice, w.DD);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int kb = k0; kb < k1; kb += 8) {
+            float4 wv[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int k = min(kb + i, k1 - 1);
+                wv[i] = *reinterpret_cast<const float4*>(w.dproj_kn + (long long)k * w.J + 4 * cg);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float hv = (kb + i < k1) ? h[kb + i] : 0.f;
+                s.x += hv * wv[i].x; s.y += hv * wv[i].y; s.z += hv * wv[i].z; s.w += hv * wv[i].w;
+            }
+        }
+        *reinterpret_cast<float4*>(scratch + ks * w.J + 4 * cg) = s;
+    }
+    __syncthreads();
+    for (int n = tid; n < w.J; n += GT) {
+        float s = w.dproj_b[n];
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) s += scratch[ks * w.J + n];
+        out[n] = s;
     }
     __syncthreads();
 }
@@ -155,7 +177,7 @@ __device__ void decoder_block_wide(const DecJoinW& w, long long y0, long long y1
 __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* actT = sm;
-    float* dec_a = actT + w.J * GF;
+    float* dec_a = actT + w.J * GF + 8 * APAD;
     float* dec_b = dec_a + w.J;
     float* dec_own = dec_b + w.J;
     float* h = dec_own + w.J;
@@ -170,8 +192,8 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
     const int t0 = a.t0 ? *a.t0 : INT_MAX;
     const int ncg = w.Vp >> 2, kper = w.J >> 3;
 
-    decoder_block_wide(w, -1, K2HIP_BLANK_ID, h, dec_a);
-    if (a.t0) decoder_block_wide(w, K2HIP_BLANK_ID, K2HIP_BLANK_ID, h, dec_b);
+    decoder_block_wide(w, -1, K2HIP_BLANK_ID, h, actT, dec_a);
+    if (a.t0) decoder_block_wide(w, K2HIP_BLANK_ID, K2HIP_BLANK_ID, h, actT, dec_b);
 
     long long y0 = -1, y1 = K2HIP_BLANK_ID;
     int n_tok = 0, t = 0;
@@ -187,7 +209,7 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
                 const float* d = own ? dec_own : ((t + f) > t0 ? dec_b : dec_a);
                 v = tanhf(enc[(long long)(t + f) * w.J + k] + d[k]);
             }
-            actT[k * GF + f] = v;
+            actT[k * GF + (k / kper) * APAD + f] = v;
         }
         __syncthreads();
         float bestv[GF];
@@ -204,19 +226,27 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
                 for (int j = 0; j < 4; j++) acc[f][j] = 0.f;
             if (valid) {
                 const float* wp = w.out_kn + (long long)(ks * kper) * w.Vp + 4 * cg;
-                const float* ap = actT + (ks * kper) * GF;
-#pragma unroll 4
-                for (int k = 0; k < kper; k++) {
-                    const float4 wv = *reinterpret_cast<const float4*>(wp + (long long)k * w.Vp);
-                    const float4 a0 = *reinterpret_cast<const float4*>(ap + k * GF);
-                    const float4 a1 = *reinterpret_cast<const float4*>(ap + k * GF + 4);
-                    const float av[GF] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                const float* ap = actT + (ks * kper) * GF + ks * APAD;
+                for (int kb = 0; kb < kper; kb += 8) {
+                    // 8 weight loads in flight per thread before any FMA: the sweep is L2-latency bound
+                    float4 wv[8];
 #pragma unroll
-                    for (int f = 0; f < GF; f++) {
-                        acc[f][0] += av[f] * wv.x;
-                        acc[f][1] += av[f] * wv.y;
-                        acc[f][2] += av[f] * wv.z;
-                        acc[f][3] += av[f] * wv.w;
+                    for (int i = 0; i < 8; i++)
+                        wv[i] = *reinterpret_cast<const float4*>(wp + (long long)min(kb + i, kper - 1) * w.Vp);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int k = min(kb + i, kper - 1);
+                        const float m = (kb + i < kper) ? 1.f : 0.f;
+                        const float4 a0 = *reinterpret_cast<const float4*>(ap + k * GF);
+                        const float4 a1 = *reinterpret_cast<const float4*>(ap + k * GF + 4);
+                        const float av[GF] = {a0.x * m, a0.y * m, a0.z * m, a0.w * m, a1.x * m, a1.y * m, a1.z * m, a1.w * m};
+#pragma unroll
+                        for (int f = 0; f < GF; f++) {
+                            acc[f][0] += av[f] * wv[i].x;
+                            acc[f][1] += av[f] * wv[i].y;
+                            acc[f][2] += av[f] * wv[i].z;
+                            acc[f][3] += av[f] * wv[i].w;
+                        }
                     }
                 }
             }
@@ -280,7 +310,7 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
             }
         }
         t += adv;
-        if (emitted) decoder_block_wide(w, y0, y1, h, dec_own);
+        if (emitted) decoder_block_wide(w, y0, y1, h, actT, dec_own);
         else __syncthreads();  // actT / fin are rewritten by the next round
     }
     if (tid == 0) a.n_tokens[b] = n_tok < a.max_tokens ? n_tok : a.max_tokens;
@@ -312,7 +342,7 @@ void first_emit_frame(const Ctx& ctx, const int* tok, int B, int Tp, int skip1, 
 void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a) {
     if (ctx.dry || a.B <= 0) return;
     K2_REQUIRE(w.J % 8 == 0, "greedy: joiner_dim %d must be a multiple of 8", w.J);
-    size_t lds = sizeof(float) * ((size_t)w.J * GF + 3 * (size_t)w.J + w.DD + 32 * GF + GF + 8);
+    size_t lds = sizeof(float) * ((size_t)w.J * GF + 8 * APAD + 3 * (size_t)w.J + w.DD + 32 * GF + GF + 8);
     K2_REQUIRE(lds <= 160 * 1024, "greedy: vocab %d / joiner %d need %zu B of LDS", w.V, w.J, lds);
     static bool attr_set = false;
     if (!attr_set) {

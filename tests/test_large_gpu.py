@@ -74,6 +74,24 @@ def test_full_size_batch_properties(hip_large):
     finally:
         hip_large.device_free(ptr)
     assert r1 == r2
+    # pipelined submit/wait gives the same tokens, in submission order, with two batches in flight
+    ptr2 = hip_large.device_alloc(s.nbytes)
+    try:
+        hip_large.device_upload(ptr2, s[::-1].copy())
+        ptr3 = hip_large.device_alloc(s.nbytes)
+        hip_large.device_upload(ptr3, s)
+        ta = hip_large.offline_submit_samples_dev(ptr3, s.shape[1], B)
+        tb = hip_large.offline_submit_samples_dev(ptr2, s.shape[1], B)
+        from k2transducerasr_amd import K2HipError
+        with pytest.raises(K2HipError):
+            hip_large.offline_submit_samples_dev(ptr3, s.shape[1], B)  # only two slots
+        ra = hip_large.offline_wait(ta)
+        rb = hip_large.offline_wait(tb)
+        assert ra == r1
+        assert rb == hip_large.offline_greedy_from_samples_dev(ptr2, s.shape[1], B)
+        hip_large.device_free(ptr3)
+    finally:
+        hip_large.device_free(ptr2)
     assert r1 == hip_large.greedy_batch(enc)
     for tok, ts in r1:
         assert len(tok) == len(ts) and all(0 <= t < 253 for t in ts) and ts == sorted(ts)
