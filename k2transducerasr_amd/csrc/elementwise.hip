@@ -18,6 +18,8 @@ __device__ __forceinline__ float fast_tanh(float v) {
     return v < 0.f ? -t : t;
 }
 
+__device__ __forceinline__ float sigm(float s) { return 1.0f / (1.0f + __expf(-s)); }
+
 inline int nblocks(long long n, int per) { return (int)((n + per - 1) / per); }
 
 // ---- F3: PadHelper.PadSequence (PadHelper.cs:20-60) on device ------------------
@@ -158,7 +160,6 @@ __global__ void k_bypass(const float* __restrict__ orig, const float* __restrict
                                                   g.z + (v.z - g.z) * s.z, g.w + (v.w - g.w) * s.w);
 }
 
-__device__ __forceinline__ float sigm(float s) { return 1.0f / (1.0f + __expf(-s)); }
 
 // y[m, d] = x[m, d] * sigmoid(x[m, D + d])       x: [M, 2D]
 __global__ void k_glu(const float* __restrict__ x, float* __restrict__ y, long long n4, int D4) {
@@ -191,38 +192,51 @@ __global__ void k_mul_cols(float* __restrict__ a, const float* __restrict__ x, i
     reinterpret_cast<float4*>(a)[i] = make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
 }
 
-// ---- ConvolutionModule depthwise Conv1d over time (zero pad K/2) + bias + SwooshR
-//  x,y: [B,T,D]; w: [K][D].  One thread = 4 channels x TT consecutive frames with a
-//  sliding register window, so every input row is read once per TT outputs.
-template <int TT>
-__global__ void k_dwconv1d(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                           float* __restrict__ y, int B, int T, int D, int K) {
-    int D4 = D >> 2;
-    int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= D4) return;
-    int t0 = blockIdx.y * TT, b = blockIdx.z;
-    int c = q * 4;
-    float4 acc[TT];
-    float4 bv = *reinterpret_cast<const float4*>(bias + c);
+// ---- ConvolutionModule: GLU + depthwise Conv1d over time (zero pad K/2) + bias + SwooshR
+//  x2: [B,T,2D] (in_proj output: value | gate), y: [B,T,D], w: [K][D].
+//  One workgroup = 4 waves = 32 output frames x 256 channels.  The GLU'd input strip
+//  (32 + K - 1 frames) is staged once in LDS with 1 KB coalesced row loads; lane = channel
+//  quad, so every LDS read of a wave is one conflict-free 1 KB row segment.
+constexpr int DW_TT = 8;                 // outputs per thread
+constexpr int DW_ROWS = 4 * DW_TT;       // output frames per workgroup
+__global__ __launch_bounds__(256) void k_glu_dwconv1d(const float* __restrict__ x2, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y, int B, int T,
+                                                      int D, int K) {
+    extern __shared__ __attribute__((aligned(16))) float sx[];  // [DW_ROWS + K - 1][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = blockIdx.x * 256 + lane * 4;
+    const int t0 = blockIdx.y * DW_ROWS, b = blockIdx.z;
+    const int half = K >> 1, nrows = DW_ROWS + K - 1;
+    const bool cok = c < D;
+    for (int r = wave; r < nrows; r += 4) {
+        const int u = t0 - half + r;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cok && u >= 0 && u < T) {
+            const float* row = x2 + ((long long)b * T + u) * 2 * D;
+            const float4 a = *reinterpret_cast<const float4*>(row + c);
+            const float4 sg = *reinterpret_cast<const float4*>(row + D + c);
+            g = make_float4(a.x * sigm(sg.x), a.y * sigm(sg.y), a.z * sigm(sg.z), a.w * sigm(sg.w));
+        }
+        *reinterpret_cast<float4*>(sx + r * 256 + lane * 4) = g;
+    }
+    __syncthreads();
+    if (!cok) return;
+    float4 acc[DW_TT];
+    const float4 bv = *reinterpret_cast<const float4*>(bias + c);
 #pragma unroll
-    for (int i = 0; i < TT; i++) acc[i] = bv;
-    int half = K >> 1;
-    // input frames t0-half .. t0+TT-1+half ; frame u contributes to output t with tap k = u - t + half
-    for (int u = t0 - half; u < t0 + TT + half; u++) {
-        if (u < 0 || u >= T) continue;
-        float4 xv = *reinterpret_cast<const float4*>(x + ((long long)b * T + u) * D + c);
+    for (int i = 0; i < DW_TT; i++) acc[i] = bv;
+    const float* base = sx + (wave * DW_TT) * 256 + lane * 4;
+    for (int k = 0; k < K; k++) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + k * D + c);
 #pragma unroll
-        for (int i = 0; i < TT; i++) {
-            int k = u - (t0 + i) + half;
-            if (k >= 0 && k < K) {
-                float4 wv = *reinterpret_cast<const float4*>(w + k * D + c);
-                acc[i].x += wv.x * xv.x; acc[i].y += wv.y * xv.y; acc[i].z += wv.z * xv.z; acc[i].w += wv.w * xv.w;
-            }
+        for (int i = 0; i < DW_TT; i++) {
+            const float4 xv = *reinterpret_cast<const float4*>(base + (i + k) * 256);
+            acc[i].x += wv.x * xv.x; acc[i].y += wv.y * xv.y; acc[i].z += wv.z * xv.z; acc[i].w += wv.w * xv.w;
         }
     }
 #pragma unroll
-    for (int i = 0; i < TT; i++) {
-        int t = t0 + i;
+    for (int i = 0; i < DW_TT; i++) {
+        const int t = t0 + wave * DW_TT + i;
         if (t < T)
             *reinterpret_cast<float4*>(y + ((long long)b * T + t) * D + c) =
                 make_float4(swoosh_r(acc[i].x), swoosh_r(acc[i].y), swoosh_r(acc[i].z), swoosh_r(acc[i].w));
@@ -336,13 +350,20 @@ void mul_cols(const Ctx& ctx, float* a, const float* x, int ldx, int col0, int M
     long long n4 = (long long)M * N / 4;
     LAUNCH(k_mul_cols, dim3(nblocks(n4, 256)), dim3(256), a, x, ldx, col0, n4, N / 4);
 }
-void dwconv1d_swoosh(const Ctx& ctx, const float* x, const float* w_kd, const float* b, float* y, int B, int T, int D, int K) {
-    constexpr int TT = 8;
-    int D4 = D / 4;
-    int bx = std::min(D4, 64);
-    dim3 grid(cdiv(D4, bx), cdiv(T, TT), B);
-    LAUNCH((k_dwconv1d<TT>), grid, dim3(bx), x, w_kd, b, y, B, T, D, K);
+void glu_dwconv1d_swoosh(const Ctx& ctx, const float* x2, const float* w_kd, const float* b, float* y, int B, int T, int D,
+                          int K) {
+    K2_REQUIRE(D % 4 == 0, "dwconv1d: D=%d", D);
+    size_t lds = sizeof(float) * (size_t)(DW_ROWS + K - 1) * 256;
+    dim3 grid(cdiv(D, 256), cdiv(T, DW_ROWS), B);
     ctx.add_flops(0.0, 2.0 * B * T * (double)D * K, 0);
+    if (ctx.dry) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_glu_dwconv1d), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_glu_dwconv1d, grid, dim3(256), lds, ctx.stream, x2, w_kd, b, y, B, T, D, K);
+    K2_HIP(hipGetLastError());
 }
 void downsample(const Ctx& ctx, const float* x, const float* bias, float* y, int B, int T, int D, int ds) {
     int Td = (T + ds - 1) / ds;

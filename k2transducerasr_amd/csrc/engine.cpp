@@ -265,8 +265,7 @@ void Engine::encoder_layer(const Ctx& c, int si, int li, float* x, const float* 
         snprintf(e, sizeof e, "conv_module%d.out_proj.weight", k);
         snprintf(f, sizeof f, "conv_module%d.out_proj.bias", k);
         linear(c, src, D, w(a), w(b), hid, 2 * D, M, D, 2 * D);
-        glu_sigmoid(c, hid, tmp, M, D);
-        dwconv1d_swoosh(c, tmp, w(cc), w(d), tmp2, B, T, D, K);
+        glu_dwconv1d_swoosh(c, hid, w(cc), w(d), tmp2, B, T, D, K);
         linear(c, tmp2, D, w(e), w(f), src, D, M, D, D, ACT_NONE, src, D);
     };
 

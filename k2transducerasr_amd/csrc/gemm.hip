@@ -179,6 +179,23 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+    // residual operand: fetched now, consumed in the epilogue, so its latency (it was written
+    // by the previous kernel and usually sits in L2/MALL) hides behind the whole K loop
+    float rres[MT][NT][16];
+    if (R) {
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int col = min(n0 + wc * WN + j * 32 + li, g.N - 1);
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = min(m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
+                    rres[i][j][r] = R[(long long)row * g.ldr + col];
+                }
+        }
+    }
+
     const int nk = (g.K + BK - 1) / BK;
     const int nfull = g.K / BK;  // tiles [0, nfull) are complete
     if (nfull > 0) K2_LOAD_TILE(0) else K2_LOAD_TAIL(0)
@@ -250,7 +267,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
                 int row = m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < g.M && !(g.ablate & 4)) {
                     float v = apply_act(acc[i][j][r] + bv, g.act);
-                    if (R) v += R[(long long)row * g.ldr + col];
+                    if (R) v += rres[i][j][r];
                     C[(long long)row * g.ldc + col] = v;
                 }
             }

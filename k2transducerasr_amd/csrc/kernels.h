@@ -93,7 +93,9 @@ void bypass(const Ctx& ctx, const float* orig, const float* x, const float* scal
 void glu_sigmoid(const Ctx& ctx, const float* x, float* y, int M, int D);          // y = x[:, :D] * sigmoid(x[:, D:])
 void tanh_gate(const Ctx& ctx, const float* x, float* y, int M, int Hc);           // y = x[:, Hc:2Hc] * tanh(x[:, :Hc])
 void mul_cols(const Ctx& ctx, float* a, const float* x, int ldx, int col0, int M, int N);  // a[m,n] *= x[m, col0+n]
-void dwconv1d_swoosh(const Ctx& ctx, const float* x, const float* w_kd, const float* b, float* y, int B, int T, int D, int K);
+// y = SwooshR(dwconv1d(glu(x2)) + b);  x2: [B,T,2D] value|gate
+void glu_dwconv1d_swoosh(const Ctx& ctx, const float* x2, const float* w_kd, const float* b, float* y, int B, int T, int D,
+                          int K);
 void downsample(const Ctx& ctx, const float* x, const float* bias, float* y, int B, int T, int D, int ds);
 void upsample_combine(const Ctx& ctx, const float* orig, const float* xd, const float* scale, float* y, int B, int T,
                       int Td, int D, int ds);
