@@ -275,6 +275,164 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// LDS-DMA variant (plain Linear, K % 32 == 0): global -> LDS directly with
+// global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass), THREE LDS stages, a counted
+// s_waitcnt vmcnt and ONE raw s_barrier per K step, so the DMA of tile kt+2 is in flight
+// across the barrier while tile kt feeds the MFMAs.
+//   * the LDS image of a stage is lane-linear (a wave instruction writes 64 x 16 B = 8 rows of
+//     32 floats); bank conflicts of the 128-byte rows are removed by swizzling on the SOURCE
+//     side: slot (row r, chunk c') receives logical chunk c = c' ^ ((r >> 1) & 7), and the
+//     fragment reads apply the same XOR.
+//   * rows beyond M / N are clamped to the last valid row (never stored).
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(GemmArgs g) {
+    constexpr int BK = 32, NST = 3;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int WCOLS = BN / WN;
+    constexpr int NW = (BM / WM) * (BN / WN);
+    constexpr int NINST = (BM + BN) / 8;       // 1 KB wave-instructions per tile
+    static_assert(NINST % NW == 0, "DMA instructions must divide evenly over the waves");
+    constexpr int IPW = NINST / NW;            // per wave
+    constexpr int STAGE = (BM + BN) * BK;      // floats per stage
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [NST][STAGE]: A rows then W rows
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WCOLS, wc = wave % WCOLS;
+    const int li = lane & 31, lh = lane >> 5;
+    const float* __restrict__ A = g.A;
+    const float* __restrict__ W = g.W;
+    float* __restrict__ C = g.C;
+    const float* __restrict__ R = g.res;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    // this lane's source pointer for each of the wave's DMA instructions (advances by BK per tile)
+    const float* src[IPW];
+#pragma unroll
+    for (int q = 0; q < IPW; q++) {
+        const int inst = wave + q * NW;          // wave-uniform
+        const int slot = inst * 64 + lane;       // 16-byte slot within the stage
+        const int r = slot >> 3, cp = slot & 7;  // row of the combined [A;W] tile, physical chunk
+        const int c = cp ^ ((r >> 1) & 7);       // logical k chunk this slot holds
+        if (inst < BM / 8) src[q] = A + (long long)min(m0 + r, g.M - 1) * g.lda + 4 * c;
+        else src[q] = W + (long long)min(n0 + (r - BM), g.N - 1) * g.ldw + 4 * c;
+    }
+    // The DMA is issued through inline asm: with the builtin, hipcc treats it as a pending LDS
+    // write and drains vmcnt(0) in front of every ds_read, which serialises the pipeline.  In asm
+    // the instruction is invisible to the compiler's wait-count bookkeeping; completion is
+    // tracked by the hand-counted s_waitcnt vmcnt below (M0 = wave-uniform LDS byte address of the
+    // 1 KB destination; written and restored inside the same statement).
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int q = 0; q < IPW; q++) {
+            const int inst = wave + q * NW;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + ((kt % NST) * STAGE + inst * 256) * 4);
+            const float* gp = src[q] + kt * BK;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(gp), "s"(dst)
+                         : "memory");
+        }
+    };
+
+    float rres[MT][NT][16];
+    if (R) {
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int col = min(n0 + wc * WN + j * 32 + li, g.N - 1);
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = min(m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
+                    rres[i][j][r] = R[(long long)row * g.ldr + col];
+                }
+        }
+        // the residual loads are ordinary VMEM ops: retire them before the DMA pipeline starts so
+        // that the counted vmcnt below only ever counts DMA instructions
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int nk = g.K / BK;
+    // fragment addressing: row-dependent XOR (rows of one lane differ by multiples of 32 -> same XOR)
+    const int arow = wr * WM + li, brow = wc * WN + li;
+    const int swa = (arow >> 1) & 7, swb = ((BM + brow) >> 1) & 7;
+
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int kt = 0; kt < nk; kt++) {
+        // tile kt landed for this wave once at most the newest tile's IPW instructions are pending
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ... and for every wave; also: everyone is done reading stage (kt+2)%3
+        if (kt + 2 < nk) issue(kt + 2);
+        const float* sa = smem + (kt % NST) * STAGE + arow * BK;
+        const float* sb = smem + (kt % NST) * STAGE + (BM + brow) * BK;
+#pragma unroll
+        for (int gk = 0; gk < 4; gk++) {
+            float4 fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; i++) fa[i] = *reinterpret_cast<const float4*>(sa + i * 32 * BK + (((2 * gk + lh) ^ swa) << 2));
+#pragma unroll
+            for (int j = 0; j < NT; j++) fb[j] = *reinterpret_cast<const float4*>(sb + j * 32 * BK + (((2 * gk + lh) ^ swb) << 2));
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int j = 0; j < NT; j++) {
+                        const float av = e == 0 ? fa[i].x : e == 1 ? fa[i].y : e == 2 ? fa[i].z : fa[i].w;
+                        const float bv = e == 0 ? fb[j].x : e == 1 ? fb[j].y : e == 2 ? fb[j].z : fb[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        int col = n0 + wc * WN + j * 32 + li;
+        if (col >= g.N) continue;
+        float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int row = m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < g.M) {
+                    float v = apply_act(acc[i][j][r] + bv, g.act);
+                    if (R) v += rres[i][j][r];
+                    C[(long long)row * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_dma(const Ctx& ctx, const GemmArgs& a) {
+    dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), 1);
+    size_t lds = sizeof(float) * 3 * (BM + BN) * 32;
+    static bool attr_set = false;
+    if (!attr_set) {
+        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_dma<BM, BN, WM, WN>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f32_mfma_dma<BM, BN, WM, WN>), grid, dim3(64 * (BM / WM) * (BN / WN)), lds, ctx.stream, a);
+}
+
 template <int BM, int BN, int WM, int WN, int BK, int MODE>
 void launch_cfg(const Ctx& ctx, const GemmArgs& a) {
     constexpr int LDSK = BK + 4;
@@ -312,16 +470,21 @@ int g_forced_cfg = getenv("K2HIP_GEMM_CFG") ? atoi(getenv("K2HIP_GEMM_CFG")) : -
 //   cfg 2:  64x64,  4 waves (32x32 per wave)
 int choose_cfg(const GemmArgs& a) {
     if (g_forced_cfg >= 0) return g_forced_cfg;
-    if (a.N <= 64) return 2;
-    const double out = (double)a.M * a.N * a.nb0 * a.nb1;
-    if (out >= 7.0e6 && a.N >= 256) return 0;
-    return 5;
+    if (a.N <= 64) return 2;    // 64x64 tiles, 4 waves
+    if (a.N <= 128) return 3;   // 64x64 tiles, K step 64
+    return 5;                   // 128x64 tiles, 8 waves (LDS-DMA pipeline when K % 32 == 0)
 }
 
 }  // namespace
 
 int g_ablate = 0;
-void debug_force_gemm_cfg(int cfg) { g_forced_cfg = cfg & 0xff; g_ablate = cfg < 0 ? 0 : (cfg >> 8); if (cfg < 0) g_forced_cfg = -1; }
+int g_use_dma = getenv("K2HIP_GEMM_NO_DMA") ? 0 : 1;
+void debug_force_gemm_cfg(int cfg) {
+    static const int dma_default = g_use_dma;
+    g_forced_cfg = cfg < 0 ? -1 : (cfg & 0x3f);
+    g_ablate = cfg < 0 ? 0 : (cfg >> 8);
+    g_use_dma = (cfg >= 0 && (cfg & 0x40)) ? 0 : dma_default;  // +64: classic (register-staged) kernel
+}
 
 void gemm(const Ctx& ctx, const GemmArgs& a) {
     K2_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty shape %dx%dx%d", a.M, a.N, a.K);
@@ -340,6 +503,14 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     int cfg = choose_cfg(a);
     GemmArgs b = a;
     b.ablate = g_ablate;
+    const bool dma_ok = a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.K % 32 == 0 && a.K >= 64 && a.lda % 4 == 0;
+    if (dma_ok && g_use_dma && (cfg == 5 || cfg == 0)) {
+        if (cfg == 5) launch_dma<128, 64, 32, 32>(ctx, b);
+        else launch_dma<128, 128, 64, 32>(ctx, b);
+        K2_HIP(hipGetLastError());
+        if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
+        return;
+    }
     if (a.cv_Fout > 0) launch_mode<MODE_CONV>(ctx, b, cfg);
     else if (a.w_kn) launch_mode<MODE_WKN>(ctx, b, cfg);
     else launch_mode<MODE_PLAIN>(ctx, b, cfg);
