@@ -57,6 +57,9 @@ def make_zipformer2_meta(
     vocab_size=500,
     context_size=2,
     comment="",
+    streaming=False,
+    chunk_size=16,
+    left_context_frames=128,
 ):
     n = len(encoder_dims)
     assert all(
@@ -86,6 +89,18 @@ def make_zipformer2_meta(
             "context_size": str(context_size),
         }
     )
+    if streaming:
+        # keys of a streaming export, as OnlineModel.cs:38-110 reads them: T = ChunkLength,
+        # decode_chunk_len = ShiftLength (OnlineModel.cs:48-49); left_context_len is already divided
+        # by each stack's downsampling factor (OnlineProjOfZipformer2.cs:72,78 use it with ds = 1)
+        meta.update(
+            {
+                "streaming": "1",
+                "decode_chunk_len": str(2 * chunk_size),
+                "T": str(2 * chunk_size + 13),
+                "left_context_len": _csv([left_context_frames // d for d in downsampling_factors]),
+            }
+        )
     return meta
 
 
@@ -112,6 +127,35 @@ PRESETS = {
         cnn_module_kernels=[31, 31, 15, 15, 15, 31],
         downsampling_factors=[1, 2, 4, 8, 4, 2],
         vocab_size=500,
+    ),
+    # BASELINE.json configs[3]: streaming multi-zh-hans (OnlineProjOfZipformer2), chunk 32 frames.
+    # 16 layers (OnlineProjOfZipformer2.cs:125 confirms 16 x 6 caches); dims of the icefall
+    # streaming recipe.
+    "zipformer2-streaming-zh": dict(
+        encoder_dims=[192, 256, 384, 512, 384, 256],
+        num_encoder_layers=[2, 2, 3, 4, 3, 2],
+        feedforward_dims=[512, 768, 1024, 1536, 1024, 768],
+        num_heads=[4, 4, 4, 8, 4, 4],
+        cnn_module_kernels=[31, 31, 15, 15, 15, 31],
+        downsampling_factors=[1, 2, 4, 8, 4, 2],
+        vocab_size=2000,
+        streaming=True,
+        chunk_size=16,
+        left_context_frames=128,
+    ),
+    "zipformer2-streaming-tiny-test": dict(
+        encoder_dims=[64, 96, 128, 64],
+        num_encoder_layers=[1, 2, 1, 1],
+        feedforward_dims=[128, 192, 256, 128],
+        num_heads=[2, 2, 4, 2],
+        cnn_module_kernels=[15, 7, 7, 15],
+        downsampling_factors=[1, 2, 4, 2],
+        vocab_size=37,
+        joiner_dim=512,
+        decoder_dim=64,
+        streaming=True,
+        chunk_size=16,
+        left_context_frames=32,
     ),
     # Parity-test model: every structural feature of the big one (unequal
     # stack dims -> channel pad/truncate + full-dim concat, three

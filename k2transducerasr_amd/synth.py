@@ -23,6 +23,8 @@ BLANK_BIAS = {
     "zipformer2-large-en": 3.656,
     "zipformer2-small-en": 2.849,
     "zipformer2-tiny-test": 1.033,
+    "zipformer2-streaming-zh": 3.0,
+    "zipformer2-streaming-tiny-test": 1.0,
 }
 
 
@@ -98,8 +100,18 @@ def zipformer2_tensor_specs(meta: Dict[str, str]) -> List[Tuple[str, tuple, str]
                 lin(p + f"self_attn{k}.out_proj", D, vhd[i] * H)
             for k in (1, 2):
                 lin(p + f"conv_module{k}.in_proj", 2 * D, D)
-                s.append((p + f"conv_module{k}.depthwise_conv.weight", (D, 1, K), "w"))
-                s.append((p + f"conv_module{k}.depthwise_conv.bias", (D,), "b"))
+                if meta.get("streaming") == "1":
+                    # ChunkCausalDepthwiseConv1d (icefall zipformer.py): causal half-kernel conv +
+                    # chunk-wise full-kernel conv scaled near the chunk edges
+                    dc = p + f"conv_module{k}.depthwise_conv."
+                    s.append((dc + "causal_conv.weight", (D, 1, (K + 1) // 2), "w"))
+                    s.append((dc + "causal_conv.bias", (D,), "b"))
+                    s.append((dc + "chunkwise_conv.weight", (D, 1, K), "w"))
+                    s.append((dc + "chunkwise_conv.bias", (D,), "b"))
+                    s.append((dc + "chunkwise_conv_scale", (2, D, K), "b"))
+                else:
+                    s.append((p + f"conv_module{k}.depthwise_conv.weight", (D, 1, K), "w"))
+                    s.append((p + f"conv_module{k}.depthwise_conv.bias", (D,), "b"))
                 lin(p + f"conv_module{k}.out_proj", D, D)
             s.append((p + "norm.log_scale", (1,), "logscale"))
             s.append((p + "norm.bias", (D,), "b"))

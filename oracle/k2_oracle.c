@@ -1124,3 +1124,6 @@ int k2o_offline_recognize_batch(const k2o_model* m, const float* const* feats, c
     free(enc);
     return rc;
 }
+
+/* streaming (OnlineRecognizer) path: same translation unit, shares the static helpers above */
+#include "k2_oracle_online.c"

@@ -87,6 +87,28 @@ int k2o_greedy_single(const k2o_model* m, const float* enc_out, int Tp,
 int k2o_offline_recognize_batch(const k2o_model* m, const float* const* feats, const int64_t* n_floats, int B,
                                 int64_t* tokens, int32_t* timestamps, int32_t* n_tokens, int max_tokens);
 
+/* ---- streaming path (OnlineRecognizer / OnlineProjOfZipformer2): see k2_oracle_online.c ---- */
+typedef struct k2o_online_stream k2o_online_stream;
+int k2o_online_chunk_length(const k2o_model* m);      /* ChunkLength = T          (OnlineModel.cs:48) */
+int k2o_online_shift_length(const k2o_model* m);      /* ShiftLength = decode_chunk_len (:49)         */
+int k2o_online_frames_per_chunk(const k2o_model* m);  /* encoder_out frames per chunk                 */
+k2o_online_stream* k2o_online_stream_create(const k2o_model* m); /* GetEncoderInitStates + Hyp/Tokens = [blank, blank] */
+void k2o_online_stream_free(k2o_online_stream* s);
+int k2o_online_stream_num_layers(const k2o_online_stream* s);
+int64_t k2o_online_stream_processed_len(const k2o_online_stream* s);
+/* kind: 0 cached_key [left, 32H], 1 cached_nonlin_attn [left, 3D/4], 2/3 cached_val1/2 [left, 12H],
+ * 4/5 cached_conv1/2 [D, K/2], 6 embed_states [128,3,19]; out == NULL returns the size */
+int64_t k2o_online_stream_state(const k2o_online_stream* s, int layer, int kind, float* out, int64_t cap);
+int k2o_online_stream_num_tokens(const k2o_online_stream* s);
+int k2o_online_stream_num_timestamps(const k2o_online_stream* s);
+void k2o_online_stream_get_tokens(const k2o_online_stream* s, int64_t* out);
+void k2o_online_stream_get_timestamps(const k2o_online_stream* s, int32_t* out);
+void k2o_online_stream_get_hyp(const k2o_online_stream* s, int64_t* out);
+/* one encoder chunk for one stream: x [T,80] (log-floored) -> enc_out [T'c, J]; returns T'c */
+int k2o_online_encoder_chunk(const k2o_model* m, k2o_online_stream* s, const float* x, float* enc_out);
+/* OnlineRecognizer.ForwardBatchGreedySearch (:85-219) over B streams with one full chunk each */
+int k2o_online_step(const k2o_model* m, k2o_online_stream** streams, const float* const* chunks, int B, int32_t* n_new);
+
 #ifdef __cplusplus
 }
 #endif
