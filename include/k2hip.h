@@ -41,6 +41,7 @@ extern "C" {
 
 typedef struct k2hip_model k2hip_model_t;
 typedef struct k2hip_offline_stream k2hip_offline_stream_t;
+typedef struct k2hip_online_stream k2hip_online_stream_t;
 
 /* Fixed ids of the reference: OfflineModel.cs:18-20. */
 #define K2HIP_BLANK_ID 0
@@ -207,6 +208,48 @@ int32_t k2hip_offline_stream_num_tokens(const k2hip_offline_stream_t* s);
 int32_t k2hip_offline_stream_num_timestamps(const k2hip_offline_stream_t* s);
 int32_t k2hip_offline_stream_get_tokens(const k2hip_offline_stream_t* s, int64_t* tokens, int32_t cap);
 int32_t k2hip_offline_stream_get_timestamps(const k2hip_offline_stream_t* s, int32_t* timestamps, int32_t cap);
+
+/* ======================= streaming path: OnlineRecognizer / IOnlineProj ==========================
+ * The reference's IOnlineProj (IOnlineProj.cs:65-71) exposes GetEncoderInitStates / stack_states /
+ * unstack_states / EncoderProj(x, states): per tick it copies every stream's ~1.85 MB of caches into
+ * batch-major ONNX inputs and back on the host (OnlineProjOfZipformer2.cs:144-489).  Here a stream's
+ * caches live in a slot of a device-resident pool for the stream's whole life, so the drop-in unit is
+ * the stream handle + one step call; stack/unstack have no counterpart (nothing is copied).
+ * NB: for B > 1 the reference's stack_states mis-strides cached_nonlin_attn (:254-262 vs :407-413) and
+ * mixes streams; this engine keeps streams independent, i.e. it reproduces the reference at B = 1. */
+
+/* OnlineStream ctor (OnlineStream.cs:22-47): GetEncoderInitStates (zeroed caches), Hyp = Tokens =
+ * [blank, blank]. */
+int32_t k2hip_online_stream_create(k2hip_model_t* model, k2hip_online_stream_t** out);
+int32_t k2hip_online_stream_destroy(k2hip_online_stream_t* s);
+/* ChunkLength = T, ShiftLength = decode_chunk_len (OnlineModel.cs:48-49); frames of encoder_out per chunk */
+int32_t k2hip_online_chunk_info(const k2hip_model_t* model, int32_t* chunk_length, int32_t* shift_length,
+                                int32_t* frames_per_chunk);
+/* OnlineStream.AddSamples (:57-79): streaming fbank on the new samples, frames appended to the FIFO */
+int32_t k2hip_online_stream_accept_samples(k2hip_online_stream_t* s, const float* samples, int64_t n);
+/* ... or push ready-made feature frames ([n_frames, feature_dim]) */
+int32_t k2hip_online_stream_accept_features(k2hip_online_stream_t* s, const float* feats, int64_t n_frames);
+/* OnlineInputEntity.SpeechLength (floats buffered) */
+int64_t k2hip_online_stream_speech_length(const k2hip_online_stream_t* s);
+/* OnlineStream.IsFinished(isEndpoint) (:124-161), including its side effect of feeding 400 zero
+ * samples when less than a chunk is buffered */
+int32_t k2hip_online_stream_is_finished(k2hip_online_stream_t* s, int32_t is_endpoint, int32_t* finished);
+/* OnlineRecognizer.GetResults -> ForwardBatchGreedySearch (OnlineRecognizer.cs:76-219), minus DecodeMulti:
+ * every stream with a full chunk buffered (GetDecodeChunk :82-100) is decoded for that chunk
+ * (RemoveChunk :102-117 drops ShiftLength frames), its Hyp / Tokens / Timestamps / caches are updated;
+ * decoded[i] = 1 for those, 0 for streams that had no chunk (the reference removes them from the
+ * caller's list, :117-120); n_new_tokens[i] = symbols emitted in this chunk. */
+int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* streams, int32_t B, int32_t* decoded,
+                          int32_t* n_new_tokens);
+int32_t k2hip_online_stream_num_tokens(const k2hip_online_stream_t* s);
+int32_t k2hip_online_stream_num_timestamps(const k2hip_online_stream_t* s);
+int32_t k2hip_online_stream_get_tokens(const k2hip_online_stream_t* s, int64_t* tokens, int32_t cap);
+int32_t k2hip_online_stream_get_timestamps(const k2hip_online_stream_t* s, int32_t* timestamps, int32_t cap);
+int32_t k2hip_online_stream_get_hyp(const k2hip_online_stream_t* s, int64_t* hyp2);
+/* copy one cache out of the stream's device slot (parity tests / debugging):
+ * kind 0 cached_key [left,32H], 1 cached_nonlin_attn [left,3D/4], 2/3 cached_val1/2 [left,12H],
+ * 4/5 cached_conv1/2 [D,K/2], 6 embed_states [128,3,19] (layer ignored); out == NULL queries n */
+int32_t k2hip_online_stream_state(k2hip_online_stream_t* s, int32_t layer, int32_t kind, float* out, int64_t cap, int64_t* n);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

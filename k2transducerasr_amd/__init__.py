@@ -15,6 +15,8 @@ from .binding import (  # noqa: F401
     Model,
     OfflineRecognizer,
     OfflineStream,
+    OnlineRecognizer,
+    OnlineStream,
     build_library,
     library_path,
     load_library,
@@ -25,6 +27,8 @@ __all__ = [
     "Model",
     "OfflineRecognizer",
     "OfflineStream",
+    "OnlineRecognizer",
+    "OnlineStream",
     "build_library",
     "library_path",
     "load_library",

@@ -420,3 +420,119 @@ class OfflineRecognizer:
     def get_result(self, stream: OfflineStream):  # GetResult :77-83
         self.model._chk(self.model._L.k2hip_offline_recognizer_get_result(self.model.handle, stream._h))
         return stream.tokens, stream.timestamps
+
+
+# ============================== streaming: OnlineStream / OnlineRecognizer ===============================
+_STATE_KINDS = {"key": 0, "nonlin": 1, "val1": 2, "val2": 3, "conv1": 4, "conv2": 5, "embed": 6}
+
+
+def _bind_online(L):
+    if getattr(L, "_online_bound", False):
+        return
+    vp = C.c_void_p
+    L.k2hip_online_stream_create.argtypes = [vp, C.POINTER(vp)]
+    L.k2hip_online_stream_destroy.argtypes = [vp]
+    L.k2hip_online_chunk_info.argtypes = [vp, ip, ip, ip]
+    L.k2hip_online_stream_accept_samples.argtypes = [vp, fp, C.c_int64]
+    L.k2hip_online_stream_accept_features.argtypes = [vp, fp, C.c_int64]
+    L.k2hip_online_stream_speech_length.restype = C.c_int64
+    L.k2hip_online_stream_speech_length.argtypes = [vp]
+    L.k2hip_online_stream_is_finished.argtypes = [vp, C.c_int32, ip]
+    L.k2hip_online_step.argtypes = [vp, C.POINTER(vp), C.c_int32, ip, ip]
+    L.k2hip_online_stream_num_tokens.argtypes = [vp]
+    L.k2hip_online_stream_num_timestamps.argtypes = [vp]
+    L.k2hip_online_stream_get_tokens.argtypes = [vp, lp, C.c_int32]
+    L.k2hip_online_stream_get_timestamps.argtypes = [vp, ip, C.c_int32]
+    L.k2hip_online_stream_get_hyp.argtypes = [vp, lp]
+    L.k2hip_online_stream_state.argtypes = [vp, C.c_int32, C.c_int32, fp, C.c_int64, lp]
+    L._online_bound = True
+
+
+class OnlineStream:
+    """OnlineStream.cs:7-199 (feature FIFO + Hyp/Tokens/Timestamps; caches live in a GPU slot)."""
+
+    def __init__(self, model: Model):
+        self._m = model
+        self._L = model._L
+        _bind_online(self._L)
+        h = C.c_void_p()
+        model._chk(self._L.k2hip_online_stream_create(model.handle, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.k2hip_online_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_samples(self, samples):  # AddSamples :57-79
+        s = _f32(samples).reshape(-1)
+        self._m._chk(self._L.k2hip_online_stream_accept_samples(self._h, _f(s), s.size))
+
+    def add_features(self, feats):
+        f = _f32(feats).reshape(-1, self._m.feature_dim)
+        self._m._chk(self._L.k2hip_online_stream_accept_features(self._h, _f(f), f.shape[0]))
+
+    @property
+    def speech_length(self) -> int:
+        return self._L.k2hip_online_stream_speech_length(self._h)
+
+    def is_finished(self, is_endpoint: bool = False) -> bool:  # IsFinished :124-161
+        out = C.c_int32()
+        self._m._chk(self._L.k2hip_online_stream_is_finished(self._h, int(is_endpoint), C.byref(out)))
+        return bool(out.value)
+
+    @property
+    def tokens(self) -> List[int]:
+        n = self._L.k2hip_online_stream_num_tokens(self._h)
+        out = np.zeros(max(n, 1), np.int64)
+        self._m._chk(self._L.k2hip_online_stream_get_tokens(self._h, _l(out), n))
+        return out[:n].tolist()
+
+    @property
+    def timestamps(self) -> List[int]:
+        n = self._L.k2hip_online_stream_num_timestamps(self._h)
+        out = np.zeros(max(n, 1), np.int32)
+        self._m._chk(self._L.k2hip_online_stream_get_timestamps(self._h, _i(out), n))
+        return out[:n].tolist()
+
+    @property
+    def hyp(self) -> List[int]:
+        out = np.zeros(2, np.int64)
+        self._m._chk(self._L.k2hip_online_stream_get_hyp(self._h, _l(out)))
+        return out.tolist()
+
+    def state(self, layer: int, kind: str) -> np.ndarray:
+        n = C.c_int64()
+        self._m._chk(self._L.k2hip_online_stream_state(self._h, layer, _STATE_KINDS[kind], None, 0, C.byref(n)))
+        out = np.empty(n.value, np.float32)
+        self._m._chk(self._L.k2hip_online_stream_state(self._h, layer, _STATE_KINDS[kind], _f(out), n.value, C.byref(n)))
+        return out
+
+
+class OnlineRecognizer:
+    """OnlineRecognizer.cs:11-84 with decodingMethod = "greedy_search" on the HIP backend."""
+
+    def __init__(self, weights_path: str, device: int = 0):
+        self.model = Model(weights_path, device)
+        _bind_online(self.model._L)
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self.model._chk(self.model._L.k2hip_online_chunk_info(self.model.handle, C.byref(a), C.byref(b), C.byref(c)))
+        self.chunk_length, self.shift_length, self.frames_per_chunk = a.value, b.value, c.value
+
+    def create_online_stream(self) -> OnlineStream:  # CreateOnlineStream :60-64
+        return OnlineStream(self.model)
+
+    def get_results(self, streams: Sequence[OnlineStream]):
+        """GetResults :76-84 (tokens, not text).  Returns (decoded flags, new-token counts)."""
+        B = len(streams)
+        arr = (C.c_void_p * B)(*[s._h for s in streams])
+        dec = np.zeros(B, np.int32)
+        n = np.zeros(B, np.int32)
+        self.model._chk(self.model._L.k2hip_online_step(self.model.handle, arr, B, _i(dec), _i(n)))
+        return dec.tolist(), n.tolist()

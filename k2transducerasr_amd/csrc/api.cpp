@@ -22,6 +22,18 @@ struct k2hip_offline_stream {
     std::vector<int32_t> timestamps;
 };
 
+// OnlineStream.cs:7-199
+struct k2hip_online_stream {
+    k2hip_model* model;
+    int slot = -1;
+    std::vector<float> speech;     // OnlineInputEntity.Speech (feature FIFO)
+    std::vector<float> remainder;  // streaming fbank state
+    long long hyp[2] = {K2HIP_BLANK_ID, K2HIP_BLANK_ID};                 // :44
+    std::vector<int64_t> tokens{K2HIP_BLANK_ID, K2HIP_BLANK_ID};         // :45
+    std::vector<int32_t> timestamps;
+    long long processed_len = 0;   // processed_lens state (16 per chunk)
+};
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -284,6 +296,178 @@ int32_t k2hip_synchronize(k2hip_model_t* model) {
     return guard([&] {
         NEED(model);
         model->engine.synchronize();
+    });
+}
+
+// ---- OnlineStream / OnlineRecognizer ----------------------------------------------------------
+int32_t k2hip_online_stream_create(k2hip_model_t* model, k2hip_online_stream_t** out) {
+    return guard([&] {
+        NEED(model); NEED(out);
+        *out = nullptr;
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        auto* s = new k2hip_online_stream();
+        s->model = model;
+        try {
+            s->slot = model->engine.online_alloc_slot();
+        } catch (...) {
+            delete s;
+            throw;
+        }
+        *out = s;
+    });
+}
+int32_t k2hip_online_stream_destroy(k2hip_online_stream_t* s) {
+    return guard([&] {
+        if (!s) return;
+        {
+            std::lock_guard<std::mutex> lk(s->model->engine.mutex());
+            s->model->engine.online_free_slot(s->slot);
+        }
+        delete s;
+    });
+}
+int32_t k2hip_online_chunk_info(const k2hip_model_t* model, int32_t* chunk_length, int32_t* shift_length, int32_t* frames_per_chunk) {
+    return guard([&] {
+        NEED(model);
+        const Config& c = model->engine.model().cfg();
+        K2_REQUIRE(c.streaming, "this model is not a streaming export");
+        if (chunk_length) *chunk_length = c.chunk_T;
+        if (shift_length) *shift_length = c.shift;
+        if (frames_per_chunk) *frames_per_chunk = model->engine.online_frames_per_chunk();
+    });
+}
+static void online_add_samples(k2hip_online_stream* s, const float* samples, int64_t n) {
+    Engine& e = s->model->engine;
+    const Config& c = e.model().cfg();
+    std::vector<float> wav(s->remainder);
+    wav.insert(wav.end(), samples, samples + n);
+    int64_t nf = e.fbank_num_frames((int64_t)wav.size());
+    if (nf > 0) {   // OnlineStream.cs:67: only when the fbank produced frames
+        size_t old = s->speech.size();
+        s->speech.resize(old + (size_t)nf * c.feat);
+        int64_t got = 0;
+        std::lock_guard<std::mutex> lk(e.mutex());
+        e.fbank_host(wav.data(), (int64_t)wav.size(), s->speech.data() + old, nf, &got);
+        s->remainder.assign(wav.begin() + (size_t)nf * c.fbank.frame_shift, wav.end());
+    } else {
+        s->remainder.swap(wav);
+    }
+}
+int32_t k2hip_online_stream_accept_samples(k2hip_online_stream_t* s, const float* samples, int64_t n) {
+    return guard([&] {
+        NEED(s);
+        if (n > 0) NEED(samples);
+        online_add_samples(s, samples, n);
+    });
+}
+int32_t k2hip_online_stream_accept_features(k2hip_online_stream_t* s, const float* feats, int64_t n_frames) {
+    return guard([&] {
+        NEED(s);
+        if (n_frames > 0) NEED(feats);
+        const int feat = s->model->engine.model().cfg().feat;
+        s->speech.insert(s->speech.end(), feats, feats + n_frames * feat);
+    });
+}
+int64_t k2hip_online_stream_speech_length(const k2hip_online_stream_t* s) { return s ? (int64_t)s->speech.size() : -1; }
+// OnlineStream.IsFinished (:124-161)
+int32_t k2hip_online_stream_is_finished(k2hip_online_stream_t* s, int32_t is_endpoint, int32_t* finished) {
+    return guard([&] {
+        NEED(s); NEED(finished);
+        const Config& c = s->model->engine.model().cfg();
+        *finished = 0;
+        if (!is_endpoint) return;
+        const size_t oLen = s->speech.size();
+        if (oLen == 0) { *finished = 1; return; }
+        double sum = 0.0;   // LINQ Average() over float[] accumulates in double and returns float
+        for (float v : s->speech) sum += v;
+        const float avg = (float)(sum / (double)oLen);
+        size_t num = 0;
+        for (float v : s->speech) num += (v != avg);
+        if (num == 0) { *finished = 1; return; }
+        if ((long long)oLen <= (long long)c.chunk_T * c.feat) {
+            std::vector<float> z(400, 0.f);  // AddSamples(new float[400]) (:146)
+            online_add_samples(s, z.data(), 400);
+        }
+    });
+}
+// OnlineRecognizer.ForwardBatchGreedySearch (:85-219)
+int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* streams, int32_t B, int32_t* decoded, int32_t* n_new_tokens) {
+    return guard([&] {
+        NEED(model); NEED(streams); NEED(decoded); NEED(n_new_tokens);
+        Engine& e = model->engine;
+        const Config& c = e.model().cfg();
+        K2_REQUIRE(c.streaming, "this model is not a streaming export");
+        const size_t chunk_floats = (size_t)c.chunk_T * c.feat, shift_floats = (size_t)c.shift * c.feat;
+        std::vector<int> idx;
+        for (int i = 0; i < B; i++) {
+            NEED(streams[i]);
+            K2_REQUIRE(streams[i]->model == model, "stream %d belongs to another model", i);
+            decoded[i] = 0;
+            n_new_tokens[i] = 0;
+            if (streams[i]->speech.size() >= chunk_floats) idx.push_back(i);   // GetDecodeChunk (:82-100)
+        }
+        if (idx.empty()) return;   // :113-116
+        const int R = (int)idx.size(), Tp = e.online_frames_per_chunk();
+        std::vector<float> chunks((size_t)R * chunk_floats);
+        std::vector<int> slots(R);
+        std::vector<long long> hyps(2 * (size_t)R), plens(R);
+        for (int r = 0; r < R; r++) {
+            k2hip_online_stream* s = streams[idx[r]];
+            memcpy(chunks.data() + (size_t)r * chunk_floats, s->speech.data(), sizeof(float) * chunk_floats);
+            s->speech.erase(s->speech.begin(), s->speech.begin() + shift_floats);   // RemoveChunk (:102-117)
+            slots[r] = s->slot;
+            hyps[2 * r] = s->hyp[0];
+            hyps[2 * r + 1] = s->hyp[1];
+            plens[r] = s->processed_len;
+        }
+        std::vector<int64_t> tok((size_t)R * Tp);
+        std::vector<int32_t> ts((size_t)R * Tp), n(R);
+        {
+            std::lock_guard<std::mutex> lk(e.mutex());
+            e.online_step(slots.data(), chunks.data(), hyps.data(), plens.data(), R, tok.data(), ts.data(), n.data());
+        }
+        for (int r = 0; r < R; r++) {
+            k2hip_online_stream* s = streams[idx[r]];
+            for (int k = 0; k < n[r]; k++) {
+                s->tokens.push_back(tok[(size_t)r * Tp + k]);          // :183
+                s->timestamps.push_back(ts[(size_t)r * Tp + k]);       // :184 (chunk-relative frame index)
+            }
+            s->hyp[0] = s->tokens[s->tokens.size() - 2];               // :208
+            s->hyp[1] = s->tokens[s->tokens.size() - 1];
+            s->processed_len += (c.chunk_T - 7) / 2 - 3;               // new_processed_lens = processed_lens + x_lens
+            decoded[idx[r]] = 1;
+            n_new_tokens[idx[r]] = n[r];
+        }
+    });
+}
+int32_t k2hip_online_stream_num_tokens(const k2hip_online_stream_t* s) { return s ? (int32_t)s->tokens.size() : -1; }
+int32_t k2hip_online_stream_num_timestamps(const k2hip_online_stream_t* s) { return s ? (int32_t)s->timestamps.size() : -1; }
+int32_t k2hip_online_stream_get_tokens(const k2hip_online_stream_t* s, int64_t* tokens, int32_t cap) {
+    return guard([&] {
+        NEED(s);
+        if ((int)s->tokens.size() > cap) failf(K2HIP_ERR_CAPACITY, "stream holds %zu tokens", s->tokens.size());
+        if (!s->tokens.empty()) { NEED(tokens); memcpy(tokens, s->tokens.data(), sizeof(int64_t) * s->tokens.size()); }
+    });
+}
+int32_t k2hip_online_stream_get_timestamps(const k2hip_online_stream_t* s, int32_t* timestamps, int32_t cap) {
+    return guard([&] {
+        NEED(s);
+        if ((int)s->timestamps.size() > cap) failf(K2HIP_ERR_CAPACITY, "stream holds %zu timestamps", s->timestamps.size());
+        if (!s->timestamps.empty()) { NEED(timestamps); memcpy(timestamps, s->timestamps.data(), sizeof(int32_t) * s->timestamps.size()); }
+    });
+}
+int32_t k2hip_online_stream_get_hyp(const k2hip_online_stream_t* s, int64_t* hyp2) {
+    return guard([&] {
+        NEED(s); NEED(hyp2);
+        hyp2[0] = s->hyp[0];
+        hyp2[1] = s->hyp[1];
+    });
+}
+int32_t k2hip_online_stream_state(k2hip_online_stream_t* s, int32_t layer, int32_t kind, float* out, int64_t cap, int64_t* n) {
+    return guard([&] {
+        NEED(s); NEED(n);
+        std::lock_guard<std::mutex> lk(s->model->engine.mutex());
+        s->model->engine.online_read_state(s->slot, layer, kind, out, cap, n);
     });
 }
 

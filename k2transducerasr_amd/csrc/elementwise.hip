@@ -81,7 +81,7 @@ __global__ void k_conv0(const float* __restrict__ x, const float* __restrict__ w
 
 // ---- ConvNeXt depthwise 7x7, pad 3, NHWC, weights [49][C]
 __global__ void k_dwconv7x7(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                            float* __restrict__ y, int B, int T, int F, int C) {
+                            float* __restrict__ y, int B, int Tin, int T, int tpad, int F, int C) {
     int C4 = C / 4;
     long long n = (long long)B * T * F * C4;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -93,12 +93,12 @@ __global__ void k_dwconv7x7(const float* __restrict__ x, const float* __restrict
     int t = (int)(bt % T), b = (int)(bt / T);
     float4 s = *reinterpret_cast<const float4*>(bias + c);
     for (int kt = 0; kt < 7; kt++) {
-        int tt = t + kt - 3;
-        if (tt < 0 || tt >= T) continue;
+        int tt = t + kt - tpad;
+        if (tt < 0 || tt >= Tin) continue;
         for (int kf = 0; kf < 7; kf++) {
             int ff = f + kf - 3;
             if (ff < 0 || ff >= F) continue;
-            float4 xv = *reinterpret_cast<const float4*>(x + (((long long)b * T + tt) * F + ff) * C + c);
+            float4 xv = *reinterpret_cast<const float4*>(x + (((long long)b * Tin + tt) * F + ff) * C + c);
             float4 wv = *reinterpret_cast<const float4*>(w + (kt * 7 + kf) * C + c);
             s.x += wv.x * xv.x; s.y += wv.y * xv.y; s.z += wv.z * xv.z; s.w += wv.w * xv.w;
         }
@@ -320,9 +320,10 @@ void conv0_swoosh(const Ctx& ctx, const float* x, const float* w, const float* b
     long long n = (long long)B * (T - 2) * F;
     LAUNCH(k_conv0, dim3(nblocks(n, 256)), dim3(256), x, w, b, y, B, T, F);
 }
-void dwconv7x7(const Ctx& ctx, const float* x, const float* w_kc, const float* b, float* y, int B, int T, int F, int C) {
+void dwconv7x7(const Ctx& ctx, const float* x, const float* w_kc, const float* b, float* y, int B, int Tin, int T, int tpad,
+               int F, int C) {
     long long n = (long long)B * T * F * (C / 4);
-    LAUNCH(k_dwconv7x7, dim3(nblocks(n, 256)), dim3(256), x, w_kc, b, y, B, T, F, C);
+    LAUNCH(k_dwconv7x7, dim3(nblocks(n, 256)), dim3(256), x, w_kc, b, y, B, Tin, T, tpad, F, C);
     ctx.add_flops(0.0, 2.0 * B * T * (double)F * C * 49, 0);
 }
 void biasnorm(const Ctx& ctx, const float* x, const float* bias, const float* log_scale, float* y, int M, int D) {

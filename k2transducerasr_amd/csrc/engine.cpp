@@ -37,6 +37,7 @@ Engine::~Engine() {
     }
     if (stream2_) (void)hipStreamDestroy(stream2_);
     for (auto& kv : pe_cache_) (void)hipFree(kv.second);
+    if (online_pool_) (void)hipFree(online_pool_);
     for (auto& e : ev_)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : evpool_) (void)hipEventDestroy(e);
@@ -66,44 +67,6 @@ Ctx Engine::make_ctx(bool dry) {
     c.evpool = &evpool_;
     c.evused = &evused_;
     return c;
-}
-
-template <typename F>
-void Engine::run_sized(F&& body) {
-    K2_HIP(hipSetDevice(device_));
-    stats_ = GemmStats();
-    cur_arena_->reset();
-    cur_arena_->set_dry(true);
-    try {
-        Ctx d = make_ctx(true);
-        body(d);
-    } catch (...) {
-        cur_arena_->set_dry(false);
-        cur_arena_->reset();
-        throw;
-    }
-    cur_arena_->set_dry(false);
-    int64_t need = cur_arena_->high_water();
-    cur_arena_->reset();
-    if (need > cur_arena_->capacity()) {
-        K2_HIP(hipStreamSynchronize(stream_));
-        cur_arena_->reserve(need + need / 8);
-    }
-    Ctx c = make_ctx(false);
-    evused_ = 0;
-    body(c);
-    if (instrument_) {
-        K2_HIP(hipStreamSynchronize(stream_));
-        for (int i = 0; i + 1 < evused_; i += 2) {
-            float ms = 0;
-            K2_HIP(hipEventElapsedTime(&ms, evpool_[i], evpool_[i + 1]));
-            stats_.ms += ms;
-        }
-    }
-    timing_.gemm_ms = stats_.ms;
-    timing_.gemm_launches = stats_.launches;
-    timing_.gemm_flops = stats_.flops;
-    timing_.total_flops = stats_.total_flops;
 }
 
 int Engine::encoder_out_frames(int T) const {
@@ -189,7 +152,7 @@ float* Engine::encoder_embed(const Ctx& c, const float* x, int B, int T, int* T5
     const int npix = B * T3 * F3;
     float* dw = ar.take<float>((int64_t)npix * 128);
     dwconv7x7(c, a3, m.w("encoder_embed.convnext.depthwise_conv.weight#kc"), m.w("encoder_embed.convnext.depthwise_conv.bias"),
-              dw, B, T3, F3, 128);
+              dw, B, T3, T3, 3, F3, 128);
     float* hid = ar.take<float>((int64_t)npix * 384);
     linear(c, dw, 128, m.w("encoder_embed.convnext.pointwise_conv1.weight"), m.w("encoder_embed.convnext.pointwise_conv1.bias"),
            hid, 384, npix, 128, 384, ACT_SWOOSH_L);

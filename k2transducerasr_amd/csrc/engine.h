@@ -1,6 +1,7 @@
 // Engine = one model replica on one GPU: weights, HIP stream, device arena and the
 // host-side orchestration of the offline path (pad -> Zipformer2 -> greedy).
 #pragma once
+#include <array>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -9,6 +10,15 @@
 #include "model.h"
 
 namespace k2hip {
+
+// float offsets of one stream's caches inside its slot of the state pool (OnlineProjOfZipformer2.cs:63-111)
+struct OnlineLayout {
+    std::vector<long long> key, nonlin, val1, val2, conv1, conv2;  // per layer
+    std::vector<std::array<long long, 6>> sizes;                   // per layer, float counts in the reference's order
+    long long embed = 0;
+    long long floats_per_stream = 0;
+    int nl = 0;
+};
 
 struct OfflineResult {
     std::vector<std::vector<int64_t>> tokens;   // emitted symbols per stream
@@ -53,6 +63,15 @@ class Engine {
     int submit_samples_dev(const float* samples_dev, int64_t n_each, int B, int max_tokens);
     void wait_ticket(int ticket, int64_t* tokens, int32_t* ts, int32_t* n_tokens);
 
+    // ---- streaming (OnlineRecognizer) path: online_engine.cpp ----
+    int online_alloc_slot();   // GetEncoderInitStates: a zeroed slot of the device state pool
+    void online_free_slot(int slot);
+    void online_read_state(int slot, int layer, int kind, float* out, int64_t cap, int64_t* n);
+    int online_frames_per_chunk() const;
+    // one tick over B streams that each have a full chunk: chunks [B][T*feat] (host), hyps [B][2], plens [B]
+    void online_step(const int* slots, const float* chunks, const long long* hyps, const long long* plens, int B,
+                     int64_t* tokens, int32_t* ts, int32_t* n_tokens);
+
     void set_instrument(bool on) { instrument_ = on; }
     const k2hip_timing& timing() const { return timing_; }
 
@@ -72,6 +91,11 @@ class Engine {
     void greedy_device(const Ctx& c, const float* enc, int B, int Tp, bool single, long long* d_tok, int* d_ts, int* d_n,
                        int max_tokens, int* d_overflow);
     const float* pos_emb(int T);  // cached CompactRelPositionalEncoding table on device
+    const float* pos_emb_stream(int Tc, int L);
+    void online_ensure_pool();
+    float* encoder_embed_stream(const Ctx& c, const float* x, const int* d_slots, int B, int T, int* Tc);
+    void encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x, const float* pe, const int* d_slots,
+                              const long long* d_plen, int B, int Tc, int L);
     DecJoinW decjoin() const;
 
     // run `body` once dry to size the arena, then for real
@@ -98,6 +122,10 @@ class Engine {
     } slots_[kSlots];
     int next_slot_ = 0;
     hipStream_t stream2_ = nullptr;
+    float* online_pool_ = nullptr;
+    int online_cap_ = 0;
+    std::vector<int> free_slots_;
+    OnlineLayout lay_;
     std::mutex mu_;
     std::map<int, float*> pe_cache_;
     bool instrument_ = false;
@@ -111,5 +139,44 @@ class Engine {
     int64_t pin_cap_ = 0;
     void* pinned(int64_t bytes);
 };
+
+template <typename F>
+void Engine::run_sized(F&& body) {
+    K2_HIP(hipSetDevice(device_));
+    stats_ = GemmStats();
+    cur_arena_->reset();
+    cur_arena_->set_dry(true);
+    try {
+        Ctx d = make_ctx(true);
+        body(d);
+    } catch (...) {
+        cur_arena_->set_dry(false);
+        cur_arena_->reset();
+        throw;
+    }
+    cur_arena_->set_dry(false);
+    int64_t need = cur_arena_->high_water();
+    cur_arena_->reset();
+    if (need > cur_arena_->capacity()) {
+        K2_HIP(hipStreamSynchronize(stream_));
+        cur_arena_->reserve(need + need / 8);
+    }
+    Ctx c = make_ctx(false);
+    evused_ = 0;
+    body(c);
+    if (instrument_) {
+        K2_HIP(hipStreamSynchronize(stream_));
+        for (int i = 0; i + 1 < evused_; i += 2) {
+            float ms = 0;
+            K2_HIP(hipEventElapsedTime(&ms, evpool_[i], evpool_[i + 1]));
+            stats_.ms += ms;
+        }
+    }
+    timing_.gemm_ms = stats_.ms;
+    timing_.gemm_launches = stats_.launches;
+    timing_.gemm_flops = stats_.flops;
+    timing_.total_flops = stats_.total_flops;
+}
+
 
 }  // namespace k2hip

@@ -192,12 +192,19 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
     const int t0 = a.t0 ? *a.t0 : INT_MAX;
     const int ncg = w.Vp >> 2, kper = w.J >> 3;
 
-    decoder_block_wide(w, -1, K2HIP_BLANK_ID, h, actT, dec_a);
-    if (a.t0) decoder_block_wide(w, K2HIP_BLANK_ID, K2HIP_BLANK_ID, h, actT, dec_b);
-
     long long y0 = -1, y1 = K2HIP_BLANK_ID;
     int n_tok = 0, t = 0;
     bool own = false;
+    if (a.init_ctx) {
+        // online: the loop starts from the stream's own last two tokens (OnlineRecognizer.cs:122-136)
+        y0 = a.init_ctx[2 * b];
+        y1 = a.init_ctx[2 * b + 1];
+        own = true;
+        decoder_block_wide(w, y0, y1, h, actT, dec_own);
+    } else {
+        decoder_block_wide(w, -1, K2HIP_BLANK_ID, h, actT, dec_a);
+        if (a.t0) decoder_block_wide(w, K2HIP_BLANK_ID, K2HIP_BLANK_ID, h, actT, dec_b);
+    }
 
     while (t < a.Tp && n_tok < a.max_sym) {
         const int nf = min(GF, a.Tp - t);

@@ -84,7 +84,10 @@ void pad_logfloor(const Ctx& ctx, const float* packed, const long long* d_off, c
                   long long L);
 void pad_logfloor_dense(const Ctx& ctx, const float* feats, long long n_each, float* out, int B, long long L);
 void conv0_swoosh(const Ctx& ctx, const float* x, const float* w, const float* b, float* y, int B, int T, int F);
-void dwconv7x7(const Ctx& ctx, const float* x, const float* w_kc, const float* b, float* y, int B, int T, int F, int C);
+// depthwise 7x7 over [B,Tin,F,C] -> [B,Tout,F,C]; time taps read in[t + kt - tpad] (zero outside [0,Tin)).
+// offline ConvNeXt: Tin = Tout, tpad = 3; streaming: Tin = Tout + 6, tpad = 0 (left cache + right context supply the taps)
+void dwconv7x7(const Ctx& ctx, const float* x, const float* w_kc, const float* b, float* y, int B, int Tin, int Tout, int tpad,
+               int F, int C);
 void biasnorm(const Ctx& ctx, const float* x, const float* bias, const float* log_scale, float* y, int M, int D);
 // y = orig + (biasnorm(x) - orig) * scale     (layer tail: norm + bypass)
 void biasnorm_bypass(const Ctx& ctx, const float* x, const float* orig, const float* nbias, const float* log_scale,
@@ -145,7 +148,24 @@ struct GreedyArgs {
     int* n_tokens;      // [B]
     int max_tokens;
     int* overflow;      // device flag
+    // online loop: per-stream starting context (stream.Hyp, OnlineRecognizer.cs:109,122-126); null = offline
+    const long long* init_ctx = nullptr;  // [B][2]
 };
 void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a);
+
+// ---- streaming (online.hip): device-resident per-stream caches indexed by slot ------------------
+void convnext_cat(const Ctx& ctx, const float* a3, const float* pool, long long slot_stride, long long embed_off,
+                  const int* slots, float* cat, int B, int T3, int F, int C);
+void convnext_cache_update(const Ctx& ctx, const float* a3, float* pool, long long slot_stride, long long embed_off,
+                           const int* slots, int B, int T3, int Tc, int F, int C);
+void cat_shift(const Ctx& ctx, float* pool, long long slot_stride, long long off, const int* slots, const float* newrows,
+               int ldn, float* cat, int B, int L, int Tc, int width);
+void attn_stream(const Ctx& ctx, const float* qkp, int ld, const float* kcat, const float* pp, const long long* plen,
+                 float* aw, int B, int Tc, int L, int KLp, int H, int ds, int left50);
+void glu_causal_conv(const Ctx& ctx, const float* x2, float* pool, long long slot_stride, long long off, const int* slots,
+                     const float* wc, const float* bc, const float* ww, const float* bw, const float* sc, float* y, int B,
+                     int Tc, int D, int K);
+void zero_floats(const Ctx& ctx, float* p, long long n);
+void logfloor_inplace(const Ctx& ctx, float* x, long long n);
 
 }  // namespace k2hip

@@ -196,6 +196,13 @@ void Model::parse_config() {
     c.ctx = geti("context_size", 2);
     c.feat = geti("feature_dim", 80);
     c.Vp = (int)align_up(c.V, 4);
+    c.streaming = get("streaming", "0") == "1";
+    if (c.streaming) {
+        c.chunk_T = geti("T", 45);
+        c.shift = geti("decode_chunk_len", 32);
+        if (fill("left_context_len", c.left) != c.ns) failf(K2HIP_ERR_INVALID, "metadata left_context_len must have %d entries", c.ns);
+        K2_REQUIRE(c.chunk_T == c.shift + 13 && c.shift % 4 == 0, "streaming geometry T=%d, decode_chunk_len=%d unsupported", c.chunk_T, c.shift);
+    }
     c.dmax = 0;
     for (int i = 0; i < c.ns; i++) {
         c.dmax = std::max(c.dmax, c.dim[i]);
@@ -266,8 +273,9 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
                 for (int f = 0; f < F3; f++) v[(size_t)d * KK + f * C + ch] = t.host[(size_t)d * KK + ch * F3 + f];
         push("encoder_embed.out.weight#fc", std::move(v), {D0, KK});
     }
-    // conv_module depthwise [D,1,K] -> [K][D]
-    for (int si = 0; si < c.ns; si++)
+    // conv_module depthwise [D,1,K] -> [K][D]  (offline models; the streaming model's causal/chunkwise
+    // filters are read in their native layout)
+    for (int si = 0; si < (c.streaming ? 0 : c.ns); si++)
         for (int li = 0; li < c.nlayer[si]; li++)
             for (int k = 1; k <= 2; k++) {
                 char nm[192];

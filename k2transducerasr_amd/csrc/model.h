@@ -38,6 +38,10 @@ struct Config {
         kern[kMaxStacks] = {0}, ds[kMaxStacks] = {0}, qhd[kMaxStacks] = {0}, vhd[kMaxStacks] = {0}, phd[kMaxStacks] = {0};
     int pos_dim = 48, J = 512, DD = 512, V = 500, ctx = 2, feat = 80, dmax = 0;
     int Vp = 0;  // vocab padded to a multiple of 4 for the k-major joiner matrix
+    // streaming export (OnlineModel.cs:38-110): ChunkLength = T, ShiftLength = decode_chunk_len,
+    // left_context_len per stack (already divided by the stack's downsampling factor)
+    bool streaming = false;
+    int chunk_T = 0, shift = 0, left[kMaxStacks] = {0};
     FbankOpts fbank;
 };
 

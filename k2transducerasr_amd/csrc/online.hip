@@ -1,0 +1,228 @@
+// Kernels of the streaming (OnlineRecognizer / OnlineProjOfZipformer2) path.
+//
+// The reference keeps every stream's caches in managed arrays and, per chunk, interleaves them
+// into batch-major ONNX inputs and back (stack_states / unstack_states,
+// OnlineProjOfZipformer2.cs:144-489: ~1.85 MB per stream per direction per chunk on one host
+// thread).  Here every stream owns a slot of one device-resident pool laid out exactly like the
+// per-stream state of GetEncoderInitStates (:63-111); kernels index the pool by slot, so
+// "stacking" is an index array and nothing is copied to or from the host.
+//   per layer: cached_key [L, 32H] | cached_nonlin_attn [L, 3D/4] | cached_val1 [L, 12H] |
+//              cached_val2 [L, 12H] | cached_conv1 [D, K/2] | cached_conv2 [D, K/2]
+//   then embed_states [128, 3, 19].  processed_lens lives on the host (it is 16 x chunks).
+#include "kernels.h"
+
+namespace k2hip {
+namespace {
+
+__device__ __forceinline__ float fast_softplus(float z) { return z > 15.f ? z : __logf(1.0f + __expf(z)); }
+__device__ __forceinline__ float swoosh_r(float v) { return fast_softplus(v - 1.0f) - 0.08f * v - 0.313261687f; }
+__device__ __forceinline__ float sigm(float s) { return 1.0f / (1.0f + __expf(-s)); }
+
+// ConvNeXt.streaming_forward: cat[b] = [cached_left_pad (3 frames) ; x (T3 frames)], NHWC
+__global__ void k_convnext_cat(const float* __restrict__ a3, const float* __restrict__ pool, long long slot_stride,
+                               long long embed_off, const int* __restrict__ slots, float* __restrict__ cat, int B, int T3,
+                               int F, int C) {
+    long long n = (long long)B * (T3 + 3) * F * C;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = (int)(i % C);
+    long long p = i / C;
+    int f = (int)(p % F);
+    long long bt = p / F;
+    int t = (int)(bt % (T3 + 3)), b = (int)(bt / (T3 + 3));
+    float v;
+    if (t < 3) v = pool[(long long)slots[b] * slot_stride + embed_off + ((long long)c * 3 + t) * F + f];
+    else v = a3[(((long long)b * T3 + (t - 3)) * F + f) * C + c];
+    cat[i] = v;
+}
+// cached_left_pad <- cat[:, :, Tc:Tc+3] = x frames Tc-3 .. Tc-1
+__global__ void k_convnext_cache(const float* __restrict__ a3, float* __restrict__ pool, long long slot_stride,
+                                 long long embed_off, const int* __restrict__ slots, int B, int T3, int Tc, int F, int C) {
+    long long n = (long long)B * C * 3 * F;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int f = (int)(i % F);
+    long long p = i / F;
+    int t = (int)(p % 3);
+    p /= 3;
+    int c = (int)(p % C), b = (int)(p / C);
+    pool[(long long)slots[b] * slot_stride + embed_off + ((long long)c * 3 + t) * F + f] =
+        a3[(((long long)b * T3 + (Tc - 3 + t)) * F + f) * C + c];
+}
+
+// cat[b] = [cache[slot_b] (L rows) ; new[b] (Tc rows)]; cache[slot_b] <- cat[b][Tc:]   (rows of `width` floats)
+// one thread per (b, 4 columns): it alone reads and writes its columns, so the in-place shift is safe
+__global__ void k_cat_shift(float* __restrict__ pool, long long slot_stride, long long off, const int* __restrict__ slots,
+                            const float* __restrict__ newrows, int ldn, float* __restrict__ cat, int B, int L, int Tc,
+                            int width) {
+    int w4 = width >> 2;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * w4) return;
+    int b = i / w4, c = (i % w4) * 4;
+    float* cache = pool + (long long)slots[b] * slot_stride + off + c;
+    float* out = cat + (long long)b * (L + Tc) * width + c;
+    const float* nw = newrows + (long long)b * Tc * ldn + c;
+    for (int r = 0; r < L; r++) *reinterpret_cast<float4*>(out + (long long)r * width) = *reinterpret_cast<const float4*>(cache + (long long)r * width);
+    for (int r = 0; r < Tc; r++) *reinterpret_cast<float4*>(out + (long long)(L + r) * width) = *reinterpret_cast<const float4*>(nw + (long long)r * ldn);
+    for (int r = 0; r < L; r++) *reinterpret_cast<float4*>(cache + (long long)r * width) = *reinterpret_cast<const float4*>(out + (long long)(Tc + r) * width);
+}
+
+// RelPositionMultiheadAttentionWeights.streaming_forward for one (stream, head):
+//   scores[i,j] = q_i.k_j + p_i.pos[Tc-1-i+j]; key j < L masked (-1000) while the left context is not
+//   yet filled (processed_lens); softmax over j.  aw: [H][B][Tc][KLp]
+__global__ __launch_bounds__(256) void k_attn_stream(const float* __restrict__ qkp, int ld, const float* __restrict__ kcat,
+                                                     const float* __restrict__ pp, const long long* __restrict__ plen,
+                                                     float* __restrict__ aw, int B, int Tc, int L, int KLp, int H, int ds,
+                                                     int left50) {
+    extern __shared__ float S[];  // [Tc][KL]
+    const int b = blockIdx.x, h = blockIdx.y, KL = L + Tc;
+    const int QH = 32, PH = 4;
+    const long long pl = plen[b];
+    for (int e = threadIdx.x; e < Tc * KL; e += blockDim.x) {
+        int i = e / KL, j = e - i * KL;
+        const float* q = qkp + ((long long)b * Tc + i) * ld + h * QH;
+        const float* p = qkp + ((long long)b * Tc + i) * ld + 2 * H * QH + h * PH;
+        const float* k = kcat + ((long long)b * KL + j) * (H * QH) + h * QH;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < QH; d += 4) {
+            float4 a = *reinterpret_cast<const float4*>(q + d), c = *reinterpret_cast<const float4*>(k + d);
+            s += a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+        }
+        float4 pv = *reinterpret_cast<const float4*>(p);
+        float4 ev = *reinterpret_cast<const float4*>(pp + (long long)(Tc - 1 - i + j) * (H * PH) + h * PH);
+        s += pv.x * ev.x + pv.y * ev.y + pv.z * ev.z + pv.w * ev.w;
+        // src_key_padding_mask[..., ::ds]: left-context slot j (50 Hz slot j*ds) is valid only once processed
+        if (j < L && pl <= (long long)(left50 - 1 - j * ds)) s = -1000.0f;
+        S[e] = s;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* out = aw + (((long long)h * B + b) * Tc) * KLp;
+    for (int i = wave; i < Tc; i += 4) {
+        float* row = S + i * KL;
+        float mx = -INFINITY;
+        for (int j = lane; j < KL; j += 64) mx = fmaxf(mx, row[j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int j = lane; j < KL; j += 64) {
+            float e = __expf(row[j] - mx);
+            row[j] = e;
+            sum += e;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        float inv = 1.0f / sum;
+        for (int j = lane; j < KLp; j += 64) out[(long long)i * KLp + j] = j < KL ? row[j] * inv : 0.f;
+    }
+}
+
+// ConvolutionModule.streaming_forward core: GLU -> ChunkCausalDepthwiseConv1d.streaming_forward -> SwooshR
+//   x2: [B*Tc, 2D]; cache [D][pad] per stream; wc [D][Kc], ww [D][K], sc [2][D][K]; y: [B*Tc, D]
+__global__ __launch_bounds__(64) void k_glu_causal_conv(const float* __restrict__ x2, float* __restrict__ pool,
+                                                        long long slot_stride, long long off, const int* __restrict__ slots,
+                                                        const float* __restrict__ wc, const float* __restrict__ bc,
+                                                        const float* __restrict__ ww, const float* __restrict__ bw,
+                                                        const float* __restrict__ sc, float* __restrict__ y, int B, int Tc,
+                                                        int D, int K) {
+    extern __shared__ float cat[];  // [(pad + Tc)][64]
+    const int c = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y, lc = threadIdx.x;
+    const int pad = K >> 1, Kc = (K + 1) >> 1;
+    if (c >= D) return;  // whole trailing lanes only; no barrier below depends on them (each lane uses its own column)
+    float* cache = pool + (long long)slots[b] * slot_stride + off + (long long)c * pad;
+    for (int r = 0; r < pad; r++) cat[r * 64 + lc] = cache[r];
+    for (int t = 0; t < Tc; t++) {
+        const float* row = x2 + ((long long)b * Tc + t) * 2 * D;
+        cat[(pad + t) * 64 + lc] = row[c] * sigm(row[D + c]);
+    }
+    for (int r = 0; r < pad; r++) cache[r] = cat[(Tc + r) * 64 + lc];  // cache = cat[..., -pad:]
+    const float bcv = bc[c], bwv = bw[c];
+    for (int t = 0; t < Tc; t++) {
+        float xc = bcv;
+        for (int k = 0; k < Kc; k++) xc += wc[c * Kc + k] * cat[(t + k) * 64 + lc];
+        float xw = bwv;
+        for (int k = 0; k < K; k++) {
+            int tt = t + k - pad;
+            if (tt >= 0 && tt < Tc) xw += ww[c * K + k] * cat[(pad + tt) * 64 + lc];
+        }
+        float le, re;
+        if (Tc < K) {
+            le = sc[(long long)c * K + t];
+            re = sc[(long long)D * K + (long long)c * K + (K - Tc) + t];
+        } else {
+            le = t < K ? sc[(long long)c * K + t] : 0.f;
+            re = t >= Tc - K ? sc[(long long)D * K + (long long)c * K + (t - (Tc - K))] : 0.f;
+        }
+        y[((long long)b * Tc + t) * D + c] = swoosh_r(xw * (1.0f + (le + re)) + xc);
+    }
+}
+
+// zero one stream's slot (GetEncoderInitStates: all caches start at 0)
+__global__ void k_zero(float* __restrict__ p, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
+// x == 0 -> log floor, in place (online PadSequence, PadHelper.cs:9-13,58)
+__global__ void k_logfloor(float* __restrict__ x, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && x[i] == 0.0f) x[i] = -23.025850929940457F;
+}
+
+inline int nb(long long n, int per) { return (int)((n + per - 1) / per); }
+
+}  // namespace
+
+void convnext_cat(const Ctx& ctx, const float* a3, const float* pool, long long slot_stride, long long embed_off,
+                  const int* slots, float* cat, int B, int T3, int F, int C) {
+    if (ctx.dry) return;
+    long long n = (long long)B * (T3 + 3) * F * C;
+    hipLaunchKernelGGL(k_convnext_cat, dim3(nb(n, 256)), dim3(256), 0, ctx.stream, a3, pool, slot_stride, embed_off, slots, cat, B, T3, F, C);
+    K2_HIP(hipGetLastError());
+}
+void convnext_cache_update(const Ctx& ctx, const float* a3, float* pool, long long slot_stride, long long embed_off,
+                           const int* slots, int B, int T3, int Tc, int F, int C) {
+    if (ctx.dry) return;
+    long long n = (long long)B * C * 3 * F;
+    hipLaunchKernelGGL(k_convnext_cache, dim3(nb(n, 256)), dim3(256), 0, ctx.stream, a3, pool, slot_stride, embed_off, slots, B, T3, Tc, F, C);
+    K2_HIP(hipGetLastError());
+}
+void cat_shift(const Ctx& ctx, float* pool, long long slot_stride, long long off, const int* slots, const float* newrows,
+               int ldn, float* cat, int B, int L, int Tc, int width) {
+    K2_REQUIRE(width % 4 == 0 && ldn % 4 == 0, "cat_shift: width %d / ld %d must be multiples of 4", width, ldn);
+    if (ctx.dry) return;
+    hipLaunchKernelGGL(k_cat_shift, dim3(nb((long long)B * (width / 4), 64)), dim3(64), 0, ctx.stream, pool, slot_stride, off, slots,
+                       newrows, ldn, cat, B, L, Tc, width);
+    K2_HIP(hipGetLastError());
+}
+void attn_stream(const Ctx& ctx, const float* qkp, int ld, const float* kcat, const float* pp, const long long* plen,
+                 float* aw, int B, int Tc, int L, int KLp, int H, int ds, int left50) {
+    ctx.add_flops(0.0, 2.0 * 36 * (double)Tc * (L + Tc) * B * H, 0);
+    if (ctx.dry) return;
+    size_t lds = sizeof(float) * Tc * (L + Tc);
+    hipLaunchKernelGGL(k_attn_stream, dim3(B, H), dim3(256), lds, ctx.stream, qkp, ld, kcat, pp, plen, aw, B, Tc, L, KLp, H, ds, left50);
+    K2_HIP(hipGetLastError());
+}
+void glu_causal_conv(const Ctx& ctx, const float* x2, float* pool, long long slot_stride, long long off, const int* slots,
+                     const float* wc, const float* bc, const float* ww, const float* bw, const float* sc, float* y, int B,
+                     int Tc, int D, int K) {
+    ctx.add_flops(0.0, 2.0 * B * Tc * (double)D * (K + (K + 1) / 2), 0);
+    if (ctx.dry) return;
+    size_t lds = sizeof(float) * (K / 2 + Tc) * 64;
+    hipLaunchKernelGGL(k_glu_causal_conv, dim3(cdiv(D, 64), B), dim3(64), lds, ctx.stream, x2, pool, slot_stride, off, slots, wc, bc,
+                       ww, bw, sc, y, B, Tc, D, K);
+    K2_HIP(hipGetLastError());
+}
+void zero_floats(const Ctx& ctx, float* p, long long n) {
+    if (ctx.dry || n <= 0) return;
+    hipLaunchKernelGGL(k_zero, dim3(nb(n, 256)), dim3(256), 0, ctx.stream, p, n);
+    K2_HIP(hipGetLastError());
+}
+void logfloor_inplace(const Ctx& ctx, float* x, long long n) {
+    if (ctx.dry || n <= 0) return;
+    hipLaunchKernelGGL(k_logfloor, dim3(nb(n, 256)), dim3(256), 0, ctx.stream, x, n);
+    K2_HIP(hipGetLastError());
+}
+
+}  // namespace k2hip

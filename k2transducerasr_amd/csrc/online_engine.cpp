@@ -1,0 +1,359 @@
+// Streaming (OnlineRecognizer) path of the engine: device-resident per-stream state pool and one
+// batched chunk step.  Replaces, per tick of OnlineRecognizer.ForwardBatchGreedySearch
+// (OnlineRecognizer.cs:85-219): stack_states (:131) + EncoderProj (:132) + the T'-frame greedy loop
+// (:141-202) + unstack_states (:204).  States never leave the GPU.
+#include <climits>
+#include <cmath>
+
+#include "engine.h"
+
+namespace k2hip {
+
+void Engine::online_ensure_pool() {
+    if (online_pool_) return;
+    const Config& c = model_->cfg();
+    K2_REQUIRE(c.streaming, "this model is not a streaming export (metadata 'streaming' != 1)");
+    OnlineLayout& L = lay_;
+    long long off = 0;
+    auto put = [&](std::vector<long long>& v, long long n) {
+        v.push_back(off);
+        off += (n + 3) / 4 * 4;  // keep every cache 16-byte aligned
+    };
+    for (int si = 0; si < c.ns; si++) {
+        const int D = c.dim[si], H = c.heads[si], left = c.left[si];
+        for (int li = 0; li < c.nlayer[si]; li++) {
+            put(L.key, (long long)left * c.qhd[si] * H);
+            put(L.nonlin, (long long)left * (3 * D / 4));
+            put(L.val1, (long long)left * c.vhd[si] * H);
+            put(L.val2, (long long)left * c.vhd[si] * H);
+            put(L.conv1, (long long)D * (c.kern[si] / 2));
+            put(L.conv2, (long long)D * (c.kern[si] / 2));
+            L.sizes.push_back({(long long)left * c.qhd[si] * H, (long long)left * (3 * D / 4), (long long)left * c.vhd[si] * H,
+                               (long long)left * c.vhd[si] * H, (long long)D * (c.kern[si] / 2), (long long)D * (c.kern[si] / 2)});
+            L.nl++;
+        }
+    }
+    L.embed = off;
+    off += 128 * 3 * 19;
+    L.floats_per_stream = (off + 63) / 64 * 64;
+    online_cap_ = 256;
+    if (const char* e = getenv("K2HIP_MAX_STREAMS")) online_cap_ = std::max(1, atoi(e));
+    K2_HIP(hipSetDevice(device_));
+    K2_HIP(hipMalloc(&online_pool_, sizeof(float) * (size_t)L.floats_per_stream * online_cap_));
+    for (int i = online_cap_ - 1; i >= 0; i--) free_slots_.push_back(i);
+}
+
+int Engine::online_alloc_slot() {
+    online_ensure_pool();
+    if (free_slots_.empty())
+        failf(K2HIP_ERR_CAPACITY, "all %d stream slots are in use (raise K2HIP_MAX_STREAMS before creating the model)", online_cap_);
+    int slot = free_slots_.back();
+    free_slots_.pop_back();
+    // GetEncoderInitStates (OnlineProjOfZipformer2.cs:63-111): every cache starts at zero
+    K2_HIP(hipSetDevice(device_));
+    K2_HIP(hipMemsetAsync(online_pool_ + (size_t)slot * lay_.floats_per_stream, 0, sizeof(float) * (size_t)lay_.floats_per_stream, stream_));
+    K2_HIP(hipStreamSynchronize(stream_));
+    return slot;
+}
+void Engine::online_free_slot(int slot) {
+    if (slot >= 0) free_slots_.push_back(slot);
+}
+
+void Engine::online_read_state(int slot, int layer, int kind, float* out, int64_t cap, int64_t* n) {
+    online_ensure_pool();
+    K2_REQUIRE(slot >= 0 && slot < online_cap_, "bad slot %d", slot);
+    long long off, cnt;
+    if (kind == 6) {
+        off = lay_.embed;
+        cnt = 128 * 3 * 19;
+    } else {
+        K2_REQUIRE(layer >= 0 && layer < lay_.nl && kind >= 0 && kind < 6, "bad state index layer=%d kind=%d", layer, kind);
+        const std::vector<long long>* v[6] = {&lay_.key, &lay_.nonlin, &lay_.val1, &lay_.val2, &lay_.conv1, &lay_.conv2};
+        off = (*v[kind])[layer];
+        cnt = lay_.sizes[layer][kind];
+    }
+    *n = cnt;
+    if (!out) return;
+    if (cnt > cap) failf(K2HIP_ERR_CAPACITY, "state needs %lld floats", cnt);
+    K2_HIP(hipSetDevice(device_));
+    K2_HIP(hipStreamSynchronize(stream_));
+    K2_HIP(hipMemcpy(out, online_pool_ + (size_t)slot * lay_.floats_per_stream + off, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost));
+}
+
+int Engine::online_frames_per_chunk() const {
+    const Config& c = model_->cfg();
+    return (c.shift / 2 + 1) / 2;
+}
+
+// CompactRelPositionalEncoding.forward(x, left_context_len): row n <-> relative position n - (Tc+L-1)
+const float* Engine::pos_emb_stream(int Tc, int L) {
+    const int key = -(Tc * 100000 + L);  // negative keys: streaming tables
+    auto it = pe_cache_.find(key);
+    if (it != pe_cache_.end()) return it->second;
+    const int pd = model_->cfg().pos_dim, n2 = 2 * Tc - 1 + L;
+    std::vector<float> pe((size_t)n2 * pd);
+    const float cl = sqrtf((float)pd), ls = (float)pd / (2.0f * (float)M_PI), logcl = logf(cl);
+    for (int n = 0; n < n2; n++) {
+        float x = (float)(n - (Tc + L - 1));
+        float sg = (float)((x > 0.f) - (x < 0.f));
+        float xa = atanf(cl * sg * (logf(fabsf(x) + cl) - logcl) / ls);
+        for (int k = 0; k < pd / 2; k++) {
+            pe[(size_t)n * pd + 2 * k] = cosf(xa * (float)(k + 1));
+            pe[(size_t)n * pd + 2 * k + 1] = sinf(xa * (float)(k + 1));
+        }
+        pe[(size_t)n * pd + pd - 1] = 1.0f;
+    }
+    float* d = nullptr;
+    K2_HIP(hipMalloc(&d, pe.size() * sizeof(float)));
+    K2_HIP(hipMemcpy(d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+    pe_cache_[key] = d;
+    return d;
+}
+
+// Conv2dSubsampling.streaming_forward, NHWC.  x: [B,T,80] -> [B*Tc, D0]
+float* Engine::encoder_embed_stream(const Ctx& c, const float* x, const int* d_slots, int B, int T, int* Tc_out) {
+    const Model& m = *model_;
+    const int F0 = 80, T1 = T - 2, T2 = (T1 - 3) / 2 + 1, F2 = (F0 - 3) / 2 + 1, T3 = T2 - 2, F3 = (F2 - 3) / 2 + 1, Tc = T3 - 3;
+    K2_REQUIRE(Tc > 0 && F3 == 19, "streaming embed: chunk of %d frames unsupported", T);
+    Arena& ar = *c.arena;
+    const int D0 = m.cfg().dim[0];
+    float* out = ar.take<float>((int64_t)B * Tc * D0);
+    int64_t mark = ar.mark();
+    float* a1 = ar.take<float>((int64_t)B * T1 * F0 * 8);
+    conv0_swoosh(c, x, m.w("encoder_embed.conv.0.weight"), m.w("encoder_embed.conv.0.bias"), a1, B, T, F0);
+    float* a2 = ar.take<float>((int64_t)B * T2 * F2 * 32);
+    {
+        GemmArgs g;
+        g.A = a1; g.W = m.w("encoder_embed.conv.4.weight#ohwi"); g.ldw = 72; g.bias = m.w("encoder_embed.conv.4.bias");
+        g.C = a2; g.ldc = 32; g.M = B * T2 * F2; g.N = 32; g.K = 72; g.act = ACT_SWOOSH_R;
+        g.cv_Fout = F2; g.cv_Tout = T2; g.cv_Tin = T1; g.cv_Fin = F0; g.cv_C = 8; g.cv_st = 2; g.cv_sf = 2;
+        g.seg_len = 24; g.seg_stride = F0 * 8;
+        gemm(c, g);
+    }
+    float* a3 = ar.take<float>((int64_t)B * T3 * F3 * 128);
+    {
+        GemmArgs g;
+        g.A = a2; g.W = m.w("encoder_embed.conv.7.weight#ohwi"); g.ldw = 288; g.bias = m.w("encoder_embed.conv.7.bias");
+        g.C = a3; g.ldc = 128; g.M = B * T3 * F3; g.N = 128; g.K = 288; g.act = ACT_SWOOSH_R;
+        g.cv_Fout = F3; g.cv_Tout = T3; g.cv_Tin = T2; g.cv_Fin = F2; g.cv_C = 32; g.cv_st = 1; g.cv_sf = 2;
+        g.seg_len = 96; g.seg_stride = F2 * 32;
+        gemm(c, g);
+    }
+    // ConvNeXt.streaming_forward: [cache(3) ; a3(T3)] -> valid 7-tap time conv -> Tc frames
+    float* cat = ar.take<float>((int64_t)B * (T3 + 3) * F3 * 128);
+    convnext_cat(c, a3, online_pool_, lay_.floats_per_stream, lay_.embed, d_slots, cat, B, T3, F3, 128);
+    convnext_cache_update(c, a3, online_pool_, lay_.floats_per_stream, lay_.embed, d_slots, B, T3, Tc, F3, 128);
+    const int npix = B * Tc * F3;
+    float* dw = ar.take<float>((int64_t)npix * 128);
+    dwconv7x7(c, cat, m.w("encoder_embed.convnext.depthwise_conv.weight#kc"), m.w("encoder_embed.convnext.depthwise_conv.bias"), dw, B,
+              T3 + 3, Tc, 0, F3, 128);
+    float* byp = ar.take<float>((int64_t)npix * 128);  // bypass = x[:, :, :Tc]
+    if (!c.dry)
+        K2_HIP(hipMemcpy2DAsync(byp, sizeof(float) * (size_t)Tc * F3 * 128, a3, sizeof(float) * (size_t)T3 * F3 * 128,
+                                sizeof(float) * (size_t)Tc * F3 * 128, B, hipMemcpyDeviceToDevice, c.stream));
+    float* hid = ar.take<float>((int64_t)npix * 384);
+    linear(c, dw, 128, m.w("encoder_embed.convnext.pointwise_conv1.weight"), m.w("encoder_embed.convnext.pointwise_conv1.bias"), hid, 384,
+           npix, 128, 384, ACT_SWOOSH_L);
+    linear(c, hid, 384, m.w("encoder_embed.convnext.pointwise_conv2.weight"), m.w("encoder_embed.convnext.pointwise_conv2.bias"), byp, 128,
+           npix, 384, 128, ACT_NONE, byp, 128);
+    float* lin = ar.take<float>((int64_t)B * Tc * D0);
+    linear(c, byp, F3 * 128, m.w("encoder_embed.out.weight#fc"), m.w("encoder_embed.out.bias"), lin, D0, B * Tc, F3 * 128, D0);
+    biasnorm(c, lin, m.w("encoder_embed.out_norm.bias"), m.w("encoder_embed.out_norm.log_scale"), out, B * Tc, D0);
+    ar.rewind(mark);
+    *Tc_out = Tc;
+    return out;
+}
+
+// Zipformer2EncoderLayer.streaming_forward, in place on x [B*Tc, D]; l = global layer index
+void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x, const float* pe, const int* d_slots,
+                                  const long long* d_plen, int B, int Tc, int L) {
+    const Model& m = *model_;
+    const Config& cf = m.cfg();
+    const int D = cf.dim[si], F = cf.ff[si], H = cf.heads[si], vh = cf.vhd[si], K = cf.kern[si], qh = cf.qhd[si], ph = cf.phd[si];
+    const int M = B * Tc, KL = L + Tc, KLp = (KL + 3) & ~3, inproj = (2 * qh + ph) * H, Hc = 3 * D / 4, HV = H * vh;
+    const int n2 = 2 * Tc - 1 + L, left50 = cf.left[0] * cf.ds[0];
+    char p[96];
+    snprintf(p, sizeof p, "encoder.encoders.%d.layers.%d.", si, li);
+    auto w = [&](const char* suffix) { return m.w(std::string(p) + suffix); };
+    Arena& ar = *c.arena;
+    int64_t mark = ar.mark();
+    const long long SS = lay_.floats_per_stream;
+
+    float* qkp = ar.take<float>((int64_t)M * inproj);
+    linear(c, x, D, w("self_attn_weights.in_proj.weight"), w("self_attn_weights.in_proj.bias"), qkp, inproj, M, D, inproj);
+    float* kcat = ar.take<float>((int64_t)B * KL * qh * H);
+    cat_shift(c, online_pool_, SS, lay_.key[l], d_slots, qkp + qh * H, inproj, kcat, B, L, Tc, qh * H);
+    float* pp = ar.take<float>((int64_t)n2 * ph * H);
+    linear(c, pe, cf.pos_dim, w("self_attn_weights.linear_pos.weight"), nullptr, pp, ph * H, n2, cf.pos_dim, ph * H);
+    float* aw = ar.take<float>((int64_t)H * B * Tc * KLp);
+    attn_stream(c, qkp, inproj, kcat, pp, d_plen, aw, B, Tc, L, KLp, H, cf.ds[si], left50);
+
+    float* src = ar.take<float>((int64_t)M * D);
+    float* hid = ar.take<float>((int64_t)M * std::max({F * 5 / 4, 3 * Hc, 2 * D}));
+    float* tmp = ar.take<float>((int64_t)M * std::max(D, Hc));
+    float* tmp2 = ar.take<float>((int64_t)M * std::max(D, Hc));
+    float* vcat = ar.take<float>((int64_t)B * KL * std::max(Hc, HV));
+
+    auto feed_forward = [&](int k, int Fk, const float* in, float* out) {
+        char a[48], b[48], cc[48], d[48];
+        snprintf(a, sizeof a, "feed_forward%d.in_proj.weight", k);
+        snprintf(b, sizeof b, "feed_forward%d.in_proj.bias", k);
+        snprintf(cc, sizeof cc, "feed_forward%d.out_proj.weight", k);
+        snprintf(d, sizeof d, "feed_forward%d.out_proj.bias", k);
+        linear(c, in, D, w(a), w(b), hid, Fk, M, D, Fk, ACT_SWOOSH_L);
+        linear(c, hid, Fk, w(cc), w(d), out, D, M, Fk, D, ACT_NONE, in, D);
+    };
+    // out[b, :, col0:col0+n] = aw[h][b] (Tc x KL) . cat[b] (KL x width)[:, col0:col0+n]
+    auto attn_apply = [&](const float* cat, int width, float* out, int ldo, int nheads, int ncols) {
+        GemmArgs g;
+        g.A = aw; g.lda = KLp; g.sA0 = (long long)Tc * KLp; g.sA1 = (long long)B * Tc * KLp;
+        g.W = cat; g.w_kn = 1; g.ldw = width; g.sW0 = (long long)KL * width; g.sW1 = ncols;
+        g.C = out; g.ldc = ldo; g.sC0 = (long long)Tc * ldo; g.sC1 = ncols;
+        g.M = Tc; g.N = ncols; g.K = KL; g.nb0 = B; g.nb1 = nheads;
+        gemm(c, g);
+    };
+    auto self_attn = [&](int k, long long cache_off) {
+        char a[48], b[48], cc[48], d[48];
+        snprintf(a, sizeof a, "self_attn%d.in_proj.weight", k);
+        snprintf(b, sizeof b, "self_attn%d.in_proj.bias", k);
+        snprintf(cc, sizeof cc, "self_attn%d.out_proj.weight", k);
+        snprintf(d, sizeof d, "self_attn%d.out_proj.bias", k);
+        linear(c, src, D, w(a), w(b), hid, HV, M, D, HV);
+        cat_shift(c, online_pool_, SS, cache_off, d_slots, hid, HV, vcat, B, L, Tc, HV);
+        attn_apply(vcat, HV, tmp, HV, H, vh);
+        linear(c, tmp, HV, w(cc), w(d), src, D, M, HV, D, ACT_NONE, src, D);
+    };
+    auto conv_module = [&](int k, long long cache_off) {
+        char a[80], b[80], e[80], f[80], n1[96], n2_[96], n3[96], n4[96], n5[96];
+        snprintf(a, sizeof a, "conv_module%d.in_proj.weight", k);
+        snprintf(b, sizeof b, "conv_module%d.in_proj.bias", k);
+        snprintf(e, sizeof e, "conv_module%d.out_proj.weight", k);
+        snprintf(f, sizeof f, "conv_module%d.out_proj.bias", k);
+        snprintf(n1, sizeof n1, "conv_module%d.depthwise_conv.causal_conv.weight", k);
+        snprintf(n2_, sizeof n2_, "conv_module%d.depthwise_conv.causal_conv.bias", k);
+        snprintf(n3, sizeof n3, "conv_module%d.depthwise_conv.chunkwise_conv.weight", k);
+        snprintf(n4, sizeof n4, "conv_module%d.depthwise_conv.chunkwise_conv.bias", k);
+        snprintf(n5, sizeof n5, "conv_module%d.depthwise_conv.chunkwise_conv_scale", k);
+        linear(c, src, D, w(a), w(b), hid, 2 * D, M, D, 2 * D);
+        glu_causal_conv(c, hid, online_pool_, SS, cache_off, d_slots, w(n1), w(n2_), w(n3), w(n4), w(n5), tmp2, B, Tc, D, K);
+        linear(c, tmp2, D, w(e), w(f), src, D, M, D, D, ACT_NONE, src, D);
+    };
+
+    feed_forward(1, F * 3 / 4, x, src);
+    {   // NonlinAttention.streaming_forward
+        linear(c, src, D, w("nonlin_attention.in_proj.weight"), w("nonlin_attention.in_proj.bias"), hid, 3 * Hc, M, D, 3 * Hc);
+        tanh_gate(c, hid, tmp, M, Hc);
+        cat_shift(c, online_pool_, SS, lay_.nonlin[l], d_slots, tmp, Hc, vcat, B, L, Tc, Hc);
+        attn_apply(vcat, Hc, tmp2, Hc, 1, Hc);
+        mul_cols(c, tmp2, hid, 3 * Hc, 2 * Hc, M, Hc);
+        linear(c, tmp2, Hc, w("nonlin_attention.out_proj.weight"), w("nonlin_attention.out_proj.bias"), src, D, M, Hc, D, ACT_NONE, src, D);
+    }
+    self_attn(1, lay_.val1[l]);
+    conv_module(1, lay_.conv1[l]);
+    feed_forward(2, F, src, src);
+    bypass(c, x, src, w("bypass_mid.bypass_scale"), src, M, D);
+    self_attn(2, lay_.val2[l]);
+    conv_module(2, lay_.conv2[l]);
+    feed_forward(3, F * 5 / 4, src, src);
+    biasnorm_bypass(c, src, x, w("norm.bias"), w("norm.log_scale"), w("bypass.bypass_scale"), x, M, D);
+    ar.rewind(mark);
+}
+
+void Engine::online_step(const int* slots, const float* chunks, const long long* hyps, const long long* plens, int B,
+                         int64_t* tokens, int32_t* ts, int32_t* n_tokens) {
+    online_ensure_pool();
+    K2_REQUIRE(B > 0, "online_step: no ready stream");
+    const Model& m = *model_;
+    const Config& cf = m.cfg();
+    const int T = cf.chunk_T, Tp = online_frames_per_chunk();
+    long long* d_tok = nullptr;
+    int *d_ts = nullptr, *d_n = nullptr, *d_ovf = nullptr;
+    run_sized([&](const Ctx& c) {
+        Arena& ar = *c.arena;
+        d_tok = ar.take<long long>((int64_t)B * Tp);
+        d_ts = ar.take<int>((int64_t)B * Tp);
+        d_n = ar.take<int>(B);
+        d_ovf = ar.take<int>(1);
+        float* d_x = ar.take<float>((int64_t)B * T * cf.feat);
+        int* d_slots = ar.take<int>(B);
+        long long* d_plen = ar.take<long long>(B);
+        long long* d_hyp = ar.take<long long>(2 * B);
+        if (!c.dry) {
+            K2_HIP(hipEventRecord(ev_[0], c.stream));
+            K2_HIP(hipMemcpyAsync(d_x, chunks, sizeof(float) * (size_t)B * T * cf.feat, hipMemcpyHostToDevice, c.stream));
+            K2_HIP(hipMemcpyAsync(d_slots, slots, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
+            K2_HIP(hipMemcpyAsync(d_plen, plens, sizeof(long long) * B, hipMemcpyHostToDevice, c.stream));
+            K2_HIP(hipMemcpyAsync(d_hyp, hyps, sizeof(long long) * 2 * B, hipMemcpyHostToDevice, c.stream));
+        }
+        logfloor_inplace(c, d_x, (long long)B * T * cf.feat);  // online PadSequence (PadHelper.cs:9-13,58)
+        int Tc = 0;
+        float* x = encoder_embed_stream(c, d_x, d_slots, B, T, &Tc);
+        const int M = B * Tc;
+        float* outputs[kMaxStacks] = {nullptr};
+        int Dcur = cf.dim[0], l = 0;
+        for (int si = 0; si < cf.ns; si++) {
+            const int D = cf.dim[si], ds = cf.ds[si], L = cf.left[si];
+            float* xi = ar.take<float>((int64_t)M * D);
+            if (D == Dcur) {
+                if (!c.dry) K2_HIP(hipMemcpyAsync(xi, x, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, c.stream));
+            } else {
+                convert_channels(c, x, xi, M, Dcur, D);
+            }
+            Dcur = D;
+            if (ds == 1) {
+                const float* pe = c.dry ? nullptr : pos_emb_stream(Tc, L);
+                for (int li = 0; li < cf.nlayer[si]; li++, l++) encoder_layer_stream(c, si, li, l, xi, pe, d_slots, d_plen, B, Tc, L);
+                x = xi;
+            } else {
+                const int Td = (Tc + ds - 1) / ds;
+                float* y = ar.take<float>((int64_t)M * D);
+                int64_t mark = ar.mark();
+                float* xd = ar.take<float>((int64_t)B * Td * D);
+                downsample(c, xi, m.wf("encoder.encoders.%d.downsample.bias", si), xd, B, Tc, D, ds);
+                const float* pe = c.dry ? nullptr : pos_emb_stream(Td, L);
+                for (int li = 0; li < cf.nlayer[si]; li++, l++) encoder_layer_stream(c, si, li, l, xd, pe, d_slots, d_plen, B, Td, L);
+                upsample_combine(c, xi, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y, B, Tc, Td, D, ds);
+                ar.rewind(mark);
+                x = y;
+            }
+            outputs[si] = x;
+        }
+        const int Dmax = cf.dmax;
+        float* full = ar.take<float>((int64_t)M * Dmax);
+        int cur = cf.dim[cf.ns - 1];
+        copy_cols(c, outputs[cf.ns - 1], cur, 0, full, Dmax, 0, M, cur);
+        for (int i = cf.ns - 2; i >= 0; i--) {
+            int d = cf.dim[i];
+            if (d > cur) {
+                copy_cols(c, outputs[i], d, cur, full, Dmax, cur, M, d - cur);
+                cur = d;
+            }
+        }
+        const int Tpp = (Tc + 1) / 2;
+        K2_REQUIRE(Tpp == Tp, "internal: chunk yields %d frames, expected %d", Tpp, Tp);
+        float* dsd = ar.take<float>((int64_t)B * Tp * Dmax);
+        downsample(c, full, m.w("encoder.downsample_output.bias"), dsd, B, Tc, Dmax, 2);
+        float* enc = ar.take<float>((int64_t)B * Tp * cf.J);
+        linear(c, dsd, Dmax, m.w("joiner.encoder_proj.weight"), m.w("joiner.encoder_proj.bias"), enc, cf.J, B * Tp, Dmax, cf.J);
+        if (!c.dry) {
+            K2_HIP(hipEventRecord(ev_[3], c.stream));
+            K2_HIP(hipMemsetAsync(d_ovf, 0, sizeof(int), c.stream));
+        }
+        // OnlineRecognizer.cs:135-202: decoder on the streams' hyps, T' joiner steps, skip {blank, unk, 1}
+        GreedyArgs a;
+        a.enc = enc; a.B = B; a.Tp = Tp; a.t0 = nullptr; a.skip1 = 1; a.max_sym = INT_MAX;
+        a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = Tp; a.overflow = d_ovf; a.init_ctx = d_hyp;
+        greedy_loop(c, decjoin(), a);
+        if (!c.dry) K2_HIP(hipEventRecord(ev_[4], c.stream));
+    });
+    finish_tokens(d_tok, d_ts, d_n, d_ovf, B, Tp, tokens, ts, n_tokens);
+    auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, ev_[a], ev_[b]); return ms; };
+    timing_.fbank_ms = 0;
+    timing_.pad_ms = 0;
+    timing_.encoder_ms = el(0, 3);
+    timing_.greedy_ms = el(3, 4);
+    timing_.d2h_ms = el(4, 5);
+    timing_.total_ms = el(0, 5);
+}
+
+}  // namespace k2hip

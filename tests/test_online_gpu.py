@@ -1,0 +1,144 @@
+"""GPU parity of the streaming path (OnlineRecognizer / OnlineProjOfZipformer2 replacement):
+libk2hip.so against the streaming CPU oracle, chunk after chunk: tokens, timestamps, Hyp, and every
+cached state tensor in the stream's device slot."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ["key", "nonlin", "val1", "val2", "conv1", "conv2"]
+
+
+@pytest.fixture(scope="module")
+def stream_model_path(tmp_path_factory):
+    from k2transducerasr_amd.synth import write_synthetic_model
+    p = str(tmp_path_factory.mktemp("smodels") / "stiny.k2w")
+    write_synthetic_model(p, "zipformer2-streaming-tiny-test")
+    return p
+
+
+@pytest.fixture(scope="module")
+def rec(stream_model_path):
+    from k2transducerasr_amd import OnlineRecognizer
+    return OnlineRecognizer(stream_model_path)
+
+
+@pytest.fixture(scope="module")
+def ora(stream_model_path):
+    from oracle.online import OnlineOracle
+    return OnlineOracle(stream_model_path)
+
+
+def test_chunk_info_and_init(rec, ora):
+    assert (rec.chunk_length, rec.shift_length, rec.frames_per_chunk) == (ora.chunk_length, ora.shift_length, ora.frames_per_chunk) == (45, 32, 8)
+    s = rec.create_online_stream()
+    o = ora.create_stream()
+    assert s.tokens == [0, 0] and s.hyp == [0, 0] and s.timestamps == []   # OnlineStream.cs:44-45
+    for l in range(o.num_layers):
+        for k in KINDS:
+            a = s.state(l, k)
+            assert a.size == o.state(l, k).size and not a.any()           # GetEncoderInitStates: zeros
+    assert s.state(0, "embed").size == 128 * 3 * 19
+
+
+def test_streaming_matches_oracle_chunk_by_chunk(rec, ora):
+    from k2transducerasr_amd.synth import synth_utterance
+    B = 3
+    feats = [ora.fbank(synth_utterance(40 + u, d)) for u, d in enumerate([2.2, 1.6, 2.2])]
+    hs = [rec.create_online_stream() for _ in range(B)]
+    os_ = [ora.create_stream() for _ in range(B)]
+    T, S = rec.chunk_length, rec.shift_length
+    pos = [0] * B
+    for h, f in zip(hs, feats):
+        h.add_features(f)                      # whole utterance buffered; chunks are consumed one per step
+    steps = 0
+    while True:
+        ready = [b for b in range(B) if pos[b] + T <= feats[b].shape[0]]
+        dec, n_new = rec.get_results(hs)
+        assert [b for b in range(B) if dec[b]] == ready      # streams without a full chunk are skipped (:101-120)
+        if not ready:
+            break
+        want_new = ora.step([os_[b] for b in ready], [feats[b][pos[b] : pos[b] + T] for b in ready])
+        for b, wn in zip(ready, want_new):
+            assert n_new[b] == wn
+            pos[b] += S
+        for b in range(B):
+            assert hs[b].tokens == os_[b].tokens, (steps, b)
+            assert hs[b].timestamps == os_[b].timestamps
+            assert hs[b].hyp == os_[b].hyp
+        if steps in (0, 2):
+            for b in ready:
+                for l in range(os_[b].num_layers):
+                    for k in KINDS:
+                        np.testing.assert_allclose(hs[b].state(l, k), os_[b].state(l, k), atol=2e-4, rtol=0, err_msg=f"step {steps} stream {b} layer {l} {k}")
+                np.testing.assert_allclose(hs[b].state(0, "embed"), os_[b].state(0, "embed"), atol=2e-4, rtol=0)
+        steps += 1
+    assert steps >= 5
+    assert sum(len(o.tokens) - 2 for o in os_) > 0
+
+
+def test_fifo_add_samples_and_is_finished(rec, ora):
+    """AddSamples in 800-sample pushes (K2TransducerAsr.Examples/OnlineRecognizer.cs:135-139) produces the
+    same frames as one-shot fbank; IsFinished mirrors OnlineStream.cs:124-161."""
+    from k2transducerasr_amd.synth import synth_utterance
+    u = synth_utterance(50, 1.0)
+    s = rec.create_online_stream()
+    for i in range(0, u.size, 800):
+        s.add_samples(u[i : i + 800])
+    f = ora.fbank(u)
+    assert s.speech_length == f.size
+    assert s.is_finished(False) is False                      # not an endpoint -> false (:157-160)
+    assert s.is_finished(True) is False                       # data pending, more than a chunk buffered: no side effect
+    assert s.speech_length == f.size
+    n0 = 0
+    while rec.get_results([s])[0][0]:
+        n0 += 1
+    assert n0 == (f.shape[0] - rec.chunk_length) // rec.shift_length + 1
+    left = s.speech_length
+    assert 0 < left <= rec.chunk_length * 80
+    assert s.is_finished(True) is False                       # <= one chunk buffered: feeds 400 zero samples (:144-147)
+    grown = s.speech_length - left
+    assert grown > 0 and grown % 80 == 0                      # the 400 zero samples completed whole frames
+    e = rec.create_online_stream()
+    assert e.is_finished(True) is True                        # empty FIFO -> finished (:152-155)
+    z = rec.create_online_stream()
+    z.add_features(np.full((3, 80), 1.5, np.float32))
+    assert z.is_finished(True) is True                        # all elements equal their average -> finished (:136-141)
+
+
+def test_slots_are_recycled(rec):
+    a = rec.create_online_stream()
+    a.add_features(np.random.default_rng(0).standard_normal((45, 80)).astype(np.float32))
+    rec.get_results([a])
+    assert a.state(0, "key").any()
+    a.close()
+    b = rec.create_online_stream()                            # may reuse a's slot: must start from zeros
+    assert not b.state(0, "key").any() and not b.state(0, "embed").any()
+
+
+def test_streaming_zh_model_matches_oracle(tmp_path_factory):
+    """The benchmark's streaming architecture (BASELINE configs[3]: 16 layers, left context 128, vocab 2000),
+    random weights, two streams, a few chunks: tokens exact, states and nothing else drift."""
+    from k2transducerasr_amd import OnlineRecognizer
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    from oracle.online import OnlineOracle
+    p = str(tmp_path_factory.mktemp("szh") / "szh.k2w")
+    write_synthetic_model(p, "zipformer2-streaming-zh")
+    rec, ora = OnlineRecognizer(p), OnlineOracle(p)
+    feats = [ora.fbank(synth_utterance(60 + u, 1.7)) for u in range(2)]
+    hs = [rec.create_online_stream() for _ in feats]
+    os_ = [ora.create_stream() for _ in feats]
+    for h, f in zip(hs, feats):
+        h.add_features(f)
+    T, S = rec.chunk_length, rec.shift_length
+    for k in range((feats[0].shape[0] - T) // S + 1):
+        dec, n_new = rec.get_results(hs)
+        assert dec == [1, 1]
+        want = ora.step(os_, [f[k * S : k * S + T] for f in feats])
+        assert n_new == want
+        for h, o in zip(hs, os_):
+            assert h.tokens == o.tokens and h.timestamps == o.timestamps
+    for h, o in zip(hs, os_):
+        for l in (0, 7, 15):
+            for kind in KINDS:
+                np.testing.assert_allclose(h.state(l, kind), o.state(l, kind), atol=5e-4, rtol=0)
