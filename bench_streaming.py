@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Streaming benchmark (BASELINE.json configs[3]): zipformer streaming (OnlineProjOfZipformer2 replacement),
+chunk = 32 frames, N concurrent streams on one MI355X.  Driver protocol of the reference's example
+(K2TransducerAsr.Examples/OnlineRecognizer.cs:135-139,184-238): every stream is fed 800-sample (50 ms) pushes,
+then 30 x 400 zero samples of tail; one GetResults per push round over all streams.
+RTFx = total audio seconds / wall seconds, host samples in -> tokens in host memory (PCIe included).
+Not the headline metric (that is bench.py); prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=128)
+    ap.add_argument("--seconds", type=float, default=20.0)
+    ap.add_argument("--preset", default="zipformer2-streaming-zh")
+    ap.add_argument("--check", type=int, default=0, help="verify the first K streams against the CPU oracle")
+    args = ap.parse_args()
+    import k2transducerasr_amd as pkg
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+
+    weights = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"k2hip_bench_{args.preset}.k2w")
+    if not os.path.exists(weights):
+        write_synthetic_model(weights, args.preset)
+    os.environ.setdefault("K2HIP_MAX_STREAMS", str(max(256, args.streams)))
+    rec = pkg.OnlineRecognizer(weights)
+    N = args.streams
+    utts = [synth_utterance(1000 + u, args.seconds) for u in range(N)]
+    n = utts[0].size
+
+    def run():
+        streams = [rec.create_online_stream() for _ in range(N)]
+        steps = 0
+        t0 = time.perf_counter()
+        for pos in range(0, n, 800):
+            rec.add_samples_batch(streams, [u[pos : pos + 800] for u in utts])
+            dec, _ = rec.get_results(streams)
+            steps += any(dec)
+        zeros = np.zeros(400, np.float32)
+        for _ in range(30):
+            rec.add_samples_batch(streams, [zeros] * N)
+            dec, _ = rec.get_results(streams)
+            steps += any(dec)
+        rec.model.synchronize()
+        dt = time.perf_counter() - t0
+        return streams, dt, steps
+
+    streams, _, _ = run()  # warm-up (arena sizing, code load)
+    for s in streams:
+        s.close()
+    streams, dt, steps = run()
+    audio = N * args.seconds
+    t = rec.model.timing()
+    out = {
+        "metric": "RTFx (audio-sec/wall-sec) streaming Zipformer2 greedy",
+        "value": round(audio / dt, 1),
+        "unit": "audio-sec/wall-sec",
+        "n_gpus": 1,
+        "config": {"workload": f"{args.preset} streaming greedy, chunk=32 frames, {N} concurrent streams x {args.seconds:g} s, "
+                               "800-sample pushes + 30 x 400 zero tail (BASELINE.json configs[3])"},
+        "chunk_steps": steps,
+        "ms_per_chunk_step": round(dt / max(steps, 1) * 1e3, 3),
+        "last_step_ms": {k: round(t[k], 3) for k in ("total_ms", "encoder_ms", "greedy_ms")},
+        "tokens": int(sum(len(s.tokens) - 2 for s in streams)),
+        "dtype": "f32",
+        "data": "synthetic",
+    }
+    if args.check:
+        from oracle.online import OnlineOracle
+        ora = OnlineOracle(weights)
+        for u in range(args.check):
+            wav = np.concatenate([utts[u], np.zeros(30 * 400, np.float32)])
+            f = ora.fbank(wav)
+            o = ora.create_stream()
+            for k in range((f.shape[0] - rec.chunk_length) // rec.shift_length + 1):
+                ora.step([o], [f[k * rec.shift_length : k * rec.shift_length + rec.chunk_length]])
+            assert o.tokens == streams[u].tokens, f"stream {u} differs from the oracle"
+        out["oracle_checked_streams"] = args.check
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

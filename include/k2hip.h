@@ -227,6 +227,11 @@ int32_t k2hip_online_chunk_info(const k2hip_model_t* model, int32_t* chunk_lengt
                                 int32_t* frames_per_chunk);
 /* OnlineStream.AddSamples (:57-79): streaming fbank on the new samples, frames appended to the FIFO */
 int32_t k2hip_online_stream_accept_samples(k2hip_online_stream_t* s, const float* samples, int64_t n);
+/* AddSamples for many streams at once (one fbank launch for the whole round when every stream is at the
+ * same position, e.g. a server that feeds all connections on a common tick; falls back to per-stream
+ * launches otherwise).  Semantically B independent AddSamples calls. */
+int32_t k2hip_online_accept_samples_batch(k2hip_model_t* model, k2hip_online_stream_t* const* streams, int32_t B,
+                                          const float* const* samples, const int64_t* n);
 /* ... or push ready-made feature frames ([n_frames, feature_dim]) */
 int32_t k2hip_online_stream_accept_features(k2hip_online_stream_t* s, const float* feats, int64_t n_frames);
 /* OnlineInputEntity.SpeechLength (floats buffered) */

@@ -435,6 +435,7 @@ def _bind_online(L):
     L.k2hip_online_chunk_info.argtypes = [vp, ip, ip, ip]
     L.k2hip_online_stream_accept_samples.argtypes = [vp, fp, C.c_int64]
     L.k2hip_online_stream_accept_features.argtypes = [vp, fp, C.c_int64]
+    L.k2hip_online_accept_samples_batch.argtypes = [vp, C.POINTER(vp), C.c_int32, C.POINTER(fp), lp]
     L.k2hip_online_stream_speech_length.restype = C.c_int64
     L.k2hip_online_stream_speech_length.argtypes = [vp]
     L.k2hip_online_stream_is_finished.argtypes = [vp, C.c_int32, ip]
@@ -527,6 +528,15 @@ class OnlineRecognizer:
 
     def create_online_stream(self) -> OnlineStream:  # CreateOnlineStream :60-64
         return OnlineStream(self.model)
+
+    def add_samples_batch(self, streams: Sequence[OnlineStream], samples: Sequence[np.ndarray]):
+        """B AddSamples calls in one (one fbank launch when all streams are at the same position)."""
+        B = len(streams)
+        ss = [_f32(x).reshape(-1) for x in samples]
+        arr = (C.c_void_p * B)(*[s._h for s in streams])
+        ptrs = (fp * B)(*[_f(x) for x in ss])
+        n = np.array([x.size for x in ss], np.int64)
+        self.model._chk(self.model._L.k2hip_online_accept_samples_batch(self.model.handle, arr, B, ptrs, _l(n)))
 
     def get_results(self, streams: Sequence[OnlineStream]):
         """GetResults :76-84 (tokens, not text).  Returns (decoded flags, new-token counts)."""

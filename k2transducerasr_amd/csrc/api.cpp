@@ -360,6 +360,44 @@ int32_t k2hip_online_stream_accept_samples(k2hip_online_stream_t* s, const float
         online_add_samples(s, samples, n);
     });
 }
+int32_t k2hip_online_accept_samples_batch(k2hip_model_t* model, k2hip_online_stream_t* const* streams, int32_t B,
+                                          const float* const* samples, const int64_t* n) {
+    return guard([&] {
+        NEED(model); NEED(streams); NEED(samples); NEED(n);
+        K2_REQUIRE(B > 0, "accept_samples_batch: empty list");
+        Engine& e = model->engine;
+        const Config& c = e.model().cfg();
+        bool uniform = true;
+        for (int i = 0; i < B; i++) {
+            NEED(streams[i]);
+            if (n[i] > 0) NEED(samples[i]);
+            uniform = uniform && n[i] == n[0] && streams[i]->remainder.size() == streams[0]->remainder.size();
+        }
+        const int64_t len = (int64_t)streams[0]->remainder.size() + n[0];
+        const int64_t nf = uniform ? e.fbank_num_frames(len) : 0;
+        if (!uniform || nf == 0) {
+            for (int i = 0; i < B; i++) online_add_samples(streams[i], samples[i], n[i]);
+            return;
+        }
+        // all streams at the same position: one [B, len] buffer, one launch
+        std::vector<float> wav((size_t)B * len), feats((size_t)B * nf * c.feat);
+        for (int i = 0; i < B; i++) {
+            float* w = wav.data() + (size_t)i * len;
+            memcpy(w, streams[i]->remainder.data(), sizeof(float) * streams[i]->remainder.size());
+            memcpy(w + streams[i]->remainder.size(), samples[i], sizeof(float) * n[i]);
+        }
+        {
+            std::lock_guard<std::mutex> lk(e.mutex());
+            e.fbank_host_batch(wav.data(), len, B, feats.data(), nf);
+        }
+        for (int i = 0; i < B; i++) {
+            k2hip_online_stream* s = streams[i];
+            s->speech.insert(s->speech.end(), feats.begin() + (size_t)i * nf * c.feat, feats.begin() + (size_t)(i + 1) * nf * c.feat);
+            const float* w = wav.data() + (size_t)i * len;
+            s->remainder.assign(w + (size_t)nf * c.fbank.frame_shift, w + len);
+        }
+    });
+}
 int32_t k2hip_online_stream_accept_features(k2hip_online_stream_t* s, const float* feats, int64_t n_frames) {
     return guard([&] {
         NEED(s);

@@ -39,6 +39,8 @@ class Engine {
 
     // ---- operator-level entry points (host buffers in/out) ----
     void fbank_host(const float* samples, int64_t n, float* feats, int64_t cap_frames, int64_t* n_frames);
+    // n_utts equal-length signals [n_utts, n] -> feats [n_utts, nf, feat] in one launch
+    void fbank_host_batch(const float* samples, int64_t n, int n_utts, float* feats, int64_t nf);
     void pad_host(const float* const* speech, const int64_t* n_floats, int B, int tail, float* out, int64_t cap, int64_t* L);
     void encoder_host(const float* x, int B, int T, float* enc_out, int64_t cap, int* Tp);
     void encoder_tap_host(const float* x, int B, int T, int tap, float* out, int64_t cap, int64_t* n);
