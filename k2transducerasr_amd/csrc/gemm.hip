@@ -471,6 +471,9 @@ int g_forced_cfg = getenv("K2HIP_GEMM_CFG") ? atoi(getenv("K2HIP_GEMM_CFG")) : -
 int choose_cfg(const GemmArgs& a) {
     if (g_forced_cfg >= 0) return g_forced_cfg;
     if (a.N <= 64) return 2;    // 64x64 tiles, 4 waves
+    // few output tiles (streaming chunks: 256..2048 rows): the launch is one latency-bound K sweep per
+    // workgroup; small tiles with a 64-deep K step are fastest (gpurun_out/gemm_tune_s1.txt)
+    if ((double)a.M * a.N * a.nb0 * a.nb1 < 2.0e6) return 3;
     if (a.N <= 128) return 3;   // 64x64 tiles, K step 64
     return 5;                   // 128x64 tiles, 8 waves (LDS-DMA pipeline when K % 32 == 0)
 }

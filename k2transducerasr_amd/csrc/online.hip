@@ -50,21 +50,34 @@ __global__ void k_convnext_cache(const float* __restrict__ a3, float* __restrict
         a3[(((long long)b * T3 + (Tc - 3 + t)) * F + f) * C + c];
 }
 
-// cat[b] = [cache[slot_b] (L rows) ; new[b] (Tc rows)]; cache[slot_b] <- cat[b][Tc:]   (rows of `width` floats)
-// one thread per (b, 4 columns): it alone reads and writes its columns, so the in-place shift is safe
-__global__ void k_cat_shift(float* __restrict__ pool, long long slot_stride, long long off, const int* __restrict__ slots,
+// cat[b] = [cache[slot_b] (L rows) ; new[b] (Tc rows)]   (rows of `width` floats), fully parallel;
+// then (second launch, after cat is complete) cache[slot_b] <- cat[b][Tc:]
+__global__ void k_cat_build(const float* __restrict__ pool, long long slot_stride, long long off, const int* __restrict__ slots,
                             const float* __restrict__ newrows, int ldn, float* __restrict__ cat, int B, int L, int Tc,
                             int width) {
     int w4 = width >> 2;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * w4) return;
-    int b = i / w4, c = (i % w4) * 4;
-    float* cache = pool + (long long)slots[b] * slot_stride + off + c;
-    float* out = cat + (long long)b * (L + Tc) * width + c;
-    const float* nw = newrows + (long long)b * Tc * ldn + c;
-    for (int r = 0; r < L; r++) *reinterpret_cast<float4*>(out + (long long)r * width) = *reinterpret_cast<const float4*>(cache + (long long)r * width);
-    for (int r = 0; r < Tc; r++) *reinterpret_cast<float4*>(out + (long long)(L + r) * width) = *reinterpret_cast<const float4*>(nw + (long long)r * ldn);
-    for (int r = 0; r < L; r++) *reinterpret_cast<float4*>(cache + (long long)r * width) = *reinterpret_cast<const float4*>(out + (long long)(Tc + r) * width);
+    long long n = (long long)B * (L + Tc) * w4;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = (int)(i % w4) * 4;
+    long long br = i / w4;
+    int r = (int)(br % (L + Tc)), b = (int)(br / (L + Tc));
+    float4 v;
+    if (r < L) v = *reinterpret_cast<const float4*>(pool + (long long)slots[b] * slot_stride + off + (long long)r * width + c);
+    else v = *reinterpret_cast<const float4*>(newrows + ((long long)b * Tc + (r - L)) * ldn + c);
+    *reinterpret_cast<float4*>(cat + ((long long)b * (L + Tc) + r) * width + c) = v;
+}
+__global__ void k_cache_from_cat(float* __restrict__ pool, long long slot_stride, long long off, const int* __restrict__ slots,
+                                 const float* __restrict__ cat, int B, int L, int Tc, int width) {
+    int w4 = width >> 2;
+    long long n = (long long)B * L * w4;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = (int)(i % w4) * 4;
+    long long br = i / w4;
+    int r = (int)(br % L), b = (int)(br / L);
+    *reinterpret_cast<float4*>(pool + (long long)slots[b] * slot_stride + off + (long long)r * width + c) =
+        *reinterpret_cast<const float4*>(cat + ((long long)b * (L + Tc) + Tc + r) * width + c);
 }
 
 // RelPositionMultiheadAttentionWeights.streaming_forward for one (stream, head):
@@ -192,8 +205,10 @@ void cat_shift(const Ctx& ctx, float* pool, long long slot_stride, long long off
                int ldn, float* cat, int B, int L, int Tc, int width) {
     K2_REQUIRE(width % 4 == 0 && ldn % 4 == 0, "cat_shift: width %d / ld %d must be multiples of 4", width, ldn);
     if (ctx.dry) return;
-    hipLaunchKernelGGL(k_cat_shift, dim3(nb((long long)B * (width / 4), 64)), dim3(64), 0, ctx.stream, pool, slot_stride, off, slots,
-                       newrows, ldn, cat, B, L, Tc, width);
+    hipLaunchKernelGGL(k_cat_build, dim3(nb((long long)B * (L + Tc) * (width / 4), 256)), dim3(256), 0, ctx.stream, pool, slot_stride,
+                       off, slots, newrows, ldn, cat, B, L, Tc, width);
+    hipLaunchKernelGGL(k_cache_from_cat, dim3(nb((long long)B * L * (width / 4), 256)), dim3(256), 0, ctx.stream, pool, slot_stride, off,
+                       slots, cat, B, L, Tc, width);
     K2_HIP(hipGetLastError());
 }
 void attn_stream(const Ctx& ctx, const float* qkp, int ld, const float* kcat, const float* pp, const long long* plen,

@@ -22,7 +22,15 @@ for M, D, F in ((16160, 192, 512), (8096, 256, 768), (4064, 512, 1536), (2048, 7
                (M, F * 5 // 4, D, 1, 0), (M, D, F * 5 // 4, 0, 1), (M, 9 * D // 4, D, 0, 0), (M, D, 3 * D // 4, 0, 1),
                (M, 12 * H, D, 0, 0), (M, D, 12 * H, 0, 1), (M, 2 * D, D, 0, 0), (M, D, D, 0, 1)]
 shapes += [(307040, 384, 128, 1, 0), (307040, 128, 384, 0, 1), (16160, 192, 2432, 0, 0), (8096, 500, 512, 0, 0), (8096, 512, 768, 0, 0)]
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1] == "streaming":
+    # streaming-zh at 128 streams: rows = 128 x chunk frames of the stack
+    shapes = []
+    for M, D, F in ((2048, 192, 512), (1024, 256, 768), (512, 384, 1024), (256, 512, 1536)):
+        H = 8 if D == 512 else 4
+        shapes += [(M, 68 * H, D, 0, 0), (M, F * 3 // 4, D, 1, 0), (M, D, F * 3 // 4, 0, 1), (M, F, D, 1, 0), (M, D, F, 0, 1),
+                   (M, F * 5 // 4, D, 1, 0), (M, D, F * 5 // 4, 0, 1), (M, 9 * D // 4, D, 0, 0), (M, D, 3 * D // 4, 0, 1),
+                   (M, 12 * H, D, 0, 0), (M, D, 12 * H, 0, 1), (M, 2 * D, D, 0, 0), (M, D, D, 0, 1)]
+elif len(sys.argv) > 1:
     shapes = shapes[: int(sys.argv[1])]
 print(f"{'M':>7} {'N':>5} {'K':>5} act res |" + "".join(f" cfg{c}: us   TF/s |" for c in range(6)) + " auto")
 tot = [0.0] * 7
