@@ -32,6 +32,19 @@ UTT_SECONDS = 10.0
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
 
 
+def pmc_traffic():
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (cannot be read live:
+    counters need their own profiler run).  Valid only for the default workload they were taken on."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_traffic.json")))
+    if not files:
+        return None, "no PMC summary under profiles/"
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return d["hbm_bytes_per_launch"], (f"bytes per launch (fetch {d['fetch_bytes_per_launch']} + write {d['write_bytes_per_launch']}), "
+                                       f"from {os.path.relpath(files[-1], ROOT)}: {d['method']}")
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -88,7 +101,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=UTT_SECONDS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one synchronous call per step (no batch overlap)")
-    ap.add_argument("--cpu-utts", type=int, default=4)
+    ap.add_argument("--cpu-utts", type=int, default=32)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,6 +181,8 @@ def main():
         audio = world * args.steps * B * secs
         value = audio / elapsed
         ach = it["gemm_flops"] / (it["gemm_ms"] * 1e-3) / 1e12 if it["gemm_ms"] > 0 else 0.0
+        default_workload = args.preset == PRESET and B == BATCH and abs(secs - UTT_SECONDS) < 1e-9
+        traffic, traffic_note = pmc_traffic() if default_workload else (None, "PMC passes exist for the default workload only")
         out = {
             "metric": "RTFx (audio-sec/wall-sec) offline Zipformer greedy",
             "value": round(value, 1),
@@ -197,7 +212,8 @@ def main():
                 "peak": F32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": traffic_note,
                 "launches_per_step": it["gemm_launches"],
                 "flops_per_step": it["gemm_flops"],
                 "avg_launch_us": round(it["gemm_ms"] * 1e3 / max(it["gemm_launches"], 1), 2),

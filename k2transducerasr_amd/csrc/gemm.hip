@@ -67,6 +67,23 @@ __device__ __forceinline__ float4 sel4(bool ok, float4 v) {
     return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so
+// the natural x-fastest order makes every XCD read all of A.  Remap so that each XCD owns a contiguous
+// run of row-major tiles (a band of M): per XCD the L2 then holds A/8 + W instead of A + W/8.
+__device__ __forceinline__ void xcd_tile(int& mb, int& nb) {
+    const int gx = gridDim.x, nwg = gx * gridDim.y;
+    if (gridDim.z != 1 || nwg < 16) {  // batched launches keep the natural order
+        mb = blockIdx.y;
+        nb = blockIdx.x;
+        return;
+    }
+    const int orig = blockIdx.x + blockIdx.y * gx;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    mb = t / gx;
+    nb = t - mb * gx;
+}
+
 template <int BM, int BN, int WM, int WN, int BK, int MODE>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(GemmArgs g) {
     constexpr int LDSK = BK + 4;
@@ -95,7 +112,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
     float* __restrict__ C = g.C + z0 * g.sC0 + z1 * g.sC1;
     const float* __restrict__ R = g.res ? g.res + z0 * g.sR0 + z1 * g.sR1 : nullptr;
 
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int mb_, nb_;
+    xcd_tile(mb_, nb_);
+    const int m0 = mb_ * BM, n0 = nb_ * BN;
     const int Kp = (g.K + 3) & ~3;
 
     // ---- per-thread global-load coordinates (rows / columns clamped into range)
@@ -306,7 +325,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
     const float* __restrict__ W = g.W;
     float* __restrict__ C = g.C;
     const float* __restrict__ R = g.res;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int mb_, nb_;
+    xcd_tile(mb_, nb_);
+    const int m0 = mb_ * BM, n0 = nb_ * BN;
 
     // this lane's source pointer for each of the wave's DMA instructions (advances by BK per tile)
     const float* src[IPW];
