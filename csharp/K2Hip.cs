@@ -31,6 +31,20 @@ namespace K2TransducerAsr.Hip
         [DllImport(Lib)] internal static extern int k2hip_offline_greedy_single(IntPtr model, float[] feats, long nFloats,
             long[] tokens, int[] timestamps, int[] nTokens, int maxTokens);
 
+        // ---- streaming path (include/k2hip.h, "streaming path" section)
+        [DllImport(Lib)] internal static extern int k2hip_online_chunk_info(IntPtr model, out int chunkLength, out int shiftLength, out int framesPerChunk);
+        [DllImport(Lib)] internal static extern int k2hip_online_stream_create(IntPtr model, out IntPtr stream);
+        [DllImport(Lib)] internal static extern int k2hip_online_stream_destroy(IntPtr stream);
+        [DllImport(Lib)] internal static extern int k2hip_online_stream_accept_samples(IntPtr stream, float[] samples, long n);
+        [DllImport(Lib)] internal static extern int k2hip_online_stream_accept_features(IntPtr stream, float[] feats, long nFrames);
+        [DllImport(Lib)] internal static extern int k2hip_online_stream_is_finished(IntPtr stream, int isEndpoint, out int finished);
+        [DllImport(Lib)] internal static extern int k2hip_online_step(IntPtr model, IntPtr[] streams, int B, int[] decoded, int[] nNewTokens);
+        [DllImport(Lib)] internal static extern int k2hip_online_stream_num_tokens(IntPtr stream);
+        [DllImport(Lib)] internal static extern int k2hip_online_stream_num_timestamps(IntPtr stream);
+        [DllImport(Lib)] internal static extern int k2hip_online_stream_get_tokens(IntPtr stream, long[] tokens, int cap);
+        [DllImport(Lib)] internal static extern int k2hip_online_stream_get_timestamps(IntPtr stream, int[] timestamps, int cap);
+        [DllImport(Lib)] internal static extern int k2hip_online_stream_get_hyp(IntPtr stream, long[] hyp2);
+
         internal static void Check(int rc, string what)
         {
             if (rc != 0)
