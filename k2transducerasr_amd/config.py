@@ -104,6 +104,55 @@ def make_zipformer2_meta(
     return meta
 
 
+def make_conformer_meta(
+    *,
+    encoder_dim=512,
+    num_encoder_layers=12,
+    feedforward_dim=2048,
+    num_heads=8,
+    cnn_module_kernel=31,
+    joiner_dim=512,
+    decoder_dim=512,
+    vocab_size=5537,
+    context_size=2,
+    comment="",
+):
+    """Offline Conformer transducer (reference: Model_type "conformer" -> OfflineProjOfTransducer,
+    OfflineRecognizer.cs:38-53; BASELINE.json configs[4]).  The graph is icefall's
+    pruned_transducer_stateless2 Conformer (Conv2dSubsampling x4, rel-pos MHSA with pos_bias_u/v,
+    macaron feed-forward with DoubleSwish, conv module with GLU + depthwise conv, BasicNorm); the
+    csv keys reuse the Zipformer names with one entry."""
+    assert encoder_dim % num_heads == 0
+    meta = dict(FBANK_DEFAULTS)
+    meta.update(
+        {
+            "model_type": "conformer",
+            "version": "1",
+            "model_author": "k2hip-synthetic",
+            "comment": comment,
+            "encoder_dims": _csv([encoder_dim]),
+            "num_encoder_layers": _csv([num_encoder_layers]),
+            "feedforward_dims": _csv([feedforward_dim]),
+            "num_heads": _csv([num_heads]),
+            "cnn_module_kernels": _csv([cnn_module_kernel]),
+            "joiner_dim": str(joiner_dim),
+            "decoder_dim": str(decoder_dim),
+            "vocab_size": str(vocab_size),
+            "context_size": str(context_size),
+        }
+    )
+    return meta
+
+
+CONFORMER_PRESETS = {
+    # BASELINE.json configs[4]: conformer-zh (wenetspeech char model), 12 x (512, 2048, 8 heads, k=31)
+    "conformer-zh": dict(vocab_size=5537),
+    # parity-test model: odd head size, small kernel, decoder conv with groups = 1
+    "conformer-tiny-test": dict(encoder_dim=64, num_encoder_layers=2, feedforward_dim=160, num_heads=4, cnn_module_kernel=7,
+                                joiner_dim=512, decoder_dim=64, vocab_size=41),
+}
+
+
 # Architecture presets.  Dimensions are those of the public icefall recipes the
 # reference's model zoo was exported from (README.EN.md:8-35 lists the model
 # names; the dims themselves are external to the reference, SURVEY.md 8a K-table).
@@ -177,8 +226,10 @@ PRESETS = {
 
 
 def preset(name: str) -> dict:
+    if name in CONFORMER_PRESETS:
+        return make_conformer_meta(comment=name, **copy.deepcopy(CONFORMER_PRESETS[name]))
     if name not in PRESETS:
-        raise KeyError(f"unknown model preset {name!r}; have {sorted(PRESETS)}")
+        raise KeyError(f"unknown model preset {name!r}; have {sorted(PRESETS) + sorted(CONFORMER_PRESETS)}")
     return make_zipformer2_meta(comment=name, **copy.deepcopy(PRESETS[name]))
 
 

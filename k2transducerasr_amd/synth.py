@@ -25,6 +25,8 @@ BLANK_BIAS = {
     "zipformer2-tiny-test": 1.033,
     "zipformer2-streaming-zh": 3.0,
     "zipformer2-streaming-tiny-test": 1.0,
+    "conformer-zh": 4.0,
+    "conformer-tiny-test": 1.0,
 }
 
 
@@ -126,6 +128,67 @@ def zipformer2_tensor_specs(meta: Dict[str, str]) -> List[Tuple[str, tuple, str]
     return s
 
 
+def conformer_tensor_specs(meta: Dict[str, str]) -> List[Tuple[str, tuple, str]]:
+    """Tensors of an offline Conformer transducer under the state-dict names of icefall's
+    pruned_transducer_stateless2 (Scaled* modules folded to plain weights, as an export does)."""
+    D = ints(meta, "encoder_dims")[0]
+    L = ints(meta, "num_encoder_layers")[0]
+    F = ints(meta, "feedforward_dims")[0]
+    H = ints(meta, "num_heads")[0]
+    K = ints(meta, "cnn_module_kernels")[0]
+    J = int(meta["joiner_dim"])
+    DD = int(meta["decoder_dim"])
+    V = int(meta["vocab_size"])
+    ctx = int(meta["context_size"])
+    fdim = int(meta["feature_dim"])
+    out_width = (((fdim - 1) // 2) - 1) // 2
+    s: List[Tuple[str, tuple, str]] = []
+
+    def lin(prefix, out_f, in_f, bias=True):
+        s.append((prefix + ".weight", (out_f, in_f), "w"))
+        if bias:
+            s.append((prefix + ".bias", (out_f,), "b"))
+
+    e = "encoder.encoder_embed."
+    s += [
+        (e + "conv.0.weight", (8, 1, 3, 3), "w"),
+        (e + "conv.0.bias", (8,), "b"),
+        (e + "conv.3.weight", (32, 8, 3, 3), "w"),
+        (e + "conv.3.bias", (32,), "b"),
+        (e + "conv.6.weight", (128, 32, 3, 3), "w"),
+        (e + "conv.6.bias", (128,), "b"),
+    ]
+    lin(e + "out", D, 128 * out_width)
+    s.append((e + "out_norm.eps", (1,), "logeps"))
+    for j in range(L):
+        p = f"encoder.encoder.layers.{j}."
+        for ff in ("feed_forward_macaron", "feed_forward"):
+            lin(p + ff + ".0", F, D)
+            lin(p + ff + ".4", D, F)
+        lin(p + "self_attn.in_proj", 3 * D, D)
+        lin(p + "self_attn.out_proj", D, D)
+        lin(p + "self_attn.linear_pos", D, D, bias=False)
+        s.append((p + "self_attn.pos_bias_u", (H, D // H), "b"))
+        s.append((p + "self_attn.pos_bias_v", (H, D // H), "b"))
+        s.append((p + "conv_module.pointwise_conv1.weight", (2 * D, D, 1), "w"))
+        s.append((p + "conv_module.pointwise_conv1.bias", (2 * D,), "b"))
+        s.append((p + "conv_module.depthwise_conv.weight", (D, 1, K), "w"))
+        s.append((p + "conv_module.depthwise_conv.bias", (D,), "b"))
+        s.append((p + "conv_module.pointwise_conv2.weight", (D, D, 1), "w"))
+        s.append((p + "conv_module.pointwise_conv2.bias", (D,), "b"))
+        s.append((p + "norm_final.eps", (1,), "logeps"))
+    lin("joiner.encoder_proj", J, D)
+    lin("joiner.decoder_proj", J, DD)
+    lin("joiner.output_linear", V, J)
+    s.append(("decoder.embedding.weight", (V, DD), "emb"))
+    s.append(("decoder.conv.weight", (DD, DD, ctx), "w"))  # stateless2 decoder: groups = 1
+    return s
+
+
+def tensor_specs(meta: Dict[str, str]) -> List[Tuple[str, tuple, str]]:
+    return conformer_tensor_specs(meta) if meta["model_type"] == "conformer" else zipformer2_tensor_specs(meta)
+
+
 def _init(name: str, shape: tuple, kind: str, seed: int) -> np.ndarray:
     g = _rng(seed, name)
     if kind == "w":
@@ -144,6 +207,8 @@ def _init(name: str, shape: tuple, kind: str, seed: int) -> np.ndarray:
         return (0.5 * g.standard_normal(shape)).astype(np.float32)
     if kind == "emb":
         return g.standard_normal(shape).astype(np.float32)
+    if kind == "logeps":
+        return np.log(g.uniform(0.1, 0.5, shape)).astype(np.float32)
     raise ValueError(kind)
 
 
@@ -163,14 +228,18 @@ def write_synthetic_model(path: str, preset_name: str, seed: int = 20231212, bla
     meta["synthetic_seed"] = str(seed)
     meta["synthetic_blank_bias"] = repr(float(blank_bias))
 
+    conformer = meta["model_type"] == "conformer"
+
     def gen():
-        for name, shape, kind in zipformer2_tensor_specs(meta):
+        for name, shape, kind in tensor_specs(meta):
             a = _init(name, shape, kind, seed)
             if name == "joiner.output_linear.bias":
                 a[0] += np.float32(blank_bias)
             if name == "joiner.encoder_proj.weight":
                 a *= np.float32(4.0)  # let the (small) temporal variation reach the logits
-            if name == "encoder_embed.conv.0.weight":
+            if conformer and (name.endswith(".4.weight") or name.endswith("out_proj.weight") or name.endswith("pointwise_conv2.weight")):
+                a *= np.float32(0.25)  # the residual branches' output layers (icefall initial_scale = 0.25)
+            if name.endswith("encoder_embed.conv.0.weight"):
                 # zero-sum along time: a constant-in-time input (the large DC of
                 # log-mel features) maps to 0, so that random-weight activations
                 # keep their temporal variation instead of collapsing to a bias.

@@ -60,6 +60,8 @@ struct k2o_model {
     int qhd[MAX_STACKS], vhd[MAX_STACKS], phd[MAX_STACKS];
     int pos_dim, J, DD, V, ctx, feat;
     int dmax;
+    int conformer; /* model_type "conformer": see k2_oracle_conformer.c */
+    int conv_cpg;  /* decoder conv input channels per group (4: Zipformer recipes; DD: stateless2, groups = 1) */
     /* fbank */
     int sample_rate, frame_len, frame_shift, padded;
     float preemph, low_freq, high_freq, input_scale;
@@ -218,7 +220,8 @@ k2o_model* k2o_model_load(const char* path) {
         (void)nb;
     }
     const char* mt = k2o_meta(m, "model_type");
-    if (!mt || strcmp(mt, "zipformer2")) {
+    m->conformer = mt && !strcmp(mt, "conformer");
+    if (!mt || (strcmp(mt, "zipformer2") && !m->conformer)) {
         fail("model_type %s not supported by the oracle", mt ? mt : "(none)");
         k2o_model_free(m);
         return NULL;
@@ -238,6 +241,10 @@ k2o_model* k2o_model_load(const char* path) {
     m->V = meta_int(m, "vocab_size", 500);
     m->ctx = meta_int(m, "context_size", 2);
     m->feat = meta_int(m, "feature_dim", 80);
+    {
+        tensor_t* cw = find_t(m, "decoder.conv.weight");
+        m->conv_cpg = cw ? (int)cw->dims[1] : 4;
+    }
     m->dmax = 0;
     for (int i = 0; i < m->ns; i++)
         if (m->dim[i] > m->dmax) m->dmax = m->dim[i];
@@ -836,8 +843,10 @@ static float* convert_channels(const float* x, int M, int Din, int Dout) {
     return y;
 }
 
+#include "k2_oracle_conformer.c"
+
 int k2o_encoder_out_frames(const k2o_model* m, int T) {
-    (void)m;
+    if (m->conformer) return conformer_out_frames(T);
     int T50 = embed_out_frames(T);
     if (T50 <= 0) return 0;
     return (T50 + 1) / 2;
@@ -939,11 +948,12 @@ static int encoder_forward(const k2o_model* m, const float* xin, int B, int T, f
 
 int k2o_offline_encoder(const k2o_model* m, const float* x, int B, int T, float* enc_out) {
     int64_t n;
+    if (m->conformer) return conformer_forward(m, x, B, T, enc_out, -1, NULL, 0, &n);
     return encoder_forward(m, x, B, T, enc_out, -1, NULL, 0, &n);
 }
 int64_t k2o_offline_encoder_tap(const k2o_model* m, const float* x, int B, int T, int tap, float* out, int64_t cap) {
     int64_t n = 0;
-    int rc = encoder_forward(m, x, B, T, NULL, tap, out, cap, &n);
+    int rc = m->conformer ? conformer_forward(m, x, B, T, NULL, tap, out, cap, &n) : encoder_forward(m, x, B, T, NULL, tap, out, cap, &n);
     return rc < 0 ? rc : n;
 }
 
@@ -956,7 +966,8 @@ int64_t k2o_offline_encoder_tap(const k2o_model* m, const float* x, int B, int T
 int k2o_decoder(const k2o_model* m, const int64_t* y, int N, float* dec_out) {
     int DD = m->DD, ctx = m->ctx, V = m->V;
     const float* emb = W(m, "decoder.embedding.weight");
-    const float* cw = W(m, "decoder.conv.weight"); /* [DD, 4, ctx] */
+    const float* cw = W(m, "decoder.conv.weight"); /* [DD, cpg, ctx]; groups = DD / cpg */
+    const int cpg = m->conv_cpg;
     const float* pwt = WT(m, m->J, DD, "joiner.decoder_proj.weight");
     const float* pb = W(m, "joiner.decoder_proj.bias");
     float* h = falloc((size_t)N * DD);
@@ -964,13 +975,13 @@ int k2o_decoder(const k2o_model* m, const int64_t* y, int N, float* dec_out) {
         for (int k = 0; k < ctx; k++)
             if (y[n * ctx + k] >= V) { free(h); return fail("decoder: token id %ld out of range", (long)y[n * ctx + k]); }
         for (int co = 0; co < DD; co++) {
-            int g = co / 4;
+            int g = co / cpg;
             float s = 0.f;
-            for (int ci = 0; ci < 4; ci++)
+            for (int ci = 0; ci < cpg; ci++)
                 for (int k = 0; k < ctx; k++) {
                     int64_t id = y[n * ctx + k];
-                    float e = id >= 0 ? emb[(size_t)id * DD + g * 4 + ci] : 0.f;
-                    s += cw[(co * 4 + ci) * ctx + k] * e;
+                    float e = id >= 0 ? emb[(size_t)id * DD + g * cpg + ci] : 0.f;
+                    s += cw[((size_t)co * cpg + ci) * ctx + k] * e;
                 }
             h[(size_t)n * DD + co] = s > 0.f ? s : 0.f;
         }

@@ -58,3 +58,23 @@ def hip_tiny(tiny_model_path):
 def utts():
     from k2transducerasr_amd.synth import synth_utterance
     return [synth_utterance(u, s) for u, s in enumerate([1.3, 0.9, 1.1, 1.3, 0.7])]
+
+
+@pytest.fixture(scope="session")
+def conformer_tiny_path(tmp_path_factory):
+    from k2transducerasr_amd.synth import write_synthetic_model
+    p = str(tmp_path_factory.mktemp("models") / "conformer_tiny.k2w")
+    write_synthetic_model(p, "conformer-tiny-test")
+    return p
+
+
+@pytest.fixture(scope="session")
+def oracle_conformer(conformer_tiny_path):
+    from oracle import Oracle
+    return Oracle(conformer_tiny_path)
+
+
+@pytest.fixture(scope="session")
+def hip_conformer(conformer_tiny_path):
+    from k2transducerasr_amd import Model
+    return Model(conformer_tiny_path, 0)
