@@ -1,0 +1,87 @@
+// Helpers of the offline Conformer's RelPositionMultiheadAttention (icefall
+// pruned_transducer_stateless2; reference side: Model_type "conformer" ->
+// OfflineProjOfTransducer.EncoderProj, OfflineProjOfTransducer.cs:48-92).
+//
+// The two score products run on the MFMA GEMM as batched launches:
+//   ac[b,h] = (q*s + u_h) . k^T        [T, T]
+//   bd[b,h] = (q*s + v_h) . p_h^T      [T, 2T-1]
+// and the rel_shift (icefall does it with as_strided) is folded into the softmax as a gather:
+//   w[i, j] = softmax_j(ac[i, j] + bd[i, T-1-i+j])
+// The softmaxed weights are then the K-contiguous A operand of the value product.
+#include "kernels.h"
+
+namespace k2hip {
+namespace {
+
+__global__ void k_conformer_qprep(const float* __restrict__ qkv, const float* __restrict__ bu, const float* __restrict__ bv,
+                                  float* __restrict__ qu, float* __restrict__ qv, long long n4, int D4, float scaling) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    long long r = i / D4;
+    int c = (int)(i % D4) * 4;
+    float4 q = *reinterpret_cast<const float4*>(qkv + r * 3 * (D4 * 4) + c);
+    float4 u = *reinterpret_cast<const float4*>(bu + c);
+    float4 v = *reinterpret_cast<const float4*>(bv + c);
+    q.x *= scaling; q.y *= scaling; q.z *= scaling; q.w *= scaling;
+    reinterpret_cast<float4*>(qu)[i] = make_float4(q.x + u.x, q.y + u.y, q.z + u.z, q.w + u.w);
+    reinterpret_cast<float4*>(qv)[i] = make_float4(q.x + v.x, q.y + v.y, q.z + v.z, q.w + v.w);
+}
+
+// one wave per (z, i) row; the row lives in registers (T <= 64 * SM_PER_LANE)
+constexpr int SM_PER_LANE = 32;  // T <= 2048
+__global__ __launch_bounds__(256) void k_conformer_softmax_shift(float* __restrict__ ac, const float* __restrict__ bd, long long rows,
+                                                                 int T, int Tp, int NPp) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(row % T);
+    float* a = ac + row * Tp;
+    const float* b = bd + row * NPp + (T - 1 - i);
+    float v[SM_PER_LANE];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < SM_PER_LANE; u++) {
+        const int j = lane + 64 * u;
+        v[u] = j < T ? a[j] + b[j] : -INFINITY;
+        mx = fmaxf(mx, v[u]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < SM_PER_LANE; u++) {
+        const int j = lane + 64 * u;
+        v[u] = j < T ? __expf(v[u] - mx) : 0.f;
+        sum += v[u];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int u = 0; u < SM_PER_LANE; u++) {
+        const int j = lane + 64 * u;
+        if (j < Tp) a[j] = v[u] * inv;  // pad columns [T, Tp) become 0
+    }
+}
+
+}  // namespace
+
+void conformer_qprep(const Ctx& ctx, const float* qkv, const float* bias_u, const float* bias_v, float* qu, float* qv, int M,
+                     int D, float scaling) {
+    if (ctx.dry) return;
+    long long n4 = (long long)M * D / 4;
+    hipLaunchKernelGGL(k_conformer_qprep, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ctx.stream, qkv, bias_u, bias_v, qu, qv,
+                       n4, D / 4, scaling);
+    K2_HIP(hipGetLastError());
+}
+
+void conformer_softmax_shift(const Ctx& ctx, float* ac, const float* bd, int Z, int T, int Tp, int NPp) {
+    K2_REQUIRE(T <= 64 * SM_PER_LANE, "conformer attention: %d frames per call exceed %d", T, 64 * SM_PER_LANE);
+    ctx.add_flops(0.0, 0.0, 0);
+    if (ctx.dry) return;
+    long long rows = (long long)Z * T;
+    hipLaunchKernelGGL(k_conformer_softmax_shift, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx.stream, ac, bd, rows, T, Tp, NPp);
+    K2_HIP(hipGetLastError());
+}
+
+}  // namespace k2hip

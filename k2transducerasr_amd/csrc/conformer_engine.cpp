@@ -1,0 +1,175 @@
+// Offline Conformer encoder on the gfx950 kernels (BASELINE.json configs[4]).
+//
+// Reference side: Model_type "conformer" selects OfflineProjOfTransducer (OfflineRecognizer.cs:38-53);
+// EncoderProj (OfflineProjOfTransducer.cs:48-92) passes x [B,T,80] with x_lens = T for every row and
+// reads encoder_out [B,T',512].  The graph in between is icefall's pruned_transducer_stateless2
+// Conformer (restated in oracle/k2_oracle_conformer.c, which cites the published structure):
+//   Conv2dSubsampling(x4) -> 12 x { x += ff_macaron(x); x += rel-pos MHSA(x); x += conv_module(x);
+//   x += ff(x); x = BasicNorm(x) } -> joiner.encoder_proj.
+// Activations are batch-major [B*T', D]; every Linear / pointwise conv / implicit 3x3 conv / score and
+// value product is a gemm_f32_mfma launch with bias + DoubleSwish + residual fused in its epilogue.
+#include <cmath>
+
+#include "engine.h"
+
+namespace k2hip {
+
+int Engine::conformer_out_frames(int T) const { return T < 7 ? 0 : ((T - 1) / 2 - 1) / 2; }
+
+// RelPositionalEncoding.extend_pe in float32 arithmetic (as torch evaluates it): row n <-> relative
+// position T-1-n, pe[n,2k] = sin(r * div_k), pe[n,2k+1] = cos(r * div_k), div_k = exp(2k * -(ln 1e4 / D))
+const float* Engine::conformer_pos_emb(int T) {
+    auto it = pe_cache_.find(-T);  // negative keys: conformer tables (the Zipformer cache uses +T)
+    if (it != pe_cache_.end()) return it->second;
+    const int D = model_->cfg().dim[0], n2 = 2 * T - 1;
+    std::vector<float> pe((size_t)n2 * D);
+    const float cc = -(logf(10000.0f) / (float)D);
+    for (int n = 0; n < n2; n++) {
+        const float r = (float)(T - 1 - n);
+        for (int k = 0; k < D / 2; k++) {
+            const float div = expf((float)(2 * k) * cc);
+            pe[(size_t)n * D + 2 * k] = sinf(r * div);
+            pe[(size_t)n * D + 2 * k + 1] = cosf(r * div);
+        }
+    }
+    float* d = nullptr;
+    K2_HIP(hipMalloc(&d, pe.size() * sizeof(float)));
+    K2_HIP(hipMemcpy(d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+    pe_cache_[-T] = d;
+    return d;
+}
+
+// Conv2dSubsampling, NHWC: x [B,T,80] -> [B,T3,D]
+float* Engine::conformer_embed(const Ctx& c, const float* x, int B, int T, int* T_out) {
+    const Model& m = *model_;
+    const int F0 = 80, T2 = (T - 1) / 2, F2 = (F0 - 1) / 2, T3 = (T2 - 1) / 2, F3 = (F2 - 1) / 2, D = m.cfg().dim[0];
+    K2_REQUIRE(T3 > 0, "encoder: %d input frames are too few (need >= 7)", T);
+    Arena& ar = *c.arena;
+    float* out = ar.take<float>((int64_t)B * T3 * D);
+    int64_t mark = ar.mark();
+    float* a1 = ar.take<float>((int64_t)B * T * F0 * 8);
+    conv0_pad1_dswish(c, x, m.w("encoder.encoder_embed.conv.0.weight"), m.w("encoder.encoder_embed.conv.0.bias"), a1, B, T, F0);
+    c.add_flops(0, 2.0 * B * T * (double)F0 * 8 * 9, 0);
+    float* a2 = ar.take<float>((int64_t)B * T2 * F2 * 32);
+    {
+        GemmArgs g;
+        g.A = a1; g.W = m.w("encoder.encoder_embed.conv.3.weight#ohwi"); g.ldw = 72; g.bias = m.w("encoder.encoder_embed.conv.3.bias");
+        g.C = a2; g.ldc = 32; g.M = B * T2 * F2; g.N = 32; g.K = 72; g.act = ACT_DOUBLE_SWISH;
+        g.cv_Fout = F2; g.cv_Tout = T2; g.cv_Tin = T; g.cv_Fin = F0; g.cv_C = 8; g.cv_st = 2; g.cv_sf = 2;
+        g.seg_len = 24; g.seg_stride = F0 * 8;
+        gemm(c, g);
+    }
+    float* a3 = ar.take<float>((int64_t)B * T3 * F3 * 128);
+    {
+        GemmArgs g;
+        g.A = a2; g.W = m.w("encoder.encoder_embed.conv.6.weight#ohwi"); g.ldw = 288; g.bias = m.w("encoder.encoder_embed.conv.6.bias");
+        g.C = a3; g.ldc = 128; g.M = B * T3 * F3; g.N = 128; g.K = 288; g.act = ACT_DOUBLE_SWISH;
+        g.cv_Fout = F3; g.cv_Tout = T3; g.cv_Tin = T2; g.cv_Fin = F2; g.cv_C = 32; g.cv_st = 2; g.cv_sf = 2;
+        g.seg_len = 96; g.seg_stride = F2 * 32;
+        gemm(c, g);
+    }
+    // (b,t,f,c) flatten == [B*T3, F3*128] with the repacked out.weight
+    float* lin = ar.take<float>((int64_t)B * T3 * D);
+    linear(c, a3, F3 * 128, m.w("encoder.encoder_embed.out.weight#fc"), m.w("encoder.encoder_embed.out.bias"), lin, D, B * T3, F3 * 128, D);
+    basicnorm(c, lin, m.w("encoder.encoder_embed.out_norm.eps"), out, B * T3, D);
+    ar.rewind(mark);
+    *T_out = T3;
+    return out;
+}
+
+// ConformerEncoderLayer.forward (eval), in place on x [B*T, D]
+void Engine::conformer_layer(const Ctx& c, int li, float* x, const float* pe, int B, int T) {
+    const Model& m = *model_;
+    const Config& cf = m.cfg();
+    const int D = cf.dim[0], F = cf.ff[0], H = cf.heads[0], K = cf.kern[0], dk = D / H;
+    const int M = B * T, Tp = (T + 3) & ~3, NP = 2 * T - 1, NPp = (NP + 3) & ~3;
+    char p[96];
+    snprintf(p, sizeof p, "encoder.encoder.layers.%d.", li);
+    auto w = [&](const char* suffix) { return m.w(std::string(p) + suffix); };
+    Arena& ar = *c.arena;
+    int64_t mark = ar.mark();
+    float* hid = ar.take<float>((int64_t)M * std::max(F, 3 * D));
+
+    auto feed_forward = [&](const char* name) {
+        std::string n(name);
+        linear(c, x, D, w((n + ".0.weight").c_str()), w((n + ".0.bias").c_str()), hid, F, M, D, F, ACT_DOUBLE_SWISH);
+        linear(c, hid, F, w((n + ".4.weight").c_str()), w((n + ".4.bias").c_str()), x, D, M, F, D, ACT_NONE, x, D);
+    };
+
+    feed_forward("feed_forward_macaron");
+    {   // x += out_proj(softmax((q+u) k^T + rel_shift((q+v) p^T)) v)
+        float* qkv = hid;
+        linear(c, x, D, w("self_attn.in_proj.weight"), w("self_attn.in_proj.bias"), qkv, 3 * D, M, D, 3 * D);
+        float* pp = ar.take<float>((int64_t)NP * D);
+        linear(c, pe, D, w("self_attn.linear_pos.weight"), nullptr, pp, D, NP, D, D);
+        float* qu = ar.take<float>((int64_t)M * D);
+        float* qv = ar.take<float>((int64_t)M * D);
+        conformer_qprep(c, qkv, w("self_attn.pos_bias_u"), w("self_attn.pos_bias_v"), qu, qv, M, D, 1.0f / sqrtf((float)dk));
+        float* ac = ar.take<float>((int64_t)B * H * T * Tp);
+        float* bd = ar.take<float>((int64_t)B * H * T * NPp);
+        {   // ac[b,h] = qu[b,:,h] . k[b,:,h]^T      z = h + H*b
+            GemmArgs g;
+            g.A = qu; g.lda = D; g.sA0 = dk; g.sA1 = (long long)T * D;
+            g.W = qkv + D; g.ldw = 3 * D; g.sW0 = dk; g.sW1 = (long long)T * 3 * D;
+            g.C = ac; g.ldc = Tp; g.sC0 = (long long)T * Tp; g.sC1 = (long long)H * T * Tp;
+            g.M = T; g.N = T; g.K = dk; g.nb0 = H; g.nb1 = B;
+            gemm(c, g);
+        }
+        {   // bd[b,h] = qv[b,:,h] . p[:,h]^T
+            GemmArgs g;
+            g.A = qv; g.lda = D; g.sA0 = dk; g.sA1 = (long long)T * D;
+            g.W = pp; g.ldw = D; g.sW0 = dk; g.sW1 = 0;
+            g.C = bd; g.ldc = NPp; g.sC0 = (long long)T * NPp; g.sC1 = (long long)H * T * NPp;
+            g.M = T; g.N = NP; g.K = dk; g.nb0 = H; g.nb1 = B;
+            gemm(c, g);
+        }
+        conformer_softmax_shift(c, ac, bd, B * H, T, Tp, NPp);
+        float* ctxv = qu;  // [M, D], column block h
+        {   // ctxv[b,:,h] = w[b,h] . v[b,:,h]
+            GemmArgs g;
+            g.A = ac; g.lda = Tp; g.sA0 = (long long)T * Tp; g.sA1 = (long long)H * T * Tp;
+            g.W = qkv + 2 * D; g.w_kn = 1; g.ldw = 3 * D; g.sW0 = dk; g.sW1 = (long long)T * 3 * D;
+            g.C = ctxv; g.ldc = D; g.sC0 = dk; g.sC1 = (long long)T * D;
+            g.M = T; g.N = dk; g.K = T; g.nb0 = H; g.nb1 = B;
+            gemm(c, g);
+        }
+        linear(c, ctxv, D, w("self_attn.out_proj.weight"), w("self_attn.out_proj.bias"), x, D, M, D, D, ACT_NONE, x, D);
+    }
+    {   // x += pointwise_conv2(DoubleSwish(depthwise(GLU(pointwise_conv1(x)))))
+        float* tmp = ar.take<float>((int64_t)M * D);
+        linear(c, x, D, w("conv_module.pointwise_conv1.weight"), w("conv_module.pointwise_conv1.bias"), hid, 2 * D, M, D, 2 * D);
+        glu_dwconv1d_dswish(c, hid, w("conv_module.depthwise_conv.weight#kd"), w("conv_module.depthwise_conv.bias"), tmp, B, T, D, K);
+        linear(c, tmp, D, w("conv_module.pointwise_conv2.weight"), w("conv_module.pointwise_conv2.bias"), x, D, M, D, D, ACT_NONE, x, D);
+    }
+    feed_forward("feed_forward");
+    basicnorm(c, x, w("norm_final.eps"), x, M, D);
+    ar.rewind(mark);
+}
+
+// taps: 0 = encoder_embed output; 1+i = output of layer i
+float* Engine::conformer_forward(const Ctx& c, const float* x, int B, int T, int* Tp, int tap, float** tap_ptr, int* tap_rows,
+                                 int* tap_dim) {
+    const Model& m = *model_;
+    const Config& cf = m.cfg();
+    Arena& ar = *c.arena;
+    const int Tpp = conformer_out_frames(T);
+    K2_REQUIRE(Tpp > 0, "encoder: %d input frames are too few", T);
+    float* enc_out = ar.take<float>((int64_t)B * Tpp * cf.J);
+    int T3 = 0;
+    float* xe = conformer_embed(c, x, B, T, &T3);
+    if (tap_rows) *tap_rows = B * T3;
+    const float* pe = c.dry ? nullptr : conformer_pos_emb(T3);
+    for (int li = 0; li <= cf.nlayer[0]; li++) {
+        if (tap == li) {
+            *tap_ptr = xe;
+            *tap_dim = cf.dim[0];
+            return nullptr;
+        }
+        if (li < cf.nlayer[0]) conformer_layer(c, li, xe, pe, B, T3);
+    }
+    linear(c, xe, cf.dim[0], m.w("joiner.encoder_proj.weight"), m.w("joiner.encoder_proj.bias"), enc_out, cf.J, B * T3, cf.dim[0], cf.J);
+    *Tp = T3;
+    return enc_out;
+}
+
+}  // namespace k2hip

@@ -19,6 +19,7 @@ __device__ __forceinline__ float fast_tanh(float v) {
 }
 
 __device__ __forceinline__ float sigm(float s) { return 1.0f / (1.0f + __expf(-s)); }
+__device__ __forceinline__ float dswish(float v) { return v / (1.0f + __expf(1.0f - v)); }  // v * sigmoid(v - 1)
 
 inline int nblocks(long long n, int per) { return (int)((n + per - 1) / per); }
 
@@ -42,14 +43,16 @@ __global__ void k_pad_logfloor_dense(const float* __restrict__ feats, long long 
     }
 }
 
-// ---- Conv2dSubsampling conv.0: 1->8 ch, 3x3, pad (0,1), + SwooshR; out NHWC [B,T-2,F,8]
+// ---- Conv2dSubsampling conv.0: 1->8 ch, 3x3, pad (TPAD,1); out NHWC [B,T-2+2*TPAD,F,8]
+//      Zipformer2: TPAD 0 + SwooshR; Conformer: TPAD 1 + DoubleSwish
+template <int TPAD, bool DSWISH>
 __global__ void k_conv0(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                         float* __restrict__ y, int B, int T, int F) {
     __shared__ float sw[72], sb[8];
     if (threadIdx.x < 72) sw[threadIdx.x] = w[threadIdx.x];
     if (threadIdx.x < 8) sb[threadIdx.x] = bias[threadIdx.x];
     __syncthreads();
-    int T1 = T - 2;
+    int T1 = T - 2 + 2 * TPAD;
     long long n = (long long)B * T1 * F;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -61,8 +64,8 @@ __global__ void k_conv0(const float* __restrict__ x, const float* __restrict__ w
     for (int kt = 0; kt < 3; kt++)
 #pragma unroll
         for (int kf = 0; kf < 3; kf++) {
-            int ff = f + kf - 1;
-            xin[kt][kf] = (ff >= 0 && ff < F) ? x[((long long)b * T + t + kt) * F + ff] : 0.f;
+            int ff = f + kf - 1, tt = t + kt - TPAD;
+            xin[kt][kf] = (ff >= 0 && ff < F && tt >= 0 && tt < T) ? x[((long long)b * T + tt) * F + ff] : 0.f;
         }
     float o[8];
 #pragma unroll
@@ -72,7 +75,7 @@ __global__ void k_conv0(const float* __restrict__ x, const float* __restrict__ w
         for (int kt = 0; kt < 3; kt++)
 #pragma unroll
             for (int kf = 0; kf < 3; kf++) s += sw[(co * 3 + kt) * 3 + kf] * xin[kt][kf];
-        o[co] = swoosh_r(s);
+        o[co] = DSWISH ? dswish(s) : swoosh_r(s);
     }
     float4* yo = reinterpret_cast<float4*>(y + i * 8);
     yo[0] = make_float4(o[0], o[1], o[2], o[3]);
@@ -149,6 +152,33 @@ __global__ void k_biasnorm(const float* __restrict__ x, const float* __restrict_
     }
 }
 
+// ---- BasicNorm (Conformer): y = x * (mean(x^2) + exp(log_eps))^-0.5, one wave per row
+__global__ void k_basicnorm(const float* __restrict__ x, const float* __restrict__ log_eps, float* __restrict__ y, int M, int D) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    int lane = threadIdx.x & 63;
+    const float* xr = x + (long long)row * D;
+    float4 v[4];  // D <= 1024
+    int nq = D >> 2;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int q = lane + 64 * j;
+        if (q < nq) {
+            v[j] = *reinterpret_cast<const float4*>(xr + 4 * q);
+            s += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    float sc = 1.0f / sqrtf(s / (float)D + expf(log_eps[0]));
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int q = lane + 64 * j;
+        if (q < nq) *reinterpret_cast<float4*>(y + (long long)row * D + 4 * q) = make_float4(v[j].x * sc, v[j].y * sc, v[j].z * sc, v[j].w * sc);
+    }
+}
+
 // BypassModule: y = orig + (x - orig) * scale[d]
 __global__ void k_bypass(const float* __restrict__ orig, const float* __restrict__ x, const float* __restrict__ scale,
                          float* __restrict__ y, long long n4, int D4) {
@@ -199,6 +229,7 @@ __global__ void k_mul_cols(float* __restrict__ a, const float* __restrict__ x, i
 //  quad, so every LDS read of a wave is one conflict-free 1 KB row segment.
 constexpr int DW_TT = 8;                 // outputs per thread
 constexpr int DW_ROWS = 4 * DW_TT;       // output frames per workgroup
+template <bool DSWISH>
 __global__ __launch_bounds__(256) void k_glu_dwconv1d(const float* __restrict__ x2, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y, int B, int T,
                                                       int D, int K) {
@@ -239,7 +270,8 @@ __global__ __launch_bounds__(256) void k_glu_dwconv1d(const float* __restrict__ 
         const int t = t0 + wave * DW_TT + i;
         if (t < T)
             *reinterpret_cast<float4*>(y + ((long long)b * T + t) * D + c) =
-                make_float4(swoosh_r(acc[i].x), swoosh_r(acc[i].y), swoosh_r(acc[i].z), swoosh_r(acc[i].w));
+                DSWISH ? make_float4(dswish(acc[i].x), dswish(acc[i].y), dswish(acc[i].z), dswish(acc[i].w))
+                       : make_float4(swoosh_r(acc[i].x), swoosh_r(acc[i].y), swoosh_r(acc[i].z), swoosh_r(acc[i].w));
     }
 }
 
@@ -318,7 +350,15 @@ void pad_logfloor_dense(const Ctx& ctx, const float* feats, long long n_each, fl
 }
 void conv0_swoosh(const Ctx& ctx, const float* x, const float* w, const float* b, float* y, int B, int T, int F) {
     long long n = (long long)B * (T - 2) * F;
-    LAUNCH(k_conv0, dim3(nblocks(n, 256)), dim3(256), x, w, b, y, B, T, F);
+    LAUNCH((k_conv0<0, false>), dim3(nblocks(n, 256)), dim3(256), x, w, b, y, B, T, F);
+}
+void conv0_pad1_dswish(const Ctx& ctx, const float* x, const float* w, const float* b, float* y, int B, int T, int F) {
+    long long n = (long long)B * T * F;
+    LAUNCH((k_conv0<1, true>), dim3(nblocks(n, 256)), dim3(256), x, w, b, y, B, T, F);
+}
+void basicnorm(const Ctx& ctx, const float* x, const float* log_eps, float* y, int M, int D) {
+    K2_REQUIRE(D % 4 == 0 && D <= 1024, "basicnorm: D=%d unsupported", D);
+    LAUNCH(k_basicnorm, dim3(nblocks(M, 4)), dim3(256), x, log_eps, y, M, D);
 }
 void dwconv7x7(const Ctx& ctx, const float* x, const float* w_kc, const float* b, float* y, int B, int Tin, int T, int tpad,
                int F, int C) {
@@ -351,8 +391,9 @@ void mul_cols(const Ctx& ctx, float* a, const float* x, int ldx, int col0, int M
     long long n4 = (long long)M * N / 4;
     LAUNCH(k_mul_cols, dim3(nblocks(n4, 256)), dim3(256), a, x, ldx, col0, n4, N / 4);
 }
-void glu_dwconv1d_swoosh(const Ctx& ctx, const float* x2, const float* w_kd, const float* b, float* y, int B, int T, int D,
-                          int K) {
+template <bool DSWISH>
+static void glu_dwconv1d_any(const Ctx& ctx, const float* x2, const float* w_kd, const float* b, float* y, int B, int T, int D,
+                             int K) {
     K2_REQUIRE(D % 4 == 0, "dwconv1d: D=%d", D);
     size_t lds = sizeof(float) * (size_t)(DW_ROWS + K - 1) * 256;
     dim3 grid(cdiv(D, 256), cdiv(T, DW_ROWS), B);
@@ -360,11 +401,19 @@ void glu_dwconv1d_swoosh(const Ctx& ctx, const float* x2, const float* w_kd, con
     if (ctx.dry) return;
     static bool attr_set = false;
     if (!attr_set) {
-        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_glu_dwconv1d), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_glu_dwconv1d<DSWISH>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_glu_dwconv1d, grid, dim3(256), lds, ctx.stream, x2, w_kd, b, y, B, T, D, K);
+    hipLaunchKernelGGL(k_glu_dwconv1d<DSWISH>, grid, dim3(256), lds, ctx.stream, x2, w_kd, b, y, B, T, D, K);
     K2_HIP(hipGetLastError());
+}
+void glu_dwconv1d_swoosh(const Ctx& ctx, const float* x2, const float* w_kd, const float* b, float* y, int B, int T, int D,
+                          int K) {
+    glu_dwconv1d_any<false>(ctx, x2, w_kd, b, y, B, T, D, K);
+}
+void glu_dwconv1d_dswish(const Ctx& ctx, const float* x2, const float* w_kd, const float* b, float* y, int B, int T, int D,
+                          int K) {
+    glu_dwconv1d_any<true>(ctx, x2, w_kd, b, y, B, T, D, K);
 }
 void downsample(const Ctx& ctx, const float* x, const float* bias, float* y, int B, int T, int D, int ds) {
     int Td = (T + ds - 1) / ds;

@@ -70,6 +70,7 @@ Ctx Engine::make_ctx(bool dry) {
 }
 
 int Engine::encoder_out_frames(int T) const {
+    if (model_->cfg().conformer) return conformer_out_frames(T);
     int T50 = (T - 7) / 2;
     return T50 <= 0 ? 0 : (T50 + 1) / 2;
 }
@@ -107,7 +108,9 @@ DecJoinW Engine::decjoin() const {
     const Config& c = model_->cfg();
     DecJoinW w;
     w.emb = model_->w("decoder.embedding.weight");
-    w.conv = model_->w("decoder.conv.weight");
+    w.cpg = c.conv_cpg;
+    K2_REQUIRE(w.cpg <= 4 || w.cpg == c.DD, "decoder conv with %d channels per group: only <= 4 or groups = 1 are built", w.cpg);
+    w.conv = model_->w(w.cpg > 4 ? "decoder.conv.weight#kn" : "decoder.conv.weight");
     w.dproj_kn = model_->w("joiner.decoder_proj.weight#kn");
     w.dproj_b = model_->w("joiner.decoder_proj.bias");
     w.out_kn = model_->w("joiner.output_linear.weight#kn");
@@ -318,6 +321,7 @@ float* Engine::encoder_forward(const Ctx& c, const float* x, int B, int T, int* 
                                int* tap_dim) {
     const Model& m = *model_;
     const Config& cf = m.cfg();
+    if (cf.conformer) return conformer_forward(c, x, B, T, Tp, tap, tap_ptr, tap_rows, tap_dim);
     Arena& ar = *c.arena;
     int T50 = 0;
     // output first so that everything after it can be rewound

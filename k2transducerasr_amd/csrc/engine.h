@@ -93,6 +93,13 @@ class Engine {
     void greedy_device(const Ctx& c, const float* enc, int B, int Tp, bool single, long long* d_tok, int* d_ts, int* d_n,
                        int max_tokens, int* d_overflow);
     const float* pos_emb(int T);  // cached CompactRelPositionalEncoding table on device
+    // offline Conformer (conformer_engine.cpp)
+    int conformer_out_frames(int T) const;
+    const float* conformer_pos_emb(int T);
+    float* conformer_embed(const Ctx& c, const float* x, int B, int T, int* T_out);
+    void conformer_layer(const Ctx& c, int li, float* x, const float* pe, int B, int T);
+    float* conformer_forward(const Ctx& c, const float* x, int B, int T, int* Tp, int tap, float** tap_ptr, int* tap_rows,
+                             int* tap_dim);
     const float* pos_emb_stream(int Tc, int L);
     void online_ensure_pool();
     float* encoder_embed_stream(const Ctx& c, const float* x, const int* d_slots, int B, int T, int* Tc);

@@ -55,6 +55,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         }
         case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
         case ACT_RELU: return fmaxf(v, 0.f);
+        case ACT_DOUBLE_SWISH: return v / (1.0f + __expf(1.0f - v));  // v * sigmoid(v - 1)
         default: return v;
     }
 }

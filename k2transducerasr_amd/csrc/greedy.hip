@@ -26,23 +26,44 @@
 namespace k2hip {
 namespace {
 
-// dec_out[J] = decoder_proj(relu(grouped_conv(emb[y0], emb[y1])))   (block-wide, 256 threads)
-//   h: LDS scratch [DD]; out: LDS or global [J]
-__device__ void decoder_block(const DecJoinW& w, long long y0, long long y1, float* h, float* out) {
-    const int tid = threadIdx.x;
-    for (int co = tid; co < w.DD; co += blockDim.x) {
-        int g4 = (co >> 2) << 2;
-        float s = 0.f;
-#pragma unroll
-        for (int ci = 0; ci < 4; ci++) {
-            float e0 = y0 >= 0 ? w.emb[y0 * w.DD + g4 + ci] : 0.f;
-            float e1 = y1 >= 0 ? w.emb[y1 * w.DD + g4 + ci] : 0.f;
-            s += w.conv[(co * 4 + ci) * 2 + 0] * e0;
-            s += w.conv[(co * 4 + ci) * 2 + 1] * e1;
+// h[co] = relu(grouped Conv1d(k = 2) over (emb[y0], emb[y1])), id < 0 -> zero embedding.
+//   cpg <= 4 (Zipformer recipes, groups = DD/4): weights [DD][cpg][2], a handful of loads per output.
+//   cpg == DD (stateless2 decoder, groups = 1): weights k-major [2*DD][DD], k = ci*2 + tap; the stacked
+//   embeddings are staged in xe (LDS, [2*DD]) and every weight load is coalesced across outputs.
+__device__ void decoder_conv_narrow(const DecJoinW& w, long long y0, long long y1, float* h, float* xe) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (w.cpg <= 4) {
+        for (int co = tid; co < w.DD; co += nt) {
+            const int g0 = (co / w.cpg) * w.cpg;
+            float s = 0.f;
+            for (int ci = 0; ci < w.cpg; ci++) {
+                float e0 = y0 >= 0 ? w.emb[y0 * w.DD + g0 + ci] : 0.f;
+                float e1 = y1 >= 0 ? w.emb[y1 * w.DD + g0 + ci] : 0.f;
+                s += w.conv[(co * w.cpg + ci) * 2 + 0] * e0;
+                s += w.conv[(co * w.cpg + ci) * 2 + 1] * e1;
+            }
+            h[co] = fmaxf(s, 0.f);
         }
-        h[co] = fmaxf(s, 0.f);
+    } else {
+        for (int c = tid; c < w.DD; c += nt) {
+            xe[2 * c] = y0 >= 0 ? w.emb[y0 * w.DD + c] : 0.f;
+            xe[2 * c + 1] = y1 >= 0 ? w.emb[y1 * w.DD + c] : 0.f;
+        }
+        __syncthreads();
+        for (int co = tid; co < w.DD; co += nt) {
+            float s = 0.f;
+            for (int k = 0; k < 2 * w.DD; k++) s += xe[k] * w.conv[(long long)k * w.DD + co];
+            h[co] = fmaxf(s, 0.f);
+        }
     }
     __syncthreads();
+}
+
+// dec_out[J] = decoder_proj(relu(grouped_conv(emb[y0], emb[y1])))   (block-wide, 256 threads)
+//   h: LDS scratch [3*DD]; out: LDS or global [J]
+__device__ void decoder_block(const DecJoinW& w, long long y0, long long y1, float* h, float* out) {
+    const int tid = threadIdx.x;
+    decoder_conv_narrow(w, y0, y1, h, h + w.DD);
     for (int n = tid; n < w.J; n += blockDim.x) {
         float s = w.dproj_b[n];
         for (int k = 0; k < w.DD; k++) s += h[k] * w.dproj_kn[(long long)k * w.J + n];
@@ -125,55 +146,71 @@ constexpr int GT = 1024;   // threads per workgroup (16 waves)
 constexpr int APAD = 8;
 
 // dec_out[J] = decoder_proj(relu(grouped_conv(emb[y0], emb[y1]))), GT threads, two per output
-__device__ void decoder_block_wide(const DecJoinW& w, long long y0, long long y1, float* h, float* scratch /* >= 8*J floats */,
-                                   float* out) {
+// out[n] = f(bias[n] + sum_k x[k] * W[k*N + n]) for a k-major matrix, GT threads: 8 k slices x N/4 column
+// groups, 8 float4 weight loads in flight per thread (a dependent load per FMA made this ~50 us per
+// emission), partials combined through LDS.  x: LDS [K]; scratch: LDS >= 8*N floats; N % 4 == 0.
+__device__ void gemv_kn_wide(const float* x, int K, const float* __restrict__ W, const float* __restrict__ bias, int N,
+                             float* scratch, float* out, bool relu) {
     const int tid = threadIdx.x;
-    for (int co = tid; co < w.DD; co += GT) {
-        int g4 = (co >> 2) << 2;
-        float s = 0.f;
-#pragma unroll
-        for (int ci = 0; ci < 4; ci++) {
-            float e0 = y0 >= 0 ? w.emb[y0 * w.DD + g4 + ci] : 0.f;
-            float e1 = y1 >= 0 ? w.emb[y1 * w.DD + g4 + ci] : 0.f;
-            s += w.conv[(co * 4 + ci) * 2 + 0] * e0;
-            s += w.conv[(co * 4 + ci) * 2 + 1] * e1;
-        }
-        h[co] = fmaxf(s, 0.f);
-    }
-    __syncthreads();
-    // decoder_proj: 8 k slices x J/4 column groups; 8 float4 weight loads in flight per thread
-    // (a dependent load per FMA made this ~50 us per emission), partials combined through LDS
-    const int ncg = w.J >> 2, kslice = (w.DD + 7) >> 3;
+    const int ncg = N >> 2, kslice = (K + 7) >> 3;
     for (int u = tid; u < 8 * ncg; u += GT) {
         const int ks = u / ncg, cg = u - ks * ncg;
-        const int k0 = ks * kslice, k1 = min(k0 + kslice, w.DD);
+        const int k0 = ks * kslice, k1 = min(k0 + kslice, K);
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int kb = k0; kb < k1; kb += 8) {
             float4 wv[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int k = min(kb + i, k1 - 1);
-                wv[i] = *reinterpret_cast<const float4*>(w.dproj_kn + (long long)k * w.J + 4 * cg);
+                wv[i] = *reinterpret_cast<const float4*>(W + (long long)k * N + 4 * cg);
             }
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const float hv = (kb + i < k1) ? h[kb + i] : 0.f;
+                const float hv = (kb + i < k1) ? x[kb + i] : 0.f;
                 s.x += hv * wv[i].x; s.y += hv * wv[i].y; s.z += hv * wv[i].z; s.w += hv * wv[i].w;
             }
         }
-        *reinterpret_cast<float4*>(scratch + ks * w.J + 4 * cg) = s;
+        *reinterpret_cast<float4*>(scratch + ks * N + 4 * cg) = s;
     }
     __syncthreads();
-    for (int n = tid; n < w.J; n += GT) {
-        float s = w.dproj_b[n];
+    for (int n = tid; n < N; n += GT) {
+        float s = bias ? bias[n] : 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) s += scratch[ks * w.J + n];
-        out[n] = s;
+        for (int ks = 0; ks < 8; ks++) s += scratch[ks * N + n];
+        out[n] = relu ? fmaxf(s, 0.f) : s;
     }
     __syncthreads();
 }
 
-// LDS: actT[J][GF] | dec_a[J] | dec_b[J] | dec_own[J] | h[DD] | redv[16][GF] | redi[16][GF] | fin[GF]
+// h: LDS [3*DD] (h | stacked embeddings); scratch: LDS >= 8*max(J, DD) floats
+__device__ void decoder_block_wide(const DecJoinW& w, long long y0, long long y1, float* h, float* scratch, float* out) {
+    const int tid = threadIdx.x;
+    if (w.cpg <= 4) {
+        for (int co = tid; co < w.DD; co += GT) {
+            const int g0 = (co / w.cpg) * w.cpg;
+            float s = 0.f;
+            for (int ci = 0; ci < w.cpg; ci++) {
+                float e0 = y0 >= 0 ? w.emb[y0 * w.DD + g0 + ci] : 0.f;
+                float e1 = y1 >= 0 ? w.emb[y1 * w.DD + g0 + ci] : 0.f;
+                s += w.conv[(co * w.cpg + ci) * 2 + 0] * e0;
+                s += w.conv[(co * w.cpg + ci) * 2 + 1] * e1;
+            }
+            h[co] = fmaxf(s, 0.f);
+        }
+        __syncthreads();
+    } else {
+        float* xe = h + w.DD;
+        for (int c = tid; c < w.DD; c += GT) {
+            xe[2 * c] = y0 >= 0 ? w.emb[y0 * w.DD + c] : 0.f;
+            xe[2 * c + 1] = y1 >= 0 ? w.emb[y1 * w.DD + c] : 0.f;
+        }
+        __syncthreads();
+        gemv_kn_wide(xe, 2 * w.DD, w.conv, nullptr, w.DD, scratch, h, true);
+    }
+    gemv_kn_wide(h, w.DD, w.dproj_kn, w.dproj_b, w.J, scratch, out, false);
+}
+
+// LDS: actT[J][GF] | dec_a[J] | dec_b[J] | dec_own[J] | h[3*DD] (h | stacked embeddings) | redv[16][GF] | redi[16][GF] | fin[GF]
 __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* actT = sm;
@@ -181,7 +218,7 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
     float* dec_b = dec_a + w.J;
     float* dec_own = dec_b + w.J;
     float* h = dec_own + w.J;
-    float* redv = h + w.DD;
+    float* redv = h + 3 * w.DD;
     int* redi = reinterpret_cast<int*>(redv + 16 * GF);
     int* fin = redi + 16 * GF;
 
@@ -327,7 +364,7 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
 
 void decoder(const Ctx& ctx, const DecJoinW& w, const long long* y, int N, float* dec_out) {
     if (ctx.dry || N <= 0) return;
-    hipLaunchKernelGGL(k_decoder, dim3(N), dim3(256), sizeof(float) * w.DD, ctx.stream, w, y, dec_out);
+    hipLaunchKernelGGL(k_decoder, dim3(N), dim3(256), sizeof(float) * 3 * w.DD, ctx.stream, w, y, dec_out);
     K2_HIP(hipGetLastError());
 }
 void tanh_add(const Ctx& ctx, const float* enc, const float* dec, int dec_stride, float* y, int N, int J) {
@@ -349,7 +386,8 @@ void first_emit_frame(const Ctx& ctx, const int* tok, int B, int Tp, int skip1, 
 void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a) {
     if (ctx.dry || a.B <= 0) return;
     K2_REQUIRE(w.J % 8 == 0, "greedy: joiner_dim %d must be a multiple of 8", w.J);
-    size_t lds = sizeof(float) * ((size_t)w.J * GF + 8 * APAD + 3 * (size_t)w.J + w.DD + 32 * GF + GF + 8);
+    K2_REQUIRE(w.DD % 4 == 0 && 8 * w.DD <= w.J * GF, "greedy: decoder_dim %d too wide for the LDS scratch", w.DD);
+    size_t lds = sizeof(float) * ((size_t)w.J * GF + 8 * APAD + 3 * (size_t)w.J + 3 * (size_t)w.DD + 32 * GF + GF + 8);
     K2_REQUIRE(lds <= 160 * 1024, "greedy: vocab %d / joiner %d need %zu B of LDS", w.V, w.J, lds);
     static bool attr_set = false;
     if (!attr_set) {

@@ -42,7 +42,7 @@ struct Ctx {
     }
 };
 
-enum Act : int { ACT_NONE = 0, ACT_SWOOSH_L = 1, ACT_SWOOSH_R = 2, ACT_TANH = 3, ACT_SIGMOID = 4, ACT_RELU = 5 };
+enum Act : int { ACT_NONE = 0, ACT_SWOOSH_L = 1, ACT_SWOOSH_R = 2, ACT_TANH = 3, ACT_SIGMOID = 4, ACT_RELU = 5, ACT_DOUBLE_SWISH = 6 };
 
 // C[M,N] = act(A[M,K] . W^T + bias) (+ residual)     (fp32 MFMA, exact-f32 products)
 //   A: row-major, K contiguous, lda % 4 == 0; rows may be gathered (implicit conv)
@@ -84,6 +84,8 @@ void pad_logfloor(const Ctx& ctx, const float* packed, const long long* d_off, c
                   long long L);
 void pad_logfloor_dense(const Ctx& ctx, const float* feats, long long n_each, float* out, int B, long long L);
 void conv0_swoosh(const Ctx& ctx, const float* x, const float* w, const float* b, float* y, int B, int T, int F);
+// Conformer Conv2dSubsampling conv.0: 1->8 ch, 3x3, padding 1 in time and frequency, DoubleSwish; y: NHWC [B,T,F,8]
+void conv0_pad1_dswish(const Ctx& ctx, const float* x, const float* w, const float* b, float* y, int B, int T, int F);
 // depthwise 7x7 over [B,Tin,F,C] -> [B,Tout,F,C]; time taps read in[t + kt - tpad] (zero outside [0,Tin)).
 // offline ConvNeXt: Tin = Tout, tpad = 3; streaming: Tin = Tout + 6, tpad = 0 (left cache + right context supply the taps)
 void dwconv7x7(const Ctx& ctx, const float* x, const float* w_kc, const float* b, float* y, int B, int Tin, int Tout, int tpad,
@@ -99,6 +101,17 @@ void mul_cols(const Ctx& ctx, float* a, const float* x, int ldx, int col0, int M
 // y = SwooshR(dwconv1d(glu(x2)) + b);  x2: [B,T,2D] value|gate
 void glu_dwconv1d_swoosh(const Ctx& ctx, const float* x2, const float* w_kd, const float* b, float* y, int B, int T, int D,
                           int K);
+// same with DoubleSwish (Conformer ConvolutionModule)
+void glu_dwconv1d_dswish(const Ctx& ctx, const float* x2, const float* w_kd, const float* b, float* y, int B, int T, int D,
+                          int K);
+// BasicNorm: y = x * (mean(x^2) + exp(log_eps))^-0.5   (in place allowed)
+void basicnorm(const Ctx& ctx, const float* x, const float* log_eps, float* y, int M, int D);
+// Conformer rel-pos attention helpers (conformer.hip)
+//   qkv [M, 3D] -> qu = q*dk^-0.5 + pos_bias_u, qv = q*dk^-0.5 + pos_bias_v   ([M, D] each)
+void conformer_qprep(const Ctx& ctx, const float* qkv, const float* bias_u, const float* bias_v, float* qu, float* qv, int M,
+                     int D, float scaling);
+//   ac[z][i][j] (ld Tp) <- softmax_j(ac[z][i][j] + bd[z][i][T-1-i+j]) (rel_shift in gather form); pad columns zeroed
+void conformer_softmax_shift(const Ctx& ctx, float* ac, const float* bd, int Z, int T, int Tp, int NPp);
 void downsample(const Ctx& ctx, const float* x, const float* bias, float* y, int B, int T, int D, int ds);
 void upsample_combine(const Ctx& ctx, const float* orig, const float* xd, const float* scale, float* y, int B, int T,
                       int Td, int D, int ds);
@@ -124,7 +137,8 @@ void fbank(const Ctx& ctx, const FbankArgs& a);
 // ---- decoder / joiner / greedy ----------------------------------------------------
 struct DecJoinW {
     const float* emb;      // [V, DD]
-    const float* conv;     // [DD, 4, ctx]
+    const float* conv;     // [DD, cpg, ctx] (cpg <= 4) or k-major [cpg*ctx][DD] (cpg > 4)
+    int cpg;               // decoder conv input channels per group
     const float* dproj_kn; // [DD, J]
     const float* dproj_b;  // [J]
     const float* out_kn;   // [J, Vp]

@@ -174,8 +174,9 @@ void Model::parse_config() {
     };
     Config& c = cfg_;
     c.model_type = get("model_type", "");
-    if (c.model_type != "zipformer2")
-        failf(K2HIP_ERR_UNSUPPORTED, "model_type '%s' is not supported (have: zipformer2)", c.model_type.c_str());
+    c.conformer = c.model_type == "conformer";
+    if (c.model_type != "zipformer2" && !c.conformer)
+        failf(K2HIP_ERR_UNSUPPORTED, "model_type '%s' is not supported (have: zipformer2, conformer)", c.model_type.c_str());
     auto fill = [&](const char* k, int* dst) {
         auto v = csv_ints(get(k, ""));
         if ((int)v.size() > kMaxStacks) failf(K2HIP_ERR_INVALID, "metadata %s has too many entries", k);
@@ -187,8 +188,14 @@ void Model::parse_config() {
     const char* keys[] = {"num_encoder_layers", "feedforward_dims", "num_heads",      "cnn_module_kernels",
                           "downsampling_factors", "query_head_dims", "value_head_dims", "pos_head_dims"};
     int* dsts[] = {c.nlayer, c.ff, c.heads, c.kern, c.ds, c.qhd, c.vhd, c.phd};
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < (c.conformer ? 4 : 8); i++)
         if (fill(keys[i], dsts[i]) != c.ns) failf(K2HIP_ERR_INVALID, "metadata %s must have %d entries", keys[i], c.ns);
+    if (c.conformer) {
+        K2_REQUIRE(c.ns == 1, "conformer: encoder_dims must have one entry");
+        K2_REQUIRE(c.dim[0] % c.heads[0] == 0 && (c.dim[0] / c.heads[0]) % 4 == 0, "conformer: head size must be a multiple of 4");
+        c.ds[0] = 1;
+        c.qhd[0] = 32; c.phd[0] = 4; c.vhd[0] = 12;  // unused; keep the Zipformer checks below quiet
+    }
     c.pos_dim = geti("pos_dim", 48);
     c.J = geti("joiner_dim", 512);
     c.DD = geti("decoder_dim", 512);
@@ -242,7 +249,54 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
     };
     // A container may hold the decoder + joiner only (the reference also loads three separate
     // sessions, OfflineModel.cs:25-27); encoder entry points then fail with "no tensor ...".
-    const bool has_encoder = has("encoder_embed.conv.0.weight");
+    if (has("decoder.conv.weight")) {
+        const Tensor& t = tensor("decoder.conv.weight");
+        K2_REQUIRE(t.ndim == 3 && t.dims[0] == c.DD && t.dims[2] == c.ctx && c.DD % t.dims[1] == 0,
+                   "decoder.conv.weight is [%lld,%lld,%lld], config says [%d,*,%d]", (long long)t.dims[0], (long long)t.dims[1],
+                   (long long)t.dims[2], c.DD, c.ctx);
+        cfg_.conv_cpg = (int)t.dims[1];
+        if (cfg_.conv_cpg > 4) {  // wide groups (stateless2: groups = 1): k-major [cpg*ctx][DD] for a coalesced GEMV
+            const int cpg = cfg_.conv_cpg, KK = cpg * c.ctx;
+            std::vector<float> v((size_t)KK * c.DD);
+            for (int co = 0; co < c.DD; co++)
+                for (int k = 0; k < KK; k++) v[(size_t)k * c.DD + co] = t.host[(size_t)co * KK + k];
+            push("decoder.conv.weight#kn", std::move(v), {KK, c.DD});
+        }
+    }
+    if (c.conformer && has("encoder.encoder_embed.conv.0.weight")) {
+        for (const char* nm : {"encoder.encoder_embed.conv.3.weight", "encoder.encoder_embed.conv.6.weight"}) {
+            const Tensor& t = tensor(nm);
+            int Co = (int)t.dims[0], Ci = (int)t.dims[1];
+            std::vector<float> v((size_t)Co * 9 * Ci);
+            for (int co = 0; co < Co; co++)
+                for (int ci = 0; ci < Ci; ci++)
+                    for (int kt = 0; kt < 3; kt++)
+                        for (int kf = 0; kf < 3; kf++)
+                            v[((size_t)co * 9 + kt * 3 + kf) * Ci + ci] = t.host[(((size_t)co * Ci + ci) * 3 + kt) * 3 + kf];
+            push(std::string(nm) + "#ohwi", std::move(v), {Co, 9 * Ci});
+        }
+        {   // out Linear [D, c*F3+f] -> [D, f*128+c] (NHWC flatten order)
+            const Tensor& t = tensor("encoder.encoder_embed.out.weight");
+            int D0 = (int)t.dims[0], KK = (int)t.dims[1], C = 128, F3 = KK / C;
+            std::vector<float> v((size_t)D0 * KK);
+            for (int d = 0; d < D0; d++)
+                for (int ch = 0; ch < C; ch++)
+                    for (int f = 0; f < F3; f++) v[(size_t)d * KK + f * C + ch] = t.host[(size_t)d * KK + ch * F3 + f];
+            push("encoder.encoder_embed.out.weight#fc", std::move(v), {D0, KK});
+        }
+        for (int li = 0; li < c.nlayer[0]; li++) {
+            char nm[192];
+            snprintf(nm, sizeof nm, "encoder.encoder.layers.%d.conv_module.depthwise_conv.weight", li);
+            const Tensor& t = tensor(nm);
+            int D = (int)t.dims[0], K = (int)t.dims[2];
+            K2_REQUIRE(D == c.dim[0] && K == c.kern[0], "%s has shape [%d,1,%d], config says [%d,1,%d]", nm, D, K, c.dim[0], c.kern[0]);
+            std::vector<float> v((size_t)K * D);
+            for (int d = 0; d < D; d++)
+                for (int kk = 0; kk < K; kk++) v[(size_t)kk * D + d] = t.host[(size_t)d * K + kk];
+            push(std::string(nm) + "#kd", std::move(v), {K, D});
+        }
+    }
+    const bool has_encoder = !c.conformer && has("encoder_embed.conv.0.weight");
     if (has_encoder) {
     // conv filters [Co,Ci,3,3] -> [Co][kt][kf][ci]  (K index of the implicit GEMM over NHWC input)
     for (const char* nm : {"encoder_embed.conv.4.weight", "encoder_embed.conv.7.weight"}) {

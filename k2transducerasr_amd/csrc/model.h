@@ -40,6 +40,10 @@ struct Config {
     int Vp = 0;  // vocab padded to a multiple of 4 for the k-major joiner matrix
     // streaming export (OnlineModel.cs:38-110): ChunkLength = T, ShiftLength = decode_chunk_len,
     // left_context_len per stack (already divided by the stack's downsampling factor)
+    // model_type "conformer" (offline; OfflineRecognizer.cs:38-53 routes it to OfflineProjOfTransducer): one stack,
+    // dim[0] / nlayer[0] / ff[0] / heads[0] / kern[0]; see conformer_engine.cpp
+    bool conformer = false;
+    int conv_cpg = 4;  // decoder conv input channels per group (4: Zipformer recipes; DD: stateless2 decoder, groups = 1)
     bool streaming = false;
     int chunk_T = 0, shift = 0, left[kMaxStacks] = {0};
     FbankOpts fbank;

@@ -25,8 +25,8 @@ BLANK_BIAS = {
     "zipformer2-tiny-test": 1.033,
     "zipformer2-streaming-zh": 3.0,
     "zipformer2-streaming-tiny-test": 1.0,
-    "conformer-zh": 4.0,
-    "conformer-tiny-test": 1.0,
+    "conformer-zh": 2.615,
+    "conformer-tiny-test": 2.179,
 }
 
 
