@@ -68,6 +68,7 @@ def lib():
         L.k2o_greedy_batch.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, lp, ip, ip, C.c_int, fp]
         L.k2o_greedy_single.argtypes = [C.c_void_p, fp, C.c_int, lp, ip, ip, C.c_int, fp]
         L.k2o_offline_recognize_batch.argtypes = [C.c_void_p, C.POINTER(fp), lp, C.c_int, lp, ip, ip, C.c_int]
+        L.k2o_modified_beam_search.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, C.c_int, lp, ip, ip, C.c_int, fp, fp]
         _lib = L
     return _lib
 
@@ -204,6 +205,25 @@ class Oracle:
                                             _fp(mg) if want_margins else None))
         res = (tok[: n[0]].tolist(), ts[: n[0]].tolist())
         return (res, mg) if want_margins else res
+
+    def modified_beam_search(self, enc_out: np.ndarray, beam: int = 4, want_margins=False, want_scores=False):
+        """icefall modified_beam_search per stream (k2_oracle_beam.c); returns [(tokens, timestamps)] (+ margins [B,T'+1])."""
+        e = np.ascontiguousarray(enc_out, dtype=np.float32)
+        B, Tp, _ = e.shape
+        mt = Tp + 1
+        tok = np.zeros((B, mt), np.int64)
+        ts = np.zeros((B, mt), np.int32)
+        n = np.zeros(B, np.int32)
+        sc = np.zeros(B, np.float32)
+        mg = np.zeros((B, Tp + 1), np.float32)
+        self._chk(self._L.k2o_modified_beam_search(self._m, _fp(e), B, Tp, beam, _lp(tok), _ip(ts), _ip(n), mt, _fp(sc), _fp(mg)))
+        res = [(tok[b, : n[b]].tolist(), ts[b, : n[b]].tolist()) for b in range(B)]
+        out = (res,)
+        if want_margins:
+            out += (mg,)
+        if want_scores:
+            out += (sc,)
+        return out if len(out) > 1 else res
 
     def recognize_batch(self, feats):
         feats = [np.ascontiguousarray(f, dtype=np.float32).reshape(-1) for f in feats]

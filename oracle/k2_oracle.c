@@ -1137,4 +1137,5 @@ int k2o_offline_recognize_batch(const k2o_model* m, const float* const* feats, c
 }
 
 /* streaming (OnlineRecognizer) path: same translation unit, shares the static helpers above */
+#include "k2_oracle_beam.c"
 #include "k2_oracle_online.c"

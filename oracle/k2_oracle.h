@@ -83,6 +83,13 @@ int k2o_greedy_single(const k2o_model* m, const float* enc_out, int Tp,
                       int64_t* tokens, int32_t* timestamps, int32_t* n_tokens, int max_tokens,
                       float* margins);
 
+/* Modified beam search (icefall beam_search.py modified_beam_search; NOT in the reference, which only has
+ * greedy_search -- BASELINE.json configs[2] asks for it): see k2_oracle_beam.c.  enc_out [B,T',J]; tokens /
+ * timestamps [B,max_tokens] of the best hypothesis (length-normalised); scores [B] its log_prob (optional);
+ * margins [B,T'+1] (optional): per-frame beam-boundary score gap, final best-vs-second gap. */
+int k2o_modified_beam_search(const k2o_model* m, const float* enc_out, int B, int Tp, int beam, int64_t* tokens,
+                             int32_t* timestamps, int32_t* n_tokens, int max_tokens, float* scores, float* margins);
+
 /* End to end: features -> pad -> encoder -> batch greedy (GetResults). */
 int k2o_offline_recognize_batch(const k2o_model* m, const float* const* feats, const int64_t* n_floats, int B,
                                 int64_t* tokens, int32_t* timestamps, int32_t* n_tokens, int max_tokens);
