@@ -197,6 +197,22 @@ int32_t k2hip_offline_stream_accept_samples(k2hip_offline_stream_t* s, const flo
 int64_t k2hip_offline_stream_speech_length(const k2hip_offline_stream_t* s);
 /* copies Speech to out (cap floats) */
 int32_t k2hip_offline_stream_get_speech(const k2hip_offline_stream_t* s, float* out, int64_t cap);
+/* ---- decoding method --------------------------------------------------------------------------
+ * The reference picks the search by the recognizer's `decodingMethod` string (OfflineRecognizer.cs:54-68) and only
+ * knows "greedy_search".  BASELINE.json configs[2] adds "modified_beam_search" (icefall semantics, restated in
+ * DESIGN.md): per stream at most `beam` hypotheses, log-softmax over the vocabulary, top-`beam` over
+ * beam x V, equal token sequences merged by logaddexp, best hypothesis by length-normalised log-prob.
+ * The setting is per model handle and applies to every BATCH entry point (k2hip_offline_greedy*,
+ * k2hip_offline_recognizer_get_results, submit/wait); the single-stream path stays greedy. */
+int32_t k2hip_set_decoding_method(k2hip_model_t* model, const char* method /* "greedy_search" | "modified_beam_search" */,
+                                  int32_t beam /* 1..8, ignored for greedy_search */);
+/* operator level: modified beam search over a host encoder_out [B,T',J]; scores [B] (optional) = log-prob of the
+ * returned hypothesis */
+int32_t k2hip_beam_search(k2hip_model_t* model, const float* enc_out, int32_t B, int32_t Tprime, int32_t beam, int64_t* tokens,
+                          int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens, float* scores);
+/* log-probs of the hypotheses returned by the last synchronous batch call made under modified_beam_search */
+int32_t k2hip_last_scores(k2hip_model_t* model, float* scores, int32_t B);
+
 /* OfflineRecognizer.GetResults (:85-91) minus DecodeMulti: runs the fused batch
  * path on the streams' feature buffers, stores Tokens/Timestamps in each stream
  * (including the reference's 2*B-blank prefix) and calls RemoveSamples (:294). */

@@ -95,6 +95,9 @@ def load_library():
     L.k2hip_decoder.argtypes = [vp, lp, C.c_int32, fp]
     L.k2hip_joiner.argtypes = [vp, fp, fp, C.c_int32, fp]
     L.k2hip_greedy_batch.argtypes = [vp, fp, C.c_int32, C.c_int32, lp, ip, ip, C.c_int32]
+    L.k2hip_beam_search.argtypes = [vp, fp, C.c_int32, C.c_int32, C.c_int32, lp, ip, ip, C.c_int32, fp]
+    L.k2hip_set_decoding_method.argtypes = [vp, C.c_char_p, C.c_int32]
+    L.k2hip_last_scores.argtypes = [vp, fp, C.c_int32]
     L.k2hip_greedy_single.argtypes = [vp, fp, C.c_int32, lp, ip, ip, C.c_int32]
     L.k2hip_offline_greedy.argtypes = [vp, C.POINTER(fp), lp, C.c_int32, lp, ip, ip, C.c_int32]
     L.k2hip_offline_greedy_single.argtypes = [vp, fp, C.c_int64, lp, ip, ip, C.c_int32]
@@ -268,6 +271,27 @@ class Model:
         self._chk(self._L.k2hip_greedy_batch(self._h, _f(e), B, Tp, _l(tok), _i(ts), _i(n), Tp))
         return self._unpack(tok, ts, n)
 
+    def beam_search(self, enc_out, beam: int = 4, want_scores: bool = False):
+        """modified beam search over a host encoder_out [B,T',J] (k2hip_beam_search)"""
+        e = _f32(enc_out)
+        B, Tp, _ = e.shape
+        tok = np.zeros((B, Tp), np.int64)
+        ts = np.zeros((B, Tp), np.int32)
+        n = np.zeros(B, np.int32)
+        sc = np.zeros(B, np.float32)
+        self._chk(self._L.k2hip_beam_search(self._h, _f(e), B, Tp, beam, _l(tok), _i(ts), _i(n), Tp, _f(sc)))
+        res = self._unpack(tok, ts, n)
+        return (res, sc) if want_scores else res
+
+    def set_decoding_method(self, method: str = "greedy_search", beam: int = 4):
+        """decodingMethod of the batch entry points (OfflineRecognizer.cs:54-68): greedy_search | modified_beam_search"""
+        self._chk(self._L.k2hip_set_decoding_method(self._h, method.encode(), beam))
+
+    def last_scores(self, B: int):
+        sc = np.zeros(B, np.float32)
+        self._chk(self._L.k2hip_last_scores(self._h, _f(sc), B))
+        return sc
+
     def greedy_single(self, enc_out):
         e = _f32(enc_out).reshape(-1, self.joiner_dim)
         Tp = e.shape[0]
@@ -403,10 +427,12 @@ class OfflineStream:
 
 
 class OfflineRecognizer:
-    """OfflineRecognizer.cs:12-91 with decodingMethod = "greedy_search" on the HIP backend."""
+    """OfflineRecognizer.cs:12-91 on the HIP backend; decoding_method "greedy_search" (the reference's only method) or
+    "modified_beam_search" (BASELINE.json configs[2])."""
 
-    def __init__(self, weights_path: str, device: int = 0):
+    def __init__(self, weights_path: str, device: int = 0, decoding_method: str = "greedy_search", beam: int = 4):
         self.model = Model(weights_path, device)
+        self.model.set_decoding_method(decoding_method, beam)
 
     def create_offline_stream(self) -> OfflineStream:  # CreateOfflineStream :71-75
         return OfflineStream(self.model)

@@ -221,6 +221,45 @@ int32_t k2hip_greedy_single(k2hip_model_t* model, const float* enc_out, int32_t 
         model->engine.greedy_host(enc_out, 1, Tprime, true, tokens, timestamps, n_tokens, max_tokens);
     });
 }
+int32_t k2hip_set_decoding_method(k2hip_model_t* model, const char* method, int32_t beam) {
+    return guard([&] {
+        NEED(model); NEED(method);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        if (!strcmp(method, "greedy_search")) {
+            model->engine.set_beam(0);
+        } else if (!strcmp(method, "modified_beam_search")) {
+            K2_REQUIRE(beam >= 1 && beam <= kMaxBeam, "modified_beam_search: beam %d out of range [1,%d]", beam, kMaxBeam);
+            model->engine.set_beam(beam);
+        } else {
+            failf(K2HIP_ERR_UNSUPPORTED, "decoding method '%s' (have: greedy_search, modified_beam_search)", method);
+        }
+    });
+}
+int32_t k2hip_beam_search(k2hip_model_t* model, const float* enc_out, int32_t B, int32_t Tprime, int32_t beam, int64_t* tokens,
+                          int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens, float* scores) {
+    return guard([&] {
+        NEED(model); NEED(enc_out); NEED(tokens); NEED(timestamps); NEED(n_tokens);
+        K2_REQUIRE(beam >= 1 && beam <= kMaxBeam, "beam search: beam %d out of range [1,%d]", beam, kMaxBeam);
+        Engine& e = model->engine;
+        std::lock_guard<std::mutex> lk(e.mutex());
+        struct Restore {
+            Engine& e; int old;
+            ~Restore() { e.set_beam(old); }
+        } restore{e, e.beam()};
+        e.set_beam(beam);
+        e.greedy_host(enc_out, B, Tprime, false, tokens, timestamps, n_tokens, max_tokens);
+        if (scores) memcpy(scores, e.last_scores().data(), sizeof(float) * B);
+    });
+}
+int32_t k2hip_last_scores(k2hip_model_t* model, float* scores, int32_t B) {
+    return guard([&] {
+        NEED(model); NEED(scores);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        K2_REQUIRE((size_t)B == model->engine.last_scores().size(), "last_scores: the last beam-search call had %zu streams, not %d",
+                   model->engine.last_scores().size(), B);
+        memcpy(scores, model->engine.last_scores().data(), sizeof(float) * B);
+    });
+}
 int32_t k2hip_offline_greedy(k2hip_model_t* model, const float* const* feats, const int64_t* n_floats, int32_t B,
                              int64_t* tokens, int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens) {
     return guard([&] {

@@ -3,7 +3,7 @@
 // Reference side: Model_type "conformer" selects OfflineProjOfTransducer (OfflineRecognizer.cs:38-53);
 // EncoderProj (OfflineProjOfTransducer.cs:48-92) passes x [B,T,80] with x_lens = T for every row and
 // reads encoder_out [B,T',512].  The graph in between is icefall's pruned_transducer_stateless2
-// Conformer (restated in oracle/k2_oracle_conformer.c, which cites the published structure):
+// Conformer (the published structure; DESIGN.md section 2 says how it is cross-checked):
 //   Conv2dSubsampling(x4) -> 12 x { x += ff_macaron(x); x += rel-pos MHSA(x); x += conv_module(x);
 //   x += ff(x); x = BasicNorm(x) } -> joiner.encoder_proj.
 // Activations are batch-major [B*T', D]; every Linear / pointwise conv / implicit 3x3 conv / score and

@@ -356,6 +356,10 @@ float* Engine::encoder_forward(const Ctx& c, const float* x, int B, int T, int* 
 // ---------------------------------------------------------------------------
 void Engine::greedy_device(const Ctx& c, const float* enc, int B, int Tp, bool single, long long* d_tok, int* d_ts, int* d_n,
                            int max_tokens, int* d_overflow) {
+    if (beam_ > 0 && !single) {
+        beam_device(c, enc, B, Tp, d_tok, d_ts, d_n, max_tokens, d_overflow);
+        return;
+    }
     const Config& cf = model_->cfg();
     Arena& ar = *c.arena;
     DecJoinW w = decjoin();
@@ -386,6 +390,18 @@ void Engine::greedy_device(const Ctx& c, const float* enc, int B, int Tp, bool s
     greedy_loop(c, w, a);
 }
 
+// modified beam search instead of the greedy loop (set_beam(K) selects it for the fused / operator entry points)
+void Engine::beam_device(const Ctx& c, const float* enc, int B, int Tp, long long* d_tok, int* d_ts, int* d_n, int max_tokens,
+                         int* d_overflow) {
+    BeamArgs a;
+    a.enc = enc; a.out_w = model_->w("joiner.output_linear.weight");
+    a.B = B; a.Tp = Tp; a.beam = beam_;
+    a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = max_tokens; a.overflow = d_overflow;
+    d_scores_ = c.arena->take<float>(B);
+    a.scores = d_scores_;
+    beam_search(c, decjoin(), a);
+}
+
 void Engine::finish_tokens(const long long* d_tok, const int* d_ts, const int* d_n, const int* d_ovf, int B, int max_tokens,
                            int64_t* tokens, int32_t* ts, int32_t* n_tokens) {
     int64_t nb_tok = (int64_t)B * max_tokens * 8, nb_ts = (int64_t)B * max_tokens * 4, nb_n = (int64_t)B * 4;
@@ -401,6 +417,10 @@ void Engine::finish_tokens(const long long* d_tok, const int* d_ts, const int* d
     memcpy(tokens, pin, nb_tok);
     memcpy(ts, pin + nb_tok, nb_ts);
     memcpy(n_tokens, pin + nb_tok + nb_ts, nb_n);
+    if (beam_ > 0 && d_scores_) {
+        last_scores_.resize(B);
+        K2_HIP(hipMemcpy(last_scores_.data(), d_scores_, sizeof(float) * B, hipMemcpyDeviceToHost));
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -75,6 +75,11 @@ class Engine {
                      int64_t* tokens, int32_t* ts, int32_t* n_tokens);
 
     void set_instrument(bool on) { instrument_ = on; }
+    // decoding method of the batch entry points: 0 = greedy_search (the reference's only method), K >= 1 = modified beam
+    // search with beam K (BASELINE.json configs[2]); the single-stream path is always greedy
+    void set_beam(int k) { beam_ = k; }
+    int beam() const { return beam_; }
+    const std::vector<float>& last_scores() const { return last_scores_; }
     const k2hip_timing& timing() const { return timing_; }
 
     float debug_gemm(int M, int N, int K, int act, bool with_res, int iters);
@@ -93,6 +98,8 @@ class Engine {
     void greedy_device(const Ctx& c, const float* enc, int B, int Tp, bool single, long long* d_tok, int* d_ts, int* d_n,
                        int max_tokens, int* d_overflow);
     const float* pos_emb(int T);  // cached CompactRelPositionalEncoding table on device
+    void beam_device(const Ctx& c, const float* enc, int B, int Tp, long long* d_tok, int* d_ts, int* d_n, int max_tokens,
+                     int* d_overflow);
     // offline Conformer (conformer_engine.cpp)
     int conformer_out_frames(int T) const;
     const float* conformer_pos_emb(int T);
@@ -138,6 +145,9 @@ class Engine {
     std::mutex mu_;
     std::map<int, float*> pe_cache_;
     bool instrument_ = false;
+    int beam_ = 0;
+    float* d_scores_ = nullptr;
+    std::vector<float> last_scores_;
     GemmStats stats_;
     k2hip_timing timing_{};
     hipEvent_t ev_[8] = {nullptr};

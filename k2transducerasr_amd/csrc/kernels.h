@@ -167,6 +167,30 @@ struct GreedyArgs {
 };
 void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a);
 
+// ---- modified beam search (beam.hip) ------------------------------------------------------------
+constexpr int kMaxBeam = 8;
+struct BeamState {       // device arrays; hypotheses double-buffered by frame parity
+    int K, cap;
+    int* ys;             // [2][B][K][cap] tokens without the ctx-blank prefix
+    int* ts;             // [2][B][K][cap]
+    int* n;              // [2][B][K]
+    float *lp, *lp_next; // [B][K] hypothesis log-probs (-inf = empty slot)
+    long long *ctx, *ctx_next;  // [B][K][2] decoder inputs
+    int *nhyp, *nhyp_next;      // [B]
+};
+struct BeamArgs {
+    const float* enc;    // [B, Tp, J]
+    const float* out_w;  // joiner.output_linear.weight [V, J] (torch layout, for the GEMM)
+    int B, Tp, beam;
+    long long* tokens;   // [B, max_tokens] best hypothesis
+    int* timestamps;
+    int* n_tokens;
+    float* scores;       // [B] log_prob of the best hypothesis (may be null)
+    int max_tokens;
+    int* overflow;
+};
+void beam_search(const Ctx& ctx, const DecJoinW& w, const BeamArgs& a);
+
 // ---- streaming (online.hip): device-resident per-stream caches indexed by slot ------------------
 void convnext_cat(const Ctx& ctx, const float* a3, const float* pool, long long slot_stride, long long embed_off,
                   const int* slots, float* cat, int B, int T3, int F, int C);
