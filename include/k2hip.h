@@ -97,6 +97,9 @@ int32_t k2hip_model_get_info(const k2hip_model_t* model, k2hip_model_info* info)
 /* CustomMetadataMap[key] -> buf (NUL terminated); K2HIP_ERR_INVALID if absent */
 int32_t k2hip_model_meta(const k2hip_model_t* model, const char* key, char* buf, int32_t cap);
 int32_t k2hip_set_instrument(k2hip_model_t* model, int32_t on);
+/* per-launch table of the last instrumented call: rows of 8 floats (M, N, K, batch, act, has_residual, kind, microseconds);
+ * kind: 0 plain, 1 conv gather, 2 [K,N] operand, +16 = LDS-DMA kernel.  rows == NULL only queries n_rows. */
+int32_t k2hip_get_gemm_profile(k2hip_model_t* model, float* rows, int32_t cap_rows, int32_t* n_rows);
 int32_t k2hip_get_timing(const k2hip_model_t* model, k2hip_timing* timing);
 
 /* ---- F1: WavFrontend.GetFbank (WavFrontend.cs:32-36 -> SpeechFeatures.OnlineFbank)

@@ -287,6 +287,15 @@ class Model:
         """decodingMethod of the batch entry points (OfflineRecognizer.cs:54-68): greedy_search | modified_beam_search"""
         self._chk(self._L.k2hip_set_decoding_method(self._h, method.encode(), beam))
 
+    def gemm_profile(self) -> np.ndarray:
+        """[n, 8] rows (M, N, K, batch, act, has_residual, kind, us) of the last instrumented call"""
+        n = C.c_int32(0)
+        self._L.k2hip_get_gemm_profile.argtypes = [C.c_void_p, fp, C.c_int32, C.POINTER(C.c_int32)]
+        self._chk(self._L.k2hip_get_gemm_profile(self._h, None, 0, C.byref(n)))
+        rows = np.zeros((max(n.value, 1), 8), np.float32)
+        self._chk(self._L.k2hip_get_gemm_profile(self._h, _f(rows), n.value, C.byref(n)))
+        return rows[: n.value]
+
     def last_scores(self, B: int):
         sc = np.zeros(B, np.float32)
         self._chk(self._L.k2hip_last_scores(self._h, _f(sc), B))

@@ -114,6 +114,21 @@ int32_t k2hip_model_meta(const k2hip_model_t* model, const char* key, char* buf,
         memcpy(buf, it->second.c_str(), it->second.size() + 1);
     });
 }
+int32_t k2hip_get_gemm_profile(k2hip_model_t* model, float* rows, int32_t cap_rows, int32_t* n_rows) {
+    return guard([&] {
+        NEED(model); NEED(n_rows);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        const auto& lg = model->engine.gemm_log();
+        *n_rows = (int32_t)lg.size();
+        if (!rows) return;
+        for (int i = 0; i < std::min<int>(cap_rows, (int)lg.size()); i++) {
+            const GemmLaunchRec& r = lg[i];
+            float* o = rows + (size_t)i * 8;
+            o[0] = (float)r.M; o[1] = (float)r.N; o[2] = (float)r.K; o[3] = (float)r.batch;
+            o[4] = (float)r.act; o[5] = (float)r.res; o[6] = (float)r.kind; o[7] = r.us;
+        }
+    });
+}
 int32_t k2hip_set_instrument(k2hip_model_t* model, int32_t on) {
     return guard([&] {
         NEED(model);

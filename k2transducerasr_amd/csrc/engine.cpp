@@ -38,6 +38,7 @@ Engine::~Engine() {
     if (stream2_) (void)hipStreamDestroy(stream2_);
     for (auto& kv : pe_cache_) (void)hipFree(kv.second);
     if (online_pool_) (void)hipFree(online_pool_);
+    if (d_ptab_) (void)hipFree(d_ptab_);
     for (auto& e : ev_)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : evpool_) (void)hipEventDestroy(e);
@@ -66,6 +67,7 @@ Ctx Engine::make_ctx(bool dry) {
     c.stats = &stats_;
     c.evpool = &evpool_;
     c.evused = &evused_;
+    c.gemm_log = &gemm_log_;
     return c;
 }
 
@@ -104,7 +106,7 @@ const float* Engine::pos_emb(int T) {
     return d;
 }
 
-DecJoinW Engine::decjoin() const {
+DecJoinW Engine::decjoin() {
     const Config& c = model_->cfg();
     DecJoinW w;
     w.emb = model_->w("decoder.embedding.weight");
@@ -116,6 +118,18 @@ DecJoinW Engine::decjoin() const {
     w.out_kn = model_->w("joiner.output_linear.weight#kn");
     w.out_b = model_->w("joiner.output_linear.bias");
     w.V = c.V; w.Vp = c.Vp; w.DD = c.DD; w.J = c.J; w.ctx = c.ctx;
+    if (w.cpg > 4) {
+        if (!d_ptab_) {  // one-off: P[tap] = emb . conv_tap^T on the MFMA GEMM
+            K2_HIP(hipMalloc(&d_ptab_, sizeof(float) * 2 * (size_t)c.V * c.DD));
+            Ctx t;
+            t.stream = stream_;
+            for (int tap = 0; tap < 2; tap++)
+                linear(t, w.emb, c.DD, model_->w("decoder.conv.weight#tap" + std::to_string(tap)), nullptr,
+                       d_ptab_ + (size_t)tap * c.V * c.DD, c.DD, c.V, c.DD, c.DD);
+            K2_HIP(hipStreamSynchronize(stream_));
+        }
+        w.ptab = d_ptab_;
+    }
     return w;
 }
 
@@ -413,6 +427,7 @@ void Engine::finish_tokens(const long long* d_tok, const int* d_ts, const int* d
     K2_HIP(hipEventRecord(ev_[5], stream_));
     K2_HIP(hipStreamSynchronize(stream_));
     int ovf = *reinterpret_cast<int*>(pin + nb_tok + nb_ts + nb_n);
+    if (ovf == 2) failf(K2HIP_ERR_HIP, "greedy search: the vocabulary-parallel exchange timed out (a workgroup never arrived)");
     if (ovf) failf(K2HIP_ERR_CAPACITY, "a stream emitted more than max_tokens=%d symbols", max_tokens);
     memcpy(tokens, pin, nb_tok);
     memcpy(ts, pin + nb_tok, nb_ts);

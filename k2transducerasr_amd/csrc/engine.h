@@ -75,6 +75,7 @@ class Engine {
                      int64_t* tokens, int32_t* ts, int32_t* n_tokens);
 
     void set_instrument(bool on) { instrument_ = on; }
+    const std::vector<GemmLaunchRec>& gemm_log() const { return gemm_log_; }
     // decoding method of the batch entry points: 0 = greedy_search (the reference's only method), K >= 1 = modified beam
     // search with beam K (BASELINE.json configs[2]); the single-stream path is always greedy
     void set_beam(int k) { beam_ = k; }
@@ -112,7 +113,8 @@ class Engine {
     float* encoder_embed_stream(const Ctx& c, const float* x, const int* d_slots, int B, int T, int* Tc);
     void encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x, const float* pe, const int* d_slots,
                               const long long* d_plen, int B, int Tc, int L);
-    DecJoinW decjoin() const;
+    DecJoinW decjoin();
+    float* d_ptab_ = nullptr;  // [2][V][DD] per-token decoder-conv table (groups = 1 models), built on first use
 
     // run `body` once dry to size the arena, then for real
     template <typename F>
@@ -152,6 +154,7 @@ class Engine {
     k2hip_timing timing_{};
     hipEvent_t ev_[8] = {nullptr};
     std::vector<hipEvent_t> evpool_;
+    std::vector<GemmLaunchRec> gemm_log_;
     int evused_ = 0;
     // pinned staging for results
     void* pin_ = nullptr;
@@ -182,6 +185,7 @@ void Engine::run_sized(F&& body) {
     }
     Ctx c = make_ctx(false);
     evused_ = 0;
+    gemm_log_.clear();
     body(c);
     if (instrument_) {
         K2_HIP(hipStreamSynchronize(stream_));
@@ -189,6 +193,7 @@ void Engine::run_sized(F&& body) {
             float ms = 0;
             K2_HIP(hipEventElapsedTime(&ms, evpool_[i], evpool_[i + 1]));
             stats_.ms += ms;
+            if ((size_t)(i / 2) < gemm_log_.size()) gemm_log_[i / 2].us = ms * 1e3f;
         }
     }
     timing_.gemm_ms = stats_.ms;

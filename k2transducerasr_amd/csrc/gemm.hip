@@ -528,11 +528,14 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     int cfg = choose_cfg(a);
     GemmArgs b = a;
     b.ablate = g_ablate;
+    if (ctx.instrument && ctx.gemm_log)
+        ctx.gemm_log->push_back({a.M, a.N, a.K, a.nb0 * a.nb1, a.act, a.res != nullptr, a.cv_Fout > 0 ? 1 : (a.w_kn ? 2 : 0), 0.f});
     const bool dma_ok = a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.K % 32 == 0 && a.K >= 64 && a.lda % 4 == 0;
     if (dma_ok && g_use_dma && (cfg == 5 || cfg == 0)) {
         if (cfg == 5) launch_dma<128, 64, 32, 32>(ctx, b);
         else launch_dma<128, 128, 64, 32>(ctx, b);
         K2_HIP(hipGetLastError());
+        if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 16;
         if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
         return;
     }

@@ -44,6 +44,10 @@ __device__ void decoder_conv_narrow(const DecJoinW& w, long long y0, long long y
             }
             h[co] = fmaxf(s, 0.f);
         }
+    } else if (w.ptab) {
+        const float* p0 = w.ptab + y0 * w.DD;
+        const float* p1 = w.ptab + ((long long)w.V + y1) * w.DD;
+        for (int co = tid; co < w.DD; co += nt) h[co] = fmaxf((y0 >= 0 ? p0[co] : 0.f) + (y1 >= 0 ? p1[co] : 0.f), 0.f);
     } else {
         for (int c = tid; c < w.DD; c += nt) {
             xe[2 * c] = y0 >= 0 ? w.emb[y0 * w.DD + c] : 0.f;
@@ -198,6 +202,11 @@ __device__ void decoder_block_wide(const DecJoinW& w, long long y0, long long y1
             h[co] = fmaxf(s, 0.f);
         }
         __syncthreads();
+    } else if (w.ptab) {
+        const float* p0 = w.ptab + y0 * w.DD;
+        const float* p1 = w.ptab + ((long long)w.V + y1) * w.DD;
+        for (int co = tid; co < w.DD; co += GT) h[co] = fmaxf((y0 >= 0 ? p0[co] : 0.f) + (y1 >= 0 ? p1[co] : 0.f), 0.f);
+        __syncthreads();
     } else {
         float* xe = h + w.DD;
         for (int c = tid; c < w.DD; c += GT) {
@@ -208,6 +217,26 @@ __device__ void decoder_block_wide(const DecJoinW& w, long long y0, long long y1
         gemv_kn_wide(xe, 2 * w.DD, w.conv, nullptr, w.DD, scratch, h, true);
     }
     gemv_kn_wide(h, w.DD, w.dproj_kn, w.dproj_b, w.J, scratch, out, false);
+}
+
+// ---- vocabulary-parallel exchange ----------------------------------------------------------------
+// With a large vocabulary (V = 5537: an 11 MB joiner matrix) one workgroup per stream spends ~300 us per
+// sweep pulling the matrix through a single CU.  The sweep is therefore split over `parts` workgroups per
+// stream (column slabs); after each sweep every part publishes its per-frame (max, argmax) as two 8-byte
+// {epoch, value} granules -- relaxed agent-scope atomic stores (write-through), the tag IS the flag
+// (cdna_hip_programming.md Guideline 16, recipe R2) -- and wave 0 of every part polls the stream's
+// granules until all carry this round's epoch.  All parts then take the same decision and run the same
+// decoder update, so no further exchange is needed.  Granules are double-buffered by round parity: a part
+// can only be one round ahead of its slowest peer.  Spins are bounded; a timeout sets *overflow = 2.
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+constexpr int kMaxParts = 16;
+constexpr unsigned kSpinLimit = 1u << 22;
+
+__device__ __forceinline__ void store_granule(unsigned long long* g, unsigned epoch, unsigned value) {
+    __hip_atomic_store((gu64*)g, ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long load_granule(const unsigned long long* g) {
+    return __hip_atomic_load((gu64*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // LDS: actT[J][GF] | dec_a[J] | dec_b[J] | dec_own[J] | h[3*DD] (h | stacked embeddings) | redv[16][GF] | redi[16][GF] | fin[GF]
@@ -221,13 +250,22 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
     float* redv = h + 3 * w.DD;
     int* redi = reinterpret_cast<int*>(redv + 16 * GF);
     int* fin = redi + 16 * GF;
+    // exchange scratch lives in the dynamic region too (static LDS would shift its 16-byte alignment)
+    float* pv = reinterpret_cast<float*>(fin + GF + 8);
+    int* pi = reinterpret_cast<int*>(pv + kMaxParts * GF);
+    int* xf = pi + kMaxParts * GF;  // [0] = exchange timed out
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ks = lane >> 3, cgl = lane & 7;  // k slice (8 per wave), column group within the wave's 8
-    const int b = blockIdx.x;
+    const int G = a.parts, b = blockIdx.x / G, part = blockIdx.x - b * G;
+    unsigned epoch = 0;
+    if (tid == 0) xf[0] = 0;
     const float* enc = a.enc + (long long)b * a.Tp * w.J;
     const int t0 = a.t0 ? *a.t0 : INT_MAX;
     const int ncg = w.Vp >> 2, kper = w.J >> 3;
+    // this part's slab of column groups (whole 8-wide wave chunks)
+    const int cper = ((ncg + G - 1) / G + 7) & ~7;
+    const int cg0 = part * cper, cg1 = min(ncg, cg0 + cper);
 
     long long y0 = -1, y1 = K2HIP_BLANK_ID;
     int n_tok = 0, t = 0;
@@ -260,9 +298,9 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
         int besti[GF];
 #pragma unroll
         for (int f = 0; f < GF; f++) { bestv[f] = -INFINITY; besti[f] = -1; }
-        for (int cgb = 0; cgb < ncg; cgb += 128) {
+        for (int cgb = cg0; cgb < cg1; cgb += 128) {
             const int cg = cgb + wave * 8 + cgl;
-            const bool valid = cg < ncg;
+            const bool valid = cg < cg1;
             float acc[GF][4];
 #pragma unroll
             for (int f = 0; f < GF; f++)
@@ -328,6 +366,54 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
             int i = redi[tid];
             for (int wv = 1; wv < GT / 64; wv++) amax_merge(v, i, redv[wv * GF + tid], redi[wv * GF + tid]);
             fin[tid] = i;
+            if (G > 1) {  // publish this slab's candidate for frame `tid` (round parity buffer)
+                unsigned long long* gr = a.gran + ((((long long)b * 2 + (epoch & 1)) * G + part) * GF + tid) * 2;
+                store_granule(gr, epoch + 1, __float_as_uint(v));
+                store_granule(gr + 1, epoch + 1, (unsigned)i);
+            }
+        }
+        if (G > 1) {
+            epoch++;
+            if (wave == 0) {  // one wave polls the stream's G*GF*2 granules of this round
+                const unsigned long long* gr = a.gran + (((long long)b * 2 + ((epoch - 1) & 1)) * G) * GF * 2;
+                const int ng = G * GF * 2;
+                unsigned vals[(kMaxParts * GF * 2) / 64];
+                bool ok_all = false;
+                for (unsigned spins = 0; spins < kSpinLimit; spins++) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < (kMaxParts * GF * 2) / 64; k++) {
+                        const int q = lane + 64 * k;
+                        if (q < ng) {
+                            const unsigned long long x = load_granule(gr + q);
+                            vals[k] = (unsigned)x;
+                            ok &= (unsigned)(x >> 32) == epoch;
+                        }
+                    }
+                    if (__all(ok)) { ok_all = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (!ok_all && lane == 0) xf[0] = 1;
+#pragma unroll
+                for (int k = 0; k < (kMaxParts * GF * 2) / 64; k++) {
+                    const int q = lane + 64 * k;
+                    if (q < ng) {
+                        if (q & 1) pi[q >> 1] = (int)vals[k];
+                        else pv[q >> 1] = __uint_as_float(vals[k]);
+                    }
+                }
+            }
+            __syncthreads();
+            if (xf[0]) {  // a peer never arrived: give up (every part of the stream times out the same way)
+                if (tid == 0) *a.overflow = 2;
+                return;
+            }
+            if (tid < GF) {
+                float v = pv[tid];
+                int i = pi[tid];
+                for (int p = 1; p < G; p++) amax_merge(v, i, pv[p * GF + tid], pi[p * GF + tid]);
+                fin[tid] = i;
+            }
         }
         __syncthreads();
         // accept frames in order up to and including the first emission
@@ -337,7 +423,7 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
             const int y = fin[f];
             if (y != K2HIP_BLANK_ID && y != K2HIP_UNK_ID && !(a.skip1 && y == 1)) {
                 if (n_tok < a.max_tokens) {
-                    if (tid == 0) {
+                    if (tid == 0 && part == 0) {
                         a.tokens[(long long)b * a.max_tokens + n_tok] = y;
                         a.timestamps[(long long)b * a.max_tokens + n_tok] = t + f;
                     }
@@ -357,7 +443,7 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
         if (emitted) decoder_block_wide(w, y0, y1, h, actT, dec_own);
         else __syncthreads();  // actT / fin are rewritten by the next round
     }
-    if (tid == 0) a.n_tokens[b] = n_tok < a.max_tokens ? n_tok : a.max_tokens;
+    if (tid == 0 && part == 0) a.n_tokens[b] = n_tok < a.max_tokens ? n_tok : a.max_tokens;
 }
 
 }  // namespace
@@ -383,18 +469,30 @@ void first_emit_frame(const Ctx& ctx, const int* tok, int B, int Tp, int skip1, 
     hipLaunchKernelGGL(k_first_emit, dim3(1), dim3(1024), 0, ctx.stream, tok, B, Tp, skip1, t0);
     K2_HIP(hipGetLastError());
 }
-void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a) {
-    if (ctx.dry || a.B <= 0) return;
+void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
+    if (a0.B <= 0) return;
+    GreedyArgs a = a0;
+    // parts per stream: enough that a part's slab is about one 128-column-group pass; all B*parts workgroups must be
+    // co-resident (they wait for each other), so stay within half the chip
+    const int ncg = w.Vp >> 2;
+    int parts = std::min({(ncg + 127) / 128, kMaxParts, 128 / std::max(a.B, 1)});
+    if (parts < 2 || getenv("K2HIP_GREEDY_ONE_PART")) parts = 1;
+    a.parts = parts;
+    const size_t gran_words = (size_t)a.B * 2 * parts * GF * 2;
+    a.gran = parts > 1 ? ctx.arena->take<unsigned long long>((int64_t)gran_words) : nullptr;
+    if (ctx.dry) return;
     K2_REQUIRE(w.J % 8 == 0, "greedy: joiner_dim %d must be a multiple of 8", w.J);
     K2_REQUIRE(w.DD % 4 == 0 && 8 * w.DD <= w.J * GF, "greedy: decoder_dim %d too wide for the LDS scratch", w.DD);
-    size_t lds = sizeof(float) * ((size_t)w.J * GF + 8 * APAD + 3 * (size_t)w.J + 3 * (size_t)w.DD + 32 * GF + GF + 8);
-    K2_REQUIRE(lds <= 160 * 1024, "greedy: vocab %d / joiner %d need %zu B of LDS", w.V, w.J, lds);
+    size_t lds = sizeof(float) * ((size_t)w.J * GF + 8 * APAD + 3 * (size_t)w.J + 3 * (size_t)w.DD + 32 * GF + GF + 8 +
+                                 2 * kMaxParts * GF + 4);
+    K2_REQUIRE(lds <= 150 * 1024, "greedy: vocab %d / joiner %d need %zu B of LDS", w.V, w.J, lds);
     static bool attr_set = false;
     if (!attr_set) {
-        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_greedy, dim3(a.B), dim3(GT), lds, ctx.stream, w, a);
+    if (parts > 1) K2_HIP(hipMemsetAsync(a.gran, 0, sizeof(unsigned long long) * gran_words, ctx.stream));
+    hipLaunchKernelGGL(k_greedy, dim3(a.B * parts), dim3(GT), lds, ctx.stream, w, a);
     K2_HIP(hipGetLastError());
 }
 

@@ -13,7 +13,13 @@ struct GemmStats {
     float ms = 0;           // summed event time (instrumented runs only)
 };
 
+struct GemmLaunchRec {  // one row per GEMM launch of an instrumented call
+    int M, N, K, batch, act, res, kind;  // kind: 0 plain, 1 conv gather, 2 [K,N] operand; +16 = LDS-DMA kernel
+    float us;
+};
+
 struct Ctx {
+    std::vector<GemmLaunchRec>* gemm_log = nullptr;  // instrumented runs only
     hipStream_t stream = nullptr;
     Arena* arena = nullptr;
     bool dry = false;
@@ -139,6 +145,9 @@ struct DecJoinW {
     const float* emb;      // [V, DD]
     const float* conv;     // [DD, cpg, ctx] (cpg <= 4) or k-major [cpg*ctx][DD] (cpg > 4)
     int cpg;               // decoder conv input channels per group
+    // groups = 1 only: per-token conv contributions P[tap][v][co] = sum_ci conv[co][ci][tap] * emb[v][ci]  ([2][V][DD]);
+    // the conv of a context is then relu(P[0][y0] + P[1][y1]) -- no GEMV inside the search loops
+    const float* ptab = nullptr;
     const float* dproj_kn; // [DD, J]
     const float* dproj_b;  // [J]
     const float* out_kn;   // [J, Vp]
@@ -164,6 +173,10 @@ struct GreedyArgs {
     int* overflow;      // device flag
     // online loop: per-stream starting context (stream.Hyp, OnlineRecognizer.cs:109,122-126); null = offline
     const long long* init_ctx = nullptr;  // [B][2]
+    // vocabulary-parallel form (set by greedy_loop): `parts` workgroups per stream, each sweeping a slab of the joiner
+    // matrix; per round they exchange their per-frame (max, argmax) through tagged 8-byte granules
+    int parts = 1;
+    unsigned long long* gran = nullptr;  // [B][2 (round parity)][parts][GF][2], zeroed per call
 };
 void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a);
 

@@ -261,6 +261,13 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
             for (int co = 0; co < c.DD; co++)
                 for (int k = 0; k < KK; k++) v[(size_t)k * c.DD + co] = t.host[(size_t)co * KK + k];
             push("decoder.conv.weight#kn", std::move(v), {KK, c.DD});
+            // per-tap matrices [co][ci] for the per-token table build (Engine::decjoin)
+            for (int tap = 0; tap < c.ctx; tap++) {
+                std::vector<float> u((size_t)c.DD * cpg);
+                for (int co = 0; co < c.DD; co++)
+                    for (int ci = 0; ci < cpg; ci++) u[(size_t)co * cpg + ci] = t.host[((size_t)co * cpg + ci) * c.ctx + tap];
+                push("decoder.conv.weight#tap" + std::to_string(tap), std::move(u), {c.DD, cpg});
+            }
         }
     }
     if (c.conformer && has("encoder.encoder_embed.conv.0.weight")) {
