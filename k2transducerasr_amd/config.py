@@ -60,6 +60,7 @@ def make_zipformer2_meta(
     streaming=False,
     chunk_size=16,
     left_context_frames=128,
+    ctc=False,
 ):
     n = len(encoder_dims)
     assert all(
@@ -89,6 +90,10 @@ def make_zipformer2_meta(
             "context_size": str(context_size),
         }
     )
+    if ctc:
+        # Zipformer2 encoder + CTC head, no decoder / joiner: Model_type "zipformer2ctc" -> OfflineProjOfZipformer2ctc /
+        # OnlineProjOfZipformer2ctc and decodingMethod "greedy_search_ctc" (OfflineRecognizer.cs:44-47, OnlineRecognizer.cs:33-36)
+        meta["model_type"] = "zipformer2ctc"
     if streaming:
         # keys of a streaming export, as OnlineModel.cs:38-110 reads them: T = ChunkLength,
         # decode_chunk_len = ShiftLength (OnlineModel.cs:48-49); left_context_len is already divided
@@ -202,6 +207,29 @@ PRESETS = {
         vocab_size=37,
         joiner_dim=512,
         decoder_dim=64,
+        streaming=True,
+        chunk_size=16,
+        left_context_frames=32,
+    ),
+    "zipformer2-ctc-tiny-test": dict(
+        encoder_dims=[64, 96, 128, 64],
+        num_encoder_layers=[1, 2, 1, 1],
+        feedforward_dims=[128, 192, 256, 128],
+        num_heads=[2, 2, 4, 2],
+        cnn_module_kernels=[15, 7, 7, 15],
+        downsampling_factors=[1, 2, 4, 2],
+        vocab_size=37,
+        ctc=True,
+    ),
+    "zipformer2-ctc-streaming-tiny-test": dict(
+        encoder_dims=[64, 96, 128, 64],
+        num_encoder_layers=[1, 2, 1, 1],
+        feedforward_dims=[128, 192, 256, 128],
+        num_heads=[2, 2, 4, 2],
+        cnn_module_kernels=[15, 7, 7, 15],
+        downsampling_factors=[1, 2, 4, 2],
+        vocab_size=37,
+        ctc=True,
         streaming=True,
         chunk_size=16,
         left_context_frames=32,

@@ -26,6 +26,8 @@ BLANK_BIAS = {
     "zipformer2-streaming-zh": 3.0,
     "zipformer2-streaming-tiny-test": 1.0,
     "conformer-zh": 2.615,
+    "zipformer2-ctc-tiny-test": 1.5,
+    "zipformer2-ctc-streaming-tiny-test": 1.5,
     "conformer-tiny-test": 2.179,
 }
 
@@ -120,6 +122,9 @@ def zipformer2_tensor_specs(meta: Dict[str, str]) -> List[Tuple[str, tuple, str]
             s.append((p + "bypass.bypass_scale", (D,), "bypass"))
             s.append((p + "bypass_mid.bypass_scale", (D,), "bypass"))
     s.append(("encoder.downsample_output.bias", (2,), "dsbias"))
+    if meta["model_type"] == "zipformer2ctc":
+        lin("ctc_output.1", V, max(dims))  # icefall: ctc_output = Sequential(Dropout, Linear, LogSoftmax)
+        return s
     lin("joiner.encoder_proj", J, max(dims))
     lin("joiner.decoder_proj", J, DD)
     lin("joiner.output_linear", V, J)
@@ -233,8 +238,10 @@ def write_synthetic_model(path: str, preset_name: str, seed: int = 20231212, bla
     def gen():
         for name, shape, kind in tensor_specs(meta):
             a = _init(name, shape, kind, seed)
-            if name == "joiner.output_linear.bias":
+            if name in ("joiner.output_linear.bias", "ctc_output.1.bias"):
                 a[0] += np.float32(blank_bias)
+            if name == "ctc_output.1.weight":
+                a *= np.float32(4.0)
             if name == "joiner.encoder_proj.weight":
                 a *= np.float32(4.0)  # let the (small) temporal variation reach the logits
             if conformer and (name.endswith(".4.weight") or name.endswith("out_proj.weight") or name.endswith("pointwise_conv2.weight")):

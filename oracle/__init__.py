@@ -68,6 +68,8 @@ def lib():
         L.k2o_greedy_batch.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, lp, ip, ip, C.c_int, fp]
         L.k2o_greedy_single.argtypes = [C.c_void_p, fp, C.c_int, lp, ip, ip, C.c_int, fp]
         L.k2o_offline_recognize_batch.argtypes = [C.c_void_p, C.POINTER(fp), lp, C.c_int, lp, ip, ip, C.c_int]
+        L.k2o_encoder_out_dim.argtypes = [C.c_void_p]
+        L.k2o_ctc_greedy.argtypes = [fp, C.c_int, C.c_int, C.c_int, ip, lp, ip, ip, C.c_int, ip]
         L.k2o_modified_beam_search.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, C.c_int, lp, ip, ip, C.c_int, fp, fp]
         _lib = L
     return _lib
@@ -99,6 +101,7 @@ class Oracle:
             raise OracleError(self._L.k2o_last_error().decode())
         self.vocab_size = self._L.k2o_vocab_size(self._m)
         self.joiner_dim = self._L.k2o_joiner_dim(self._m)
+        self.encoder_out_dim = self._L.k2o_encoder_out_dim(self._m)  # vocab_size for a zipformer2ctc model
         self.context_size = self._L.k2o_context_size(self._m)
         self.feature_dim = self._L.k2o_feature_dim(self._m)
 
@@ -149,7 +152,7 @@ class Oracle:
         x = np.ascontiguousarray(x, dtype=np.float32)
         B, T, _ = x.shape
         Tp = self.encoder_out_frames(T)
-        out = np.empty((B, Tp, self.joiner_dim), np.float32)
+        out = np.empty((B, Tp, self.encoder_out_dim), np.float32)
         self._chk(self._L.k2o_offline_encoder(self._m, _fp(x), B, T, _fp(out)))
         return out
 
@@ -205,6 +208,18 @@ class Oracle:
                                             _fp(mg) if want_margins else None))
         res = (tok[: n[0]].tolist(), ts[: n[0]].tolist())
         return (res, mg) if want_margins else res
+
+    def ctc_greedy(self, log_probs: np.ndarray, frame_offsets=None, num_trailing_blank=None):
+        """ForwardBatchGreedySearchCTC over log_probs [B,T',V]; returns [(tokens, timestamps)] and trailing-blank counts"""
+        lp_ = np.ascontiguousarray(log_probs, dtype=np.float32)
+        B, Tp, V = lp_.shape
+        tok = np.zeros((B, Tp + 1), np.int64)
+        ts = np.zeros((B, Tp + 1), np.int32)
+        n = np.zeros(B, np.int32)
+        fo = np.zeros(B, np.int32) if frame_offsets is None else np.ascontiguousarray(frame_offsets, dtype=np.int32)
+        tb = np.zeros(B, np.int32) if num_trailing_blank is None else np.ascontiguousarray(num_trailing_blank, dtype=np.int32).copy()
+        self._chk(self._L.k2o_ctc_greedy(_fp(lp_), B, Tp, V, _ip(fo), _lp(tok), _ip(ts), _ip(n), Tp + 1, _ip(tb)))
+        return [(tok[b, : n[b]].tolist(), ts[b, : n[b]].tolist()) for b in range(B)], tb
 
     def modified_beam_search(self, enc_out: np.ndarray, beam: int = 4, want_margins=False, want_scores=False):
         """icefall modified_beam_search per stream (k2_oracle_beam.c); returns [(tokens, timestamps)] (+ margins [B,T'+1])."""

@@ -61,6 +61,7 @@ struct k2o_model {
     int pos_dim, J, DD, V, ctx, feat;
     int dmax;
     int conformer; /* model_type "conformer": see k2_oracle_conformer.c */
+    int ctc;       /* model_type "zipformer2ctc": Zipformer2 encoder + CTC head, no decoder / joiner */
     int conv_cpg;  /* decoder conv input channels per group (4: Zipformer recipes; DD: stateless2, groups = 1) */
     /* fbank */
     int sample_rate, frame_len, frame_shift, padded;
@@ -78,6 +79,7 @@ const char* k2o_meta(const k2o_model* m, const char* key) {
 }
 int k2o_vocab_size(const k2o_model* m) { return m->V; }
 int k2o_joiner_dim(const k2o_model* m) { return m->J; }
+int k2o_encoder_out_dim(const k2o_model* m) { return m->ctc ? m->V : m->J; }
 int k2o_context_size(const k2o_model* m) { return m->ctx; }
 int k2o_feature_dim(const k2o_model* m) { return m->feat; }
 
@@ -221,7 +223,8 @@ k2o_model* k2o_model_load(const char* path) {
     }
     const char* mt = k2o_meta(m, "model_type");
     m->conformer = mt && !strcmp(mt, "conformer");
-    if (!mt || (strcmp(mt, "zipformer2") && !m->conformer)) {
+    m->ctc = mt && !strcmp(mt, "zipformer2ctc");
+    if (!mt || (strcmp(mt, "zipformer2") && !m->conformer && !m->ctc)) {
         fail("model_type %s not supported by the oracle", mt ? mt : "(none)");
         k2o_model_free(m);
         return NULL;
@@ -852,6 +855,24 @@ int k2o_encoder_out_frames(const k2o_model* m, int T) {
     return (T50 + 1) / 2;
 }
 
+/* CTC head of a zipformer2ctc export (icefall: ctc_output = Dropout, Linear(max(encoder_dims), vocab), LogSoftmax) on the
+ * 25 Hz encoder output; this is what OfflineProjOfZipformer2ctc.EncoderProj returns as "log_probs" [B,T',V]
+ * (OfflineProjOfZipformer2ctc.cs:48-92, consumed at OfflineRecognizer.cs:323-326). */
+static void ctc_head(const k2o_model* m, const float* x, int rows, float* out) {
+    const int V = m->V, D = m->dmax;
+    linear(out, V, x, D, WT(m, V, D, "ctc_output.1.weight"), W(m, "ctc_output.1.bias"), rows, D, V);
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < rows; r++) {
+        float* l = out + (size_t)r * V;
+        float mx = l[0];
+        for (int v = 1; v < V; v++) mx = l[v] > mx ? l[v] : mx;
+        float s = 0.f;
+        for (int v = 0; v < V; v++) s += expf(l[v] - mx);
+        float lse = logf(s);
+        for (int v = 0; v < V; v++) l[v] = l[v] - mx - lse;
+    }
+}
+
 /* Zipformer2.forward + encoder_proj.  taps: see header. */
 static int encoder_forward(const k2o_model* m, const float* xin, int B, int T, float* enc_out, int tap, float* tap_out,
                            int64_t tap_cap, int64_t* tap_n) {
@@ -941,7 +962,8 @@ static int encoder_forward(const k2o_model* m, const float* xin, int B, int T, f
     int Tp;
     float* dsd = simple_downsample(full, W(m, "encoder.downsample_output.bias"), 2, B, T50, Dmax, &Tp);
     free(full);
-    linear(enc_out, m->J, dsd, Dmax, WT(m, m->J, Dmax, "joiner.encoder_proj.weight"), W(m, "joiner.encoder_proj.bias"), B * Tp, Dmax, m->J);
+    if (m->ctc) ctc_head(m, dsd, B * Tp, enc_out);
+    else linear(enc_out, m->J, dsd, Dmax, WT(m, m->J, Dmax, "joiner.encoder_proj.weight"), W(m, "joiner.encoder_proj.bias"), B * Tp, Dmax, m->J);
     free(dsd);
     return 0;
 }
@@ -1118,6 +1140,37 @@ int k2o_greedy_single(const k2o_model* m, const float* enc_out, int Tp, int64_t*
     return rc;
 }
 
+/* ForwardBatchGreedySearchCTC (OfflineRecognizer.cs:366-424) / ForwardGreedySearchCTC (:305-364) over log_probs
+ * [B,T',V]:  y = Array.IndexOf(frame, frame.Max())  -- the FIRST index of the maximum (unlike the transducer loops);
+ * emit when y != blank && y != prev_id (prev_id = -1 at the start of every call); timestamp = t + frame_offset[b];
+ * num_trailing_blank[b] counts blanks since the last non-blank frame (accumulates onto its input value). */
+int k2o_ctc_greedy(const float* log_probs, int B, int Tp, int V, const int32_t* frame_offsets, int64_t* tokens,
+                   int32_t* timestamps, int32_t* n_tokens, int max_tokens, int32_t* num_trailing_blank) {
+    const int blank = 0;
+    for (int b = 0; b < B; b++) {
+        int64_t prev = -1;
+        int n = 0;
+        for (int t = 0; t < Tp; t++) {
+            const float* l = log_probs + ((size_t)b * Tp + t) * V;
+            float mx = l[0];
+            for (int v = 1; v < V; v++) mx = l[v] > mx ? l[v] : mx;   /* Enumerable.Max */
+            int y = 0;
+            while (y < V && !(l[y] == mx)) y++;                       /* Array.IndexOf: first match */
+            if (y == V) y = 0;
+            if (num_trailing_blank) num_trailing_blank[b] = (y == blank) ? num_trailing_blank[b] + 1 : 0;
+            if (y != blank && y != prev) {
+                if (n >= max_tokens) return fail("ctc greedy: stream %d exceeds max_tokens %d", b, max_tokens);
+                tokens[(size_t)b * max_tokens + n] = y;
+                timestamps[(size_t)b * max_tokens + n] = t + (frame_offsets ? frame_offsets[b] : 0);
+                n++;
+            }
+            prev = y;
+        }
+        n_tokens[b] = n;
+    }
+    return 0;
+}
+
 /* GetResults (OfflineRecognizer.cs:85-91): EncoderProj (pad -> encoder) + batch greedy */
 int k2o_offline_recognize_batch(const k2o_model* m, const float* const* feats, const int64_t* n_floats, int B,
                                 int64_t* tokens, int32_t* timestamps, int32_t* n_tokens, int max_tokens) {
@@ -1128,6 +1181,7 @@ int k2o_offline_recognize_batch(const k2o_model* m, const float* const* feats, c
     int T = (int)(L / m->feat);
     int Tp = k2o_encoder_out_frames(m, T);
     if (Tp <= 0) { free(x); return fail("utterances too short: T=%d", T); }
+    if (m->ctc) return fail("recognize_batch: CTC models decode through k2o_ctc_greedy");
     float* enc = falloc((size_t)B * Tp * m->J);
     int rc = k2o_offline_encoder(m, x, B, T, enc);
     free(x);

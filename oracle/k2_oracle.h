@@ -37,6 +37,8 @@ const char* k2o_last_error(void);
 const char* k2o_meta(const k2o_model* m, const char* key);
 int k2o_vocab_size(const k2o_model* m);
 int k2o_joiner_dim(const k2o_model* m);
+/* width of the offline / online encoder output: joiner_dim, or vocab_size for a zipformer2ctc model (log_probs) */
+int k2o_encoder_out_dim(const k2o_model* m);
 int k2o_context_size(const k2o_model* m);
 int k2o_feature_dim(const k2o_model* m);
 
@@ -89,6 +91,11 @@ int k2o_greedy_single(const k2o_model* m, const float* enc_out, int Tp,
  * margins [B,T'+1] (optional): per-frame beam-boundary score gap, final best-vs-second gap. */
 int k2o_modified_beam_search(const k2o_model* m, const float* enc_out, int B, int Tp, int beam, int64_t* tokens,
                              int32_t* timestamps, int32_t* n_tokens, int max_tokens, float* scores, float* margins);
+
+/* CTC greedy search (OfflineRecognizer.cs:305-424, OnlineRecognizer.cs:220-313) over log_probs [B,T',V]:
+ * first-index argmax, drop blanks and repeats; frame_offsets / num_trailing_blank may be NULL */
+int k2o_ctc_greedy(const float* log_probs, int B, int Tp, int V, const int32_t* frame_offsets, int64_t* tokens,
+                   int32_t* timestamps, int32_t* n_tokens, int max_tokens, int32_t* num_trailing_blank);
 
 /* End to end: features -> pad -> encoder -> batch greedy (GetResults). */
 int k2o_offline_recognize_batch(const k2o_model* m, const float* const* feats, const int64_t* n_floats, int B,

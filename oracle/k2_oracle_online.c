@@ -453,7 +453,8 @@ int k2o_online_encoder_chunk(const k2o_model* m, k2o_online_stream* s, const flo
     int Tp;
     float* dsd = simple_downsample(full, W(m, "encoder.downsample_output.bias"), 2, 1, Tc, Dmax, &Tp);
     free(full);
-    linear(enc_out, m->J, dsd, Dmax, WT(m, m->J, Dmax, "joiner.encoder_proj.weight"), W(m, "joiner.encoder_proj.bias"), Tp, Dmax, m->J);
+    if (m->ctc) ctc_head(m, dsd, Tp, enc_out);
+    else linear(enc_out, m->J, dsd, Dmax, WT(m, m->J, Dmax, "joiner.encoder_proj.weight"), W(m, "joiner.encoder_proj.bias"), Tp, Dmax, m->J);
     free(dsd);
     s->processed_len += Tc; /* new_processed_lens = processed_lens + x_lens, x_lens = (T-7)//2 - 3 */
     return Tp;
@@ -468,7 +469,32 @@ static void stream_push_token(k2o_online_stream* s, int64_t y, int32_t t) {
 
 /* OnlineRecognizer.ForwardBatchGreedySearch (:85-219) for B streams that each have one full chunk
  * (chunks[b]: [T*80] raw features; the online PadSequence maps 0.0 to the log floor, PadHelper.cs:9-13,58). */
+/* OnlineRecognizer.ForwardBatchGreedySearchCTC (:220-313): per chunk, CTC greedy over the chunk's log_probs with
+ * prev_id reset to -1 (a symbol repeated across the chunk boundary is emitted again) and timestamp = t +
+ * stream.FrameOffset -- which the reference never writes back (:298-301 update a local list only), so it stays 0
+ * and timestamps restart at every chunk.  NumTrailingBlank is not written back either. */
+static int online_step_ctc(const k2o_model* m, k2o_online_stream** streams, const float* const* chunks, int B, int32_t* n_new) {
+    int T = k2o_online_chunk_length(m), V = m->V;
+    int Tp = k2o_online_frames_per_chunk(m);
+    float* lp = falloc((size_t)Tp * V);
+    float* xf = falloc((size_t)T * m->feat);
+    int rc = 0;
+    for (int b = 0; b < B && !rc; b++) {
+        for (int i = 0; i < T * m->feat; i++) xf[i] = chunks[b][i] == 0.0f ? -23.025850929940457F : chunks[b][i];
+        int tp = k2o_online_encoder_chunk(m, streams[b], xf, lp);
+        if (tp != Tp) { rc = tp < 0 ? tp : fail("chunk gave %d frames, expected %d", tp, Tp); break; }
+        int64_t tok[64];
+        int32_t ts[64], n = 0;
+        rc = k2o_ctc_greedy(lp, 1, Tp, V, NULL, tok, ts, &n, 64, NULL);
+        for (int i = 0; i < n && !rc; i++) stream_push_token(streams[b], tok[i], ts[i]);
+        n_new[b] = n;
+    }
+    free(lp); free(xf);
+    return rc;
+}
+
 int k2o_online_step(const k2o_model* m, k2o_online_stream** streams, const float* const* chunks, int B, int32_t* n_new) {
+    if (m->ctc) return online_step_ctc(m, streams, chunks, B, n_new);
     int T = k2o_online_chunk_length(m), J = m->J, V = m->V, ctx = m->ctx;
     const int blank = 0, unk = 2;
     int Tp = k2o_online_frames_per_chunk(m);

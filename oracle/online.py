@@ -98,7 +98,7 @@ class OnlineOracle(Oracle):
 
     def encoder_chunk(self, stream: OnlineOracleStream, x: np.ndarray) -> np.ndarray:
         x = np.ascontiguousarray(x, np.float32).reshape(self.chunk_length, self.feature_dim)
-        out = np.empty((self.frames_per_chunk, self.joiner_dim), np.float32)
+        out = np.empty((self.frames_per_chunk, self.encoder_out_dim), np.float32)
         rc = self._L.k2o_online_encoder_chunk(self._m, stream._s, _fp(x), _fp(out))
         if rc < 0:
             raise OracleError(self._L.k2o_last_error().decode())
