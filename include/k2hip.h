@@ -56,7 +56,7 @@ typedef struct k2hip_model_info {
     int32_t sample_rate;
     int32_t num_stacks;
     int32_t device;
-    int32_t reserved;
+    int32_t reserved; /* encoder output width: joiner_dim, or vocab_size for a zipformer2ctc model (log_probs) */
 } k2hip_model_info;
 
 /* Per-call stage timings of the last fused call, measured with HIP events on the
@@ -200,6 +200,17 @@ int32_t k2hip_offline_stream_accept_samples(k2hip_offline_stream_t* s, const flo
 int64_t k2hip_offline_stream_speech_length(const k2hip_offline_stream_t* s);
 /* copies Speech to out (cap floats) */
 int32_t k2hip_offline_stream_get_speech(const k2hip_offline_stream_t* s, float* out, int64_t cap);
+/* ---- CTC models (Model_type "zipformer2ctc": OfflineProjOfZipformer2ctc / OnlineProjOfZipformer2ctc) -------------------
+ * The encoder entry points (k2hip_offline_encoder, the online step) return log_probs [B,T',V] for such a model.
+ * k2hip_ctc_greedy replaces the loop of ForwardBatchGreedySearchCTC (OfflineRecognizer.cs:383-408): y = first index of the
+ * frame maximum (Array.IndexOf), emitted when y != blank and y != previous frame's y (prev_id = -1 at the start of every
+ * call); timestamps get frame_offsets[b] added; num_trailing_blank[b] (in/out) follows :392-397.  The fused batch entries
+ * (k2hip_offline_greedy*, get_results, k2hip_online_step) run this search automatically for a CTC model. */
+int32_t k2hip_ctc_greedy(k2hip_model_t* model, const float* log_probs, int32_t B, int32_t Tprime, const int32_t* frame_offsets,
+                         int64_t* tokens, int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens, int32_t* num_trailing_blank);
+/* OfflineStream.FrameOffset / NumTrailingBlank (OfflineStream.cs:39-40) */
+int32_t k2hip_offline_stream_get_ctc_state(const k2hip_offline_stream_t* s, int32_t* frame_offset, int32_t* num_trailing_blank);
+
 /* ---- decoding method --------------------------------------------------------------------------
  * The reference picks the search by the recognizer's `decodingMethod` string (OfflineRecognizer.cs:54-68) and only
  * knows "greedy_search".  BASELINE.json configs[2] adds "modified_beam_search" (icefall semantics, restated in

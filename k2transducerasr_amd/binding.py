@@ -156,6 +156,7 @@ class Model:
         self.vocab_size = info.vocab_size
         self.context_size = info.context_size
         self.joiner_dim = info.joiner_dim
+        self.encoder_out_dim = info.reserved  # vocab_size for a zipformer2ctc model (log_probs)
         self.feature_dim = info.feature_dim
         self.sample_rate = info.sample_rate
         self.device = info.device
@@ -226,7 +227,7 @@ class Model:
         x = _f32(x)
         B, T, _ = x.shape
         tp = max(self.encoder_out_frames(T), 0)
-        out = np.empty((B, tp, self.joiner_dim), np.float32)
+        out = np.empty((B, tp, self.encoder_out_dim), np.float32)
         lens = np.zeros(B, np.int64)
         xl = np.full(B, T, np.int64)
         got = C.c_int32()
@@ -270,6 +271,19 @@ class Model:
         n = np.zeros(B, np.int32)
         self._chk(self._L.k2hip_greedy_batch(self._h, _f(e), B, Tp, _l(tok), _i(ts), _i(n), Tp))
         return self._unpack(tok, ts, n)
+
+    def ctc_greedy(self, log_probs, frame_offsets=None, num_trailing_blank=None):
+        """ForwardBatchGreedySearchCTC over host log_probs [B,T',V] (k2hip_ctc_greedy)"""
+        e = _f32(log_probs)
+        B, Tp, _ = e.shape
+        tok = np.zeros((B, Tp), np.int64)
+        ts = np.zeros((B, Tp), np.int32)
+        n = np.zeros(B, np.int32)
+        fo = np.zeros(B, np.int32) if frame_offsets is None else np.ascontiguousarray(frame_offsets, dtype=np.int32)
+        tb = np.zeros(B, np.int32) if num_trailing_blank is None else np.ascontiguousarray(num_trailing_blank, dtype=np.int32).copy()
+        self._L.k2hip_ctc_greedy.argtypes = [C.c_void_p, fp, C.c_int32, C.c_int32, ip, lp, ip, ip, C.c_int32, ip]
+        self._chk(self._L.k2hip_ctc_greedy(self._h, _f(e), B, Tp, _i(fo), _l(tok), _i(ts), _i(n), Tp, _i(tb)))
+        return self._unpack(tok, ts, n), tb
 
     def beam_search(self, enc_out, beam: int = 4, want_scores: bool = False):
         """modified beam search over a host encoder_out [B,T',J] (k2hip_beam_search)"""

@@ -20,6 +20,8 @@ struct k2hip_offline_stream {
     std::vector<float> remainder;  // samples not yet covered by a full frame shift (streaming fbank state)
     std::vector<int64_t> tokens;   // Tokens, initialised to [blank, blank] (:34)
     std::vector<int32_t> timestamps;
+    int32_t frame_offset = 0;        // FrameOffset (:39), read by the CTC search (OfflineRecognizer.cs:376,402)
+    int32_t num_trailing_blank = 0;  // NumTrailingBlank (:40)
 };
 
 // OnlineStream.cs:7-199
@@ -95,11 +97,11 @@ int32_t k2hip_model_get_info(const k2hip_model_t* model, k2hip_model_info* info)
         info->vocab_size = c.V;
         info->context_size = c.ctx;
         info->joiner_dim = c.J;
+        info->reserved = c.enc_dim();  // width of the encoder entry points' output (vocab_size for zipformer2ctc)
         info->feature_dim = c.feat;
         info->sample_rate = c.fbank.sample_rate;
         info->num_stacks = c.ns;
         info->device = model->engine.model().device();
-        info->reserved = 0;
     });
 }
 int32_t k2hip_model_meta(const k2hip_model_t* model, const char* key, char* buf, int32_t cap) {
@@ -234,6 +236,28 @@ int32_t k2hip_greedy_single(k2hip_model_t* model, const float* enc_out, int32_t 
         NEED(model); NEED(enc_out); NEED(tokens); NEED(timestamps); NEED(n_tokens);
         std::lock_guard<std::mutex> lk(model->engine.mutex());
         model->engine.greedy_host(enc_out, 1, Tprime, true, tokens, timestamps, n_tokens, max_tokens);
+    });
+}
+int32_t k2hip_ctc_greedy(k2hip_model_t* model, const float* log_probs, int32_t B, int32_t Tprime, const int32_t* frame_offsets,
+                         int64_t* tokens, int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens, int32_t* num_trailing_blank) {
+    return guard([&] {
+        NEED(model); NEED(log_probs); NEED(tokens); NEED(timestamps); NEED(n_tokens);
+        Engine& e = model->engine;
+        K2_REQUIRE(e.model().cfg().ctc, "ctc_greedy: model_type '%s' has no CTC head", e.model().cfg().model_type.c_str());
+        std::lock_guard<std::mutex> lk(e.mutex());
+        e.greedy_host(log_probs, B, Tprime, false, tokens, timestamps, n_tokens, max_tokens);
+        for (int b = 0; b < B; b++) {
+            if (frame_offsets)
+                for (int k = 0; k < n_tokens[b]; k++) timestamps[(size_t)b * max_tokens + k] += frame_offsets[b];
+            if (num_trailing_blank) num_trailing_blank[b] = e.last_any()[b] ? e.last_trail()[b] : num_trailing_blank[b] + e.last_trail()[b];
+        }
+    });
+}
+int32_t k2hip_offline_stream_get_ctc_state(const k2hip_offline_stream_t* s, int32_t* frame_offset, int32_t* num_trailing_blank) {
+    return guard([&] {
+        NEED(s);
+        if (frame_offset) *frame_offset = s->frame_offset;
+        if (num_trailing_blank) *num_trailing_blank = s->num_trailing_blank;
     });
 }
 int32_t k2hip_set_decoding_method(k2hip_model_t* model, const char* method, int32_t beam) {
@@ -524,8 +548,10 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
                 s->tokens.push_back(tok[(size_t)r * Tp + k]);          // :183
                 s->timestamps.push_back(ts[(size_t)r * Tp + k]);       // :184 (chunk-relative frame index)
             }
-            s->hyp[0] = s->tokens[s->tokens.size() - 2];               // :208
-            s->hyp[1] = s->tokens[s->tokens.size() - 1];
+            if (!c.ctc) {  // the CTC delegate leaves Hyp alone (OnlineRecognizer.cs:302-310)
+                s->hyp[0] = s->tokens[s->tokens.size() - 2];           // :208
+                s->hyp[1] = s->tokens[s->tokens.size() - 1];
+            }
             s->processed_len += (c.chunk_T - 7) / 2 - 3;               // new_processed_lens = processed_lens + x_lens
             decoded[idx[r]] = 1;
             n_new_tokens[idx[r]] = n[r];
@@ -649,6 +675,24 @@ int32_t k2hip_offline_recognizer_get_results(k2hip_model_t* model, k2hip_offline
             std::lock_guard<std::mutex> lk(e.mutex());
             e.offline_greedy_feats(ptrs.data(), nfl.data(), B, false, tok.data(), ts.data(), n.data(), max_tokens);
         }
+        if (c.ctc) {
+            // ForwardBatchGreedySearchCTC (:366-424): new symbols are appended to the stream's OWN lists (Tokens starts as
+            // [blank, blank], OfflineStream.cs:34), timestamps carry FrameOffset, NumTrailingBlank accumulates
+            const std::vector<int>&trail = e.last_trail(), &any = e.last_any();
+            for (int b = 0; b < B; b++) {
+                k2hip_offline_stream* s = streams[b];
+                for (int k = 0; k < n[b]; k++) {
+                    s->tokens.push_back(tok[(size_t)b * max_tokens + k]);
+                    s->timestamps.push_back(ts[(size_t)b * max_tokens + k] + s->frame_offset);
+                }
+                s->num_trailing_blank = any[b] ? trail[b] : s->num_trailing_blank + trail[b];
+                if ((int)s->tokens.size() > c.ctx) {  // RemoveSamples (:418)
+                    s->speech.clear();
+                    s->speech.shrink_to_fit();
+                }
+            }
+            return;
+        }
         for (int b = 0; b < B; b++) {
             k2hip_offline_stream* s = streams[b];
             // tokens[m] / timestamps[m] are seeded with 2*B blanks / zeros (:250-267)
@@ -682,9 +726,10 @@ int32_t k2hip_offline_recognizer_get_result(k2hip_model_t* model, k2hip_offline_
             std::lock_guard<std::mutex> lk(e.mutex());
             e.offline_greedy_feats(p, nfl, 1, true, tok.data(), ts.data(), &n, max_tokens);
         }
-        s->tokens = {-1, K2HIP_BLANK_ID};  // hypList (:115-117, :180)
+        s->tokens = {-1, K2HIP_BLANK_ID};  // hypList (:115-117, :180); the CTC single path seeds the same pair (:318-320)
         s->tokens.insert(s->tokens.end(), tok.begin(), tok.begin() + n);
-        s->timestamps.insert(s->timestamps.end(), ts.begin(), ts.begin() + n);  // (:181)
+        s->timestamps.insert(s->timestamps.end(), ts.begin(), ts.begin() + n);  // (:181; CTC :355 with frameOffset = 0)
+        if (c.ctc) s->num_trailing_blank = e.last_any()[0] ? e.last_trail()[0] : e.last_trail()[0];  // local counter from 0 (:316,:354)
     });
 }
 int32_t k2hip_offline_stream_num_tokens(const k2hip_offline_stream_t* s) { return s ? (int32_t)s->tokens.size() : -1; }

@@ -342,7 +342,7 @@ float* Engine::encoder_forward(const Ctx& c, const float* x, int B, int T, int* 
     int T50_pre = (T - 7) / 2;
     K2_REQUIRE(T50_pre > 0, "encoder: %d input frames are too few", T);
     int Tpp = (T50_pre + 1) / 2;
-    float* enc_out = ar.take<float>((int64_t)B * Tpp * cf.J);
+    float* enc_out = ar.take<float>((int64_t)B * Tpp * cf.enc_dim());
     float* x0 = encoder_embed(c, x, B, T, &T50);
     if (tap_rows) *tap_rows = B * T50;
     if (tap == 0) {
@@ -360,7 +360,12 @@ float* Engine::encoder_forward(const Ctx& c, const float* x, int B, int T, int* 
     }
     float* dsd = ar.take<float>((int64_t)B * Tpp * cf.dmax);
     downsample(c, full, m.w("encoder.downsample_output.bias"), dsd, B, T50, cf.dmax, 2);
-    linear(c, dsd, cf.dmax, m.w("joiner.encoder_proj.weight"), m.w("joiner.encoder_proj.bias"), enc_out, cf.J, B * Tpp, cf.dmax, cf.J);
+    if (cf.ctc) {  // CTC head: Linear(Dmax -> V) + log_softmax = the model's "log_probs" output
+        linear(c, dsd, cf.dmax, m.w("ctc_output.1.weight"), m.w("ctc_output.1.bias"), enc_out, cf.V, B * Tpp, cf.dmax, cf.V);
+        log_softmax_rows(c, enc_out, B * Tpp, cf.V);
+    } else {
+        linear(c, dsd, cf.dmax, m.w("joiner.encoder_proj.weight"), m.w("joiner.encoder_proj.bias"), enc_out, cf.J, B * Tpp, cf.dmax, cf.J);
+    }
     *Tp = Tpp;
     return enc_out;
 }
@@ -370,6 +375,10 @@ float* Engine::encoder_forward(const Ctx& c, const float* x, int B, int T, int* 
 // ---------------------------------------------------------------------------
 void Engine::greedy_device(const Ctx& c, const float* enc, int B, int Tp, bool single, long long* d_tok, int* d_ts, int* d_n,
                            int max_tokens, int* d_overflow) {
+    if (model_->cfg().ctc) {
+        ctc_device(c, enc, B, Tp, d_tok, d_ts, d_n, max_tokens, d_overflow);
+        return;
+    }
     if (beam_ > 0 && !single) {
         beam_device(c, enc, B, Tp, d_tok, d_ts, d_n, max_tokens, d_overflow);
         return;
@@ -404,6 +413,20 @@ void Engine::greedy_device(const Ctx& c, const float* enc, int B, int Tp, bool s
     greedy_loop(c, w, a);
 }
 
+// ForwardBatchGreedySearchCTC (OfflineRecognizer.cs:366-424): first-index argmax per frame (parallel), then per stream drop
+// blanks and repeats.  logp: [B, Tp, V]
+void Engine::ctc_device(const Ctx& c, const float* logp, int B, int Tp, long long* d_tok, int* d_ts, int* d_n, int max_tokens,
+                        int* d_overflow) {
+    const Config& cf = model_->cfg();
+    Arena& ar = *c.arena;
+    int* tok = ar.take<int>((int64_t)B * Tp);
+    d_trail_ = ar.take<int>(B);
+    d_any_ = ar.take<int>(B);
+    if (!c.dry) K2_HIP(hipMemsetAsync(d_overflow, 0, sizeof(int), c.stream));
+    argmax_first_rows(c, logp, cf.V, B * Tp, cf.V, tok);
+    ctc_collapse(c, tok, B, Tp, nullptr, d_tok, d_ts, d_n, max_tokens, d_trail_, d_any_, d_overflow);
+}
+
 // modified beam search instead of the greedy loop (set_beam(K) selects it for the fused / operator entry points)
 void Engine::beam_device(const Ctx& c, const float* enc, int B, int Tp, long long* d_tok, int* d_ts, int* d_n, int max_tokens,
                          int* d_overflow) {
@@ -432,6 +455,12 @@ void Engine::finish_tokens(const long long* d_tok, const int* d_ts, const int* d
     memcpy(tokens, pin, nb_tok);
     memcpy(ts, pin + nb_tok, nb_ts);
     memcpy(n_tokens, pin + nb_tok + nb_ts, nb_n);
+    if (model_->cfg().ctc && d_trail_) {
+        last_trail_.resize(B);
+        last_any_.resize(B);
+        K2_HIP(hipMemcpy(last_trail_.data(), d_trail_, sizeof(int) * B, hipMemcpyDeviceToHost));
+        K2_HIP(hipMemcpy(last_any_.data(), d_any_, sizeof(int) * B, hipMemcpyDeviceToHost));
+    }
     if (beam_ > 0 && d_scores_) {
         last_scores_.resize(B);
         K2_HIP(hipMemcpy(last_scores_.data(), d_scores_, sizeof(float) * B, hipMemcpyDeviceToHost));
@@ -512,7 +541,7 @@ void Engine::encoder_host(const float* x, int B, int T, float* enc_out, int64_t 
     K2_REQUIRE(B > 0 && T > 0, "encoder: bad shape B=%d T=%d", B, T);
     int tp = encoder_out_frames(T);
     K2_REQUIRE(tp > 0, "encoder: %d input frames are too few", T);
-    const int J = model_->cfg().J, feat = model_->cfg().feat;
+    const int J = model_->cfg().enc_dim(), feat = model_->cfg().feat;
     if ((int64_t)B * tp * J > cap) failf(K2HIP_ERR_CAPACITY, "encoder: output needs %lld floats", (long long)B * tp * J);
     float* d_enc = nullptr;
     run_sized([&](const Ctx& c) {
@@ -596,12 +625,12 @@ void Engine::greedy_host(const float* enc_out, int B, int Tp, bool single, int64
     long long* d_tok = nullptr;
     int *d_ts = nullptr, *d_n = nullptr, *d_ovf = nullptr;
     run_sized([&](const Ctx& c) {
-        float* d_e = c.arena->take<float>((int64_t)B * Tp * cf.J);
+        float* d_e = c.arena->take<float>((int64_t)B * Tp * cf.enc_dim());
         d_tok = c.arena->take<long long>((int64_t)B * max_tokens);
         d_ts = c.arena->take<int>((int64_t)B * max_tokens);
         d_n = c.arena->take<int>(B);
         d_ovf = c.arena->take<int>(1);
-        if (!c.dry) K2_HIP(hipMemcpyAsync(d_e, enc_out, sizeof(float) * (size_t)B * Tp * cf.J, hipMemcpyHostToDevice, c.stream));
+        if (!c.dry) K2_HIP(hipMemcpyAsync(d_e, enc_out, sizeof(float) * (size_t)B * Tp * cf.enc_dim(), hipMemcpyHostToDevice, c.stream));
         greedy_device(c, d_e, B, Tp, single, d_tok, d_ts, d_n, max_tokens, d_ovf);
     });
     finish_tokens(d_tok, d_ts, d_n, d_ovf, B, max_tokens, tokens, ts, n_tokens);
@@ -615,7 +644,7 @@ void Engine::offline_greedy_feats(const float* const* feats, const int64_t* n_fl
     K2_REQUIRE(B > 0 && max_tokens > 0, "offline_greedy: bad B=%d / max_tokens=%d", B, max_tokens);
     K2_REQUIRE(!single || B == 1, "offline_greedy_single: B must be 1");
     const Config& cf = model_->cfg();
-    K2_REQUIRE(cf.J == 512, "offline loops hard-code a 512-wide encoder_out (OfflineRecognizer.cs:103,201); joiner_dim is %d", cf.J);
+    K2_REQUIRE(cf.ctc || cf.J == 512, "offline loops hard-code a 512-wide encoder_out (OfflineRecognizer.cs:103,201); joiner_dim is %d", cf.J);
     int64_t mx = 0, total = 0;
     for (int b = 0; b < B; b++) {
         K2_REQUIRE(feats[b] != nullptr && n_floats[b] > 0, "offline_greedy: stream %d has no features", b);
@@ -678,7 +707,7 @@ void Engine::offline_greedy_samples_dev(const float* samples_dev, int64_t n_each
     K2_REQUIRE(B > 0 && max_tokens > 0 && samples_dev != nullptr, "offline_greedy_from_samples: bad arguments");
     const Config& cf = model_->cfg();
     const FbankOpts& f = cf.fbank;
-    K2_REQUIRE(cf.J == 512, "offline loops hard-code a 512-wide encoder_out; joiner_dim is %d", cf.J);
+    K2_REQUIRE(cf.ctc || cf.J == 512, "offline loops hard-code a 512-wide encoder_out; joiner_dim is %d", cf.J);
     const int64_t nf = fbank_num_frames(n_each);
     K2_REQUIRE(nf > 0, "offline_greedy_from_samples: %lld samples give no frame", (long long)n_each);
     const int64_t n_fl = nf * cf.feat, L = n_fl + 80 * kTailFrames;
@@ -740,7 +769,7 @@ int Engine::submit_samples_dev(const float* samples_dev, int64_t n_each, int B, 
     K2_REQUIRE(B > 0 && max_tokens > 0 && samples_dev != nullptr, "offline_submit: bad arguments");
     const Config& cf = model_->cfg();
     const FbankOpts& f = cf.fbank;
-    K2_REQUIRE(cf.J == 512, "offline loops hard-code a 512-wide encoder_out; joiner_dim is %d", cf.J);
+    K2_REQUIRE(cf.ctc || cf.J == 512, "offline loops hard-code a 512-wide encoder_out; joiner_dim is %d", cf.J);
     const int64_t nf = fbank_num_frames(n_each);
     K2_REQUIRE(nf > 0, "offline_submit: %lld samples give no frame", (long long)n_each);
     const int ticket = next_slot_;

@@ -80,6 +80,8 @@ class Engine {
     // search with beam K (BASELINE.json configs[2]); the single-stream path is always greedy
     void set_beam(int k) { beam_ = k; }
     int beam() const { return beam_; }
+    const std::vector<int>& last_trail() const { return last_trail_; }
+    const std::vector<int>& last_any() const { return last_any_; }
     const std::vector<float>& last_scores() const { return last_scores_; }
     const k2hip_timing& timing() const { return timing_; }
 
@@ -99,6 +101,8 @@ class Engine {
     void greedy_device(const Ctx& c, const float* enc, int B, int Tp, bool single, long long* d_tok, int* d_ts, int* d_n,
                        int max_tokens, int* d_overflow);
     const float* pos_emb(int T);  // cached CompactRelPositionalEncoding table on device
+    void ctc_device(const Ctx& c, const float* logp, int B, int Tp, long long* d_tok, int* d_ts, int* d_n, int max_tokens,
+                    int* d_overflow);
     void beam_device(const Ctx& c, const float* enc, int B, int Tp, long long* d_tok, int* d_ts, int* d_n, int max_tokens,
                      int* d_overflow);
     // offline Conformer (conformer_engine.cpp)
@@ -148,6 +152,9 @@ class Engine {
     std::map<int, float*> pe_cache_;
     bool instrument_ = false;
     int beam_ = 0;
+    // CTC search by-products of the last synchronous call (NumTrailingBlank bookkeeping, OfflineRecognizer.cs:392-397)
+    int *d_trail_ = nullptr, *d_any_ = nullptr;
+    std::vector<int> last_trail_, last_any_;
     float* d_scores_ = nullptr;
     std::vector<float> last_scores_;
     GemmStats stats_;

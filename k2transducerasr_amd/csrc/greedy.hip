@@ -106,7 +106,8 @@ __device__ __forceinline__ void amax_wave(float& v, int& i) {
     }
 }
 
-// one wave per row
+// one wave per row; FIRST = false: later index wins ties (transducer loops); true: first index (CTC, Array.IndexOf)
+template <bool FIRST>
 __global__ void k_argmax_rows(const float* __restrict__ logits, int ld, int N, int V, int* __restrict__ tok) {
     int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= N) return;
@@ -114,9 +115,66 @@ __global__ void k_argmax_rows(const float* __restrict__ logits, int ld, int N, i
     const float* l = logits + (long long)row * ld;
     float v = -INFINITY;
     int idx = -1;
-    for (int k = lane; k < V; k += 64) amax_merge(v, idx, l[k], k);
-    amax_wave(v, idx);
+    if (!FIRST) {
+        for (int k = lane; k < V; k += 64) amax_merge(v, idx, l[k], k);
+        amax_wave(v, idx);
+    } else {
+        for (int k = lane; k < V; k += 64)
+            if (idx < 0 || l[k] > v) { v = l[k]; idx = k; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ov = __shfl_xor(v, o);
+            int oi = __shfl_xor(idx, o);
+            if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
+        }
+    }
     if (lane == 0) tok[row] = idx;
+}
+
+// in-place row log_softmax: x - max - log(sum(exp(x - max))), one wave per row
+__global__ void k_log_softmax_rows(float* __restrict__ x, int M, int V) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    int lane = threadIdx.x & 63;
+    float* l = x + (long long)row * V;
+    float mx = -INFINITY;
+    for (int k = lane; k < V; k += 64) mx = fmaxf(mx, l[k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float s = 0.f;
+    for (int k = lane; k < V; k += 64) s += expf(l[k] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float lse = logf(s);
+    for (int k = lane; k < V; k += 64) l[k] = l[k] - mx - lse;
+}
+
+// CTC collapse, one thread per stream (T' is a few hundred frames; the argmax above is the parallel part)
+__global__ void k_ctc_collapse(const int* __restrict__ tok, int B, int Tp, const int* __restrict__ frame_off,
+                               long long* __restrict__ tokens, int* __restrict__ timestamps, int* __restrict__ n_tokens,
+                               int max_tokens, int* __restrict__ trail, int* __restrict__ any, int* __restrict__ overflow) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int prev = -1, n = 0, tr = 0, an = 0;
+    const int fo = frame_off ? frame_off[b] : 0;
+    for (int t = 0; t < Tp; t++) {
+        const int y = tok[(long long)b * Tp + t];
+        if (y == K2HIP_BLANK_ID) tr++;
+        else { tr = 0; an = 1; }
+        if (y != K2HIP_BLANK_ID && y != prev) {
+            if (n < max_tokens) {
+                tokens[(long long)b * max_tokens + n] = y;
+                timestamps[(long long)b * max_tokens + n] = t + fo;
+            } else {
+                *overflow = 1;
+            }
+            n++;
+        }
+        prev = y;
+    }
+    n_tokens[b] = n < max_tokens ? n : max_tokens;
+    trail[b] = tr;
+    any[b] = an;
 }
 
 __global__ void k_first_emit(const int* __restrict__ tok, int B, int Tp, int skip1, int* __restrict__ t0) {
@@ -461,7 +519,24 @@ void tanh_add(const Ctx& ctx, const float* enc, const float* dec, int dec_stride
 }
 void argmax_rows(const Ctx& ctx, const float* logits, int ld, int N, int V, int* tok) {
     if (ctx.dry || N <= 0) return;
-    hipLaunchKernelGGL(k_argmax_rows, dim3(cdiv(N, 4)), dim3(256), 0, ctx.stream, logits, ld, N, V, tok);
+    hipLaunchKernelGGL(k_argmax_rows<false>, dim3(cdiv(N, 4)), dim3(256), 0, ctx.stream, logits, ld, N, V, tok);
+    K2_HIP(hipGetLastError());
+}
+void argmax_first_rows(const Ctx& ctx, const float* logits, int ld, int N, int V, int* tok) {
+    if (ctx.dry || N <= 0) return;
+    hipLaunchKernelGGL(k_argmax_rows<true>, dim3(cdiv(N, 4)), dim3(256), 0, ctx.stream, logits, ld, N, V, tok);
+    K2_HIP(hipGetLastError());
+}
+void log_softmax_rows(const Ctx& ctx, float* x, int M, int V) {
+    if (ctx.dry || M <= 0) return;
+    hipLaunchKernelGGL(k_log_softmax_rows, dim3(cdiv(M, 4)), dim3(256), 0, ctx.stream, x, M, V);
+    K2_HIP(hipGetLastError());
+}
+void ctc_collapse(const Ctx& ctx, const int* tok, int B, int Tp, const int* frame_off, long long* tokens, int* timestamps,
+                  int* n_tokens, int max_tokens, int* trail, int* any, int* overflow) {
+    if (ctx.dry || B <= 0) return;
+    hipLaunchKernelGGL(k_ctc_collapse, dim3(cdiv(B, 64)), dim3(64), 0, ctx.stream, tok, B, Tp, frame_off, tokens, timestamps, n_tokens,
+                       max_tokens, trail, any, overflow);
     K2_HIP(hipGetLastError());
 }
 void first_emit_frame(const Ctx& ctx, const int* tok, int B, int Tp, int skip1, int* t0) {

@@ -158,6 +158,14 @@ void decoder(const Ctx& ctx, const DecJoinW& w, const long long* y, int N, float
 void tanh_add(const Ctx& ctx, const float* enc, const float* dec, int dec_stride, float* y, int N, int J);
 // row argmax with the reference tie-break (later index wins) -> emit flag (token not in {0,2} [,1])
 void argmax_rows(const Ctx& ctx, const float* logits, int ld, int N, int V, int* tok);
+// ---- CTC (zipformer2ctc models) ------------------------------------------------------------------
+void log_softmax_rows(const Ctx& ctx, float* x, int M, int V);  // in place
+// Array.IndexOf(row, row.Max()): the FIRST index of the maximum (OfflineRecognizer.cs:388)
+void argmax_first_rows(const Ctx& ctx, const float* logits, int ld, int N, int V, int* tok);
+// per stream: drop blanks and repeats (prev_id = -1), timestamp = t + frame_off[b]; trail[b] = blank frames at the end,
+// any[b] = 1 if some frame was non-blank (OfflineRecognizer.cs:383-408)
+void ctc_collapse(const Ctx& ctx, const int* tok, int B, int Tp, const int* frame_off, long long* tokens, int* timestamps,
+                  int* n_tokens, int max_tokens, int* trail, int* any, int* overflow);
 // t0 = first frame at which any stream emits under the initial context
 void first_emit_frame(const Ctx& ctx, const int* tok, int B, int Tp, int skip1, int* t0);
 struct GreedyArgs {

@@ -175,8 +175,9 @@ void Model::parse_config() {
     Config& c = cfg_;
     c.model_type = get("model_type", "");
     c.conformer = c.model_type == "conformer";
-    if (c.model_type != "zipformer2" && !c.conformer)
-        failf(K2HIP_ERR_UNSUPPORTED, "model_type '%s' is not supported (have: zipformer2, conformer)", c.model_type.c_str());
+    c.ctc = c.model_type == "zipformer2ctc";
+    if (c.model_type != "zipformer2" && !c.conformer && !c.ctc)
+        failf(K2HIP_ERR_UNSUPPORTED, "model_type '%s' is not supported (have: zipformer2, zipformer2ctc, conformer)", c.model_type.c_str());
     auto fill = [&](const char* k, int* dst) {
         auto v = csv_ints(get(k, ""));
         if ((int)v.size() > kMaxStacks) failf(K2HIP_ERR_INVALID, "metadata %s has too many entries", k);
@@ -351,7 +352,7 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
                 push(std::string(nm) + "#kd", std::move(v), {K, D});
             }
     }  // has_encoder
-    {   // joiner.output_linear [V,J] -> k-major [J][Vp]
+    if (has("joiner.output_linear.weight")) {   // joiner.output_linear [V,J] -> k-major [J][Vp]
         const Tensor& t = tensor("joiner.output_linear.weight");
         K2_REQUIRE(t.dims[0] == c.V && t.dims[1] == c.J, "joiner.output_linear.weight is [%lld,%lld], config says [%d,%d]",
                    (long long)t.dims[0], (long long)t.dims[1], c.V, c.J);
@@ -360,7 +361,7 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
             for (int k = 0; k < c.J; k++) v[(size_t)k * c.Vp + n] = t.host[(size_t)n * c.J + k];
         push("joiner.output_linear.weight#kn", std::move(v), {c.J, c.Vp});
     }
-    {   // joiner.decoder_proj [J,DD] -> k-major [DD][J]
+    if (has("joiner.decoder_proj.weight")) {   // joiner.decoder_proj [J,DD] -> k-major [DD][J]
         const Tensor& t = tensor("joiner.decoder_proj.weight");
         K2_REQUIRE(t.dims[0] == c.J && t.dims[1] == c.DD, "joiner.decoder_proj.weight shape mismatch");
         std::vector<float> v((size_t)c.DD * c.J);

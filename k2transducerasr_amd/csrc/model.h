@@ -43,6 +43,10 @@ struct Config {
     // model_type "conformer" (offline; OfflineRecognizer.cs:38-53 routes it to OfflineProjOfTransducer): one stack,
     // dim[0] / nlayer[0] / ff[0] / heads[0] / kern[0]; see conformer_engine.cpp
     bool conformer = false;
+    // model_type "zipformer2ctc": Zipformer2 encoder + CTC head (ctc_output.1), no decoder / joiner; the encoder entry points
+    // return log_probs [B,T',V] (OfflineProjOfZipformer2ctc.cs:48-92, OnlineProjOfZipformer2ctc)
+    bool ctc = false;
+    int enc_dim() const { return ctc ? V : J; }
     int conv_cpg = 4;  // decoder conv input channels per group (4: Zipformer recipes; DD: stateless2 decoder, groups = 1)
     bool streaming = false;
     int chunk_T = 0, shift = 0, left[kMaxStacks] = {0};

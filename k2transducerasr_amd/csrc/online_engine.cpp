@@ -333,11 +333,22 @@ void Engine::online_step(const int* slots, const float* chunks, const long long*
         K2_REQUIRE(Tpp == Tp, "internal: chunk yields %d frames, expected %d", Tpp, Tp);
         float* dsd = ar.take<float>((int64_t)B * Tp * Dmax);
         downsample(c, full, m.w("encoder.downsample_output.bias"), dsd, B, Tc, Dmax, 2);
-        float* enc = ar.take<float>((int64_t)B * Tp * cf.J);
-        linear(c, dsd, Dmax, m.w("joiner.encoder_proj.weight"), m.w("joiner.encoder_proj.bias"), enc, cf.J, B * Tp, Dmax, cf.J);
+        float* enc = ar.take<float>((int64_t)B * Tp * cf.enc_dim());
+        if (cf.ctc) {
+            linear(c, dsd, Dmax, m.w("ctc_output.1.weight"), m.w("ctc_output.1.bias"), enc, cf.V, B * Tp, Dmax, cf.V);
+            log_softmax_rows(c, enc, B * Tp, cf.V);
+        } else {
+            linear(c, dsd, Dmax, m.w("joiner.encoder_proj.weight"), m.w("joiner.encoder_proj.bias"), enc, cf.J, B * Tp, Dmax, cf.J);
+        }
         if (!c.dry) {
             K2_HIP(hipEventRecord(ev_[3], c.stream));
             K2_HIP(hipMemsetAsync(d_ovf, 0, sizeof(int), c.stream));
+        }
+        if (cf.ctc) {
+            // OnlineRecognizer.ForwardBatchGreedySearchCTC (:220-313): per-chunk CTC collapse, prev_id reset per chunk
+            ctc_device(c, enc, B, Tp, d_tok, d_ts, d_n, Tp, d_ovf);
+            if (!c.dry) K2_HIP(hipEventRecord(ev_[4], c.stream));
+            return;
         }
         // OnlineRecognizer.cs:135-202: decoder on the streams' hyps, T' joiner steps, skip {blank, unk, 1}
         GreedyArgs a;

@@ -61,11 +61,11 @@ def test_ctc_head_is_log_softmax_of_linear(oracle_ctc, ctc_path, utts):
     # tap 100 is the full-dim 50 Hz output; the head sits on its SimpleDownsample(2) -- restate both with torch
     full = torch.from_numpy(oracle_ctc.encoder_tap(x, 100).reshape(2, -1, 128))
     T50 = full.shape[1]
-    wts = torch.softmax(torch.from_numpy(w["encoder.downsample_output.bias"]), 0)
+    wts = torch.softmax(torch.from_numpy(w["encoder.downsample_output.bias"].copy()), 0)
     pad = full[:, -1:].expand(-1, (-T50) % 2, -1)
     ds = (torch.cat([full, pad], 1).reshape(2, -1, 2, 128) * wts[None, None, :, None]).sum(2)
-    want = torch.log_softmax(torch.nn.functional.linear(ds, torch.from_numpy(w["ctc_output.1.weight"]),
-                                                        torch.from_numpy(w["ctc_output.1.bias"])), -1).numpy()
+    want = torch.log_softmax(torch.nn.functional.linear(ds, torch.from_numpy(w["ctc_output.1.weight"].copy()),
+                                                        torch.from_numpy(w["ctc_output.1.bias"].copy())), -1).numpy()
     np.testing.assert_allclose(lp, want, atol=2e-5)
     res, _ = oracle_ctc.ctc_greedy(lp)
     assert sum(len(t) for t, _ in res) > 0
