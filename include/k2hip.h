@@ -42,6 +42,7 @@ extern "C" {
 typedef struct k2hip_model k2hip_model_t;
 typedef struct k2hip_offline_stream k2hip_offline_stream_t;
 typedef struct k2hip_online_stream k2hip_online_stream_t;
+typedef struct k2hip_tokens k2hip_tokens_t;
 
 /* Fixed ids of the reference: OfflineModel.cs:18-20. */
 #define K2HIP_BLANK_ID 0
@@ -200,6 +201,17 @@ int32_t k2hip_offline_stream_accept_samples(k2hip_offline_stream_t* s, const flo
 int64_t k2hip_offline_stream_speech_length(const k2hip_offline_stream_t* s);
 /* copies Speech to out (cap floats) */
 int32_t k2hip_offline_stream_get_speech(const k2hip_offline_stream_t* s, float* out, int64_t cap);
+/* ---- token ids -> text (host only; no GPU involved) ------------------------------------------------------------------
+ * OfflineRecognizer.DecodeMulti + CheckText + HexToStr (OfflineRecognizer.cs:432-565; online :321-352) and
+ * Utils/ByteDataHelper.SmartByteDecode (:352-397): tokens.txt lookup (first space-separated field), stop at id 2, skip id -1
+ * (offline), drop <blk> / <sos/eos> / <unk>, U+2581 -> ' ', <0x..> byte runs -> UTF-8, otherwise spaces removed + byte-BPE
+ * decode, lower-case.  Text is UTF-8, NUL terminated; out == NULL only queries len (bytes without the NUL). */
+int32_t k2hip_tokens_load(const char* tokens_path, k2hip_tokens_t** out);   /* File.ReadAllLines(tokensFilePath), :36 */
+int32_t k2hip_tokens_destroy(k2hip_tokens_t* t);
+int32_t k2hip_tokens_size(const k2hip_tokens_t* t);                          /* _tokens.Length (the CTC vocab_size, :325) */
+int32_t k2hip_decode_text(const k2hip_tokens_t* t, const int64_t* ids, int32_t n, int32_t online, char* out, int32_t cap,
+                          int32_t* len);
+
 /* ---- CTC models (Model_type "zipformer2ctc": OfflineProjOfZipformer2ctc / OnlineProjOfZipformer2ctc) -------------------
  * The encoder entry points (k2hip_offline_encoder, the online step) return log_probs [B,T',V] for such a model.
  * k2hip_ctc_greedy replaces the loop of ForwardBatchGreedySearchCTC (OfflineRecognizer.cs:383-408): y = first index of the

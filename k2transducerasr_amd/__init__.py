@@ -17,6 +17,7 @@ from .binding import (  # noqa: F401
     OfflineStream,
     OnlineRecognizer,
     OnlineStream,
+    TokenTable,
     build_library,
     library_path,
     load_library,
@@ -29,6 +30,7 @@ __all__ = [
     "OfflineStream",
     "OnlineRecognizer",
     "OnlineStream",
+    "TokenTable",
     "build_library",
     "library_path",
     "load_library",

@@ -141,6 +141,45 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+class TokenTable:
+    """tokens.txt + the reference's token -> text stage (OfflineRecognizer.DecodeMulti / CheckText, :432-565); host only."""
+
+    def __init__(self, tokens_path: str):
+        self._L = load_library()
+        self._L.k2hip_tokens_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        self._L.k2hip_tokens_destroy.argtypes = [C.c_void_p]
+        self._L.k2hip_tokens_size.argtypes = [C.c_void_p]
+        self._L.k2hip_decode_text.argtypes = [C.c_void_p, lp, C.c_int32, C.c_int32, C.c_char_p, C.c_int32, ip]
+        h = C.c_void_p()
+        rc = self._L.k2hip_tokens_load(tokens_path.encode(), C.byref(h))
+        if rc != 0:
+            raise K2HipError(rc, self._L.k2hip_last_error().decode())
+        self._h = h
+
+    def __len__(self):
+        return self._L.k2hip_tokens_size(self._h)
+
+    def decode(self, ids, online: bool = False) -> str:
+        a = np.ascontiguousarray(ids, dtype=np.int64)
+        n = C.c_int32()
+        rc = self._L.k2hip_decode_text(self._h, _l(a), a.size, int(online), None, 0, C.byref(n))
+        if rc != 0:
+            raise K2HipError(rc, self._L.k2hip_last_error().decode())
+        buf = C.create_string_buffer(n.value + 1)
+        rc = self._L.k2hip_decode_text(self._h, _l(a), a.size, int(online), buf, n.value + 1, C.byref(n))
+        if rc != 0:
+            raise K2HipError(rc, self._L.k2hip_last_error().decode())
+        return buf.raw[: n.value].decode("utf-8")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.k2hip_tokens_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 class Model:
     """One model replica on one GPU (k2hip_model_t): the IOfflineProj operators."""
 

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <new>
 
+#include "text.h"
 #include "engine.h"
 
 using namespace k2hip;
@@ -236,6 +237,38 @@ int32_t k2hip_greedy_single(k2hip_model_t* model, const float* enc_out, int32_t 
         NEED(model); NEED(enc_out); NEED(tokens); NEED(timestamps); NEED(n_tokens);
         std::lock_guard<std::mutex> lk(model->engine.mutex());
         model->engine.greedy_host(enc_out, 1, Tprime, true, tokens, timestamps, n_tokens, max_tokens);
+    });
+}
+// ---- token ids -> text (text.cpp) ----------------------------------------------------------------
+struct k2hip_tokens {
+    k2hip::TokenTable* tab;
+};
+int32_t k2hip_tokens_load(const char* tokens_path, k2hip_tokens_t** out) {
+    return guard([&] {
+        NEED(tokens_path); NEED(out);
+        auto* t = new k2hip_tokens{token_table_load(tokens_path)};
+        *out = t;
+    });
+}
+int32_t k2hip_tokens_destroy(k2hip_tokens_t* t) {
+    return guard([&] {
+        if (t) {
+            token_table_free(t->tab);
+            delete t;
+        }
+    });
+}
+int32_t k2hip_tokens_size(const k2hip_tokens_t* t) { return t ? token_table_size(t->tab) : -1; }
+int32_t k2hip_decode_text(const k2hip_tokens_t* t, const int64_t* ids, int32_t n, int32_t online, char* out, int32_t cap,
+                          int32_t* len) {
+    return guard([&] {
+        NEED(t); NEED(len);
+        K2_REQUIRE(n == 0 || ids != nullptr, "decode_text: ids is NULL");
+        std::string s = decode_tokens(*t->tab, ids, n, online != 0);
+        *len = (int32_t)s.size();
+        if (!out) return;
+        if ((int32_t)s.size() + 1 > cap) failf(K2HIP_ERR_CAPACITY, "decode_text: text needs %zu bytes", s.size() + 1);
+        memcpy(out, s.c_str(), s.size() + 1);
     });
 }
 int32_t k2hip_ctc_greedy(k2hip_model_t* model, const float* log_probs, int32_t B, int32_t Tprime, const int32_t* frame_offsets,

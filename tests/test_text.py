@@ -1,0 +1,125 @@
+"""Token ids -> text.  Host-only stage, so these run on the CPU box: the C ABI (csrc/text.cpp through
+k2hip_decode_text -- no GPU call is made) against oracle/text.py, on hand-derived known answers and on fuzzed inputs."""
+import ctypes as C
+import random
+
+import pytest
+
+from k2transducerasr_amd import load_library
+from oracle import text as otext
+
+TOKENS = ["<blk>", "<sos/eos>", "<unk>", "▁HE", "LLO", "▁WORLD", "<0xE4>", "<0xBD>", "<0xA0>", "你", "好", "▁", "S",
+          "<0xE5>", "<0xA5>", "<0xBD>", "▁ÀÉ", "Ω", "Ж", "ƌ", "x", "Ĉ", "<0x41>", "<0x4>", "Ａ"]
+
+
+@pytest.fixture(scope="module")
+def tok(tmp_path_factory):
+    p = tmp_path_factory.mktemp("tok") / "tokens.txt"
+    p.write_bytes(("\n".join(f"{t} {i}" for i, t in enumerate(TOKENS)) + "\n").encode("utf-8"))
+    L = load_library()
+    L.k2hip_tokens_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    L.k2hip_tokens_size.argtypes = [C.c_void_p]
+    L.k2hip_decode_text.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
+    h = C.c_void_p()
+    assert L.k2hip_tokens_load(str(p).encode(), C.byref(h)) == 0
+    assert L.k2hip_tokens_size(h) == len(TOKENS)
+    lines = otext.read_tokens(str(p))
+    assert [l.split(" ")[0] for l in lines] == TOKENS
+
+    def decode(ids, online=False):
+        arr = (C.c_int64 * max(len(ids), 1))(*ids)
+        n = C.c_int32()
+        buf = C.create_string_buffer(4096)
+        rc = L.k2hip_decode_text(h, arr, len(ids), int(online), buf, 4096, C.byref(n))
+        if rc != 0:
+            raise RuntimeError(L.k2hip_last_error().decode())
+        return buf.raw[: n.value].decode("utf-8")
+
+    return decode, lines
+
+
+KAT = [
+    # ids, expected, why
+    ([0, 0, 3, 4, 5], "helloworld", "no <..> match -> CheckText drops every space before the byte-BPE decode (OfflineRecognizer.cs:482-485)"),
+    ([-1, 0, 3, 4], "hello", "the single path's [-1, blank] prefix is skipped (:445-452)"),
+    ([3, 2, 4, 5], "he", "id 2 (<unk>) stops the loop (:441-444)"),
+    ([0, 6, 7, 8], "你", "<0xE4><0xBD><0xA0> -> UTF-8 bytes E4 BD A0 (:487-533)"),
+    ([6, 7, 8, 13, 14, 15], "你好", "one run of six byte tokens, starts exactly 6 chars apart"),
+    ([3, 6, 7, 8, 5], " he你 world", "with a <..> match the spaces from U+2581 survive"),
+    ([9, 10], "你好", "plain CJK tokens pass through ByteDecode's failure path unchanged (ByteDataHelper.cs:341-344)"),
+    ([6, 7, 8, 20, 13, 14, 15], "你x好", "two runs: 'x' breaks the 6-apart chain"),
+    ([16, 17, 18, 6, 7, 8], " àéωж你", "ToLower on Latin-1 / Greek / Cyrillic"),
+    ([22], "a", "<0x41> -> 'A' -> lower-cased"),
+    ([23], "b", "odd hex length gets '20' appended (:541-544): '4' -> '420' -> byte[3 / 2] = one byte 0x42"),
+    ([], "", "empty token list"),
+    ([0, 1, 2], "", "only specials"),
+]
+
+
+@pytest.mark.parametrize("ids,want,why", KAT)
+def test_known_answers(tok, ids, want, why):
+    decode, lines = tok
+    assert otext.decode_tokens(lines, ids) == want, why
+    assert decode(ids) == want, why
+
+
+def test_online_variant_has_no_minus_one_case(tok):
+    decode, lines = tok
+    # OnlineRecognizer.DecodeMulti (:321-352) has no `token == -1` branch; online Tokens never contain -1
+    assert decode([0, 0, 3, 4], online=True) == otext.decode_tokens(lines, [0, 0, 3, 4], online=True) == "hello"
+
+
+def test_byte_bpe_alphabet_round_trip():
+    # the byte-BPE alphabet is the published icefall one: 95 printable ASCII self-mapped, the rest from 256 up, NFKC-stable
+    assert len(set(otext.BYTE_TO_BCHAR.values())) == 256
+    assert all(otext.BYTE_TO_BCHAR[b] == chr(b) for b in range(32, 127))
+    assert ord(otext.BYTE_TO_BCHAR[0]) == 256 and ord(otext.BYTE_TO_BCHAR[127]) == 288 and ord(otext.BYTE_TO_BCHAR[255]) == 422
+    enc = "".join(otext.BYTE_TO_BCHAR[b] for b in "你好 k2".encode("utf-8"))
+    assert otext.smart_byte_decode(enc) == "你好 k2"
+
+
+def test_byte_bpe_text_through_the_abi(tmp_path):
+    # a byte-BPE vocabulary: tokens are strings over the alphabet; invalid UTF-8 becomes U+FFFD like Encoding.UTF8.GetString
+    pieces = ["<blk>", "<sos/eos>", "<unk>"]
+    enc = [otext.BYTE_TO_BCHAR[b] for b in "你好".encode("utf-8")]
+    pieces += ["▁" + enc[0] + enc[1], enc[2], enc[3] + enc[4] + enc[5], otext.BYTE_TO_BCHAR[0xE4], "OK", otext.BPE_UNK]
+    p = tmp_path / "bbpe_tokens.txt"
+    p.write_bytes("\n".join(f"{t} {i}" for i, t in enumerate(pieces)).encode("utf-8"))
+    L = load_library()
+    h = C.c_void_p()
+    assert L.k2hip_tokens_load(str(p).encode(), C.byref(h)) == 0
+    lines = otext.read_tokens(str(p))
+
+    def decode(ids):
+        arr = (C.c_int64 * len(ids))(*ids)
+        n = C.c_int32()
+        buf = C.create_string_buffer(1024)
+        assert L.k2hip_decode_text(h, arr, len(ids), 0, buf, 1024, C.byref(n)) == 0
+        return buf.raw[: n.value].decode("utf-8")
+
+    for ids in ([3, 4, 5], [3, 4, 5, 7], [6, 7], [3, 4, 6, 5], [8, 7]):
+        assert decode(ids) == otext.decode_tokens(lines, ids)
+    assert decode([3, 4, 5]) == "你好"
+    assert decode([6, 7]) == "�ok"            # a lone E4 lead byte
+    assert decode([8, 7]) == " ok"                  # BPE_UNK -> byte 32
+
+
+def test_fuzz_abi_against_oracle(tok):
+    decode, lines = tok
+    rng = random.Random(7)
+    for _ in range(400):
+        ids = [rng.randrange(-1, len(TOKENS)) for _ in range(rng.randrange(0, 14))]
+        want = None
+        try:
+            want = otext.decode_tokens(lines, ids)
+        except ValueError:
+            with pytest.raises(RuntimeError):
+                decode(ids)
+            continue
+        assert decode(ids) == want, ids
+
+
+def test_errors(tok):
+    decode, _ = tok
+    with pytest.raises(RuntimeError):
+        decode([len(TOKENS)])           # the reference would throw IndexOutOfRange here
