@@ -18,7 +18,9 @@ Engine::Engine(const std::string& weights, const char* overrides, int device) : 
     model_.reset(new Model(weights, overrides, device));
     K2_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     K2_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+    if (const char* pm = getenv("K2HIP_PIPE_MODE")) pipe_mode_ = atoi(pm);
     for (auto& sl : slots_) {
+        K2_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
         K2_HIP(hipEventCreateWithFlags(&sl.enc_done, hipEventDisableTiming));
         K2_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
@@ -33,6 +35,7 @@ Engine::~Engine() {
         if (sl.enc_done) (void)hipEventDestroy(sl.enc_done);
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.pin) (void)hipHostFree(sl.pin);
+        if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
         sl.arena.release();
     }
     if (stream2_) (void)hipStreamDestroy(stream2_);
@@ -60,7 +63,7 @@ void* Engine::pinned(int64_t bytes) {
 
 Ctx Engine::make_ctx(bool dry) {
     Ctx c;
-    c.stream = stream_;
+    c.stream = cur_stream_ ? cur_stream_ : stream_;
     c.arena = cur_arena_;
     c.dry = dry;
     c.instrument = instrument_ && !dry;
@@ -786,6 +789,9 @@ int Engine::submit_samples_dev(const float* samples_dev, int64_t n_each, int B, 
         sl.pin_cap = nb;
     }
     cur_arena_ = &sl.arena;
+    const bool own = pipe_mode_ == 1;
+    hipStream_t s2 = own ? sl.stream : stream2_;
+    cur_stream_ = own ? sl.stream : nullptr;
     try {
         run_sized([&](const Ctx& c) {
             Arena& ar = *c.arena;
@@ -802,9 +808,9 @@ int Engine::submit_samples_dev(const float* samples_dev, int64_t n_each, int B, 
             int Tp = 0;
             float* enc = encoder_forward(c, d_x, B, T, &Tp, -1, nullptr, nullptr, nullptr);
             Ctx cd = c;
-            cd.stream = stream2_;
+            cd.stream = s2;
             cd.instrument = false;
-            if (!c.dry) {
+            if (!c.dry && !own) {
                 K2_HIP(hipEventRecord(sl.enc_done, c.stream));
                 K2_HIP(hipStreamWaitEvent(stream2_, sl.enc_done, 0));
             }
@@ -812,16 +818,18 @@ int Engine::submit_samples_dev(const float* samples_dev, int64_t n_each, int B, 
         });
     } catch (...) {
         cur_arena_ = &arena_;
+        cur_stream_ = nullptr;
         throw;
     }
     cur_arena_ = &arena_;
+    cur_stream_ = nullptr;
     const int64_t nb_tok = (int64_t)B * max_tokens * 8, nb_ts = (int64_t)B * max_tokens * 4, nb_n = (int64_t)B * 4;
     char* pin = static_cast<char*>(sl.pin);
-    K2_HIP(hipMemcpyAsync(pin, sl.d_tok, nb_tok, hipMemcpyDeviceToHost, stream2_));
-    K2_HIP(hipMemcpyAsync(pin + nb_tok, sl.d_ts, nb_ts, hipMemcpyDeviceToHost, stream2_));
-    K2_HIP(hipMemcpyAsync(pin + nb_tok + nb_ts, sl.d_n, nb_n, hipMemcpyDeviceToHost, stream2_));
-    K2_HIP(hipMemcpyAsync(pin + nb_tok + nb_ts + nb_n, sl.d_ovf, 4, hipMemcpyDeviceToHost, stream2_));
-    K2_HIP(hipEventRecord(sl.done, stream2_));
+    K2_HIP(hipMemcpyAsync(pin, sl.d_tok, nb_tok, hipMemcpyDeviceToHost, s2));
+    K2_HIP(hipMemcpyAsync(pin + nb_tok, sl.d_ts, nb_ts, hipMemcpyDeviceToHost, s2));
+    K2_HIP(hipMemcpyAsync(pin + nb_tok + nb_ts, sl.d_n, nb_n, hipMemcpyDeviceToHost, s2));
+    K2_HIP(hipMemcpyAsync(pin + nb_tok + nb_ts + nb_n, sl.d_ovf, 4, hipMemcpyDeviceToHost, s2));
+    K2_HIP(hipEventRecord(sl.done, s2));
     sl.B = B;
     sl.max_tokens = max_tokens;
     sl.busy = true;
@@ -891,6 +899,7 @@ void Engine::synchronize() {
     K2_HIP(hipSetDevice(device_));
     K2_HIP(hipStreamSynchronize(stream_));
     K2_HIP(hipStreamSynchronize(stream2_));
+    for (auto& sl : slots_) K2_HIP(hipStreamSynchronize(sl.stream));
 }
 
 }  // namespace k2hip

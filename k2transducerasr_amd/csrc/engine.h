@@ -75,6 +75,7 @@ class Engine {
                      int64_t* tokens, int32_t* ts, int32_t* n_tokens);
 
     void set_instrument(bool on) { instrument_ = on; }
+    void set_pipe_mode(int m) { pipe_mode_ = m; }
     const std::vector<GemmLaunchRec>& gemm_log() const { return gemm_log_; }
     // decoding method of the batch entry points: 0 = greedy_search (the reference's only method), K >= 1 = modified beam
     // search with beam K (BASELINE.json configs[2]); the single-stream path is always greedy
@@ -135,6 +136,7 @@ class Engine {
     struct Slot {
         Arena arena;
         hipEvent_t enc_done = nullptr, done = nullptr;
+        hipStream_t stream = nullptr;  // pipe mode 1: the slot's whole pipeline (fbank .. search .. D2H) runs here
         void* pin = nullptr;
         int64_t pin_cap = 0;
         long long* d_tok = nullptr;
@@ -144,6 +146,10 @@ class Engine {
     } slots_[kSlots];
     int next_slot_ = 0;
     hipStream_t stream2_ = nullptr;
+    hipStream_t cur_stream_ = nullptr;  // stream of the call being built (nullptr = stream_)
+    // submit/wait overlap: 0 = search of batch i (stream2) under the encoder of batch i+1 (stream); 1 = every slot owns a
+    // stream, so two whole batches run concurrently and each other's GEMM prologues / epilogues / tails are filled
+    int pipe_mode_ = 0;
     float* online_pool_ = nullptr;
     int online_cap_ = 0;
     std::vector<int> free_slots_;
@@ -187,7 +193,7 @@ void Engine::run_sized(F&& body) {
     int64_t need = cur_arena_->high_water();
     cur_arena_->reset();
     if (need > cur_arena_->capacity()) {
-        K2_HIP(hipStreamSynchronize(stream_));
+        K2_HIP(hipStreamSynchronize(cur_stream_ ? cur_stream_ : stream_));
         cur_arena_->reserve(need + need / 8);
     }
     Ctx c = make_ctx(false);
@@ -195,7 +201,7 @@ void Engine::run_sized(F&& body) {
     gemm_log_.clear();
     body(c);
     if (instrument_) {
-        K2_HIP(hipStreamSynchronize(stream_));
+        K2_HIP(hipStreamSynchronize(cur_stream_ ? cur_stream_ : stream_));
         for (int i = 0; i + 1 < evused_; i += 2) {
             float ms = 0;
             K2_HIP(hipEventElapsedTime(&ms, evpool_[i], evpool_[i + 1]));

@@ -495,7 +495,7 @@ int choose_cfg(const GemmArgs& a) {
     if (a.N <= 64) return 2;    // 64x64 tiles, 4 waves
     // few output tiles (streaming chunks: 256..2048 rows): the launch is one latency-bound K sweep per
     // workgroup; small tiles with a 64-deep K step are fastest (gpurun_out/gemm_tune_s1.txt)
-    if ((double)a.M * a.N * a.nb0 * a.nb1 < 2.0e6) return 3;
+    if ((long long)cdiv(a.M, 128) * cdiv(a.N, 64) * a.nb0 * a.nb1 < 144) return 3;  // fewer 128x64 tiles than ~half the CUs
     if (a.N <= 128) return 3;   // 64x64 tiles, K step 64
     return 5;                   // 128x64 tiles, 8 waves (LDS-DMA pipeline when K % 32 == 0)
 }
