@@ -109,6 +109,59 @@ __global__ void k_dwconv7x7(const float* __restrict__ x, const float* __restrict
     *reinterpret_cast<float4*>(y + p * C + c) = s;
 }
 
+// LDS-tiled form: one workgroup = 8 output frames x all F bins x 32 channels.  The (8+6) x (F+6) x 32 input patch (zero
+// halo) is staged once; a thread owns one (bin, channel quad) column of 8 outputs and slides down the patch, so every staged
+// value is read 7 times from LDS instead of 49 times from L2 (the per-pixel kernel above fetched 11x the tensor: 1.78 GB per
+// launch against 157 MB, profiles/r01_v2_pmc_fetch_summary.csv).
+constexpr int DW7_TT = 8, DW7_CG = 32;
+__global__ __launch_bounds__(192) void k_dwconv7x7_tiled(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int Tin, int T,
+                                                         int tpad, int F, int C) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [DW7_TT + 6][F + 6][32]
+    const int tid = threadIdx.x, cq = tid & 7, fi = tid >> 3;
+    const int c0 = blockIdx.x * DW7_CG, t0 = blockIdx.y * DW7_TT, b = blockIdx.z;
+    const int FP = F + 6, ncell = (DW7_TT + 6) * FP * 8;
+    for (int idx = tid; idx < ncell; idx += 192) {
+        const int q = idx & 7, cell = idx >> 3;
+        const int fp = cell % FP, r = cell / FP;
+        const int f = fp - 3, tt = t0 + r - tpad;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f >= 0 && f < F && tt >= 0 && tt < Tin) v = *reinterpret_cast<const float4*>(x + (((long long)b * Tin + tt) * F + f) * C + c0 + 4 * q);
+        *reinterpret_cast<float4*>(xs + (long long)cell * 32 + 4 * q) = v;
+    }
+    __syncthreads();
+    if (fi >= F) return;
+    const int c = c0 + 4 * cq;
+    float4 acc[DW7_TT];
+    const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+#pragma unroll
+    for (int i = 0; i < DW7_TT; i++) acc[i] = bv;
+#pragma unroll 1  // fully unrolled, the compiler hoists all 147 loads and spills
+    for (int kf = 0; kf < 7; kf++) {
+        float4 wv[7];
+#pragma unroll
+        for (int kt = 0; kt < 7; kt++) wv[kt] = *reinterpret_cast<const float4*>(w + (kt * 7 + kf) * C + c);
+        const float* col = xs + (fi + kf) * 32 + 4 * cq;
+#pragma unroll
+        for (int r = 0; r < DW7_TT + 6; r++) {
+            const float4 xv = *reinterpret_cast<const float4*>(col + r * FP * 32);
+#pragma unroll
+            for (int kt = 0; kt < 7; kt++) {
+                const int to = r - kt;  // output frame fed by patch row r through tap kt
+                if (to >= 0 && to < DW7_TT) {
+                    acc[to].x += wv[kt].x * xv.x; acc[to].y += wv[kt].y * xv.y;
+                    acc[to].z += wv[kt].z * xv.z; acc[to].w += wv[kt].w * xv.w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < DW7_TT; i++) {
+        const int t = t0 + i;
+        if (t < T) *reinterpret_cast<float4*>(y + (((long long)b * T + t) * F + fi) * C + c) = acc[i];
+    }
+}
+
 // ---- BiasNorm (+ optional bypass): one wave per row, row kept in registers
 //   scale = (mean((x-b)^2))^-0.5 * exp(log_scale);  y = x*scale
 //   with orig: y = orig + (x*scale - orig) * bscale
@@ -362,9 +415,17 @@ void basicnorm(const Ctx& ctx, const float* x, const float* log_eps, float* y, i
 }
 void dwconv7x7(const Ctx& ctx, const float* x, const float* w_kc, const float* b, float* y, int B, int Tin, int T, int tpad,
                int F, int C) {
+    ctx.add_flops(0.0, 2.0 * B * T * (double)F * C * 49, 0);
+    if (C % DW7_CG == 0 && F <= 24 && !getenv("K2HIP_DW7_SIMPLE")) {
+        if (ctx.dry) return;
+        size_t lds = sizeof(float) * (size_t)(DW7_TT + 6) * (F + 6) * 32;
+        hipLaunchKernelGGL(k_dwconv7x7_tiled, dim3(C / DW7_CG, cdiv(T, DW7_TT), B), dim3(192), lds, ctx.stream, x, w_kc, b, y, Tin, T,
+                           tpad, F, C);
+        K2_HIP(hipGetLastError());
+        return;
+    }
     long long n = (long long)B * T * F * (C / 4);
     LAUNCH(k_dwconv7x7, dim3(nblocks(n, 256)), dim3(256), x, w_kc, b, y, B, Tin, T, tpad, F, C);
-    ctx.add_flops(0.0, 2.0 * B * T * (double)F * C * 49, 0);
 }
 void biasnorm(const Ctx& ctx, const float* x, const float* bias, const float* log_scale, float* y, int M, int D) {
     K2_REQUIRE(D % 4 == 0 && D <= 1024, "biasnorm: D=%d unsupported", D);
