@@ -31,6 +31,7 @@
 namespace k2hip {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -442,6 +443,72 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Skinny-N variant (N <= 96, K % 64 == 0): the value projections of the attention modules
+// (N = 12 x heads).  With so few columns a tiled launch is a handful of workgroups, each walking
+// the whole K serially (22 us for 4064 x 48 x 512).  Here a workgroup owns 16 rows x all N, its
+// four waves split K four ways, operands go straight from global memory into the
+// v_mfma_f32_16x16x4_f32 fragment layout (lane l: A[l&15][k = l>>4]; a float4 per lane holds 4
+// consecutive k, so four MFMAs consume its components -- the k order inside a 16-wide group is
+// permuted, which a sum does not care about), and the four partial tiles meet in LDS.
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_skinny(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float red[4][NT][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    const int Kw = g.K >> 2, kbeg = wave * Kw;
+    const float* __restrict__ ap = g.A + (long long)min(m0 + r, g.M - 1) * g.lda + kbeg + 4 * q;
+    const float* __restrict__ wp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) wp[j] = g.W + (long long)min(16 * j + r, g.N - 1) * g.ldw + kbeg + 4 * q;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int UN = NT <= 3 ? 4 : 2;  // 16-k groups loaded ahead of their MFMAs
+    for (int k = 0; k < Kw; k += 16 * UN) {
+        float4 a4[UN], w4[UN][NT];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            // groups past this wave's K slice (Kw is a multiple of 16, not of 16*UN) contribute zero; clamp the address
+            const int kk = min(k + 16 * u, Kw - 16);
+            const float m = (k + 16 * u < Kw) ? 1.f : 0.f;
+            a4[u] = *reinterpret_cast<const float4*>(ap + kk);
+            a4[u].x *= m; a4[u].y *= m; a4[u].z *= m; a4[u].w *= m;
+#pragma unroll
+            for (int j = 0; j < NT; j++) w4[u][j] = *reinterpret_cast<const float4*>(wp[j] + kk);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    const float av = e == 0 ? a4[u].x : e == 1 ? a4[u].y : e == 2 ? a4[u].z : a4[u].w;
+                    const float bv = e == 0 ? w4[u][j].x : e == 1 ? w4[u][j].y : e == 2 ? w4[u][j].z : w4[u][j].w;
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[j], 0, 0, 0);
+                }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; j++) *reinterpret_cast<f32x4*>(&red[wave][j][lane][0]) = acc[j];
+    __syncthreads();
+    // wave w finishes the column tiles j = w, w + 4, ...: C/D layout col = lane & 15, row = 4 * (lane >> 4) + reg
+    for (int j = wave; j < NT; j += 4) {
+        const int col = 16 * j + r;
+        if (col >= g.N) continue;
+        const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int row = m0 + 4 * q + e;
+            if (row >= g.M) continue;
+            float v = red[0][j][lane][e] + red[1][j][lane][e] + red[2][j][lane][e] + red[3][j][lane][e];
+            v = apply_act(v + bv, g.act);
+            if (g.res) v += g.res[(long long)row * g.ldr + col];
+            g.C[(long long)row * g.ldc + col] = v;
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN>
 void launch_dma(const Ctx& ctx, const GemmArgs& a) {
     dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), 1);
@@ -530,6 +597,17 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     b.ablate = g_ablate;
     if (ctx.instrument && ctx.gemm_log)
         ctx.gemm_log->push_back({a.M, a.N, a.K, a.nb0 * a.nb1, a.act, a.res != nullptr, a.cv_Fout > 0 ? 1 : (a.w_kn ? 2 : 0), 0.f});
+    const bool skinny_ok = g_forced_cfg < 0 && a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.N <= 96 && a.K % 64 == 0 &&
+                           a.K >= 64 && a.M >= 512 && !getenv("K2HIP_GEMM_NO_SKINNY");
+    if (skinny_ok) {
+        dim3 grid(cdiv(a.M, 16));
+        if (a.N <= 48) hipLaunchKernelGGL(gemm_f32_mfma_skinny<3>, grid, dim3(256), 0, ctx.stream, b);
+        else hipLaunchKernelGGL(gemm_f32_mfma_skinny<6>, grid, dim3(256), 0, ctx.stream, b);
+        K2_HIP(hipGetLastError());
+        if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 32;
+        if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
+        return;
+    }
     const bool dma_ok = a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.K % 32 == 0 && a.K >= 64 && a.lda % 4 == 0;
     if (dma_ok && g_use_dma && (cfg == 5 || cfg == 0)) {
         if (cfg == 5) launch_dma<128, 64, 32, 32>(ctx, b);
