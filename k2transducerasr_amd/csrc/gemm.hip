@@ -306,9 +306,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
 //     side: slot (row r, chunk c') receives logical chunk c = c' ^ ((r >> 1) & 7), and the
 //     fragment reads apply the same XOR.
 //   * rows beyond M / N are clamped to the last valid row (never stored).
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NST = 3>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(GemmArgs g) {
-    constexpr int BK = 32, NST = 3;
+    constexpr int BK = 32, PF = NST - 1;  // PF stages are in flight ahead of the one being multiplied
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WCOLS = BN / WN;
     constexpr int NW = (BM / WM) * (BN / WN);
@@ -393,14 +393,15 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
     const int arow = wr * WM + li, brow = wc * WN + li;
     const int swa = (arow >> 1) & 7, swb = ((BM + brow) >> 1) & 7;
 
-    issue(0);
-    if (nk > 1) issue(1);
+#pragma unroll
+    for (int p = 0; p < PF; p++)
+        if (p < nk) issue(p);
     for (int kt = 0; kt < nk; kt++) {
-        // tile kt landed for this wave once at most the newest tile's IPW instructions are pending
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
+        // tile kt landed for this wave once at most the PF-1 newer tiles' instructions are pending
+        if (kt + PF - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * IPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // ... and for every wave; also: everyone is done reading stage (kt+2)%3
-        if (kt + 2 < nk) issue(kt + 2);
+        __builtin_amdgcn_s_barrier();  // ... and for every wave; also: everyone is done reading the stage about to be refilled
+        if (kt + PF < nk) issue(kt + PF);
         const float* sa = smem + (kt % NST) * STAGE + arow * BK;
         const float* sb = smem + (kt % NST) * STAGE + (BM + brow) * BK;
 #pragma unroll
@@ -509,17 +510,17 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_skinny(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NST = 3>
 void launch_dma(const Ctx& ctx, const GemmArgs& a) {
     dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), 1);
-    size_t lds = sizeof(float) * 3 * (BM + BN) * 32;
+    size_t lds = sizeof(float) * NST * (BM + BN) * 32;
     static bool attr_set = false;
     if (!attr_set) {
-        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_dma<BM, BN, WM, WN>),
+        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_dma<BM, BN, WM, WN, NST>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32_mfma_dma<BM, BN, WM, WN>), grid, dim3(64 * (BM / WM) * (BN / WN)), lds, ctx.stream, a);
+    hipLaunchKernelGGL((gemm_f32_mfma_dma<BM, BN, WM, WN, NST>), grid, dim3(64 * (BM / WM) * (BN / WN)), lds, ctx.stream, a);
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int MODE>
@@ -609,8 +610,13 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         return;
     }
     const bool dma_ok = a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.K % 32 == 0 && a.K >= 64 && a.lda % 4 == 0;
-    if (dma_ok && g_use_dma && (cfg == 5 || cfg == 0)) {
-        if (cfg == 5) launch_dma<128, 64, 32, 32>(ctx, b);
+    if (dma_ok && g_use_dma && (cfg == 5 || cfg == 0 || (cfg >= 7 && cfg <= 10))) {
+        if (cfg == 9) launch_dma<64, 64, 32, 32, 2>(ctx, b);         // tuning: 64x64 tiles, 2 stages
+        else if (cfg == 10) launch_dma<64, 64, 32, 32, 3>(ctx, b);   // tuning: 64x64 tiles, 3 stages
+        else if (cfg == 7) launch_dma<128, 64, 32, 32, 2>(ctx, b);  // tuning: 2 stages, 3 workgroups per CU
+        else if (cfg == 8) launch_dma<128, 64, 32, 32, 4>(ctx, b);  // tuning: 4 stages, 1 workgroup per CU
+        else if (cfg == 5 && !getenv("K2HIP_GEMM_NST3")) launch_dma<128, 64, 32, 32, 2>(ctx, b);  // 2 stages: 3 workgroups per CU
+        else if (cfg == 5) launch_dma<128, 64, 32, 32>(ctx, b);
         else launch_dma<128, 128, 64, 32>(ctx, b);
         K2_HIP(hipGetLastError());
         if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 16;
