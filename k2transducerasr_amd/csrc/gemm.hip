@@ -457,12 +457,12 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_skinny(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float red[4][NT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int m0 = blockIdx.x * 16;
+    const int m0 = blockIdx.x * 16, n0 = blockIdx.y * (16 * NT);  // grid.y walks N in chunks of 16*NT columns
     const int Kw = g.K >> 2, kbeg = wave * Kw;
     const float* __restrict__ ap = g.A + (long long)min(m0 + r, g.M - 1) * g.lda + kbeg + 4 * q;
     const float* __restrict__ wp[NT];
 #pragma unroll
-    for (int j = 0; j < NT; j++) wp[j] = g.W + (long long)min(16 * j + r, g.N - 1) * g.ldw + kbeg + 4 * q;
+    for (int j = 0; j < NT; j++) wp[j] = g.W + (long long)min(n0 + 16 * j + r, g.N - 1) * g.ldw + kbeg + 4 * q;
     f32x4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_skinny(GemmArgs g) {
     __syncthreads();
     // wave w finishes the column tiles j = w, w + 4, ...: C/D layout col = lane & 15, row = 4 * (lane >> 4) + reg
     for (int j = wave; j < NT; j += 4) {
-        const int col = 16 * j + r;
+        const int col = n0 + 16 * j + r;
         if (col >= g.N) continue;
         const float bv = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
@@ -598,12 +598,16 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     b.ablate = g_ablate;
     if (ctx.instrument && ctx.gemm_log)
         ctx.gemm_log->push_back({a.M, a.N, a.K, a.nb0 * a.nb1, a.act, a.res != nullptr, a.cv_Fout > 0 ? 1 : (a.w_kn ? 2 : 0), 0.f});
-    const bool skinny_ok = g_forced_cfg < 0 && a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.N <= 96 && a.K % 64 == 0 &&
-                           a.K >= 64 && a.M >= 512 && !getenv("K2HIP_GEMM_NO_SKINNY");
+    // (a) N <= 96: few columns; (b) small problems (streaming chunks, beam search: a 128x64 grid would leave most CUs idle and
+    // every workgroup would walk K serially): the same kernel over column chunks of 96
+    static const bool no_skinny = getenv("K2HIP_GEMM_NO_SKINNY") != nullptr;
+    const bool plain = a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.K % 64 == 0 && a.K >= 64;
+    // (16-row workgroups re-read the weight chunk M/16 times: with many rows and a short K the 64x64 tiles are better)
+    const bool few_tiles = (long long)cdiv(a.M, 128) * cdiv(a.N, 64) < 144 && a.M <= 4096 && !(a.M >= 2048 && a.K <= 256 && a.N > 272);
+    const bool skinny_ok = g_forced_cfg < 0 && !no_skinny && plain && ((a.N <= 96 && a.M >= 512) || few_tiles);
     if (skinny_ok) {
-        dim3 grid(cdiv(a.M, 16));
-        if (a.N <= 48) hipLaunchKernelGGL(gemm_f32_mfma_skinny<3>, grid, dim3(256), 0, ctx.stream, b);
-        else hipLaunchKernelGGL(gemm_f32_mfma_skinny<6>, grid, dim3(256), 0, ctx.stream, b);
+        if (a.N <= 48) hipLaunchKernelGGL(gemm_f32_mfma_skinny<3>, dim3(cdiv(a.M, 16), 1), dim3(256), 0, ctx.stream, b);
+        else hipLaunchKernelGGL(gemm_f32_mfma_skinny<6>, dim3(cdiv(a.M, 16), cdiv(a.N, 96)), dim3(256), 0, ctx.stream, b);
         K2_HIP(hipGetLastError());
         if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 32;
         if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
