@@ -64,6 +64,31 @@ __global__ __launch_bounds__(256) void k_conformer_softmax_shift(float* __restri
     }
 }
 
+// any T: the same row operation with three sweeps over global memory instead of a register-resident row
+__global__ __launch_bounds__(256) void k_conformer_softmax_shift_long(float* __restrict__ ac, const float* __restrict__ bd, long long rows,
+                                                                      int T, int Tp, int NPp) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(row % T);
+    float* a = ac + row * Tp;
+    const float* b = bd + row * NPp + (T - 1 - i);
+    float mx = -INFINITY;
+    for (int j = lane; j < T; j += 64) mx = fmaxf(mx, a[j] + b[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int j = lane; j < T; j += 64) {
+        const float e = __expf(a[j] + b[j] - mx);
+        a[j] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < Tp; j += 64) a[j] = j < T ? a[j] * inv : 0.f;
+}
+
 }  // namespace
 
 void conformer_qprep(const Ctx& ctx, const float* qkv, const float* bias_u, const float* bias_v, float* qu, float* qv, int M,
@@ -76,10 +101,14 @@ void conformer_qprep(const Ctx& ctx, const float* qkv, const float* bias_u, cons
 }
 
 void conformer_softmax_shift(const Ctx& ctx, float* ac, const float* bd, int Z, int T, int Tp, int NPp) {
-    K2_REQUIRE(T <= 64 * SM_PER_LANE, "conformer attention: %d frames per call exceed %d", T, 64 * SM_PER_LANE);
-    ctx.add_flops(0.0, 0.0, 0);
     if (ctx.dry) return;
     long long rows = (long long)Z * T;
+    static const bool force_long = getenv("K2HIP_ATTN_LONG") != nullptr;
+    if (T > 64 * SM_PER_LANE || force_long) {
+        hipLaunchKernelGGL(k_conformer_softmax_shift_long, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx.stream, ac, bd, rows, T, Tp, NPp);
+        K2_HIP(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL(k_conformer_softmax_shift, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx.stream, ac, bd, rows, T, Tp, NPp);
     K2_HIP(hipGetLastError());
 }

@@ -97,3 +97,19 @@ def test_full_size_batch_properties(hip_large):
         assert len(tok) == len(ts) and all(0 <= t < 253 for t in ts) and ts == sorted(ts)
         assert len(set(ts)) == len(ts)  # at most one symbol per frame (Q5)
         assert all(t not in (0, 2) and 0 < t < 500 for t in tok)
+
+
+def test_long_utterances_beyond_the_lds_strip(hip_tiny, oracle_tiny, hip_conformer, oracle_conformer):
+    """Attention for sequences longer than the in-LDS score strip (Zipformer2: > 1275 frames at 50 Hz, i.e. > 25 s; Conformer:
+    > 2048 frames at 25 Hz) takes the two-pass kernels; same numbers, no length limit."""
+    from k2transducerasr_amd.synth import synth_utterance
+    u = synth_utterance(77, 31.0)                      # T = 3117 -> T50 = 1555
+    f = oracle_tiny.fbank(u)
+    x = oracle_tiny.pad_sequence([f]).reshape(1, -1, 80)
+    assert (x.shape[1] - 7) // 2 > 1275
+    np.testing.assert_allclose(hip_tiny.encoder_proj(x), oracle_tiny.encoder(x), atol=5e-4, rtol=0)
+    u2 = synth_utterance(78, 84.0)                     # T' = 2104 > 2048
+    f2 = oracle_conformer.fbank(u2)
+    x2 = oracle_conformer.pad_sequence([f2]).reshape(1, -1, 80)
+    assert oracle_conformer.encoder_out_frames(x2.shape[1]) > 2048
+    np.testing.assert_allclose(hip_conformer.encoder_proj(x2), oracle_conformer.encoder(x2), atol=5e-4, rtol=0)

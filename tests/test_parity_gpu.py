@@ -69,7 +69,8 @@ def test_encoder_batch_of_one_equals_batch_rows(hip_tiny, oracle_tiny, utts):
     x = oracle_tiny.pad_sequence(f).reshape(2, -1, 80)
     both = hip_tiny.encoder_proj(x)
     one = hip_tiny.encoder_proj(x[1:2])
-    np.testing.assert_allclose(both[1], one[0], atol=1e-6, rtol=0)
+    # not bit-identical: a different row count may select a different GEMM tiling, i.e. another f32 summation order
+    np.testing.assert_allclose(both[1], one[0], atol=1e-5, rtol=0)
 
 
 def test_decoder_proj(hip_tiny, oracle_tiny):
