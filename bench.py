@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one synchronous call per step (no batch overlap)")
     ap.add_argument("--cpu-utts", type=int, default=32)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal of the N > 1 path on one GPU)")
     ap.add_argument("--beam", type=int, default=0, help="0 = greedy_search (headline metric); K = modified_beam_search with beam K (BASELINE configs[2])")
     args = ap.parse_args()
 
@@ -115,8 +116,11 @@ def main():
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     def barrier():
         if dist is not None:
@@ -128,7 +132,9 @@ def main():
     weights = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"k2hip_bench_{args.preset}.k2w")
     ensure_weights(weights, args.preset, rank, barrier)
 
-    model = pkg.Model(weights, local_rank)  # no fallback: raises without a GPU / library
+    n_dev = pkg.load_library().k2hip_device_count()
+    device = local_rank if args.dist_backend == "nccl" else local_rank % max(n_dev, 1)  # gloo rehearsal: ranks may share a GPU
+    model = pkg.Model(weights, device)  # no fallback: raises without a GPU / library
     if args.beam > 0:
         model.set_decoding_method("modified_beam_search", args.beam)
     B, secs = args.batch, args.seconds
@@ -167,7 +173,7 @@ def main():
     elapsed = time.perf_counter() - t0
     from k2transducerasr_amd.shard import max_over_ranks
 
-    elapsed = max_over_ranks(dist, elapsed, device="cuda" if dist is not None else None)
+    elapsed = max_over_ranks(dist, elapsed, device="cuda" if (dist is not None and args.dist_backend == "nccl") else None)
     res_sync = step()  # one synchronous pass: per-stage HIP-event timings + pipelined == synchronous check
     stages = model.timing()
     assert res_sync == res, "pipelined and synchronous results differ"

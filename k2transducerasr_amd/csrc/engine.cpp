@@ -900,6 +900,7 @@ void Engine::synchronize() {
     K2_HIP(hipStreamSynchronize(stream_));
     K2_HIP(hipStreamSynchronize(stream2_));
     for (auto& sl : slots_) K2_HIP(hipStreamSynchronize(sl.stream));
+    K2_HIP(hipDeviceSynchronize());  // the bench brackets its timed region with this (device-wide, like torch.cuda.synchronize())
 }
 
 }  // namespace k2hip

@@ -564,7 +564,7 @@ int choose_cfg(const GemmArgs& a) {
     // few output tiles (streaming chunks: 256..2048 rows): the launch is one latency-bound K sweep per
     // workgroup; small tiles with a 64-deep K step are fastest (gpurun_out/gemm_tune_s1.txt)
     if ((long long)cdiv(a.M, 128) * cdiv(a.N, 64) * a.nb0 * a.nb1 < 144) return 3;  // fewer 128x64 tiles than ~half the CUs
-    if (a.N <= 128) return 3;   // 64x64 tiles, K step 64
+    if (a.N <= 128 && a.M < 32768) return 3;   // 64x64 tiles, K step 64 (the ConvNeXt 1x1s have enough rows for 128x64)
     return 5;                   // 128x64 tiles, 8 waves (LDS-DMA pipeline when K % 32 == 0)
 }
 
