@@ -243,12 +243,8 @@ void attn_scores_softmax(const Ctx& ctx, const float* qkp, int ld, const float* 
         K2_HIP(hipGetLastError());
         return;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_scores_softmax),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsAttrOnce lds_attr;
+    lds_attr.ensure(k_attn_scores_softmax, 160 * 1024);
     dim3 grid(cdiv(T, R), B, H);
     hipLaunchKernelGGL(k_attn_scores_softmax, grid, dim3(256), lds, ctx.stream, qkp, ld, pp, aw, B, T, Tp, H, lds_stride);
     K2_HIP(hipGetLastError());

@@ -43,6 +43,20 @@ struct Error : std::runtime_error {
         if (!(cond)) ::k2hip::failf(K2HIP_ERR_INVALID, __VA_ARGS__); \
     } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: a host that opens one model per GPU in ONE process (the C ABI
+// allows it) needs it on every device, so the "done" flag is kept per (call site, device).
+struct LdsAttrOnce {
+    bool done[64] = {false};
+    template <typename F>
+    void ensure(F* func, int bytes) {
+        int dev = 0;
+        K2_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || done[dev]) return;
+        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(func), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        done[dev] = true;
+    }
+};
+
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

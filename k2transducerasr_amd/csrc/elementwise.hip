@@ -460,11 +460,8 @@ static void glu_dwconv1d_any(const Ctx& ctx, const float* x2, const float* w_kd,
     dim3 grid(cdiv(D, 256), cdiv(T, DW_ROWS), B);
     ctx.add_flops(0.0, 2.0 * B * T * (double)D * K, 0);
     if (ctx.dry) return;
-    static bool attr_set = false;
-    if (!attr_set) {
-        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_glu_dwconv1d<DSWISH>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
-    }
+    static LdsAttrOnce lds_attr;
+    lds_attr.ensure(k_glu_dwconv1d<DSWISH>, 128 * 1024);
     hipLaunchKernelGGL(k_glu_dwconv1d<DSWISH>, grid, dim3(256), lds, ctx.stream, x2, w_kd, b, y, B, T, D, K);
     K2_HIP(hipGetLastError());
 }

@@ -514,12 +514,8 @@ template <int BM, int BN, int WM, int WN, int NST = 3>
 void launch_dma(const Ctx& ctx, const GemmArgs& a) {
     dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), 1);
     size_t lds = sizeof(float) * NST * (BM + BN) * 32;
-    static bool attr_set = false;
-    if (!attr_set) {
-        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_dma<BM, BN, WM, WN, NST>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsAttrOnce lds_attr;
+    lds_attr.ensure(gemm_f32_mfma_dma<BM, BN, WM, WN, NST>, (int)lds);
     hipLaunchKernelGGL((gemm_f32_mfma_dma<BM, BN, WM, WN, NST>), grid, dim3(64 * (BM / WM) * (BN / WN)), lds, ctx.stream, a);
 }
 
@@ -528,12 +524,8 @@ void launch_cfg(const Ctx& ctx, const GemmArgs& a) {
     constexpr int LDSK = BK + 4;
     dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.nb0 * a.nb1);
     size_t lds = sizeof(float) * 2 * (BM + BN) * LDSK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma<BM, BN, WM, WN, BK, MODE>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsAttrOnce lds_attr;
+    lds_attr.ensure(gemm_f32_mfma<BM, BN, WM, WN, BK, MODE>, (int)lds);
     hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, BK, MODE>), grid, dim3(64 * (BM / WM) * (BN / WN)), lds, ctx.stream, a);
 }
 

@@ -561,11 +561,8 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     size_t lds = sizeof(float) * ((size_t)w.J * GF + 8 * APAD + 3 * (size_t)w.J + 3 * (size_t)w.DD + 32 * GF + GF + 8 +
                                  2 * kMaxParts * GF + 4);
     K2_REQUIRE(lds <= 150 * 1024, "greedy: vocab %d / joiner %d need %zu B of LDS", w.V, w.J, lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
+    static LdsAttrOnce lds_attr;
+    lds_attr.ensure(k_greedy, 150 * 1024);
     if (parts > 1) K2_HIP(hipMemsetAsync(a.gran, 0, sizeof(unsigned long long) * gran_words, ctx.stream));
     hipLaunchKernelGGL(k_greedy, dim3(a.B * parts), dim3(GT), lds, ctx.stream, w, a);
     K2_HIP(hipGetLastError());

@@ -262,3 +262,37 @@ def test_hip_matches_committed_golden(hip_tiny):
     np.testing.assert_allclose(hip_tiny.joiner_proj(g["encoder_out"][0, :6], g["decoder_out"][:6]), g["logits"], atol=1e-4, rtol=0)
     want = [(g[f"tok{b}"].tolist(), g[f"ts{b}"].tolist()) for b in range(g["x"].shape[0])]
     assert hip_tiny.greedy_batch(g["encoder_out"]) == want
+
+
+def test_two_handles_from_two_threads(tiny_model_path, oracle_tiny, utts):
+    """INTEGRATION.md threading contract: different model handles may be driven concurrently from different host threads
+    (a C# host opens one per GPU); each handle serialises its own calls."""
+    import threading
+    from k2transducerasr_amd import Model
+    feats = [oracle_tiny.fbank(u) for u in utts]
+    want = oracle_tiny.recognize_batch(feats)
+    models = [Model(tiny_model_path, 0) for _ in range(2)]
+    out = [None, None]
+
+    def work(i):
+        for _ in range(5):
+            out[i] = models[i].offline_greedy(feats)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert out[0] == want and out[1] == want
+    # one handle from two threads is serialised by its mutex
+    res = [None, None]
+
+    def work2(i):
+        res[i] = models[0].offline_greedy_from_samples(utts)
+
+    ts = [threading.Thread(target=work2, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert res[0] == res[1] == want
