@@ -149,6 +149,53 @@ def make_conformer_meta(
     return meta
 
 
+def make_lstm_meta(
+    *,
+    d_model=512,
+    rnn_hidden_size=1024,
+    dim_feedforward=2048,
+    num_encoder_layers=12,
+    joiner_dim=512,
+    decoder_dim=512,
+    vocab_size=500,
+    context_size=2,
+    comment="",
+):
+    """LSTM transducer (Model_type "lstm": offline through OfflineProjOfTransducer, OfflineRecognizer.cs:38-53; streaming
+    through OnlineProjOfLstm, whose states are h [layers, B, d_model] and c [layers, B, rnn_hidden_size],
+    OnlineProjOfLstm.cs:55-75).  The graph is icefall's lstm_transducer_stateless2: Conv2dSubsampling (no padding in time, two
+    stride-2 convs) + layers of {LSTM with projection, feed-forward with DoubleSwish, BasicNorm}.  The streaming export consumes
+    T = 9 frames and advances by decode_chunk_len = 4 (one encoder frame per chunk); the same file serves both paths."""
+    meta = dict(FBANK_DEFAULTS)
+    meta.update(
+        {
+            "model_type": "lstm",
+            "version": "1",
+            "model_author": "k2hip-synthetic",
+            "comment": comment,
+            "num_encoder_layers": _csv([num_encoder_layers]),
+            "encoder_dims": _csv([d_model]),
+            "feedforward_dims": _csv([dim_feedforward]),
+            "d_model": str(d_model),
+            "rnn_hidden_size": str(rnn_hidden_size),
+            "decode_chunk_len": "4",
+            "T": "9",
+            "joiner_dim": str(joiner_dim),
+            "decoder_dim": str(decoder_dim),
+            "vocab_size": str(vocab_size),
+            "context_size": str(context_size),
+        }
+    )
+    return meta
+
+
+LSTM_PRESETS = {
+    "lstm-en": dict(),
+    "lstm-tiny-test": dict(d_model=64, rnn_hidden_size=96, dim_feedforward=160, num_encoder_layers=3, joiner_dim=512, decoder_dim=64,
+                           vocab_size=41),
+}
+
+
 CONFORMER_PRESETS = {
     # BASELINE.json configs[4]: conformer-zh (wenetspeech char model), 12 x (512, 2048, 8 heads, k=31)
     "conformer-zh": dict(vocab_size=5537),
@@ -256,6 +303,8 @@ PRESETS = {
 def preset(name: str) -> dict:
     if name in CONFORMER_PRESETS:
         return make_conformer_meta(comment=name, **copy.deepcopy(CONFORMER_PRESETS[name]))
+    if name in LSTM_PRESETS:
+        return make_lstm_meta(comment=name, **copy.deepcopy(LSTM_PRESETS[name]))
     if name not in PRESETS:
         raise KeyError(f"unknown model preset {name!r}; have {sorted(PRESETS) + sorted(CONFORMER_PRESETS)}")
     return make_zipformer2_meta(comment=name, **copy.deepcopy(PRESETS[name]))

@@ -26,6 +26,8 @@ BLANK_BIAS = {
     "zipformer2-streaming-zh": 3.0,
     "zipformer2-streaming-tiny-test": 1.0,
     "conformer-zh": 2.615,
+    "lstm-en": 3.0,
+    "lstm-tiny-test": 2.0,
     "zipformer2-ctc-tiny-test": 1.5,
     "zipformer2-ctc-streaming-tiny-test": 1.5,
     "conformer-tiny-test": 2.179,
@@ -190,8 +192,59 @@ def conformer_tensor_specs(meta: Dict[str, str]) -> List[Tuple[str, tuple, str]]
     return s
 
 
+def lstm_tensor_specs(meta: Dict[str, str]) -> List[Tuple[str, tuple, str]]:
+    """icefall lstm_transducer_stateless2 state dict (Scaled* folded); torch.nn.LSTM parameter names and gate order i,f,g,o."""
+    D = int(meta["d_model"])
+    Hh = int(meta["rnn_hidden_size"])
+    F = ints(meta, "feedforward_dims")[0]
+    L = ints(meta, "num_encoder_layers")[0]
+    J = int(meta["joiner_dim"])
+    DD = int(meta["decoder_dim"])
+    V = int(meta["vocab_size"])
+    ctx = int(meta["context_size"])
+    fdim = int(meta["feature_dim"])
+    out_width = (((fdim - 1) // 2) - 1) // 2
+    s: List[Tuple[str, tuple, str]] = []
+
+    def lin(prefix, out_f, in_f, bias=True):
+        s.append((prefix + ".weight", (out_f, in_f), "w"))
+        if bias:
+            s.append((prefix + ".bias", (out_f,), "b"))
+
+    e = "encoder.encoder_embed."
+    s += [
+        (e + "conv.0.weight", (8, 1, 3, 3), "w"), (e + "conv.0.bias", (8,), "b"),
+        (e + "conv.3.weight", (32, 8, 3, 3), "w"), (e + "conv.3.bias", (32,), "b"),
+        (e + "conv.6.weight", (128, 32, 3, 3), "w"), (e + "conv.6.bias", (128,), "b"),
+    ]
+    lin(e + "out", D, 128 * out_width)
+    s.append((e + "out_norm.eps", (1,), "logeps"))
+    for j in range(L):
+        p = f"encoder.encoder.layers.{j}."
+        s += [
+            (p + "lstm.weight_ih_l0", (4 * Hh, D), "w"),
+            (p + "lstm.weight_hh_l0", (4 * Hh, D), "w"),
+            (p + "lstm.bias_ih_l0", (4 * Hh,), "b"),
+            (p + "lstm.bias_hh_l0", (4 * Hh,), "b"),
+            (p + "lstm.weight_hr_l0", (D, Hh), "w"),
+        ]
+        lin(p + "feed_forward.0", F, D)
+        lin(p + "feed_forward.4", D, F)
+        s.append((p + "norm_final.eps", (1,), "logeps"))
+    lin("joiner.encoder_proj", J, D)
+    lin("joiner.decoder_proj", J, DD)
+    lin("joiner.output_linear", V, J)
+    s.append(("decoder.embedding.weight", (V, DD), "emb"))
+    s.append(("decoder.conv.weight", (DD, DD, ctx), "w"))
+    return s
+
+
 def tensor_specs(meta: Dict[str, str]) -> List[Tuple[str, tuple, str]]:
-    return conformer_tensor_specs(meta) if meta["model_type"] == "conformer" else zipformer2_tensor_specs(meta)
+    if meta["model_type"] == "conformer":
+        return conformer_tensor_specs(meta)
+    if meta["model_type"] == "lstm":
+        return lstm_tensor_specs(meta)
+    return zipformer2_tensor_specs(meta)
 
 
 def _init(name: str, shape: tuple, kind: str, seed: int) -> np.ndarray:
@@ -233,7 +286,7 @@ def write_synthetic_model(path: str, preset_name: str, seed: int = 20231212, bla
     meta["synthetic_seed"] = str(seed)
     meta["synthetic_blank_bias"] = repr(float(blank_bias))
 
-    conformer = meta["model_type"] == "conformer"
+    conformer = meta["model_type"] in ("conformer", "lstm")  # stateless2-style residual branches
 
     def gen():
         for name, shape, kind in tensor_specs(meta):

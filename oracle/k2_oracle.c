@@ -61,6 +61,8 @@ struct k2o_model {
     int pos_dim, J, DD, V, ctx, feat;
     int dmax;
     int conformer; /* model_type "conformer": see k2_oracle_conformer.c */
+    int lstm;      /* model_type "lstm": see k2_oracle_lstm.c */
+    int rnn_hidden;
     int ctc;       /* model_type "zipformer2ctc": Zipformer2 encoder + CTC head, no decoder / joiner */
     int conv_cpg;  /* decoder conv input channels per group (4: Zipformer recipes; DD: stateless2, groups = 1) */
     /* fbank */
@@ -224,7 +226,9 @@ k2o_model* k2o_model_load(const char* path) {
     const char* mt = k2o_meta(m, "model_type");
     m->conformer = mt && !strcmp(mt, "conformer");
     m->ctc = mt && !strcmp(mt, "zipformer2ctc");
-    if (!mt || (strcmp(mt, "zipformer2") && !m->conformer && !m->ctc)) {
+    m->lstm = mt && !strcmp(mt, "lstm");
+    m->rnn_hidden = meta_int(m, "rnn_hidden_size", 0);
+    if (!mt || (strcmp(mt, "zipformer2") && !m->conformer && !m->ctc && !m->lstm)) {
         fail("model_type %s not supported by the oracle", mt ? mt : "(none)");
         k2o_model_free(m);
         return NULL;
@@ -847,9 +851,11 @@ static float* convert_channels(const float* x, int M, int Din, int Dout) {
 }
 
 #include "k2_oracle_conformer.c"
+#include "k2_oracle_lstm.c"
 
 int k2o_encoder_out_frames(const k2o_model* m, int T) {
     if (m->conformer) return conformer_out_frames(T);
+    if (m->lstm) return lstm_out_frames(T);
     int T50 = embed_out_frames(T);
     if (T50 <= 0) return 0;
     return (T50 + 1) / 2;
@@ -971,11 +977,14 @@ static int encoder_forward(const k2o_model* m, const float* xin, int B, int T, f
 int k2o_offline_encoder(const k2o_model* m, const float* x, int B, int T, float* enc_out) {
     int64_t n;
     if (m->conformer) return conformer_forward(m, x, B, T, enc_out, -1, NULL, 0, &n);
+    if (m->lstm) return lstm_forward(m, x, B, T, enc_out, -1, NULL, 0, &n);
     return encoder_forward(m, x, B, T, enc_out, -1, NULL, 0, &n);
 }
 int64_t k2o_offline_encoder_tap(const k2o_model* m, const float* x, int B, int T, int tap, float* out, int64_t cap) {
     int64_t n = 0;
-    int rc = m->conformer ? conformer_forward(m, x, B, T, NULL, tap, out, cap, &n) : encoder_forward(m, x, B, T, NULL, tap, out, cap, &n);
+    int rc = m->conformer ? conformer_forward(m, x, B, T, NULL, tap, out, cap, &n)
+             : m->lstm    ? lstm_forward(m, x, B, T, NULL, tap, out, cap, &n)
+                          : encoder_forward(m, x, B, T, NULL, tap, out, cap, &n);
     return rc < 0 ? rc : n;
 }
 

@@ -118,6 +118,8 @@ int k2o_online_stream_num_timestamps(const k2o_online_stream* s);
 void k2o_online_stream_get_tokens(const k2o_online_stream* s, int64_t* out);
 void k2o_online_stream_get_timestamps(const k2o_online_stream* s, int32_t* out);
 void k2o_online_stream_get_hyp(const k2o_online_stream* s, int64_t* out);
+/* lstm streams (OnlineProjOfLstm.cs:55-75): kind 0 = h of `layer` [d_model], 1 = c of `layer` [rnn_hidden_size] */
+int64_t k2o_online_stream_lstm_state(const k2o_model* m, const k2o_online_stream* s, int layer, int kind, float* out, int64_t cap);
 /* one encoder chunk for one stream: x [T,80] (log-floored) -> enc_out [T'c, J]; returns T'c */
 int k2o_online_encoder_chunk(const k2o_model* m, k2o_online_stream* s, const float* x, float* enc_out);
 /* OnlineRecognizer.ForwardBatchGreedySearch (:85-219) over B streams with one full chunk each */

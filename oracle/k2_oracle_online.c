@@ -25,6 +25,7 @@ struct k2o_online_stream {
     size_t *nkey, *nnonlin, *nval, *nconv;
     float* embed;     /* [128][3][19] */
     int64_t processed_len;
+    float *lstm_h, *lstm_c; /* model_type lstm: h [layers][d_model], c [layers][rnn_hidden] (OnlineProjOfLstm.cs:55-75) */
     int64_t hyp[2];
     int64_t* tokens;  /* Tokens list, starts [blank, blank] (OnlineStream.cs:45) */
     int n_tokens, cap_tokens;
@@ -39,15 +40,30 @@ static int online_left(const k2o_model* m, int si) {
 }
 int k2o_online_chunk_length(const k2o_model* m) { return meta_int(m, "T", 45); }
 int k2o_online_shift_length(const k2o_model* m) { return meta_int(m, "decode_chunk_len", 32); }
-int k2o_online_frames_per_chunk(const k2o_model* m) { return (meta_int(m, "decode_chunk_len", 32) / 2 + 1) / 2; }
+int k2o_online_frames_per_chunk(const k2o_model* m) {
+    if (m->lstm) return lstm_out_frames(meta_int(m, "T", 9));
+    return (meta_int(m, "decode_chunk_len", 32) / 2 + 1) / 2;
+}
 
 k2o_online_stream* k2o_online_stream_create(const k2o_model* m) {
     const char* st = k2o_meta(m, "streaming");
-    if (!st || strcmp(st, "1")) {
+    if (!m->lstm && (!st || strcmp(st, "1"))) {
         fail("model is not a streaming export (metadata streaming != 1)");
         return NULL;
     }
     k2o_online_stream* s = (k2o_online_stream*)calloc(1, sizeof *s);
+    if (m->lstm) {  /* GetEncoderInitStates: zero h and c */
+        s->nl = m->nlayer[0];
+        s->lstm_h = calloc((size_t)s->nl * m->dim[0], sizeof(float));
+        s->lstm_c = calloc((size_t)s->nl * m->rnn_hidden, sizeof(float));
+        s->cap_tokens = 64;
+        s->tokens = malloc(sizeof(int64_t) * s->cap_tokens);
+        s->tokens[0] = s->tokens[1] = 0;
+        s->n_tokens = 2;
+        s->cap_ts = 64;
+        s->timestamps = malloc(sizeof(int32_t) * s->cap_ts);
+        return s;
+    }
     for (int i = 0; i < m->ns; i++) s->nl += m->nlayer[i];
     s->key = calloc(s->nl, sizeof(float*)); s->nonlin = calloc(s->nl, sizeof(float*));
     s->val1 = calloc(s->nl, sizeof(float*)); s->val2 = calloc(s->nl, sizeof(float*));
@@ -82,6 +98,11 @@ k2o_online_stream* k2o_online_stream_create(const k2o_model* m) {
 }
 void k2o_online_stream_free(k2o_online_stream* s) {
     if (!s) return;
+    if (s->lstm_h) {
+        free(s->lstm_h); free(s->lstm_c); free(s->tokens); free(s->timestamps);
+        free(s);
+        return;
+    }
     for (int l = 0; l < s->nl; l++) {
         free(s->key[l]); free(s->nonlin[l]); free(s->val1[l]); free(s->val2[l]); free(s->conv1[l]); free(s->conv2[l]);
     }
@@ -96,6 +117,9 @@ int64_t k2o_online_stream_processed_len(const k2o_online_stream* s) { return s->
 int64_t k2o_online_stream_state(const k2o_online_stream* s, int layer, int kind, float* out, int64_t cap) {
     const float* p = NULL;
     size_t n = 0;
+    if (s->lstm_h) {  /* kind 0: h of `layer` [d_model]; kind 1: c of `layer` [rnn_hidden]; sizes from the allocation */
+        return fail("use k2o_online_stream_lstm_state for an lstm stream");
+    }
     switch (kind) {
         case 0: p = s->key[layer]; n = s->nkey[layer]; break;
         case 1: p = s->nonlin[layer]; n = s->nnonlin[layer]; break;
@@ -389,7 +413,9 @@ static void online_layer(const k2o_model* m, k2o_online_stream* s, int si, int l
 }
 
 /* OnnxEncoder.forward of the streaming export for ONE stream: x [T,80] (already log-floored) -> enc_out [T'c, J] */
+static int lstm_online_chunk(const k2o_model* m, k2o_online_stream* s, const float* x, float* enc_out);
 int k2o_online_encoder_chunk(const k2o_model* m, k2o_online_stream* s, const float* x, float* enc_out) {
+    if (m->lstm) return lstm_online_chunk(m, s, x, enc_out);
     int T = k2o_online_chunk_length(m);
     int Tc;
     float* cur = online_embed(m, x, T, s->embed, &Tc);
@@ -458,6 +484,27 @@ int k2o_online_encoder_chunk(const k2o_model* m, k2o_online_stream* s, const flo
     free(dsd);
     s->processed_len += Tc; /* new_processed_lens = processed_lens + x_lens, x_lens = (T-7)//2 - 3 */
     return Tp;
+}
+
+/* lstm: one chunk x [T = 9, 80] -> enc_out [1, J]; h / c of every layer advance by one frame */
+static int lstm_online_chunk(const k2o_model* m, k2o_online_stream* s, const float* x, float* enc_out) {
+    int Tp;
+    float* e = lstm_embed(m, x, 1, k2o_online_chunk_length(m), &Tp);
+    if (!e) return fail("lstm chunk too short");
+    const int D = m->dim[0];
+    for (int li = 0; li < m->nlayer[0]; li++) lstm_layer(m, li, e, 1, Tp, s->lstm_h + (size_t)li * D, s->lstm_c + (size_t)li * m->rnn_hidden);
+    linear(enc_out, m->J, e, D, WT(m, m->J, D, "joiner.encoder_proj.weight"), W(m, "joiner.encoder_proj.bias"), Tp, D, m->J);
+    free(e);
+    return Tp;
+}
+int64_t k2o_online_stream_lstm_state(const k2o_model* m, const k2o_online_stream* s, int layer, int kind, float* out, int64_t cap) {
+    if (!s->lstm_h) return fail("not an lstm stream");
+    size_t n = kind == 0 ? (size_t)m->dim[0] : (size_t)m->rnn_hidden;
+    const float* p = kind == 0 ? s->lstm_h + (size_t)layer * n : s->lstm_c + (size_t)layer * n;
+    if (!out) return (int64_t)n;
+    if ((int64_t)n > cap) return fail("state buffer too small");
+    memcpy(out, p, sizeof(float) * n);
+    return (int64_t)n;
 }
 
 static void stream_push_token(k2o_online_stream* s, int64_t y, int32_t t) {

@@ -60,6 +60,16 @@ class OnlineOracleStream:
         self._L.k2o_online_stream_state(self._s, layer, _KINDS[kind], _fp(out), n)
         return out
 
+    def lstm_state(self, layer: int, kind: str) -> np.ndarray:
+        """kind 'h' ([d_model]) or 'c' ([rnn_hidden_size]) of one layer (OnlineProjOfLstm.cs:55-75)"""
+        k = {"h": 0, "c": 1}[kind]
+        self._L.k2o_online_stream_lstm_state.restype = C.c_int64
+        self._L.k2o_online_stream_lstm_state.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int64]
+        n = self._L.k2o_online_stream_lstm_state(self._o._m, self._s, layer, k, None, 0)
+        out = np.empty(n, np.float32)
+        self._L.k2o_online_stream_lstm_state(self._o._m, self._s, layer, k, _fp(out), n)
+        return out
+
     @property
     def processed_len(self) -> int:
         return self._L.k2o_online_stream_processed_len(self._s)
