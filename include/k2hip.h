@@ -295,7 +295,8 @@ int32_t k2hip_online_stream_get_timestamps(const k2hip_online_stream_t* s, int32
 int32_t k2hip_online_stream_get_hyp(const k2hip_online_stream_t* s, int64_t* hyp2);
 /* copy one cache out of the stream's device slot (parity tests / debugging):
  * kind 0 cached_key [left,32H], 1 cached_nonlin_attn [left,3D/4], 2/3 cached_val1/2 [left,12H],
- * 4/5 cached_conv1/2 [D,K/2], 6 embed_states [128,3,19] (layer ignored); out == NULL queries n */
+ * 4/5 cached_conv1/2 [D,K/2], 6 embed_states [128,3,19] (layer ignored); out == NULL queries n.
+ * For an "lstm" model (OnlineProjOfLstm.cs:55-75): kind 0 = h of `layer` [d_model], kind 1 = c of `layer` [rnn_hidden_size] */
 int32_t k2hip_online_stream_state(k2hip_online_stream_t* s, int32_t layer, int32_t kind, float* out, int64_t cap, int64_t* n);
 
 #if defined(__GNUC__)

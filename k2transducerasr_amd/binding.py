@@ -511,7 +511,7 @@ class OfflineRecognizer:
 
 
 # ============================== streaming: OnlineStream / OnlineRecognizer ===============================
-_STATE_KINDS = {"key": 0, "nonlin": 1, "val1": 2, "val2": 3, "conv1": 4, "conv2": 5, "embed": 6}
+_STATE_KINDS = {"key": 0, "nonlin": 1, "val1": 2, "val2": 3, "conv1": 4, "conv2": 5, "embed": 6, "lstm_h": 0, "lstm_c": 1}
 
 
 def _bind_online(L):

@@ -441,7 +441,7 @@ int32_t k2hip_online_chunk_info(const k2hip_model_t* model, int32_t* chunk_lengt
     return guard([&] {
         NEED(model);
         const Config& c = model->engine.model().cfg();
-        K2_REQUIRE(c.streaming, "this model is not a streaming export");
+        K2_REQUIRE(c.streaming || c.lstm, "this model is not a streaming export");
         if (chunk_length) *chunk_length = c.chunk_T;
         if (shift_length) *shift_length = c.shift;
         if (frames_per_chunk) *frames_per_chunk = model->engine.online_frames_per_chunk();
@@ -545,7 +545,7 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
         NEED(model); NEED(streams); NEED(decoded); NEED(n_new_tokens);
         Engine& e = model->engine;
         const Config& c = e.model().cfg();
-        K2_REQUIRE(c.streaming, "this model is not a streaming export");
+        K2_REQUIRE(c.streaming || c.lstm, "this model is not a streaming export");
         const size_t chunk_floats = (size_t)c.chunk_T * c.feat, shift_floats = (size_t)c.shift * c.feat;
         std::vector<int> idx;
         for (int i = 0; i < B; i++) {

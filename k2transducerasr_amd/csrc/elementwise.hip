@@ -405,6 +405,10 @@ void conv0_swoosh(const Ctx& ctx, const float* x, const float* w, const float* b
     long long n = (long long)B * (T - 2) * F;
     LAUNCH((k_conv0<0, false>), dim3(nblocks(n, 256)), dim3(256), x, w, b, y, B, T, F);
 }
+void conv0_nopad_dswish(const Ctx& ctx, const float* x, const float* w, const float* b, float* y, int B, int T, int F) {
+    long long n = (long long)B * (T - 2) * F;
+    LAUNCH((k_conv0<0, true>), dim3(nblocks(n, 256)), dim3(256), x, w, b, y, B, T, F);
+}
 void conv0_pad1_dswish(const Ctx& ctx, const float* x, const float* w, const float* b, float* y, int B, int T, int F) {
     long long n = (long long)B * T * F;
     LAUNCH((k_conv0<1, true>), dim3(nblocks(n, 256)), dim3(256), x, w, b, y, B, T, F);

@@ -76,6 +76,7 @@ Ctx Engine::make_ctx(bool dry) {
 
 int Engine::encoder_out_frames(int T) const {
     if (model_->cfg().conformer) return conformer_out_frames(T);
+    if (model_->cfg().lstm) return lstm_out_frames(T);
     int T50 = (T - 7) / 2;
     return T50 <= 0 ? 0 : (T50 + 1) / 2;
 }
@@ -339,6 +340,7 @@ float* Engine::encoder_forward(const Ctx& c, const float* x, int B, int T, int* 
     const Model& m = *model_;
     const Config& cf = m.cfg();
     if (cf.conformer) return conformer_forward(c, x, B, T, Tp, tap, tap_ptr, tap_rows, tap_dim);
+    if (cf.lstm) return lstm_forward(c, x, B, T, Tp, tap, tap_ptr, tap_rows, tap_dim);
     Arena& ar = *c.arena;
     int T50 = 0;
     // output first so that everything after it can be rewound

@@ -106,6 +106,12 @@ class Engine {
                     int* d_overflow);
     void beam_device(const Ctx& c, const float* enc, int B, int Tp, long long* d_tok, int* d_ts, int* d_n, int max_tokens,
                      int* d_overflow);
+    // LSTM transducer (lstm_engine.cpp)
+    int lstm_out_frames(int T) const;
+    float* lstm_embed(const Ctx& c, const float* x, int B, int T, int* T_out);
+    void lstm_layer(const Ctx& c, int li, float* x, const float* h0, int ldh0, float* cst, int B, int T, float* y);
+    float* lstm_forward(const Ctx& c, const float* x, int B, int T, int* Tp, int tap, float** tap_ptr, int* tap_rows, int* tap_dim);
+    float* lstm_chunk(const Ctx& c, const float* x, const int* d_slots, int B);
     // offline Conformer (conformer_engine.cpp)
     int conformer_out_frames(int T) const;
     const float* conformer_pos_emb(int T);

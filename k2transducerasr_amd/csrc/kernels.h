@@ -110,6 +110,14 @@ void glu_dwconv1d_swoosh(const Ctx& ctx, const float* x2, const float* w_kd, con
 // same with DoubleSwish (Conformer ConvolutionModule)
 void glu_dwconv1d_dswish(const Ctx& ctx, const float* x2, const float* w_kd, const float* b, float* y, int B, int T, int D,
                           int K);
+// LSTM transducer (lstm.hip)
+void conv0_nopad_dswish(const Ctx& ctx, const float* x, const float* w, const float* b, float* y, int B, int T, int F);
+// gates i,f,g,o = gx[b] + gh[b] ([4*Hh] each, row strides ldgx / ldgh): c = f*c + i*g; hf = o * tanh(c)
+void lstm_cell(const Ctx& ctx, const float* gx, long long ldgx, const float* gh, int ldgh, float* c, float* hf, int B, int Hh);
+void add_inplace(const Ctx& ctx, float* a, const float* b, long long n);
+// rows of `width` floats between a [B, width] work buffer and the per-stream pool slots (pool + slot*stride + off)
+void gather_rows(const Ctx& ctx, const float* pool, long long slot_stride, long long off, const int* slots, float* out, int B, int width);
+void scatter_rows(const Ctx& ctx, float* pool, long long slot_stride, long long off, const int* slots, const float* in, int ldin, int B, int width);
 // BasicNorm: y = x * (mean(x^2) + exp(log_eps))^-0.5   (in place allowed)
 void basicnorm(const Ctx& ctx, const float* x, const float* log_eps, float* y, int M, int D);
 // Conformer rel-pos attention helpers (conformer.hip)

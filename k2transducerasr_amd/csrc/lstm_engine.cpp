@@ -1,0 +1,144 @@
+// LSTM transducer encoder on the gfx950 kernels: Model_type "lstm", offline through OfflineProjOfTransducer
+// (OfflineRecognizer.cs:38-53) and streaming through OnlineProjOfLstm, whose per-stream states are
+// h [layers, d_model] and c [layers, rnn_hidden_size] (OnlineProjOfLstm.cs:55-75).  The graph is icefall's
+// lstm_transducer_stateless2: Conv2dSubsampling (no padding in time, two stride-2 convs: T' = ((T-3)//2 - 1)//2), then layers
+// of { LSTM with projection; x += y; x += feed_forward(x); BasicNorm }.
+//
+// Per layer the input products of ALL frames are one MFMA GEMM ([B*T', D] x [D, 4H]); the recurrence is, per frame, the
+// recurrent product h_{t-1}.W_hh^T (small-problem GEMM), the cell kernel and the projection hf.W_hr^T, which writes h_t straight
+// into row t of the layer's output so that it is also the next frame's operand -- no copies.  (Launch-bound: three small
+// launches per frame and layer; a persistent wavefront-over-layers kernel is the obvious next step.)
+#include <cmath>
+
+#include "engine.h"
+
+namespace k2hip {
+
+int Engine::lstm_out_frames(int T) const { return T < 9 ? 0 : ((T - 3) / 2 - 1) / 2; }
+
+float* Engine::lstm_embed(const Ctx& c, const float* x, int B, int T, int* T_out) {
+    const Model& m = *model_;
+    const int F0 = 80, T1 = T - 2, T2 = (T1 - 3) / 2 + 1, F2 = (F0 - 3) / 2 + 1, T3 = (T2 - 3) / 2 + 1, F3 = (F2 - 3) / 2 + 1;
+    const int D = m.cfg().dim[0];
+    K2_REQUIRE(T >= 9 && T3 > 0, "encoder: %d input frames are too few (need >= 9)", T);
+    Arena& ar = *c.arena;
+    float* out = ar.take<float>((int64_t)B * T3 * D);
+    int64_t mark = ar.mark();
+    float* a1 = ar.take<float>((int64_t)B * T1 * F0 * 8);
+    conv0_nopad_dswish(c, x, m.w("encoder.encoder_embed.conv.0.weight"), m.w("encoder.encoder_embed.conv.0.bias"), a1, B, T, F0);
+    c.add_flops(0, 2.0 * B * T1 * (double)F0 * 8 * 9, 0);
+    float* a2 = ar.take<float>((int64_t)B * T2 * F2 * 32);
+    {
+        GemmArgs g;
+        g.A = a1; g.W = m.w("encoder.encoder_embed.conv.3.weight#ohwi"); g.ldw = 72; g.bias = m.w("encoder.encoder_embed.conv.3.bias");
+        g.C = a2; g.ldc = 32; g.M = B * T2 * F2; g.N = 32; g.K = 72; g.act = ACT_DOUBLE_SWISH;
+        g.cv_Fout = F2; g.cv_Tout = T2; g.cv_Tin = T1; g.cv_Fin = F0; g.cv_C = 8; g.cv_st = 2; g.cv_sf = 2;
+        g.seg_len = 24; g.seg_stride = F0 * 8;
+        gemm(c, g);
+    }
+    float* a3 = ar.take<float>((int64_t)B * T3 * F3 * 128);
+    {
+        GemmArgs g;
+        g.A = a2; g.W = m.w("encoder.encoder_embed.conv.6.weight#ohwi"); g.ldw = 288; g.bias = m.w("encoder.encoder_embed.conv.6.bias");
+        g.C = a3; g.ldc = 128; g.M = B * T3 * F3; g.N = 128; g.K = 288; g.act = ACT_DOUBLE_SWISH;
+        g.cv_Fout = F3; g.cv_Tout = T3; g.cv_Tin = T2; g.cv_Fin = F2; g.cv_C = 32; g.cv_st = 2; g.cv_sf = 2;
+        g.seg_len = 96; g.seg_stride = F2 * 32;
+        gemm(c, g);
+    }
+    float* lin = ar.take<float>((int64_t)B * T3 * D);
+    linear(c, a3, F3 * 128, m.w("encoder.encoder_embed.out.weight#fc"), m.w("encoder.encoder_embed.out.bias"), lin, D, B * T3, F3 * 128, D);
+    basicnorm(c, lin, m.w("encoder.encoder_embed.out_norm.eps"), out, B * T3, D);
+    ar.rewind(mark);
+    *T_out = T3;
+    return out;
+}
+
+// one RNNEncoderLayer in place on x [B*T, D]; h0 [B, D] (row stride ldh0) is the incoming hidden state, cst [B, Hh] the cell
+// state (updated in place); *h_last receives the pointer / stride of the outgoing hidden state (row T-1 of the layer's y)
+void Engine::lstm_layer(const Ctx& c, int li, float* x, const float* h0, int ldh0, float* cst, int B, int T, float* y) {
+    const Model& m = *model_;
+    const Config& cf = m.cfg();
+    const int D = cf.dim[0], Hh = cf.rnn_hidden, F = cf.ff[0], G = 4 * Hh, M = B * T;
+    char p[96];
+    snprintf(p, sizeof p, "encoder.encoder.layers.%d.", li);
+    auto w = [&](const char* suffix) { return m.w(std::string(p) + suffix); };
+    Arena& ar = *c.arena;
+    int64_t mark = ar.mark();
+    float* gx = ar.take<float>((int64_t)M * G);
+    linear(c, x, D, w("lstm.weight_ih_l0"), w("lstm.bias_ih_l0"), gx, G, M, D, G);
+    float* gh = ar.take<float>((int64_t)B * G);
+    float* hf = ar.take<float>((int64_t)B * Hh);
+    const long long ldy = (long long)T * D;
+    for (int t = 0; t < T; t++) {
+        const float* hprev = t == 0 ? h0 : y + (long long)(t - 1) * D;
+        const int ldh = t == 0 ? ldh0 : (int)ldy;
+        linear(c, hprev, ldh, w("lstm.weight_hh_l0"), w("lstm.bias_hh_l0"), gh, G, B, D, G);
+        lstm_cell(c, gx + (long long)t * G, (long long)T * G, gh, G, cst, hf, B, Hh);
+        linear(c, hf, Hh, w("lstm.weight_hr_l0"), nullptr, y + (long long)t * D, (int)ldy, B, Hh, D);
+    }
+    add_inplace(c, x, y, (long long)M * D);  // src = lstm(src) + src
+    float* hid = ar.take<float>((int64_t)M * F);
+    linear(c, x, D, w("feed_forward.0.weight"), w("feed_forward.0.bias"), hid, F, M, D, F, ACT_DOUBLE_SWISH);
+    linear(c, hid, F, w("feed_forward.4.weight"), w("feed_forward.4.bias"), x, D, M, F, D, ACT_NONE, x, D);
+    basicnorm(c, x, w("norm_final.eps"), x, M, D);
+    ar.rewind(mark);
+}
+
+// offline: zero initial states.  taps: 0 = embed output; 1+i = after layer i
+float* Engine::lstm_forward(const Ctx& c, const float* x, int B, int T, int* Tp, int tap, float** tap_ptr, int* tap_rows, int* tap_dim) {
+    const Model& m = *model_;
+    const Config& cf = m.cfg();
+    Arena& ar = *c.arena;
+    const int Tpp = lstm_out_frames(T);
+    K2_REQUIRE(Tpp > 0, "encoder: %d input frames are too few", T);
+    float* enc_out = ar.take<float>((int64_t)B * Tpp * cf.J);
+    int T3 = 0;
+    float* xe = lstm_embed(c, x, B, T, &T3);
+    if (tap_rows) *tap_rows = B * T3;
+    const int D = cf.dim[0], Hh = cf.rnn_hidden;
+    float* h0 = ar.take<float>((int64_t)B * D);
+    float* cst = ar.take<float>((int64_t)B * Hh);
+    float* y = ar.take<float>((int64_t)B * T3 * D);
+    for (int li = 0; li <= cf.nlayer[0]; li++) {
+        if (tap == li) {
+            *tap_ptr = xe;
+            *tap_dim = D;
+            return nullptr;
+        }
+        if (li == cf.nlayer[0]) break;
+        zero_floats(c, h0, (long long)B * D);
+        zero_floats(c, cst, (long long)B * Hh);
+        lstm_layer(c, li, xe, h0, D, cst, B, T3, y);
+    }
+    linear(c, xe, D, m.w("joiner.encoder_proj.weight"), m.w("joiner.encoder_proj.bias"), enc_out, cf.J, B * T3, D, cf.J);
+    *Tp = T3;
+    return enc_out;
+}
+
+// streaming: one chunk (9 frames -> 1 encoder frame) for B streams whose h / c live in the pool; returns enc [B, 1, J]
+float* Engine::lstm_chunk(const Ctx& c, const float* x, const int* d_slots, int B) {
+    const Model& m = *model_;
+    const Config& cf = m.cfg();
+    Arena& ar = *c.arena;
+    const int D = cf.dim[0], Hh = cf.rnn_hidden, L = cf.nlayer[0];
+    float* enc = ar.take<float>((int64_t)B * cf.J);
+    int T3 = 0;
+    float* xe = lstm_embed(c, x, B, cf.chunk_T, &T3);
+    K2_REQUIRE(T3 == 1, "internal: lstm chunk yields %d frames", T3);
+    float* h0 = ar.take<float>((int64_t)B * D);
+    float* cst = ar.take<float>((int64_t)B * Hh);
+    float* y = ar.take<float>((int64_t)B * D);
+    const long long stride = lay_.floats_per_stream;
+    for (int li = 0; li < L; li++) {
+        const long long off_h = (long long)li * D, off_c = (long long)L * D + (long long)li * Hh;
+        gather_rows(c, online_pool_, stride, off_h, d_slots, h0, B, D);
+        gather_rows(c, online_pool_, stride, off_c, d_slots, cst, B, Hh);
+        lstm_layer(c, li, xe, h0, D, cst, B, 1, y);
+        scatter_rows(c, online_pool_, stride, off_h, d_slots, y, D, B, D);
+        scatter_rows(c, online_pool_, stride, off_c, d_slots, cst, Hh, B, Hh);
+    }
+    linear(c, xe, D, m.w("joiner.encoder_proj.weight"), m.w("joiner.encoder_proj.bias"), enc, cf.J, B, D, cf.J);
+    return enc;
+}
+
+}  // namespace k2hip

@@ -176,8 +176,9 @@ void Model::parse_config() {
     c.model_type = get("model_type", "");
     c.conformer = c.model_type == "conformer";
     c.ctc = c.model_type == "zipformer2ctc";
-    if (c.model_type != "zipformer2" && !c.conformer && !c.ctc)
-        failf(K2HIP_ERR_UNSUPPORTED, "model_type '%s' is not supported (have: zipformer2, zipformer2ctc, conformer)", c.model_type.c_str());
+    c.lstm = c.model_type == "lstm";
+    if (c.model_type != "zipformer2" && !c.conformer && !c.ctc && !c.lstm)
+        failf(K2HIP_ERR_UNSUPPORTED, "model_type '%s' is not supported (have: zipformer2, zipformer2ctc, conformer, lstm)", c.model_type.c_str());
     auto fill = [&](const char* k, int* dst) {
         auto v = csv_ints(get(k, ""));
         if ((int)v.size() > kMaxStacks) failf(K2HIP_ERR_INVALID, "metadata %s has too many entries", k);
@@ -189,7 +190,14 @@ void Model::parse_config() {
     const char* keys[] = {"num_encoder_layers", "feedforward_dims", "num_heads",      "cnn_module_kernels",
                           "downsampling_factors", "query_head_dims", "value_head_dims", "pos_head_dims"};
     int* dsts[] = {c.nlayer, c.ff, c.heads, c.kern, c.ds, c.qhd, c.vhd, c.phd};
-    for (int i = 0; i < (c.conformer ? 4 : 8); i++)
+    if (c.lstm) {
+        K2_REQUIRE(c.ns == 1 && fill("num_encoder_layers", c.nlayer) == 1 && fill("feedforward_dims", c.ff) == 1,
+                   "lstm: encoder_dims / num_encoder_layers / feedforward_dims must have one entry");
+        c.rnn_hidden = geti("rnn_hidden_size", 0);
+        K2_REQUIRE(c.rnn_hidden > 0 && c.rnn_hidden % 4 == 0 && c.dim[0] == geti("d_model", c.dim[0]), "lstm: bad d_model / rnn_hidden_size");
+        c.heads[0] = 1; c.kern[0] = 1; c.ds[0] = 1; c.qhd[0] = 32; c.phd[0] = 4; c.vhd[0] = 12;  // unused
+    }
+    for (int i = 0; i < (c.lstm ? 0 : c.conformer ? 4 : 8); i++)
         if (fill(keys[i], dsts[i]) != c.ns) failf(K2HIP_ERR_INVALID, "metadata %s must have %d entries", keys[i], c.ns);
     if (c.conformer) {
         K2_REQUIRE(c.ns == 1, "conformer: encoder_dims must have one entry");
@@ -204,6 +212,11 @@ void Model::parse_config() {
     c.ctx = geti("context_size", 2);
     c.feat = geti("feature_dim", 80);
     c.Vp = (int)align_up(c.V, 4);
+    if (c.lstm) {  // the same file serves the offline and the streaming operator (OnlineModel.cs:48-49: ChunkLength = T, ShiftLength)
+        c.chunk_T = geti("T", 9);
+        c.shift = geti("decode_chunk_len", 4);
+        K2_REQUIRE(c.chunk_T == 9 && c.shift == 4, "lstm streaming geometry T=%d, decode_chunk_len=%d unsupported (9 / 4)", c.chunk_T, c.shift);
+    }
     c.streaming = get("streaming", "0") == "1";
     if (c.streaming) {
         c.chunk_T = geti("T", 45);
@@ -271,7 +284,7 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
             }
         }
     }
-    if (c.conformer && has("encoder.encoder_embed.conv.0.weight")) {
+    if ((c.conformer || c.lstm) && has("encoder.encoder_embed.conv.0.weight")) {
         for (const char* nm : {"encoder.encoder_embed.conv.3.weight", "encoder.encoder_embed.conv.6.weight"}) {
             const Tensor& t = tensor(nm);
             int Co = (int)t.dims[0], Ci = (int)t.dims[1];
@@ -292,7 +305,7 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
                     for (int f = 0; f < F3; f++) v[(size_t)d * KK + f * C + ch] = t.host[(size_t)d * KK + ch * F3 + f];
             push("encoder.encoder_embed.out.weight#fc", std::move(v), {D0, KK});
         }
-        for (int li = 0; li < c.nlayer[0]; li++) {
+        for (int li = 0; li < (c.conformer ? c.nlayer[0] : 0); li++) {
             char nm[192];
             snprintf(nm, sizeof nm, "encoder.encoder.layers.%d.conv_module.depthwise_conv.weight", li);
             const Tensor& t = tensor(nm);

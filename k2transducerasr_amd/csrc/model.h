@@ -46,6 +46,10 @@ struct Config {
     // model_type "zipformer2ctc": Zipformer2 encoder + CTC head (ctc_output.1), no decoder / joiner; the encoder entry points
     // return log_probs [B,T',V] (OfflineProjOfZipformer2ctc.cs:48-92, OnlineProjOfZipformer2ctc)
     bool ctc = false;
+    // model_type "lstm" (icefall lstm_transducer_stateless2; offline via OfflineProjOfTransducer, streaming via OnlineProjOfLstm):
+    // dim[0] = d_model, ff[0], nlayer[0], rnn_hidden; chunk_T = 9, shift = 4, one encoder frame per chunk
+    bool lstm = false;
+    int rnn_hidden = 0;
     int enc_dim() const { return ctc ? V : J; }
     int conv_cpg = 4;  // decoder conv input channels per group (4: Zipformer recipes; DD: stateless2 decoder, groups = 1)
     bool streaming = false;

@@ -12,9 +12,19 @@ namespace k2hip {
 void Engine::online_ensure_pool() {
     if (online_pool_) return;
     const Config& c = model_->cfg();
-    K2_REQUIRE(c.streaming, "this model is not a streaming export (metadata 'streaming' != 1)");
+    K2_REQUIRE(c.streaming || c.lstm, "this model is not a streaming export (metadata 'streaming' != 1)");
     OnlineLayout& L = lay_;
     long long off = 0;
+    if (c.lstm) {  // OnlineProjOfLstm.GetEncoderInitStates (:55-75): h [layers][d_model] then c [layers][rnn_hidden]
+        L.nl = c.nlayer[0];
+        L.floats_per_stream = ((long long)c.nlayer[0] * (c.dim[0] + c.rnn_hidden) + 63) / 64 * 64;
+        online_cap_ = 256;
+        if (const char* e = getenv("K2HIP_MAX_STREAMS")) online_cap_ = std::max(1, atoi(e));
+        K2_HIP(hipSetDevice(device_));
+        K2_HIP(hipMalloc(&online_pool_, sizeof(float) * (size_t)L.floats_per_stream * online_cap_));
+        for (int i = online_cap_ - 1; i >= 0; i--) free_slots_.push_back(i);
+        return;
+    }
     auto put = [&](std::vector<long long>& v, long long n) {
         v.push_back(off);
         off += (n + 3) / 4 * 4;  // keep every cache 16-byte aligned
@@ -63,7 +73,12 @@ void Engine::online_read_state(int slot, int layer, int kind, float* out, int64_
     online_ensure_pool();
     K2_REQUIRE(slot >= 0 && slot < online_cap_, "bad slot %d", slot);
     long long off, cnt;
-    if (kind == 6) {
+    if (model_->cfg().lstm) {  // kind 0: h of `layer` [d_model]; kind 1: c of `layer` [rnn_hidden]
+        const Config& cf = model_->cfg();
+        K2_REQUIRE(layer >= 0 && layer < cf.nlayer[0] && (kind == 0 || kind == 1), "bad lstm state index layer=%d kind=%d", layer, kind);
+        cnt = kind == 0 ? cf.dim[0] : cf.rnn_hidden;
+        off = kind == 0 ? (long long)layer * cf.dim[0] : (long long)cf.nlayer[0] * cf.dim[0] + (long long)layer * cf.rnn_hidden;
+    } else if (kind == 6) {
         off = lay_.embed;
         cnt = 128 * 3 * 19;
     } else {
@@ -82,6 +97,7 @@ void Engine::online_read_state(int slot, int layer, int kind, float* out, int64_
 
 int Engine::online_frames_per_chunk() const {
     const Config& c = model_->cfg();
+    if (c.lstm) return lstm_out_frames(c.chunk_T);
     return (c.shift / 2 + 1) / 2;
 }
 
@@ -286,6 +302,19 @@ void Engine::online_step(const int* slots, const float* chunks, const long long*
             K2_HIP(hipMemcpyAsync(d_hyp, hyps, sizeof(long long) * 2 * B, hipMemcpyHostToDevice, c.stream));
         }
         logfloor_inplace(c, d_x, (long long)B * T * cf.feat);  // online PadSequence (PadHelper.cs:9-13,58)
+        if (cf.lstm) {
+            float* enc = lstm_chunk(c, d_x, d_slots, B);
+            if (!c.dry) {
+                K2_HIP(hipEventRecord(ev_[3], c.stream));
+                K2_HIP(hipMemsetAsync(d_ovf, 0, sizeof(int), c.stream));
+            }
+            GreedyArgs a;
+            a.enc = enc; a.B = B; a.Tp = Tp; a.t0 = nullptr; a.skip1 = 1; a.max_sym = INT_MAX;
+            a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = Tp; a.overflow = d_ovf; a.init_ctx = d_hyp;
+            greedy_loop(c, decjoin(), a);
+            if (!c.dry) K2_HIP(hipEventRecord(ev_[4], c.stream));
+            return;
+        }
         int Tc = 0;
         float* x = encoder_embed_stream(c, d_x, d_slots, B, T, &Tc);
         const int M = B * Tc;
