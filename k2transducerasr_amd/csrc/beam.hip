@@ -29,6 +29,27 @@ __global__ void k_beam_init(BeamState s, int B) {
     if (k == 0) s.nhyp[i / s.K] = 1;
 }
 
+// h[m][co] = relu(Conv1d(k = 2) over (emb[y0], emb[y1])) for every hypothesis row m (id < 0 -> zero embedding)
+__global__ void k_beam_embconv(DecJoinW w, const long long* __restrict__ y, float* __restrict__ h, int M) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)M * w.DD) return;
+    const int m = (int)(i / w.DD), co = (int)(i - (long long)m * w.DD);
+    const long long y0 = y[2 * m], y1 = y[2 * m + 1];
+    float s = 0.f;
+    if (w.cpg <= 4) {
+        const int g0 = (co / w.cpg) * w.cpg;
+        for (int ci = 0; ci < w.cpg; ci++) {
+            const float e0 = y0 >= 0 ? w.emb[y0 * w.DD + g0 + ci] : 0.f;
+            const float e1 = y1 >= 0 ? w.emb[y1 * w.DD + g0 + ci] : 0.f;
+            s += w.conv[(co * w.cpg + ci) * 2 + 0] * e0;
+            s += w.conv[(co * w.cpg + ci) * 2 + 1] * e1;
+        }
+    } else {
+        s = (y0 >= 0 ? w.ptab[y0 * w.DD + co] : 0.f) + (y1 >= 0 ? w.ptab[((long long)w.V + y1) * w.DD + co] : 0.f);
+    }
+    h[i] = fmaxf(s, 0.f);
+}
+
 __global__ void k_beam_act(const float* __restrict__ enc, const float* __restrict__ dec, float* __restrict__ act, int B, int K,
                            int Tp, int t, int J4) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -40,85 +61,74 @@ __global__ void k_beam_act(const float* __restrict__ enc, const float* __restric
     reinterpret_cast<float4*>(act)[i] = make_float4(tanhf(e.x + d.x), tanhf(e.y + d.y), tanhf(e.z + d.z), tanhf(e.w + d.w));
 }
 
-__device__ __forceinline__ float block_max(float v, float* red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float r = red[0];
-    for (int w = 1; w < BT / 64; w++) r = fmaxf(r, red[w]);
-    __syncthreads();
-    return r;
-}
-__device__ __forceinline__ float block_sum(float v, float* red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float r = red[0];
-    for (int w = 1; w < BT / 64; w++) r += red[w];
-    __syncthreads();
-    return r;
-}
-
 // one workgroup per stream; `cur` = buffer holding frame t's input hypotheses
 __global__ __launch_bounds__(BT) void k_beam_step(BeamState s, const float* __restrict__ logits, int V, int t, int cur, int B) {
-    __shared__ float red[BT / 64];
-    __shared__ float mxs[kMaxBeam], lses[kMaxBeam];  // per hypothesis: max logit, log(sum(exp(l - max)))
     __shared__ int taken[kMaxBeam];
     __shared__ float topv[kMaxBeam];
     __shared__ int topi[kMaxBeam];
-    __shared__ float rv[BT / 64];
-    __shared__ int ri[BT / 64];
     __shared__ int dupof[kMaxBeam];           // for new entry r: index of the earlier entry it merges into, or -1
     __shared__ int same;
     const int b = blockIdx.x, tid = threadIdx.x, K = s.K;
     const int nA = s.nhyp[b];
     const float* lg = logits + (long long)b * K * V;
-    // ---- log_softmax offsets per hypothesis
-    for (int k = 0; k < nA; k++) {
-        float mx = -INFINITY;
-        for (int v = tid; v < V; v += BT) mx = fmaxf(mx, lg[(long long)k * V + v]);
-        mx = block_max(mx, red);
-        float sm = 0.f;
-        for (int v = tid; v < V; v += BT) sm += expf(lg[(long long)k * V + v] - mx);
-        sm = block_sum(sm, red);
-        if (tid == 0) { mxs[k] = mx; lses[k] = logf(sm); }
-        __syncthreads();
-    }
-    // ---- top `want` of nA*V by (score desc, flat index asc)
+    // ---- one wave per hypothesis (4 waves, K <= 8): log_softmax statistics, then the hypothesis' own top `want` candidates by
+    //      (score desc, token asc) with wave shuffles only; the global top `want` is the top of the union (no block-wide
+    //      reductions, which is what made this step cost more than the joiner GEMM)
     const int nc = nA * V, want = min(K, nc);
-    for (int r = 0; r < want; r++) {
-        float bv = -INFINITY;
-        int bi = -1;
-        for (int i = tid; i < nc; i += BT) {
-            bool tk = false;
-            for (int q = 0; q < r; q++) tk |= (taken[q] == i);
-            if (tk) continue;
-            const int k = i / V;
-            const float sc = (lg[i] - mxs[k] - lses[k]) + s.lp[b * K + k];  // the oracle's order of operations
-            if (bi < 0 || sc > bv) { bv = sc; bi = i; }   // ascending i per thread: first maximum wins
-        }
-        // block argmax: value desc, then flat index asc (bi < 0 loses)
+    const int lane = tid & 63, wave = tid >> 6;
+    __shared__ float candv[kMaxBeam * kMaxBeam];
+    __shared__ int candi[kMaxBeam * kMaxBeam];
+    for (int k = wave; k < nA; k += BT / 64) {
+        const float* l = lg + (long long)k * V;
+        float mx = -INFINITY;
+        for (int v = lane; v < V; v += 64) mx = fmaxf(mx, l[v]);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            float ov = __shfl_xor(bv, o);
-            int oi = __shfl_xor(bi, o);
-            if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sm = 0.f;
+        for (int v = lane; v < V; v += 64) sm += expf(l[v] - mx);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+        const float lse = logf(sm), lpk = s.lp[b * K + k];
+        int excl[kMaxBeam];
+        for (int r = 0; r < want; r++) {
+            float bv = -INFINITY;
+            int bi = -1;
+            for (int v = lane; v < V; v += 64) {
+                bool tk = false;
+                for (int q = 0; q < r; q++) tk |= (excl[q] == v);
+                if (tk) continue;
+                const float sc = (l[v] - mx - lse) + lpk;  // the oracle's order of operations
+                if (bi < 0 || sc > bv) { bv = sc; bi = v; }   // ascending v per lane: first maximum wins
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o);
+                const int oi = __shfl_xor(bi, o);
+                if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+            }
+            excl[r] = bi;
+            if (lane == 0) { candv[k * kMaxBeam + r] = bv; candi[k * kMaxBeam + r] = bi < 0 ? -1 : k * V + bi; }
         }
-        if ((tid & 63) == 0) { rv[tid >> 6] = bv; ri[tid >> 6] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            float v = rv[0];
-            int i = ri[0];
-            for (int w = 1; w < BT / 64; w++)
-                if (ri[w] >= 0 && (i < 0 || rv[w] > v || (rv[w] == v && ri[w] < i))) { v = rv[w]; i = ri[w]; }
-            taken[r] = i;
-            topv[r] = v;
-            topi[r] = i;
-        }
-        __syncthreads();
     }
+    __syncthreads();
+    if (wave == 0) {  // merge the nA x want candidates: lane = k * kMaxBeam + r
+        const bool has = (lane / kMaxBeam) < nA && (lane % kMaxBeam) < want;
+        float myv = has ? candv[lane] : -INFINITY;
+        int myi = has ? candi[lane] : -1;
+        for (int r = 0; r < want; r++) {
+            float bv = myv;
+            int bi = myi;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o);
+                const int oi = __shfl_xor(bi, o);
+                if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+            }
+            if (lane == 0) { topv[r] = bv; topi[r] = bi; taken[r] = bi; }
+            if (myi == bi) myi = -1;  // that candidate is used up (flat indexes are unique)
+        }
+    }
+    __syncthreads();
     // ---- expand + merge (HypothesisList.add) into the other buffer
     const int nxt = cur ^ 1;
     const long long BK = (long long)B * K;
@@ -210,17 +220,6 @@ __global__ __launch_bounds__(BT) void k_beam_step(BeamState s, const float* __re
     }
 }
 
-// lp/ctx/nhyp are single-buffered inputs of the next frame's decoder + step: commit after the step
-__global__ void k_beam_commit(BeamState s, int B) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B * s.K) {
-        s.lp[i] = s.lp_next[i];
-        s.ctx[2 * i] = s.ctx_next[2 * i];
-        s.ctx[2 * i + 1] = s.ctx_next[2 * i + 1];
-    }
-    if (i < B) s.nhyp[i] = s.nhyp_next[i];
-}
-
 // get_most_probable(length_norm=True): max of log_prob / len(ys) (len counts the 2 ctx blanks), first maximum
 __global__ void k_beam_final(BeamState s, int fin, int B, long long* __restrict__ tokens, int* __restrict__ timestamps,
                              int* __restrict__ n_tokens, float* __restrict__ scores, int max_tokens, int* __restrict__ overflow) {
@@ -264,11 +263,12 @@ void beam_search(const Ctx& ctx, const DecJoinW& w, const BeamArgs& a) {
     s.ts = ar.take<int>((int64_t)2 * M * cap);
     s.n = ar.take<int>((int64_t)2 * M);
     s.lp = ar.take<float>(M);
-    s.lp_next = ar.take<float>(M);
+    s.lp_next = s.lp;  // in place: within k_beam_step every read of a stream's lp / nhyp precedes (barrier-separated) tid 0's write
     s.ctx = ar.take<long long>((int64_t)2 * M);
-    s.ctx_next = ar.take<long long>((int64_t)2 * M);
+    s.ctx_next = s.ctx;
     s.nhyp = ar.take<int>(B);
-    s.nhyp_next = ar.take<int>(B);
+    s.nhyp_next = s.nhyp;
+    float* hbuf = ar.take<float>((int64_t)M * w.DD);
     float* dec = ar.take<float>((int64_t)M * w.J);
     float* act = ar.take<float>((int64_t)M * w.J);
     float* logits = ar.take<float>((int64_t)M * w.V);
@@ -278,7 +278,10 @@ void beam_search(const Ctx& ctx, const DecJoinW& w, const BeamArgs& a) {
         K2_HIP(hipGetLastError());
     }
     for (int t = 0; t < a.Tp; t++) {
-        decoder(ctx, w, s.ctx, M, dec);
+        // decoder of every hypothesis: embedding + conv + ReLU elementwise, then decoder_proj as ONE small-problem GEMM
+        // (k_decoder would re-read the 1 MB projection once per hypothesis)
+        if (!ctx.dry) hipLaunchKernelGGL(k_beam_embconv, dim3(cdiv((long long)M * w.DD, 256)), dim3(256), 0, ctx.stream, w, s.ctx, hbuf, M);
+        linear(ctx, hbuf, w.DD, a.dproj_w, w.dproj_b, dec, w.J, M, w.DD, w.J);
         if (!ctx.dry) {
             long long n4 = (long long)M * w.J / 4;
             hipLaunchKernelGGL(k_beam_act, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ctx.stream, a.enc, dec, act, B, K, a.Tp, t,
@@ -287,7 +290,6 @@ void beam_search(const Ctx& ctx, const DecJoinW& w, const BeamArgs& a) {
         linear(ctx, act, w.J, a.out_w, w.out_b, logits, w.V, M, w.J, w.V);
         if (!ctx.dry) {
             hipLaunchKernelGGL(k_beam_step, dim3(B), dim3(BT), 0, ctx.stream, s, logits, w.V, t, t & 1, B);
-            hipLaunchKernelGGL(k_beam_commit, dim3(cdiv(M, 256)), dim3(256), 0, ctx.stream, s, B);
             K2_HIP(hipGetLastError());
         }
     }

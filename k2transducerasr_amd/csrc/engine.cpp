@@ -437,6 +437,7 @@ void Engine::beam_device(const Ctx& c, const float* enc, int B, int Tp, long lon
                          int* d_overflow) {
     BeamArgs a;
     a.enc = enc; a.out_w = model_->w("joiner.output_linear.weight");
+    a.dproj_w = model_->w("joiner.decoder_proj.weight");
     a.B = B; a.Tp = Tp; a.beam = beam_;
     a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = max_tokens; a.overflow = d_overflow;
     d_scores_ = c.arena->take<float>(B);

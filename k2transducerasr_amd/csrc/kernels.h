@@ -210,6 +210,7 @@ struct BeamState {       // device arrays; hypotheses double-buffered by frame p
 struct BeamArgs {
     const float* enc;    // [B, Tp, J]
     const float* out_w;  // joiner.output_linear.weight [V, J] (torch layout, for the GEMM)
+    const float* dproj_w;  // joiner.decoder_proj.weight [J, DD] (torch layout)
     int B, Tp, beam;
     long long* tokens;   // [B, max_tokens] best hypothesis
     int* timestamps;
