@@ -121,6 +121,10 @@ def make_conformer_meta(
     vocab_size=5537,
     context_size=2,
     comment="",
+    streaming=False,
+    chunk_size=16,
+    left_context=64,
+    right_context=0,
 ):
     """Offline Conformer transducer (reference: Model_type "conformer" -> OfflineProjOfTransducer,
     OfflineRecognizer.cs:38-53; BASELINE.json configs[4]).  The graph is icefall's
@@ -146,6 +150,24 @@ def make_conformer_meta(
             "context_size": str(context_size),
         }
     )
+    if streaming:
+        # streaming export (causal convolutions, chunk_forward): the keys OnlineModel.cs:131-166 reads for OnlineProjOfConformer.
+        # T = (chunk_size + 2 + right_context) * 4 + 3 input frames per chunk (one embed frame is cut on each side),
+        # decode_chunk_len = chunk_size * 4
+        assert right_context == 0, "only right_context = 0 is built"
+        meta.update(
+            {
+                "streaming": "1",
+                "encoder_dim": str(encoder_dim),
+                "cnn_module_kernel": str(cnn_module_kernel),
+                "left_context": str(left_context),
+                "right_context": str(right_context),
+                "chunk_size": str(chunk_size),
+                "pad_length": str((2 + right_context) * 4 + 3),
+                "decode_chunk_len": str(chunk_size * 4),
+                "T": str((chunk_size + 2 + right_context) * 4 + 3),
+            }
+        )
     return meta
 
 
@@ -200,6 +222,8 @@ CONFORMER_PRESETS = {
     # BASELINE.json configs[4]: conformer-zh (wenetspeech char model), 12 x (512, 2048, 8 heads, k=31)
     "conformer-zh": dict(vocab_size=5537),
     # parity-test model: odd head size, small kernel, decoder conv with groups = 1
+    "conformer-streaming-tiny-test": dict(encoder_dim=64, num_encoder_layers=2, feedforward_dim=160, num_heads=4, cnn_module_kernel=7,
+                                          joiner_dim=512, decoder_dim=64, vocab_size=41, streaming=True, chunk_size=8, left_context=16),
     "conformer-tiny-test": dict(encoder_dim=64, num_encoder_layers=2, feedforward_dim=160, num_heads=4, cnn_module_kernel=7,
                                 joiner_dim=512, decoder_dim=64, vocab_size=41),
 }

@@ -31,6 +31,7 @@ BLANK_BIAS = {
     "zipformer2-ctc-tiny-test": 1.5,
     "zipformer2-ctc-streaming-tiny-test": 1.5,
     "conformer-tiny-test": 2.179,
+    "conformer-streaming-tiny-test": 2.0,
 }
 
 

@@ -263,3 +263,136 @@ static int conformer_forward(const k2o_model* m, const float* xin, int B, int T,
     free(x);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Streaming Conformer (OnlineProjOfConformer): Conformer.streaming_forward / ConformerEncoderLayer.chunk_forward of the same
+ * recipe with causal convolutions.  Per stream and layer the states are cached_attn [left_context, D] -- the layer INPUT to the
+ * attention (keys / values are re-projected every chunk) -- and cached_conv [K-1, D] -- the GLU output feeding the causal
+ * depthwise conv (OnlineProjOfConformer.cs:55-82 gives the shapes).  One chunk = T input frames -> embed -> drop one frame on
+ * each side -> chunk_size frames; keys = [cached_attn ; chunk]; rel-pos table for left + chunk; the oldest
+ * (left - processed_lens) cache slots are masked with -inf.  right_context = 0 only.
+ * ---------------------------------------------------------------------------------------------------------------------- */
+static float* conformer_pos_emb_left(int Tc, int left, int D) {
+    const int n2 = left + 2 * Tc - 1;
+    float* pe = falloc((size_t)n2 * D);
+    const float c = -(logf(10000.0f) / (float)D);
+    for (int n = 0; n < n2; n++) {
+        float r = (float)(left + Tc - 1 - n);
+        for (int k = 0; k < D / 2; k++) {
+            float div = expf((float)(2 * k) * c);
+            pe[(size_t)n * D + 2 * k] = sinf(r * div);
+            pe[(size_t)n * D + 2 * k + 1] = cosf(r * div);
+        }
+    }
+    return pe;
+}
+
+/* x [Tc, D] in place; attn_cache [left, D], conv_cache [K-1, D] updated */
+static void conformer_layer_stream(const k2o_model* m, int li, float* x, const float* pe, int Tc, int left, int64_t processed,
+                                   float* attn_cache, float* conv_cache) {
+    const int D = m->dim[0], H = m->heads[0], K = m->kern[0], dk = D / H, KL = left + Tc;
+    char pfx[64];
+    snprintf(pfx, sizeof pfx, "encoder.encoder.layers.%d.", li);
+    conformer_ff(m, pfx, "feed_forward_macaron", x, Tc, D, m->ff[0]);
+    {   /* attention over key = [cache ; x] */
+        float* key = falloc((size_t)KL * D);
+        memcpy(key, attn_cache, sizeof(float) * (size_t)left * D);
+        memcpy(key + (size_t)left * D, x, sizeof(float) * (size_t)Tc * D);
+        memcpy(attn_cache, key + (size_t)Tc * D, sizeof(float) * (size_t)left * D);   /* states[0] = key[-left:] */
+        const float* wt = WT(m, 3 * D, D, "%sself_attn.in_proj.weight", pfx);           /* [D, 3D] */
+        const float* bias = W(m, "%sself_attn.in_proj.bias", pfx);
+        float* q = falloc((size_t)Tc * 3 * D);   /* only the first D columns are used */
+        float* kv = falloc((size_t)KL * 3 * D);
+        linear(q, 3 * D, x, D, wt, bias, Tc, D, 3 * D);
+        linear(kv, 3 * D, key, D, wt, bias, KL, D, 3 * D);
+        const int NP = left + 2 * Tc - 1;
+        float* p = falloc((size_t)NP * D);
+        linear(p, D, pe, D, WT(m, D, D, "%sself_attn.linear_pos.weight", pfx), NULL, NP, D, D);
+        const float* bu = W(m, "%sself_attn.pos_bias_u", pfx);
+        const float* bv = W(m, "%sself_attn.pos_bias_v", pfx);
+        const float scaling = 1.0f / sqrtf((float)dk);
+        float* ctxv = falloc((size_t)Tc * D);
+        float* sc = falloc((size_t)KL);
+        for (int h = 0; h < H; h++)
+            for (int i = 0; i < Tc; i++) {
+                float qu[256], qv[256];
+                for (int d = 0; d < dk; d++) {
+                    float qs = q[(size_t)i * 3 * D + h * dk + d] * scaling;
+                    qu[d] = qs + bu[h * dk + d];
+                    qv[d] = qs + bv[h * dk + d];
+                }
+                float mx = -INFINITY;
+                for (int j = 0; j < KL; j++) {
+                    const float* kk = kv + (size_t)j * 3 * D + D + h * dk;
+                    const float* pr = p + (size_t)(Tc - 1 - i + j) * D + h * dk;   /* rel_shift(x, left_context) */
+                    float ac = 0.f, bd = 0.f;
+                    for (int d = 0; d < dk; d++) ac += qu[d] * kk[d];
+                    for (int d = 0; d < dk; d++) bd += qv[d] * pr[d];
+                    float s = ac + bd;
+                    if (j < left && processed <= (int64_t)(left - 1 - j)) s = -INFINITY;   /* key_padding_mask */
+                    sc[j] = s;
+                    if (s > mx) mx = s;
+                }
+                float sum = 0.f;
+                for (int j = 0; j < KL; j++) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+                float inv = 1.0f / sum;
+                float* o = ctxv + (size_t)i * D + h * dk;
+                for (int d = 0; d < dk; d++) o[d] = 0.f;
+                for (int j = 0; j < KL; j++) {
+                    const float* v = kv + (size_t)j * 3 * D + 2 * D + h * dk;
+                    float a = sc[j] * inv;
+                    for (int d = 0; d < dk; d++) o[d] += a * v[d];
+                }
+            }
+        float* out = falloc((size_t)Tc * D);
+        linear(out, D, ctxv, D, WT(m, D, D, "%sself_attn.out_proj.weight", pfx), W(m, "%sself_attn.out_proj.bias", pfx), Tc, D, D);
+        add_inplace(x, out, (size_t)Tc * D);
+        free(out); free(sc); free(ctxv); free(p); free(kv); free(q); free(key);
+    }
+    {   /* causal convolution module with its cache */
+        const int lo = K - 1;
+        float* x2 = falloc((size_t)Tc * 2 * D);
+        linear(x2, 2 * D, x, D, WT(m, 2 * D, D, "%sconv_module.pointwise_conv1.weight", pfx), W(m, "%sconv_module.pointwise_conv1.bias", pfx),
+               Tc, D, 2 * D);
+        float* g = falloc((size_t)(lo + Tc) * D);
+        memcpy(g, conv_cache, sizeof(float) * (size_t)lo * D);
+        for (int t = 0; t < Tc; t++)
+            for (int d = 0; d < D; d++)
+                g[(size_t)(lo + t) * D + d] = x2[(size_t)t * 2 * D + d] * (1.0f / (1.0f + expf(-x2[(size_t)t * 2 * D + D + d])));
+        memcpy(conv_cache, g + (size_t)Tc * D, sizeof(float) * (size_t)lo * D);   /* cache = x[-lorder:] */
+        const float* dw = W(m, "%sconv_module.depthwise_conv.weight", pfx);
+        const float* db = W(m, "%sconv_module.depthwise_conv.bias", pfx);
+        float* y = falloc((size_t)Tc * D);
+        for (int t = 0; t < Tc; t++)
+            for (int d = 0; d < D; d++) {
+                float s = db[d];
+                for (int k = 0; k < K; k++) s += dw[d * K + k] * g[(size_t)(t + k) * D + d];
+                y[(size_t)t * D + d] = double_swish(s);
+            }
+        float* out = falloc((size_t)Tc * D);
+        linear(out, D, y, D, WT(m, D, D, "%sconv_module.pointwise_conv2.weight", pfx), W(m, "%sconv_module.pointwise_conv2.bias", pfx), Tc, D, D);
+        add_inplace(x, out, (size_t)Tc * D);
+        free(out); free(y); free(g); free(x2);
+    }
+    conformer_ff(m, pfx, "feed_forward", x, Tc, D, m->ff[0]);
+    basic_norm(x, x, W(m, "%snorm_final.eps", pfx)[0], Tc, D);
+}
+
+/* one chunk for one stream: xin [T, 80] -> enc_out [chunk_size, J]; caches [L][left][D], [L][K-1][D] */
+static int conformer_stream_chunk(const k2o_model* m, const float* xin, int T, int left, int64_t processed, float* attn_caches,
+                                  float* conv_caches, float* enc_out) {
+    int T3;
+    float* e = conformer_embed(m, xin, 1, T, &T3);
+    if (!e || T3 < 3) { free(e); return fail("conformer chunk of %d frames is too short", T); }
+    const int D = m->dim[0], Tc = T3 - 2, K = m->kern[0];
+    float* x = falloc((size_t)Tc * D);
+    memcpy(x, e + D, sizeof(float) * (size_t)Tc * D);   /* embed[:, 1:-1] */
+    free(e);
+    float* pe = conformer_pos_emb_left(Tc, left, D);
+    for (int li = 0; li < m->nlayer[0]; li++)
+        conformer_layer_stream(m, li, x, pe, Tc, left, processed, attn_caches + (size_t)li * left * D, conv_caches + (size_t)li * (K - 1) * D);
+    free(pe);
+    linear(enc_out, m->J, x, D, WT(m, m->J, D, "joiner.encoder_proj.weight"), W(m, "joiner.encoder_proj.bias"), Tc, D, m->J);
+    free(x);
+    return Tc;
+}

@@ -25,6 +25,7 @@ struct k2o_online_stream {
     size_t *nkey, *nnonlin, *nval, *nconv;
     float* embed;     /* [128][3][19] */
     int64_t processed_len;
+    float *conf_attn, *conf_conv; /* streaming conformer: cached_attn [L][left][D], cached_conv [L][K-1][D] */
     float *lstm_h, *lstm_c; /* model_type lstm: h [layers][d_model], c [layers][rnn_hidden] (OnlineProjOfLstm.cs:55-75) */
     int64_t hyp[2];
     int64_t* tokens;  /* Tokens list, starts [blank, blank] (OnlineStream.cs:45) */
@@ -42,6 +43,7 @@ int k2o_online_chunk_length(const k2o_model* m) { return meta_int(m, "T", 45); }
 int k2o_online_shift_length(const k2o_model* m) { return meta_int(m, "decode_chunk_len", 32); }
 int k2o_online_frames_per_chunk(const k2o_model* m) {
     if (m->lstm) return lstm_out_frames(meta_int(m, "T", 9));
+    if (m->conformer) return meta_int(m, "chunk_size", 16);
     return (meta_int(m, "decode_chunk_len", 32) / 2 + 1) / 2;
 }
 
@@ -52,6 +54,21 @@ k2o_online_stream* k2o_online_stream_create(const k2o_model* m) {
         return NULL;
     }
     k2o_online_stream* s = (k2o_online_stream*)calloc(1, sizeof *s);
+    if (m->conformer) {
+        /* OnlineProjOfConformer.GetEncoderInitStates (:55-82): zero caches and processed_lens[0] = 2 (sic) */
+        const int left = meta_int(m, "left_context", 64), D = m->dim[0], K = m->kern[0];
+        s->nl = m->nlayer[0];
+        s->conf_attn = calloc((size_t)s->nl * left * D, sizeof(float));
+        s->conf_conv = calloc((size_t)s->nl * (K - 1) * D, sizeof(float));
+        s->processed_len = 2;
+        s->cap_tokens = 64;
+        s->tokens = malloc(sizeof(int64_t) * s->cap_tokens);
+        s->tokens[0] = s->tokens[1] = 0;
+        s->n_tokens = 2;
+        s->cap_ts = 64;
+        s->timestamps = malloc(sizeof(int32_t) * s->cap_ts);
+        return s;
+    }
     if (m->lstm) {  /* GetEncoderInitStates: zero h and c */
         s->nl = m->nlayer[0];
         s->lstm_h = calloc((size_t)s->nl * m->dim[0], sizeof(float));
@@ -98,6 +115,11 @@ k2o_online_stream* k2o_online_stream_create(const k2o_model* m) {
 }
 void k2o_online_stream_free(k2o_online_stream* s) {
     if (!s) return;
+    if (s->conf_attn) {
+        free(s->conf_attn); free(s->conf_conv); free(s->tokens); free(s->timestamps);
+        free(s);
+        return;
+    }
     if (s->lstm_h) {
         free(s->lstm_h); free(s->lstm_c); free(s->tokens); free(s->timestamps);
         free(s);
@@ -117,7 +139,7 @@ int64_t k2o_online_stream_processed_len(const k2o_online_stream* s) { return s->
 int64_t k2o_online_stream_state(const k2o_online_stream* s, int layer, int kind, float* out, int64_t cap) {
     const float* p = NULL;
     size_t n = 0;
-    if (s->lstm_h) {  /* kind 0: h of `layer` [d_model]; kind 1: c of `layer` [rnn_hidden]; sizes from the allocation */
+    if (s->lstm_h || s->conf_attn) {
         return fail("use k2o_online_stream_lstm_state for an lstm stream");
     }
     switch (kind) {
@@ -416,6 +438,12 @@ static void online_layer(const k2o_model* m, k2o_online_stream* s, int si, int l
 static int lstm_online_chunk(const k2o_model* m, k2o_online_stream* s, const float* x, float* enc_out);
 int k2o_online_encoder_chunk(const k2o_model* m, k2o_online_stream* s, const float* x, float* enc_out) {
     if (m->lstm) return lstm_online_chunk(m, s, x, enc_out);
+    if (m->conformer) {   /* model semantics: new processed_lens = processed_lens + chunk frames */
+        const int left = meta_int(m, "left_context", 64);
+        int tc = conformer_stream_chunk(m, x, k2o_online_chunk_length(m), left, s->processed_len, s->conf_attn, s->conf_conv, enc_out);
+        if (tc > 0) s->processed_len += tc;
+        return tc;
+    }
     int T = k2o_online_chunk_length(m);
     int Tc;
     float* cur = online_embed(m, x, T, s->embed, &Tc);
@@ -498,6 +526,15 @@ static int lstm_online_chunk(const k2o_model* m, k2o_online_stream* s, const flo
     return Tp;
 }
 int64_t k2o_online_stream_lstm_state(const k2o_model* m, const k2o_online_stream* s, int layer, int kind, float* out, int64_t cap) {
+    if (s->conf_attn) {   /* streaming conformer: kind 0 = cached_attn [left, D], 1 = cached_conv [K-1, D] of `layer` */
+        const int left = meta_int(m, "left_context", 64), D = m->dim[0], K = m->kern[0];
+        size_t n = kind == 0 ? (size_t)left * D : (size_t)(K - 1) * D;
+        const float* p = kind == 0 ? s->conf_attn + (size_t)layer * n : s->conf_conv + (size_t)layer * n;
+        if (!out) return (int64_t)n;
+        if ((int64_t)n > cap) return fail("state buffer too small");
+        memcpy(out, p, sizeof(float) * n);
+        return (int64_t)n;
+    }
     if (!s->lstm_h) return fail("not an lstm stream");
     size_t n = kind == 0 ? (size_t)m->dim[0] : (size_t)m->rnn_hidden;
     const float* p = kind == 0 ? s->lstm_h + (size_t)layer * n : s->lstm_c + (size_t)layer * n;
@@ -578,6 +615,8 @@ int k2o_online_step(const k2o_model* m, k2o_online_stream** streams, const float
             rc = k2o_decoder(m, hyps, B, dec);
         }
     }
+    if (m->conformer)   /* OnlineProjOfConformer.unstack_states (:229): processed_lens is overwritten with the BATCH SIZE, not the model output */
+        for (int b = 0; b < B; b++) streams[b]->processed_len = B;
     for (int b = 0; b < B; b++) {   /* :208 stream.Hyp = last ctx tokens */
         streams[b]->hyp[0] = streams[b]->tokens[streams[b]->n_tokens - 2];
         streams[b]->hyp[1] = streams[b]->tokens[streams[b]->n_tokens - 1];

@@ -61,3 +61,53 @@ def test_conformer_greedy_emits(oracle_conformer, feats):
     res = oracle_conformer.recognize_batch([f.reshape(-1)[: 80 * 100] for f in feats])
     n = [len(t) for t, _ in res]
     assert sum(n) > 0 and max(n) < 30
+
+
+# ------------------------------------------------------------------------------------------------ streaming (OnlineProjOfConformer)
+@pytest.fixture(scope="module")
+def cstream_path(tmp_path_factory):
+    from k2transducerasr_amd.synth import write_synthetic_model
+    p = str(tmp_path_factory.mktemp("cs") / "conformer_stream.k2w")
+    write_synthetic_model(p, "conformer-streaming-tiny-test")
+    return p
+
+
+def test_streaming_conformer_matches_twin(cstream_path, utts):
+    import torch
+    from oracle.online import OnlineOracle
+    from torch_twin_conformer import ConformerStreamTwin
+    meta, tensors = read_k2w(cstream_path)
+    tw = ConformerStreamTwin(meta, tensors)
+    oo = OnlineOracle(cstream_path)
+    assert (oo.chunk_length, oo.shift_length, oo.frames_per_chunk) == (43, 32, 8)   # T = (8 + 2) * 4 + 3, decode_chunk_len = 8 * 4
+    f = oo.fbank(utts[0])
+    s = oo.create_stream()
+    assert s.processed_len == 2            # OnlineProjOfConformer.GetEncoderInitStates: processed_lens[0] = 2 (:77)
+    st = tw.init_states(1)
+    pl = torch.tensor([2])
+    pos = n = 0
+    while pos + 43 <= f.shape[0]:
+        x = f[pos : pos + 43]
+        a = oo.encoder_chunk(s, x)
+        b, st, pl = tw.chunk(x[None], st, pl)
+        np.testing.assert_allclose(a, b[0], atol=5e-5, rtol=0)
+        for l in range(2):
+            np.testing.assert_allclose(s.lstm_state(l, "h").reshape(16, 64), st[0][l, :, 0].numpy(), atol=5e-5, rtol=0)   # cached_attn
+            np.testing.assert_allclose(s.lstm_state(l, "c").reshape(6, 64), st[1][l, :, 0].numpy(), atol=5e-5, rtol=0)    # cached_conv
+        assert s.processed_len == int(pl[0]) == 2 + 8 * (n + 1)
+        pos += 32
+        n += 1
+    assert n >= 3
+
+
+def test_streaming_conformer_step_reproduces_the_processed_lens_bug(cstream_path, utts):
+    """OnlineProjOfConformer.unstack_states (:229) stores the BATCH SIZE as processed_lens instead of the model's output, so
+    after a step with B streams only the newest B left-context frames stay unmasked."""
+    from oracle.online import OnlineOracle
+    oo = OnlineOracle(cstream_path)
+    f = [oo.fbank(u) for u in utts[:3]]
+    ss = [oo.create_stream() for _ in f]
+    oo.step(ss, [x[:43] for x in f])
+    assert [s.processed_len for s in ss] == [3, 3, 3]
+    oo.step(ss[:1], [f[0][32:75]])
+    assert ss[0].processed_len == 1

@@ -139,3 +139,88 @@ class ConformerTwin:
         groups = cw.shape[0] // cw.shape[1]
         h = F.relu(F.conv1d(emb.permute(0, 2, 1), cw, groups=groups).permute(0, 2, 1)).squeeze(1)
         return F.linear(h, w["joiner.decoder_proj.weight"], w["joiner.decoder_proj.bias"]).numpy()
+
+
+# ------------------------------------------------------------------------------------------------ streaming (chunk_forward)
+def rel_pos_encoding_left(T: int, left: int, D: int) -> torch.Tensor:
+    """RelPositionalEncoding.forward(x, left_context): rows for relative positions (left + T - 1) .. -(T - 1)"""
+    x_size_1 = T + left
+    pe = rel_pos_encoding(x_size_1, D)          # [1, 2*x_size_1 - 1, D], centre at index x_size_1 - 1
+    center = pe.size(1) // 2
+    return pe[:, center - x_size_1 + 1 : center + T]
+
+
+def rel_shift_left(x, left_context: int):
+    (batch_size, num_heads, time1, n) = x.shape
+    time2 = time1 + left_context
+    assert n == left_context + 2 * time1 - 1
+    batch_stride, head_stride, time1_stride, n_stride = x.stride()
+    return x.as_strided((batch_size, num_heads, time1, time2), (batch_stride, head_stride, time1_stride - n_stride, n_stride),
+                        storage_offset=n_stride * (time1 - 1))
+
+
+class ConformerStreamTwin(ConformerTwin):
+    def __init__(self, meta, tensors):
+        super().__init__(meta, tensors)
+        self.left = int(meta["left_context"])
+
+    def init_states(self, N=1):
+        return [torch.zeros(self.L, self.left, N, self.D), torch.zeros(self.L, self.K - 1, N, self.D)]
+
+    def attn_chunk(self, p, src, key, pos_emb, key_padding_mask):
+        w = self.w
+        T, B, D = src.shape
+        S = key.shape[0]
+        H, hd = self.H, D // self.H
+        W_, b_ = w[p + "in_proj.weight"], w[p + "in_proj.bias"]
+        q = F.linear(src, W_[:D], b_[:D])
+        k, v = F.linear(key, W_[D:], b_[D:]).chunk(2, dim=-1)
+        q = (q * float(hd) ** -0.5).contiguous().view(T, B, H, hd).transpose(0, 1)
+        k = k.contiguous().view(S, B, H, hd)
+        v = v.contiguous().view(S, B * H, hd).transpose(0, 1)
+        pm = F.linear(pos_emb, w[p + "linear_pos.weight"]).view(1, -1, H, hd).transpose(1, 2)
+        qu = (q + w[p + "pos_bias_u"]).transpose(1, 2)
+        qv = (q + w[p + "pos_bias_v"]).transpose(1, 2)
+        ac = torch.matmul(qu, k.permute(1, 2, 3, 0))
+        bd = rel_shift_left(torch.matmul(qv, pm.transpose(-2, -1)).contiguous(), self.left)
+        aw = (ac + bd).view(B, H, T, S).masked_fill(key_padding_mask.unsqueeze(1).unsqueeze(2), float("-inf")).view(B * H, T, S)
+        aw = F.softmax(aw, dim=-1)
+        out = torch.bmm(aw, v).transpose(0, 1).contiguous().view(T, B, D)
+        return F.linear(out, w[p + "out_proj.weight"], w[p + "out_proj.bias"])
+
+    def conv_chunk(self, p, x, cache):  # x (T, B, D); cache (K-1, B, D)
+        w = self.w
+        x = x.permute(1, 2, 0)
+        x = F.glu(F.conv1d(x, w[p + "pointwise_conv1.weight"], w[p + "pointwise_conv1.bias"]), dim=1)
+        x = torch.cat([cache.permute(1, 2, 0), x], dim=2)
+        cache = x.permute(2, 0, 1)[-(self.K - 1):, ...]
+        x = F.conv1d(x, w[p + "depthwise_conv.weight"], w[p + "depthwise_conv.bias"], groups=self.D)   # causal: no padding
+        x = F.conv1d(double_swish(x), w[p + "pointwise_conv2.weight"], w[p + "pointwise_conv2.bias"])
+        return x.permute(2, 0, 1), cache
+
+    @torch.no_grad()
+    def chunk(self, x, states, processed_lens):
+        """Conformer.streaming_forward (simulate_streaming=False, right_context=0): x (N, T, 80) -> (N, chunk, J), new states"""
+        x = torch.as_tensor(x)
+        N = x.size(0)
+        embed = self.embed(x)[:, 1:-1, :]
+        T = embed.size(1)
+        pos_emb = rel_pos_encoding_left(T, self.left, self.D)
+        processed_mask = torch.arange(self.left).expand(N, self.left)
+        processed_mask = (processed_lens.view(N, 1) <= processed_mask).flip(1)
+        mask = torch.cat([processed_mask, torch.zeros(N, T, dtype=torch.bool)], dim=1)
+        src = embed.permute(1, 0, 2)
+        new_attn, new_conv = [], []
+        for i in range(self.L):
+            p = f"encoder.encoder.layers.{i}."
+            src = src + self.feed_forward(p + "feed_forward_macaron", src)
+            key = torch.cat([states[0][i], src], dim=0)
+            new_attn.append(key[-self.left:, ...])
+            src = src + self.attn_chunk(p + "self_attn.", src, key, pos_emb, mask)
+            conv, cc = self.conv_chunk(p + "conv_module.", src, states[1][i])
+            new_conv.append(cc)
+            src = src + conv
+            src = src + self.feed_forward(p + "feed_forward", src)
+            src = basic_norm(src, self.w[p + "norm_final.eps"])
+        out = F.linear(src.permute(1, 0, 2), self.w["joiner.encoder_proj.weight"], self.w["joiner.encoder_proj.bias"])
+        return out.contiguous().numpy(), [torch.stack(new_attn), torch.stack(new_conv)], processed_lens + T
