@@ -288,6 +288,9 @@ int32_t k2hip_online_stream_is_finished(k2hip_online_stream_t* s, int32_t is_end
  * caller's list, :117-120); n_new_tokens[i] = symbols emitted in this chunk. */
 int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* streams, int32_t B, int32_t* decoded,
                           int32_t* n_new_tokens);
+/* the stream's processed_lens state as the reference holds it between steps (Zipformer2: frames consumed; Conformer: 2 at
+ * creation, then the batch size of its last step -- OnlineProjOfConformer.cs:77,229) */
+int64_t k2hip_online_stream_processed_len(const k2hip_online_stream_t* s);
 int32_t k2hip_online_stream_num_tokens(const k2hip_online_stream_t* s);
 int32_t k2hip_online_stream_num_timestamps(const k2hip_online_stream_t* s);
 int32_t k2hip_online_stream_get_tokens(const k2hip_online_stream_t* s, int64_t* tokens, int32_t cap);
@@ -296,7 +299,9 @@ int32_t k2hip_online_stream_get_hyp(const k2hip_online_stream_t* s, int64_t* hyp
 /* copy one cache out of the stream's device slot (parity tests / debugging):
  * kind 0 cached_key [left,32H], 1 cached_nonlin_attn [left,3D/4], 2/3 cached_val1/2 [left,12H],
  * 4/5 cached_conv1/2 [D,K/2], 6 embed_states [128,3,19] (layer ignored); out == NULL queries n.
- * For an "lstm" model (OnlineProjOfLstm.cs:55-75): kind 0 = h of `layer` [d_model], kind 1 = c of `layer` [rnn_hidden_size] */
+ * For an "lstm" model (OnlineProjOfLstm.cs:55-75): kind 0 = h of `layer` [d_model], kind 1 = c of `layer` [rnn_hidden_size];
+ * for a streaming "conformer" (OnlineProjOfConformer.cs:55-82): kind 0 = cached_attn of `layer` [left_context, D], kind 1 =
+ * cached_conv of `layer` [K-1, D] */
 int32_t k2hip_online_stream_state(k2hip_online_stream_t* s, int32_t layer, int32_t kind, float* out, int64_t cap, int64_t* n);
 
 #if defined(__GNUC__)

@@ -511,7 +511,7 @@ class OfflineRecognizer:
 
 
 # ============================== streaming: OnlineStream / OnlineRecognizer ===============================
-_STATE_KINDS = {"key": 0, "nonlin": 1, "val1": 2, "val2": 3, "conv1": 4, "conv2": 5, "embed": 6, "lstm_h": 0, "lstm_c": 1}
+_STATE_KINDS = {"key": 0, "nonlin": 1, "val1": 2, "val2": 3, "conv1": 4, "conv2": 5, "embed": 6, "lstm_h": 0, "lstm_c": 1, "conf_attn": 0, "conf_conv": 1}
 
 
 def _bind_online(L):
@@ -595,6 +595,12 @@ class OnlineStream:
         out = np.zeros(2, np.int64)
         self._m._chk(self._L.k2hip_online_stream_get_hyp(self._h, _l(out)))
         return out.tolist()
+
+    @property
+    def processed_len(self) -> int:
+        self._L.k2hip_online_stream_processed_len.restype = C.c_int64
+        self._L.k2hip_online_stream_processed_len.argtypes = [C.c_void_p]
+        return int(self._L.k2hip_online_stream_processed_len(self._h))
 
     def state(self, layer: int, kind: str) -> np.ndarray:
         n = C.c_int64()

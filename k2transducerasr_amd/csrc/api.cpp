@@ -424,6 +424,8 @@ int32_t k2hip_online_stream_create(k2hip_model_t* model, k2hip_online_stream_t**
             delete s;
             throw;
         }
+        // OnlineProjOfConformer.GetEncoderInitStates (:76-77) starts processed_lens at 2, not 0
+        if (model->engine.model().cfg().conformer) s->processed_len = 2;
         *out = s;
     });
 }
@@ -585,12 +587,14 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
                 s->hyp[0] = s->tokens[s->tokens.size() - 2];           // :208
                 s->hyp[1] = s->tokens[s->tokens.size() - 1];
             }
-            s->processed_len += (c.chunk_T - 7) / 2 - 3;               // new_processed_lens = processed_lens + x_lens
+            if (c.conformer) s->processed_len = R;   // OnlineProjOfConformer.unstack_states (:229) stores the BATCH SIZE (sic), not the model's output
+            else s->processed_len += (c.chunk_T - 7) / 2 - 3;      // new_processed_lens = processed_lens + x_lens
             decoded[idx[r]] = 1;
             n_new_tokens[idx[r]] = n[r];
         }
     });
 }
+int64_t k2hip_online_stream_processed_len(const k2hip_online_stream_t* s) { return s ? (int64_t)s->processed_len : -1; }
 int32_t k2hip_online_stream_num_tokens(const k2hip_online_stream_t* s) { return s ? (int32_t)s->tokens.size() : -1; }
 int32_t k2hip_online_stream_num_timestamps(const k2hip_online_stream_t* s) { return s ? (int32_t)s->timestamps.size() : -1; }
 int32_t k2hip_online_stream_get_tokens(const k2hip_online_stream_t* s, int64_t* tokens, int32_t cap) {

@@ -14,12 +14,12 @@ namespace k2hip {
 namespace {
 
 __global__ void k_conformer_qprep(const float* __restrict__ qkv, const float* __restrict__ bu, const float* __restrict__ bv,
-                                  float* __restrict__ qu, float* __restrict__ qv, long long n4, int D4, float scaling) {
+                                  float* __restrict__ qu, float* __restrict__ qv, long long n4, int D4, float scaling, int ldq) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     long long r = i / D4;
     int c = (int)(i % D4) * 4;
-    float4 q = *reinterpret_cast<const float4*>(qkv + r * 3 * (D4 * 4) + c);
+    float4 q = *reinterpret_cast<const float4*>(qkv + r * ldq + c);
     float4 u = *reinterpret_cast<const float4*>(bu + c);
     float4 v = *reinterpret_cast<const float4*>(bv + c);
     q.x *= scaling; q.y *= scaling; q.z *= scaling; q.w *= scaling;
@@ -89,14 +89,97 @@ __global__ __launch_bounds__(256) void k_conformer_softmax_shift_long(float* __r
     for (int j = lane; j < Tp; j += 64) a[j] = j < T ? a[j] * inv : 0.f;
 }
 
+// streaming: one wave per (stream, head, query) row over KL = left + Tc keys
+__global__ __launch_bounds__(256) void k_conformer_softmax_shift_stream(float* __restrict__ ac, const float* __restrict__ bd,
+                                                                         const long long* __restrict__ plen, long long rows, int H, int Tc,
+                                                                         int left, int KLp, int NPp) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(row % Tc);
+    const int b = (int)(row / ((long long)Tc * H));
+    const int KL = left + Tc;
+    const long long pl = plen[b];
+    float* a = ac + row * KLp;
+    const float* sh = bd + row * NPp + (Tc - 1 - i);
+    float mx = -INFINITY;
+    for (int j = lane; j < KL; j += 64) {
+        float s = a[j] + sh[j];
+        if (j < left && pl <= (long long)(left - 1 - j)) s = -INFINITY;
+        a[j] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int j = lane; j < KL; j += 64) {
+        const float e = __expf(a[j] - mx);
+        a[j] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < KLp; j += 64) a[j] = j < KL ? a[j] * inv : 0.f;
+}
+
+__global__ void k_slice_rows(const float* __restrict__ in, float* __restrict__ out, int Tin, int row0, int Tout, int D4, long long n4) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int q = (int)(i % D4);
+    const long long bt = i / D4;
+    const int t = (int)(bt % Tout), b = (int)(bt / Tout);
+    reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(in)[((long long)b * Tin + row0 + t) * D4 + q];
+}
+
+__global__ void k_dwconv_valid_dswish(const float* __restrict__ cat, const float* __restrict__ w, const float* __restrict__ bias,
+                                      float* __restrict__ y, int Tc, int D4, int K, long long n4) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int q = (int)(i % D4);
+    const long long bt = i / D4;
+    const int t = (int)(bt % Tc), b = (int)(bt / Tc);
+    const int D = D4 * 4, Tin = K - 1 + Tc;
+    float4 s = *reinterpret_cast<const float4*>(bias + 4 * q);
+    for (int k = 0; k < K; k++) {
+        const float4 xv = *reinterpret_cast<const float4*>(cat + ((long long)b * Tin + t + k) * D + 4 * q);
+        const float4 wv = *reinterpret_cast<const float4*>(w + (long long)k * D + 4 * q);
+        s.x += wv.x * xv.x; s.y += wv.y * xv.y; s.z += wv.z * xv.z; s.w += wv.w * xv.w;
+    }
+    auto ds = [](float v) { return v / (1.0f + __expf(1.0f - v)); };
+    reinterpret_cast<float4*>(y)[i] = make_float4(ds(s.x), ds(s.y), ds(s.z), ds(s.w));
+}
+
 }  // namespace
 
+void conformer_softmax_shift_stream(const Ctx& ctx, float* ac, const float* bd, const long long* plen, int B, int H, int Tc, int left,
+                                    int KLp, int NPp) {
+    if (ctx.dry) return;
+    const long long rows = (long long)B * H * Tc;
+    hipLaunchKernelGGL(k_conformer_softmax_shift_stream, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx.stream, ac, bd, plen, rows, H, Tc,
+                       left, KLp, NPp);
+    K2_HIP(hipGetLastError());
+}
+void slice_rows(const Ctx& ctx, const float* in, float* out, int B, int Tin, int row0, int Tout, int D) {
+    if (ctx.dry) return;
+    const long long n4 = (long long)B * Tout * (D / 4);
+    hipLaunchKernelGGL(k_slice_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ctx.stream, in, out, Tin, row0, Tout, D / 4, n4);
+    K2_HIP(hipGetLastError());
+}
+void dwconv_valid_dswish(const Ctx& ctx, const float* cat, const float* w_kd, const float* bias, float* y, int B, int Tc, int D, int K) {
+    ctx.add_flops(0.0, 2.0 * B * Tc * (double)D * K, 0);
+    if (ctx.dry) return;
+    const long long n4 = (long long)B * Tc * (D / 4);
+    hipLaunchKernelGGL(k_dwconv_valid_dswish, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ctx.stream, cat, w_kd, bias, y, Tc, D / 4, K, n4);
+    K2_HIP(hipGetLastError());
+}
+
 void conformer_qprep(const Ctx& ctx, const float* qkv, const float* bias_u, const float* bias_v, float* qu, float* qv, int M,
-                     int D, float scaling) {
+                     int D, float scaling, int ldq) {
     if (ctx.dry) return;
     long long n4 = (long long)M * D / 4;
     hipLaunchKernelGGL(k_conformer_qprep, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ctx.stream, qkv, bias_u, bias_v, qu, qv,
-                       n4, D / 4, scaling);
+                       n4, D / 4, scaling, ldq > 0 ? ldq : 3 * D);
     K2_HIP(hipGetLastError());
 }
 

@@ -172,4 +172,121 @@ float* Engine::conformer_forward(const Ctx& c, const float* x, int B, int T, int
     return enc_out;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Streaming (OnlineProjOfConformer): Conformer.streaming_forward / chunk_forward with causal convolutions and
+// right_context = 0.  Per stream slot the pool holds cached_attn [L][left][D] (the layers' attention INPUT; keys and values are
+// re-projected every chunk) followed by cached_conv [L][K-1][D] (GLU outputs feeding the causal depthwise conv), the shapes of
+// OnlineProjOfConformer.GetEncoderInitStates (:55-82).
+// ---------------------------------------------------------------------------------------------------------------------
+const float* Engine::conformer_pos_emb_left(int Tc, int left) {
+    const int key = -(50000000 + Tc * 10000 + left);
+    auto it = pe_cache_.find(key);
+    if (it != pe_cache_.end()) return it->second;
+    const int D = model_->cfg().dim[0], n2 = left + 2 * Tc - 1;
+    std::vector<float> pe((size_t)n2 * D);
+    const float cc = -(logf(10000.0f) / (float)D);
+    for (int n = 0; n < n2; n++) {
+        const float r = (float)(left + Tc - 1 - n);  // RelPositionalEncoding.forward(x, left_context)
+        for (int k = 0; k < D / 2; k++) {
+            const float div = expf((float)(2 * k) * cc);
+            pe[(size_t)n * D + 2 * k] = sinf(r * div);
+            pe[(size_t)n * D + 2 * k + 1] = cosf(r * div);
+        }
+    }
+    float* d = nullptr;
+    K2_HIP(hipMalloc(&d, pe.size() * sizeof(float)));
+    K2_HIP(hipMemcpy(d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+    pe_cache_[key] = d;
+    return d;
+}
+
+// one chunk for B streams: x [B, T, 80] -> enc [B, chunk, J]
+float* Engine::conformer_chunk(const Ctx& c, const float* x, const int* d_slots, const long long* d_plen, int B, int* Tc_out) {
+    const Model& m = *model_;
+    const Config& cf = m.cfg();
+    Arena& ar = *c.arena;
+    const int D = cf.dim[0], F = cf.ff[0], H = cf.heads[0], K = cf.kern[0], dk = D / H, L = cf.nlayer[0], left = cf.left[0];
+    const int T3 = conformer_out_frames(cf.chunk_T), Tc = T3 - 2, KL = left + Tc, KLp = (KL + 3) & ~3, NP = left + 2 * Tc - 1,
+              NPp = (NP + 3) & ~3, M = B * Tc;
+    float* enc = ar.take<float>((int64_t)M * cf.J);
+    int t3 = 0;
+    float* e = conformer_embed(c, x, B, cf.chunk_T, &t3);
+    K2_REQUIRE(t3 == T3 && Tc > 0, "internal: conformer chunk yields %d frames", t3);
+    float* xs = ar.take<float>((int64_t)M * D);
+    slice_rows(c, e, xs, B, T3, 1, Tc, D);  // embed[:, 1:-1]: the edge frames saw the conv padding
+    const float* pe = c.dry ? nullptr : conformer_pos_emb_left(Tc, left);
+    float* hid = ar.take<float>((int64_t)M * std::max(F, 2 * D));
+    float* cat = ar.take<float>((int64_t)B * KL * D);
+    float* kv = ar.take<float>((int64_t)B * KL * 2 * D);
+    float* q = ar.take<float>((int64_t)M * D);
+    float* qu = ar.take<float>((int64_t)M * D);
+    float* qv = ar.take<float>((int64_t)M * D);
+    float* pp = ar.take<float>((int64_t)NP * D);
+    float* ac = ar.take<float>((int64_t)B * H * Tc * KLp);
+    float* bd = ar.take<float>((int64_t)B * H * Tc * NPp);
+    float* ccat = ar.take<float>((int64_t)B * (K - 1 + Tc) * D);
+    float* g = ar.take<float>((int64_t)M * D);
+    const long long stride = lay_.floats_per_stream;
+    for (int li = 0; li < L; li++) {
+        char p[96];
+        snprintf(p, sizeof p, "encoder.encoder.layers.%d.", li);
+        auto w = [&](const char* suffix) { return m.w(std::string(p) + suffix); };
+        auto feed_forward = [&](const char* name) {
+            std::string n(name);
+            linear(c, xs, D, w((n + ".0.weight").c_str()), w((n + ".0.bias").c_str()), hid, F, M, D, F, ACT_DOUBLE_SWISH);
+            linear(c, hid, F, w((n + ".4.weight").c_str()), w((n + ".4.bias").c_str()), xs, D, M, F, D, ACT_NONE, xs, D);
+        };
+        feed_forward("feed_forward_macaron");
+        {
+            // key = [cached_attn ; chunk]; cached_attn <- key[-left:]
+            cat_shift(c, online_pool_, stride, (long long)li * left * D, d_slots, xs, D, cat, B, left, Tc, D);
+            const float* Win = w("self_attn.in_proj.weight");
+            const float* bin = w("self_attn.in_proj.bias");
+            linear(c, xs, D, Win, bin, q, D, M, D, D);                                    // q from the chunk
+            linear(c, cat, D, Win + (long long)D * D, bin + D, kv, 2 * D, B * KL, D, 2 * D);  // k | v from the keys
+            linear(c, pe, D, w("self_attn.linear_pos.weight"), nullptr, pp, D, NP, D, D);
+            conformer_qprep(c, q, w("self_attn.pos_bias_u"), w("self_attn.pos_bias_v"), qu, qv, M, D, 1.0f / sqrtf((float)dk), D);
+            {
+                GemmArgs a;
+                a.A = qu; a.lda = D; a.sA0 = dk; a.sA1 = (long long)Tc * D;
+                a.W = kv; a.ldw = 2 * D; a.sW0 = dk; a.sW1 = (long long)KL * 2 * D;
+                a.C = ac; a.ldc = KLp; a.sC0 = (long long)Tc * KLp; a.sC1 = (long long)H * Tc * KLp;
+                a.M = Tc; a.N = KL; a.K = dk; a.nb0 = H; a.nb1 = B;
+                gemm(c, a);
+            }
+            {
+                GemmArgs a;
+                a.A = qv; a.lda = D; a.sA0 = dk; a.sA1 = (long long)Tc * D;
+                a.W = pp; a.ldw = D; a.sW0 = dk; a.sW1 = 0;
+                a.C = bd; a.ldc = NPp; a.sC0 = (long long)Tc * NPp; a.sC1 = (long long)H * Tc * NPp;
+                a.M = Tc; a.N = NP; a.K = dk; a.nb0 = H; a.nb1 = B;
+                gemm(c, a);
+            }
+            conformer_softmax_shift_stream(c, ac, bd, d_plen, B, H, Tc, left, KLp, NPp);
+            float* ctxv = qu;
+            {
+                GemmArgs a;
+                a.A = ac; a.lda = KLp; a.sA0 = (long long)Tc * KLp; a.sA1 = (long long)H * Tc * KLp;
+                a.W = kv + D; a.w_kn = 1; a.ldw = 2 * D; a.sW0 = dk; a.sW1 = (long long)KL * 2 * D;
+                a.C = ctxv; a.ldc = D; a.sC0 = dk; a.sC1 = (long long)Tc * D;
+                a.M = Tc; a.N = dk; a.K = KL; a.nb0 = H; a.nb1 = B;
+                gemm(c, a);
+            }
+            linear(c, ctxv, D, w("self_attn.out_proj.weight"), w("self_attn.out_proj.bias"), xs, D, M, D, D, ACT_NONE, xs, D);
+        }
+        {   // causal ConvolutionModule: cache holds the K-1 latest GLU outputs
+            linear(c, xs, D, w("conv_module.pointwise_conv1.weight"), w("conv_module.pointwise_conv1.bias"), hid, 2 * D, M, D, 2 * D);
+            glu_sigmoid(c, hid, g, M, D);
+            cat_shift(c, online_pool_, stride, (long long)L * left * D + (long long)li * (K - 1) * D, d_slots, g, D, ccat, B, K - 1, Tc, D);
+            dwconv_valid_dswish(c, ccat, w("conv_module.depthwise_conv.weight#kd"), w("conv_module.depthwise_conv.bias"), g, B, Tc, D, K);
+            linear(c, g, D, w("conv_module.pointwise_conv2.weight"), w("conv_module.pointwise_conv2.bias"), xs, D, M, D, D, ACT_NONE, xs, D);
+        }
+        feed_forward("feed_forward");
+        basicnorm(c, xs, w("norm_final.eps"), xs, M, D);
+    }
+    linear(c, xs, D, m.w("joiner.encoder_proj.weight"), m.w("joiner.encoder_proj.bias"), enc, cf.J, M, D, cf.J);
+    *Tc_out = Tc;
+    return enc;
+}
+
 }  // namespace k2hip

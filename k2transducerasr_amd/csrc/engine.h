@@ -113,6 +113,8 @@ class Engine {
     float* lstm_forward(const Ctx& c, const float* x, int B, int T, int* Tp, int tap, float** tap_ptr, int* tap_rows, int* tap_dim);
     float* lstm_chunk(const Ctx& c, const float* x, const int* d_slots, int B);
     // offline Conformer (conformer_engine.cpp)
+    const float* conformer_pos_emb_left(int Tc, int left);
+    float* conformer_chunk(const Ctx& c, const float* x, const int* d_slots, const long long* d_plen, int B, int* Tc_out);
     int conformer_out_frames(int T) const;
     const float* conformer_pos_emb(int T);
     float* conformer_embed(const Ctx& c, const float* x, int B, int T, int* T_out);

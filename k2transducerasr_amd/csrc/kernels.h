@@ -123,7 +123,14 @@ void basicnorm(const Ctx& ctx, const float* x, const float* log_eps, float* y, i
 // Conformer rel-pos attention helpers (conformer.hip)
 //   qkv [M, 3D] -> qu = q*dk^-0.5 + pos_bias_u, qv = q*dk^-0.5 + pos_bias_v   ([M, D] each)
 void conformer_qprep(const Ctx& ctx, const float* qkv, const float* bias_u, const float* bias_v, float* qu, float* qv, int M,
-                     int D, float scaling);
+                     int D, float scaling, int ldq = 0 /* row stride of q; 0 = 3*D */);
+// streaming (OnlineProjOfConformer): keys = [left cache ; chunk]; w[i,j] = softmax_j(ac[i,j] + bd[i, Tc-1-i+j]) over KL = left + Tc keys,
+// left slot j masked (-inf) while plen[b] <= left-1-j; rows of stream b are z = b*H + h
+void conformer_softmax_shift_stream(const Ctx& ctx, float* ac, const float* bd, const long long* plen, int B, int H, int Tc, int left,
+                                    int KLp, int NPp);
+void slice_rows(const Ctx& ctx, const float* in, float* out, int B, int Tin, int row0, int Tout, int D);  // out[b] = in[b][row0 : row0+Tout]
+// y[b,t,:] = DoubleSwish(bias + sum_k w_kd[k] * cat[b, t+k, :])  (valid depthwise conv over [K-1 cached ; chunk] frames)
+void dwconv_valid_dswish(const Ctx& ctx, const float* cat, const float* w_kd, const float* bias, float* y, int B, int Tc, int D, int K);
 //   ac[z][i][j] (ld Tp) <- softmax_j(ac[z][i][j] + bd[z][i][T-1-i+j]) (rel_shift in gather form); pad columns zeroed
 void conformer_softmax_shift(const Ctx& ctx, float* ac, const float* bd, int Z, int T, int Tp, int NPp);
 void downsample(const Ctx& ctx, const float* x, const float* bias, float* y, int B, int T, int D, int ds);

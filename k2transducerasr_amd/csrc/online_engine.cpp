@@ -15,6 +15,16 @@ void Engine::online_ensure_pool() {
     K2_REQUIRE(c.streaming || c.lstm, "this model is not a streaming export (metadata 'streaming' != 1)");
     OnlineLayout& L = lay_;
     long long off = 0;
+    if (c.conformer) {  // OnlineProjOfConformer.GetEncoderInitStates (:55-82): cached_attn [L][left][D] then cached_conv [L][K-1][D]
+        L.nl = c.nlayer[0];
+        L.floats_per_stream = ((long long)c.nlayer[0] * (c.left[0] + c.kern[0] - 1) * c.dim[0] + 63) / 64 * 64;
+        online_cap_ = 256;
+        if (const char* e = getenv("K2HIP_MAX_STREAMS")) online_cap_ = std::max(1, atoi(e));
+        K2_HIP(hipSetDevice(device_));
+        K2_HIP(hipMalloc(&online_pool_, sizeof(float) * (size_t)L.floats_per_stream * online_cap_));
+        for (int i = online_cap_ - 1; i >= 0; i--) free_slots_.push_back(i);
+        return;
+    }
     if (c.lstm) {  // OnlineProjOfLstm.GetEncoderInitStates (:55-75): h [layers][d_model] then c [layers][rnn_hidden]
         L.nl = c.nlayer[0];
         L.floats_per_stream = ((long long)c.nlayer[0] * (c.dim[0] + c.rnn_hidden) + 63) / 64 * 64;
@@ -73,7 +83,13 @@ void Engine::online_read_state(int slot, int layer, int kind, float* out, int64_
     online_ensure_pool();
     K2_REQUIRE(slot >= 0 && slot < online_cap_, "bad slot %d", slot);
     long long off, cnt;
-    if (model_->cfg().lstm) {  // kind 0: h of `layer` [d_model]; kind 1: c of `layer` [rnn_hidden]
+    if (model_->cfg().conformer) {  // kind 0: cached_attn of `layer` [left, D]; kind 1: cached_conv of `layer` [K-1, D]
+        const Config& cf = model_->cfg();
+        K2_REQUIRE(layer >= 0 && layer < cf.nlayer[0] && (kind == 0 || kind == 1), "bad conformer state index layer=%d kind=%d", layer, kind);
+        const long long na = (long long)cf.left[0] * cf.dim[0], ncv = (long long)(cf.kern[0] - 1) * cf.dim[0];
+        cnt = kind == 0 ? na : ncv;
+        off = kind == 0 ? layer * na : cf.nlayer[0] * na + layer * ncv;
+    } else if (model_->cfg().lstm) {  // kind 0: h of `layer` [d_model]; kind 1: c of `layer` [rnn_hidden]
         const Config& cf = model_->cfg();
         K2_REQUIRE(layer >= 0 && layer < cf.nlayer[0] && (kind == 0 || kind == 1), "bad lstm state index layer=%d kind=%d", layer, kind);
         cnt = kind == 0 ? cf.dim[0] : cf.rnn_hidden;
@@ -98,6 +114,7 @@ void Engine::online_read_state(int slot, int layer, int kind, float* out, int64_
 int Engine::online_frames_per_chunk() const {
     const Config& c = model_->cfg();
     if (c.lstm) return lstm_out_frames(c.chunk_T);
+    if (c.conformer) return conformer_out_frames(c.chunk_T) - 2;
     return (c.shift / 2 + 1) / 2;
 }
 
@@ -302,8 +319,10 @@ void Engine::online_step(const int* slots, const float* chunks, const long long*
             K2_HIP(hipMemcpyAsync(d_hyp, hyps, sizeof(long long) * 2 * B, hipMemcpyHostToDevice, c.stream));
         }
         logfloor_inplace(c, d_x, (long long)B * T * cf.feat);  // online PadSequence (PadHelper.cs:9-13,58)
-        if (cf.lstm) {
-            float* enc = lstm_chunk(c, d_x, d_slots, B);
+        if (cf.lstm || cf.conformer) {
+            int tc = Tp;
+            float* enc = cf.lstm ? lstm_chunk(c, d_x, d_slots, B) : conformer_chunk(c, d_x, d_slots, d_plen, B, &tc);
+            K2_REQUIRE(tc == Tp, "internal: chunk yields %d frames, expected %d", tc, Tp);
             if (!c.dry) {
                 K2_HIP(hipEventRecord(ev_[3], c.stream));
                 K2_HIP(hipMemsetAsync(d_ovf, 0, sizeof(int), c.stream));

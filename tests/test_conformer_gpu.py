@@ -127,3 +127,44 @@ def test_conformer_zh_full_size_properties(hip_zh):
     assert r1 == r2
     assert all(len(t) == len(ts) and all(0 <= q < 753 for q in ts) and ts == sorted(ts) for t, ts in r1)
     assert sum(len(t) for t, _ in r1) > 0
+
+
+# ---------------------------------------------------------------- streaming (OnlineProjOfConformer)
+def test_streaming_conformer_matches_oracle(tmp_path_factory):
+    """chunk_forward on the GPU against the oracle: tokens, timestamps, hyp, every cache, and the reference's processed_lens
+    behaviour (2 at creation, then the batch size of the last step, OnlineProjOfConformer.cs:77,229), which decides how much of
+    the left context is visible."""
+    from k2transducerasr_amd import OnlineRecognizer
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    from oracle.online import OnlineOracle
+    p = str(tmp_path_factory.mktemp("csg") / "conformer_stream.k2w")
+    write_synthetic_model(p, "conformer-streaming-tiny-test")
+    oo = OnlineOracle(p)
+    rec = OnlineRecognizer(p)
+    assert (rec.chunk_length, rec.shift_length, rec.frames_per_chunk) == (43, 32, 8)
+    utts = [synth_utterance(60 + u, 2.2) for u in range(3)]
+    feats = [oo.fbank(u) for u in utts]
+    hs = [rec.create_online_stream() for _ in utts]
+    os_ = [oo.create_stream() for _ in utts]
+    assert [h.processed_len for h in hs] == [2, 2, 2]
+    for h, f in zip(hs, feats):
+        h.add_features(f)
+    pos, n = 0, 0
+    while pos + 43 <= feats[0].shape[0]:
+        if n == 3:   # one step with a single stream: processed_lens becomes 1 for it
+            oo.step(os_[:1], [feats[0][pos : pos + 43]])
+            rec.get_results(hs[:1])
+            oo.step(os_[1:], [f[pos : pos + 43] for f in feats[1:]])
+            rec.get_results(hs[1:])
+        else:
+            oo.step(os_, [f[pos : pos + 43] for f in feats])
+            rec.get_results(hs)
+        assert [h.processed_len for h in hs] == [o.processed_len for o in os_]
+        pos += 32
+        n += 1
+    assert n >= 5 and sum(len(o.tokens) - 2 for o in os_) > 0
+    for h, o in zip(hs, os_):
+        assert h.tokens == o.tokens and h.timestamps == o.timestamps and h.hyp == o.hyp
+        for l in range(2):
+            np.testing.assert_allclose(h.state(l, "conf_attn"), o.lstm_state(l, "h"), atol=ACT_TOL, rtol=0)
+            np.testing.assert_allclose(h.state(l, "conf_conv"), o.lstm_state(l, "c"), atol=ACT_TOL, rtol=0)
