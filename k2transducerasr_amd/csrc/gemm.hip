@@ -574,7 +574,7 @@ void debug_force_gemm_cfg(int cfg) {
 void gemm(const Ctx& ctx, const GemmArgs& a) {
     K2_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty shape %dx%dx%d", a.M, a.N, a.K);
     K2_REQUIRE(a.cv_Fout > 0 || a.lda % 4 == 0, "gemm: lda %d must be a multiple of 4", a.lda);
-    K2_REQUIRE(a.K >= 4, "gemm: K=%d too small", a.K);
+    K2_REQUIRE(a.K >= 4 || (a.w_kn && a.K >= 1), "gemm: K=%d too small", a.K);  // [K,N] form: A rows are zero-padded to 4, W rows k >= K masked
     K2_REQUIRE(a.w_kn || a.K % 4 == 0, "gemm: K %d must be a multiple of 4", a.K);
     K2_REQUIRE(!a.w_kn || a.lda >= ((a.K + 3) & ~3), "gemm: [K,N] form needs A rows zero-padded to a multiple of 4");
     K2_REQUIRE(a.ldw % 4 == 0, "gemm: ldw %d must be a multiple of 4", a.ldw);

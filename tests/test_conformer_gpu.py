@@ -168,3 +168,13 @@ def test_streaming_conformer_matches_oracle(tmp_path_factory):
         for l in range(2):
             np.testing.assert_allclose(h.state(l, "conf_attn"), o.lstm_state(l, "h"), atol=ACT_TOL, rtol=0)
             np.testing.assert_allclose(h.state(l, "conf_conv"), o.lstm_state(l, "c"), atol=ACT_TOL, rtol=0)
+
+
+def test_conformer_shortest_inputs(hip_conformer, oracle_conformer):
+    rng = np.random.default_rng(9)
+    for T in (7, 8, 9, 11, 20):     # T' = 1, 1, 1, 2, 4
+        x = rng.standard_normal((3, T, 80)).astype(np.float32)
+        np.testing.assert_allclose(hip_conformer.encoder_proj(x), oracle_conformer.encoder(x), atol=ACT_TOL, rtol=0)
+    from k2transducerasr_amd import K2HipError
+    with pytest.raises(K2HipError):
+        hip_conformer.encoder_proj(np.zeros((1, 6, 80), np.float32))

@@ -75,3 +75,13 @@ def test_lstm_streaming_matches_oracle(lstm_path, oracle_lstm):
         for l in range(3):
             np.testing.assert_allclose(h.state(l, "lstm_h"), o.lstm_state(l, "h"), atol=ACT_TOL, rtol=0)
             np.testing.assert_allclose(h.state(l, "lstm_c"), o.lstm_state(l, "c"), atol=ACT_TOL, rtol=0)
+
+
+def test_lstm_shortest_inputs(hip_lstm, oracle_lstm):
+    rng = np.random.default_rng(9)
+    for T in (9, 12, 13, 20):
+        x = rng.standard_normal((2, T, 80)).astype(np.float32)
+        np.testing.assert_allclose(hip_lstm.encoder_proj(x), oracle_lstm.encoder(x), atol=ACT_TOL, rtol=0)
+    from k2transducerasr_amd import K2HipError
+    with pytest.raises(K2HipError):
+        hip_lstm.encoder_proj(np.zeros((1, 8, 80), np.float32))

@@ -296,3 +296,22 @@ def test_two_handles_from_two_threads(tiny_model_path, oracle_tiny, utts):
     for t in ts:
         t.join()
     assert res[0] == res[1] == want
+
+
+def test_random_ragged_batches_match_oracle(hip_tiny, oracle_tiny):
+    """Seeded sweep over batch sizes and ragged lengths (the reference pads every stream to the longest + 19 frames and decodes
+    all rows for all frames, Q1-Q3): fused samples -> tokens on the GPU against the oracle, including 1-stream batches, the
+    shortest inputs the encoder accepts and lengths around the frame / subsampling boundaries."""
+    from k2transducerasr_amd.synth import synth_utterance
+    rng = np.random.default_rng(2024)
+    lens_pool = [400, 401, 559, 560, 1999, 3200, 4801, 8000, 12345, 16000, 20001]
+    for case in range(14):
+        B = int(rng.integers(1, 7))
+        ns = [int(rng.choice(lens_pool)) if rng.random() < 0.6 else int(rng.integers(400, 24000)) for _ in range(B)]
+        utts = [synth_utterance(1000 + 10 * case + b, n / 16000.0)[:n] for b, n in enumerate(ns)]
+        feats = [oracle_tiny.fbank(u) for u in utts]
+        want = oracle_tiny.recognize_batch(feats)
+        x = oracle_tiny.pad_sequence(feats).reshape(B, -1, 80)
+        _, mg = oracle_tiny.greedy_batch(oracle_tiny.encoder(x), want_margins=True)
+        got = hip_tiny.offline_greedy_from_samples(utts)
+        assert_tokens_match(got, want, mg, what=f"ragged case {case} (B={B}, samples={ns})")
