@@ -404,23 +404,38 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
         if (kt + PF < nk) issue(kt + PF);
         const float* sa = smem + (kt % NST) * STAGE + arow * BK;
         const float* sb = smem + (kt % NST) * STAGE + (BM + brow) * BK;
+        // one-group look-ahead: the reads of 8-k group gk+1 are issued between the first and the second MFMA of group gk, so
+        // they land while the (dependent, 64-cycle) MFMA chain of gk runs instead of after it.  sched_barrier(0) pins the
+        // order (the scheduler otherwise sinks the reads back next to their first use).
+        float4 fa[2][MT], fb[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; i++) fa[0][i] = *reinterpret_cast<const float4*>(sa + i * 32 * BK + (((0 + lh) ^ swa) << 2));
+#pragma unroll
+        for (int j = 0; j < NT; j++) fb[0][j] = *reinterpret_cast<const float4*>(sb + j * 32 * BK + (((0 + lh) ^ swb) << 2));
 #pragma unroll
         for (int gk = 0; gk < 4; gk++) {
-            float4 fa[MT], fb[NT];
+            const int cu = gk & 1, nx = cu ^ 1;
 #pragma unroll
-            for (int i = 0; i < MT; i++) fa[i] = *reinterpret_cast<const float4*>(sa + i * 32 * BK + (((2 * gk + lh) ^ swa) << 2));
-#pragma unroll
-            for (int j = 0; j < NT; j++) fb[j] = *reinterpret_cast<const float4*>(sb + j * 32 * BK + (((2 * gk + lh) ^ swb) << 2));
-#pragma unroll
-            for (int e = 0; e < 4; e++)
+            for (int e = 0; e < 4; e++) {
 #pragma unroll
                 for (int i = 0; i < MT; i++)
 #pragma unroll
                     for (int j = 0; j < NT; j++) {
-                        const float av = e == 0 ? fa[i].x : e == 1 ? fa[i].y : e == 2 ? fa[i].z : fa[i].w;
-                        const float bv = e == 0 ? fb[j].x : e == 1 ? fb[j].y : e == 2 ? fb[j].z : fb[j].w;
+                        const float av = e == 0 ? fa[cu][i].x : e == 1 ? fa[cu][i].y : e == 2 ? fa[cu][i].z : fa[cu][i].w;
+                        const float bv = e == 0 ? fb[cu][j].x : e == 1 ? fb[cu][j].y : e == 2 ? fb[cu][j].z : fb[cu][j].w;
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                     }
+                if (e == 0 && gk < 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < MT; i++)
+                        fa[nx][i] = *reinterpret_cast<const float4*>(sa + i * 32 * BK + (((2 * (gk + 1) + lh) ^ swa) << 2));
+#pragma unroll
+                    for (int j = 0; j < NT; j++)
+                        fb[nx][j] = *reinterpret_cast<const float4*>(sb + j * 32 * BK + (((2 * (gk + 1) + lh) ^ swb) << 2));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
     }
 
