@@ -313,8 +313,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
     constexpr int WCOLS = BN / WN;
     constexpr int NW = (BM / WM) * (BN / WN);
     constexpr int NINST = (BM + BN) / 8;       // 1 KB wave-instructions per tile
-    static_assert(NINST % NW == 0, "DMA instructions must divide evenly over the waves");
-    constexpr int IPW = NINST / NW;            // per wave
+    constexpr int IPW = (NINST + NW - 1) / NW;  // per wave (the last round may be short: wave w issues inst w + q*NW < NINST)
+    constexpr int NFULL = NINST % NW == 0 ? NW : NINST % NW;  // waves 0..NFULL-1 issue IPW instructions, the others IPW - 1
     constexpr int STAGE = (BM + BN) * BK;      // floats per stage
 
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [NST][STAGE]: A rows then W rows
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
     const float* src[IPW];
 #pragma unroll
     for (int q = 0; q < IPW; q++) {
-        const int inst = wave + q * NW;          // wave-uniform
+        const int inst = min(wave + q * NW, NINST - 1);  // wave-uniform (clamped: the pointer of a missing slot is unused)
         const int slot = inst * 64 + lane;       // 16-byte slot within the stage
         const int r = slot >> 3, cp = slot & 7;  // row of the combined [A;W] tile, physical chunk
         const int c = cp ^ ((r >> 1) & 7);       // logical k chunk this slot holds
@@ -352,6 +352,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
 #pragma unroll
         for (int q = 0; q < IPW; q++) {
             const int inst = wave + q * NW;
+            if (inst >= NINST) break;  // wave-uniform
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + ((kt % NST) * STAGE + inst * 256) * 4);
             const float* gp = src[q] + kt * BK;
             unsigned keep;
@@ -398,8 +399,12 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
         if (p < nk) issue(p);
     for (int kt = 0; kt < nk; kt++) {
         // tile kt landed for this wave once at most the PF-1 newer tiles' instructions are pending
-        if (kt + PF - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * IPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + PF - 1 < nk && (PF - 1) * (IPW - 1) > 0) {
+            if (wave < NFULL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * IPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * (IPW - 1)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();  // ... and for every wave; also: everyone is done reading the stage about to be refilled
         if (kt + PF < nk) issue(kt + PF);
         const float* sa = smem + (kt % NST) * STAGE + arow * BK;
@@ -551,7 +556,7 @@ void launch_mode(const Ctx& ctx, const GemmArgs& a, int cfg) {
         case 1: launch_cfg<128, 128, 64, 32, 64, MODE>(ctx, a); break;  // 8 waves, BK 64
         case 3: launch_cfg<64, 64, 32, 32, 64, MODE>(ctx, a); break;    // 4 waves, BK 64
         case 4: launch_cfg<128, 64, 32, 32, 64, MODE>(ctx, a); break;   // 8 waves, BK 64
-        case 5: launch_cfg<128, 64, 32, 32, 32, MODE>(ctx, a); break;   // 8 waves
+        case 5: case 7: case 8: case 11: launch_cfg<128, 64, 32, 32, 32, MODE>(ctx, a); break;   // 8 waves (and the fallback of the DMA-only configs)
         default: launch_cfg<64, 64, 32, 32, 32, MODE>(ctx, a); break;   // 4 waves
     }
 }
@@ -572,6 +577,12 @@ int choose_cfg(const GemmArgs& a) {
     // workgroup; small tiles with a 64-deep K step are fastest (gpurun_out/gemm_tune_s1.txt)
     if ((long long)cdiv(a.M, 128) * cdiv(a.N, 64) * a.nb0 * a.nb1 < 144) return 3;  // fewer 128x64 tiles than ~half the CUs
     if (a.N <= 128 && a.M < 32768) return 3;   // 64x64 tiles, K step 64 (the ConvNeXt 1x1s have enough rows for 128x64)
+    {   // N a multiple of 96 and a multi-round 128x64 grid that leaves the last round mostly empty: 64x96 tiles balance it
+        // (measured -9 % on 4064x1152x512, -4 % on 2048x1536x768; no gain on single-round grids, which are bubble-bound)
+        const long long b5 = (long long)cdiv(a.M, 128) * cdiv(a.N, 64), b6 = (long long)cdiv(a.M, 64) * (a.N / 96);
+        const bool plain = a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.K % 32 == 0 && a.K >= 64;
+        if (plain && a.N % 96 == 0 && b5 > 256 && cdiv(b6, 256) * 6144 * 100 <= cdiv(b5, 256) * 8192 * 80) return 11;
+    }
     return 5;                   // 128x64 tiles, 8 waves (LDS-DMA pipeline when K % 32 == 0)
 }
 
@@ -621,8 +632,9 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         return;
     }
     const bool dma_ok = a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.K % 32 == 0 && a.K >= 64 && a.lda % 4 == 0;
-    if (dma_ok && g_use_dma && (cfg == 5 || cfg == 0 || (cfg >= 7 && cfg <= 10))) {
-        if (cfg == 9) launch_dma<64, 64, 32, 32, 2>(ctx, b);         // tuning: 64x64 tiles, 2 stages
+    if (dma_ok && g_use_dma && (cfg == 5 || cfg == 0 || (cfg >= 7 && cfg <= 11))) {
+        if (cfg == 11) launch_dma<64, 96, 32, 32, 2>(ctx, b);        // 64x96 tiles (6 waves): N % 96 == 0 outputs that 128x64 quantises badly
+        else if (cfg == 9) launch_dma<64, 64, 32, 32, 2>(ctx, b);    // tuning: 64x64 tiles, 2 stages
         else if (cfg == 10) launch_dma<64, 64, 32, 32, 3>(ctx, b);   // tuning: 64x64 tiles, 3 stages
         else if (cfg == 7) launch_dma<128, 64, 32, 32, 2>(ctx, b);  // tuning: 2 stages, 3 workgroups per CU
         else if (cfg == 8) launch_dma<128, 64, 32, 32, 4>(ctx, b);  // tuning: 4 stages, 1 workgroup per CU
