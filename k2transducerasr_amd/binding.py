@@ -626,8 +626,15 @@ class OnlineRecognizer:
     def add_samples_batch(self, streams: Sequence[OnlineStream], samples: Sequence[np.ndarray]):
         """B AddSamples calls in one (one fbank launch when all streams are at the same position)."""
         B = len(streams)
-        ss = [_f32(x).reshape(-1) for x in samples]
         arr = (C.c_void_p * B)(*[s._h for s in streams])
+        if isinstance(samples, np.ndarray) and samples.ndim == 2 and samples.dtype == np.float32 and samples.strides[1] == 4:
+            # one [B, n] matrix (rows contiguous, any row stride): pointer arithmetic instead of B ctypes conversions
+            base, rs = samples.ctypes.data, samples.strides[0]
+            ptrs = (C.c_void_p * B)(*[base + i * rs for i in range(B)])
+            n = np.full(B, samples.shape[1], np.int64)
+            self.model._chk(self.model._L.k2hip_online_accept_samples_batch(self.model.handle, arr, B, C.cast(ptrs, C.POINTER(fp)), _l(n)))
+            return
+        ss = [_f32(x).reshape(-1) for x in samples]
         ptrs = (fp * B)(*[_f(x) for x in ss])
         n = np.array([x.size for x in ss], np.int64)
         self.model._chk(self.model._L.k2hip_online_accept_samples_batch(self.model.handle, arr, B, ptrs, _l(n)))

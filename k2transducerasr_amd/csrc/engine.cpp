@@ -497,16 +497,22 @@ void Engine::fbank_host(const float* samples, int64_t n, float* feats, int64_t c
 void Engine::fbank_host_batch(const float* samples, int64_t n, int n_utts, float* feats, int64_t nf) {
     const FbankOpts& f = model_->cfg().fbank;
     K2_REQUIRE(nf == fbank_num_frames(n) && nf > 0 && n_utts > 0, "fbank_host_batch: bad shape");
+    // both directions go through the pinned staging buffer: from pageable memory each copy is a synchronous staged transfer,
+    // which made a 128-stream AddSamples round cost as much as a tenth of a chunk step
+    const size_t nb_in = sizeof(float) * (size_t)n * n_utts, nb_out = sizeof(float) * (size_t)nf * f.num_bins * n_utts;
+    char* pin = static_cast<char*>(pinned((int64_t)(nb_in + nb_out + 64)));
+    memcpy(pin, samples, nb_in);
     float* d_out = nullptr;
     run_sized([&](const Ctx& c) {
         float* d_s = c.arena->take<float>(n * n_utts);
         d_out = c.arena->take<float>(nf * f.num_bins * n_utts);
-        if (!c.dry) K2_HIP(hipMemcpyAsync(d_s, samples, sizeof(float) * n * n_utts, hipMemcpyHostToDevice, c.stream));
+        if (!c.dry) K2_HIP(hipMemcpyAsync(d_s, pin, nb_in, hipMemcpyHostToDevice, c.stream));
         FbankArgs a{d_s, n, n, n_utts, nf, d_out, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift, f.preemph, f.input_scale, f.remove_dc};
         fbank(c, a);
     });
-    K2_HIP(hipMemcpyAsync(feats, d_out, sizeof(float) * nf * f.num_bins * n_utts, hipMemcpyDeviceToHost, stream_));
+    K2_HIP(hipMemcpyAsync(pin + nb_in, d_out, nb_out, hipMemcpyDeviceToHost, stream_));
     K2_HIP(hipStreamSynchronize(stream_));
+    memcpy(feats, pin + nb_in, nb_out);
 }
 
 void Engine::pad_host(const float* const* speech, const int64_t* n_floats, int B, int tail, float* out, int64_t cap, int64_t* Lout) {
