@@ -211,6 +211,80 @@ def make_lstm_meta(
     return meta
 
 
+def make_zipformer_meta(
+    *,
+    encoder_dims,
+    attention_dims,
+    num_encoder_layers,
+    feedforward_dims,
+    num_heads,
+    cnn_module_kernels,
+    downsampling_factors,
+    pos_dim=4,
+    decode_chunk_size=16,
+    num_left_chunks=4,
+    joiner_dim=512,
+    decoder_dim=512,
+    vocab_size=500,
+    context_size=2,
+    comment="",
+):
+    """Streaming Zipformer (v1) transducer: Model_type "zipformer" -> OnlineProjOfZipformer (OnlineRecognizer.cs:28-30), whose
+    per-stack states are cached_len [L,B], cached_avg [L,B,D], cached_key [L,left,B,att], cached_val / cached_val2
+    [L,left,B,att/2], cached_conv1 / cached_conv2 [L,B,D,K-1] (OnlineProjOfZipformer.cs:56-111).  The graph is icefall's
+    pruned_transducer_stateless7_streaming Zipformer: Conv2dSubsampling ((T-7)//2 frames), stacks of ZipformerEncoderLayer
+    (three feed-forwards, cumulative-mean pooling, rel-pos attention whose weights are used twice, two causal convolution
+    modules, BasicNorm, scalar bypass) behind AttentionDownsample / SimpleUpsample / SimpleCombiner, and a final
+    AttentionDownsample by 2.  The reference reads encoder_dims, attention_dims, num_encoder_layers, cnn_module_kernels,
+    left_context_len, T and decode_chunk_len (OnlineModel.cs:38-72); num_heads, feedforward_dims, downsampling_factors and
+    pos_dim are baked into an ONNX graph and are carried as extra keys here."""
+    n = len(encoder_dims)
+    assert all(len(x) == n for x in (attention_dims, num_encoder_layers, feedforward_dims, num_heads, cnn_module_kernels, downsampling_factors))
+    meta = dict(FBANK_DEFAULTS)
+    meta.update(
+        {
+            "model_type": "zipformer",
+            "version": "1",
+            "model_author": "k2hip-synthetic",
+            "comment": comment,
+            "encoder_dims": _csv(encoder_dims),
+            "attention_dims": _csv(attention_dims),
+            "num_encoder_layers": _csv(num_encoder_layers),
+            "feedforward_dims": _csv(feedforward_dims),
+            "num_heads": _csv(num_heads),
+            "cnn_module_kernels": _csv(cnn_module_kernels),
+            "downsampling_factors": _csv(downsampling_factors),
+            "left_context_len": _csv([num_left_chunks * decode_chunk_size // d for d in downsampling_factors]),
+            "pos_dim": str(pos_dim),
+            "streaming": "1",
+            "decode_chunk_len": str(2 * decode_chunk_size),
+            "T": str(2 * decode_chunk_size + 7),
+            "joiner_dim": str(joiner_dim),
+            "decoder_dim": str(decoder_dim),
+            "vocab_size": str(vocab_size),
+            "context_size": str(context_size),
+        }
+    )
+    return meta
+
+
+ZIPFORMER1_PRESETS = {
+    # the icefall pruned_transducer_stateless7_streaming recipe (the streaming-zipformer-en / bilingual-zh-en exports the
+    # reference's README lists): 5 stacks of 384, chunk 32 frames in (T = 39), 4 left chunks
+    "zipformer-streaming-en": dict(
+        encoder_dims=[384] * 5, attention_dims=[192] * 5, num_encoder_layers=[2, 4, 3, 2, 4], feedforward_dims=[1024, 1024, 2048, 2048, 1024],
+        num_heads=[8] * 5, cnn_module_kernels=[31] * 5, downsampling_factors=[1, 2, 4, 8, 2], vocab_size=500,
+    ),
+    # parity-test model: growing stack widths (AttentionDownsample.extra_proj + SimpleCombiner padding), a skip connection
+    # (stack 3 takes stack 1's output), head sizes 16 and 24, short left context
+    "zipformer-streaming-tiny-test": dict(
+        encoder_dims=[64, 64, 96, 96], attention_dims=[32, 32, 96, 96], num_encoder_layers=[1, 2, 1, 1], feedforward_dims=[128, 128, 160, 160],
+        num_heads=[2, 2, 4, 4], cnn_module_kernels=[7, 7, 5, 7], downsampling_factors=[1, 2, 4, 2], num_left_chunks=2,
+        joiner_dim=512, decoder_dim=64, vocab_size=37,
+    ),
+}
+
+
 LSTM_PRESETS = {
     "lstm-en": dict(),
     "lstm-tiny-test": dict(d_model=64, rnn_hidden_size=96, dim_feedforward=160, num_encoder_layers=3, joiner_dim=512, decoder_dim=64,
@@ -329,6 +403,8 @@ def preset(name: str) -> dict:
         return make_conformer_meta(comment=name, **copy.deepcopy(CONFORMER_PRESETS[name]))
     if name in LSTM_PRESETS:
         return make_lstm_meta(comment=name, **copy.deepcopy(LSTM_PRESETS[name]))
+    if name in ZIPFORMER1_PRESETS:
+        return make_zipformer_meta(comment=name, **copy.deepcopy(ZIPFORMER1_PRESETS[name]))
     if name not in PRESETS:
         raise KeyError(f"unknown model preset {name!r}; have {sorted(PRESETS) + sorted(CONFORMER_PRESETS)}")
     return make_zipformer2_meta(comment=name, **copy.deepcopy(PRESETS[name]))

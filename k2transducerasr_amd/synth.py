@@ -32,6 +32,8 @@ BLANK_BIAS = {
     "zipformer2-ctc-streaming-tiny-test": 1.5,
     "conformer-tiny-test": 2.179,
     "conformer-streaming-tiny-test": 2.0,
+    "zipformer-streaming-en": 3.0,
+    "zipformer-streaming-tiny-test": 1.5,
 }
 
 
@@ -240,7 +242,80 @@ def lstm_tensor_specs(meta: Dict[str, str]) -> List[Tuple[str, tuple, str]]:
     return s
 
 
+def zipformer1_tensor_specs(meta: Dict[str, str]) -> List[Tuple[str, tuple, str]]:
+    """icefall pruned_transducer_stateless7_streaming state dict (Scaled* folded): Zipformer v1."""
+    dims = ints(meta, "encoder_dims")
+    atts = ints(meta, "attention_dims")
+    layers = ints(meta, "num_encoder_layers")
+    ffs = ints(meta, "feedforward_dims")
+    heads = ints(meta, "num_heads")
+    kernels = ints(meta, "cnn_module_kernels")
+    dss = ints(meta, "downsampling_factors")
+    pos_dim = int(meta["pos_dim"])
+    J = int(meta["joiner_dim"])
+    DD = int(meta["decoder_dim"])
+    V = int(meta["vocab_size"])
+    ctx = int(meta["context_size"])
+    fdim = int(meta["feature_dim"])
+    out_width = (((fdim - 1) // 2) - 1) // 2
+    s: List[Tuple[str, tuple, str]] = []
+
+    def lin(prefix, out_f, in_f, bias=True):
+        s.append((prefix + ".weight", (out_f, in_f), "w"))
+        if bias:
+            s.append((prefix + ".bias", (out_f,), "b"))
+
+    e = "encoder.encoder_embed."
+    s += [
+        (e + "conv.0.weight", (8, 1, 3, 3), "w"), (e + "conv.0.bias", (8,), "b"),
+        (e + "conv.3.weight", (32, 8, 3, 3), "w"), (e + "conv.3.bias", (32,), "b"),
+        (e + "conv.6.weight", (128, 32, 3, 3), "w"), (e + "conv.6.bias", (128,), "b"),
+    ]
+    lin(e + "out", dims[0], 128 * out_width)
+    for i, (D, A, L, F, H, K, ds) in enumerate(zip(dims, atts, layers, ffs, heads, kernels, dss)):
+        st = f"encoder.encoders.{i}."
+        if ds > 1:
+            Din = dims[i - 1] if i > 0 else dims[0]
+            s.append((st + "downsample.query", (Din,), "w1"))
+            if D > Din:
+                s.append((st + "downsample.extra_proj.weight", (D - Din, Din * ds), "w"))
+            s.append((st + "upsample.bias", (ds, D), "b"))
+            s.append((st + "out_combiner.weight1", (1,), "mix"))
+            st += "encoder."
+        if i >= 2 and dss[i - 1] > ds:
+            s.append((f"encoder.skip_modules.{i}.weight1", (1,), "mix"))
+        for j in range(L):
+            p = st + f"layers.{j}."
+            for k in (1, 2, 3):
+                lin(p + f"feed_forward{k}.in_proj", F, D)
+                lin(p + f"feed_forward{k}.out_proj", D, F)
+            lin(p + "pooling.proj", D, D, bias=False)
+            lin(p + "self_attn.in_proj", 2 * A + A // 2 + pos_dim * H, D)
+            lin(p + "self_attn.linear_pos", pos_dim * H, D, bias=False)
+            lin(p + "self_attn.out_proj", D, A // 2)
+            lin(p + "self_attn.in_proj2", A // 2, D, bias=False)
+            lin(p + "self_attn.out_proj2", D, A // 2)
+            for k in (1, 2):
+                s.append((p + f"conv_module{k}.pointwise_conv1.weight", (2 * D, D, 1), "w"))
+                s.append((p + f"conv_module{k}.pointwise_conv1.bias", (2 * D,), "b"))
+                s.append((p + f"conv_module{k}.depthwise_conv.weight", (D, 1, K), "w"))
+                s.append((p + f"conv_module{k}.depthwise_conv.bias", (D,), "b"))
+                s.append((p + f"conv_module{k}.pointwise_conv2.weight", (D, D, 1), "w"))
+                s.append((p + f"conv_module{k}.pointwise_conv2.bias", (D,), "b"))
+            s.append((p + "norm_final.eps", (1,), "logeps"))
+            s.append((p + "bypass_scale", (1,), "bypass"))
+    s.append(("encoder.downsample_output.query", (dims[-1],), "w1"))
+    lin("joiner.encoder_proj", J, dims[-1])
+    lin("joiner.decoder_proj", J, DD)
+    lin("joiner.output_linear", V, J)
+    s.append(("decoder.embedding.weight", (V, DD), "emb"))
+    s.append(("decoder.conv.weight", (DD, 4, ctx), "w"))
+    return s
+
+
 def tensor_specs(meta: Dict[str, str]) -> List[Tuple[str, tuple, str]]:
+    if meta["model_type"] == "zipformer":
+        return zipformer1_tensor_specs(meta)
     if meta["model_type"] == "conformer":
         return conformer_tensor_specs(meta)
     if meta["model_type"] == "lstm":
@@ -260,6 +335,10 @@ def _init(name: str, shape: tuple, kind: str, seed: int) -> np.ndarray:
         # identity, so the input's temporal structure survives 19 layers
         lo, hi = (0.3, 0.9) if "out_combiner" in name else (0.05, 0.25)
         return g.uniform(lo, hi, shape).astype(np.float32)
+    if kind == "w1":  # a vector used as a dot-product weight (AttentionDownsample.query)
+        return (g.standard_normal(shape) / np.sqrt(shape[0])).astype(np.float32)
+    if kind == "mix":  # SimpleCombiner.weight1
+        return g.uniform(0.2, 0.8, shape).astype(np.float32)
     if kind == "logscale":
         return g.uniform(-0.2, 0.2, shape).astype(np.float32)
     if kind == "dsbias":
@@ -287,7 +366,7 @@ def write_synthetic_model(path: str, preset_name: str, seed: int = 20231212, bla
     meta["synthetic_seed"] = str(seed)
     meta["synthetic_blank_bias"] = repr(float(blank_bias))
 
-    conformer = meta["model_type"] in ("conformer", "lstm")  # stateless2-style residual branches
+    conformer = meta["model_type"] in ("conformer", "lstm", "zipformer")  # residual branches without a per-channel bypass
 
     def gen():
         for name, shape, kind in tensor_specs(meta):
@@ -298,7 +377,8 @@ def write_synthetic_model(path: str, preset_name: str, seed: int = 20231212, bla
                 a *= np.float32(4.0)
             if name == "joiner.encoder_proj.weight":
                 a *= np.float32(4.0)  # let the (small) temporal variation reach the logits
-            if conformer and (name.endswith(".4.weight") or name.endswith("out_proj.weight") or name.endswith("pointwise_conv2.weight")):
+            if conformer and (name.endswith(".4.weight") or name.endswith("out_proj.weight") or name.endswith("pointwise_conv2.weight")
+                              or name.endswith("out_proj2.weight") or name.endswith("pooling.proj.weight")):
                 a *= np.float32(0.25)  # the residual branches' output layers (icefall initial_scale = 0.25)
             if name.endswith("encoder_embed.conv.0.weight"):
                 # zero-sum along time: a constant-in-time input (the large DC of

@@ -58,6 +58,8 @@ struct k2o_model {
     int ns;
     int dim[MAX_STACKS], nlayer[MAX_STACKS], ff[MAX_STACKS], heads[MAX_STACKS], kern[MAX_STACKS], ds[MAX_STACKS];
     int qhd[MAX_STACKS], vhd[MAX_STACKS], phd[MAX_STACKS];
+    int att[MAX_STACKS]; /* model_type "zipformer" (v1): attention_dims */
+    int zip1;            /* model_type "zipformer": streaming Zipformer v1, see k2_oracle_zipformer1.c */
     int pos_dim, J, DD, V, ctx, feat;
     int dmax;
     int conformer; /* model_type "conformer": see k2_oracle_conformer.c */
@@ -227,8 +229,9 @@ k2o_model* k2o_model_load(const char* path) {
     m->conformer = mt && !strcmp(mt, "conformer");
     m->ctc = mt && !strcmp(mt, "zipformer2ctc");
     m->lstm = mt && !strcmp(mt, "lstm");
+    m->zip1 = mt && !strcmp(mt, "zipformer");
     m->rnn_hidden = meta_int(m, "rnn_hidden_size", 0);
-    if (!mt || (strcmp(mt, "zipformer2") && !m->conformer && !m->ctc && !m->lstm)) {
+    if (!mt || (strcmp(mt, "zipformer2") && !m->conformer && !m->ctc && !m->lstm && !m->zip1)) {
         fail("model_type %s not supported by the oracle", mt ? mt : "(none)");
         k2o_model_free(m);
         return NULL;
@@ -242,6 +245,7 @@ k2o_model* k2o_model_load(const char* path) {
     parse_csv(k2o_meta(m, "query_head_dims"), m->qhd, MAX_STACKS);
     parse_csv(k2o_meta(m, "value_head_dims"), m->vhd, MAX_STACKS);
     parse_csv(k2o_meta(m, "pos_head_dims"), m->phd, MAX_STACKS);
+    parse_csv(k2o_meta(m, "attention_dims"), m->att, MAX_STACKS);
     m->pos_dim = meta_int(m, "pos_dim", 48);
     m->J = meta_int(m, "joiner_dim", 512);
     m->DD = meta_int(m, "decoder_dim", 512);

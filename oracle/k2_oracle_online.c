@@ -26,6 +26,8 @@ struct k2o_online_stream {
     float* embed;     /* [128][3][19] */
     int64_t processed_len;
     float *conf_attn, *conf_conv; /* streaming conformer: cached_attn [L][left][D], cached_conv [L][K-1][D] */
+    float **avg; float* clen; size_t* navg; /* model_type zipformer (v1): cached_avg [D] and cached_len per layer; key / val1 / val2 /
+                                               conv1 / conv2 above hold cached_key / cached_val / cached_val2 / cached_conv1 / cached_conv2 */
     float *lstm_h, *lstm_c; /* model_type lstm: h [layers][d_model], c [layers][rnn_hidden] (OnlineProjOfLstm.cs:55-75) */
     int64_t hyp[2];
     int64_t* tokens;  /* Tokens list, starts [blank, blank] (OnlineStream.cs:45) */
@@ -42,6 +44,7 @@ static int online_left(const k2o_model* m, int si) {
 int k2o_online_chunk_length(const k2o_model* m) { return meta_int(m, "T", 45); }
 int k2o_online_shift_length(const k2o_model* m) { return meta_int(m, "decode_chunk_len", 32); }
 int k2o_online_frames_per_chunk(const k2o_model* m) {
+    if (m->zip1) return ((meta_int(m, "T", 39) - 7) / 2 + 1) / 2;
     if (m->lstm) return lstm_out_frames(meta_int(m, "T", 9));
     if (m->conformer) return meta_int(m, "chunk_size", 16);
     return (meta_int(m, "decode_chunk_len", 32) / 2 + 1) / 2;
@@ -82,6 +85,36 @@ k2o_online_stream* k2o_online_stream_create(const k2o_model* m) {
         return s;
     }
     for (int i = 0; i < m->ns; i++) s->nl += m->nlayer[i];
+    if (m->zip1) {   /* OnlineProjOfZipformer.GetEncoderInitStates (:56-111), B = 1, every cache zero */
+        s->key = calloc(s->nl, sizeof(float*)); s->val1 = calloc(s->nl, sizeof(float*)); s->val2 = calloc(s->nl, sizeof(float*));
+        s->conv1 = calloc(s->nl, sizeof(float*)); s->conv2 = calloc(s->nl, sizeof(float*)); s->avg = calloc(s->nl, sizeof(float*));
+        s->nonlin = calloc(s->nl, sizeof(float*));
+        s->nkey = calloc(s->nl, sizeof(size_t)); s->nval = calloc(s->nl, sizeof(size_t)); s->nconv = calloc(s->nl, sizeof(size_t));
+        s->navg = calloc(s->nl, sizeof(size_t)); s->nnonlin = calloc(s->nl, sizeof(size_t));
+        s->clen = calloc(s->nl, sizeof(float));
+        int l = 0;
+        for (int si = 0; si < m->ns; si++)
+            for (int li = 0; li < m->nlayer[si]; li++, l++) {
+                int L = online_left(m, si);
+                s->nkey[l] = (size_t)L * m->att[si];
+                s->nval[l] = (size_t)L * (m->att[si] / 2);
+                s->nconv[l] = (size_t)m->dim[si] * (m->kern[si] - 1);
+                s->navg[l] = (size_t)m->dim[si];
+                s->key[l] = calloc(s->nkey[l], sizeof(float));
+                s->val1[l] = calloc(s->nval[l], sizeof(float));
+                s->val2[l] = calloc(s->nval[l], sizeof(float));
+                s->conv1[l] = calloc(s->nconv[l], sizeof(float));
+                s->conv2[l] = calloc(s->nconv[l], sizeof(float));
+                s->avg[l] = calloc(s->navg[l], sizeof(float));
+            }
+        s->cap_tokens = 64;
+        s->tokens = malloc(sizeof(int64_t) * s->cap_tokens);
+        s->tokens[0] = s->tokens[1] = 0;
+        s->n_tokens = 2;
+        s->cap_ts = 64;
+        s->timestamps = malloc(sizeof(int32_t) * s->cap_ts);
+        return s;
+    }
     s->key = calloc(s->nl, sizeof(float*)); s->nonlin = calloc(s->nl, sizeof(float*));
     s->val1 = calloc(s->nl, sizeof(float*)); s->val2 = calloc(s->nl, sizeof(float*));
     s->conv1 = calloc(s->nl, sizeof(float*)); s->conv2 = calloc(s->nl, sizeof(float*));
@@ -125,6 +158,10 @@ void k2o_online_stream_free(k2o_online_stream* s) {
         free(s);
         return;
     }
+    if (s->avg) {
+        for (int l = 0; l < s->nl; l++) free(s->avg[l]);
+        free(s->avg); free(s->navg); free(s->clen);
+    }
     for (int l = 0; l < s->nl; l++) {
         free(s->key[l]); free(s->nonlin[l]); free(s->val1[l]); free(s->val2[l]); free(s->conv1[l]); free(s->conv2[l]);
     }
@@ -135,12 +172,23 @@ void k2o_online_stream_free(k2o_online_stream* s) {
 }
 int k2o_online_stream_num_layers(const k2o_online_stream* s) { return s->nl; }
 int64_t k2o_online_stream_processed_len(const k2o_online_stream* s) { return s->processed_len; }
-/* kind: 0 key, 1 nonlin, 2 val1, 3 val2, 4 conv1, 5 conv2, 6 embed (layer ignored) */
+/* kind: 0 key, 1 nonlin, 2 val1, 3 val2, 4 conv1, 5 conv2, 6 embed (layer ignored);
+ * zipformer (v1) streams: 0 cached_key, 1 cached_avg, 2 cached_val, 3 cached_val2, 4 cached_conv1, 5 cached_conv2, 7 cached_len (1 float) */
 int64_t k2o_online_stream_state(const k2o_online_stream* s, int layer, int kind, float* out, int64_t cap) {
     const float* p = NULL;
     size_t n = 0;
     if (s->lstm_h || s->conf_attn) {
         return fail("use k2o_online_stream_lstm_state for an lstm stream");
+    }
+    if (layer < 0 || layer >= s->nl) return fail("bad layer %d", layer);
+    if (s->avg && (kind == 1 || kind == 6 || kind == 7)) {
+        if (kind == 6) return fail("a zipformer (v1) stream has no embed state");
+        p = kind == 1 ? s->avg[layer] : s->clen + layer;
+        n = kind == 1 ? s->navg[layer] : 1;
+        if (!out) return (int64_t)n;
+        if ((int64_t)n > cap) return fail("state buffer too small");
+        memcpy(out, p, sizeof(float) * n);
+        return (int64_t)n;
     }
     switch (kind) {
         case 0: p = s->key[layer]; n = s->nkey[layer]; break;
@@ -434,10 +482,13 @@ static void online_layer(const k2o_model* m, k2o_online_stream* s, int si, int l
     free(nm); free(aw); free(orig);
 }
 
+#include "k2_oracle_zipformer1.c"
+
 /* OnnxEncoder.forward of the streaming export for ONE stream: x [T,80] (already log-floored) -> enc_out [T'c, J] */
 static int lstm_online_chunk(const k2o_model* m, k2o_online_stream* s, const float* x, float* enc_out);
 int k2o_online_encoder_chunk(const k2o_model* m, k2o_online_stream* s, const float* x, float* enc_out) {
     if (m->lstm) return lstm_online_chunk(m, s, x, enc_out);
+    if (m->zip1) return z1_stream_chunk(m, s, x, enc_out);
     if (m->conformer) {   /* model semantics: new processed_lens = processed_lens + chunk frames */
         const int left = meta_int(m, "left_context", 64);
         int tc = conformer_stream_chunk(m, x, k2o_online_chunk_length(m), left, s->processed_len, s->conf_attn, s->conf_conv, enc_out);

@@ -8,7 +8,9 @@ import numpy as np
 
 from . import Oracle, OracleError, _fp, _ip, _lp, lib
 
-_KINDS = {"key": 0, "nonlin": 1, "val1": 2, "val2": 3, "conv1": 4, "conv2": 5, "embed": 6}
+_KINDS = {"key": 0, "nonlin": 1, "val1": 2, "val2": 3, "conv1": 4, "conv2": 5, "embed": 6,
+          # Zipformer v1 streams (OnlineProjOfZipformer.cs:56-111)
+          "avg": 1, "val": 2, "len": 7}
 
 
 def _bind(L):
