@@ -511,7 +511,9 @@ class OfflineRecognizer:
 
 
 # ============================== streaming: OnlineStream / OnlineRecognizer ===============================
-_STATE_KINDS = {"key": 0, "nonlin": 1, "val1": 2, "val2": 3, "conv1": 4, "conv2": 5, "embed": 6, "lstm_h": 0, "lstm_c": 1, "conf_attn": 0, "conf_conv": 1}
+_STATE_KINDS = {"key": 0, "nonlin": 1, "val1": 2, "val2": 3, "conv1": 4, "conv2": 5, "embed": 6, "lstm_h": 0, "lstm_c": 1, "conf_attn": 0, "conf_conv": 1,
+                # Zipformer v1 streams (OnlineProjOfZipformer.cs:56-111)
+                "avg": 1, "val": 2, "len": 7}
 
 
 def _bind_online(L):

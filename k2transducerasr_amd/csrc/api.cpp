@@ -588,6 +588,7 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
                 s->hyp[1] = s->tokens[s->tokens.size() - 1];
             }
             if (c.conformer) s->processed_len = R;   // OnlineProjOfConformer.unstack_states (:229) stores the BATCH SIZE (sic), not the model's output
+            else if (c.zip1) s->processed_len += (c.chunk_T - 7) / 2;  // no processed_lens state in v1; kept as a frame counter
             else s->processed_len += (c.chunk_T - 7) / 2 - 3;      // new_processed_lens = processed_lens + x_lens
             decoded[idx[r]] = 1;
             n_new_tokens[idx[r]] = n[r];

@@ -13,7 +13,8 @@ namespace k2hip {
 
 // float offsets of one stream's caches inside its slot of the state pool (OnlineProjOfZipformer2.cs:63-111)
 struct OnlineLayout {
-    std::vector<long long> key, nonlin, val1, val2, conv1, conv2;  // per layer
+    std::vector<long long> key, nonlin, val1, val2, conv1, conv2;  // per layer (Zipformer v1: nonlin = cached_avg, val1 = cached_val)
+    std::vector<long long> clen;                                   // Zipformer v1: cached_len (one float) per layer
     std::vector<std::array<long long, 6>> sizes;                   // per layer, float counts in the reference's order
     long long embed = 0;
     long long floats_per_stream = 0;
@@ -112,6 +113,13 @@ class Engine {
     void lstm_layer(const Ctx& c, int li, float* x, const float* h0, int ldh0, float* cst, int B, int T, float* y);
     float* lstm_forward(const Ctx& c, const float* x, int B, int T, int* Tp, int tap, float** tap_ptr, int* tap_rows, int* tap_dim);
     float* lstm_chunk(const Ctx& c, const float* x, const int* d_slots, int B);
+    // streaming Zipformer v1 (zipformer1_engine.cpp)
+    const float* sinus_pos_emb(int Tc, int left, int D);
+    const float* zip1_pos_proj(const Ctx& c, int l, const std::string& pfx, int Tc, int L, int D, int H);
+    float* zip1_embed(const Ctx& c, const float* x, int B, int T, int* Tc_out);
+    void zip1_layer(const Ctx& c, int si, const std::string& pfx, int l, float* x, const float* pp, const int* d_slots, int B, int Tc, int L);
+    float* zip1_chunk(const Ctx& c, const float* x, const int* d_slots, int B, int* Tp_out);
+    std::map<int, float*> z1_pp_cache_;  // per layer: linear_pos(pos_emb), input-independent
     // offline Conformer (conformer_engine.cpp)
     const float* conformer_pos_emb_left(int Tc, int left);
     float* conformer_chunk(const Ctx& c, const float* x, const int* d_slots, const long long* d_plen, int B, int* Tc_out);

@@ -241,6 +241,23 @@ void glu_causal_conv(const Ctx& ctx, const float* x2, float* pool, long long slo
                      const float* wc, const float* bc, const float* ww, const float* bw, const float* sc, float* y, int B,
                      int Tc, int D, int K);
 void zero_floats(const Ctx& ctx, float* p, long long n);
+// ---- streaming Zipformer v1 (zipformer1.hip; OnlineProjOfZipformer) ------------------------------
+// running mean over every frame seen so far: out [B*Tc, D]; cached_avg (avg_off, [D]) and cached_len (len_off, 1 float) per slot
+void z1_pool(const Ctx& ctx, const float* x, float* pool, long long slot_stride, long long avg_off, long long len_off, const int* slots,
+             float* out, int B, int Tc, int D);
+// qkvp rows (ld): q [A] | k [A] | v [A/2] | p [H*4]; kcat [B, L+Tc, A]; pp [2Tc-1+L, H*4]; aw out [H][B][Tc][KLp]
+void z1_attn(const Ctx& ctx, const float* qkvp, int ld, const float* kcat, const float* pp, float* aw, int B, int Tc, int L, int KLp,
+             int H, int A);
+// y = DoubleSwish(dwconv_K([cache ; glu(x2)]) + bias); cache [D][K-1] per slot at `off`, updated
+void z1_glu_conv(const Ctx& ctx, const float* x2, float* pool, long long slot_stride, long long off, const int* slots, const float* w,
+                 const float* bias, float* y, int B, int Tc, int D, int K);
+// y = orig + (BasicNorm(x) - orig) * bypass_scale (scalar)
+void z1_norm_bypass(const Ctx& ctx, const float* x, const float* orig, const float* log_eps, const float* bscale, float* y, int M, int D);
+// AttentionDownsample, first Din channels: x [B,T,Din] -> y [B,ceil(T/ds),ldy]
+void z1_attn_downsample(const Ctx& ctx, const float* x, const float* query, float* y, int B, int T, int Din, int ldy, int ds);
+// SimpleCombiner(src1 [B*T,d1], src2) -> y [B*T,d2]; ub != null: src2 = SimpleUpsample(xd [B,Td,d2], ub [ds,d2])[:T]
+void z1_combine(const Ctx& ctx, const float* s1, int d1, const float* s2, int d2, const float* w1, const float* ub, int ds, int B, int T,
+                int Td, float* y);
 void logfloor_inplace(const Ctx& ctx, float* x, long long n);
 
 }  // namespace k2hip

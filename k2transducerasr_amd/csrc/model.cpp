@@ -177,8 +177,10 @@ void Model::parse_config() {
     c.conformer = c.model_type == "conformer";
     c.ctc = c.model_type == "zipformer2ctc";
     c.lstm = c.model_type == "lstm";
-    if (c.model_type != "zipformer2" && !c.conformer && !c.ctc && !c.lstm)
-        failf(K2HIP_ERR_UNSUPPORTED, "model_type '%s' is not supported (have: zipformer2, zipformer2ctc, conformer, lstm)", c.model_type.c_str());
+    c.zip1 = c.model_type == "zipformer";
+    if (c.model_type != "zipformer2" && !c.conformer && !c.ctc && !c.lstm && !c.zip1)
+        failf(K2HIP_ERR_UNSUPPORTED, "model_type '%s' is not supported (have: zipformer2, zipformer2ctc, zipformer, conformer, lstm)",
+              c.model_type.c_str());
     auto fill = [&](const char* k, int* dst) {
         auto v = csv_ints(get(k, ""));
         if ((int)v.size() > kMaxStacks) failf(K2HIP_ERR_INVALID, "metadata %s has too many entries", k);
@@ -197,7 +199,20 @@ void Model::parse_config() {
         K2_REQUIRE(c.rnn_hidden > 0 && c.rnn_hidden % 4 == 0 && c.dim[0] == geti("d_model", c.dim[0]), "lstm: bad d_model / rnn_hidden_size");
         c.heads[0] = 1; c.kern[0] = 1; c.ds[0] = 1; c.qhd[0] = 32; c.phd[0] = 4; c.vhd[0] = 12;  // unused
     }
-    for (int i = 0; i < (c.lstm ? 0 : c.conformer ? 4 : 8); i++)
+    if (c.zip1) {
+        K2_REQUIRE(fill("attention_dims", c.att) == c.ns, "metadata attention_dims must have %d entries", c.ns);
+        for (int i = 0; i < 5; i++)
+            if (fill(keys[i], dsts[i]) != c.ns) failf(K2HIP_ERR_INVALID, "metadata %s must have %d entries", keys[i], c.ns);
+        K2_REQUIRE(geti("pos_dim", 4) == 4, "zipformer: pos_dim %d unsupported (4)", geti("pos_dim", 4));
+        for (int i = 0; i < c.ns; i++) {
+            K2_REQUIRE(c.heads[i] > 0 && c.att[i] % (2 * c.heads[i]) == 0 && (c.att[i] / c.heads[i]) % 4 == 0 && c.att[i] % 8 == 0,
+                       "zipformer: attention_dims[%d]=%d with %d heads unsupported", i, c.att[i], c.heads[i]);
+            K2_REQUIRE(i == 0 || c.dim[i] >= c.dim[i - 1], "zipformer: encoder_dims must not shrink (stack %d: %d -> %d)", i, c.dim[i - 1], c.dim[i]);
+            K2_REQUIRE(c.ds[i] > 1 || i == 0 || c.dim[i] == c.dim[i - 1], "zipformer: stack %d has downsampling 1 but changes width", i);
+            c.qhd[i] = 32; c.phd[i] = 4; c.vhd[i] = c.att[i] / 2 / c.heads[i];  // qhd: keep the Zipformer2 checks below quiet
+        }
+    }
+    for (int i = 0; i < (c.lstm || c.zip1 ? 0 : c.conformer ? 4 : 8); i++)
         if (fill(keys[i], dsts[i]) != c.ns) failf(K2HIP_ERR_INVALID, "metadata %s must have %d entries", keys[i], c.ns);
     if (c.conformer) {
         K2_REQUIRE(c.ns == 1, "conformer: encoder_dims must have one entry");
@@ -229,6 +244,10 @@ void Model::parse_config() {
             K2_REQUIRE(c.shift == 4 * chunk && c.chunk_T == (chunk + 2) * 4 + 3 && c.left[0] > 0 && c.left[0] % 4 == 0,
                        "streaming conformer geometry T=%d, decode_chunk_len=%d, chunk_size=%d, left_context=%d unsupported", c.chunk_T,
                        c.shift, chunk, c.left[0]);
+        } else if (c.zip1) {
+            if (fill("left_context_len", c.left) != c.ns) failf(K2HIP_ERR_INVALID, "metadata left_context_len must have %d entries", c.ns);
+            K2_REQUIRE(c.chunk_T == c.shift + 7 && c.shift % 4 == 0, "zipformer streaming geometry T=%d, decode_chunk_len=%d unsupported", c.chunk_T, c.shift);
+            for (int i = 0; i < c.ns; i++) K2_REQUIRE(c.left[i] > 0, "zipformer: left_context_len[%d] must be positive", i);
         } else {
             if (fill("left_context_len", c.left) != c.ns) failf(K2HIP_ERR_INVALID, "metadata left_context_len must have %d entries", c.ns);
             K2_REQUIRE(c.chunk_T == c.shift + 13 && c.shift % 4 == 0, "streaming geometry T=%d, decode_chunk_len=%d unsupported", c.chunk_T, c.shift);
@@ -294,7 +313,7 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
             }
         }
     }
-    if ((c.conformer || c.lstm) && has("encoder.encoder_embed.conv.0.weight")) {
+    if ((c.conformer || c.lstm || c.zip1) && has("encoder.encoder_embed.conv.0.weight")) {
         for (const char* nm : {"encoder.encoder_embed.conv.3.weight", "encoder.encoder_embed.conv.6.weight"}) {
             const Tensor& t = tensor(nm);
             int Co = (int)t.dims[0], Ci = (int)t.dims[1];
@@ -327,7 +346,7 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
             push(std::string(nm) + "#kd", std::move(v), {K, D});
         }
     }
-    const bool has_encoder = !c.conformer && has("encoder_embed.conv.0.weight");
+    const bool has_encoder = !c.conformer && !c.zip1 && has("encoder_embed.conv.0.weight");
     if (has_encoder) {
     // conv filters [Co,Ci,3,3] -> [Co][kt][kf][ci]  (K index of the implicit GEMM over NHWC input)
     for (const char* nm : {"encoder_embed.conv.4.weight", "encoder_embed.conv.7.weight"}) {

@@ -50,6 +50,10 @@ struct Config {
     // dim[0] = d_model, ff[0], nlayer[0], rnn_hidden; chunk_T = 9, shift = 4, one encoder frame per chunk
     bool lstm = false;
     int rnn_hidden = 0;
+    // model_type "zipformer" (streaming Zipformer v1, OnlineProjOfZipformer): att[] = attention_dims; qhd = att / heads,
+    // vhd = att / 2 / heads, phd = pos_dim (4); chunk_T = shift + 7; see zipformer1_engine.cpp
+    bool zip1 = false;
+    int att[kMaxStacks] = {0};
     int enc_dim() const { return ctc ? V : J; }
     int conv_cpg = 4;  // decoder conv input channels per group (4: Zipformer recipes; DD: stateless2 decoder, groups = 1)
     bool streaming = false;

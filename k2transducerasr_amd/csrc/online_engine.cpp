@@ -39,6 +39,28 @@ void Engine::online_ensure_pool() {
         v.push_back(off);
         off += (n + 3) / 4 * 4;  // keep every cache 16-byte aligned
     };
+    if (c.zip1) {  // OnlineProjOfZipformer.GetEncoderInitStates (:56-111), batch 1, layer by layer
+        for (int si = 0; si < c.ns; si++)
+            for (int li = 0; li < c.nlayer[si]; li++) {
+                const long long D = c.dim[si], A = c.att[si], left = c.left[si], K = c.kern[si];
+                put(L.clen, 1);
+                put(L.nonlin, D);  // cached_avg
+                put(L.key, left * A);
+                put(L.val1, left * (A / 2));
+                put(L.val2, left * (A / 2));
+                put(L.conv1, D * (K - 1));
+                put(L.conv2, D * (K - 1));
+                L.sizes.push_back({left * A, D, left * (A / 2), left * (A / 2), D * (K - 1), D * (K - 1)});
+                L.nl++;
+            }
+        L.floats_per_stream = (off + 63) / 64 * 64;
+        online_cap_ = 256;
+        if (const char* e = getenv("K2HIP_MAX_STREAMS")) online_cap_ = std::max(1, atoi(e));
+        K2_HIP(hipSetDevice(device_));
+        K2_HIP(hipMalloc(&online_pool_, sizeof(float) * (size_t)L.floats_per_stream * online_cap_));
+        for (int i = online_cap_ - 1; i >= 0; i--) free_slots_.push_back(i);
+        return;
+    }
     for (int si = 0; si < c.ns; si++) {
         const int D = c.dim[si], H = c.heads[si], left = c.left[si];
         for (int li = 0; li < c.nlayer[si]; li++) {
@@ -94,7 +116,12 @@ void Engine::online_read_state(int slot, int layer, int kind, float* out, int64_
         K2_REQUIRE(layer >= 0 && layer < cf.nlayer[0] && (kind == 0 || kind == 1), "bad lstm state index layer=%d kind=%d", layer, kind);
         cnt = kind == 0 ? cf.dim[0] : cf.rnn_hidden;
         off = kind == 0 ? (long long)layer * cf.dim[0] : (long long)cf.nlayer[0] * cf.dim[0] + (long long)layer * cf.rnn_hidden;
+    } else if (model_->cfg().zip1 && kind == 7) {  // cached_len of `layer`
+        K2_REQUIRE(layer >= 0 && layer < lay_.nl, "bad state index layer=%d", layer);
+        off = lay_.clen[layer];
+        cnt = 1;
     } else if (kind == 6) {
+        K2_REQUIRE(!model_->cfg().zip1, "a zipformer (v1) stream has no embed state");
         off = lay_.embed;
         cnt = 128 * 3 * 19;
     } else {
@@ -115,6 +142,7 @@ int Engine::online_frames_per_chunk() const {
     const Config& c = model_->cfg();
     if (c.lstm) return lstm_out_frames(c.chunk_T);
     if (c.conformer) return conformer_out_frames(c.chunk_T) - 2;
+    if (c.zip1) return ((c.chunk_T - 7) / 2 + 1) / 2;
     return (c.shift / 2 + 1) / 2;
 }
 
@@ -319,9 +347,9 @@ void Engine::online_step(const int* slots, const float* chunks, const long long*
             K2_HIP(hipMemcpyAsync(d_hyp, hyps, sizeof(long long) * 2 * B, hipMemcpyHostToDevice, c.stream));
         }
         logfloor_inplace(c, d_x, (long long)B * T * cf.feat);  // online PadSequence (PadHelper.cs:9-13,58)
-        if (cf.lstm || cf.conformer) {
+        if (cf.lstm || cf.conformer || cf.zip1) {
             int tc = Tp;
-            float* enc = cf.lstm ? lstm_chunk(c, d_x, d_slots, B) : conformer_chunk(c, d_x, d_slots, d_plen, B, &tc);
+            float* enc = cf.lstm ? lstm_chunk(c, d_x, d_slots, B) : cf.zip1 ? zip1_chunk(c, d_x, d_slots, B, &tc) : conformer_chunk(c, d_x, d_slots, d_plen, B, &tc);
             K2_REQUIRE(tc == Tp, "internal: chunk yields %d frames, expected %d", tc, Tp);
             if (!c.dry) {
                 K2_HIP(hipEventRecord(ev_[3], c.stream));
