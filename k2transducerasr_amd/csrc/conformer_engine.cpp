@@ -100,8 +100,7 @@ void Engine::conformer_layer(const Ctx& c, int li, float* x, const float* pe, in
     {   // x += out_proj(softmax((q+u) k^T + rel_shift((q+v) p^T)) v)
         float* qkv = hid;
         linear(c, x, D, w("self_attn.in_proj.weight"), w("self_attn.in_proj.bias"), qkv, 3 * D, M, D, 3 * D);
-        float* pp = ar.take<float>((int64_t)NP * D);
-        linear(c, pe, D, w("self_attn.linear_pos.weight"), nullptr, pp, D, NP, D, D);
+        const float* pp = pos_proj_cached(c, 3000 + li, pe, D, w("self_attn.linear_pos.weight"), NP, D);
         float* qu = ar.take<float>((int64_t)M * D);
         float* qv = ar.take<float>((int64_t)M * D);
         conformer_qprep(c, qkv, w("self_attn.pos_bias_u"), w("self_attn.pos_bias_v"), qu, qv, M, D, 1.0f / sqrtf((float)dk));
@@ -221,7 +220,6 @@ float* Engine::conformer_chunk(const Ctx& c, const float* x, const int* d_slots,
     float* q = ar.take<float>((int64_t)M * D);
     float* qu = ar.take<float>((int64_t)M * D);
     float* qv = ar.take<float>((int64_t)M * D);
-    float* pp = ar.take<float>((int64_t)NP * D);
     float* ac = ar.take<float>((int64_t)B * H * Tc * KLp);
     float* bd = ar.take<float>((int64_t)B * H * Tc * NPp);
     float* ccat = ar.take<float>((int64_t)B * (K - 1 + Tc) * D);
@@ -244,7 +242,7 @@ float* Engine::conformer_chunk(const Ctx& c, const float* x, const int* d_slots,
             const float* bin = w("self_attn.in_proj.bias");
             linear(c, xs, D, Win, bin, q, D, M, D, D);                                    // q from the chunk
             linear(c, cat, D, Win + (long long)D * D, bin + D, kv, 2 * D, B * KL, D, 2 * D);  // k | v from the keys
-            linear(c, pe, D, w("self_attn.linear_pos.weight"), nullptr, pp, D, NP, D, D);
+            const float* pp = pos_proj_cached(c, 4000 + li, pe, D, w("self_attn.linear_pos.weight"), NP, D);
             conformer_qprep(c, q, w("self_attn.pos_bias_u"), w("self_attn.pos_bias_v"), qu, qv, M, D, 1.0f / sqrtf((float)dk), D);
             {
                 GemmArgs a;

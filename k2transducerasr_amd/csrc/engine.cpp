@@ -40,6 +40,7 @@ Engine::~Engine() {
     }
     if (stream2_) (void)hipStreamDestroy(stream2_);
     for (auto& kv : pe_cache_) (void)hipFree(kv.second);
+    for (auto& kv : pp_cache_) (void)hipFree(kv.second);
     if (online_pool_) (void)hipFree(online_pool_);
     if (d_ptab_) (void)hipFree(d_ptab_);
     for (auto& e : ev_)
@@ -188,6 +189,30 @@ float* Engine::encoder_embed(const Ctx& c, const float* x, int B, int T, int* T5
     return out;
 }
 
+const float* Engine::pos_proj_cached(const Ctx& c, int layer, const float* pe, int pe_dim, const float* W, int rows, int ncols) {
+    if (c.dry) return nullptr;
+    const auto key = std::make_pair(layer, rows);
+    auto it = pp_cache_.find(key);
+    if (it != pp_cache_.end()) return it->second;
+    const size_t bytes = sizeof(float) * (size_t)rows * ncols;
+    if (pp_cache_bytes_ + bytes > ((size_t)1 << 30)) {  // many distinct utterance lengths: start over (stream-ordered frees)
+        K2_HIP(hipDeviceSynchronize());
+        for (auto& kv : pp_cache_) (void)hipFree(kv.second);
+        pp_cache_.clear();
+        pp_cache_bytes_ = 0;
+    }
+    float* pp = nullptr;
+    K2_HIP(hipMalloc(&pp, bytes));
+    Ctx plain = c;  // not one of the call's logged / timed GEMMs
+    plain.instrument = false;
+    plain.gemm_log = nullptr;
+    linear(plain, pe, pe_dim, W, nullptr, pp, ncols, rows, pe_dim, ncols);
+    K2_HIP(hipStreamSynchronize(c.stream));  // other HIP streams of this engine may read it next
+    pp_cache_[key] = pp;
+    pp_cache_bytes_ += bytes;
+    return pp;
+}
+
 // ---------------------------------------------------------------------------
 // Zipformer2EncoderLayer.forward (inference), in place on x [B*T, D]
 // ---------------------------------------------------------------------------
@@ -205,9 +230,9 @@ void Engine::encoder_layer(const Ctx& c, int si, int li, float* x, const float* 
     // attention weights, shared by nonlin_attention / self_attn1 / self_attn2
     float* qkp = ar.take<float>((int64_t)M * inproj);
     linear(c, x, D, w("self_attn_weights.in_proj.weight"), w("self_attn_weights.in_proj.bias"), qkp, inproj, M, D, inproj);
-    float* pp = ar.take<float>((int64_t)(2 * T - 1) * cf.phd[si] * H);
-    linear(c, pe, cf.pos_dim, w("self_attn_weights.linear_pos.weight"), nullptr, pp, cf.phd[si] * H, 2 * T - 1, cf.pos_dim,
-           cf.phd[si] * H);
+    int gl = li;  // global layer index: the cache key of the layer's positional projection
+    for (int i = 0; i < si; i++) gl += cf.nlayer[i];
+    const float* pp = pos_proj_cached(c, gl, pe, cf.pos_dim, w("self_attn_weights.linear_pos.weight"), 2 * T - 1, cf.phd[si] * H);
     float* aw = ar.take<float>((int64_t)H * B * T * Tp);
     attn_scores_softmax(c, qkp, inproj, pp, aw, B, T, Tp, H);
 

@@ -103,6 +103,11 @@ class Engine {
     void greedy_device(const Ctx& c, const float* enc, int B, int Tp, bool single, long long* d_tok, int* d_ts, int* d_n,
                        int max_tokens, int* d_overflow);
     const float* pos_emb(int T);  // cached CompactRelPositionalEncoding table on device
+    // linear_pos(pos_emb) of one layer: [rows, ncols] = pe [rows, pe_dim] . W^T.  It does not depend on the audio, so it is computed
+    // once per (layer, rows) and kept on the device (a handful of utterance lengths in flight; the cache is dropped when it grows)
+    const float* pos_proj_cached(const Ctx& c, int layer, const float* pe, int pe_dim, const float* W, int rows, int ncols);
+    std::map<std::pair<int, int>, float*> pp_cache_;
+    size_t pp_cache_bytes_ = 0;
     void ctc_device(const Ctx& c, const float* logp, int B, int Tp, long long* d_tok, int* d_ts, int* d_n, int max_tokens,
                     int* d_overflow);
     void beam_device(const Ctx& c, const float* enc, int B, int Tp, long long* d_tok, int* d_ts, int* d_n, int max_tokens,
@@ -115,11 +120,9 @@ class Engine {
     float* lstm_chunk(const Ctx& c, const float* x, const int* d_slots, int B);
     // streaming Zipformer v1 (zipformer1_engine.cpp)
     const float* sinus_pos_emb(int Tc, int left, int D);
-    const float* zip1_pos_proj(const Ctx& c, int l, const std::string& pfx, int Tc, int L, int D, int H);
     float* zip1_embed(const Ctx& c, const float* x, int B, int T, int* Tc_out);
     void zip1_layer(const Ctx& c, int si, const std::string& pfx, int l, float* x, const float* pp, const int* d_slots, int B, int Tc, int L);
     float* zip1_chunk(const Ctx& c, const float* x, const int* d_slots, int B, int* Tp_out);
-    std::map<int, float*> z1_pp_cache_;  // per layer: linear_pos(pos_emb), input-independent
     // offline Conformer (conformer_engine.cpp)
     const float* conformer_pos_emb_left(int Tc, int left);
     float* conformer_chunk(const Ctx& c, const float* x, const int* d_slots, const long long* d_plen, int B, int* Tc_out);

@@ -244,8 +244,7 @@ void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x,
     linear(c, x, D, w("self_attn_weights.in_proj.weight"), w("self_attn_weights.in_proj.bias"), qkp, inproj, M, D, inproj);
     float* kcat = ar.take<float>((int64_t)B * KL * qh * H);
     cat_shift(c, online_pool_, SS, lay_.key[l], d_slots, qkp + qh * H, inproj, kcat, B, L, Tc, qh * H);
-    float* pp = ar.take<float>((int64_t)n2 * ph * H);
-    linear(c, pe, cf.pos_dim, w("self_attn_weights.linear_pos.weight"), nullptr, pp, ph * H, n2, cf.pos_dim, ph * H);
+    const float* pp = pos_proj_cached(c, 1000 + l, pe, cf.pos_dim, w("self_attn_weights.linear_pos.weight"), n2, ph * H);
     float* aw = ar.take<float>((int64_t)H * B * Tc * KLp);
     attn_stream(c, qkp, inproj, kcat, pp, d_plen, aw, B, Tc, L, KLp, H, cf.ds[si], left50);
 

@@ -38,23 +38,6 @@ const float* Engine::sinus_pos_emb(int Tc, int left, int D) {
     return d;
 }
 
-// linear_pos(pos_emb) of layer l: [2Tc-1+L, H*4].  It does not depend on the input, so it is computed once per layer (first
-// chunk) and kept.
-const float* Engine::zip1_pos_proj(const Ctx& c, int l, const std::string& pfx, int Tc, int L, int D, int H) {
-    if (c.dry) return nullptr;
-    auto it = z1_pp_cache_.find(l);
-    if (it != z1_pp_cache_.end()) return it->second;
-    const int n2 = 2 * Tc - 1 + L;
-    float* pp = nullptr;
-    K2_HIP(hipMalloc(&pp, sizeof(float) * (size_t)n2 * H * 4));
-    Ctx plain = c;  // not part of the per-call GEMM log / event pairs
-    plain.instrument = false;
-    plain.gemm_log = nullptr;
-    linear(plain, sinus_pos_emb(Tc, L, D), D, model_->w(pfx + "self_attn.linear_pos.weight"), nullptr, pp, H * 4, n2, D, H * 4);
-    z1_pp_cache_[l] = pp;
-    return pp;
-}
-
 // Conv2dSubsampling (v1), NHWC: x [B,T,80] -> [B*Tc, D0], Tc = (T-7)//2
 float* Engine::zip1_embed(const Ctx& c, const float* x, int B, int T, int* Tc_out) {
     const Model& m = *model_;
@@ -185,7 +168,8 @@ float* Engine::zip1_chunk(const Ctx& c, const float* x, const int* d_slots, int 
             if (!c.dry) K2_HIP(hipMemcpyAsync(xi, cur, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, c.stream));
             for (int li = 0; li < cf.nlayer[si]; li++, l++) {
                 snprintf(pfx, sizeof pfx, "encoder.encoders.%d.layers.%d.", si, li);
-                zip1_layer(c, si, pfx, l, xi, zip1_pos_proj(c, l, pfx, Tc, L, D, H), d_slots, B, Tc, L);
+                const float* pp = c.dry ? nullptr : pos_proj_cached(c, 2000 + l, sinus_pos_emb(Tc, L, D), D, m.w(std::string(pfx) + "self_attn.linear_pos.weight"), 2 * Tc - 1 + L, H * 4);
+                zip1_layer(c, si, pfx, l, xi, pp, d_slots, B, Tc, L);
             }
             cur = xi;
         } else {
@@ -202,7 +186,8 @@ float* Engine::zip1_chunk(const Ctx& c, const float* x, const int* d_slots, int 
             }
             for (int li = 0; li < cf.nlayer[si]; li++, l++) {
                 snprintf(pfx, sizeof pfx, "encoder.encoders.%d.encoder.layers.%d.", si, li);
-                zip1_layer(c, si, pfx, l, xd, zip1_pos_proj(c, l, pfx, Td, L, D, H), d_slots, B, Td, L);
+                const float* pp = c.dry ? nullptr : pos_proj_cached(c, 2000 + l, sinus_pos_emb(Td, L, D), D, m.w(std::string(pfx) + "self_attn.linear_pos.weight"), 2 * Td - 1 + L, H * 4);
+                zip1_layer(c, si, pfx, l, xd, pp, d_slots, B, Td, L);
             }
             z1_combine(c, cur, Dcur, xd, D, m.wf("encoder.encoders.%d.out_combiner.weight1", si), m.wf("encoder.encoders.%d.upsample.bias", si),
                        ds, B, Tc, Td, y);
