@@ -229,6 +229,122 @@ __global__ __launch_bounds__(256) void k_attn_scores_softmax_long(const float* _
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// SelfAttention.forward after its value projection, fused:  x += out_proj(concat_h(aw_h . v_h)) + bias.
+//   aw [H][B][T][Tp] softmax weights over KL keys (pad columns zero), v [B*KL, HV] (HV = H*vh, head h = columns h*vh ..),
+//   Wout [D, HV] (torch Linear layout), x [B*T, D] updated in place.  Offline KL = T; streaming KL = left context + chunk.
+// One workgroup = 16 rows of one stream.  Phase A: the stream's values sit in LDS ([Tk][HV+2], zero rows past T); wave w takes
+// heads w, w+4, ...: 16x16x4 f32 MFMAs over the keys, A = a 16-row strip of aw read straight from HBM (two float4 per lane per
+// 32 keys -- the launch is bound by that read: every attention-weight element is fetched exactly once), B = the head's values
+// (vh <= 16 columns of the 16-wide tile).  Phase B: the 16 x HV context rows go through LDS.  Phase C: the waves split the D/16
+// column tiles of out_proj (K = HV, the operand Wout comes from L2), add bias and residual, store.
+// Replaces a batched N=12 GEMM (13 us .. 56 us at 4 .. 14 TFLOP/s) plus a K=48 GEMM (15 us) per use.
+// ---------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_attn_av_out(const float* __restrict__ aw, const float* __restrict__ v,
+                                                     const float* __restrict__ wout, const float* __restrict__ bias,
+                                                     float* __restrict__ x, int B, int T, int KL, int Tp, int Tk, int H, int vh,
+                                                     int D, int tiles_per_z) {
+    extern __shared__ float avs[];  // [16][HV + 1]
+    const int HV = H * vh, AS = HV + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, i0 = blockIdx.x * 16;
+    const int n = lane & 15, kq = lane >> 4;
+    // ---- phase A: 64 keys per step = 4 groups of 16; lane (n, kq) holds keys k0 + 16 g + 4 kq + {0..3} of row i0 + n (A operand,
+    // one float4 of aw) and of value column h*vh + n (B operand, four scalar loads: the stream's values, T x HV floats, stay in L2).
+    const int row_a = min(i0 + n, T - 1);  // clamped rows are computed and dropped
+    const bool ncol = n < vh;
+    for (int h = wave; h < H; h += 4) {
+        const float* arow = aw + (((long long)h * B + b) * T + row_a) * Tp + 4 * kq;
+        const float* vb = v + ((long long)b * KL + 4 * kq) * HV + h * vh + (ncol ? n : 0);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < Tk; k0 += 64) {
+            float4 a4[4];
+            float bv[4][4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int kb = k0 + 16 * g + 4 * kq;
+                a4[g] = kb < Tp ? *reinterpret_cast<const float4*>(arow + k0 + 16 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int m = 0; m < 4; m++) bv[g][m] = (ncol && kb + m < KL) ? vb[(long long)(k0 + 16 * g + m) * HV] : 0.f;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                if (g & 1) {
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].x, bv[g][0], acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].y, bv[g][1], acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].z, bv[g][2], acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].w, bv[g][3], acc1, 0, 0, 0);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].x, bv[g][0], acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].y, bv[g][1], acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].z, bv[g][2], acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].w, bv[g][3], acc0, 0, 0, 0);
+                }
+            }
+        }
+        if (ncol) {  // C layout: col = lane & 15, row = 4 * (lane >> 4) + e
+#pragma unroll
+            for (int e = 0; e < 4; e++) avs[(4 * kq + e) * AS + h * vh + n] = acc0[e] + acc1[e];
+        }
+    }
+    __syncthreads();
+    // ---- phase C: out[16, D] = avs[16, HV] . wout^T; the A operand (this lane's context values) is the same for every column tile.
+    // blockIdx.z splits the column tiles when there are too few row strips to fill the chip (phase A is then repeated per slice).
+    constexpr int MAXC = 8;  // HV <= 128
+    const int nch = (HV + 15) >> 4;
+    float4 av4[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+        const int kb = 16 * c + 4 * kq;
+        const float* ar = avs + n * AS + kb;
+        av4[c] = (c < nch && kb < HV) ? make_float4(ar[0], ar[1], ar[2], ar[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int ct0 = blockIdx.z * tiles_per_z, ct1 = min(D >> 4, ct0 + tiles_per_z);
+    float4 wc[MAXC], wn[MAXC];
+    auto load_w = [&](float4* dst, int ct) {
+        const float* wr = wout + (long long)(ct * 16 + n) * HV + 4 * kq;
+#pragma unroll
+        for (int c = 0; c < MAXC; c++)
+            dst[c] = (c < nch && 16 * c + 4 * kq < HV) ? *reinterpret_cast<const float4*>(wr + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if (ct0 + wave < ct1) load_w(wc, ct0 + wave);
+    for (int ct = ct0 + wave; ct < ct1; ct += 4) {
+        if (ct + 4 < ct1) load_w(wn, ct + 4);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < MAXC; c++) {
+            if (c < nch) {
+                if (c & 1) {
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].x, wc[c].x, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].y, wc[c].y, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].z, wc[c].z, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].w, wc[c].w, acc1, 0, 0, 0);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].x, wc[c].x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].y, wc[c].y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].z, wc[c].z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].w, wc[c].w, acc0, 0, 0, 0);
+                }
+            }
+        }
+        const int col = ct * 16 + n;
+        const float bv = bias[col];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = i0 + 4 * kq + e;
+            if (i < T) {
+                const long long idx = ((long long)b * T + i) * D + col;
+                x[idx] = acc0[e] + acc1[e] + bv + x[idx];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; c++) wc[c] = wn[c];
+    }
+}
+
 }  // namespace
 
 void attn_scores_softmax(const Ctx& ctx, const float* qkp, int ld, const float* pp, float* aw, int B, int T, int Tp, int H) {
@@ -248,6 +364,26 @@ void attn_scores_softmax(const Ctx& ctx, const float* qkp, int ld, const float* 
     dim3 grid(cdiv(T, R), B, H);
     hipLaunchKernelGGL(k_attn_scores_softmax, grid, dim3(256), lds, ctx.stream, qkp, ld, pp, aw, B, T, Tp, H, lds_stride);
     K2_HIP(hipGetLastError());
+}
+
+bool attn_av_out(const Ctx& ctx, const float* aw, const float* v, const float* wout, const float* bias, float* x, int B, int T, int KL, int Tp,
+                 int H, int vh, int D) {
+    const int HV = H * vh, Tk = (KL + 63) & ~63;
+    static const bool off = getenv("K2HIP_NO_FUSED_AV") != nullptr;
+    if (off || vh > 16 || HV % 4 != 0 || HV > 128 || D % 16 != 0 || Tp % 4 != 0 || Tp < KL) return false;
+    ctx.add_flops(0.0, 2.0 * B * (double)T * HV * (KL + D), 0);
+    if (ctx.dry) return true;
+    // few row strips (short sequences): split out_proj's column tiles over blockIdx.z so that ~2 workgroups per CU exist
+    const int strips = cdiv(T, 16) * B, ntile = D / 16;
+    int cs = std::max(1, std::min(4, 512 / std::max(1, strips)));
+    cs = std::min(cs, ntile);
+    const int tiles_per_z = cdiv(ntile, cs);
+    cs = cdiv(ntile, tiles_per_z);
+    const size_t lds = sizeof(float) * 16 * (HV + 1);
+    hipLaunchKernelGGL(k_attn_av_out, dim3(cdiv(T, 16), B, cs), dim3(256), lds, ctx.stream, aw, v, wout, bias, x, B, T, KL, Tp, Tk, H, vh,
+                       D, tiles_per_z);
+    K2_HIP(hipGetLastError());
+    return true;
 }
 
 }  // namespace k2hip

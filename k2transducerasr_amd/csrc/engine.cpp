@@ -257,6 +257,7 @@ void Engine::encoder_layer(const Ctx& c, int si, int li, float* x, const float* 
         snprintf(cc, sizeof cc, "self_attn%d.out_proj.weight", k);
         snprintf(d, sizeof d, "self_attn%d.out_proj.bias", k);
         linear(c, src, D, w(a), w(b), hid, HV, M, D, HV);
+        if (attn_av_out(c, aw, hid, w(cc), w(d), src, B, T, T, Tp, H, vh, D)) return;  // fused attention-apply + out_proj + residual
         GemmArgs g;  // tmp[b, :, h*vh : (h+1)*vh] = aw[h][b] . hid[b, :, h*vh : ...]
         g.A = aw; g.lda = Tp; g.sA0 = (long long)T * Tp; g.sA1 = (long long)B * T * Tp;
         g.W = hid; g.w_kn = 1; g.ldw = HV; g.sW0 = (long long)T * HV; g.sW1 = vh;
@@ -513,6 +514,7 @@ void Engine::fbank_host(const float* samples, int64_t n, float* feats, int64_t c
         d_out = c.arena->take<float>(nf * f.num_bins);
         if (!c.dry) K2_HIP(hipMemcpyAsync(d_s, samples, sizeof(float) * n, hipMemcpyHostToDevice, c.stream));
         FbankArgs a{d_s, n, n, 1, nf, d_out, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift, f.preemph, f.input_scale, f.remove_dc};
+        a.melrange = model_->d_melrange;
         fbank(c, a);
     });
     K2_HIP(hipMemcpyAsync(feats, d_out, sizeof(float) * nf * f.num_bins, hipMemcpyDeviceToHost, stream_));
@@ -533,6 +535,7 @@ void Engine::fbank_host_batch(const float* samples, int64_t n, int n_utts, float
         d_out = c.arena->take<float>(nf * f.num_bins * n_utts);
         if (!c.dry) K2_HIP(hipMemcpyAsync(d_s, pin, nb_in, hipMemcpyHostToDevice, c.stream));
         FbankArgs a{d_s, n, n, n_utts, nf, d_out, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift, f.preemph, f.input_scale, f.remove_dc};
+        a.melrange = model_->d_melrange;
         fbank(c, a);
     });
     K2_HIP(hipMemcpyAsync(pin + nb_in, d_out, nb_out, hipMemcpyDeviceToHost, stream_));
@@ -762,6 +765,7 @@ void Engine::offline_greedy_samples_dev(const float* samples_dev, int64_t n_each
         if (!c.dry) K2_HIP(hipEventRecord(ev_[0], c.stream));
         FbankArgs a{samples_dev, n_each, n_each, B, nf, d_feats, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift,
                     f.preemph, f.input_scale, f.remove_dc};
+        a.melrange = model_->d_melrange;
         fbank(c, a);
         if (!c.dry) K2_HIP(hipEventRecord(ev_[1], c.stream));
         pad_logfloor_dense(c, d_feats, n_fl, d_x, B, L);
@@ -837,7 +841,8 @@ int Engine::submit_samples_dev(const float* samples_dev, int64_t n_each, int B, 
             float* d_x = ar.take<float>((int64_t)B * L);
             FbankArgs a{samples_dev, n_each, n_each, B, nf, d_feats, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift,
                         f.preemph, f.input_scale, f.remove_dc};
-            fbank(c, a);
+            a.melrange = model_->d_melrange;
+        fbank(c, a);
             pad_logfloor_dense(c, d_feats, n_fl, d_x, B, L);
             int Tp = 0;
             float* enc = encoder_forward(c, d_x, B, T, &Tp, -1, nullptr, nullptr, nullptr);

@@ -74,18 +74,15 @@ __global__ __launch_bounds__(256) void k_fbank(FbankArgs a, const double2* __res
     re[tid] = pw;
     __syncthreads();
     float* out = a.feats + ((long long)u * a.n_frames + f) * num_mel;
-    for (int b = wave; b < num_mel; b += 4) {
-        const float* w = a.melw + b * NBIN;
+    // one lane per mel filter: a triangle spans a few FFT bins (2 .. ~30), summed in index order
+    if (tid < num_mel) {
+        const int lo = (int)a.melrange[2 * tid], hi = (int)a.melrange[2 * tid + 1];
+        const float* w = a.melw + tid * NBIN;
         double e = 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) e += (double)w[lane + 64 * q] * re[lane + 64 * q];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
-        if (lane == 0) {
-            float ef = (float)e;
-            if (ef < FLT_EPSILON) ef = FLT_EPSILON;
-            out[b] = logf(ef);
-        }
+        for (int k = lo; k < hi; k++) e += (double)w[k] * re[k];
+        float ef = (float)e;
+        if (ef < FLT_EPSILON) ef = FLT_EPSILON;
+        out[tid] = logf(ef);
     }
 }
 
@@ -111,6 +108,7 @@ const double2* twiddles(int device) {
 void fbank(const Ctx& ctx, const FbankArgs& a) {
     if (a.n_frames <= 0 || a.n_utts <= 0) return;
     K2_REQUIRE(a.frame_len <= NFFT && a.frame_len > 256, "fbank: frame_len %d unsupported", a.frame_len);
+    K2_REQUIRE(a.melrange != nullptr, "fbank: mel filter extents missing");
     if (ctx.dry) return;
     int dev = 0;
     K2_HIP(hipGetDevice(&dev));

@@ -84,6 +84,12 @@ void linear(const Ctx& ctx, const float* A, int lda, const float* W, const float
 // aw out: [H][B][T][Tp] (Tp = T rounded up to 4, pad columns zeroed)
 void attn_scores_softmax(const Ctx& ctx, const float* qkp, int ld, const float* pp, float* aw, int B, int T, int Tp, int H);
 
+// fused x += out_proj(concat_h(aw_h . v_h)) + bias  (SelfAttention after its value projection); aw [H][B][T][Tp] over KL keys,
+// v [B*KL, H*vh], wout [D, H*vh];
+// returns false (nothing launched, nothing tallied) when the shape does not fit the kernel -- the caller then takes the GEMM path
+bool attn_av_out(const Ctx& ctx, const float* aw, const float* v, const float* wout, const float* bias, float* x, int B, int T, int KL, int Tp,
+                 int H, int vh, int D);
+
 // ---- elementwise / small -----------------------------------------------------
 // packed: all streams' features back to back; d_off/d_len: per-stream start and float count (device)
 void pad_logfloor(const Ctx& ctx, const float* packed, const long long* d_off, const long long* d_len, float* out, int B,
@@ -152,6 +158,7 @@ struct FbankArgs {
     int frame_len, frame_shift;
     float preemph, input_scale;
     int remove_dc;
+    const float* melrange = nullptr;  // [num_bins][2] extent of each mel filter's non-zero weights (model table)
 };
 void fbank(const Ctx& ctx, const FbankArgs& a);
 

@@ -137,6 +137,7 @@ Model::Model(const std::string& path, const char* overrides, int device) : devic
     }
     d_window = w("#fbank.window");
     d_melw = w("#fbank.melw");
+    d_melrange = w("#fbank.melrange");
 }
 
 Model::~Model() {
@@ -443,7 +444,18 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
                     mw[(size_t)b * nb + i] = (float)((mel <= center) ? (mel - left) / (center - left) : (right - mel) / (right - center));
             }
         }
+        // extent [lo, hi) of each filter's non-zero weights (a triangle covers a few FFT bins): the kernel sums only those
+        std::vector<float> mr((size_t)f.num_bins * 2, 0.f);
+        for (int b = 0; b < f.num_bins; b++) {
+            int lo = nb, hi2 = 0;
+            for (int i = 0; i < nb; i++)
+                if (mw[(size_t)b * nb + i] != 0.f) { lo = std::min(lo, i); hi2 = i + 1; }
+            if (hi2 <= lo) lo = hi2 = 0;
+            mr[2 * b] = (float)lo;
+            mr[2 * b + 1] = (float)hi2;
+        }
         push("#fbank.melw", std::move(mw), {f.num_bins, nb});
+        push("#fbank.melrange", std::move(mr), {f.num_bins, 2});
     }
 }
 

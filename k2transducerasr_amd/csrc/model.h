@@ -81,6 +81,7 @@ class Model {
     // fbank tables (device): window [frame_len], mel weights [num_bins, padded/2]
     const float* d_window = nullptr;
     const float* d_melw = nullptr;
+    const float* d_melrange = nullptr;  // [num_bins][2]: first / one-past-last FFT bin with a non-zero weight
 
   private:
     void parse_config();

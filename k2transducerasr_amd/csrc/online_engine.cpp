@@ -280,6 +280,7 @@ void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x,
         snprintf(d, sizeof d, "self_attn%d.out_proj.bias", k);
         linear(c, src, D, w(a), w(b), hid, HV, M, D, HV);
         cat_shift(c, online_pool_, SS, cache_off, d_slots, hid, HV, vcat, B, L, Tc, HV);
+        if (attn_av_out(c, aw, vcat, w(cc), w(d), src, B, Tc, KL, KLp, H, vh, D)) return;  // fused apply + out_proj + residual
         attn_apply(vcat, HV, tmp, HV, H, vh);
         linear(c, tmp, HV, w(cc), w(d), src, D, M, HV, D, ACT_NONE, src, D);
     };

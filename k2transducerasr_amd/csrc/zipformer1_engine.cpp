@@ -122,15 +122,19 @@ void Engine::zip1_layer(const Ctx& c, int si, const std::string& pfx, int l, flo
     cat_shift(c, online_pool_, SS, lay_.key[l], d_slots, hid + A, inproj, kcat, B, L, Tc, A);
     cat_shift(c, online_pool_, SS, lay_.val1[l], d_slots, hid + 2 * A, inproj, vcat, B, L, Tc, A2);
     z1_attn(c, hid, inproj, kcat, pp, aw, B, Tc, L, KLp, H, A);
-    attn_apply();
-    linear(c, tmp, A2, w("self_attn.out_proj.weight"), w("self_attn.out_proj.bias"), src, D, M, A2, D, ACT_NONE, src, D);
+    if (!attn_av_out(c, aw, vcat, w("self_attn.out_proj.weight"), w("self_attn.out_proj.bias"), src, B, Tc, KL, KLp, H, vd, D)) {
+        attn_apply();
+        linear(c, tmp, A2, w("self_attn.out_proj.weight"), w("self_attn.out_proj.bias"), src, D, M, A2, D, ACT_NONE, src, D);
+    }
     conv_module(1, lay_.conv1[l]);
     feed_forward(2, src, src);
     // self_attn.streaming_forward2
     linear(c, src, D, w("self_attn.in_proj2.weight"), nullptr, hid, A2, M, D, A2);
     cat_shift(c, online_pool_, SS, lay_.val2[l], d_slots, hid, A2, vcat, B, L, Tc, A2);
-    attn_apply();
-    linear(c, tmp, A2, w("self_attn.out_proj2.weight"), w("self_attn.out_proj2.bias"), src, D, M, A2, D, ACT_NONE, src, D);
+    if (!attn_av_out(c, aw, vcat, w("self_attn.out_proj2.weight"), w("self_attn.out_proj2.bias"), src, B, Tc, KL, KLp, H, vd, D)) {
+        attn_apply();
+        linear(c, tmp, A2, w("self_attn.out_proj2.weight"), w("self_attn.out_proj2.bias"), src, D, M, A2, D, ACT_NONE, src, D);
+    }
     conv_module(2, lay_.conv2[l]);
     feed_forward(3, src, src);
     z1_norm_bypass(c, src, x, w("norm_final.eps"), w("bypass_scale"), x, M, D);
