@@ -4,7 +4,7 @@
 //   scores[i,j] = q_i . k_j  +  p_i . pos[T-1-i+j]      (no 1/sqrt(d): folded into the weights)
 //   aw[i,:]     = softmax_j(scores[i,:])
 //
-// One workgroup (4 waves) owns 32 query rows of one (head, batch) pair and ALL T
+// One workgroup (8 waves) owns 32 query rows of one (head, batch) pair and ALL T
 // keys: q.k^T runs on the f32 MFMA (32x32x2, exact f32 products; K = 32), the
 // 4-wide positional term is added on the VALU in the accumulator layout, the
 // 32 x T score strip lives in LDS, and the row softmax is done in place before a
@@ -23,7 +23,7 @@ constexpr int QH = 32;  // query/key head dim (config-checked at load)
 constexpr int PH = 4;   // pos head dim
 constexpr int R = 32;   // query rows per workgroup
 
-__global__ __launch_bounds__(256) void k_attn_scores_softmax(const float* __restrict__ qkp, int ld,
+__global__ __launch_bounds__(512, 4) void k_attn_scores_softmax(const float* __restrict__ qkp, int ld,
                                                              const float* __restrict__ pp, float* __restrict__ aw, int B,
                                                              int T, int Tp, int H, int lds_stride) {
     extern __shared__ __attribute__((aligned(16))) float S[];  // [R][lds_stride]
@@ -44,17 +44,18 @@ __global__ __launch_bounds__(256) void k_attn_scores_softmax(const float* __rest
             if (row < T) fq[g] = *reinterpret_cast<const float4*>(base + (long long)row * ld + qoff + 8 * g + 4 * lh);
         }
     }
-    // p vectors of the 16 accumulator rows of this lane
-    float4 pr[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        pr[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < T) pr[r] = *reinterpret_cast<const float4*>(base + (long long)row * ld + poff);
-    }
+    // the positional rows this workgroup can touch, n = T-1-i+j for its rows i and every key j: one window of <= T+R-1
+    // consecutive rows of pp (16 B each for this head) -> LDS, so the per-element gather below is an LDS read
+    float4* PW = reinterpret_cast<float4*>(S + R * lds_stride);
+    const int nlo = T - 1 - min(i0 + R - 1, T - 1), nwin = (2 * T - 2 - i0) - nlo + 1;
+    for (int wdx = tid; wdx < nwin; wdx += 512) PW[wdx] = *reinterpret_cast<const float4*>(pp + (long long)(nlo + wdx) * ppld + h * PH);
+    // the positional queries p_i of the 32 rows (read back as LDS broadcasts: all lanes of a half-wave share the row)
+    float4* PR = PW + (T + R);
+    if (tid < R) PR[tid] = i0 + tid < T ? *reinterpret_cast<const float4*>(base + (long long)(i0 + tid) * ld + poff) : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
 
     const int njt = (T + 31) / 32;
-    for (int jt = wave; jt < njt; jt += 4) {
+    for (int jt = wave; jt < njt; jt += 8) {
         int j = jt * 32 + li;  // this lane's key (as B-operand column and as accumulator column)
         float4 fk[4];
 #pragma unroll
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(256) void k_attn_scores_softmax(const float* __rest
                 float s = acc[r];
                 if (i < T) {
                     // rel-shift in gather form: relative index n = T-1-i+j in [0, 2T-2]
-                    float4 e = *reinterpret_cast<const float4*>(pp + (long long)(T - 1 - i + j) * ppld + h * PH);
-                    s += pr[r].x * e.x + pr[r].y * e.y + pr[r].z * e.z + pr[r].w * e.w;
+                    const float4 e = PW[T - 1 - i + j - nlo], pq = PR[rl];
+                    s += pq.x * e.x + pq.y * e.y + pq.z * e.z + pq.w * e.w;
                 }
                 S[rl * lds_stride + j] = s;
             }
@@ -89,10 +90,10 @@ __global__ __launch_bounds__(256) void k_attn_scores_softmax(const float* __rest
     }
     __syncthreads();
 
-    // row softmax: wave w owns rows 8w..8w+7
+    // row softmax: wave w (of 8) owns rows 4w..4w+3
     float* out = aw + (((long long)h * B + b) * T) * Tp;
-    for (int rr = 0; rr < 8; rr++) {
-        int rl = wave * 8 + rr, i = i0 + rl;
+    for (int rr = 0; rr < 4; rr++) {
+        int rl = wave * 4 + rr, i = i0 + rl;
         if (i >= T) break;
         float* srow = S + rl * lds_stride;
         float mx = -INFINITY;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void k_attn_av_out(const float* __restrict__ a
 void attn_scores_softmax(const Ctx& ctx, const float* qkp, int ld, const float* pp, float* aw, int B, int T, int Tp, int H) {
     K2_REQUIRE(Tp % 4 == 0 && Tp >= T, "attn: Tp=%d must be T=%d rounded up to 4", Tp, T);
     int lds_stride = Tp + 4;  // rows 16 B aligned; +4 floats de-phases the 4-row-apart writers of one MFMA register
-    size_t lds = sizeof(float) * R * lds_stride;
+    size_t lds = sizeof(float) * (R * lds_stride + 4 * (T + R) + 4 * R);  // score strip + the positional window + the rows' p
     ctx.add_flops(0.0, 2.0 * (QH + PH) * (double)T * T * B * H, 0);
     if (ctx.dry) return;
     static const bool force_long = getenv("K2HIP_ATTN_LONG") != nullptr;
@@ -362,7 +363,7 @@ void attn_scores_softmax(const Ctx& ctx, const float* qkp, int ld, const float* 
     static LdsAttrOnce lds_attr;
     lds_attr.ensure(k_attn_scores_softmax, 160 * 1024);
     dim3 grid(cdiv(T, R), B, H);
-    hipLaunchKernelGGL(k_attn_scores_softmax, grid, dim3(256), lds, ctx.stream, qkp, ld, pp, aw, B, T, Tp, H, lds_stride);
+    hipLaunchKernelGGL(k_attn_scores_softmax, grid, dim3(512), lds, ctx.stream, qkp, ld, pp, aw, B, T, Tp, H, lds_stride);
     K2_HIP(hipGetLastError());
 }
 
