@@ -261,16 +261,20 @@ __global__ __launch_bounds__(256) void k_attn_av_out(const float* __restrict__ a
         const float* arow = aw + (((long long)h * B + b) * T + row_a) * Tp + 4 * kq;
         const float* vb = v + ((long long)b * KL + 4 * kq) * HV + h * vh + (ncol ? n : 0);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < Tk; k0 += 64) {
-            float4 a4[4];
-            float bv[4][4];
+        float4 a4[4], a4n[4];
+        float bv[4][4], bvn[4][4];
+        auto load_step = [&](float4* ad, float (*bd)[4], int k0) {
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int kb = k0 + 16 * g + 4 * kq;
-                a4[g] = kb < Tp ? *reinterpret_cast<const float4*>(arow + k0 + 16 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ad[g] = kb < Tp ? *reinterpret_cast<const float4*>(arow + k0 + 16 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int m = 0; m < 4; m++) bv[g][m] = (ncol && kb + m < KL) ? vb[(long long)(k0 + 16 * g + m) * HV] : 0.f;
+                for (int m = 0; m < 4; m++) bd[g][m] = (ncol && kb + m < KL) ? vb[(long long)(k0 + 16 * g + m) * HV] : 0.f;
             }
+        };
+        load_step(a4, bv, 0);
+        for (int k0 = 0; k0 < Tk; k0 += 64) {
+            if (k0 + 64 < Tk) load_step(a4n, bvn, k0 + 64);  // in flight under this step's MFMAs
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 if (g & 1) {
@@ -284,6 +288,12 @@ __global__ __launch_bounds__(256) void k_attn_av_out(const float* __restrict__ a
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].z, bv[g][2], acc0, 0, 0, 0);
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].w, bv[g][3], acc0, 0, 0, 0);
                 }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                a4[g] = a4n[g];
+#pragma unroll
+                for (int m = 0; m < 4; m++) bv[g][m] = bvn[g][m];
             }
         }
         if (ncol) {  // C layout: col = lane & 15, row = 4 * (lane >> 4) + e
@@ -314,6 +324,14 @@ __global__ __launch_bounds__(256) void k_attn_av_out(const float* __restrict__ a
     if (ct0 + wave < ct1) load_w(wc, ct0 + wave);
     for (int ct = ct0 + wave; ct < ct1; ct += 4) {
         if (ct + 4 < ct1) load_w(wn, ct + 4);
+        const int col = ct * 16 + n;
+        const float bv = bias[col];
+        float xr[4];  // residual, fetched under the MFMAs
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = i0 + 4 * kq + e;
+            xr[e] = i < T ? x[((long long)b * T + i) * D + col] : 0.f;
+        }
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < MAXC; c++) {
@@ -331,15 +349,10 @@ __global__ __launch_bounds__(256) void k_attn_av_out(const float* __restrict__ a
                 }
             }
         }
-        const int col = ct * 16 + n;
-        const float bv = bias[col];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int i = i0 + 4 * kq + e;
-            if (i < T) {
-                const long long idx = ((long long)b * T + i) * D + col;
-                x[idx] = acc0[e] + acc1[e] + bv + x[idx];
-            }
+            if (i < T) x[((long long)b * T + i) * D + col] = acc0[e] + acc1[e] + bv + xr[e];
         }
 #pragma unroll
         for (int c = 0; c < MAXC; c++) wc[c] = wn[c];

@@ -193,7 +193,7 @@ __global__ void k_first_emit(const int* __restrict__ tok, int B, int Tp, int ski
 }
 
 // ---- multi-frame greedy loop ---------------------------------------------------------
-// One workgroup of 1024 threads per stream.  The joiner matrix (J x V f32, 1 MB for the
+// One workgroup of GT threads per stream.  The joiner matrix (J x V f32, 1 MB for the
 // large-en model) does not fit in LDS and streaming it from L2 once per frame made the loop
 // latency-bound (~50 us / frame).  Blank wins most frames and the decoder context only
 // changes on an emission, so each ROUND evaluates the next GF frames against the CURRENT
@@ -202,10 +202,12 @@ __global__ void k_first_emit(const int* __restrict__ tok, int B, int Tp, int ski
 // emission are re-evaluated in the next round under the new context, so the result is
 // exactly the frame-by-frame loop of OfflineRecognizer.cs:216-288.
 constexpr int GF = 8;      // frames per round
-constexpr int GT = 1024;   // threads per workgroup (16 waves)
+constexpr int GT = 512;    // threads per workgroup (8 waves; 1024 spilled 65 VGPRs to scratch and was slower, 256 starves the sweep)
 // the 8 k slices of a wave read actT rows kper*GF floats apart (a multiple of 64 dwords: the same
 // LDS banks, an 8-way conflict on every read); skew each slice by APAD floats
 constexpr int APAD = 8;
+// weight loads in flight per thread in the joiner sweep
+constexpr int GL = 8;
 
 // dec_out[J] = decoder_proj(relu(grouped_conv(emb[y0], emb[y1]))), GT threads, two per output
 // out[n] = f(bias[n] + sum_k x[k] * W[k*N + n]) for a k-major matrix, GT threads: 8 k slices x N/4 column
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
         int besti[GF];
 #pragma unroll
         for (int f = 0; f < GF; f++) { bestv[f] = -INFINITY; besti[f] = -1; }
-        for (int cgb = cg0; cgb < cg1; cgb += 128) {
+        for (int cgb = cg0; cgb < cg1; cgb += (GT / 64) * 8) {
             const int cg = cgb + wave * 8 + cgl;
             const bool valid = cg < cg1;
             float acc[GF][4];
@@ -367,14 +369,14 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
             if (valid) {
                 const float* wp = w.out_kn + (long long)(ks * kper) * w.Vp + 4 * cg;
                 const float* ap = actT + (ks * kper) * GF + ks * APAD;
-                for (int kb = 0; kb < kper; kb += 8) {
-                    // 8 weight loads in flight per thread before any FMA: the sweep is L2-latency bound
-                    float4 wv[8];
+                for (int kb = 0; kb < kper; kb += GL) {
+                    // GL weight loads in flight per thread before any FMA: the sweep is L2-latency bound
+                    float4 wv[GL];
 #pragma unroll
-                    for (int i = 0; i < 8; i++)
+                    for (int i = 0; i < GL; i++)
                         wv[i] = *reinterpret_cast<const float4*>(wp + (long long)min(kb + i, kper - 1) * w.Vp);
 #pragma unroll
-                    for (int i = 0; i < 8; i++) {
+                    for (int i = 0; i < GL; i++) {
                         const int k = min(kb + i, kper - 1);
                         const float m = (kb + i < kper) ? 1.f : 0.f;
                         const float4 a0 = *reinterpret_cast<const float4*>(ap + k * GF);
