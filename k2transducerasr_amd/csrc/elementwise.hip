@@ -292,16 +292,29 @@ __global__ __launch_bounds__(256) void k_glu_dwconv1d(const float* __restrict__ 
     const int t0 = blockIdx.y * DW_ROWS, b = blockIdx.z;
     const int half = K >> 1, nrows = DW_ROWS + K - 1;
     const bool cok = c < D;
-    for (int r = wave; r < nrows; r += 4) {
-        const int u = t0 - half + r;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cok && u >= 0 && u < T) {
-            const float* row = x2 + ((long long)b * T + u) * 2 * D;
-            const float4 a = *reinterpret_cast<const float4*>(row + c);
-            const float4 sg = *reinterpret_cast<const float4*>(row + D + c);
-            g = make_float4(a.x * sigm(sg.x), a.y * sigm(sg.y), a.z * sigm(sg.z), a.w * sigm(sg.w));
+    // four rows (eight 16-byte loads) in flight per lane: one row at a time made the staging a chain of ~16 memory latencies
+    for (int r0 = wave; r0 < nrows; r0 += 16) {
+        float4 a[4], sg[4];
+        bool ok[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = r0 + 4 * i, u = t0 - half + r;
+            ok[i] = cok && r < nrows && u >= 0 && u < T;
+            if (ok[i]) {
+                const float* row = x2 + ((long long)b * T + u) * 2 * D;
+                a[i] = *reinterpret_cast<const float4*>(row + c);
+                sg[i] = *reinterpret_cast<const float4*>(row + D + c);
+            }
         }
-        *reinterpret_cast<float4*>(sx + r * 256 + lane * 4) = g;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = r0 + 4 * i;
+            if (r < nrows) {
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok[i]) g = make_float4(a[i].x * sigm(sg[i].x), a[i].y * sigm(sg[i].y), a[i].z * sigm(sg[i].z), a[i].w * sigm(sg[i].w));
+                *reinterpret_cast<float4*>(sx + r * 256 + lane * 4) = g;
+            }
+        }
     }
     __syncthreads();
     if (!cok) return;
@@ -310,12 +323,21 @@ __global__ __launch_bounds__(256) void k_glu_dwconv1d(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < DW_TT; i++) acc[i] = bv;
     const float* base = sx + (wave * DW_TT) * 256 + lane * 4;
-    for (int k = 0; k < K; k++) {
-        const float4 wv = *reinterpret_cast<const float4*>(w + k * D + c);
+    // taps in groups of 8: the 8 weight loads are in flight together (one load per tap inside the loop was a chain of K latencies)
+    for (int kb = 0; kb < K; kb += 8) {
+        float4 wv[8];
 #pragma unroll
-        for (int i = 0; i < DW_TT; i++) {
-            const float4 xv = *reinterpret_cast<const float4*>(base + (i + k) * 256);
-            acc[i].x += wv.x * xv.x; acc[i].y += wv.y * xv.y; acc[i].z += wv.z * xv.z; acc[i].w += wv.w * xv.w;
+        for (int q = 0; q < 8; q++)
+            wv[q] = kb + q < K ? *reinterpret_cast<const float4*>(w + (kb + q) * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (kb + q < K) {
+#pragma unroll
+                for (int i = 0; i < DW_TT; i++) {
+                    const float4 xv = *reinterpret_cast<const float4*>(base + (i + kb + q) * 256);
+                    acc[i].x += wv[q].x * xv.x; acc[i].y += wv[q].y * xv.y; acc[i].z += wv[q].z * xv.z; acc[i].w += wv[q].w * xv.w;
+                }
+            }
         }
     }
 #pragma unroll
