@@ -227,14 +227,22 @@ void Engine::encoder_layer(const Ctx& c, int si, int li, float* x, const float* 
     Arena& ar = *c.arena;
     int64_t mark = ar.mark();
 
-    // attention weights, shared by nonlin_attention / self_attn1 / self_attn2
-    float* qkp = ar.take<float>((int64_t)M * inproj);
-    linear(c, x, D, w("self_attn_weights.in_proj.weight"), w("self_attn_weights.in_proj.bias"), qkp, inproj, M, D, inproj);
+    // [ff1.in_proj | attention-weights in_proj] of the layer input in one GEMM (model.cpp stacks the two weight matrices);
+    // the attention weights are shared by nonlin_attention / self_attn1 / self_attn2
+    const int F1 = F * 3 / 4, ldcat = F1 + inproj;
+    float* cat = ar.take<float>((int64_t)M * ldcat);
+    {
+        GemmArgs g;
+        g.A = x; g.lda = D; g.W = w("#ff1_attn_in.weight"); g.ldw = D; g.bias = w("#ff1_attn_in.bias");
+        g.C = cat; g.ldc = ldcat; g.M = M; g.N = ldcat; g.K = D; g.act = ACT_SWOOSH_L; g.act_cols = F1;
+        gemm(c, g);
+    }
+    const float* qkp = cat + F1;
     int gl = li;  // global layer index: the cache key of the layer's positional projection
     for (int i = 0; i < si; i++) gl += cf.nlayer[i];
     const float* pp = pos_proj_cached(c, gl, pe, cf.pos_dim, w("self_attn_weights.linear_pos.weight"), 2 * T - 1, cf.phd[si] * H);
     float* aw = ar.take<float>((int64_t)H * B * T * Tp);
-    attn_scores_softmax(c, qkp, inproj, pp, aw, B, T, Tp, H);
+    attn_scores_softmax(c, qkp, ldcat, pp, aw, B, T, Tp, H);
 
     float* src = ar.take<float>((int64_t)M * D);
     float* hid = ar.take<float>((int64_t)M * std::max({F * 5 / 4, 3 * Hc, 2 * D}));
@@ -279,7 +287,8 @@ void Engine::encoder_layer(const Ctx& c, int si, int li, float* x, const float* 
         linear(c, tmp2, D, w(e), w(f), src, D, M, D, D, ACT_NONE, src, D);
     };
 
-    feed_forward(1, F * 3 / 4, x, src);  // src = x + ff1(x)
+    // src = x + ff1(x): the hidden activations are the first F1 columns of `cat`
+    linear(c, cat, ldcat, w("feed_forward1.out_proj.weight"), w("feed_forward1.out_proj.bias"), src, D, M, F1, D, ACT_NONE, x, D);
     {   // src += NonlinAttention(src, aw[0])
         linear(c, src, D, w("nonlin_attention.in_proj.weight"), w("nonlin_attention.in_proj.bias"), hid, 3 * Hc, M, D, 3 * Hc);
         tanh_gate(c, hid, tmp, M, Hc);

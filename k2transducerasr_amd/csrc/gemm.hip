@@ -281,13 +281,14 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
         int col = n0 + wc * WN + j * 32 + li;
         if (col >= g.N) continue;
         float bv = g.bias ? g.bias[col] : 0.f;
+        const int act = (g.act_cols == 0 || col < g.act_cols) ? g.act : (int)ACT_NONE;
 #pragma unroll
         for (int i = 0; i < MT; i++) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int row = m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < g.M && !(g.ablate & 4)) {
-                    float v = apply_act(acc[i][j][r] + bv, g.act);
+                    float v = apply_act(acc[i][j][r] + bv, act);
                     if (R) v += rres[i][j][r];
                     C[(long long)row * g.ldc + col] = v;
                 }
@@ -449,13 +450,14 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
         int col = n0 + wc * WN + j * 32 + li;
         if (col >= g.N) continue;
         float bv = g.bias ? g.bias[col] : 0.f;
+        const int act = (g.act_cols == 0 || col < g.act_cols) ? g.act : (int)ACT_NONE;
 #pragma unroll
         for (int i = 0; i < MT; i++) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int row = m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < g.M) {
-                    float v = apply_act(acc[i][j][r] + bv, g.act);
+                    float v = apply_act(acc[i][j][r] + bv, act);
                     if (R) v += rres[i][j][r];
                     C[(long long)row * g.ldc + col] = v;
                 }
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_skinny(GemmArgs g) {
             const int row = m0 + 4 * q + e;
             if (row >= g.M) continue;
             float v = red[0][j][lane][e] + red[1][j][lane][e] + red[2][j][lane][e] + red[3][j][lane][e];
-            v = apply_act(v + bv, g.act);
+            v = apply_act(v + bv, (g.act_cols == 0 || col < g.act_cols) ? g.act : (int)ACT_NONE);
             if (g.res) v += g.res[(long long)row * g.ldr + col];
             g.C[(long long)row * g.ldc + col] = v;
         }

@@ -62,6 +62,7 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0;
     int lda = 0, ldw = 0, ldc = 0, ldr = 0;
     int act = ACT_NONE;
+    int act_cols = 0;  // > 0: the activation applies to output columns < act_cols only (two Linears of one input fused in one launch)
     int w_kn = 0;
     // batching over blockIdx.z = z0 + nb0 * z1
     int nb0 = 1, nb1 = 1;

@@ -394,6 +394,27 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
                     for (int kk = 0; kk < K; kk++) v[(size_t)kk * D + d] = t.host[(size_t)d * K + kk];
                 push(std::string(nm) + "#kd", std::move(v), {K, D});
             }
+    // [feed_forward1.in_proj ; self_attn_weights.in_proj] stacked: both read the layer input, so the engine runs them as ONE GEMM
+    // (SwooshL on the first F1 columns only) -- one launch and one pass over x instead of two
+    for (int si = 0; si < c.ns; si++)
+        for (int li = 0; li < c.nlayer[si]; li++) {
+            char pf[160];
+            snprintf(pf, sizeof pf, "encoder.encoders.%d.layers.%d.", si, li);
+            const std::string P(pf);
+            const Tensor& wf = tensor(P + "feed_forward1.in_proj.weight");
+            const Tensor& wa = tensor(P + "self_attn_weights.in_proj.weight");
+            const Tensor& bf = tensor(P + "feed_forward1.in_proj.bias");
+            const Tensor& ba = tensor(P + "self_attn_weights.in_proj.bias");
+            const int F1 = (int)wf.dims[0], NA = (int)wa.dims[0], D = (int)wf.dims[1];
+            K2_REQUIRE(D == c.dim[si] && (int)wa.dims[1] == D, "%s: in_proj widths disagree", pf);
+            std::vector<float> wv((size_t)(F1 + NA) * D), bv((size_t)F1 + NA);
+            std::copy(wf.host, wf.host + (size_t)F1 * D, wv.begin());
+            std::copy(wa.host, wa.host + (size_t)NA * D, wv.begin() + (size_t)F1 * D);
+            std::copy(bf.host, bf.host + F1, bv.begin());
+            std::copy(ba.host, ba.host + NA, bv.begin() + F1);
+            push(P + "#ff1_attn_in.weight", std::move(wv), {F1 + NA, D});
+            push(P + "#ff1_attn_in.bias", std::move(bv), {F1 + NA});
+        }
     }  // has_encoder
     if (has("joiner.output_linear.weight")) {   // joiner.output_linear [V,J] -> k-major [J][Vp]
         const Tensor& t = tensor("joiner.output_linear.weight");
