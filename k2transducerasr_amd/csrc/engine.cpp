@@ -297,15 +297,21 @@ void Engine::encoder_layer(const Ctx& c, int si, int li, float* x, const float* 
         g.W = tmp; g.w_kn = 1; g.ldw = Hc; g.sW0 = (long long)T * Hc;
         g.C = tmp2; g.ldc = Hc; g.sC0 = (long long)T * Hc;
         g.M = T; g.N = Hc; g.K = T; g.nb0 = B; g.nb1 = 1;
+        g.mul = hid + 2 * Hc; g.ldm = 3 * Hc; g.sM0 = (long long)T * 3 * Hc;  // x * y (the third chunk of in_proj) in the epilogue
         gemm(c, g);
-        mul_cols(c, tmp2, hid, 3 * Hc, 2 * Hc, M, Hc);
         linear(c, tmp2, Hc, w("nonlin_attention.out_proj.weight"), w("nonlin_attention.out_proj.bias"), src, D, M, Hc, D,
                ACT_NONE, src, D);
     }
     self_attn(1);
     conv_module(1);
-    feed_forward(2, F, src, src);
-    bypass(c, x, src, w("bypass_mid.bypass_scale"), src, M, D);
+    {   // src = bypass_mid(x, src + ff2(src)): the bypass mix runs in the out_proj GEMM's epilogue
+        linear(c, src, D, w("feed_forward2.in_proj.weight"), w("feed_forward2.in_proj.bias"), hid, F, M, D, F, ACT_SWOOSH_L);
+        GemmArgs g;
+        g.A = hid; g.lda = F; g.W = w("feed_forward2.out_proj.weight"); g.ldw = F; g.bias = w("feed_forward2.out_proj.bias");
+        g.C = src; g.ldc = D; g.M = M; g.N = D; g.K = F; g.res = src; g.ldr = D;
+        g.byp_orig = x; g.ld_orig = D; g.byp_scale = w("bypass_mid.bypass_scale");
+        gemm(c, g);
+    }
     self_attn(2);
     conv_module(2);
     feed_forward(3, F * 5 / 4, src, src);

@@ -290,6 +290,11 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
                 if (row < g.M && !(g.ablate & 4)) {
                     float v = apply_act(acc[i][j][r] + bv, act);
                     if (R) v += rres[i][j][r];
+                    if (g.mul) v *= g.mul[z0 * g.sM0 + z1 * g.sM1 + (long long)row * g.ldm + col];
+                    if (g.byp_orig) {
+                        const float o = g.byp_orig[(long long)row * g.ld_orig + col];
+                        v = o + (v - o) * g.byp_scale[col];
+                    }
                     C[(long long)row * g.ldc + col] = v;
                 }
             }
@@ -459,6 +464,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
                 if (row < g.M) {
                     float v = apply_act(acc[i][j][r] + bv, act);
                     if (R) v += rres[i][j][r];
+                    if (g.byp_orig) {
+                        const float o = g.byp_orig[(long long)row * g.ld_orig + col];
+                        v = o + (v - o) * g.byp_scale[col];
+                    }
                     C[(long long)row * g.ldc + col] = v;
                 }
             }
@@ -624,7 +633,7 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     const bool plain = a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.K % 64 == 0 && a.K >= 64;
     // (16-row workgroups re-read the weight chunk M/16 times: with many rows and a short K the 64x64 tiles are better)
     const bool few_tiles = (long long)cdiv(a.M, 128) * cdiv(a.N, 64) < 144 && a.M <= 4096 && !(a.M >= 2048 && a.K <= 256 && a.N > 272);
-    const bool skinny_ok = g_forced_cfg < 0 && !no_skinny && plain && ((a.N <= 96 && a.M >= 512) || few_tiles);
+    const bool skinny_ok = g_forced_cfg < 0 && !no_skinny && plain && !a.mul && !a.byp_orig && ((a.N <= 96 && a.M >= 512) || few_tiles);
     if (skinny_ok) {
         if (a.N <= 48) hipLaunchKernelGGL(gemm_f32_mfma_skinny<3>, dim3(cdiv(a.M, 16), 1), dim3(256), 0, ctx.stream, b);
         else hipLaunchKernelGGL(gemm_f32_mfma_skinny<6>, dim3(cdiv(a.M, 16), cdiv(a.N, 96)), dim3(256), 0, ctx.stream, b);
@@ -633,7 +642,7 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
         return;
     }
-    const bool dma_ok = a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.K % 32 == 0 && a.K >= 64 && a.lda % 4 == 0;
+    const bool dma_ok = a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.K % 32 == 0 && a.K >= 64 && a.lda % 4 == 0 && !a.mul;
     if (dma_ok && g_use_dma && (cfg == 5 || cfg == 0 || (cfg >= 7 && cfg <= 11))) {
         if (cfg == 11) launch_dma<64, 96, 32, 32, 2>(ctx, b);        // 64x96 tiles (6 waves): N % 96 == 0 outputs that 128x64 quantises badly
         else if (cfg == 9) launch_dma<64, 64, 32, 32, 2>(ctx, b);    // tuning: 64x64 tiles, 2 stages

@@ -72,6 +72,15 @@ struct GemmArgs {
     //   k -> (k / seg_len) * seg_stride + k % seg_len
     int cv_Fout = 0, cv_Tout = 0, cv_Tin = 0, cv_Fin = 0, cv_C = 0, cv_st = 1, cv_sf = 1;
     int seg_len = 0, seg_stride = 0;
+    // epilogue extras (after bias, activation and residual):
+    //   mul:  v *= mul[row*ldm + col]                      (batched like C: + z0*sM0 + z1*sM1)   -- NonlinAttention's output gate
+    //   byp:  v = o + (v - o) * byp_scale[col], o = byp_orig[row*ld_orig + col]                 -- Zipformer bypass module
+    const float* mul = nullptr;
+    int ldm = 0;
+    long long sM0 = 0, sM1 = 0;
+    const float* byp_orig = nullptr;
+    const float* byp_scale = nullptr;
+    int ld_orig = 0;
     int ablate = 0;  // tuning only: 1 = skip in-loop global loads, 2 = skip MFMAs, 4 = skip epilogue stores
 };
 void gemm(const Ctx& ctx, const GemmArgs& a);
