@@ -121,13 +121,24 @@ __global__ __launch_bounds__(192) void k_dwconv7x7_tiled(const float* __restrict
     const int tid = threadIdx.x, cq = tid & 7, fi = tid >> 3;
     const int c0 = blockIdx.x * DW7_CG, t0 = blockIdx.y * DW7_TT, b = blockIdx.z;
     const int FP = F + 6, ncell = (DW7_TT + 6) * FP * 8;
-    for (int idx = tid; idx < ncell; idx += 192) {
-        const int q = idx & 7, cell = idx >> 3;
-        const int fp = cell % FP, r = cell / FP;
-        const int f = fp - 3, tt = t0 + r - tpad;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f >= 0 && f < F && tt >= 0 && tt < Tin) v = *reinterpret_cast<const float4*>(x + (((long long)b * Tin + tt) * F + f) * C + c0 + 4 * q);
-        *reinterpret_cast<float4*>(xs + (long long)cell * 32 + 4 * q) = v;
+    // five patch cells per lane in flight (one at a time, the staging was a chain of ~15 memory latencies per workgroup)
+    for (int base = tid; base < ncell; base += 5 * 192) {
+        float4 v[5];
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            const int idx = base + u * 192;
+            const int q = idx & 7, cell = idx >> 3;
+            const int fp = cell % FP, r = cell / FP;
+            const int f = fp - 3, tt = t0 + r - tpad;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < ncell && f >= 0 && f < F && tt >= 0 && tt < Tin)
+                v[u] = *reinterpret_cast<const float4*>(x + (((long long)b * Tin + tt) * F + f) * C + c0 + 4 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            const int idx = base + u * 192;
+            if (idx < ncell) *reinterpret_cast<float4*>(xs + (long long)(idx >> 3) * 32 + 4 * (idx & 7)) = v[u];
+        }
     }
     __syncthreads();
     if (fi >= F) return;
