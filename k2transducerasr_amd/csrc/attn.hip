@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_scores_softmax(const float* __r
     }
 }
 
-// Long-sequence form (T beyond the LDS strip, i.e. > 1275 frames at this stack's rate): two passes over the key tiles with
+// Long-sequence form (T beyond the LDS strip, i.e. > ~1120 frames at this stack's rate): two passes over the key tiles with
 // nothing but the row statistics kept -- pass 1 builds each row's running (max, sum of exp) per lane, combined once across
 // lanes and waves; pass 2 recomputes the scores and writes exp(s - max) / sum straight to the weights.  Twice the (small)
 // score arithmetic, no strip.
@@ -368,7 +368,7 @@ void attn_scores_softmax(const Ctx& ctx, const float* qkp, int ld, const float* 
     ctx.add_flops(0.0, 2.0 * (QH + PH) * (double)T * T * B * H, 0);
     if (ctx.dry) return;
     static const bool force_long = getenv("K2HIP_ATTN_LONG") != nullptr;
-    if (lds > 160 * 1024 || force_long) {  // > 1275 frames: two-pass form without the LDS strip
+    if (lds > 160 * 1024 || force_long) {  // > ~1120 frames: two-pass form without the LDS strip
         hipLaunchKernelGGL(k_attn_scores_softmax_long, dim3(cdiv(T, R), B, H), dim3(256), 0, ctx.stream, qkp, ld, pp, aw, B, T, Tp, H);
         K2_HIP(hipGetLastError());
         return;

@@ -100,7 +100,7 @@ def test_full_size_batch_properties(hip_large):
 
 
 def test_long_utterances_beyond_the_lds_strip(hip_tiny, oracle_tiny, hip_conformer, oracle_conformer):
-    """Attention for sequences longer than the in-LDS score strip (Zipformer2: > 1275 frames at 50 Hz, i.e. > 25 s; Conformer:
+    """Attention for sequences longer than the in-LDS score strip (Zipformer2: > ~1120 frames at 50 Hz, i.e. > 22 s; Conformer:
     > 2048 frames at 25 Hz) takes the two-pass kernels; same numbers, no length limit."""
     from k2transducerasr_amd.synth import synth_utterance
     u = synth_utterance(77, 31.0)                      # T = 3117 -> T50 = 1555
