@@ -289,6 +289,9 @@ LSTM_PRESETS = {
     "lstm-en": dict(),
     "lstm-tiny-test": dict(d_model=64, rnn_hidden_size=96, dim_feedforward=160, num_encoder_layers=3, joiner_dim=512, decoder_dim=64,
                            vocab_size=41),
+    # wide enough for the split-K form of the projection / feed-forward products of the layer wavefront, 5 layers deep
+    "lstm-tiny-split-test": dict(d_model=64, rnn_hidden_size=256, dim_feedforward=384, num_encoder_layers=5, joiner_dim=512, decoder_dim=64,
+                                 vocab_size=41),
 }
 
 

@@ -116,6 +116,7 @@ class Engine {
     int lstm_out_frames(int T) const;
     float* lstm_embed(const Ctx& c, const float* x, int B, int T, int* T_out);
     void lstm_layer(const Ctx& c, int li, float* x, const float* h0, int ldh0, float* cst, int B, int T, float* y);
+    float* lstm_forward_seq(const Ctx& c, float* xe, int B, int T3, float* enc_out, int tap, float** tap_ptr, int* tap_dim);
     float* lstm_forward(const Ctx& c, const float* x, int B, int T, int* Tp, int tap, float** tap_ptr, int* tap_rows, int* tap_dim);
     float* lstm_chunk(const Ctx& c, const float* x, const int* d_slots, int B);
     // streaming Zipformer v1 (zipformer1_engine.cpp)

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
     for (int j = 0; j < NT; j++) {
         int col = n0 + wc * WN + j * 32 + li;
         if (col >= g.N) continue;
-        float bv = g.bias ? g.bias[col] : 0.f;
+        float bv = g.bias ? g.bias[z0 * g.sBias0 + col] : 0.f;
         const int act = (g.act_cols == 0 || col < g.act_cols) ? g.act : (int)ACT_NONE;
 #pragma unroll
         for (int i = 0; i < MT; i++) {
@@ -329,10 +329,12 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WCOLS, wc = wave % WCOLS;
     const int li = lane & 31, lh = lane >> 5;
-    const float* __restrict__ A = g.A;
-    const float* __restrict__ W = g.W;
-    float* __restrict__ C = g.C;
-    const float* __restrict__ R = g.res;
+    // blockIdx.z = z0 + nb0 * z1: batched launches (the LSTM layer wavefront: one z per layer, every operand at its own stride)
+    const int z0 = blockIdx.z % g.nb0, z1 = blockIdx.z / g.nb0;
+    const float* __restrict__ A = g.A + z0 * g.sA0 + z1 * g.sA1;
+    const float* __restrict__ W = g.W + z0 * g.sW0 + z1 * g.sW1;
+    float* __restrict__ C = g.C + z0 * g.sC0 + z1 * g.sC1;
+    const float* __restrict__ R = g.res ? g.res + z0 * g.sR0 + z1 * g.sR1 : nullptr;
     int mb_, nb_;
     xcd_tile(mb_, nb_);
     const int m0 = mb_ * BM, n0 = nb_ * BN;
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
     for (int j = 0; j < NT; j++) {
         int col = n0 + wc * WN + j * 32 + li;
         if (col >= g.N) continue;
-        float bv = g.bias ? g.bias[col] : 0.f;
+        float bv = g.bias ? g.bias[z0 * g.sBias0 + col] : 0.f;
         const int act = (g.act_cols == 0 || col < g.act_cols) ? g.act : (int)ACT_NONE;
 #pragma unroll
         for (int i = 0; i < MT; i++) {
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_skinny(GemmArgs g) {
 
 template <int BM, int BN, int WM, int WN, int NST = 3>
 void launch_dma(const Ctx& ctx, const GemmArgs& a) {
-    dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), 1);
+    dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.nb0 * a.nb1);
     size_t lds = sizeof(float) * NST * (BM + BN) * 32;
     static LdsAttrOnce lds_attr;
     lds_attr.ensure(gemm_f32_mfma_dma<BM, BN, WM, WN, NST>, (int)lds);
@@ -584,6 +586,7 @@ int g_forced_cfg = getenv("K2HIP_GEMM_CFG") ? atoi(getenv("K2HIP_GEMM_CFG")) : -
 int choose_cfg(const GemmArgs& a) {
     if (g_forced_cfg >= 0) return g_forced_cfg;
     if (a.N <= 64) return 2;    // 64x64 tiles, 4 waves
+    if (a.M <= 64) return 3;    // a handful of rows (per-frame recurrent products, batched over layers): 64x64 tiles, K step 64
     // few output tiles (streaming chunks: 256..2048 rows): the launch is one latency-bound K sweep per
     // workgroup; small tiles with a 64-deep K step are fastest (gpurun_out/gemm_tune_s1.txt)
     if ((long long)cdiv(a.M, 128) * cdiv(a.N, 64) * a.nb0 * a.nb1 < 144) return 3;  // fewer 128x64 tiles than ~half the CUs
@@ -642,8 +645,17 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
         return;
     }
-    const bool dma_ok = a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.K % 32 == 0 && a.K >= 64 && a.lda % 4 == 0 && !a.mul;
-    if (dma_ok && g_use_dma && (cfg == 5 || cfg == 0 || (cfg >= 7 && cfg <= 11))) {
+    const bool dma_ok = a.cv_Fout == 0 && !a.w_kn && a.K % 32 == 0 && a.K >= 64 && a.lda % 4 == 0 && !a.mul;
+    if (dma_ok && g_use_dma && g_forced_cfg < 0 && a.nb0 * a.nb1 > 1 && a.M <= 64) {
+        // a handful of rows against many layers' weight matrices (LSTM wavefront): a weight-streaming problem -- 64x64 tiles, three
+        // 16 KB stages in flight per workgroup
+        launch_dma<32, 64, 32, 32, 4>(ctx, b);
+        K2_HIP(hipGetLastError());
+        if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 16;
+        if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
+        return;
+    }
+    if (dma_ok && a.nb0 * a.nb1 == 1 && g_use_dma && (cfg == 5 || cfg == 0 || (cfg >= 7 && cfg <= 11))) {
         if (cfg == 11) launch_dma<64, 96, 32, 32, 2>(ctx, b);        // 64x96 tiles (6 waves): N % 96 == 0 outputs that 128x64 quantises badly
         else if (cfg == 9) launch_dma<64, 64, 32, 32, 2>(ctx, b);    // tuning: 64x64 tiles, 2 stages
         else if (cfg == 10) launch_dma<64, 64, 32, 32, 3>(ctx, b);   // tuning: 64x64 tiles, 3 stages

@@ -67,6 +67,7 @@ struct GemmArgs {
     // batching over blockIdx.z = z0 + nb0 * z1
     int nb0 = 1, nb1 = 1;
     long long sA0 = 0, sA1 = 0, sW0 = 0, sW1 = 0, sC0 = 0, sC1 = 0, sR0 = 0, sR1 = 0;
+    long long sBias0 = 0;  // bias + z0 * sBias0 (batched launches over layers, each with its own bias)
     // implicit-conv gather of A over an NHWC tensor [B, Tin, Fin, C]:
     //   row r = (b*Tout + t)*Fout + f  ->  base = ((b*Tin + t*st)*Fin + f*sf)*C
     //   k -> (k / seg_len) * seg_stride + k % seg_len
@@ -131,6 +132,17 @@ void conv0_nopad_dswish(const Ctx& ctx, const float* x, const float* w, const fl
 // gates i,f,g,o = gx[b] + gh[b] ([4*Hh] each, row strides ldgx / ldgh): c = f*c + i*g; hf = o * tanh(c)
 void lstm_cell(const Ctx& ctx, const float* gx, long long ldgx, const float* gh, int ldgh, float* c, float* hf, int B, int Hh);
 void add_inplace(const Ctx& ctx, float* a, const float* b, long long n);
+// layer-wavefront form (lstm_engine.cpp): rows r = z*B + b over the n active layers z (layer lo + z works on frame s - lo - z)
+//   gates [n*B, 4Hh] (both biases already added by the GEMMs) -> c [n*B, Hh] updated, hf [n*B, Hh]
+void lstm_cell_rows(const Ctx& ctx, const float* gates, float* c, float* hf, int rows, int Hh);
+//   h[z][b] = sum_q hp[q][z][b] (the S split-K partials of the projection, `pstride` floats apart); x1[z][b] = Y[lo+z][b*T + t_z] + h
+//   (Y: [L+1][B*T][D], layer stride SY)
+void lstm_add_frame(const Ctx& ctx, const float* Y, long long SY, const float* hp, long long pstride, int S, float* h, float* x1, int n, int B,
+                    int T, int D, int lo, int s);
+//   x2 = x1 + b2 + sum_q fp[q] (split-K partials of feed_forward.4); Y[lo+z+1][b*T + t_z] = BasicNorm(x2); b2 / eps of layer l at
+//   b2_0 + l*lstride / eps0 + l*lstride
+void lstm_norm_frame(const Ctx& ctx, const float* x1, const float* fp, long long pstride, int S, const float* b2_0, const float* eps0,
+                     long long lstride, float* Y, long long SY, int n, int B, int T, int D, int lo, int s);
 // rows of `width` floats between a [B, width] work buffer and the per-stream pool slots (pool + slot*stride + off)
 void gather_rows(const Ctx& ctx, const float* pool, long long slot_stride, long long off, const int* slots, float* out, int B, int width);
 void scatter_rows(const Ctx& ctx, float* pool, long long slot_stride, long long off, const int* slots, const float* in, int ldin, int B, int width);

@@ -25,6 +25,62 @@ __global__ void k_lstm_cell(const float* __restrict__ gx, long long ldgx, const 
     hf[i] = og * tanhf(cn);
 }
 
+// wavefront form: gates already hold x.W_ih + b_ih + h.W_hh + b_hh
+__global__ void k_lstm_cell_rows(const float* __restrict__ gates, float* __restrict__ c, float* __restrict__ hf, int rows, int Hh) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * Hh) return;
+    const int r = i / Hh, j = i - r * Hh;
+    const float* g = gates + (long long)r * 4 * Hh;
+    const float ig = sigm(g[j]), fg = sigm(g[Hh + j]), gg = tanhf(g[2 * Hh + j]), og = sigm(g[3 * Hh + j]);
+    const float cn = fg * c[i] + ig * gg;
+    c[i] = cn;
+    hf[i] = og * tanhf(cn);
+}
+// h[z][b] = sum of the S split-K partials hp[s][z][b] of the projection; x1 = x_t + h
+__global__ void k_lstm_add_frame(const float* __restrict__ Y, long long SY, const float* __restrict__ hp, long long pstride, int S,
+                                 float* __restrict__ h, float* __restrict__ x1, int n, int B, int T, int D, int lo, int s) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * B * D) return;
+    const int d = i % D, r = i / D, b = r % B, z = r / B;
+    const int t = s - lo - z;
+    float hv = hp[i];
+    for (int q = 1; q < S; q++) hv += hp[(long long)q * pstride + i];
+    h[i] = hv;
+    x1[i] = Y[(long long)(lo + z) * SY + ((long long)b * T + t) * D + d] + hv;
+}
+// one wave per row: x2 = x1 + b2 + sum of the S split-K partials of feed_forward.4; Y[l+1][frame] = BasicNorm(x2)
+__global__ __launch_bounds__(256) void k_lstm_norm_frame(const float* __restrict__ x1, const float* __restrict__ fp, long long pstride, int S,
+                                                         const float* __restrict__ b2_0, const float* __restrict__ eps0, long long lstride,
+                                                         float* __restrict__ Y, long long SY, int n, int B, int T, int D, int lo, int s) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n * B) return;
+    const int b = r % B, z = r / B, t = s - lo - z;
+    const float* b2 = b2_0 + (long long)(lo + z) * lstride;
+    float v[16];  // D <= 1024
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int d = lane + 64 * k;
+        v[k] = 0.f;
+        if (d < D) {
+            const long long i = (long long)r * D + d;
+            float a = fp[i];
+            for (int q = 1; q < S; q++) a += fp[(long long)q * pstride + i];
+            v[k] = (a + b2[d]) + x1[i];
+            ss += v[k] * v[k];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float sc = 1.0f / sqrtf(ss / (float)D + expf(eps0[(long long)(lo + z) * lstride]));
+    float* yr = Y + (long long)(lo + z + 1) * SY + ((long long)b * T + t) * D;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int d = lane + 64 * k;
+        if (d < D) yr[d] = v[k] * sc;
+    }
+}
+
 __global__ void k_add_inplace(float* __restrict__ a, const float* __restrict__ b, long long n4) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
@@ -52,6 +108,26 @@ __global__ void k_scatter_rows(float* __restrict__ pool, long long slot_stride, 
 void lstm_cell(const Ctx& ctx, const float* gx, long long ldgx, const float* gh, int ldgh, float* c, float* hf, int B, int Hh) {
     if (ctx.dry) return;
     hipLaunchKernelGGL(k_lstm_cell, dim3(cdiv((long long)B * Hh, 256)), dim3(256), 0, ctx.stream, gx, ldgx, gh, ldgh, c, hf, B, Hh);
+    K2_HIP(hipGetLastError());
+}
+void lstm_cell_rows(const Ctx& ctx, const float* gates, float* c, float* hf, int rows, int Hh) {
+    if (ctx.dry) return;
+    hipLaunchKernelGGL(k_lstm_cell_rows, dim3(cdiv((long long)rows * Hh, 256)), dim3(256), 0, ctx.stream, gates, c, hf, rows, Hh);
+    K2_HIP(hipGetLastError());
+}
+void lstm_add_frame(const Ctx& ctx, const float* Y, long long SY, const float* hp, long long pstride, int S, float* h, float* x1, int n, int B,
+                    int T, int D, int lo, int s) {
+    if (ctx.dry) return;
+    hipLaunchKernelGGL(k_lstm_add_frame, dim3(cdiv((long long)n * B * D, 256)), dim3(256), 0, ctx.stream, Y, SY, hp, pstride, S, h, x1, n, B, T,
+                       D, lo, s);
+    K2_HIP(hipGetLastError());
+}
+void lstm_norm_frame(const Ctx& ctx, const float* x1, const float* fp, long long pstride, int S, const float* b2_0, const float* eps0,
+                     long long lstride, float* Y, long long SY, int n, int B, int T, int D, int lo, int s) {
+    K2_REQUIRE(D <= 1024, "lstm: d_model %d unsupported (<= 1024)", D);
+    if (ctx.dry) return;
+    hipLaunchKernelGGL(k_lstm_norm_frame, dim3(cdiv(n * B, 4)), dim3(256), 0, ctx.stream, x1, fp, pstride, S, b2_0, eps0, lstride, Y, SY, n, B, T,
+                       D, lo, s);
     K2_HIP(hipGetLastError());
 }
 void add_inplace(const Ctx& ctx, float* a, const float* b, long long n) {

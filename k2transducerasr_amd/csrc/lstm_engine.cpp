@@ -84,17 +84,11 @@ void Engine::lstm_layer(const Ctx& c, int li, float* x, const float* h0, int ldh
     ar.rewind(mark);
 }
 
-// offline: zero initial states.  taps: 0 = embed output; 1+i = after layer i
-float* Engine::lstm_forward(const Ctx& c, const float* x, int B, int T, int* Tp, int tap, float** tap_ptr, int* tap_rows, int* tap_dim) {
+// offline, layer by layer (three launches per frame and layer): the fallback when the layers' tensors are not evenly spaced
+float* Engine::lstm_forward_seq(const Ctx& c, float* xe, int B, int T3, float* enc_out, int tap, float** tap_ptr, int* tap_dim) {
     const Model& m = *model_;
     const Config& cf = m.cfg();
     Arena& ar = *c.arena;
-    const int Tpp = lstm_out_frames(T);
-    K2_REQUIRE(Tpp > 0, "encoder: %d input frames are too few", T);
-    float* enc_out = ar.take<float>((int64_t)B * Tpp * cf.J);
-    int T3 = 0;
-    float* xe = lstm_embed(c, x, B, T, &T3);
-    if (tap_rows) *tap_rows = B * T3;
     const int D = cf.dim[0], Hh = cf.rnn_hidden;
     float* h0 = ar.take<float>((int64_t)B * D);
     float* cst = ar.take<float>((int64_t)B * Hh);
@@ -111,7 +105,124 @@ float* Engine::lstm_forward(const Ctx& c, const float* x, int B, int T, int* Tp,
         lstm_layer(c, li, xe, h0, D, cst, B, T3, y);
     }
     linear(c, xe, D, m.w("joiner.encoder_proj.weight"), m.w("joiner.encoder_proj.bias"), enc_out, cf.J, B * T3, D, cf.J);
+    return enc_out;
+}
+
+// offline: zero initial states.  taps: 0 = embed output; 1+i = after layer i.
+//
+// Layer wavefront: layer l can work on frame t as soon as layer l-1 has finished frame t and layer l itself frame t-1, so at
+// step s every layer l with 0 <= s-l < T' advances by one frame (t = s-l) -- T'+L-1 steps instead of T'.L.  The layers' weights
+// sit in the model blob at one constant stride (same tensors, same order per layer), so each product of a step is ONE batched GEMM
+// over the active layers (blockIdx.z = layer; operands, bias and output addressed by batch strides): 8 launches per step
+// (x.W_ih, + h.W_hh, cell, projection, residual, feed-forward in / out, BasicNorm) against 3 per frame AND layer before.
+float* Engine::lstm_forward(const Ctx& c, const float* x, int B, int T, int* Tp, int tap, float** tap_ptr, int* tap_rows, int* tap_dim) {
+    const Model& m = *model_;
+    const Config& cf = m.cfg();
+    Arena& ar = *c.arena;
+    const int Tpp = lstm_out_frames(T);
+    K2_REQUIRE(Tpp > 0, "encoder: %d input frames are too few", T);
+    float* enc_out = ar.take<float>((int64_t)B * Tpp * cf.J);
+    int T3 = 0;
+    float* xe = lstm_embed(c, x, B, T, &T3);
+    if (tap_rows) *tap_rows = B * T3;
     *Tp = T3;
+    const int D = cf.dim[0], Hh = cf.rnn_hidden, F = cf.ff[0], G = 4 * Hh, L = cf.nlayer[0];
+    // constant layer stride of every per-layer tensor?
+    static const char* kNames[] = {"lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0", "lstm.weight_hr_l0",
+                                   "feed_forward.0.weight", "feed_forward.0.bias", "feed_forward.4.weight", "feed_forward.4.bias",
+                                   "norm_final.eps"};
+    const float* base[10];
+    long long LS = 0;
+    bool even = !getenv("K2HIP_LSTM_SEQ");
+    for (int k = 0; k < 10 && even; k++) {
+        base[k] = m.wf("encoder.encoder.layers.0.%s", kNames[k]);
+        for (int l = 1; l < L && even; l++) {
+            const long long d = m.wf("encoder.encoder.layers.%d.%s", l, kNames[k]) - m.wf("encoder.encoder.layers.%d.%s", l - 1, kNames[k]);
+            if (LS == 0) LS = d;
+            even = d == LS && d > 0;
+        }
+    }
+    if (!even) return lstm_forward_seq(c, xe, B, T3, enc_out, tap, tap_ptr, tap_dim);
+
+    const long long SY = (long long)B * T3 * D;
+    float* Y = ar.take<float>((int64_t)(L + 1) * SY);        // Y[0] = embed output, Y[l+1] = output of layer l
+    float* gates = ar.take<float>((int64_t)L * B * G);
+    float* cst = ar.take<float>((int64_t)L * B * Hh);
+    float* hf = ar.take<float>((int64_t)L * B * Hh);
+    float* h = ar.take<float>((int64_t)L * B * D);
+    float* x1 = ar.take<float>((int64_t)L * B * D);
+    // the two N = d_model products (projection, feed_forward.4) have few output tiles but long K: split K four ways over
+    // blockIdx.z as well (partials summed, in a fixed order, by the small kernel that consumes them)
+    const int SP = (Hh % 128 == 0 && Hh >= 256) ? 4 : 1, SF = (F % 128 == 0 && F >= 256) ? 4 : 1;
+    const long long PST = (long long)L * B * D;
+    float* hp = ar.take<float>((int64_t)SP * PST);
+    float* fp = ar.take<float>((int64_t)SF * PST);
+    float* ffh = ar.take<float>((int64_t)L * B * F);
+    if (!c.dry) K2_HIP(hipMemcpyAsync(Y, xe, sizeof(float) * (size_t)SY, hipMemcpyDeviceToDevice, c.stream));
+    zero_floats(c, cst, (long long)L * B * Hh);
+    zero_floats(c, h, (long long)L * B * D);
+    const long long ldy = (long long)T3 * D;
+    for (int s = 0; s < T3 + L - 1; s++) {
+        const int lo = std::max(0, s - T3 + 1), hi = std::min(L - 1, s), n = hi - lo + 1;
+        auto layers = [&](GemmArgs& g) {
+            g.M = B; g.nb0 = n; g.nb1 = 1;
+            g.W += lo * LS; g.sW0 = LS;
+            if (g.bias) { g.bias += lo * LS; g.sBias0 = LS; }
+        };
+        {   // gates = x_t . W_ih^T + b_ih
+            GemmArgs g;
+            g.A = Y + lo * SY + (long long)(s - lo) * D; g.lda = (int)ldy; g.sA0 = SY - D;
+            g.W = base[0]; g.ldw = D; g.bias = base[2];
+            g.C = gates + (long long)lo * B * G; g.ldc = G; g.sC0 = (long long)B * G; g.N = G; g.K = D;
+            layers(g);
+            gemm(c, g);
+        }
+        {   // gates += h_{t-1} . W_hh^T + b_hh
+            GemmArgs g;
+            g.A = h + (long long)lo * B * D; g.lda = D; g.sA0 = (long long)B * D;
+            g.W = base[1]; g.ldw = D; g.bias = base[3];
+            g.C = gates + (long long)lo * B * G; g.ldc = G; g.sC0 = (long long)B * G; g.N = G; g.K = D;
+            g.res = g.C; g.ldr = G; g.sR0 = g.sC0;
+            layers(g);
+            gemm(c, g);
+        }
+        lstm_cell_rows(c, gates + (long long)lo * B * G, cst + (long long)lo * B * Hh, hf + (long long)lo * B * Hh, n * B, Hh);
+        {   // h_t = hf . W_hr^T (split-K partials)
+            GemmArgs g;
+            g.A = hf + (long long)lo * B * Hh; g.lda = Hh; g.sA0 = (long long)B * Hh;
+            g.W = base[4]; g.ldw = Hh;
+            g.C = hp + (long long)lo * B * D; g.ldc = D; g.sC0 = (long long)B * D; g.N = D; g.K = Hh / SP;
+            layers(g);
+            g.nb1 = SP; g.sA1 = Hh / SP; g.sW1 = Hh / SP; g.sC1 = PST;
+            gemm(c, g);
+        }
+        // h_t = sum of the partials; x1 = x_t + h_t
+        lstm_add_frame(c, Y, SY, hp + (long long)lo * B * D, PST, SP, h + (long long)lo * B * D, x1 + (long long)lo * B * D, n, B, T3, D, lo, s);
+        {   // feed-forward
+            GemmArgs g;
+            g.A = x1 + (long long)lo * B * D; g.lda = D; g.sA0 = (long long)B * D;
+            g.W = base[5]; g.ldw = D; g.bias = base[6]; g.act = ACT_DOUBLE_SWISH;
+            g.C = ffh + (long long)lo * B * F; g.ldc = F; g.sC0 = (long long)B * F; g.N = F; g.K = D;
+            layers(g);
+            gemm(c, g);
+        }
+        {   // feed_forward.4 (split-K partials; bias, residual and BasicNorm in the consumer)
+            GemmArgs g;
+            g.A = ffh + (long long)lo * B * F; g.lda = F; g.sA0 = (long long)B * F;
+            g.W = base[7]; g.ldw = F;
+            g.C = fp + (long long)lo * B * D; g.ldc = D; g.sC0 = (long long)B * D; g.N = D; g.K = F / SF;
+            layers(g);
+            g.nb1 = SF; g.sA1 = F / SF; g.sW1 = F / SF; g.sC1 = PST;
+            gemm(c, g);
+        }
+        lstm_norm_frame(c, x1 + (long long)lo * B * D, fp + (long long)lo * B * D, PST, SF, base[8], base[9], LS, Y, SY, n, B, T3, D, lo, s);
+    }
+    if (tap >= 0 && tap <= L) {
+        *tap_ptr = Y + (long long)tap * SY;
+        *tap_dim = D;
+        return nullptr;
+    }
+    linear(c, Y + (long long)L * SY, D, m.w("joiner.encoder_proj.weight"), m.w("joiner.encoder_proj.bias"), enc_out, cf.J, B * T3, D, cf.J);
     return enc_out;
 }
 

@@ -28,6 +28,7 @@ BLANK_BIAS = {
     "conformer-zh": 2.615,
     "lstm-en": 3.0,
     "lstm-tiny-test": 2.0,
+    "lstm-tiny-split-test": 2.0,
     "zipformer2-ctc-tiny-test": 1.5,
     "zipformer2-ctc-streaming-tiny-test": 1.5,
     "conformer-tiny-test": 2.179,

@@ -85,3 +85,31 @@ def test_lstm_shortest_inputs(hip_lstm, oracle_lstm):
     from k2transducerasr_amd import K2HipError
     with pytest.raises(K2HipError):
         hip_lstm.encoder_proj(np.zeros((1, 8, 80), np.float32))
+
+
+def test_lstm_wavefront_split_k_and_sequential_fallback(tmp_path_factory, utts):
+    """A model wide enough for the split-K products of the layer wavefront (projection and feed_forward.4 summed from four
+    partials) and deeper than the utterances are short: encoder output and tokens against the oracle, and against the
+    layer-by-layer fallback path (K2HIP_LSTM_SEQ) of the same library."""
+    import os
+    from k2transducerasr_amd import Model
+    from k2transducerasr_amd.synth import write_synthetic_model
+    from oracle.online import OnlineOracle
+    p = str(tmp_path_factory.mktemp("lstms") / "lstm_split.k2w")
+    write_synthetic_model(p, "lstm-tiny-split-test")
+    hip, ora = Model(p, 0), OnlineOracle(p)
+    feats = [ora.fbank(u) for u in utts]
+    x = ora.pad_sequence(feats).reshape(len(feats), -1, 80)
+    enc = ora.encoder(x)
+    got = hip.encoder_proj(x)
+    np.testing.assert_allclose(got, enc, atol=ACT_TOL, rtol=0)
+    want, mg = ora.greedy_batch(enc, want_margins=True)
+    assert_tokens_match(hip.offline_greedy_from_samples(utts), want, mg, what="lstm split-K")
+    for T in (9, 13, 20):   # fewer frames than layers: the wavefront never has all layers active
+        xs = np.random.default_rng(T).standard_normal((2, T, 80)).astype(np.float32)
+        np.testing.assert_allclose(hip.encoder_proj(xs), ora.encoder(xs), atol=ACT_TOL, rtol=0)
+    os.environ["K2HIP_LSTM_SEQ"] = "1"
+    try:
+        np.testing.assert_allclose(hip.encoder_proj(x), got, atol=ACT_TOL, rtol=0)
+    finally:
+        del os.environ["K2HIP_LSTM_SEQ"]
