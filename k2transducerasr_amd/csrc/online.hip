@@ -50,34 +50,47 @@ __global__ void k_convnext_cache(const float* __restrict__ a3, float* __restrict
         a3[(((long long)b * T3 + (Tc - 3 + t)) * F + f) * C + c];
 }
 
-// cat[b] = [cache[slot_b] (L rows) ; new[b] (Tc rows)]   (rows of `width` floats), fully parallel;
-// then (second launch, after cat is complete) cache[slot_b] <- cat[b][Tc:]
-__global__ void k_cat_build(const float* __restrict__ pool, long long slot_stride, long long off, const int* __restrict__ slots,
-                            const float* __restrict__ newrows, int ldn, float* __restrict__ cat, int B, int L, int Tc,
-                            int width) {
-    int w4 = width >> 2;
-    long long n = (long long)B * (L + Tc) * w4;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// cat[b] = [cache[slot_b] (L rows) ; new[b] (Tc rows)] and cache[slot_b] <- cat[b][Tc:], in ONE pass: a thread owns the rows
+// r0, r0+Tc, r0+2Tc, ... of one 16-byte column of one stream.  Row r of the new cache is row r+Tc of the old one (or a new row), so
+// walking the chain upwards every old value is read exactly once -- it goes to cat[r] and, one step later, into cache[r-Tc] -- and
+// no other thread touches these addresses.  (Two launches before: build cat, then copy the cache back out of it.)
+__global__ void k_cat_shift(float* __restrict__ pool, long long slot_stride, long long off, const int* __restrict__ slots,
+                            const float* __restrict__ newrows, int ldn, float* __restrict__ cat, int B, int L, int Tc, int width) {
+    const int w4 = width >> 2;
+    const long long n = (long long)B * Tc * w4;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int c = (int)(i % w4) * 4;
-    long long br = i / w4;
-    int r = (int)(br % (L + Tc)), b = (int)(br / (L + Tc));
-    float4 v;
-    if (r < L) v = *reinterpret_cast<const float4*>(pool + (long long)slots[b] * slot_stride + off + (long long)r * width + c);
-    else v = *reinterpret_cast<const float4*>(newrows + ((long long)b * Tc + (r - L)) * ldn + c);
-    *reinterpret_cast<float4*>(cat + ((long long)b * (L + Tc) + r) * width + c) = v;
-}
-__global__ void k_cache_from_cat(float* __restrict__ pool, long long slot_stride, long long off, const int* __restrict__ slots,
-                                 const float* __restrict__ cat, int B, int L, int Tc, int width) {
-    int w4 = width >> 2;
-    long long n = (long long)B * L * w4;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int c = (int)(i % w4) * 4;
-    long long br = i / w4;
-    int r = (int)(br % L), b = (int)(br / L);
-    *reinterpret_cast<float4*>(pool + (long long)slots[b] * slot_stride + off + (long long)r * width + c) =
-        *reinterpret_cast<const float4*>(cat + ((long long)b * (L + Tc) + Tc + r) * width + c);
+    const int c = (int)(i % w4) * 4;
+    const long long br = i / w4;
+    const int r0 = (int)(br % Tc), b = (int)(br / Tc);
+    float* cache = pool + (long long)slots[b] * slot_stride + off + c;
+    const float* nw = newrows + (long long)b * Tc * ldn + c;
+    float* ct = cat + (long long)b * (L + Tc) * width + c;
+    const float4 mine = *reinterpret_cast<const float4*>(nw + (long long)r0 * ldn);
+    *reinterpret_cast<float4*>(ct + (long long)(L + r0) * width) = mine;
+    if (r0 >= L) return;
+    // the chain's values are fetched in groups of 8 independent loads before any store (the stores go through the same pointer, so
+    // load-after-store would otherwise serialise the walk into one memory latency per row)
+    float4 cur = *reinterpret_cast<const float4*>(cache + (long long)r0 * width);  // old cache[r]
+    for (int rb = r0; rb < L; rb += 8 * Tc) {
+        float4 nx[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = rb + (u + 1) * Tc;  // row of [old cache ; new] that becomes cache[rb + u*Tc]
+            if (q - Tc < L)
+                nx[u] = q < L ? *reinterpret_cast<const float4*>(cache + (long long)q * width)
+                              : *reinterpret_cast<const float4*>(nw + (long long)(q - L) * ldn);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int r = rb + u * Tc;
+            if (r < L) {
+                *reinterpret_cast<float4*>(ct + (long long)r * width) = cur;
+                *reinterpret_cast<float4*>(cache + (long long)r * width) = nx[u];
+                cur = nx[u];
+            }
+        }
+    }
 }
 
 // RelPositionMultiheadAttentionWeights.streaming_forward for one (stream, head):
@@ -205,10 +218,8 @@ void cat_shift(const Ctx& ctx, float* pool, long long slot_stride, long long off
                int ldn, float* cat, int B, int L, int Tc, int width) {
     K2_REQUIRE(width % 4 == 0 && ldn % 4 == 0, "cat_shift: width %d / ld %d must be multiples of 4", width, ldn);
     if (ctx.dry) return;
-    hipLaunchKernelGGL(k_cat_build, dim3(nb((long long)B * (L + Tc) * (width / 4), 256)), dim3(256), 0, ctx.stream, pool, slot_stride,
-                       off, slots, newrows, ldn, cat, B, L, Tc, width);
-    hipLaunchKernelGGL(k_cache_from_cat, dim3(nb((long long)B * L * (width / 4), 256)), dim3(256), 0, ctx.stream, pool, slot_stride, off,
-                       slots, cat, B, L, Tc, width);
+    hipLaunchKernelGGL(k_cat_shift, dim3(nb((long long)B * Tc * (width / 4), 256)), dim3(256), 0, ctx.stream, pool, slot_stride, off, slots,
+                       newrows, ldn, cat, B, L, Tc, width);
     K2_HIP(hipGetLastError());
 }
 void attn_stream(const Ctx& ctx, const float* qkp, int ld, const float* kcat, const float* pp, const long long* plen,
