@@ -596,6 +596,12 @@ int choose_cfg(const GemmArgs& a) {
         const long long b5 = (long long)cdiv(a.M, 128) * cdiv(a.N, 64), b6 = (long long)cdiv(a.M, 64) * (a.N / 96);
         const bool plain = a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.K % 32 == 0 && a.K >= 64;
         if (plain && a.N % 96 == 0 && b5 > 256 && cdiv(b6, 256) * 6144 * 100 <= cdiv(b5, 256) * 8192 * 80) return 11;
+        // 128x64 tiles that fill the last round of the 256 CUs badly while 64x64 tiles fill it well (the 6.25 Hz stack: 2048 rows x
+        // 1536 / 2080 / 2560 columns -> 384 / 528 / 640 tiles): the smaller tile costs ~7 % per tile and wins 7-14 % on balance
+        // (tools/probes/m2048_probe.py)
+        const long long b9 = (long long)cdiv(a.M, 64) * cdiv(a.N, 64);
+        const double e5 = (double)b5 / (double)(cdiv(b5, 256) * 256), e9 = (double)b9 / (double)(cdiv(b9, 256) * 256);
+        if (plain && a.K >= 512 && b5 > 256 && e9 >= e5 + 0.12) return 9;
     }
     return 5;                   // 128x64 tiles, 8 waves (LDS-DMA pipeline when K % 32 == 0)
 }
