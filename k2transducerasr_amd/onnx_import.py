@@ -166,7 +166,47 @@ def map_initializers(inits: Dict[str, np.ndarray], nodes) -> Tuple[Dict[str, np.
     for nname, op, ins, _ in nodes:
         for pos, i in enumerate(ins):
             consumers.setdefault(i, (nname, op, pos))
+    # onnxruntime's dynamic quantisation (the reference's *.int8.onnx model zoo, README.EN.md:8-35): a Linear becomes
+    # DynamicQuantizeLinear -> MatMulInteger(A_q, W_quantized, a_zp, W_zero_point) -> Cast -> Mul(a_scale * W_scale); the weight is
+    # stored as <w>_quantized (int8 / uint8, [in, out]) with <w>_scale and <w>_zero_point.  The weights are dequantised here,
+    # W = (W_q - zp) * scale, and the engine computes in f32 -- the dynamic quantisation of the ACTIVATIONS is not reproduced
+    # (int8 graphs are outside the parity scope).
+    handled = set()
     for name, arr in inits.items():
+        if not name.endswith("_quantized") or arr.dtype not in (np.int8, np.uint8):
+            continue
+        stem = name[: -len("_quantized")]
+        scale = inits.get(stem + "_scale")
+        if scale is None:
+            continue
+        zp = inits.get(stem + "_zero_point")
+        c = consumers.get(name)
+        if c is None or not c[0]:
+            unmapped.append(name)
+            continue
+        nname, op, pos = c
+        sc = np.asarray(scale, np.float32)
+        z = np.asarray(zp if zp is not None else 0).astype(np.int32)
+        if op == "ConvInteger" and arr.ndim > 1 and sc.ndim == 1 and sc.size == arr.shape[0]:
+            shp = (-1,) + (1,) * (arr.ndim - 1)          # per-output-channel scales of a conv filter [O, I, ...]
+            sc, z = sc.reshape(shp), (z.reshape(shp) if z.ndim == 1 and z.size == arr.shape[0] else z)
+        w = ((arr.astype(np.int32) - z) * sc).astype(np.float32)
+        mod = _scope_to_module(nname)
+        for suffix in ("_quant",):                        # quantize_dynamic renames the node '<scope>/MatMul' -> '<scope>/MatMul_quant'
+            if mod.endswith(suffix):
+                mod = mod[: -len(suffix)]
+        mod = _canonical(mod + ".")[:-1]
+        if op == "MatMulInteger" and w.ndim == 2:
+            out[mod + ".weight"] = np.ascontiguousarray(w.T)
+        elif op == "ConvInteger":
+            out[mod + ".weight"] = w
+        else:
+            unmapped.append(name)
+            continue
+        handled.update({name, stem + "_scale", stem + "_zero_point"})
+    for name, arr in inits.items():
+        if name in handled:
+            continue
         anonymous = name.startswith("onnx::") or "." not in name
         if not anonymous:
             out[_canonical(name)] = arr

@@ -25,7 +25,7 @@ def _vi(fn: int, x: int) -> bytes:
 
 def tensor(name: str, arr: np.ndarray, raw: bool = True) -> bytes:
     arr = np.ascontiguousarray(arr)
-    code = {np.dtype(np.float32): 1, np.dtype(np.int64): 7}[arr.dtype]
+    code = {np.dtype(np.float32): 1, np.dtype(np.int64): 7, np.dtype(np.uint8): 2, np.dtype(np.int8): 3}[arr.dtype]
     b = b"".join(_vi(1, d) for d in arr.shape) + _vi(2, code) + _ld(8, name.encode())
     if raw:
         b += _ld(9, arr.tobytes())

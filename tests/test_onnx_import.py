@@ -101,3 +101,29 @@ def test_report_lists_what_is_missing(tmp_path):
     assert rep["unmapped"] == [f"{p}:onnx::Mul_9"]
     _, t = read_k2w(str(tmp_path / "o.k2w"))
     assert t["joiner.encoder_proj.weight"].shape == (3, 4)
+
+
+def test_int8_dynamic_quantised_weights_are_dequantised(tmp_path):
+    """A Linear as onnxruntime's quantize_dynamic leaves it (MatMulInteger on <w>_quantized with <w>_scale / <w>_zero_point,
+    README.EN.md:8-35 lists the *.int8.onnx model zoo): the importer must hand the engine W = (W_q - zp) * scale in torch layout,
+    and drop the scale / zero-point helpers."""
+    rng = np.random.default_rng(3)
+    wq = rng.integers(0, 256, (48, 24), dtype=np.uint8)                 # [in, out]
+    scale, zp = np.float32(0.0123), np.uint8(131)
+    sq = rng.integers(-128, 128, (16, 48), dtype=np.int8)
+    s_scale = np.float32(0.5)
+    inits = [ow.tensor("onnx::MatMul_77_quantized", wq), ow.tensor("onnx::MatMul_77_scale", np.asarray(scale).reshape(())),
+             ow.tensor("onnx::MatMul_77_zero_point", np.asarray(zp).reshape(())),
+             ow.tensor("onnx::MatMul_78_quantized", sq), ow.tensor("onnx::MatMul_78_scale", np.asarray(s_scale).reshape(())),
+             ow.tensor("encoder_proj.bias", np.ones(24, np.float32))]
+    nodes = [ow.node("/encoder_proj/MatMul_quant", "MatMulInteger", ["a_q", "onnx::MatMul_77_quantized", "a_zp", "onnx::MatMul_77_zero_point"], ["y"]),
+             ow.node("/encoder/encoders.0/layers.1/feed_forward1/in_proj/MatMul_quant", "MatMulInteger", ["b_q", "onnx::MatMul_78_quantized", "b_zp"], ["z"])]
+    p = tmp_path / "enc.int8.onnx"
+    p.write_bytes(ow.model({"model_type": "zipformer2"}, inits, nodes))
+    rep = import_onnx([str(p)], str(tmp_path / "m.k2w"))
+    assert rep["unmapped"] == []
+    _, t = read_k2w(str(tmp_path / "m.k2w"))
+    want = ((wq.astype(np.int32) - 131) * scale).astype(np.float32).T
+    np.testing.assert_array_equal(t["joiner.encoder_proj.weight"], want)
+    np.testing.assert_array_equal(t["encoder.encoders.0.layers.1.feed_forward1.in_proj.weight"], (sq.astype(np.float32) * 0.5).T)   # no zero point
+    assert set(t) == {"joiner.encoder_proj.weight", "joiner.encoder_proj.bias", "encoder.encoders.0.layers.1.feed_forward1.in_proj.weight"}
