@@ -142,3 +142,58 @@ def test_streaming_zh_model_matches_oracle(tmp_path_factory):
         for l in (0, 7, 15):
             for kind in KINDS:
                 np.testing.assert_allclose(h.state(l, kind), o.state(l, kind), atol=5e-4, rtol=0)
+
+
+@pytest.mark.parametrize("preset", ["zipformer2-streaming-tiny-test", "zipformer-streaming-tiny-test", "conformer-streaming-tiny-test"])
+def test_streaming_random_churn(tmp_path_factory, preset):
+    """Streams that arrive at different times, are fed in uneven pushes, finish and are replaced (slots recycled), so every
+    GetResults call sees a different ready subset at different positions: tokens / timestamps / Hyp of every stream must equal
+    the oracle's, which decodes each stream on its own.  (The streaming conformer is left out of the mixed-batch comparison of
+    processed_lens: the reference overwrites it with the batch size, OnlineProjOfConformer.cs:229, so there the oracle is stepped
+    with exactly the same ready subsets.)"""
+    from k2transducerasr_amd import OnlineRecognizer
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    from oracle.online import OnlineOracle
+    p = str(tmp_path_factory.mktemp("churn") / f"{preset}.k2w")
+    write_synthetic_model(p, preset)
+    rec, ora = OnlineRecognizer(p), OnlineOracle(p)
+    T, S = rec.chunk_length, rec.shift_length
+    rng = np.random.default_rng(20240607)
+    NSLOT, TOTAL = 6, 14
+    live = []          # dicts: h (hip stream), o (oracle stream), feats, fed (frames handed over), pos (frames consumed)
+    started = finished = 0
+    checked_tokens = 0
+    for it in range(400):
+        while len(live) < NSLOT and started < TOTAL and rng.random() < 0.5:
+            f = ora.fbank(synth_utterance(300 + started, float(rng.uniform(0.6, 1.8))))
+            live.append(dict(h=rec.create_online_stream(), o=ora.create_stream(), feats=f, fed=0, pos=0))
+            started += 1
+        for s in live:   # uneven pushes of whole frames
+            if s["fed"] < s["feats"].shape[0] and rng.random() < 0.8:
+                n = int(rng.integers(1, 40))
+                s["h"].add_features(s["feats"][s["fed"] : s["fed"] + n])
+                s["fed"] = min(s["fed"] + n, s["feats"].shape[0])
+        if not live:
+            if started == TOTAL:
+                break
+            continue
+        ready = [i for i, s in enumerate(live) if s["pos"] + T <= s["fed"]]
+        dec, n_new = rec.get_results([s["h"] for s in live])
+        assert [i for i in range(len(live)) if dec[i]] == ready, it
+        if ready:
+            want = ora.step([live[i]["o"] for i in ready], [live[i]["feats"][live[i]["pos"] : live[i]["pos"] + T] for i in ready])
+            for i, wn in zip(ready, want):
+                assert n_new[i] == wn
+                live[i]["pos"] += S
+        for s in live:
+            assert s["h"].tokens == s["o"].tokens and s["h"].timestamps == s["o"].timestamps and s["h"].hyp == s["o"].hyp, it
+        keep = []
+        for s in live:
+            if s["fed"] == s["feats"].shape[0] and s["pos"] + T > s["fed"]:
+                checked_tokens += len(s["o"].tokens) - 2
+                s["h"].close()
+                finished += 1
+            else:
+                keep.append(s)
+        live = keep
+    assert finished == TOTAL and checked_tokens > 0
