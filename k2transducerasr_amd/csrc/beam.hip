@@ -2,10 +2,10 @@
 //
 // The reference has no beam search (OfflineRecognizer.cs:54-68 only dispatches "greedy_search"); the
 // semantics are icefall's beam_search.py modified_beam_search, restated and tie-broken in
-// DESIGN.md.  Frame-synchronous, so the whole search is enqueued up front (5 launches
+// DESIGN.md.  Frame-synchronous, so the whole search is enqueued up front (4 launches
 // per frame, no host round trip): for frame t
-//   decoder(ctx of every hypothesis)              k_decoder           [B*K rows]
-//   act = tanh(enc[b,t] + dec[b,k])               k_beam_act
+//   h = relu(conv(emb(ctx)))  of every hypothesis  k_beam_embconv      [B*K rows]
+//   act = tanh(enc[b,t] + decoder_proj(h)[b,k])   one GEMM, the encoder frame added (row / K) before the tanh in its epilogue
 //   logits = act . W^T + bias                     gemm_f32_mfma       [B*K, V]
 //   per stream: log_softmax + hyp score, top-K over K*V by (score desc, flat index asc), expand,
 //   merge equal token sequences by logaddexp (first-inserted hypothesis keeps its timestamps)   k_beam_step
@@ -29,12 +29,8 @@ __global__ void k_beam_init(BeamState s, int B) {
     if (k == 0) s.nhyp[i / s.K] = 1;
 }
 
-// h[m][co] = relu(Conv1d(k = 2) over (emb[y0], emb[y1])) for every hypothesis row m (id < 0 -> zero embedding)
-__global__ void k_beam_embconv(DecJoinW w, const long long* __restrict__ y, float* __restrict__ h, int M) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)M * w.DD) return;
-    const int m = (int)(i / w.DD), co = (int)(i - (long long)m * w.DD);
-    const long long y0 = y[2 * m], y1 = y[2 * m + 1];
+// relu(Conv1d(k = 2) over (emb[y0], emb[y1]))[co]  (id < 0 -> zero embedding)
+__device__ __forceinline__ float embconv1(const DecJoinW& w, long long y0, long long y1, int co) {
     float s = 0.f;
     if (w.cpg <= 4) {
         const int g0 = (co / w.cpg) * w.cpg;
@@ -47,18 +43,14 @@ __global__ void k_beam_embconv(DecJoinW w, const long long* __restrict__ y, floa
     } else {
         s = (y0 >= 0 ? w.ptab[y0 * w.DD + co] : 0.f) + (y1 >= 0 ? w.ptab[((long long)w.V + y1) * w.DD + co] : 0.f);
     }
-    h[i] = fmaxf(s, 0.f);
+    return fmaxf(s, 0.f);
 }
-
-__global__ void k_beam_act(const float* __restrict__ enc, const float* __restrict__ dec, float* __restrict__ act, int B, int K,
-                           int Tp, int t, int J4) {
+// h[m][co] for every hypothesis row m
+__global__ void k_beam_embconv(DecJoinW w, const long long* __restrict__ y, float* __restrict__ h, int M) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)B * K * J4) return;
-    int q = (int)(i % J4);
-    int m = (int)(i / J4), b = m / K;
-    float4 e = *reinterpret_cast<const float4*>(enc + ((long long)b * Tp + t) * (J4 * 4) + 4 * q);
-    float4 d = reinterpret_cast<const float4*>(dec)[i];
-    reinterpret_cast<float4*>(act)[i] = make_float4(tanhf(e.x + d.x), tanhf(e.y + d.y), tanhf(e.z + d.z), tanhf(e.w + d.w));
+    if (i >= (long long)M * w.DD) return;
+    const int m = (int)(i / w.DD), co = (int)(i - (long long)m * w.DD);
+    h[i] = embconv1(w, y[2 * m], y[2 * m + 1], co);
 }
 
 // one workgroup per stream; `cur` = buffer holding frame t's input hypotheses
@@ -269,7 +261,6 @@ void beam_search(const Ctx& ctx, const DecJoinW& w, const BeamArgs& a) {
     s.nhyp = ar.take<int>(B);
     s.nhyp_next = s.nhyp;
     float* hbuf = ar.take<float>((int64_t)M * w.DD);
-    float* dec = ar.take<float>((int64_t)M * w.J);
     float* act = ar.take<float>((int64_t)M * w.J);
     float* logits = ar.take<float>((int64_t)M * w.V);
     if (!ctx.dry) {
@@ -278,14 +269,16 @@ void beam_search(const Ctx& ctx, const DecJoinW& w, const BeamArgs& a) {
         K2_HIP(hipGetLastError());
     }
     for (int t = 0; t < a.Tp; t++) {
-        // decoder of every hypothesis: embedding + conv + ReLU elementwise, then decoder_proj as ONE small-problem GEMM
-        // (k_decoder would re-read the 1 MB projection once per hypothesis)
+        // four launches per frame: the decoder front end (embedding + conv + ReLU, elementwise); act = tanh(enc_t + decoder_proj(h)) as
+        // ONE small-problem GEMM whose epilogue adds the stream's encoder frame (row / K) before the tanh; the joiner GEMM; the
+        // per-stream step.  (Folding the front end into the step's tail only moved its time into the 32-workgroup step kernel.)
         if (!ctx.dry) hipLaunchKernelGGL(k_beam_embconv, dim3(cdiv((long long)M * w.DD, 256)), dim3(256), 0, ctx.stream, w, s.ctx, hbuf, M);
-        linear(ctx, hbuf, w.DD, a.dproj_w, w.dproj_b, dec, w.J, M, w.DD, w.J);
-        if (!ctx.dry) {
-            long long n4 = (long long)M * w.J / 4;
-            hipLaunchKernelGGL(k_beam_act, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ctx.stream, a.enc, dec, act, B, K, a.Tp, t,
-                               w.J / 4);
+        {
+            GemmArgs g;
+            g.A = hbuf; g.lda = w.DD; g.W = a.dproj_w; g.ldw = w.DD; g.bias = w.dproj_b;
+            g.C = act; g.ldc = w.J; g.M = M; g.N = w.J; g.K = w.DD;
+            g.act = ACT_TANH; g.act_after_res = 1; g.res = a.enc + (long long)t * w.J; g.ldr = a.Tp * w.J; g.res_div = K;
+            gemm(ctx, g);
         }
         linear(ctx, act, w.J, a.out_w, w.out_b, logits, w.V, M, w.J, w.V);
         if (!ctx.dry) {

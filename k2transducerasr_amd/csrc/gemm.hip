@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int row = min(m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
-                    rres[i][j][r] = R[(long long)row * g.ldr + col];
+                    rres[i][j][r] = R[(long long)(g.res_div > 1 ? row / g.res_div : row) * g.ldr + col];
                 }
         }
     }
@@ -288,8 +288,14 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
             for (int r = 0; r < 16; r++) {
                 int row = m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < g.M && !(g.ablate & 4)) {
-                    float v = apply_act(acc[i][j][r] + bv, act);
-                    if (R) v += rres[i][j][r];
+                    float v = acc[i][j][r] + bv;
+                    if (g.act_after_res) {
+                        if (R) v += rres[i][j][r];
+                        v = apply_act(v, act);
+                    } else {
+                        v = apply_act(v, act);
+                        if (R) v += rres[i][j][r];
+                    }
                     if (g.mul) v *= g.mul[z0 * g.sM0 + z1 * g.sM1 + (long long)row * g.ldm + col];
                     if (g.byp_orig) {
                         const float o = g.byp_orig[(long long)row * g.ld_orig + col];
@@ -536,8 +542,9 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_skinny(GemmArgs g) {
             const int row = m0 + 4 * q + e;
             if (row >= g.M) continue;
             float v = red[0][j][lane][e] + red[1][j][lane][e] + red[2][j][lane][e] + red[3][j][lane][e];
-            v = apply_act(v + bv, (g.act_cols == 0 || col < g.act_cols) ? g.act : (int)ACT_NONE);
-            if (g.res) v += g.res[(long long)row * g.ldr + col];
+            const int act = (g.act_cols == 0 || col < g.act_cols) ? g.act : (int)ACT_NONE;
+            const float rv = g.res ? g.res[(long long)(g.res_div > 1 ? row / g.res_div : row) * g.ldr + col] : 0.f;
+            v = g.act_after_res ? apply_act(v + bv + rv, act) : apply_act(v + bv, act) + rv;
             g.C[(long long)row * g.ldc + col] = v;
         }
     }
@@ -651,7 +658,7 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
         return;
     }
-    const bool dma_ok = a.cv_Fout == 0 && !a.w_kn && a.K % 32 == 0 && a.K >= 64 && a.lda % 4 == 0 && !a.mul;
+    const bool dma_ok = a.cv_Fout == 0 && !a.w_kn && a.K % 32 == 0 && a.K >= 64 && a.lda % 4 == 0 && !a.mul && a.res_div == 1 && !a.act_after_res;
     if (dma_ok && g_use_dma && g_forced_cfg < 0 && a.nb0 * a.nb1 > 1 && a.M <= 64) {
         // a handful of rows against many layers' weight matrices (LSTM wavefront): a weight-streaming problem -- 64x64 tiles, three
         // 16 KB stages in flight per workgroup

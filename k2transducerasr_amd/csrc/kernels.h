@@ -76,6 +76,10 @@ struct GemmArgs {
     // epilogue extras (after bias, activation and residual):
     //   mul:  v *= mul[row*ldm + col]                      (batched like C: + z0*sM0 + z1*sM1)   -- NonlinAttention's output gate
     //   byp:  v = o + (v - o) * byp_scale[col], o = byp_orig[row*ld_orig + col]                 -- Zipformer bypass module
+    //   res_div > 1: residual row = row / res_div (K hypothesis rows share their stream's encoder frame)
+    //   act_after_res: v = act(acc + bias + res) instead of act(acc + bias) + res          -- the joiner's tanh(enc + dec)
+    int res_div = 1;
+    int act_after_res = 0;
     const float* mul = nullptr;
     int ldm = 0;
     long long sM0 = 0, sM1 = 0;
