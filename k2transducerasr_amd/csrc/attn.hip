@@ -383,7 +383,7 @@ void attn_scores_softmax(const Ctx& ctx, const float* qkp, int ld, const float* 
 bool attn_av_out(const Ctx& ctx, const float* aw, const float* v, const float* wout, const float* bias, float* x, int B, int T, int KL, int Tp,
                  int H, int vh, int D) {
     const int HV = H * vh, Tk = (KL + 63) & ~63;
-    static const bool off = getenv("K2HIP_NO_FUSED_AV") != nullptr;
+    const bool off = getenv("K2HIP_NO_FUSED_AV") != nullptr;  // read per call: the tests compare both paths in one process
     if (off || vh > 16 || HV % 4 != 0 || HV > 128 || D % 16 != 0 || Tp % 4 != 0 || Tp < KL) return false;
     ctx.add_flops(0.0, 2.0 * B * (double)T * HV * (KL + D), 0);
     if (ctx.dry) return true;
