@@ -545,6 +545,10 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_skinny(GemmArgs g) {
             const int act = (g.act_cols == 0 || col < g.act_cols) ? g.act : (int)ACT_NONE;
             const float rv = g.res ? g.res[(long long)(g.res_div > 1 ? row / g.res_div : row) * g.ldr + col] : 0.f;
             v = g.act_after_res ? apply_act(v + bv + rv, act) : apply_act(v + bv, act) + rv;
+            if (g.byp_orig) {
+                const float o = g.byp_orig[(long long)row * g.ld_orig + col];
+                v = o + (v - o) * g.byp_scale[col];
+            }
             g.C[(long long)row * g.ldc + col] = v;
         }
     }
@@ -649,7 +653,7 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     const bool plain = a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.K % 64 == 0 && a.K >= 64;
     // (16-row workgroups re-read the weight chunk M/16 times: with many rows and a short K the 64x64 tiles are better)
     const bool few_tiles = (long long)cdiv(a.M, 128) * cdiv(a.N, 64) < 144 && a.M <= 4096 && !(a.M >= 2048 && a.K <= 256 && a.N > 272);
-    const bool skinny_ok = g_forced_cfg < 0 && !no_skinny && plain && !a.mul && !a.byp_orig && ((a.N <= 96 && a.M >= 512) || few_tiles);
+    const bool skinny_ok = g_forced_cfg < 0 && !no_skinny && plain && !a.mul && ((a.N <= 96 && a.M >= 512) || few_tiles);
     if (skinny_ok) {
         if (a.N <= 48) hipLaunchKernelGGL(gemm_f32_mfma_skinny<3>, dim3(cdiv(a.M, 16), 1), dim3(256), 0, ctx.stream, b);
         else hipLaunchKernelGGL(gemm_f32_mfma_skinny<6>, dim3(cdiv(a.M, 16), cdiv(a.N, 96)), dim3(256), 0, ctx.stream, b);

@@ -264,8 +264,9 @@ void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x,
         linear(c, hid, Fk, w(cc), w(d), out, D, M, Fk, D, ACT_NONE, in, D);
     };
     // out[b, :, col0:col0+n] = aw[h][b] (Tc x KL) . cat[b] (KL x width)[:, col0:col0+n]
-    auto attn_apply = [&](const float* cat, int width, float* out, int ldo, int nheads, int ncols) {
+    auto attn_apply = [&](const float* cat, int width, float* out, int ldo, int nheads, int ncols, const float* gate = nullptr, int ldg = 0) {
         GemmArgs g;
+        if (gate) { g.mul = gate; g.ldm = ldg; g.sM0 = (long long)Tc * ldg; }  // out *= gate in the epilogue
         g.A = aw; g.lda = KLp; g.sA0 = (long long)Tc * KLp; g.sA1 = (long long)B * Tc * KLp;
         g.W = cat; g.w_kn = 1; g.ldw = width; g.sW0 = (long long)KL * width; g.sW1 = ncols;
         g.C = out; g.ldc = ldo; g.sC0 = (long long)Tc * ldo; g.sC1 = ncols;
@@ -305,14 +306,19 @@ void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x,
         linear(c, src, D, w("nonlin_attention.in_proj.weight"), w("nonlin_attention.in_proj.bias"), hid, 3 * Hc, M, D, 3 * Hc);
         tanh_gate(c, hid, tmp, M, Hc);
         cat_shift(c, online_pool_, SS, lay_.nonlin[l], d_slots, tmp, Hc, vcat, B, L, Tc, Hc);
-        attn_apply(vcat, Hc, tmp2, Hc, 1, Hc);
-        mul_cols(c, tmp2, hid, 3 * Hc, 2 * Hc, M, Hc);
+        attn_apply(vcat, Hc, tmp2, Hc, 1, Hc, hid + 2 * Hc, 3 * Hc);  // x * y (the third chunk of in_proj) in the epilogue
         linear(c, tmp2, Hc, w("nonlin_attention.out_proj.weight"), w("nonlin_attention.out_proj.bias"), src, D, M, Hc, D, ACT_NONE, src, D);
     }
     self_attn(1, lay_.val1[l]);
     conv_module(1, lay_.conv1[l]);
-    feed_forward(2, F, src, src);
-    bypass(c, x, src, w("bypass_mid.bypass_scale"), src, M, D);
+    {   // src = bypass_mid(x, src + ff2(src)): the bypass mix runs in the out_proj GEMM's epilogue
+        linear(c, src, D, w("feed_forward2.in_proj.weight"), w("feed_forward2.in_proj.bias"), hid, F, M, D, F, ACT_SWOOSH_L);
+        GemmArgs g;
+        g.A = hid; g.lda = F; g.W = w("feed_forward2.out_proj.weight"); g.ldw = F; g.bias = w("feed_forward2.out_proj.bias");
+        g.C = src; g.ldc = D; g.M = M; g.N = D; g.K = F; g.res = src; g.ldr = D;
+        g.byp_orig = x; g.ld_orig = D; g.byp_scale = w("bypass_mid.bypass_scale");
+        gemm(c, g);
+    }
     self_attn(2, lay_.val2[l]);
     conv_module(2, lay_.conv2[l]);
     feed_forward(3, F * 5 / 4, src, src);
