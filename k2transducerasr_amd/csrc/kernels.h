@@ -266,8 +266,9 @@ void convnext_cat(const Ctx& ctx, const float* a3, const float* pool, long long 
                   const int* slots, float* cat, int B, int T3, int F, int C);
 void convnext_cache_update(const Ctx& ctx, const float* a3, float* pool, long long slot_stride, long long embed_off,
                            const int* slots, int B, int T3, int Tc, int F, int C);
+// tanh_gated: the new rows are formed as x[width + c] * tanh(x[c]) from rows of >= 2*width floats (NonlinAttention's gated input)
 void cat_shift(const Ctx& ctx, float* pool, long long slot_stride, long long off, const int* slots, const float* newrows,
-               int ldn, float* cat, int B, int L, int Tc, int width);
+               int ldn, float* cat, int B, int L, int Tc, int width, bool tanh_gated = false);
 void attn_stream(const Ctx& ctx, const float* qkp, int ld, const float* kcat, const float* pp, const long long* plen,
                  float* aw, int B, int Tc, int L, int KLp, int H, int ds, int left50);
 void glu_causal_conv(const Ctx& ctx, const float* x2, float* pool, long long slot_stride, long long off, const int* slots,

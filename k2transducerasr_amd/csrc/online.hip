@@ -54,8 +54,19 @@ __global__ void k_convnext_cache(const float* __restrict__ a3, float* __restrict
 // r0, r0+Tc, r0+2Tc, ... of one 16-byte column of one stream.  Row r of the new cache is row r+Tc of the old one (or a new row), so
 // walking the chain upwards every old value is read exactly once -- it goes to cat[r] and, one step later, into cache[r-Tc] -- and
 // no other thread touches these addresses.  (Two launches before: build cat, then copy the cache back out of it.)
+// GATE: the new rows are not read as they are but formed on the fly as x[width + c] * tanh(x[c]) from rows of >= 2*width floats
+// (NonlinAttention's gated input, which is what its cache holds) -- saves the separate gating kernel and its round trip.
+template <bool GATE>
 __global__ void k_cat_shift(float* __restrict__ pool, long long slot_stride, long long off, const int* __restrict__ slots,
                             const float* __restrict__ newrows, int ldn, float* __restrict__ cat, int B, int L, int Tc, int width) {
+    auto newrow = [&](const float* p) {
+        float4 v = *reinterpret_cast<const float4*>(GATE ? p + width : p);
+        if (GATE) {
+            const float4 sg = *reinterpret_cast<const float4*>(p);
+            v = make_float4(v.x * tanhf(sg.x), v.y * tanhf(sg.y), v.z * tanhf(sg.z), v.w * tanhf(sg.w));
+        }
+        return v;
+    };
     const int w4 = width >> 2;
     const long long n = (long long)B * Tc * w4;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -66,7 +77,7 @@ __global__ void k_cat_shift(float* __restrict__ pool, long long slot_stride, lon
     float* cache = pool + (long long)slots[b] * slot_stride + off + c;
     const float* nw = newrows + (long long)b * Tc * ldn + c;
     float* ct = cat + (long long)b * (L + Tc) * width + c;
-    const float4 mine = *reinterpret_cast<const float4*>(nw + (long long)r0 * ldn);
+    const float4 mine = newrow(nw + (long long)r0 * ldn);
     *reinterpret_cast<float4*>(ct + (long long)(L + r0) * width) = mine;
     if (r0 >= L) return;
     // the chain's values are fetched in groups of 8 independent loads before any store (the stores go through the same pointer, so
@@ -79,7 +90,7 @@ __global__ void k_cat_shift(float* __restrict__ pool, long long slot_stride, lon
             const int q = rb + (u + 1) * Tc;  // row of [old cache ; new] that becomes cache[rb + u*Tc]
             if (q - Tc < L)
                 nx[u] = q < L ? *reinterpret_cast<const float4*>(cache + (long long)q * width)
-                              : *reinterpret_cast<const float4*>(nw + (long long)(q - L) * ldn);
+                              : newrow(nw + (long long)(q - L) * ldn);
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -215,11 +226,14 @@ void convnext_cache_update(const Ctx& ctx, const float* a3, float* pool, long lo
     K2_HIP(hipGetLastError());
 }
 void cat_shift(const Ctx& ctx, float* pool, long long slot_stride, long long off, const int* slots, const float* newrows,
-               int ldn, float* cat, int B, int L, int Tc, int width) {
+               int ldn, float* cat, int B, int L, int Tc, int width, bool tanh_gated) {
     K2_REQUIRE(width % 4 == 0 && ldn % 4 == 0, "cat_shift: width %d / ld %d must be multiples of 4", width, ldn);
     if (ctx.dry) return;
-    hipLaunchKernelGGL(k_cat_shift, dim3(nb((long long)B * Tc * (width / 4), 256)), dim3(256), 0, ctx.stream, pool, slot_stride, off, slots,
-                       newrows, ldn, cat, B, L, Tc, width);
+    const dim3 grid(nb((long long)B * Tc * (width / 4), 256));
+    if (tanh_gated)
+        hipLaunchKernelGGL(k_cat_shift<true>, grid, dim3(256), 0, ctx.stream, pool, slot_stride, off, slots, newrows, ldn, cat, B, L, Tc, width);
+    else
+        hipLaunchKernelGGL(k_cat_shift<false>, grid, dim3(256), 0, ctx.stream, pool, slot_stride, off, slots, newrows, ldn, cat, B, L, Tc, width);
     K2_HIP(hipGetLastError());
 }
 void attn_stream(const Ctx& ctx, const float* qkp, int ld, const float* kcat, const float* pp, const long long* plen,

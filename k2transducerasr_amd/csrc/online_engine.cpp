@@ -304,8 +304,7 @@ void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x,
     feed_forward(1, F * 3 / 4, x, src);
     {   // NonlinAttention.streaming_forward
         linear(c, src, D, w("nonlin_attention.in_proj.weight"), w("nonlin_attention.in_proj.bias"), hid, 3 * Hc, M, D, 3 * Hc);
-        tanh_gate(c, hid, tmp, M, Hc);
-        cat_shift(c, online_pool_, SS, lay_.nonlin[l], d_slots, tmp, Hc, vcat, B, L, Tc, Hc);
+        cat_shift(c, online_pool_, SS, lay_.nonlin[l], d_slots, hid, 3 * Hc, vcat, B, L, Tc, Hc, /*tanh_gated=*/true);  // x * tanh(s) on the fly
         attn_apply(vcat, Hc, tmp2, Hc, 1, Hc, hid + 2 * Hc, 3 * Hc);  // x * y (the third chunk of in_proj) in the epilogue
         linear(c, tmp2, Hc, w("nonlin_attention.out_proj.weight"), w("nonlin_attention.out_proj.bias"), src, D, M, Hc, D, ACT_NONE, src, D);
     }
