@@ -491,13 +491,15 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
 // v_mfma_f32_16x16x4_f32 fragment layout (lane l: A[l&15][k = l>>4]; a float4 per lane holds 4
 // consecutive k, so four MFMAs consume its components -- the k order inside a 16-wide group is
 // permuted, which a sum does not care about), and the four partial tiles meet in LDS.
-template <int NT>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_skinny(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float red[4][NT][64][4];
+// NW = waves per workgroup = K split: 4, or 8 for long K with few workgroups (K = 1024 .. 1920 against 256 .. 1024 rows in the
+// streaming chunk step: the launch is one chain of K / (32 NW) dependent load rounds per wave)
+template <int NT, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_f32_mfma_skinny(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float red[NW][NT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.x * 16, n0 = blockIdx.y * (16 * NT);  // grid.y walks N in chunks of 16*NT columns
-    const int Kw = g.K >> 2, kbeg = wave * Kw;
+    const int Kw = g.K / NW, kbeg = wave * Kw;
     const float* __restrict__ ap = g.A + (long long)min(m0 + r, g.M - 1) * g.lda + kbeg + 4 * q;
     const float* __restrict__ wp[NT];
 #pragma unroll
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_skinny(GemmArgs g) {
     for (int j = 0; j < NT; j++) *reinterpret_cast<f32x4*>(&red[wave][j][lane][0]) = acc[j];
     __syncthreads();
     // wave w finishes the column tiles j = w, w + 4, ...: C/D layout col = lane & 15, row = 4 * (lane >> 4) + reg
-    for (int j = wave; j < NT; j += 4) {
+    for (int j = wave; j < NT; j += NW) {
         const int col = n0 + 16 * j + r;
         if (col >= g.N) continue;
         const float bv = g.bias ? g.bias[col] : 0.f;
@@ -542,6 +544,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_skinny(GemmArgs g) {
             const int row = m0 + 4 * q + e;
             if (row >= g.M) continue;
             float v = red[0][j][lane][e] + red[1][j][lane][e] + red[2][j][lane][e] + red[3][j][lane][e];
+            if (NW == 8) v += (red[4][j][lane][e] + red[5][j][lane][e]) + (red[6][j][lane][e] + red[7][j][lane][e]);
             const int act = (g.act_cols == 0 || col < g.act_cols) ? g.act : (int)ACT_NONE;
             const float rv = g.res ? g.res[(long long)(g.res_div > 1 ? row / g.res_div : row) * g.ldr + col] : 0.f;
             v = g.act_after_res ? apply_act(v + bv + rv, act) : apply_act(v + bv, act) + rv;
@@ -656,6 +659,8 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     const bool skinny_ok = g_forced_cfg < 0 && !no_skinny && plain && !a.mul && ((a.N <= 96 && a.M >= 512) || few_tiles);
     if (skinny_ok) {
         if (a.N <= 48) hipLaunchKernelGGL(gemm_f32_mfma_skinny<3>, dim3(cdiv(a.M, 16), 1), dim3(256), 0, ctx.stream, b);
+        else if (a.K >= 1024 && a.K % 128 == 0 && (long long)cdiv(a.M, 16) * cdiv(a.N, 96) <= 384)
+            hipLaunchKernelGGL((gemm_f32_mfma_skinny<6, 8>), dim3(cdiv(a.M, 16), cdiv(a.N, 96)), dim3(512), 0, ctx.stream, b);
         else hipLaunchKernelGGL(gemm_f32_mfma_skinny<6>, dim3(cdiv(a.M, 16), cdiv(a.N, 96)), dim3(256), 0, ctx.stream, b);
         K2_HIP(hipGetLastError());
         if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 32;
