@@ -197,3 +197,29 @@ def test_streaming_random_churn(tmp_path_factory, preset):
                 keep.append(s)
         live = keep
     assert finished == TOTAL and checked_tokens > 0
+
+
+def test_left_context_shorter_than_chunk(tmp_path_factory):
+    """left_context_len 8 / 4 / 2 / 4 against chunks of 16 / 8 / 4 / 8 frames: every cache is refilled entirely from the newest rows
+    of each chunk (the concat + roll kernel's chains are one element long and read only new rows)."""
+    from k2transducerasr_amd import OnlineRecognizer
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    from oracle.online import OnlineOracle
+    p = str(tmp_path_factory.mktemp("shortleft") / "m.k2w")
+    write_synthetic_model(p, "zipformer2-streaming-tiny-test", meta_overrides={"left_context_len": "8,4,2,4"})
+    rec, ora = OnlineRecognizer(p), OnlineOracle(p)
+    feats = [ora.fbank(synth_utterance(90 + u, 1.4)) for u in range(2)]
+    hs = [rec.create_online_stream() for _ in feats]
+    os_ = [ora.create_stream() for _ in feats]
+    for h, f in zip(hs, feats):
+        h.add_features(f)
+    T, S = rec.chunk_length, rec.shift_length
+    for k in range((feats[0].shape[0] - T) // S + 1):
+        rec.get_results(hs)
+        ora.step(os_, [f[k * S : k * S + T] for f in feats])
+        for h, o in zip(hs, os_):
+            assert h.tokens == o.tokens and h.timestamps == o.timestamps
+    for h, o in zip(hs, os_):
+        for l in range(o.num_layers):
+            for kind in KINDS:
+                np.testing.assert_allclose(h.state(l, kind), o.state(l, kind), atol=2e-4, rtol=0, err_msg=f"layer {l} {kind}")
