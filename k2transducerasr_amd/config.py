@@ -228,6 +228,7 @@ def make_zipformer_meta(
     vocab_size=500,
     context_size=2,
     comment="",
+    streaming=True,
 ):
     """Streaming Zipformer (v1) transducer: Model_type "zipformer" -> OnlineProjOfZipformer (OnlineRecognizer.cs:28-30), whose
     per-stack states are cached_len [L,B], cached_avg [L,B,D], cached_key [L,left,B,att], cached_val / cached_val2
@@ -254,17 +255,25 @@ def make_zipformer_meta(
             "num_heads": _csv(num_heads),
             "cnn_module_kernels": _csv(cnn_module_kernels),
             "downsampling_factors": _csv(downsampling_factors),
-            "left_context_len": _csv([num_left_chunks * decode_chunk_size // d for d in downsampling_factors]),
             "pos_dim": str(pos_dim),
-            "streaming": "1",
-            "decode_chunk_len": str(2 * decode_chunk_size),
-            "T": str(2 * decode_chunk_size + 7),
             "joiner_dim": str(joiner_dim),
             "decoder_dim": str(decoder_dim),
             "vocab_size": str(vocab_size),
             "context_size": str(context_size),
         }
     )
+    if streaming:
+        meta.update(
+            {
+                "left_context_len": _csv([num_left_chunks * decode_chunk_size // d for d in downsampling_factors]),
+                "streaming": "1",
+                "decode_chunk_len": str(2 * decode_chunk_size),
+                "T": str(2 * decode_chunk_size + 7),
+            }
+        )
+    # streaming=False: the offline graph of the non-streaming recipe (pruned_transducer_stateless7): Model_type "zipformer" in
+    # OfflineRecognizer's switch (OfflineRecognizer.cs:40-44) -- mean pooling over the utterance, centred depthwise convolutions,
+    # attention over the whole utterance; same state-dict names
     return meta
 
 
@@ -274,6 +283,16 @@ ZIPFORMER1_PRESETS = {
     "zipformer-streaming-en": dict(
         encoder_dims=[384] * 5, attention_dims=[192] * 5, num_encoder_layers=[2, 4, 3, 2, 4], feedforward_dims=[1024, 1024, 2048, 2048, 1024],
         num_heads=[8] * 5, cnn_module_kernels=[31] * 5, downsampling_factors=[1, 2, 4, 8, 2], vocab_size=500,
+    ),
+    # the offline recipe (icefall pruned_transducer_stateless7, 70 M parameters)
+    "zipformer-en": dict(
+        encoder_dims=[384] * 5, attention_dims=[192] * 5, num_encoder_layers=[2, 4, 3, 2, 4], feedforward_dims=[1024, 1024, 2048, 2048, 1024],
+        num_heads=[8] * 5, cnn_module_kernels=[31] * 5, downsampling_factors=[1, 2, 4, 8, 2], vocab_size=500, streaming=False,
+    ),
+    "zipformer-tiny-test": dict(
+        encoder_dims=[64, 64, 96, 96], attention_dims=[32, 32, 96, 96], num_encoder_layers=[1, 2, 1, 1], feedforward_dims=[128, 128, 160, 160],
+        num_heads=[2, 2, 4, 4], cnn_module_kernels=[7, 7, 5, 7], downsampling_factors=[1, 2, 4, 2],
+        joiner_dim=512, decoder_dim=64, vocab_size=37, streaming=False,
     ),
     # parity-test model: growing stack widths (AttentionDownsample.extra_proj + SimpleCombiner padding), a skip connection
     # (stack 3 takes stack 1's output), head sizes 16 and 24, short left context

@@ -34,6 +34,8 @@ BLANK_BIAS = {
     "conformer-tiny-test": 2.179,
     "conformer-streaming-tiny-test": 2.0,
     "zipformer-streaming-en": 3.0,
+    "zipformer-en": 3.0,
+    "zipformer-tiny-test": 1.5,
     "zipformer-streaming-tiny-test": 1.5,
 }
 

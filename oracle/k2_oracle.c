@@ -857,6 +857,9 @@ static float* convert_channels(const float* x, int M, int Din, int Dout) {
 #include "k2_oracle_conformer.c"
 #include "k2_oracle_lstm.c"
 
+static int zip1_offline_forward(const k2o_model* m, const float* xin, int B, int T, float* enc_out, int tap, float* tap_out, int64_t tap_cap,
+                                int64_t* tap_n);   /* k2_oracle_zipformer1.c */
+
 int k2o_encoder_out_frames(const k2o_model* m, int T) {
     if (m->conformer) return conformer_out_frames(T);
     if (m->lstm) return lstm_out_frames(T);
@@ -982,12 +985,14 @@ int k2o_offline_encoder(const k2o_model* m, const float* x, int B, int T, float*
     int64_t n;
     if (m->conformer) return conformer_forward(m, x, B, T, enc_out, -1, NULL, 0, &n);
     if (m->lstm) return lstm_forward(m, x, B, T, enc_out, -1, NULL, 0, &n);
+    if (m->zip1) return zip1_offline_forward(m, x, B, T, enc_out, -1, NULL, 0, &n);
     return encoder_forward(m, x, B, T, enc_out, -1, NULL, 0, &n);
 }
 int64_t k2o_offline_encoder_tap(const k2o_model* m, const float* x, int B, int T, int tap, float* out, int64_t cap) {
     int64_t n = 0;
     int rc = m->conformer ? conformer_forward(m, x, B, T, NULL, tap, out, cap, &n)
              : m->lstm    ? lstm_forward(m, x, B, T, NULL, tap, out, cap, &n)
+             : m->zip1    ? zip1_offline_forward(m, x, B, T, NULL, tap, out, cap, &n)
                           : encoder_forward(m, x, B, T, NULL, tap, out, cap, &n);
     return rc < 0 ? rc : n;
 }

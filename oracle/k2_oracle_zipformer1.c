@@ -330,3 +330,187 @@ static int z1_stream_chunk(const k2o_model* m, k2o_online_stream* s, const float
     free(dsd);
     return Tp;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Offline Zipformer v1: Model_type "zipformer" in OfflineRecognizer's switch (OfflineRecognizer.cs:40-44 -> OfflineProjOfTransducer,
+ * x [B,T,80], x_lens = T for every row, :48-92).  The graph is icefall's pruned_transducer_stateless7 Zipformer.forward (the
+ * non-streaming recipe), inference: the same modules as above with
+ *   PoolingModule.forward: the mean over ALL frames of the utterance (the key-padding mask is all False, so every frame gets
+ *     weight 1/T), projected and added to every frame;
+ *   attention over the whole utterance (rel-pos table for positions T-1 .. -(T-1)), weights used twice;
+ *   ConvolutionModule.forward: depthwise conv with zero padding K//2 on both sides (not causal).
+ * Utterances are independent (no padding mask can couple them: x_lens = T), so the batch is a loop.
+ * ------------------------------------------------------------------------------------------------------------------------ */
+static void z1_conv_module_offline(const k2o_model* m, const char* pfx, int k, float* src, int T, int D, int K) {
+    const int pad = K / 2;
+    float* x = falloc((size_t)T * 2 * D);
+    linear(x, 2 * D, src, D, WT(m, 2 * D, D, "%sconv_module%d.pointwise_conv1.weight", pfx, k), W(m, "%sconv_module%d.pointwise_conv1.bias", pfx, k), T, D, 2 * D);
+    float* g = falloc((size_t)T * D);
+    for (int t = 0; t < T; t++)
+        for (int d = 0; d < D; d++) g[(size_t)t * D + d] = x[(size_t)t * 2 * D + d] * (1.0f / (1.0f + expf(-x[(size_t)t * 2 * D + D + d])));
+    const float* wd = W(m, "%sconv_module%d.depthwise_conv.weight", pfx, k);
+    const float* bd = W(m, "%sconv_module%d.depthwise_conv.bias", pfx, k);
+    float* c1 = falloc((size_t)T * D);
+    for (int t = 0; t < T; t++)
+        for (int d = 0; d < D; d++) {
+            float s = bd[d];
+            for (int kk = 0; kk < K; kk++) {
+                int tt = t + kk - pad;
+                if (tt >= 0 && tt < T) s += wd[d * K + kk] * g[(size_t)tt * D + d];
+            }
+            c1[(size_t)t * D + d] = double_swish(s);
+        }
+    float* o = falloc((size_t)T * D);
+    linear(o, D, c1, D, WT(m, D, D, "%sconv_module%d.pointwise_conv2.weight", pfx, k), W(m, "%sconv_module%d.pointwise_conv2.bias", pfx, k), T, D, D);
+    add_inplace(src, o, (size_t)T * D);
+    free(x); free(g); free(c1); free(o);
+}
+
+static void z1_layer_offline(const k2o_model* m, int si, const char* pfx, float* src, const float* pe, int T) {
+    const int D = m->dim[si], A = m->att[si], H = m->heads[si], F = m->ff[si], K = m->kern[si], P = m->pos_dim;
+    const int hd = A / H, vd = A / 2 / H, n2 = 2 * T - 1, inproj = 2 * A + A / 2 + P * H;
+    float* orig = falloc((size_t)T * D);
+    memcpy(orig, src, sizeof(float) * (size_t)T * D);
+    z1_feed_forward(m, pfx, 1, src, T, D, F);
+    {   /* pooling: mean over the utterance's frames, (x * 1/T).sum(0) */
+        float* mean = falloc(D);
+        const float wgt = 1.0f / (float)T;
+        for (int d = 0; d < D; d++) {
+            float a = 0.f;
+            for (int t = 0; t < T; t++) a += src[(size_t)t * D + d] * wgt;
+            mean[d] = a;
+        }
+        float* o = falloc(D);
+        linear(o, D, mean, D, WT(m, D, D, "%spooling.proj.weight", pfx), NULL, 1, D, D);
+        for (int t = 0; t < T; t++)
+            for (int d = 0; d < D; d++) src[(size_t)t * D + d] += o[d];
+        free(mean); free(o);
+    }
+    float* aw = falloc((size_t)H * T * T);
+    {
+        float* x = falloc((size_t)T * inproj);
+        linear(x, inproj, src, D, WT(m, inproj, D, "%sself_attn.in_proj.weight", pfx), W(m, "%sself_attn.in_proj.bias", pfx), T, D, inproj);
+        float* pp = falloc((size_t)n2 * P * H);
+        linear(pp, P * H, pe, D, WT(m, P * H, D, "%sself_attn.linear_pos.weight", pfx), NULL, n2, D, P * H);
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int h = 0; h < H; h++)
+            for (int i = 0; i < T; i++) {
+                const float* qi = x + (size_t)i * inproj + h * hd;
+                const float* pi = x + (size_t)i * inproj + 2 * A + A / 2 + h * P;
+                float* row = aw + ((size_t)h * T + i) * T;
+                float mx = -INFINITY;
+                for (int j = 0; j < T; j++) {
+                    const float* kj = x + (size_t)j * inproj + A + h * hd;
+                    float sc = 0.f;
+                    for (int d = 0; d < hd; d++) sc += qi[d] * kj[d];
+                    const float* pr = pp + (size_t)(T - 1 - i + j) * (P * H) + h * P;
+                    float ps = 0.f;
+                    for (int c = 0; c < P; c++) ps += pi[c] * pr[c];
+                    row[j] = sc + ps;
+                    if (row[j] > mx) mx = row[j];
+                }
+                float sum = 0.f;
+                for (int j = 0; j < T; j++) { row[j] = expf(row[j] - mx); sum += row[j]; }
+                float inv = 1.0f / sum;
+                for (int j = 0; j < T; j++) row[j] *= inv;
+            }
+        float* v = falloc((size_t)T * (A / 2));
+        for (int t = 0; t < T; t++) memcpy(v + (size_t)t * (A / 2), x + (size_t)t * inproj + 2 * A, sizeof(float) * (A / 2));
+        float* a = falloc((size_t)T * (A / 2));
+        for (int h = 0; h < H; h++) attn_apply1(a, A / 2, aw + (size_t)h * T * T, v, A / 2, T, T, h * vd, vd);
+        float* o = falloc((size_t)T * D);
+        linear(o, D, a, A / 2, WT(m, D, A / 2, "%sself_attn.out_proj.weight", pfx), W(m, "%sself_attn.out_proj.bias", pfx), T, A / 2, D);
+        add_inplace(src, o, (size_t)T * D);
+        free(x); free(pp); free(v); free(a); free(o);
+    }
+    z1_conv_module_offline(m, pfx, 1, src, T, D, K);
+    z1_feed_forward(m, pfx, 2, src, T, D, F);
+    {
+        float* v = falloc((size_t)T * (A / 2));
+        linear(v, A / 2, src, D, WT(m, A / 2, D, "%sself_attn.in_proj2.weight", pfx), NULL, T, D, A / 2);
+        float* a = falloc((size_t)T * (A / 2));
+        for (int h = 0; h < H; h++) attn_apply1(a, A / 2, aw + (size_t)h * T * T, v, A / 2, T, T, h * vd, vd);
+        float* o = falloc((size_t)T * D);
+        linear(o, D, a, A / 2, WT(m, D, A / 2, "%sself_attn.out_proj2.weight", pfx), W(m, "%sself_attn.out_proj2.bias", pfx), T, A / 2, D);
+        add_inplace(src, o, (size_t)T * D);
+        free(v); free(a); free(o);
+    }
+    free(aw);
+    z1_conv_module_offline(m, pfx, 2, src, T, D, K);
+    z1_feed_forward(m, pfx, 3, src, T, D, F);
+    basic_norm(src, src, W(m, "%snorm_final.eps", pfx)[0], T, D);
+    const float bs = W(m, "%sbypass_scale", pfx)[0];
+    for (size_t i = 0; i < (size_t)T * D; i++) src[i] = orig[i] + (src[i] - orig[i]) * bs;
+    free(orig);
+}
+
+/* taps: 0 = embed output [B*T50, D0]; 1+i = output of stack i [B*T50, dim[i]]; -1 = encoder_out [B, T', J] */
+static int zip1_offline_forward(const k2o_model* m, const float* xin, int B, int T, float* enc_out, int tap, float* tap_out, int64_t tap_cap,
+                                int64_t* tap_n) {
+    if (T < 9) return fail("encoder: T=%d too short", T);
+    int Tc0 = (T - 7) / 2, Tp0 = (Tc0 + 1) / 2;
+    if (tap >= 0) {
+        if (tap > m->ns) return fail("tap %d out of range", tap);
+        int64_t n = (int64_t)B * Tc0 * (tap == 0 ? m->dim[0] : m->dim[tap - 1]);
+        if (n > tap_cap) return fail("tap buffer too small");
+        *tap_n = n;
+    }
+    for (int b = 0; b < B; b++) {
+        int Tc;
+        float* cur = z1_embed(m, xin + (size_t)b * T * m->feat, T, &Tc);
+        float* outputs[MAX_STACKS] = {0};
+        int Dcur = m->dim[0], rc = 0, done = 0;
+        if (tap == 0) { memcpy(tap_out + (size_t)b * Tc * Dcur, cur, sizeof(float) * (size_t)Tc * Dcur); done = 1; }
+        for (int si = 0; si < m->ns && !done && !rc; si++) {
+            const int D = m->dim[si], ds = m->ds[si];
+            int k = z1_skip_layer(m, si);
+            if (k >= 0) {
+                float* y = z1_combine(outputs[k], m->dim[k], cur, Dcur, W(m, "encoder.skip_modules.%d.weight1", si)[0], Tc);
+                free(cur);
+                cur = y;
+            }
+            char pfx[128];
+            if (ds == 1) {
+                if (D != Dcur) { rc = fail("zipformer: stack %d has downsampling 1 but changes width", si); break; }
+                float* pe = z1_rel_pos(Tc, 0, D);
+                for (int li = 0; li < m->nlayer[si]; li++) {
+                    snprintf(pfx, sizeof pfx, "encoder.encoders.%d.layers.%d.", si, li);
+                    z1_layer_offline(m, si, pfx, cur, pe, Tc);
+                }
+                free(pe);
+            } else {
+                if (D < Dcur) { rc = fail("zipformer: stack %d narrows %d -> %d (unsupported)", si, Dcur, D); break; }
+                int Td;
+                snprintf(pfx, sizeof pfx, "encoder.encoders.%d.downsample.", si);
+                float* xd = z1_attn_downsample(m, pfx, cur, Tc, Dcur, D, ds, &Td);
+                float* pe = z1_rel_pos(Td, 0, D);
+                for (int li = 0; li < m->nlayer[si]; li++) {
+                    snprintf(pfx, sizeof pfx, "encoder.encoders.%d.encoder.layers.%d.", si, li);
+                    z1_layer_offline(m, si, pfx, xd, pe, Td);
+                }
+                free(pe);
+                const float* ub = W(m, "encoder.encoders.%d.upsample.bias", si);
+                float* up = falloc((size_t)Tc * D);
+                for (int t = 0; t < Tc; t++)
+                    for (int d = 0; d < D; d++) up[(size_t)t * D + d] = xd[(size_t)(t / ds) * D + d] + ub[(size_t)(t % ds) * D + d];
+                float* y = z1_combine(cur, Dcur, up, D, W(m, "encoder.encoders.%d.out_combiner.weight1", si)[0], Tc);
+                free(up); free(xd); free(cur);
+                cur = y;
+                Dcur = D;
+            }
+            outputs[si] = falloc((size_t)Tc * Dcur);
+            memcpy(outputs[si], cur, sizeof(float) * (size_t)Tc * Dcur);
+            if (tap == si + 1) { memcpy(tap_out + (size_t)b * Tc * Dcur, cur, sizeof(float) * (size_t)Tc * Dcur); done = 1; }
+        }
+        for (int i = 0; i < m->ns; i++) free(outputs[i]);
+        if (rc) { free(cur); return rc; }
+        if (!done) {
+            int Tp;
+            float* dsd = z1_attn_downsample(m, "encoder.downsample_output.", cur, Tc, Dcur, Dcur, 2, &Tp);
+            linear(enc_out + (size_t)b * Tp0 * m->J, m->J, dsd, Dcur, WT(m, m->J, Dcur, "joiner.encoder_proj.weight"), W(m, "joiner.encoder_proj.bias"), Tp, Dcur, m->J);
+            free(dsd);
+        }
+        free(cur);
+    }
+    return 0;
+}

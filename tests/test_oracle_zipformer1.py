@@ -90,3 +90,29 @@ def test_online_step_matches_per_stream_chunks(z1_oracle):
         pos += S
     assert sa.tokens == ta.tokens and sb.tokens == tb.tokens and sa.timestamps == ta.timestamps
     assert len(sa.tokens) > 2 and all(t not in (0, 1, 2) for t in sa.tokens[2:])
+
+
+def test_offline_encoder_matches_torch_twin(tmp_path_factory):
+    """The offline Zipformer v1 graph (Model_type "zipformer" at OfflineRecognizer.cs:40): oracle against the independent torch
+    restatement -- the embed output, every stack's output and the projected encoder output, for odd and even lengths."""
+    import torch
+    from k2transducerasr_amd.k2w import read_k2w
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    from oracle import Oracle
+    from torch_twin_zipformer1 import Zipformer1Twin
+    p = str(tmp_path_factory.mktemp("z1off") / "z1off.k2w")
+    write_synthetic_model(p, "zipformer-tiny-test")
+    ora = Oracle(p)
+    meta, tensors = read_k2w(p)
+    tw = Zipformer1Twin(meta, tensors)
+    torch.set_num_threads(4)
+    for secs in (0.83, 1.21):
+        feats = [ora.fbank(synth_utterance(7 + u, secs)) for u in range(2)]
+        x = ora.pad_sequence(feats).reshape(2, -1, 80)
+        assert ora.encoder_out_frames(x.shape[1]) == ((x.shape[1] - 7) // 2 + 1) // 2
+        with torch.no_grad():
+            for tap in (0, 1, 2, 3, 4):
+                want = tw.forward_offline(torch.from_numpy(x), tap).numpy()
+                np.testing.assert_allclose(ora.encoder_tap(x, tap).reshape(want.shape), want, rtol=2e-4, atol=2e-4, err_msg=f"tap {tap}")
+            want = tw.forward_offline(torch.from_numpy(x)).numpy()
+        np.testing.assert_allclose(ora.encoder(x), want, rtol=2e-4, atol=2e-4)

@@ -28,9 +28,9 @@ class Zipformer1Twin:
         self.heads = _ints(meta, "num_heads")
         self.kern = _ints(meta, "cnn_module_kernels")
         self.ds = _ints(meta, "downsampling_factors")
-        self.left = _ints(meta, "left_context_len")
+        self.left = _ints(meta, "left_context_len") if "left_context_len" in meta else []
         self.pos_dim = int(meta["pos_dim"])
-        self.T = int(meta["T"])
+        self.T = int(meta.get("T", 0))
 
     def init_states(self):
         st = []
@@ -195,4 +195,84 @@ class Zipformer1Twin:
                 x = self.combine(orig, up[: orig.shape[0]], w[base + "out_combiner.weight1"])
             outputs.append(x)
         x = self.attn_downsample("encoder.downsample_output.", x, 2).permute(1, 0, 2)[0]
+        return F.linear(x, w["joiner.encoder_proj.weight"], w["joiner.encoder_proj.bias"])
+
+    # ---- offline graph (pruned_transducer_stateless7 Zipformer.forward, x_lens = T) ----
+    def conv_offline(self, p, k, x):  # x [T,N,D]
+        w = self.w
+        q = p + f"conv_module{k}."
+        x = x.permute(1, 2, 0)
+        x = F.glu(F.conv1d(x, w[q + "pointwise_conv1.weight"], w[q + "pointwise_conv1.bias"]), dim=1)
+        K = w[q + "depthwise_conv.weight"].shape[2]
+        x = dswish(F.conv1d(x, w[q + "depthwise_conv.weight"], w[q + "depthwise_conv.bias"], groups=x.shape[1], padding=K // 2))
+        x = F.conv1d(x, w[q + "pointwise_conv2.weight"], w[q + "pointwise_conv2.bias"])
+        return x.permute(2, 0, 1)
+
+    def layer_offline(self, p, si, src, pos_emb):
+        w = self.w
+        A, H, P = self.atts[si], self.heads[si], self.pos_dim
+        hd = A // H
+        orig = src
+        src = src + self.ff(p, 1, src)
+        T, N, _ = src.shape
+        # PoolingModule.forward with an all-False key_padding_mask: weight 1/T per frame, summed over time
+        pooling_mask = torch.ones(N, T)
+        pooling_mask = pooling_mask / pooling_mask.sum(dim=1, keepdim=True)
+        pooling_mask = pooling_mask.transpose(0, 1).contiguous().unsqueeze(-1)
+        pooled = (src * pooling_mask).sum(dim=0, keepdim=True)
+        src = src + F.linear(pooled, w[p + "pooling.proj.weight"])
+        xp = F.linear(src, w[p + "self_attn.in_proj.weight"], w[p + "self_attn.in_proj.bias"])
+        pos = F.linear(pos_emb, w[p + "self_attn.linear_pos.weight"])
+        q, k_, v, pq = xp[..., :A], xp[..., A : 2 * A], xp[..., 2 * A : 2 * A + A // 2], xp[..., 2 * A + A // 2 :]
+        q = q.reshape(T, N, H, hd).permute(1, 2, 0, 3)
+        pq = pq.reshape(T, N, H, P).permute(1, 2, 0, 3)
+        kk = k_.reshape(T, N, H, hd).permute(1, 2, 3, 0)
+        vv = v.reshape(T, N * H, hd // 2).transpose(0, 1)
+        pos = pos.reshape(1, 2 * T - 1, H, P).permute(0, 2, 3, 1)
+        pw = torch.matmul(pq, pos).contiguous()
+        pw = pw.as_strided((N, H, T, T), (pw.stride(0), pw.stride(1), pw.stride(2) - pw.stride(3), pw.stride(3)), storage_offset=pw.stride(3) * (T - 1))
+        aw = (torch.matmul(q, kk) + pw).view(N * H, T, T).softmax(dim=-1)
+        out = torch.bmm(aw, vv).transpose(0, 1).contiguous().view(T, N, A // 2)
+        src = src + F.linear(out, w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"])
+        src = src + self.conv_offline(p, 1, src)
+        src = src + self.ff(p, 2, src)
+        v2 = F.linear(src, w[p + "self_attn.in_proj2.weight"])
+        vv2 = v2.reshape(T, N * H, hd // 2).transpose(0, 1)
+        out = torch.bmm(aw, vv2).transpose(0, 1).contiguous().view(T, N, A // 2)
+        src = src + F.linear(out, w[p + "self_attn.out_proj2.weight"], w[p + "self_attn.out_proj2.bias"])
+        src = src + self.conv_offline(p, 2, src)
+        src = src + self.ff(p, 3, src)
+        eps = w[p + "norm_final.eps"].exp()
+        src = src * (src.pow(2).mean(dim=-1, keepdim=True) + eps) ** -0.5
+        return orig + (src - orig) * w[p + "bypass_scale"]
+
+    def forward_offline(self, x, tap=-1):
+        """x [N,T,80] -> encoder_out [N,T',J] (after joiner.encoder_proj); tap: 0 embed output, 1+i output of stack i ([N,T50,D])."""
+        w = self.w
+        x = self.embed(x).permute(1, 0, 2)
+        if tap == 0:
+            return x.permute(1, 0, 2)
+        outputs = []
+        for i, ds in enumerate(self.ds):
+            k = self.skip_layer(i)
+            if k is not None:
+                x = self.combine(outputs[k], x, w[f"encoder.skip_modules.{i}.weight1"])
+            base = f"encoder.encoders.{i}."
+            if ds == 1:
+                pe = self.rel_pos(x.shape[0], 0, self.dims[i]).unsqueeze(0)
+                for li in range(self.layers[i]):
+                    x = self.layer_offline(base + f"layers.{li}.", i, x, pe)
+            else:
+                orig = x
+                xd = self.attn_downsample(base + "downsample.", x, ds)
+                pe = self.rel_pos(xd.shape[0], 0, self.dims[i]).unsqueeze(0)
+                for li in range(self.layers[i]):
+                    xd = self.layer_offline(base + f"encoder.layers.{li}.", i, xd, pe)
+                T, N, C = xd.shape
+                up = (xd.unsqueeze(1).expand(T, ds, N, C) + w[base + "upsample.bias"].unsqueeze(1)).reshape(T * ds, N, C)
+                x = self.combine(orig, up[: orig.shape[0]], w[base + "out_combiner.weight1"])
+            outputs.append(x)
+            if tap == i + 1:
+                return x.permute(1, 0, 2)
+        x = self.attn_downsample("encoder.downsample_output.", x, 2).permute(1, 0, 2)
         return F.linear(x, w["joiner.encoder_proj.weight"], w["joiner.encoder_proj.bias"])
