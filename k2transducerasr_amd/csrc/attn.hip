@@ -19,27 +19,30 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int QH = 32;  // query/key head dim (config-checked at load)
 constexpr int PH = 4;   // pos head dim
 constexpr int R = 32;   // query rows per workgroup
 
+// NG = query / key head dim / 8 (4: Zipformer2's 32; 3 and 2: Zipformer v1's attention_dim / heads = 24, 16); koff0 / poff0 = float
+// offsets of head 0's key / positional query inside a projected row (the query sits at h * 8 NG)
+template <int NG>
 __global__ __launch_bounds__(512, 4) void k_attn_scores_softmax(const float* __restrict__ qkp, int ld,
                                                              const float* __restrict__ pp, float* __restrict__ aw, int B,
-                                                             int T, int Tp, int H, int lds_stride) {
+                                                             int T, int Tp, int H, int lds_stride, int koff0, int poff0) {
+    constexpr int QH = 8 * NG;
     extern __shared__ __attribute__((aligned(16))) float S[];  // [R][lds_stride]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int i0 = blockIdx.x * R, b = blockIdx.y, h = blockIdx.z;
     const float* base = qkp + (long long)b * T * ld;
-    const int qoff = h * QH, koff = H * QH + h * QH, poff = 2 * H * QH + h * PH;
+    const int qoff = h * QH, koff = koff0 + h * QH, poff = poff0 + h * PH;
     const int ppld = H * PH;
 
     // Q fragments of this workgroup's 32 rows (every wave holds all of them)
-    float4 fq[4];
+    float4 fq[NG];
     {
         int row = i0 + li;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
+        for (int g = 0; g < NG; g++) {
             fq[g] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < T) fq[g] = *reinterpret_cast<const float4*>(base + (long long)row * ld + qoff + 8 * g + 4 * lh);
         }
@@ -57,9 +60,9 @@ __global__ __launch_bounds__(512, 4) void k_attn_scores_softmax(const float* __r
     const int njt = (T + 31) / 32;
     for (int jt = wave; jt < njt; jt += 8) {
         int j = jt * 32 + li;  // this lane's key (as B-operand column and as accumulator column)
-        float4 fk[4];
+        float4 fk[NG];
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
+        for (int g = 0; g < NG; g++) {
             fk[g] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (j < T) fk[g] = *reinterpret_cast<const float4*>(base + (long long)j * ld + koff + 8 * g + 4 * lh);
         }
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_scores_softmax(const float* __r
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
+        for (int g = 0; g < NG; g++) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fq[g].x, fk[g].x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fq[g].y, fk[g].y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fq[g].z, fk[g].z, acc, 0, 0, 0);
@@ -125,20 +128,22 @@ __global__ __launch_bounds__(512, 4) void k_attn_scores_softmax(const float* __r
 // nothing but the row statistics kept -- pass 1 builds each row's running (max, sum of exp) per lane, combined once across
 // lanes and waves; pass 2 recomputes the scores and writes exp(s - max) / sum straight to the weights.  Twice the (small)
 // score arithmetic, no strip.
+template <int NG>
 __global__ __launch_bounds__(256) void k_attn_scores_softmax_long(const float* __restrict__ qkp, int ld, const float* __restrict__ pp,
-                                                                  float* __restrict__ aw, int B, int T, int Tp, int H) {
+                                                                  float* __restrict__ aw, int B, int T, int Tp, int H, int koff0, int poff0) {
+    constexpr int QH = 8 * NG;
     __shared__ float smx[4][R], ssm[4][R];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int i0 = blockIdx.x * R, b = blockIdx.y, h = blockIdx.z;
     const float* base = qkp + (long long)b * T * ld;
-    const int qoff = h * QH, koff = H * QH + h * QH, poff = 2 * H * QH + h * PH;
+    const int qoff = h * QH, koff = koff0 + h * QH, poff = poff0 + h * PH;
     const int ppld = H * PH;
-    float4 fq[4];
+    float4 fq[NG];
     {
         int row = i0 + li;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
+        for (int g = 0; g < NG; g++) {
             fq[g] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < T) fq[g] = *reinterpret_cast<const float4*>(base + (long long)row * ld + qoff + 8 * g + 4 * lh);
         }
@@ -158,9 +163,9 @@ __global__ __launch_bounds__(256) void k_attn_scores_softmax_long(const float* _
     for (int pass = 0; pass < 2; pass++) {
         for (int jt = wave; jt < njt; jt += 4) {
             const int j = jt * 32 + li;
-            float4 fk[4];
+            float4 fk[NG];
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
+            for (int g = 0; g < NG; g++) {
                 fk[g] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (j < T) fk[g] = *reinterpret_cast<const float4*>(base + (long long)j * ld + koff + 8 * g + 4 * lh);
             }
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(256) void k_attn_scores_softmax_long(const float* _
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
+            for (int g = 0; g < NG; g++) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fq[g].x, fk[g].x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fq[g].y, fk[g].y, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fq[g].z, fk[g].z, acc, 0, 0, 0);
@@ -361,23 +366,39 @@ __global__ __launch_bounds__(256) void k_attn_av_out(const float* __restrict__ a
 
 }  // namespace
 
-void attn_scores_softmax(const Ctx& ctx, const float* qkp, int ld, const float* pp, float* aw, int B, int T, int Tp, int H) {
-    K2_REQUIRE(Tp % 4 == 0 && Tp >= T, "attn: Tp=%d must be T=%d rounded up to 4", Tp, T);
+template <int NG>
+static void attn_scores_launch(const Ctx& ctx, const float* qkp, int ld, const float* pp, float* aw, int B, int T, int Tp, int H, int koff0,
+                               int poff0) {
     int lds_stride = Tp + 4;  // rows 16 B aligned; +4 floats de-phases the 4-row-apart writers of one MFMA register
     size_t lds = sizeof(float) * (R * lds_stride + 4 * (T + R) + 4 * R);  // score strip + the positional window + the rows' p
-    ctx.add_flops(0.0, 2.0 * (QH + PH) * (double)T * T * B * H, 0);
-    if (ctx.dry) return;
     static const bool force_long = getenv("K2HIP_ATTN_LONG") != nullptr;
     if (lds > 160 * 1024 || force_long) {  // > ~1120 frames: two-pass form without the LDS strip
-        hipLaunchKernelGGL(k_attn_scores_softmax_long, dim3(cdiv(T, R), B, H), dim3(256), 0, ctx.stream, qkp, ld, pp, aw, B, T, Tp, H);
+        hipLaunchKernelGGL(k_attn_scores_softmax_long<NG>, dim3(cdiv(T, R), B, H), dim3(256), 0, ctx.stream, qkp, ld, pp, aw, B, T, Tp, H, koff0,
+                           poff0);
         K2_HIP(hipGetLastError());
         return;
     }
     static LdsAttrOnce lds_attr;
-    lds_attr.ensure(k_attn_scores_softmax, 160 * 1024);
+    lds_attr.ensure(k_attn_scores_softmax<NG>, 160 * 1024);
     dim3 grid(cdiv(T, R), B, H);
-    hipLaunchKernelGGL(k_attn_scores_softmax, grid, dim3(512), lds, ctx.stream, qkp, ld, pp, aw, B, T, Tp, H, lds_stride);
+    hipLaunchKernelGGL(k_attn_scores_softmax<NG>, grid, dim3(512), lds, ctx.stream, qkp, ld, pp, aw, B, T, Tp, H, lds_stride, koff0, poff0);
     K2_HIP(hipGetLastError());
+}
+
+void attn_scores_softmax(const Ctx& ctx, const float* qkp, int ld, const float* pp, float* aw, int B, int T, int Tp, int H, int qh, int koff0,
+                         int poff0) {
+    K2_REQUIRE(Tp % 4 == 0 && Tp >= T, "attn: Tp=%d must be T=%d rounded up to 4", Tp, T);
+    if (koff0 < 0) koff0 = H * qh;       // Zipformer2 row: q [H*qh] | k [H*qh] | p [H*4]
+    if (poff0 < 0) poff0 = 2 * H * qh;
+    K2_REQUIRE(koff0 % 4 == 0 && poff0 % 4 == 0 && ld % 4 == 0, "attn: operand offsets must be multiples of 4 floats");
+    ctx.add_flops(0.0, 2.0 * (qh + PH) * (double)T * T * B * H, 0);
+    if (ctx.dry) return;
+    switch (qh) {
+        case 32: attn_scores_launch<4>(ctx, qkp, ld, pp, aw, B, T, Tp, H, koff0, poff0); break;
+        case 24: attn_scores_launch<3>(ctx, qkp, ld, pp, aw, B, T, Tp, H, koff0, poff0); break;
+        case 16: attn_scores_launch<2>(ctx, qkp, ld, pp, aw, B, T, Tp, H, koff0, poff0); break;
+        default: failf(K2HIP_ERR_UNSUPPORTED, "attention head size %d unsupported (16, 24, 32)", qh);
+    }
 }
 
 bool attn_av_out(const Ctx& ctx, const float* aw, const float* v, const float* wout, const float* bias, float* x, int B, int T, int KL, int Tp,

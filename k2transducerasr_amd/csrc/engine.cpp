@@ -41,6 +41,7 @@ Engine::~Engine() {
     if (stream2_) (void)hipStreamDestroy(stream2_);
     for (auto& kv : pe_cache_) (void)hipFree(kv.second);
     for (auto& kv : pp_cache_) (void)hipFree(kv.second);
+    for (auto& kv : sinus_cache_) (void)hipFree(kv.second);
     if (online_pool_) (void)hipFree(online_pool_);
     if (d_ptab_) (void)hipFree(d_ptab_);
     for (auto& e : ev_)
@@ -198,6 +199,7 @@ const float* Engine::pos_proj_cached(const Ctx& c, int layer, const float* pe, i
     if (pp_cache_bytes_ + bytes > ((size_t)1 << 30)) {  // many distinct utterance lengths: start over (stream-ordered frees)
         K2_HIP(hipDeviceSynchronize());
         for (auto& kv : pp_cache_) (void)hipFree(kv.second);
+    for (auto& kv : sinus_cache_) (void)hipFree(kv.second);
         pp_cache_.clear();
         pp_cache_bytes_ = 0;
     }
@@ -382,6 +384,7 @@ float* Engine::encoder_forward(const Ctx& c, const float* x, int B, int T, int* 
     const Config& cf = m.cfg();
     if (cf.conformer) return conformer_forward(c, x, B, T, Tp, tap, tap_ptr, tap_rows, tap_dim);
     if (cf.lstm) return lstm_forward(c, x, B, T, Tp, tap, tap_ptr, tap_rows, tap_dim);
+    if (cf.zip1) return zip1_forward(c, x, B, T, Tp, tap, tap_ptr, tap_rows, tap_dim);
     Arena& ar = *c.arena;
     int T50 = 0;
     // output first so that everything after it can be rewound

@@ -5,6 +5,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <tuple>
 
 #include "kernels.h"
 #include "model.h"
@@ -121,9 +122,12 @@ class Engine {
     float* lstm_chunk(const Ctx& c, const float* x, const int* d_slots, int B);
     // streaming Zipformer v1 (zipformer1_engine.cpp)
     const float* sinus_pos_emb(int Tc, int left, int D);
+    std::map<std::tuple<int, int, int>, float*> sinus_cache_;  // (frames, left context, width) -> device table
     float* zip1_embed(const Ctx& c, const float* x, int B, int T, int* Tc_out);
     void zip1_layer(const Ctx& c, int si, const std::string& pfx, int l, float* x, const float* pp, const int* d_slots, int B, int Tc, int L);
     float* zip1_chunk(const Ctx& c, const float* x, const int* d_slots, int B, int* Tp_out);
+    void zip1_layer_offline(const Ctx& c, int si, const std::string& pfx, int l, float* x, const float* pe, int B, int T);
+    float* zip1_forward(const Ctx& c, const float* x, int B, int T, int* Tp, int tap, float** tap_ptr, int* tap_rows, int* tap_dim);
     // offline Conformer (conformer_engine.cpp)
     const float* conformer_pos_emb_left(int Tc, int left);
     float* conformer_chunk(const Ctx& c, const float* x, const int* d_slots, const long long* d_plen, int B, int* Tc_out);

@@ -97,7 +97,10 @@ void linear(const Ctx& ctx, const float* A, int lda, const float* W, const float
 // ---- attention ------------------------------------------------------------
 // qkp: [B*T, ld] rows = (q[H*32] | k[H*32] | p[H*4]); pp: [2T-1, H*4];
 // aw out: [H][B][T][Tp] (Tp = T rounded up to 4, pad columns zeroed)
-void attn_scores_softmax(const Ctx& ctx, const float* qkp, int ld, const float* pp, float* aw, int B, int T, int Tp, int H);
+// qh: query / key head size (16, 24 or 32); koff0 / poff0: float offset of head 0's key / positional query in a row (default: the
+// Zipformer2 row above; Zipformer v1: q [A] | k [A] | v [A/2] | p [H*4])
+void attn_scores_softmax(const Ctx& ctx, const float* qkp, int ld, const float* pp, float* aw, int B, int T, int Tp, int H, int qh = 32,
+                         int koff0 = -1, int poff0 = -1);
 
 // fused x += out_proj(concat_h(aw_h . v_h)) + bias  (SelfAttention after its value projection); aw [H][B][T][Tp] over KL keys,
 // v [B*KL, H*vh], wout [D, H*vh];
@@ -289,6 +292,10 @@ void z1_glu_conv(const Ctx& ctx, const float* x2, float* pool, long long slot_st
 void z1_norm_bypass(const Ctx& ctx, const float* x, const float* orig, const float* log_eps, const float* bscale, float* y, int M, int D);
 // AttentionDownsample, first Din channels: x [B,T,Din] -> y [B,ceil(T/ds),ldy]
 void z1_attn_downsample(const Ctx& ctx, const float* x, const float* query, float* y, int B, int T, int Din, int ldy, int ds);
+// offline graph: mean over the utterance's frames [B,D]; x[b,t,:] += v[b,:]; the ds frames of a downsampling group side by side
+void z1_mean(const Ctx& ctx, const float* x, float* mean, int B, int T, int D);
+void z1_add_bcast(const Ctx& ctx, float* x, const float* v, int B, int T, int D);
+void z1_group_rows(const Ctx& ctx, const float* x, float* grp, int B, int T, int Din, int ds);
 // SimpleCombiner(src1 [B*T,d1], src2) -> y [B*T,d2]; ub != null: src2 = SimpleUpsample(xd [B,Td,d2], ub [ds,d2])[:T]
 void z1_combine(const Ctx& ctx, const float* s1, int d1, const float* s2, int d2, const float* w1, const float* ub, int ds, int B, int T,
                 int Td, float* y);

@@ -347,6 +347,21 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
             push(std::string(nm) + "#kd", std::move(v), {K, D});
         }
     }
+    if (c.zip1 && !c.streaming) {  // offline v1: conv_module depthwise [D,1,K] -> [K][D] for the LDS-tiled GLU + depthwise kernel
+        for (int si = 0; si < c.ns; si++)
+            for (int li = 0; li < c.nlayer[si]; li++)
+                for (int k = 1; k <= 2; k++) {
+                    char nm[192];
+                    snprintf(nm, sizeof nm, "encoder.encoders.%d.%slayers.%d.conv_module%d.depthwise_conv.weight", si, c.ds[si] > 1 ? "encoder." : "", li, k);
+                    const Tensor& t = tensor(nm);
+                    const int D = (int)t.dims[0], K = (int)t.dims[2];
+                    K2_REQUIRE(D == c.dim[si] && K == c.kern[si], "%s has shape [%d,1,%d], config says [%d,1,%d]", nm, D, K, c.dim[si], c.kern[si]);
+                    std::vector<float> v((size_t)K * D);
+                    for (int d = 0; d < D; d++)
+                        for (int kk = 0; kk < K; kk++) v[(size_t)kk * D + d] = t.host[(size_t)d * K + kk];
+                    push(std::string(nm) + "#kd", std::move(v), {K, D});
+                }
+    }
     const bool has_encoder = !c.conformer && !c.zip1 && has("encoder_embed.conv.0.weight");
     if (has_encoder) {
     // conv filters [Co,Ci,3,3] -> [Co][kt][kf][ci]  (K index of the implicit GEMM over NHWC input)

@@ -176,9 +176,64 @@ __global__ void k_z1_combine(const float* __restrict__ s1, int d1, const float* 
     y[i] = a + v2 * (1.0f - w);
 }
 
+// ---- offline graph (OfflineRecognizer.cs:40: Model_type "zipformer" through OfflineProjOfTransducer) ----
+// PoolingModule.forward with x_lens = T: mean over the utterance's frames, sum_t x[b,t,d] * (1/T) in frame order
+__global__ void k_z1_mean(const float* __restrict__ x, float* __restrict__ mean, int B, int T, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, d = i - b * D;
+    const float w = 1.0f / (float)T;
+    const float* p = x + (long long)b * T * D + d;
+    float a = 0.f;
+    for (int t = 0; t < T; t++) a += p[(long long)t * D] * w;
+    mean[i] = a;
+}
+// x[b, t, :] += v[b, :]
+__global__ void k_z1_add_bcast(float* __restrict__ x, const float* __restrict__ v, int T, int D4, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int q = (int)(i % D4);
+    const long long b = i / ((long long)T * D4);
+    float4 a = reinterpret_cast<float4*>(x)[i];
+    const float4 c = reinterpret_cast<const float4*>(v)[b * D4 + q];
+    reinterpret_cast<float4*>(x)[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+}
+// grp[b, td, k*Din + d] = x[b, min(td*ds + k, T-1), d]: the ds frames of a group side by side, the last frame repeated as padding
+__global__ void k_z1_group_rows(const float* __restrict__ x, float* __restrict__ grp, int T, int Td, int Din, int ds, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int d = (int)(i % Din);
+    long long r = i / Din;
+    const int k = (int)(r % ds);
+    r /= ds;
+    const int td = (int)(r % Td);
+    const long long b = r / Td;
+    grp[i] = x[(b * T + min(td * ds + k, T - 1)) * Din + d];
+}
+
 inline int nb(long long n, int per) { return (int)((n + per - 1) / per); }
 
 }  // namespace
+
+void z1_mean(const Ctx& ctx, const float* x, float* mean, int B, int T, int D) {
+    if (ctx.dry) return;
+    hipLaunchKernelGGL(k_z1_mean, dim3(nb((long long)B * D, 64)), dim3(64), 0, ctx.stream, x, mean, B, T, D);
+    K2_HIP(hipGetLastError());
+}
+void z1_add_bcast(const Ctx& ctx, float* x, const float* v, int B, int T, int D) {
+    K2_REQUIRE(D % 4 == 0, "z1_add_bcast: D=%d", D);
+    if (ctx.dry) return;
+    const long long n4 = (long long)B * T * (D / 4);
+    hipLaunchKernelGGL(k_z1_add_bcast, dim3(nb(n4, 256)), dim3(256), 0, ctx.stream, x, v, T, D / 4, n4);
+    K2_HIP(hipGetLastError());
+}
+void z1_group_rows(const Ctx& ctx, const float* x, float* grp, int B, int T, int Din, int ds) {
+    if (ctx.dry) return;
+    const int Td = (T + ds - 1) / ds;
+    const long long n = (long long)B * Td * ds * Din;
+    hipLaunchKernelGGL(k_z1_group_rows, dim3(nb(n, 256)), dim3(256), 0, ctx.stream, x, grp, T, Td, Din, ds, n);
+    K2_HIP(hipGetLastError());
+}
 
 void z1_pool(const Ctx& ctx, const float* x, float* pool, long long slot_stride, long long avg_off, long long len_off, const int* slots,
              float* out, int B, int Tc, int D) {

@@ -112,3 +112,56 @@ def test_streaming_en_model_matches_oracle(tmp_path_factory):
         for l in (0, 5, 14):
             for kind in KINDS:
                 np.testing.assert_allclose(h.state(l, kind), o.state(l, kind), atol=5e-4, rtol=0)
+
+
+# ---- offline graph: Model_type "zipformer" in OfflineRecognizer's switch (OfflineRecognizer.cs:40-44) ----
+@pytest.fixture(scope="module")
+def z1off(tmp_path_factory):
+    from k2transducerasr_amd import Model
+    from k2transducerasr_amd.synth import write_synthetic_model
+    from oracle import Oracle
+    p = str(tmp_path_factory.mktemp("z1off") / "z1off.k2w")
+    write_synthetic_model(p, "zipformer-tiny-test")
+    return Model(p, 0), Oracle(p)
+
+
+@pytest.mark.parametrize("tap", [0, 1, 2, 3, 4])
+def test_offline_taps(z1off, utts, tap):
+    from parity import ACT_TOL
+    hip, ora = z1off
+    x = ora.pad_sequence([ora.fbank(u) for u in utts[:3]]).reshape(3, -1, 80)
+    np.testing.assert_allclose(hip.encoder_tap(x, tap), ora.encoder_tap(x, tap), atol=ACT_TOL, rtol=0)
+
+
+def test_offline_end_to_end_and_lengths(z1off, utts):
+    from parity import ACT_TOL, assert_tokens_match
+    hip, ora = z1off
+    x = ora.pad_sequence([ora.fbank(u) for u in utts]).reshape(len(utts), -1, 80)
+    enc = ora.encoder(x)
+    np.testing.assert_allclose(hip.encoder_proj(x), enc, atol=ACT_TOL, rtol=0)
+    want, mg = ora.greedy_batch(enc, want_margins=True)
+    assert sum(len(w[0]) for w in want) > 0
+    assert_tokens_match(hip.offline_greedy_from_samples(utts), want, mg, what="zipformer v1 offline")
+    rng = np.random.default_rng(11)
+    for T in (9, 10, 23, 38, 61, 100):   # frame counts that do / do not divide by the downsampling factors
+        xs = rng.standard_normal((2, T, 80)).astype(np.float32)
+        assert hip.encoder_out_frames(T) == ora.encoder_out_frames(T)
+        np.testing.assert_allclose(hip.encoder_proj(xs), ora.encoder(xs), atol=ACT_TOL, rtol=0, err_msg=f"T={T}")
+
+
+def test_offline_en_architecture(tmp_path_factory):
+    """The published offline recipe's architecture (5 x 384, 15 layers, head size 24), random weights, 2 x 3 s: encoder output
+    against the oracle and exact tokens."""
+    from k2transducerasr_amd import Model
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    from oracle import Oracle
+    from parity import ACT_TOL, assert_tokens_match
+    p = str(tmp_path_factory.mktemp("z1en") / "z1en_off.k2w")
+    write_synthetic_model(p, "zipformer-en")
+    hip, ora = Model(p, 0), Oracle(p)
+    us = [synth_utterance(120 + u, 3.0) for u in range(2)]
+    x = ora.pad_sequence([ora.fbank(u) for u in us]).reshape(2, -1, 80)
+    enc = ora.encoder(x)
+    np.testing.assert_allclose(hip.encoder_proj(x), enc, atol=5 * ACT_TOL, rtol=0)
+    want, mg = ora.greedy_batch(enc, want_margins=True)
+    assert_tokens_match(hip.offline_greedy_from_samples(us), want, mg, what="zipformer-en offline")
