@@ -659,7 +659,8 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     const bool skinny_ok = g_forced_cfg < 0 && !no_skinny && plain && !a.mul && ((a.N <= 96 && a.M >= 512) || few_tiles);
     if (skinny_ok) {
         if (a.N <= 48) hipLaunchKernelGGL(gemm_f32_mfma_skinny<3>, dim3(cdiv(a.M, 16), 1), dim3(256), 0, ctx.stream, b);
-        else if (a.K >= 1024 && a.K % 128 == 0 && (long long)cdiv(a.M, 16) * cdiv(a.N, 96) <= 384)
+        else if (a.K % 128 == 0 && ((a.K >= 1024 && (long long)cdiv(a.M, 16) * cdiv(a.N, 96) <= 384) ||
+                                    (a.K >= 512 && (long long)cdiv(a.M, 16) * cdiv(a.N, 96) <= 128)))
             hipLaunchKernelGGL((gemm_f32_mfma_skinny<6, 8>), dim3(cdiv(a.M, 16), cdiv(a.N, 96)), dim3(512), 0, ctx.stream, b);
         else hipLaunchKernelGGL(gemm_f32_mfma_skinny<6>, dim3(cdiv(a.M, 16), cdiv(a.N, 96)), dim3(256), 0, ctx.stream, b);
         K2_HIP(hipGetLastError());
