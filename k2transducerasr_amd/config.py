@@ -317,6 +317,8 @@ LSTM_PRESETS = {
 CONFORMER_PRESETS = {
     # BASELINE.json configs[4]: conformer-zh (wenetspeech char model), 12 x (512, 2048, 8 heads, k=31)
     "conformer-zh": dict(vocab_size=5537),
+    # the same architecture as a streaming export (OnlineProjOfConformer): chunks of 16 frames at 25 Hz, 64 frames of left context
+    "conformer-streaming-zh": dict(vocab_size=5537, streaming=True, chunk_size=16, left_context=64),
     # parity-test model: odd head size, small kernel, decoder conv with groups = 1
     "conformer-streaming-tiny-test": dict(encoder_dim=64, num_encoder_layers=2, feedforward_dim=160, num_heads=4, cnn_module_kernel=7,
                                           joiner_dim=512, decoder_dim=64, vocab_size=41, streaming=True, chunk_size=8, left_context=16),

@@ -26,6 +26,7 @@ BLANK_BIAS = {
     "zipformer2-streaming-zh": 3.0,
     "zipformer2-streaming-tiny-test": 1.0,
     "conformer-zh": 2.615,
+    "conformer-streaming-zh": 2.615,
     "lstm-en": 3.0,
     "lstm-tiny-test": 2.0,
     "lstm-tiny-split-test": 2.0,
