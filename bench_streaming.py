@@ -23,6 +23,10 @@ def main():
     ap.add_argument("--preset", default="zipformer2-streaming-zh")
     ap.add_argument("--check", type=int, default=0, help="verify the first K streams against the CPU oracle")
     args = ap.parse_args()
+    if args.check and "conformer" in args.preset:
+        raise SystemExit("--check decodes each stream alone on the oracle; the streaming conformer's processed_lens quirk "
+                         "(OnlineProjOfConformer.cs:229: it becomes the batch size) makes that a different computation -- see "
+                         "tests/test_online_gpu.py::test_streaming_random_churn for the batched comparison")
     import k2transducerasr_amd as pkg
     from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
 
@@ -91,10 +95,6 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
     }
-    if args.check and "conformer" in args.preset:
-        raise SystemExit("--check decodes each stream alone on the oracle; the streaming conformer's processed_lens quirk "
-                         "(OnlineProjOfConformer.cs:229: it becomes the batch size) makes that a different computation -- see "
-                         "tests/test_online_gpu.py::test_streaming_random_churn for the batched comparison")
     if args.check:
         from oracle.online import OnlineOracle
         ora = OnlineOracle(weights)
