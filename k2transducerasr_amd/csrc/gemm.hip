@@ -672,7 +672,10 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     if (dma_ok && g_use_dma && g_forced_cfg < 0 && a.nb0 * a.nb1 > 1 && a.M <= 64) {
         // a handful of rows against many layers' weight matrices (LSTM wavefront): a weight-streaming problem -- 64x64 tiles, three
         // 16 KB stages in flight per workgroup
-        launch_dma<32, 64, 32, 32, 4>(ctx, b);
+        // enough workgroups to keep ~3 per CU streaming (bytes in flight are what sets the rate): 32-column tiles when 64-column
+        // tiles would give fewer than ~600
+        if ((long long)cdiv(a.N, 64) * a.nb0 * a.nb1 < 600) launch_dma<32, 32, 32, 32, 4>(ctx, b);
+        else launch_dma<32, 64, 32, 32, 4>(ctx, b);
         K2_HIP(hipGetLastError());
         if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 16;
         if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));

@@ -48,37 +48,49 @@ __global__ void k_lstm_add_frame(const float* __restrict__ Y, long long SY, cons
     h[i] = hv;
     x1[i] = Y[(long long)(lo + z) * SY + ((long long)b * T + t) * D + d] + hv;
 }
-// one wave per row: x2 = x1 + b2 + sum of the S split-K partials of feed_forward.4; Y[l+1][frame] = BasicNorm(x2)
+// one wave per row: x2 = x1 + b2 + sum of the S split-K partials of feed_forward.4; Y[l+1][frame] = BasicNorm(x2).  float4 per lane,
+// every load of the row issued before the first use (D <= 1024: at most 4 float4 per lane, S <= 4 partials)
 __global__ __launch_bounds__(256) void k_lstm_norm_frame(const float* __restrict__ x1, const float* __restrict__ fp, long long pstride, int S,
                                                          const float* __restrict__ b2_0, const float* __restrict__ eps0, long long lstride,
                                                          float* __restrict__ Y, long long SY, int n, int B, int T, int D, int lo, int s) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= n * B) return;
-    const int b = r % B, z = r / B, t = s - lo - z;
-    const float* b2 = b2_0 + (long long)(lo + z) * lstride;
-    float v[16];  // D <= 1024
+    const int b = r % B, z = r / B, t = s - lo - z, nq = D >> 2;
+    const float4* b2 = reinterpret_cast<const float4*>(b2_0 + (long long)(lo + z) * lstride);
+    const float4* xr = reinterpret_cast<const float4*>(x1 + (long long)r * D);
+    float4 pv[4][4], xv[4], bv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int q = lane + 64 * k;
+        if (q < nq) {
+            xv[k] = xr[q];
+            bv[k] = b2[q];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (u < S) pv[k][u] = reinterpret_cast<const float4*>(fp + (long long)u * pstride + (long long)r * D)[q];
+        }
+    }
+    float4 v[4];
     float ss = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int d = lane + 64 * k;
-        v[k] = 0.f;
-        if (d < D) {
-            const long long i = (long long)r * D + d;
-            float a = fp[i];
-            for (int q = 1; q < S; q++) a += fp[(long long)q * pstride + i];
-            v[k] = (a + b2[d]) + x1[i];
-            ss += v[k] * v[k];
+    for (int k = 0; k < 4; k++) {
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane + 64 * k < nq) {
+            float4 a = pv[k][0];
+#pragma unroll
+            for (int u = 1; u < 4; u++)
+                if (u < S) { a.x += pv[k][u].x; a.y += pv[k][u].y; a.z += pv[k][u].z; a.w += pv[k][u].w; }
+            v[k] = make_float4((a.x + bv[k].x) + xv[k].x, (a.y + bv[k].y) + xv[k].y, (a.z + bv[k].z) + xv[k].z, (a.w + bv[k].w) + xv[k].w);
+            ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     const float sc = 1.0f / sqrtf(ss / (float)D + expf(eps0[(long long)(lo + z) * lstride]));
-    float* yr = Y + (long long)(lo + z + 1) * SY + ((long long)b * T + t) * D;
+    float4* yr = reinterpret_cast<float4*>(Y + (long long)(lo + z + 1) * SY + ((long long)b * T + t) * D);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int d = lane + 64 * k;
-        if (d < D) yr[d] = v[k] * sc;
-    }
+    for (int k = 0; k < 4; k++)
+        if (lane + 64 * k < nq) yr[lane + 64 * k] = make_float4(v[k].x * sc, v[k].y * sc, v[k].z * sc, v[k].w * sc);
 }
 
 __global__ void k_add_inplace(float* __restrict__ a, const float* __restrict__ b, long long n4) {
@@ -124,7 +136,7 @@ void lstm_add_frame(const Ctx& ctx, const float* Y, long long SY, const float* h
 }
 void lstm_norm_frame(const Ctx& ctx, const float* x1, const float* fp, long long pstride, int S, const float* b2_0, const float* eps0,
                      long long lstride, float* Y, long long SY, int n, int B, int T, int D, int lo, int s) {
-    K2_REQUIRE(D <= 1024, "lstm: d_model %d unsupported (<= 1024)", D);
+    K2_REQUIRE(D <= 1024 && D % 4 == 0 && S <= 4 && pstride % 4 == 0, "lstm: d_model %d / %d partials unsupported", D, S);
     if (ctx.dry) return;
     hipLaunchKernelGGL(k_lstm_norm_frame, dim3(cdiv(n * B, 4)), dim3(256), 0, ctx.stream, x1, fp, pstride, S, b2_0, eps0, lstride, Y, SY, n, B, T,
                        D, lo, s);
