@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU): a longer seeded sweep than tests/test_parity_gpu.py::test_random_ragged_batches_match_oracle, over every offline
+model type: random batch sizes and ragged lengths, fused samples -> tokens on the GPU against the CPU oracle (tests/parity.py
+criteria).  usage: soak_offline.py [cases-per-model] [seed]"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import k2transducerasr_amd as pkg  # noqa: E402
+from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model  # noqa: E402
+from oracle import Oracle  # noqa: E402
+from parity import assert_tokens_match  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+presets = ["zipformer2-tiny-test", "zipformer-tiny-test", "conformer-tiny-test", "lstm-tiny-test", "lstm-tiny-split-test"]
+tmp = tempfile.mkdtemp()
+lens_pool = [400, 401, 559, 560, 1999, 3200, 4801, 8000, 12345, 16000, 20001, 31999]
+for preset in presets:
+    path = os.path.join(tmp, preset + ".k2w")
+    write_synthetic_model(path, preset)
+    hip, ora = pkg.Model(path, 0), Oracle(path)
+    rng = np.random.default_rng(seed)
+    exact = tot = skipped = 0
+    for case in range(cases):
+        B = int(rng.integers(1, 9))
+        ns = [int(rng.choice(lens_pool)) if rng.random() < 0.5 else int(rng.integers(400, 40000)) for _ in range(B)]
+        utts = [synth_utterance(5000 + 16 * case + b, n / 16000.0)[:n] for b, n in enumerate(ns)]
+        feats = [ora.fbank(u) for u in utts]
+        x = ora.pad_sequence(feats).reshape(B, -1, 80)
+        if ora.encoder_out_frames(x.shape[1]) <= 0:
+            skipped += 1
+            continue
+        want = ora.recognize_batch(feats)
+        _, mg = ora.greedy_batch(ora.encoder(x), want_margins=True)
+        got = hip.offline_greedy_from_samples(utts)
+        exact += assert_tokens_match(got, want, mg, what=f"{preset} case {case} (B={B}, samples={ns})")
+        tot += B
+    print(f"{preset}: {cases - skipped} batches, {exact}/{tot} streams token-exact (the rest diverge on an oracle near-tie)", flush=True)
+print("soak ok")
