@@ -70,6 +70,48 @@ __global__ __launch_bounds__(BT) void k_beam_step(BeamState s, const float* __re
     const int lane = tid & 63, wave = tid >> 6;
     __shared__ float candv[kMaxBeam * kMaxBeam];
     __shared__ int candi[kMaxBeam * kMaxBeam];
+    if (V <= 64 * 16) {
+        // the hypothesis' logits, V / 64 per lane, are read ONCE into registers: the max, the sum and the `want` selection rounds below
+        // went through global memory 2 + want times before (a chain of dependent loads that made this step 20 us)
+        for (int k = wave; k < nA; k += BT / 64) {
+            const float* l = lg + (long long)k * V;
+            float lv[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) lv[i] = lane + 64 * i < V ? l[lane + 64 * i] : -INFINITY;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; i++) mx = fmaxf(mx, lv[i]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                if (lane + 64 * i < V) sm += expf(lv[i] - mx);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+            const float lse = logf(sm), lpk = s.lp[b * K + k];
+            unsigned used = 0;  // bit i: this lane's element i was already selected
+            for (int r = 0; r < want; r++) {
+                float bv = -INFINITY;
+                int bi = -1;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int v = lane + 64 * i;
+                    if (v >= V || (used >> i & 1)) continue;
+                    const float sc = (lv[i] - mx - lse) + lpk;  // the oracle's order of operations
+                    if (bi < 0 || sc > bv) { bv = sc; bi = v; }   // ascending v per lane: first maximum wins
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(bv, o);
+                    const int oi = __shfl_xor(bi, o);
+                    if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+                }
+                if (bi >= 0 && (bi & 63) == lane) used |= 1u << (bi >> 6);
+                if (lane == 0) { candv[k * kMaxBeam + r] = bv; candi[k * kMaxBeam + r] = bi < 0 ? -1 : k * V + bi; }
+            }
+        }
+    } else
     for (int k = wave; k < nA; k += BT / 64) {
         const float* l = lg + (long long)k * V;
         float mx = -INFINITY;
