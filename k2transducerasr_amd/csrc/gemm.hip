@@ -681,7 +681,8 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
         return;
     }
-    if (dma_ok && a.nb0 * a.nb1 == 1 && g_use_dma && (cfg == 5 || cfg == 0 || (cfg >= 7 && cfg <= 11))) {
+    // (batched launches too -- the Conformer's per-(head, stream) score products -- as long as the tile choice is one of the DMA kernel's)
+    if (dma_ok && g_use_dma && (cfg == 5 || cfg == 0 || (cfg >= 7 && cfg <= 11))) {
         if (cfg == 11) launch_dma<64, 96, 32, 32, 2>(ctx, b);        // 64x96 tiles (6 waves): N % 96 == 0 outputs that 128x64 quantises badly
         else if (cfg == 9) launch_dma<64, 64, 32, 32, 2>(ctx, b);    // tuning: 64x64 tiles, 2 stages
         else if (cfg == 10) launch_dma<64, 64, 32, 32, 3>(ctx, b);   // tuning: 64x64 tiles, 3 stages
