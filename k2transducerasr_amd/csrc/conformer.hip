@@ -150,6 +150,130 @@ __global__ void k_dwconv_valid_dswish(const float* __restrict__ cat, const float
     reinterpret_cast<float4*>(y)[i] = make_float4(ds(s.x), ds(s.y), ds(s.z), ds(s.w));
 }
 
+
+// ---------------------------------------------------------------------------------------
+// RelPositionMultiheadAttention scores + softmax, fused (offline Conformer): for one (stream, head) and a strip of 32 query rows
+//   s[i,j] = (q_i + u).k_j + (q_i + v).p[T-1-i+j]          w[i,:] = softmax_j s[i,:]
+// without the two [T, T] / [T, 2T-1] score tensors of the GEMM form (145 + 290 MB per layer at T = 753, written and re-read).
+// Eight waves share the 32 x T strip in LDS; a wave takes key tiles of 32: the content term is 32x32x2 f32 MFMAs as in the Zipformer
+// kernel (K = dk); the positional term of the tile only involves the 63 table rows n = base .. base + 62 (base = T-1-i0-31+j0), so
+// it is two more MFMA tiles G[32, 64] = (q+v) . p[base ..]^T whose elements are ADDED into the strip skewed -- G[r, col] belongs to key
+// j0 + col - 31 + r -- icefall's rel-shift as an LDS scatter (each strip element receives exactly one of them, so the sum is exact and
+// needs no staging tile: the strip is the only LDS, which is what lets eight waves share it).  Then the row softmax and one
+// coalesced write.
+// NG = dk / 8.
+// ---------------------------------------------------------------------------------------
+typedef float cf32x16 __attribute__((ext_vector_type(16)));
+constexpr int CR = 32;       // rows per strip
+
+template <int NG>
+__global__ __launch_bounds__(512) void k_conformer_scores_softmax(const float* __restrict__ qu, const float* __restrict__ qv,
+                                                                  const float* __restrict__ kmat, int ldk, const float* __restrict__ pp,
+                                                                  float* __restrict__ aw, int B, int H, int T, int Tp, int D,
+                                                                  int lds_stride) {
+    constexpr int DK = 8 * NG;
+    extern __shared__ __attribute__((aligned(16))) float csm[];
+    float* S = csm;                                   // [CR][lds_stride]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int i0 = blockIdx.x * CR, b = blockIdx.y, h = blockIdx.z, NP = 2 * T - 1;
+    const long long rowbase = (long long)b * T;
+    // A operands: this lane's query row (strip row li), k chunks 8g + 4lh .. +3
+    float4 fu[NG], fv[NG];
+    {
+        const int row = i0 + li;
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            fu[g] = fv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < T) {
+                fu[g] = *reinterpret_cast<const float4*>(qu + (rowbase + row) * D + h * DK + 8 * g + 4 * lh);
+                fv[g] = *reinterpret_cast<const float4*>(qv + (rowbase + row) * D + h * DK + 8 * g + 4 * lh);
+            }
+        }
+    }
+    const int njt = (T + 31) / 32;
+    // B operands of a key tile: the keys' rows and the two runs of 32 table rows
+    float4 fk[NG], p0[NG], p1[NG];
+    auto load_tile = [&](int jt, float4* k_, float4* a_, float4* b_) {
+        const int j0 = jt * 32, base = T - 1 - i0 - 31 + j0;
+        const int jr = min(j0 + li, T - 1);
+        const int n0 = min(max(base + li, 0), NP - 1), n1 = min(max(base + 32 + li, 0), NP - 1);  // out-of-table rows only meet masked entries
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            k_[g] = *reinterpret_cast<const float4*>(kmat + (rowbase + jr) * ldk + h * DK + 8 * g + 4 * lh);
+            a_[g] = *reinterpret_cast<const float4*>(pp + (long long)n0 * D + h * DK + 8 * g + 4 * lh);
+            b_[g] = *reinterpret_cast<const float4*>(pp + (long long)n1 * D + h * DK + 8 * g + 4 * lh);
+        }
+    };
+    for (int jt = wave; jt < njt; jt += 8) {
+        const int j0 = jt * 32, j = j0 + li;
+        load_tile(jt, fk, p0, p1);
+        cf32x16 acc, g0, g1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = g0[r] = g1[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; g++) {   // content term, and the positional term against table rows base + li / base + 32 + li
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[g].x, fk[g].x, acc, 0, 0, 0);
+            g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].x, p0[g].x, g0, 0, 0, 0);
+            g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].x, p1[g].x, g1, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[g].y, fk[g].y, acc, 0, 0, 0);
+            g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].y, p0[g].y, g0, 0, 0, 0);
+            g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].y, p1[g].y, g1, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[g].z, fk[g].z, acc, 0, 0, 0);
+            g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].z, p0[g].z, g0, 0, 0, 0);
+            g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].z, p1[g].z, g1, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[g].w, fk[g].w, acc, 0, 0, 0);
+            g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].w, p0[g].w, g0, 0, 0, 0);
+            g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].w, p1[g].w, g1, 0, 0, 0);
+        }
+        // C layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  The tile's 32 strip columns belong to this
+        // wave alone; LDS operations of one wave complete in order.
+        if (j < T) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) S[((r & 3) + 8 * (r >> 2) + 4 * lh) * lds_stride + j] = acc[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int c0 = li - 31 + rl, c1 = li + 1 + rl;   // strip column (within the tile) fed by G[rl][li] / G[rl][32 + li]
+            if (c0 >= 0 && j0 + c0 < T) S[rl * lds_stride + j0 + c0] += g0[r];
+            if (c1 < 32 && j0 + c1 < T) S[rl * lds_stride + j0 + c1] += g1[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // row softmax: wave w owns rows 4w .. 4w+3
+    float* out = aw + (((long long)b * H + h) * T) * Tp;
+    for (int rr = 0; rr < 4; rr++) {
+        const int rl = wave * 4 + rr, i = i0 + rl;
+        if (i >= T) break;
+        float* srow = S + rl * lds_stride;
+        float mx = -INFINITY;
+        for (int jj = lane; jj < T; jj += 64) mx = fmaxf(mx, srow[jj]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int jj = lane; jj < T; jj += 64) {
+            const float e = __expf(srow[jj] - mx);
+            srow[jj] = e;
+            sum += e;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.0f / sum;
+        float* orow = out + (long long)i * Tp;
+        for (int j4 = lane * 4; j4 < Tp; j4 += 256) {
+            float4 v;
+            v.x = (j4 + 0 < T) ? srow[j4 + 0] * inv : 0.f;
+            v.y = (j4 + 1 < T) ? srow[j4 + 1] * inv : 0.f;
+            v.z = (j4 + 2 < T) ? srow[j4 + 2] * inv : 0.f;
+            v.w = (j4 + 3 < T) ? srow[j4 + 3] * inv : 0.f;
+            *reinterpret_cast<float4*>(orow + j4) = v;
+        }
+    }
+}
+
 }  // namespace
 
 void conformer_softmax_shift_stream(const Ctx& ctx, float* ac, const float* bd, const long long* plen, int B, int H, int Tc, int left,
@@ -194,6 +318,35 @@ void conformer_softmax_shift(const Ctx& ctx, float* ac, const float* bd, int Z, 
     }
     hipLaunchKernelGGL(k_conformer_softmax_shift, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx.stream, ac, bd, rows, T, Tp, NPp);
     K2_HIP(hipGetLastError());
+}
+
+template <int NG>
+static bool conformer_scores_launch(const Ctx& ctx, const float* qu, const float* qv, const float* kmat, int ldk, const float* pp, float* aw, int B,
+                                    int H, int T, int Tp, int D) {
+    const int lds_stride = Tp + 4;
+    const size_t lds = sizeof(float) * (size_t)CR * lds_stride;
+    if (lds > 156 * 1024) return false;  // longer utterances: the GEMM form
+    static LdsAttrOnce lds_attr;
+    lds_attr.ensure(k_conformer_scores_softmax<NG>, 156 * 1024);
+    hipLaunchKernelGGL(k_conformer_scores_softmax<NG>, dim3(cdiv(T, CR), B, H), dim3(512), lds, ctx.stream, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp,
+                       D, lds_stride);
+    K2_HIP(hipGetLastError());
+    return true;
+}
+
+// fused scores + softmax of the offline Conformer attention; returns false (nothing launched) when the shape does not fit
+bool conformer_scores_softmax(const Ctx& ctx, const float* qu, const float* qv, const float* kmat, int ldk, const float* pp, float* aw, int B, int H,
+                              int T, int Tp, int D) {
+    const int dk = D / H;
+    if (getenv("K2HIP_CONFORMER_GEMM_SCORES") || Tp % 4 != 0 || D % 4 != 0 || ldk % 4 != 0 || (dk != 16 && dk != 32 && dk != 64)) return false;
+    if (sizeof(float) * (size_t)CR * (Tp + 4) > 156 * 1024) return false;
+    ctx.add_flops(0.0, 2.0 * dk * (double)T * (3.0 * T) * B * H, 0);
+    if (ctx.dry) return true;
+    switch (dk) {
+        case 64: return conformer_scores_launch<8>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
+        case 32: return conformer_scores_launch<4>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
+        default: return conformer_scores_launch<2>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
+    }
 }
 
 }  // namespace k2hip

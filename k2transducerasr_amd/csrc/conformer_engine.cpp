@@ -106,23 +106,27 @@ void Engine::conformer_layer(const Ctx& c, int li, float* x, const float* pe, in
         conformer_qprep(c, qkv, w("self_attn.pos_bias_u"), w("self_attn.pos_bias_v"), qu, qv, M, D, 1.0f / sqrtf((float)dk));
         float* ac = ar.take<float>((int64_t)B * H * T * Tp);
         float* bd = ar.take<float>((int64_t)B * H * T * NPp);
-        {   // ac[b,h] = qu[b,:,h] . k[b,:,h]^T      z = h + H*b
-            GemmArgs g;
-            g.A = qu; g.lda = D; g.sA0 = dk; g.sA1 = (long long)T * D;
-            g.W = qkv + D; g.ldw = 3 * D; g.sW0 = dk; g.sW1 = (long long)T * 3 * D;
-            g.C = ac; g.ldc = Tp; g.sC0 = (long long)T * Tp; g.sC1 = (long long)H * T * Tp;
-            g.M = T; g.N = T; g.K = dk; g.nb0 = H; g.nb1 = B;
-            gemm(c, g);
+        // scores + softmax in one kernel (no [T,T] / [T,2T-1] score tensors); the GEMM form below is the fallback for shapes it does
+        // not cover (very long utterances, unusual head sizes)
+        if (!conformer_scores_softmax(c, qu, qv, qkv + D, 3 * D, pp, ac, B, H, T, Tp, D)) {
+            {   // ac[b,h] = qu[b,:,h] . k[b,:,h]^T      z = h + H*b
+                GemmArgs g;
+                g.A = qu; g.lda = D; g.sA0 = dk; g.sA1 = (long long)T * D;
+                g.W = qkv + D; g.ldw = 3 * D; g.sW0 = dk; g.sW1 = (long long)T * 3 * D;
+                g.C = ac; g.ldc = Tp; g.sC0 = (long long)T * Tp; g.sC1 = (long long)H * T * Tp;
+                g.M = T; g.N = T; g.K = dk; g.nb0 = H; g.nb1 = B;
+                gemm(c, g);
+            }
+            {   // bd[b,h] = qv[b,:,h] . p[:,h]^T
+                GemmArgs g;
+                g.A = qv; g.lda = D; g.sA0 = dk; g.sA1 = (long long)T * D;
+                g.W = pp; g.ldw = D; g.sW0 = dk; g.sW1 = 0;
+                g.C = bd; g.ldc = NPp; g.sC0 = (long long)T * NPp; g.sC1 = (long long)H * T * NPp;
+                g.M = T; g.N = NP; g.K = dk; g.nb0 = H; g.nb1 = B;
+                gemm(c, g);
+            }
+            conformer_softmax_shift(c, ac, bd, B * H, T, Tp, NPp);
         }
-        {   // bd[b,h] = qv[b,:,h] . p[:,h]^T
-            GemmArgs g;
-            g.A = qv; g.lda = D; g.sA0 = dk; g.sA1 = (long long)T * D;
-            g.W = pp; g.ldw = D; g.sW0 = dk; g.sW1 = 0;
-            g.C = bd; g.ldc = NPp; g.sC0 = (long long)T * NPp; g.sC1 = (long long)H * T * NPp;
-            g.M = T; g.N = NP; g.K = dk; g.nb0 = H; g.nb1 = B;
-            gemm(c, g);
-        }
-        conformer_softmax_shift(c, ac, bd, B * H, T, Tp, NPp);
         float* ctxv = qu;  // [M, D], column block h
         {   // ctxv[b,:,h] = w[b,h] . v[b,:,h]
             GemmArgs g;

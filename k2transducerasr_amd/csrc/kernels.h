@@ -168,6 +168,10 @@ void slice_rows(const Ctx& ctx, const float* in, float* out, int B, int Tin, int
 void dwconv_valid_dswish(const Ctx& ctx, const float* cat, const float* w_kd, const float* bias, float* y, int B, int Tc, int D, int K);
 //   ac[z][i][j] (ld Tp) <- softmax_j(ac[z][i][j] + bd[z][i][T-1-i+j]) (rel_shift in gather form); pad columns zeroed
 void conformer_softmax_shift(const Ctx& ctx, float* ac, const float* bd, int Z, int T, int Tp, int NPp);
+// fused form: aw[b*H+h][i][:] = softmax_j((q+u)_i.k_j + (q+v)_i.p[T-1-i+j]) straight from qu / qv [B*T, D], k rows (row stride ldk) and the
+// projected positional table pp [2T-1, D]; false = shape not covered (caller takes the GEMM + conformer_softmax_shift form)
+bool conformer_scores_softmax(const Ctx& ctx, const float* qu, const float* qv, const float* kmat, int ldk, const float* pp, float* aw, int B, int H,
+                              int T, int Tp, int D);
 void downsample(const Ctx& ctx, const float* x, const float* bias, float* y, int B, int T, int D, int ds);
 void upsample_combine(const Ctx& ctx, const float* orig, const float* xd, const float* scale, float* y, int B, int T,
                       int Td, int D, int ds);
