@@ -178,3 +178,28 @@ def test_conformer_shortest_inputs(hip_conformer, oracle_conformer):
     from k2transducerasr_amd import K2HipError
     with pytest.raises(K2HipError):
         hip_conformer.encoder_proj(np.zeros((1, 6, 80), np.float32))
+
+
+def test_fused_and_gemm_attention_scores_agree(tmp_path_factory, utts):
+    """K2HIP_CONFORMER_GEMM_SCORES selects the two-GEMM + gather form of the attention scores; both forms against the oracle and
+    against each other, for lengths that are / are not multiples of the 32-row strip."""
+    import os
+    from k2transducerasr_amd import Model
+    from k2transducerasr_amd.synth import write_synthetic_model
+    from oracle import Oracle
+    from parity import ACT_TOL
+    p = str(tmp_path_factory.mktemp("confs") / "conf.k2w")
+    write_synthetic_model(p, "conformer-tiny-test")
+    hip, ora = Model(p, 0), Oracle(p)
+    rng = np.random.default_rng(5)
+    for T in (40, 135, 263):
+        x = rng.standard_normal((3, T, 80)).astype(np.float32)
+        want = ora.encoder(x)
+        fused = hip.encoder_proj(x)
+        os.environ["K2HIP_CONFORMER_GEMM_SCORES"] = "1"
+        try:
+            gemm = hip.encoder_proj(x)
+        finally:
+            del os.environ["K2HIP_CONFORMER_GEMM_SCORES"]
+        np.testing.assert_allclose(fused, want, atol=ACT_TOL, rtol=0, err_msg=f"fused T={T}")
+        np.testing.assert_allclose(gemm, want, atol=ACT_TOL, rtol=0, err_msg=f"gemm T={T}")
