@@ -243,33 +243,36 @@ __global__ __launch_bounds__(512) void k_conformer_scores_softmax(const float* _
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    // row softmax: wave w owns rows 4w .. 4w+3
+    // row softmax: wave w owns rows 4w .. 4w+3; a row's T scores are read ONCE into registers (T <= 64 * 20)
     float* out = aw + (((long long)b * H + h) * T) * Tp;
     for (int rr = 0; rr < 4; rr++) {
         const int rl = wave * 4 + rr, i = i0 + rl;
         if (i >= T) break;
-        float* srow = S + rl * lds_stride;
+        const float* srow = S + rl * lds_stride;
+        float v[20];
         float mx = -INFINITY;
-        for (int jj = lane; jj < T; jj += 64) mx = fmaxf(mx, srow[jj]);
+#pragma unroll
+        for (int u = 0; u < 20; u++) {
+            const int jj = lane + 64 * u;
+            v[u] = jj < T ? srow[jj] : -INFINITY;
+            mx = fmaxf(mx, v[u]);
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         float sum = 0.f;
-        for (int jj = lane; jj < T; jj += 64) {
-            const float e = __expf(srow[jj] - mx);
-            srow[jj] = e;
-            sum += e;
+#pragma unroll
+        for (int u = 0; u < 20; u++) {
+            v[u] = lane + 64 * u < T ? __expf(v[u] - mx) : 0.f;
+            sum += v[u];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
         const float inv = 1.0f / sum;
         float* orow = out + (long long)i * Tp;
-        for (int j4 = lane * 4; j4 < Tp; j4 += 256) {
-            float4 v;
-            v.x = (j4 + 0 < T) ? srow[j4 + 0] * inv : 0.f;
-            v.y = (j4 + 1 < T) ? srow[j4 + 1] * inv : 0.f;
-            v.z = (j4 + 2 < T) ? srow[j4 + 2] * inv : 0.f;
-            v.w = (j4 + 3 < T) ? srow[j4 + 3] * inv : 0.f;
-            *reinterpret_cast<float4*>(orow + j4) = v;
+#pragma unroll
+        for (int u = 0; u < 20; u++) {
+            const int jj = lane + 64 * u;
+            if (jj < Tp) orow[jj] = v[u] * inv;   // pad columns [T, Tp) get 0
         }
     }
 }
@@ -339,7 +342,7 @@ bool conformer_scores_softmax(const Ctx& ctx, const float* qu, const float* qv, 
                               int T, int Tp, int D) {
     const int dk = D / H;
     if (getenv("K2HIP_CONFORMER_GEMM_SCORES") || Tp % 4 != 0 || D % 4 != 0 || ldk % 4 != 0 || (dk != 16 && dk != 32 && dk != 64)) return false;
-    if (sizeof(float) * (size_t)CR * (Tp + 4) > 156 * 1024) return false;
+    if (sizeof(float) * (size_t)CR * (Tp + 4) > 156 * 1024 || Tp > 64 * 20) return false;
     ctx.add_flops(0.0, 2.0 * dk * (double)T * (3.0 * T) * B * H, 0);
     if (ctx.dry) return true;
     switch (dk) {
