@@ -157,13 +157,17 @@ __global__ __launch_bounds__(256) void k_attn_stream(const float* __restrict__ q
 
 // ConvolutionModule.streaming_forward core: GLU -> ChunkCausalDepthwiseConv1d.streaming_forward -> SwooshR
 //   x2: [B*Tc, 2D]; cache [D][pad] per stream; wc [D][Kc], ww [D][K], sc [2][D][K]; y: [B*Tc, D]
+// KT = the kernel size as a compile-time constant (31 / 15 / 7; 0 = any): the channel's causal and chunk-wise taps are then held in
+// registers for the whole chunk (read per frame and tap from memory they were a chain of ~(K + Kc) Tc dependent loads per lane).
+template <int KT>
 __global__ __launch_bounds__(64) void k_glu_causal_conv(const float* __restrict__ x2, float* __restrict__ pool,
                                                         long long slot_stride, long long off, const int* __restrict__ slots,
                                                         const float* __restrict__ wc, const float* __restrict__ bc,
                                                         const float* __restrict__ ww, const float* __restrict__ bw,
                                                         const float* __restrict__ sc, float* __restrict__ y, int B, int Tc,
-                                                        int D, int K) {
+                                                        int D, int Krt) {
     extern __shared__ float cat[];  // [(pad + Tc)][64]
+    const int K = KT ? KT : Krt;
     const int c = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y, lc = threadIdx.x;
     const int pad = K >> 1, Kc = (K + 1) >> 1;
     if (c >= D) return;  // whole trailing lanes only; no barrier below depends on them (each lane uses its own column)
@@ -175,13 +179,30 @@ __global__ __launch_bounds__(64) void k_glu_causal_conv(const float* __restrict_
     }
     for (int r = 0; r < pad; r++) cache[r] = cat[(Tc + r) * 64 + lc];  // cache = cat[..., -pad:]
     const float bcv = bc[c], bwv = bw[c];
+    constexpr int KR = KT ? KT : 1, KCR = KT ? (KT + 1) / 2 : 1;
+    float wcr[KCR], wwr[KR];
+    if (KT) {
+#pragma unroll
+        for (int k = 0; k < KCR; k++) wcr[k] = wc[c * KCR + k];
+#pragma unroll
+        for (int k = 0; k < KR; k++) wwr[k] = ww[c * KR + k];
+    }
     for (int t = 0; t < Tc; t++) {
-        float xc = bcv;
-        for (int k = 0; k < Kc; k++) xc += wc[c * Kc + k] * cat[(t + k) * 64 + lc];
-        float xw = bwv;
-        for (int k = 0; k < K; k++) {
-            int tt = t + k - pad;
-            if (tt >= 0 && tt < Tc) xw += ww[c * K + k] * cat[(pad + tt) * 64 + lc];
+        float xc = bcv, xw = bwv;
+        if (KT) {
+#pragma unroll
+            for (int k = 0; k < KCR; k++) xc += wcr[k] * cat[(t + k) * 64 + lc];
+#pragma unroll
+            for (int k = 0; k < KR; k++) {
+                const int tt = t + k - (KR >> 1);
+                if (tt >= 0 && tt < Tc) xw += wwr[k] * cat[((KR >> 1) + tt) * 64 + lc];
+            }
+        } else {
+            for (int k = 0; k < Kc; k++) xc += wc[c * Kc + k] * cat[(t + k) * 64 + lc];
+            for (int k = 0; k < K; k++) {
+                int tt = t + k - pad;
+                if (tt >= 0 && tt < Tc) xw += ww[c * K + k] * cat[(pad + tt) * 64 + lc];
+            }
         }
         float le, re;
         if (Tc < K) {
@@ -250,8 +271,15 @@ void glu_causal_conv(const Ctx& ctx, const float* x2, float* pool, long long slo
     ctx.add_flops(0.0, 2.0 * B * Tc * (double)D * (K + (K + 1) / 2), 0);
     if (ctx.dry) return;
     size_t lds = sizeof(float) * (K / 2 + Tc) * 64;
-    hipLaunchKernelGGL(k_glu_causal_conv, dim3(cdiv(D, 64), B), dim3(64), lds, ctx.stream, x2, pool, slot_stride, off, slots, wc, bc,
-                       ww, bw, sc, y, B, Tc, D, K);
+    const dim3 grid(cdiv(D, 64), B);
+#define K2_GCC(KT) hipLaunchKernelGGL(k_glu_causal_conv<KT>, grid, dim3(64), lds, ctx.stream, x2, pool, slot_stride, off, slots, wc, bc, ww, bw, sc, y, B, Tc, D, K)
+    switch (K) {
+        case 31: K2_GCC(31); break;
+        case 15: K2_GCC(15); break;
+        case 7: K2_GCC(7); break;
+        default: K2_GCC(0); break;
+    }
+#undef K2_GCC
     K2_HIP(hipGetLastError());
 }
 void zero_floats(const Ctx& ctx, float* p, long long n) {
