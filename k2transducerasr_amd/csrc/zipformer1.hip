@@ -82,11 +82,14 @@ __global__ __launch_bounds__(256) void k_z1_attn(const float* __restrict__ qkvp,
 }
 
 // ConvolutionModule.streaming_forward core: GLU -> [cache (K-1) ; chunk] -> depthwise K (valid) + bias -> DoubleSwish
-//   x2 [B*Tc, 2D]; cache [D][K-1] per stream; w [D][K]; y [B*Tc, D]
+//   x2 [B*Tc, 2D]; cache [D][K-1] per stream; w [D][K]; y [B*Tc, D].  KT = kernel size as a compile-time constant (0 = any): the
+//   channel's taps then sit in registers for the whole chunk.
+template <int KT>
 __global__ __launch_bounds__(64) void k_z1_glu_conv(const float* __restrict__ x2, float* __restrict__ pool, long long slot_stride,
                                                     long long off, const int* __restrict__ slots, const float* __restrict__ w,
-                                                    const float* __restrict__ bias, float* __restrict__ y, int Tc, int D, int K) {
+                                                    const float* __restrict__ bias, float* __restrict__ y, int Tc, int D, int Krt) {
     extern __shared__ float cat[];  // [(K-1 + Tc)][64]
+    const int K = KT ? KT : Krt;
     const int c = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y, lc = threadIdx.x, lo = K - 1;
     if (c >= D) return;  // whole trailing lanes only; each lane touches its own LDS column, no barrier needed
     float* cache = pool + (long long)slots[b] * slot_stride + off + (long long)c * lo;
@@ -97,9 +100,20 @@ __global__ __launch_bounds__(64) void k_z1_glu_conv(const float* __restrict__ x2
     }
     for (int r = 0; r < lo; r++) cache[r] = cat[(Tc + r) * 64 + lc];  // cache = cat[..., -(K-1):]
     const float bv = bias[c];
+    constexpr int KR = KT ? KT : 1;
+    float wr[KR];
+    if (KT) {
+#pragma unroll
+        for (int k = 0; k < KR; k++) wr[k] = w[c * KR + k];
+    }
     for (int t = 0; t < Tc; t++) {
         float s = bv;
-        for (int k = 0; k < K; k++) s += w[c * K + k] * cat[(t + k) * 64 + lc];
+        if (KT) {
+#pragma unroll
+            for (int k = 0; k < KR; k++) s += wr[k] * cat[(t + k) * 64 + lc];
+        } else {
+            for (int k = 0; k < K; k++) s += w[c * K + k] * cat[(t + k) * 64 + lc];
+        }
         y[((long long)b * Tc + t) * D + c] = dswish(s);
     }
 }
@@ -257,8 +271,16 @@ void z1_glu_conv(const Ctx& ctx, const float* x2, float* pool, long long slot_st
     ctx.add_flops(0.0, 2.0 * B * Tc * (double)D * K, 0);
     if (ctx.dry) return;
     size_t lds = sizeof(float) * (K - 1 + Tc) * 64;
-    hipLaunchKernelGGL(k_z1_glu_conv, dim3(cdiv(D, 64), B), dim3(64), lds, ctx.stream, x2, pool, slot_stride, off, slots, w, bias, y, Tc,
-                       D, K);
+    const dim3 grid(cdiv(D, 64), B);
+#define K2_ZGC(KT) hipLaunchKernelGGL(k_z1_glu_conv<KT>, grid, dim3(64), lds, ctx.stream, x2, pool, slot_stride, off, slots, w, bias, y, Tc, D, K)
+    switch (K) {
+        case 31: K2_ZGC(31); break;
+        case 15: K2_ZGC(15); break;
+        case 7: K2_ZGC(7); break;
+        case 5: K2_ZGC(5); break;
+        default: K2_ZGC(0); break;
+    }
+#undef K2_ZGC
     K2_HIP(hipGetLastError());
 }
 void z1_norm_bypass(const Ctx& ctx, const float* x, const float* orig, const float* log_eps, const float* bscale, float* y, int M, int D) {
