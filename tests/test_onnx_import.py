@@ -59,7 +59,8 @@ def _scope_parts(mod: str):
     return out
 
 
-@pytest.mark.parametrize("preset", ["zipformer2-tiny-test", "conformer-tiny-test"])
+@pytest.mark.parametrize("preset", ["zipformer2-tiny-test", "conformer-tiny-test", "zipformer-tiny-test", "zipformer-streaming-tiny-test",
+                                    "lstm-tiny-test", "zipformer2-ctc-tiny-test"])
 def test_round_trip_through_onnx(tmp_path, preset):
     from k2transducerasr_amd.synth import write_synthetic_model
     src = str(tmp_path / "src.k2w")
