@@ -88,3 +88,23 @@ def test_k2w_roundtrip(tmp_path):
     assert m2 == meta
     for n, a in tensors:
         np.testing.assert_array_equal(t2[n], a)
+
+
+def test_header_is_plain_c_and_a_c_host_links(tmp_path):
+    """The boundary is a C ABI: include/k2hip.h must compile as C99 (no C++ in the signatures), and a C translation unit that calls
+    an entry point must link against libk2hip.so with nothing but the C runtime."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    hdr = os.path.join(root, "include", "k2hip.h")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    src = tmp_path / "host.c"
+    src.write_text('#include "k2hip.h"\n#include <stdio.h>\nint main(void) { printf("%s\\n", k2hip_version()); return k2hip_last_error() == 0; }\n')
+    lib = os.path.join(root, "k2transducerasr_amd")
+    exe = tmp_path / "host"
+    subprocess.run([gcc, "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), "-L", lib, "-lk2hip", "-Wl,-rpath," + lib], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, env={**os.environ, "LD_LIBRARY_PATH": lib + ":" + os.environ.get("LD_LIBRARY_PATH", "")})
+    assert out.returncode == 0 and out.stdout.strip()
