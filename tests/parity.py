@@ -1,41 +1,89 @@
 """Shared parity criteria.
 
-Integer outputs (tokens, timestamps) must be identical.  The one allowed
-exception is a frame where the oracle itself is undecided at fp32 resolution:
-if two vocabulary entries are closer than LOGIT_TOL in the oracle's logits, a
-different summation order may legally pick the other one, and everything after
-that frame follows a different decoder context.  `assert_tokens_match` accepts a
-divergence only if its first differing emission sits on such a frame.
+Integer outputs (tokens, timestamps) must be identical: `assert_tokens_match` is STRICT by default
+and fails on any difference.
+
+The north star allows fp32 logits within 1e-3, so a frame on which the oracle's own top-2 gap is
+below that resolution may legally resolve the other way under a different summation order, and
+everything after it follows a different decoder context.  A caller that wants to tolerate exactly
+that passes `allow_tie=True`; then a divergence of stream b is excused only if
+
+  * stream b's OWN margin at the frame where b first diverges is < tol, or
+  * (batch entry points) some stream's margin at the batch's first-emission frame t0 is < tol --
+    the reference re-runs the decoder for every stream there (OfflineRecognizer.cs:278-286), so a
+    tie on that single frame changes every stream's context from t0 + 1 on.
+
+Every excuse is recorded in `EXCUSED`; tests/conftest.py prints the count at the end of the session
+and fails the session if it is not zero (K2HIP_ALLOW_TIES=1 downgrades that to a report, for soak
+runs over thousands of random streams).
 """
 import numpy as np
 
 LOGIT_TOL = 1e-3   # north_star: fp32 logits within 1e-3
 ACT_TOL = 2e-4     # encoder activations (O(1) magnitude), fp32 accumulate-order noise
 
+EXCUSED = []       # (what, stream, frame, margin) of every tolerated divergence in this process
+COMPARED = [0]     # streams compared through assert_tokens_match (all of them exact unless listed above)
+
 
 def first_divergence(a, b):
+    """frame index of the first emission on which two (tokens, timestamps) results differ"""
     (ta, sa), (tb, sb) = a, b
     n = min(len(ta), len(tb))
     for i in range(n):
         if ta[i] != tb[i] or sa[i] != sb[i]:
             return min(sa[i], sb[i])
     if len(ta) != len(tb):
-        return (sa + sb)[n] if n < len(sa + sb) else None
+        rest = sa[n:] if len(sa) > n else sb[n:]
+        return rest[0] if rest else None
     return None
 
 
-def assert_tokens_match(got, want, margins=None, tol=LOGIT_TOL, what=""):
-    """got/want: list of (tokens, timestamps) per stream; margins: [B, T'] oracle top-2 gaps."""
-    assert len(got) == len(want)
+def _first_emit(results):
+    ts = [r[1][0] for r in results if r[1]]
+    return min(ts) if ts else None
+
+
+def assert_tokens_match(got, want, margins=None, tol=LOGIT_TOL, what="", allow_tie=False, batch_context=True):
+    """got/want: list of (tokens, timestamps) per stream; margins: [B, T'] (or [T'] for one stream)
+    oracle top-2 gaps.  Returns the number of exactly equal streams (== len(want) unless allow_tie)."""
+    assert len(got) == len(want), f"{what}: {len(got)} results for {len(want)} streams"
     exact = 0
+    COMPARED[0] += len(want)
     for b, (g, w) in enumerate(zip(got, want)):
         if g == w:
             exact += 1
             continue
         t = first_divergence(g, w)
-        assert margins is not None, f"{what} stream {b}: tokens differ at frame {t}: {g} vs {w}"
-        # a near-tie anywhere up to the divergence frame (context switches propagate) excuses it
-        m = float(np.min(margins[:, : t + 1])) if margins.ndim == 2 else float(np.min(margins[: t + 1]))
-        assert m < tol, (f"{what} stream {b}: tokens differ at frame {t} but the oracle's smallest top-2 gap "
-                         f"up to there is {m:.3g} >= {tol}: {g} vs {w}")
+        msg = f"{what} stream {b}: tokens differ at frame {t}: got {g} want {w}"
+        assert allow_tie and margins is not None and t is not None, msg
+        mg = np.asarray(margins)
+        own = float(mg[b, t]) if mg.ndim == 2 else float(mg[t])
+        cands = [own]
+        if batch_context and mg.ndim == 2:
+            # the batch's first-emission frame, as seen by either side
+            for t0 in {_first_emit(got), _first_emit(want)} - {None}:
+                if t0 <= t:
+                    cands.append(float(mg[:, t0].min()))
+        m = min(cands)
+        assert m < tol, f"{msg}; the oracle's top-2 gap there is {own:.3g} (batch t0 gap {cands[1:]}) >= {tol}"
+        EXCUSED.append((what, b, int(t), m))
+    return exact
+
+
+def assert_beam_match(got, want, margins, tol=LOGIT_TOL, what="", allow_tie=False):
+    """Modified beam search: margins[b] holds stream b's beam-boundary gap per frame and its final-score
+    gap; any of them below `tol` can change the surviving hypothesis, so the excuse is per stream."""
+    assert len(got) == len(want)
+    exact = 0
+    COMPARED[0] += len(want)
+    for b, (g, w) in enumerate(zip(got, want)):
+        if g == w:
+            exact += 1
+            continue
+        msg = f"{what} stream {b}: beam results differ: got {g} want {w}"
+        assert allow_tie, msg
+        m = float(np.asarray(margins)[b].min())
+        assert m < tol, f"{msg}; smallest decision gap {m:.3g} >= {tol}"
+        EXCUSED.append((what, b, -1, m))
     return exact

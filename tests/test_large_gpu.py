@@ -113,3 +113,64 @@ def test_long_utterances_beyond_the_lds_strip(hip_tiny, oracle_tiny, hip_conform
     x2 = oracle_conformer.pad_sequence([f2]).reshape(1, -1, 80)
     assert oracle_conformer.encoder_out_frames(x2.shape[1]) > 2048
     np.testing.assert_allclose(hip_conformer.encoder_proj(x2), oracle_conformer.encoder(x2), atol=5e-4, rtol=0)
+
+
+# ---- BASELINE configs[2]: modified beam search, beam = 4, on zipformer2-large-en ---------------------------
+def test_large_beam4_matches_oracle(hip_large, oracle_large):
+    """Three short utterances on the benchmark architecture: tokens, timestamps and scores of the device search equal
+    oracle/k2_oracle_beam.c (icefall modified_beam_search; the reference itself has no beam search,
+    OfflineRecognizer.cs:54-68), both at the operator level (same encoder_out) and through the fused samples -> tokens
+    entry selected by set_decoding_method."""
+    from parity import assert_beam_match
+    from k2transducerasr_amd.synth import synth_utterance
+    utts = [synth_utterance(400 + u, s) for u, s in enumerate([2.4, 1.9, 2.4])]
+    feats = [oracle_large.fbank(u) for u in utts]
+    x = oracle_large.pad_sequence(feats).reshape(len(utts), -1, 80)
+    enc_o = oracle_large.encoder(x)
+    want, mg, sc = oracle_large.modified_beam_search(enc_o, 4, want_margins=True, want_scores=True)
+    assert sum(len(w[0]) for w in want) > 0
+    got, gsc = hip_large.beam_search(enc_o, 4, want_scores=True)
+    assert_beam_match(got, want, mg, what="large beam-4 (oracle encoder_out)")
+    np.testing.assert_allclose(gsc, sc, atol=2e-3, rtol=0)
+    hip_large.set_decoding_method("modified_beam_search", 4)
+    try:
+        got2 = hip_large.offline_greedy_from_samples(utts)
+        assert_beam_match(got2, want, mg, what="large beam-4 (fused, from samples)")
+        np.testing.assert_allclose(hip_large.last_scores(len(utts)), sc, atol=2e-3, rtol=0)
+    finally:
+        hip_large.set_decoding_method("greedy_search")
+
+
+def test_full_size_beam4_properties(hip_large):
+    """One GPU's shard of configs[2] (32 of the 256 utterances, 10 s each, beam 4): determinism, stream independence
+    (x_lens = T' for every stream, so a stream searched alone gives the same hypothesis), pipelined == synchronous under
+    set_decoding_method, and the result geometry."""
+    from k2transducerasr_amd.synth import synth_utterance
+    B = 32
+    s = np.stack([synth_utterance(u, 10.0) for u in range(B)])
+    ptr = hip_large.device_alloc(s.nbytes)
+    hip_large.set_decoding_method("modified_beam_search", 4)
+    try:
+        hip_large.device_upload(ptr, s)
+        r1 = hip_large.offline_greedy_from_samples_dev(ptr, s.shape[1], B)
+        sc1 = hip_large.last_scores(B)
+        r2 = hip_large.offline_greedy_from_samples_dev(ptr, s.shape[1], B)
+        assert r1 == r2 and np.array_equal(sc1, hip_large.last_scores(B))
+        ta = hip_large.offline_submit_samples_dev(ptr, s.shape[1], B)
+        tb = hip_large.offline_submit_samples_dev(ptr, s.shape[1], B)
+        assert hip_large.offline_wait(ta) == r1 and hip_large.offline_wait(tb) == r1
+        feats = [hip_large.fbank(s[b]) for b in range(B)]
+        enc = hip_large.encoder_proj(hip_large.pad_sequence(feats).reshape(B, -1, 80))
+        full, fsc = hip_large.beam_search(enc, 4, want_scores=True)
+        assert full == r1
+        for b in (0, 13, 31):
+            alone, asc = hip_large.beam_search(enc[b : b + 1], 4, want_scores=True)
+            assert alone[0] == full[b] and abs(float(asc[0]) - float(fsc[b])) < 1e-4
+    finally:
+        hip_large.set_decoding_method("greedy_search")
+        hip_large.device_free(ptr)
+    assert sum(len(t) for t, _ in r1) > 0
+    for tok, ts in r1:
+        assert len(tok) == len(ts) and all(0 <= t < 253 for t in ts) and ts == sorted(ts)
+        assert all(t not in (0, 2) and 0 < t < 500 for t in tok)      # blank / unk never enter ys
+    assert np.isfinite(sc1).all() and (sc1 < 0).all()                 # log-probabilities

@@ -223,3 +223,59 @@ def test_left_context_shorter_than_chunk(tmp_path_factory):
         for l in range(o.num_layers):
             for kind in KINDS:
                 np.testing.assert_allclose(h.state(l, kind), o.state(l, kind), atol=2e-4, rtol=0, err_msg=f"layer {l} {kind}")
+
+
+def test_streaming_128_concurrent_slots_zh(tmp_path_factory):
+    """BASELINE configs[3] at its own size: 128 concurrent streams of the zipformer-multi-zh-hans streaming architecture in one
+    GetResults call per chunk (pool growth past its first allocation, 128-row launches, every slot live).  Streams 0 and 77 are
+    checked against the oracle chunk by chunk; all 128 are checked for stream independence: five of them (first, last, and three
+    in between, including an oracle-checked one) are decoded again ALONE on a fresh recognizer and must give the same tokens,
+    timestamps and cached states; the rest repeat 8 distinct utterances, and copies of one utterance sitting in different slots
+    of the same 128-row launches must agree with each other exactly."""
+    from k2transducerasr_amd import OnlineRecognizer
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    from oracle.online import OnlineOracle
+    p = str(tmp_path_factory.mktemp("szh128") / "szh.k2w")
+    write_synthetic_model(p, "zipformer2-streaming-zh")
+    rec, ora = OnlineRecognizer(p), OnlineOracle(p)
+    N, DISTINCT = 128, 8
+    T, S = rec.chunk_length, rec.shift_length
+    base = [ora.fbank(synth_utterance(800 + u, 1.7)) for u in range(DISTINCT)]
+    nchunks = (base[0].shape[0] - T) // S + 1
+    assert nchunks >= 4
+    feats = [base[u % DISTINCT] for u in range(N)]
+    hs = [rec.create_online_stream() for _ in range(N)]
+    for h, f in zip(hs, feats):
+        h.add_features(f)
+    checked = {0: ora.create_stream(), 77: ora.create_stream()}
+    for k in range(nchunks):
+        dec, n_new = rec.get_results(hs)
+        assert dec == [1] * N
+        for u, o in checked.items():
+            want = ora.step([o], [feats[u][k * S : k * S + T]])
+            assert n_new[u] == want[0]
+            assert hs[u].tokens == o.tokens and hs[u].timestamps == o.timestamps and hs[u].hyp == o.hyp, (k, u)
+    assert rec.get_results(hs)[0] == [0] * N                  # nothing left to decode
+    assert sum(len(o.tokens) - 2 for o in checked.values()) > 0
+    for u, o in checked.items():
+        for l in (0, 8, 15):
+            for kind in KINDS:
+                np.testing.assert_allclose(hs[u].state(l, kind), o.state(l, kind), atol=5e-4, rtol=0)
+    # copies of one utterance in different slots of the same launches: bit-identical results
+    for u in range(DISTINCT, N):
+        r = u % DISTINCT
+        assert hs[u].tokens == hs[r].tokens and hs[u].timestamps == hs[r].timestamps, u
+    for u in (DISTINCT + 3, 127):
+        for kind in KINDS:
+            assert np.array_equal(hs[u].state(15, kind), hs[u % DISTINCT].state(15, kind))
+    # a stream decoded alone (batch of one, fresh pool) gives what it gave among 127 others
+    rec1 = OnlineRecognizer(p)
+    for u in (0, 3, 5, 6, 7):
+        a = rec1.create_online_stream()
+        a.add_features(feats[u])
+        for _ in range(nchunks):
+            assert rec1.get_results([a])[0] == [1]
+        assert a.tokens == hs[u].tokens and a.timestamps == hs[u].timestamps and a.hyp == hs[u].hyp, u
+        for kind in KINDS:
+            np.testing.assert_allclose(a.state(15, kind), hs[u].state(15, kind), atol=1e-5, rtol=0)
+        a.close()

@@ -1,0 +1,51 @@
+"""BASELINE configs[0]: zipformer-small-en offline greedy, ONE utterance through OfflineRecognizer.GetResult -- the reference's
+single-stream path (OfflineRecognizer.cs:77-83 -> ForwardGreedySearch :93-187): hypList starts [-1, blank], at most one symbol
+per frame, stops at 1000 symbols, the stream keeps its samples (no RemoveSamples)."""
+import numpy as np
+import pytest
+
+from parity import LOGIT_TOL, assert_tokens_match
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small_path(tmp_path_factory):
+    from k2transducerasr_amd.synth import write_synthetic_model
+    p = str(tmp_path_factory.mktemp("small") / "small.k2w")
+    write_synthetic_model(p, "zipformer2-small-en")
+    return p
+
+
+def test_small_en_single_utterance_get_result(small_path):
+    from k2transducerasr_amd import OfflineRecognizer
+    from k2transducerasr_amd.synth import synth_utterance
+    from oracle import Oracle
+    ora = Oracle(small_path)
+    rec = OfflineRecognizer(small_path)                 # decodingMethod = greedy_search
+    u = synth_utterance(700, 6.0)
+    s = rec.create_offline_stream()
+    s.add_samples(u[:40000])                            # two AddSamples calls, as a file read in pieces would make
+    s.add_samples(u[40000:])
+    f = ora.fbank(u)
+    assert s.speech_length == f.size
+    np.testing.assert_allclose(s.speech.reshape(-1, 80), f, atol=2e-5, rtol=0)
+    x = ora.pad_sequence([f]).reshape(1, -1, 80)
+    enc_o = ora.encoder(x)
+    enc_h = rec.model.encoder_proj(x)
+    np.testing.assert_allclose(enc_h, enc_o, atol=5e-4, rtol=0)
+    dec = ora.decoder(np.array([[-1, 0]], np.int64))
+    n = enc_o.shape[1]
+    assert float(np.abs(ora.joiner(enc_o[0], np.repeat(dec, n, 0)) - rec.model.joiner_proj(enc_h[0], np.repeat(dec, n, 0))).max()) < LOGIT_TOL
+    (wt, wts), mg = ora.greedy_single(enc_o[0], want_margins=True)
+    assert len(wt) > 0
+    tok, ts = rec.get_result(s)
+    assert tok[:2] == [-1, 0]                           # OfflineRecognizer.cs:115-117
+    assert_tokens_match([(tok[2:], ts)], [(wt, wts)], mg, what="small-en GetResult", batch_context=False)
+    assert s.speech_length == f.size                    # the single path does not call RemoveSamples
+    # the same stream through the batch entry as a batch of one (GetResults :85-91): Tokens is REPLACED by the batch list with its
+    # 2*B-blank prefix (:250-258, :292), Timestamps.AddRange appends to what GetResult left (:293), samples removed (:294)
+    (tok_b, ts_b), = rec.get_results([s])
+    want_b = ora.recognize_batch([f])[0]
+    assert tok_b == [0, 0] + want_b[0] and ts_b == ts + [0, 0] + want_b[1]
+    assert s.speech_length == 0

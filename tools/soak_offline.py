@@ -39,7 +39,7 @@ for preset in presets:
         want = ora.recognize_batch(feats)
         _, mg = ora.greedy_batch(ora.encoder(x), want_margins=True)
         got = hip.offline_greedy_from_samples(utts)
-        exact += assert_tokens_match(got, want, mg, what=f"{preset} case {case} (B={B}, samples={ns})")
+        exact += assert_tokens_match(got, want, mg, what=f"{preset} case {case} (B={B}, samples={ns})", allow_tie=True)
         tot += B
     print(f"{preset}: {cases - skipped} batches, {exact}/{tot} streams token-exact (the rest diverge on an oracle near-tie)", flush=True)
 print("soak ok")
