@@ -1,23 +1,34 @@
 #!/usr/bin/env python3
-"""Benchmark of the K2TransducerAsr offline greedy hot path on MI355X.
+"""Benchmark of the K2TransducerAsr offline hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): zipformer-large-en offline greedy, batch = 32
-synthetic 10 s utterances per GPU, 16 kHz f32 samples already resident in HBM when the
-timed region starts.  One step = one pass of the whole path over one batch:
-fbank -> PadSequence (+19 frames, log-floor) -> Zipformer2-large encoder -> on-device
-greedy search -> token arrays back in host memory.
+Default workload (BASELINE.json configs[1]): zipformer-large-en offline greedy, batch = 32
+synthetic 10 s utterances per GPU.  One step = one pass of the whole path over the rank's shard
+of utterances: fbank -> PadSequence (+19 frames, log-floor) -> Zipformer2-large encoder ->
+on-device greedy search -> token arrays back in host memory.
 
 Metric: RTFx = audio seconds / wall seconds (inverse of the reference's printed
 `rtf = elapsed_ms / total_duration_ms`, K2TransducerAsr.Examples/OfflineRecognizer.cs:185-189),
-whole job over all ranks.  Multi-GPU: one process per GPU (torch.distributed.run), each
-rank decodes its own shard of utterances with no collective on the data path (weak
-scaling); RCCL is used only for the timing barrier and the max-over-ranks.
+whole job over all ranks.  `value` is timed with the samples already resident in HBM;
+`value_from_host_memory` is the same K steps with the samples in page-locked host memory and
+the H2D copy inside the pipeline (the reference's protocol: float[] in, text out).
+
+Multi-GPU: one process per GPU, each rank decodes its own contiguous shard of the utterance list
+exactly as the reference would decode that shard as its own GetResults batches; no collective on
+the data path (RCCL / gloo carry the timing barrier, the max-over-ranks and the KB-sized gather
+of the token lists).  `python bench.py --gpus N` with no WORLD_SIZE in the environment starts the
+N ranks itself (before any GPU call); under torch.distributed.run it is one of the ranks.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus 8 --total-utts 256 --beam 4                              # configs[2]
+    python bench.py --gpus 8 --preset conformer-zh --total-utts 64 --batch 8 --seconds 30   # configs[4]
+    python bench.py --gpus 2 --dist-backend gloo                                    # rehearsal on one GPU
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -47,6 +58,59 @@ def pmc_traffic():
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--preset", default=PRESET)
+    ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GetResults batch")
+    ap.add_argument("--seconds", type=float, default=UTT_SECONDS)
+    ap.add_argument("--total-utts", type=int, default=0,
+                    help="utterances of the whole job, sharded contiguously over the ranks (strong scaling); "
+                         "default = --batch per rank (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the second timing with samples in host memory")
+    ap.add_argument("--no-pipeline", action="store_true", help="one synchronous call per batch (no batch overlap)")
+    ap.add_argument("--cpu-utts", type=int, default=32)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal of the N > 1 path on one GPU)")
+    ap.add_argument("--beam", type=int, default=0, help="0 = greedy_search (headline metric); K = modified_beam_search with beam K (BASELINE configs[2])")
+    ap.add_argument("--dump-results", default="", help="rank 0 writes every utterance's (tokens, timestamps) of the last step here (JSON)")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous + shard bookkeeping only; no GPU work (CPU test of the launcher)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts its own ranks.  Nothing here may touch the GPU: the
+# children are separate programs, started before any HIP call of this process.
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(n: int) -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                log(f"[bench] rank {r} exited with {code}; stopping the other ranks")
+                for o in alive:
+                    procs[o].terminate()     # exactly the processes started above
+        time.sleep(0.05)
+    return rc
 
 
 def ensure_weights(path, preset, rank, barrier):
@@ -91,40 +155,66 @@ def cpu_baseline(weights, n_utts, seconds):
     }, res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--preset", default=PRESET)
-    ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--seconds", type=float, default=UTT_SECONDS)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true", help="one synchronous call per step (no batch overlap)")
-    ap.add_argument("--cpu-utts", type=int, default=32)
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal of the N > 1 path on one GPU)")
-    ap.add_argument("--beam", type=int, default=0, help="0 = greedy_search (headline metric); K = modified_beam_search with beam K (BASELINE configs[2])")
-    args = ap.parse_args()
+def baseline_config_of(args, world, total):
+    """which BASELINE.json config (if any) this invocation is"""
+    if args.preset == PRESET and args.beam == 0 and args.batch == 32 and abs(args.seconds - 10.0) < 1e-9 and not args.total_utts:
+        return "BASELINE.json configs[1]" + ("" if world == 1 else f" per GPU, x{world} GPUs")
+    if args.preset == PRESET and args.beam == 4 and abs(args.seconds - 10.0) < 1e-9:
+        if total == 256 and world == 8:
+            return "BASELINE.json configs[2]"
+        return f"BASELINE.json configs[2] at {total} utterances on {world} GPU(s) (the config is 256 on 8)"
+    if args.preset == "conformer-zh" and args.beam == 0 and abs(args.seconds - 30.0) < 1e-9:
+        if total == 64 and world == 8:
+            return "BASELINE.json configs[4]"
+        return f"BASELINE.json configs[4] at {total} utterances on {world} GPU(s) (the config is 64 on 8)"
+    return "not a BASELINE.json config"
 
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a line for a different job size")
+        sys.exit(2)
+    if os.environ.get("K2HIP_BENCH_FAIL_RANK") == str(rank):  # launcher test hook: this rank dies before the rendezvous
+        sys.exit(3)
     dist = None
     if world > 1:
         import torch
         import torch.distributed as dist
 
-        if args.dist_backend == "nccl":
+        if args.dist_backend == "nccl" and not args.launch_check:
+            if local_rank >= torch.cuda.device_count():
+                log(f"[bench] rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible); "
+                    "use --dist-backend gloo to rehearse N ranks on fewer GPUs")
+                sys.exit(4)
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend=args.dist_backend)
+            dist.init_process_group(backend="gloo")
 
     def barrier():
         if dist is not None:
             dist.barrier()
+
+    from k2transducerasr_amd.shard import batches_of, gather_results, max_over_ranks, shard_range
+
+    B, secs = args.batch, args.seconds
+    total = args.total_utts or B * world
+    lo, hi = shard_range(total, world, rank)
+    my_batches = batches_of(lo, hi, B)          # [(first utterance id, count)]: the GetResults batches of this rank
+    if args.launch_check:
+        got = gather_results(dist, [(rank, lo, hi, my_batches)], world, rank)
+        barrier()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "total_utts": total, "shards": got}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     import k2transducerasr_amd as pkg
     from k2transducerasr_amd.synth import synth_utterance
@@ -137,63 +227,88 @@ def main():
     model = pkg.Model(weights, device)  # no fallback: raises without a GPU / library
     if args.beam > 0:
         model.set_decoding_method("modified_beam_search", args.beam)
-    B, secs = args.batch, args.seconds
     n_each = int(round(secs * 16000))
-    # each rank owns a different shard of utterances (seeds offset by rank)
-    samples = np.stack([synth_utterance(rank * B + u, secs) for u in range(B)])
-    dptr = model.device_alloc(samples.nbytes)
-    model.device_upload(dptr, samples)
+    # utterance u is the same signal whichever rank decodes it (seed = u)
+    host, dev = [], []
+    for first, cnt in my_batches:
+        h = model.host_alloc((cnt, n_each))
+        for i in range(cnt):
+            h[i] = synth_utterance(first + i, secs)
+        d = model.device_alloc(h.nbytes)
+        model.device_upload(d, h)
+        host.append(h)
+        dev.append(d)
+    nb = len(my_batches)
 
-    def step():
-        return model.offline_greedy_from_samples_dev(dptr, n_each, B)
+    def submit(i, from_host):
+        cnt = my_batches[i][1]
+        return model.offline_submit_samples(host[i], None) if from_host else model.offline_submit_samples_dev(dev[i], n_each, cnt)
 
-    def run_steps(n):
-        """n passes over the batch, software-pipelined two deep: batch i+1 is submitted before
-        batch i's tokens are collected, so its encoder overlaps batch i's greedy loop.  Every
-        batch's tokens are back in host memory before this returns."""
-        if args.no_pipeline or n == 0:
-            out = None
+    def run_steps(n, from_host=False):
+        """n passes over the rank's batches, software-pipelined two deep: the next batch is submitted before the previous one's
+        tokens are collected, so its encoder (and, from host memory, its H2D copy) overlaps that batch's search.  Every batch's
+        tokens are back in host memory before this returns; the last pass's results are returned in utterance order."""
+        last = [None] * nb
+        if n == 0 or nb == 0:
+            return last
+        if args.no_pipeline:
             for _ in range(n):
-                out = step()
-            return out
-        tk = model.offline_submit_samples_dev(dptr, n_each, B)
-        for _ in range(n - 1):
-            nxt = model.offline_submit_samples_dev(dptr, n_each, B)
-            out = model.offline_wait(tk)
+                for i in range(nb):
+                    last[i] = model.offline_wait(submit(i, from_host))
+            return last
+        seq = [i for _ in range(n) for i in range(nb)]
+        tk = submit(seq[0], from_host)
+        for k in range(1, len(seq)):
+            nxt = submit(seq[k], from_host)
+            last[seq[k - 1]] = model.offline_wait(tk)
             tk = nxt
-        return model.offline_wait(tk)
+        last[seq[-1]] = model.offline_wait(tk)
+        return last
 
-    res = run_steps(args.warmup)
-    model.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    res = run_steps(args.steps)
-    model.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    from k2transducerasr_amd.shard import max_over_ranks
+    def timed(from_host):
+        run_steps(args.warmup, from_host)
+        model.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        r = run_steps(args.steps, from_host)
+        model.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        return r, max_over_ranks(dist, el, device="cuda" if (dist is not None and args.dist_backend == "nccl") else None)
 
-    elapsed = max_over_ranks(dist, elapsed, device="cuda" if (dist is not None and args.dist_backend == "nccl") else None)
-    res_sync = step()  # one synchronous pass: per-stage HIP-event timings + pipelined == synchronous check
-    stages = model.timing()
-    assert res_sync == res, "pipelined and synchronous results differ"
+    res, elapsed = timed(False)
+    host_elapsed = None
+    if not args.no_host_leg:
+        res_h, host_elapsed = timed(True)
+        assert res_h == res, "results from host memory and from device memory differ"
+    local = [r for batch in res for r in batch]
+    allres = gather_results(dist, local, world, rank)   # rank order == utterance order
 
-    # roofline of the dominant kernel (fp32 MFMA GEMM): one extra instrumented pass
-    # over the same batch, HIP events recorded around every GEMM launch on the
-    # engine's own stream (no per-launch sync, launches stay back to back).
-    model.set_instrument(True)
-    step()
-    it = model.timing()
-    model.set_instrument(False)
+    # one synchronous pass over the first batch: per-stage HIP-event timings + pipelined == synchronous check
+    stages = it = None
+    if nb:
+        res_sync = model.offline_greedy_from_samples_dev(dev[0], n_each, my_batches[0][1])
+        stages = model.timing()
+        assert res_sync == res[0], "pipelined and synchronous results differ"
+        # roofline of the dominant kernel (fp32 MFMA GEMM): one extra instrumented pass over the same batch, HIP events
+        # recorded around every GEMM launch on the engine's own stream (no per-launch sync, launches stay back to back).
+        model.set_instrument(True)
+        model.offline_greedy_from_samples_dev(dev[0], n_each, my_batches[0][1])
+        it = model.timing()
+        model.set_instrument(False)
 
     if rank == 0:
-        audio = world * args.steps * B * secs
+        assert len(allres) == total, f"gathered {len(allres)} results for {total} utterances"
+        audio = args.steps * total * secs
         value = audio / elapsed
-        ach = it["gemm_flops"] / (it["gemm_ms"] * 1e-3) / 1e12 if it["gemm_ms"] > 0 else 0.0
-        default_workload = args.preset == PRESET and B == BATCH and abs(secs - UTT_SECONDS) < 1e-9 and args.beam == 0
+        ach = it["gemm_flops"] / (it["gemm_ms"] * 1e-3) / 1e12 if it and it["gemm_ms"] > 0 else 0.0
+        default_workload = args.preset == PRESET and B == BATCH and abs(secs - UTT_SECONDS) < 1e-9 and args.beam == 0 and not args.total_utts
         traffic, traffic_note = pmc_traffic() if default_workload else (None, "PMC passes exist for the default workload only")
+        method = "greedy" if args.beam == 0 else f"modified-beam-search beam={args.beam}"
+        tprime = max(1, model.encoder_out_frames(model.fbank_num_frames(n_each) + 19))
+        n_tok = int(sum(len(r[0]) for r in allres))
         out = {
-            "metric": "RTFx (audio-sec/wall-sec) offline Zipformer greedy",
+            "metric": "RTFx (audio-sec/wall-sec) offline Zipformer greedy" if default_workload else f"RTFx (audio-sec/wall-sec) offline {args.preset} {method}",
             "value": round(value, 1),
             "unit": "audio-sec/wall-sec",
             "n_gpus": world,
@@ -201,20 +316,30 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_utts else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.preset} offline {'greedy' if args.beam == 0 else 'modified-beam-search beam=%d' % args.beam}, batch={B} synthetic {secs:g} s utterances per GPU "
-                            "(BASELINE.json configs[1]); samples resident in HBM, tokens returned to host",
-                "batch_per_gpu": B,
+                "workload": f"{args.preset} offline {method}, {total} synthetic {secs:g} s utterances per step in GetResults batches of "
+                            f"{B} ({baseline_config_of(args, world, total)}); samples resident in HBM, tokens returned to host",
+                "batch": B,
+                "total_utts_per_step": total,
                 "utt_seconds": secs,
-                "parallelism": f"utterance-sharded x{world}, no data-path collective",
-                "pipeline": "synchronous" if args.no_pipeline else "2 batches in flight (greedy of batch i overlaps encoder of i+1)",
-                "weights": "seeded random init of the zipformer-large architecture (no checkpoints available)",
+                "parallelism": f"utterance-sharded x{world} ({'one rank per GPU, RCCL' if args.dist_backend == 'nccl' else 'gloo rehearsal, ranks share GPUs'}), "
+                               "no data-path collective",
+                "pipeline": "synchronous" if args.no_pipeline else "2 batches in flight (search of batch i overlaps encoder of i+1)",
+                "weights": f"seeded random init of the {args.preset} architecture (no checkpoints available)",
             },
-            "roofline": {
+            "tokens_emitted_per_step": n_tok,
+            "emission_rate": round(n_tok / (total * tprime), 4),
+            "results_sha1": hashlib.sha1(json.dumps(allres).encode()).hexdigest()[:16],
+        }
+        if host_elapsed is not None:
+            out["value_from_host_memory"] = round(audio / host_elapsed, 1)
+            out["ms_per_step_from_host_memory"] = round(host_elapsed / args.steps * 1e3, 3)
+        if it:
+            out["roofline"] = {
                 "kernel": "gemm_f32_mfma (all Linear / pointwise-conv / implicit-conv / attention-apply launches)",
                 "bound": "mfma",
                 "achieved": round(ach, 2),
@@ -223,19 +348,22 @@ def main():
                 "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic,
                 "traffic_note": traffic_note,
-                "launches_per_step": it["gemm_launches"],
-                "flops_per_step": it["gemm_flops"],
+                "launches_per_batch": it["gemm_launches"],
+                "flops_per_batch": it["gemm_flops"],
                 "avg_launch_us": round(it["gemm_ms"] * 1e3 / max(it["gemm_launches"], 1), 2),
-                "all_matrix_flops_per_step": it["total_flops"],
-            },
-            "stages_ms_one_synchronous_pass": {k: round(stages[k], 3) for k in ("total_ms", "fbank_ms", "pad_ms", "encoder_ms", "greedy_ms", "d2h_ms")},
-            "tokens_emitted_last_step": int(sum(len(r[0]) for r in res)),
-        }
+                "all_matrix_flops_per_batch": it["total_flops"],
+            }
+            out["stages_ms_one_synchronous_batch"] = {k: round(stages[k], 3) for k in ("total_ms", "fbank_ms", "pad_ms", "encoder_ms", "greedy_ms", "d2h_ms")}
         if world == 1 and not args.no_cpu_baseline:
             cb, _ = cpu_baseline(weights, args.cpu_utts, secs)
             out["cpu_baseline"] = cb
+        if args.dump_results:
+            with open(args.dump_results, "w") as f:
+                json.dump({"results": allres, "batches_per_rank": nb, "n_gpus": world}, f)
         print(json.dumps(out), flush=True)
-    model.device_free(dptr)
+    for h, d in zip(host, dev):
+        model.device_free(d)
+        model.host_free(h)
     model.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -16,12 +16,44 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+def cpu_baseline(weights, n_streams, seconds):
+    """The CPU restatement (oracle/k2_oracle_online.c, 'port') of the same streaming path on this box's host cores, on a
+    bounded sample: n_streams concurrent streams of `seconds` s each (+ the 30 x 400 zero tail), one batched step per chunk."""
+    from k2transducerasr_amd.synth import synth_utterance
+    from oracle.online import OnlineOracle
+
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(len(os.sched_getaffinity(0)), 16)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    ora = OnlineOracle(weights)
+    T, S = ora.chunk_length, ora.shift_length
+    t0 = time.time()
+    feats = [ora.fbank(np.concatenate([synth_utterance(1000 + u, seconds), np.zeros(30 * 400, np.float32)])) for u in range(n_streams)]
+    ss = [ora.create_stream() for _ in range(n_streams)]
+    k = 0
+    while k * S + T <= feats[0].shape[0]:
+        ora.step(ss, [f[k * S : k * S + T] for f in feats])
+        k += 1
+    dt = time.time() - t0
+    return {
+        "value": round(n_streams * seconds / dt, 2),
+        "unit": "x real-time (audio-sec/wall-sec)",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{n_streams} concurrent streams x {seconds:g} s of the same synthetic workload ({k} chunk steps) through oracle/ "
+                  f"(C + OpenMP restatement of fbank + the streaming encoder + the online greedy loop; the reference's ONNXRuntime path "
+                  f"cannot run here), {dt:.2f} s wall",
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=128)
     ap.add_argument("--seconds", type=float, default=20.0)
     ap.add_argument("--preset", default="zipformer2-streaming-zh")
     ap.add_argument("--check", type=int, default=0, help="verify the first K streams against the CPU oracle")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-streams", type=int, default=8, help="streams of the CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="audio seconds per stream of the CPU-baseline sample")
     args = ap.parse_args()
     if args.check and "conformer" in args.preset:
         raise SystemExit("--check decodes each stream alone on the oracle; the streaming conformer's processed_lens quirk "
@@ -80,20 +112,67 @@ def main():
     streams, dt, steps = run()
     audio = N * args.seconds
     t = rec.model.timing()
+    tokens = int(sum(len(s.tokens) - 2 for s in streams))
+    checked_tokens = [streams[u].tokens for u in range(args.check)]
+    for s in streams:
+        s.close()
+
+    # roofline legs: one more full-width tick with HIP events around every GEMM launch (instrumented pass, not timed above).
+    # All N streams get exactly one chunk, so this is the 128-row-per-frame tick the metric is made of.
+    F32_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS = 157.3, 8000.0   # MI355X_MICROARCH.md
+    probe = [rec.create_online_stream() for _ in range(N)]
+    need = (rec.chunk_length - 1) * 160 + 400             # samples that give exactly chunk_length frames
+    rec.add_samples_batch(probe, wave[:, :need])
+    rec.model.set_instrument(True)
+    dec, _ = rec.get_results(probe)
+    it = rec.model.timing()
+    rec.model.set_instrument(False)
+    assert all(dec), "instrumented tick did not decode every stream"
+    state_floats = sum(probe[0].state(l, k).size for l in range(rec.num_layers) for k in rec.state_kinds) + rec.embed_state_floats
+    for s in probe:
+        s.close()
+    import k2transducerasr_amd.k2w as k2w
+    _, tensors = k2w.read_k2w(weights)
+    weight_bytes = int(sum(a.nbytes for n_, a in tensors.items() if n_.startswith(("encoder", "joiner", "decoder"))))
+    tick_ms = dt / max(steps, 1) * 1e3
+    tick_bytes = 2 * 4 * state_floats * N + weight_bytes   # every cache read and rewritten once per tick + the weights once
+    ach = it["gemm_flops"] / (it["gemm_ms"] * 1e-3) / 1e12 if it["gemm_ms"] > 0 else 0.0
     out = {
         "metric": "RTFx (audio-sec/wall-sec) streaming Zipformer2 greedy",
         "value": round(audio / dt, 1),
         "unit": "audio-sec/wall-sec",
         "n_gpus": 1,
+        "higher_is_better": True,
+        "vs_baseline": None,
         "config": {"workload": f"{args.preset} streaming greedy, chunk=32 frames, {N} concurrent streams x {args.seconds:g} s, "
-                               "800-sample pushes + 30 x 400 zero tail (BASELINE.json configs[3])"},
+                               "800-sample pushes + 30 x 400 zero tail (BASELINE.json configs[3]); host samples in, tokens in host memory"},
         "chunk_steps": steps,
-        "ms_per_chunk_step": round(dt / max(steps, 1) * 1e3, 3),
+        "ms_per_chunk_step": round(tick_ms, 3),
         "last_step_ms": {k: round(t[k], 3) for k in ("total_ms", "encoder_ms", "greedy_ms")},
         "host_phases_ms": {"add_samples": round(prof[0] * 1e3, 1), "get_results_decoding": round(prof[1] * 1e3, 1), "get_results_idle": round(prof[2] * 1e3, 1)},
-        "tokens": int(sum(len(s.tokens) - 2 for s in streams)),
+        "tokens": tokens,
+        "emission_rate": round(tokens / max(steps * N * rec.frames_per_chunk, 1), 4),
         "dtype": "f32",
         "data": "synthetic",
+        "roofline": {
+            "kernel": "gemm_f32_mfma* (every Linear / pointwise-conv / implicit-conv / attention-apply launch of one chunk step)",
+            "bound": "mfma",
+            "achieved": round(ach, 2),
+            "peak": F32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": None,
+            "launches_per_tick": it["gemm_launches"],
+            "flops_per_tick": it["gemm_flops"],
+            "avg_launch_us": round(it["gemm_ms"] * 1e3 / max(it["gemm_launches"], 1), 2),
+            "gemm_ms_per_tick": round(it["gemm_ms"], 3),
+            # the whole tick against both ceilings (the step is launch/latency bound: it sits far from either)
+            "tick": {"all_matrix_flops": it["total_flops"], "tflops": round(it["total_flops"] / (tick_ms * 1e-3) / 1e12, 2),
+                     "frac_of_mfma_peak": round(it["total_flops"] / (tick_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                     "algorithmic_hbm_bytes": tick_bytes, "gbs": round(tick_bytes / (tick_ms * 1e-3) / 1e9, 1),
+                     "frac_of_hbm_peak": round(tick_bytes / (tick_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "state_bytes_per_stream": 4 * state_floats, "weight_bytes": weight_bytes},
+        },
     }
     if args.check:
         from oracle.online import OnlineOracle
@@ -104,8 +183,10 @@ def main():
             o = ora.create_stream()
             for k in range((f.shape[0] - rec.chunk_length) // rec.shift_length + 1):
                 ora.step([o], [f[k * rec.shift_length : k * rec.shift_length + rec.chunk_length]])
-            assert o.tokens == streams[u].tokens, f"stream {u} differs from the oracle"
+            assert o.tokens == checked_tokens[u], f"stream {u} differs from the oracle"
         out["oracle_checked_streams"] = args.check
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(weights, args.cpu_streams, args.cpu_seconds)
     print(json.dumps(out), flush=True)
 
 

@@ -182,6 +182,21 @@ int32_t k2hip_offline_submit_samples_dev(k2hip_model_t* model, const float* samp
                                          int32_t B, int32_t max_tokens, int32_t* ticket);
 int32_t k2hip_offline_wait(k2hip_model_t* model, int32_t ticket, int64_t* tokens, int32_t* timestamps,
                            int32_t* n_tokens);
+/* The same with the samples still in HOST memory ([B, n_samples_each] f32), as the reference's caller holds them
+ * (K2TransducerAsr.Examples/OfflineRecognizer.cs:164-171): the host-to-device copy is part of the pipeline -- it runs
+ * on its own HIP stream under the previous batch's encoder.  The buffer must stay valid and unchanged until
+ * k2hip_offline_wait returns for this ticket.  For the copy to be asynchronous it must be page-locked:
+ * k2hip_host_alloc / k2hip_host_free hand out such memory (a managed host pins its float[] and registers it, or copies
+ * into one of these). */
+int32_t k2hip_offline_submit_samples(k2hip_model_t* model, const float* samples_host, int64_t n_samples_each,
+                                     int32_t B, int32_t max_tokens, int32_t* ticket);
+int32_t k2hip_host_alloc(k2hip_model_t* model, int64_t bytes, void** host_ptr);
+int32_t k2hip_host_free(k2hip_model_t* model, void* host_ptr);
+
+/* Development switches (INTEGRATION.md lists them): K2HIP_* environment variables select alternative kernels for the same
+ * math or tuning variants.  They are read ONCE, when the first model of the process is created; this call flips one afterwards
+ * (the parity tests compare both paths inside one process with it).  Not part of the reference's surface. */
+int32_t k2hip_debug_set_switch(const char* env_name, int32_t value);
 
 /* device memory helpers for the benchmark / host runtimes without a HIP binding */
 int32_t k2hip_device_alloc(k2hip_model_t* model, int64_t bytes, void** dev_ptr);
@@ -211,6 +226,10 @@ int32_t k2hip_tokens_destroy(k2hip_tokens_t* t);
 int32_t k2hip_tokens_size(const k2hip_tokens_t* t);                          /* _tokens.Length (the CTC vocab_size, :325) */
 int32_t k2hip_decode_text(const k2hip_tokens_t* t, const int64_t* ids, int32_t n, int32_t online, char* out, int32_t cap,
                           int32_t* len);
+/* The byte-BPE alphabet the decode above uses: BYTE_TO_BCHAR[byte] as a code point (ByteDataHelper.cs:27-285,295-299;
+ * -1 outside 0..255) and its inverse BCHAR_TO_BYTE (:300-304, BPE_UNK 8263 -> 32; -1 for a char outside the alphabet). */
+int32_t k2hip_bbpe_char(int32_t byte);
+int32_t k2hip_bbpe_byte(int32_t code_point);
 
 /* ---- CTC models (Model_type "zipformer2ctc": OfflineProjOfZipformer2ctc / OnlineProjOfZipformer2ctc) -------------------
  * The encoder entry points (k2hip_offline_encoder, the online step) return log_probs [B,T',V] for such a model.

@@ -21,6 +21,7 @@ from .binding import (  # noqa: F401
     build_library,
     library_path,
     load_library,
+    set_switch,
 )
 
 __all__ = [
@@ -34,6 +35,7 @@ __all__ = [
     "build_library",
     "library_path",
     "load_library",
+    "set_switch",
     "config",
     "k2w",
     "synth",

@@ -105,6 +105,9 @@ def load_library():
     L.k2hip_offline_greedy_from_samples_dev.argtypes = [vp, vp, C.c_int64, C.c_int32, lp, ip, ip, C.c_int32]
     L.k2hip_offline_submit_samples_dev.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int32, ip]
     L.k2hip_offline_wait.argtypes = [vp, C.c_int32, lp, ip, ip]
+    L.k2hip_offline_submit_samples.argtypes = [vp, fp, C.c_int64, C.c_int32, C.c_int32, ip]
+    L.k2hip_host_alloc.argtypes = [vp, C.c_int64, C.POINTER(vp)]
+    L.k2hip_host_free.argtypes = [vp, vp]
     L.k2hip_device_alloc.argtypes = [vp, C.c_int64, C.POINTER(vp)]
     L.k2hip_device_free.argtypes = [vp, vp]
     L.k2hip_device_upload.argtypes = [vp, vp, vp, C.c_int64]
@@ -123,6 +126,15 @@ def load_library():
     L.k2hip_offline_stream_get_timestamps.argtypes = [vp, ip, C.c_int32]
     _lib = L
     return L
+
+
+def set_switch(env_name: str, value: int = 1):
+    """k2hip_debug_set_switch: flip one development switch (named like its K2HIP_* environment variable) after start-up"""
+    L = load_library()
+    L.k2hip_debug_set_switch.argtypes = [C.c_char_p, C.c_int32]
+    rc = L.k2hip_debug_set_switch(env_name.encode(), int(value))
+    if rc != 0:
+        raise K2HipError(rc, L.k2hip_last_error().decode())
 
 
 def _f(a):
@@ -428,6 +440,31 @@ class Model:
         self._chk(self._L.k2hip_offline_submit_samples_dev(self._h, C.c_void_p(dev_ptr), n_each, B, mt, C.byref(t)))
         return (t.value, B, mt)
 
+    def host_alloc(self, shape, dtype=np.float32) -> np.ndarray:
+        """page-locked host array (k2hip_host_alloc); release with host_free(array)"""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._chk(self._L.k2hip_host_alloc(self._h, nbytes, C.byref(p)))
+        buf = (C.c_char * nbytes).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p.value
+        return a
+
+    def host_free(self, a: np.ndarray):
+        p = getattr(self, "_pinned", {}).pop(a.ctypes.data, None)
+        if p is not None:
+            self._chk(self._L.k2hip_host_free(self._h, C.c_void_p(p)))
+
+    def offline_submit_samples(self, samples: np.ndarray, max_tokens: Optional[int] = None):
+        """pipelined submit of a [B, n] f32 batch that is still in host memory (H2D inside the pipeline)"""
+        assert samples.dtype == np.float32 and samples.ndim == 2 and samples.flags.c_contiguous
+        B, n_each = samples.shape
+        mt = max_tokens or max(1, self.encoder_out_frames(self.fbank_num_frames(n_each) + 19))
+        t = C.c_int32()
+        self._chk(self._L.k2hip_offline_submit_samples(self._h, _f(samples), n_each, B, mt, C.byref(t)))
+        return (t.value, B, mt)
+
     def offline_wait(self, ticket):
         t, B, mt = ticket
         tok = np.zeros((B, mt), np.int64)
@@ -621,6 +658,14 @@ class OnlineRecognizer:
         a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
         self.model._chk(self.model._L.k2hip_online_chunk_info(self.model.handle, C.byref(a), C.byref(b), C.byref(c)))
         self.chunk_length, self.shift_length, self.frames_per_chunk = a.value, b.value, c.value
+        mt = self.model.meta("model_type")
+        nl = self.model.meta("num_encoder_layers")
+        self.num_layers = sum(int(x) for x in nl.split(",")) if nl else 0
+        # names of the per-layer caches of this operator's GetEncoderInitStates, and the floats of embed_states (Zipformer2 only)
+        self.state_kinds = {"zipformer2": ["key", "nonlin", "val1", "val2", "conv1", "conv2"], "zipformer2ctc": ["key", "nonlin", "val1", "val2", "conv1", "conv2"],
+                            "zipformer": ["len", "avg", "key", "val", "val2", "conv1", "conv2"], "conformer": ["conf_attn", "conf_conv"],
+                            "lstm": ["lstm_h", "lstm_c"]}.get(mt, [])
+        self.embed_state_floats = 128 * 3 * 19 if mt in ("zipformer2", "zipformer2ctc") else 0
 
     def create_online_stream(self) -> OnlineStream:  # CreateOnlineStream :60-64
         return OnlineStream(self.model)

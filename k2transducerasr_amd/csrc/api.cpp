@@ -259,6 +259,8 @@ int32_t k2hip_tokens_destroy(k2hip_tokens_t* t) {
     });
 }
 int32_t k2hip_tokens_size(const k2hip_tokens_t* t) { return t ? token_table_size(t->tab) : -1; }
+int32_t k2hip_bbpe_char(int32_t byte) { return bbpe_char_of_byte(byte); }
+int32_t k2hip_bbpe_byte(int32_t code_point) { return code_point < 0 ? -1 : bbpe_byte_of_char((uint32_t)code_point); }
 int32_t k2hip_decode_text(const k2hip_tokens_t* t, const int64_t* ids, int32_t n, int32_t online, char* out, int32_t cap,
                           int32_t* len) {
     return guard([&] {
@@ -375,6 +377,27 @@ int32_t k2hip_offline_submit_samples_dev(k2hip_model_t* model, const float* samp
         NEED(model); NEED(samples_dev); NEED(ticket);
         std::lock_guard<std::mutex> lk(model->engine.mutex());
         *ticket = model->engine.submit_samples_dev(samples_dev, n_samples_each, B, max_tokens);
+    });
+}
+int32_t k2hip_offline_submit_samples(k2hip_model_t* model, const float* samples_host, int64_t n_samples_each, int32_t B,
+                                     int32_t max_tokens, int32_t* ticket) {
+    return guard([&] {
+        NEED(model); NEED(samples_host); NEED(ticket);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        *ticket = model->engine.submit_samples_host(samples_host, n_samples_each, B, max_tokens);
+    });
+}
+int32_t k2hip_host_alloc(k2hip_model_t* model, int64_t bytes, void** host_ptr) {
+    return guard([&] {
+        NEED(model); NEED(host_ptr);
+        K2_REQUIRE(bytes > 0, "host_alloc: %lld bytes", (long long)bytes);
+        *host_ptr = model->engine.host_alloc(bytes);
+    });
+}
+int32_t k2hip_host_free(k2hip_model_t* model, void* host_ptr) {
+    return guard([&] {
+        NEED(model);
+        if (host_ptr) model->engine.host_free(host_ptr);
     });
 }
 int32_t k2hip_offline_wait(k2hip_model_t* model, int32_t ticket, int64_t* tokens, int32_t* timestamps, int32_t* n_tokens) {
@@ -557,6 +580,11 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
             n_new_tokens[i] = 0;
             if (streams[i]->speech.size() >= chunk_floats) idx.push_back(i);   // GetDecodeChunk (:82-100)
         }
+        {   // one stream twice in the list would consume two chunks against one state slot in the same launch
+            std::vector<const k2hip_online_stream*> seen(streams, streams + B);
+            std::sort(seen.begin(), seen.end());
+            K2_REQUIRE(std::adjacent_find(seen.begin(), seen.end()) == seen.end(), "GetResults: the same stream appears twice in the list");
+        }
         if (idx.empty()) return;   // :113-116
         const int R = (int)idx.size(), Tp = e.online_frames_per_chunk();
         std::vector<float> chunks((size_t)R * chunk_floats);
@@ -565,7 +593,6 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
         for (int r = 0; r < R; r++) {
             k2hip_online_stream* s = streams[idx[r]];
             memcpy(chunks.data() + (size_t)r * chunk_floats, s->speech.data(), sizeof(float) * chunk_floats);
-            s->speech.erase(s->speech.begin(), s->speech.begin() + shift_floats);   // RemoveChunk (:102-117)
             slots[r] = s->slot;
             hyps[2 * r] = s->hyp[0];
             hyps[2 * r + 1] = s->hyp[1];
@@ -577,8 +604,11 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
             std::lock_guard<std::mutex> lk(e.mutex());
             e.online_step(slots.data(), chunks.data(), hyps.data(), plens.data(), R, tok.data(), ts.data(), n.data());
         }
+        // RemoveChunk (:102-117) only now: if the step above threw (a HIP failure, a search timeout), every stream still holds
+        // its chunk and nothing host-side has moved -- the caller may retry or drop the streams
         for (int r = 0; r < R; r++) {
             k2hip_online_stream* s = streams[idx[r]];
+            s->speech.erase(s->speech.begin(), s->speech.begin() + shift_floats);
             for (int k = 0; k < n[r]; k++) {
                 s->tokens.push_back(tok[(size_t)r * Tp + k]);          // :183
                 s->timestamps.push_back(ts[(size_t)r * Tp + k]);       // :184 (chunk-relative frame index)
@@ -628,6 +658,13 @@ int32_t k2hip_online_stream_state(k2hip_online_stream_t* s, int32_t layer, int32
 }
 
 // ---- tuning hook (not part of include/k2hip.h): time one GEMM shape/config on random data
+int32_t k2hip_debug_set_switch(const char* env_name, int32_t value) {
+    return guard([&] {
+        NEED(env_name);
+        tunables_init_from_env();  // so that a later model creation does not overwrite what is set here
+        if (!tunables_set(env_name, value)) failf(K2HIP_ERR_INVALID, "unknown switch '%s'", env_name);
+    });
+}
 __attribute__((visibility("default"))) int32_t k2hip_debug_gemm(k2hip_model_t* model, int32_t M, int32_t N, int32_t K,
                                                                  int32_t act, int32_t with_res, int32_t cfg, int32_t iters, float* ms) {
     return guard([&] {

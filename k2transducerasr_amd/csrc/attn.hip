@@ -371,7 +371,7 @@ static void attn_scores_launch(const Ctx& ctx, const float* qkp, int ld, const f
                                int poff0) {
     int lds_stride = Tp + 4;  // rows 16 B aligned; +4 floats de-phases the 4-row-apart writers of one MFMA register
     size_t lds = sizeof(float) * (R * lds_stride + 4 * (T + R) + 4 * R);  // score strip + the positional window + the rows' p
-    static const bool force_long = getenv("K2HIP_ATTN_LONG") != nullptr;
+    const bool force_long = tunables().attn_long != 0;
     if (lds > 160 * 1024 || force_long) {  // > ~1120 frames: two-pass form without the LDS strip
         hipLaunchKernelGGL(k_attn_scores_softmax_long<NG>, dim3(cdiv(T, R), B, H), dim3(256), 0, ctx.stream, qkp, ld, pp, aw, B, T, Tp, H, koff0,
                            poff0);
@@ -404,7 +404,7 @@ void attn_scores_softmax(const Ctx& ctx, const float* qkp, int ld, const float* 
 bool attn_av_out(const Ctx& ctx, const float* aw, const float* v, const float* wout, const float* bias, float* x, int B, int T, int KL, int Tp,
                  int H, int vh, int D) {
     const int HV = H * vh, Tk = (KL + 63) & ~63;
-    const bool off = getenv("K2HIP_NO_FUSED_AV") != nullptr;  // read per call: the tests compare both paths in one process
+    const bool off = tunables().no_fused_av != 0;  // the tests compare both paths in one process (k2hip_debug_set_switch)
     if (off || vh > 16 || HV % 4 != 0 || HV > 128 || D % 16 != 0 || Tp % 4 != 0 || Tp < KL) return false;
     ctx.add_flops(0.0, 2.0 * B * (double)T * HV * (KL + D), 0);
     if (ctx.dry) return true;

@@ -12,23 +12,9 @@
 #include <vector>
 
 #include "../../include/k2hip.h"
+#include "errors.h"
 
 namespace k2hip {
-
-// Internal exception; converted to (status, last_error) at the ABI boundary.
-struct Error : std::runtime_error {
-    int32_t code;
-    Error(int32_t c, const std::string& m) : std::runtime_error(m), code(c) {}
-};
-
-[[noreturn]] inline void failf(int32_t code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    throw Error(code, buf);
-}
 
 #define K2_HIP(expr)                                                                                   \
     do {                                                                                               \
@@ -36,11 +22,6 @@ struct Error : std::runtime_error {
         if (_e != hipSuccess)                                                                          \
             ::k2hip::failf(K2HIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
                            __LINE__);                                                                  \
-    } while (0)
-
-#define K2_REQUIRE(cond, ...)                                        \
-    do {                                                             \
-        if (!(cond)) ::k2hip::failf(K2HIP_ERR_INVALID, __VA_ARGS__); \
     } while (0)
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: a host that opens one model per GPU in ONE process (the C ABI

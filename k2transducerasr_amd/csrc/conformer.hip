@@ -313,7 +313,7 @@ void conformer_qprep(const Ctx& ctx, const float* qkv, const float* bias_u, cons
 void conformer_softmax_shift(const Ctx& ctx, float* ac, const float* bd, int Z, int T, int Tp, int NPp) {
     if (ctx.dry) return;
     long long rows = (long long)Z * T;
-    static const bool force_long = getenv("K2HIP_ATTN_LONG") != nullptr;
+    const bool force_long = tunables().attn_long != 0;
     if (T > 64 * SM_PER_LANE || force_long) {
         hipLaunchKernelGGL(k_conformer_softmax_shift_long, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx.stream, ac, bd, rows, T, Tp, NPp);
         K2_HIP(hipGetLastError());
@@ -341,7 +341,7 @@ static bool conformer_scores_launch(const Ctx& ctx, const float* qu, const float
 bool conformer_scores_softmax(const Ctx& ctx, const float* qu, const float* qv, const float* kmat, int ldk, const float* pp, float* aw, int B, int H,
                               int T, int Tp, int D) {
     const int dk = D / H;
-    if (getenv("K2HIP_CONFORMER_GEMM_SCORES") || Tp % 4 != 0 || D % 4 != 0 || ldk % 4 != 0 || (dk != 16 && dk != 32 && dk != 64)) return false;
+    if (tunables().conformer_gemm_scores || Tp % 4 != 0 || D % 4 != 0 || ldk % 4 != 0 || (dk != 16 && dk != 32 && dk != 64)) return false;
     if (sizeof(float) * (size_t)CR * (Tp + 4) > 156 * 1024 || Tp > 64 * 20) return false;
     ctx.add_flops(0.0, 2.0 * dk * (double)T * (3.0 * T) * B * H, 0);
     if (ctx.dry) return true;

@@ -10,19 +10,24 @@ constexpr int kTailFrames = 19;  // PadHelper.cs:17
 }
 
 Engine::Engine(const std::string& weights, const char* overrides, int device) : device_(device) {
+    // the container is parsed and validated on the host first: a missing / truncated / mismatched file is K2HIP_ERR_IO
+    // whether or not a GPU is present
+    model_.reset(new Model(weights, overrides));
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         failf(K2HIP_ERR_NO_DEVICE, "no HIP device visible: libk2hip has no CPU fallback");
     if (device < 0 || device >= n) failf(K2HIP_ERR_NO_DEVICE, "device %d out of range (have %d)", device, n);
     K2_HIP(hipSetDevice(device));
-    model_.reset(new Model(weights, overrides, device));
+    model_->upload(device);
     K2_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     K2_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
-    if (const char* pm = getenv("K2HIP_PIPE_MODE")) pipe_mode_ = atoi(pm);
+    tunables_init_from_env();
+    pipe_mode_ = tunables().pipe_mode;
     for (auto& sl : slots_) {
         K2_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
         K2_HIP(hipEventCreateWithFlags(&sl.enc_done, hipEventDisableTiming));
         K2_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        K2_HIP(hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming));
     }
     for (auto& e : ev_) K2_HIP(hipEventCreate(&e));
 }
@@ -34,6 +39,7 @@ Engine::~Engine() {
     for (auto& sl : slots_) {
         if (sl.enc_done) (void)hipEventDestroy(sl.enc_done);
         if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.h2d_done) (void)hipEventDestroy(sl.h2d_done);
         if (sl.pin) (void)hipHostFree(sl.pin);
         if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
         sl.arena.release();
@@ -424,6 +430,10 @@ float* Engine::encoder_forward(const Ctx& c, const float* x, int B, int T, int* 
 // ---------------------------------------------------------------------------
 void Engine::greedy_device(const Ctx& c, const float* enc, int B, int Tp, bool single, long long* d_tok, int* d_ts, int* d_n,
                            int max_tokens, int* d_overflow) {
+    // by-products of the search this call runs, and of no earlier one (their arena may have been rebuilt since)
+    d_scores_ = nullptr;
+    d_trail_ = nullptr;
+    d_any_ = nullptr;
     if (model_->cfg().ctc) {
         ctc_device(c, enc, B, Tp, d_tok, d_ts, d_n, max_tokens, d_overflow);
         return;
@@ -825,7 +835,19 @@ void Engine::offline_greedy_samples(const float* const* samples, const int64_t* 
 }
 
 int Engine::submit_samples_dev(const float* samples_dev, int64_t n_each, int B, int max_tokens) {
-    K2_REQUIRE(B > 0 && max_tokens > 0 && samples_dev != nullptr, "offline_submit: bad arguments");
+    K2_REQUIRE(samples_dev != nullptr, "offline_submit: bad arguments");
+    return submit_impl(samples_dev, nullptr, n_each, B, max_tokens);
+}
+int Engine::submit_samples_host(const float* samples_host, int64_t n_each, int B, int max_tokens) {
+    K2_REQUIRE(samples_host != nullptr, "offline_submit: bad arguments");
+    return submit_impl(nullptr, samples_host, n_each, B, max_tokens);
+}
+
+// samples_host != nullptr: the batch's samples are still in host memory ([B, n_each] f32, ideally pinned: k2hip_host_alloc).
+// The H2D copy goes on the slot's own stream, so it runs under the previous batch's encoder, and the encoder stream waits
+// for it through an event -- PCIe is inside the pipeline, not in front of it.
+int Engine::submit_impl(const float* samples_dev, const float* samples_host, int64_t n_each, int B, int max_tokens) {
+    K2_REQUIRE(B > 0 && max_tokens > 0, "offline_submit: bad arguments");
     const Config& cf = model_->cfg();
     const FbankOpts& f = cf.fbank;
     K2_REQUIRE(cf.ctc || cf.J == 512, "offline loops hard-code a 512-wide encoder_out; joiner_dim is %d", cf.J);
@@ -857,10 +879,23 @@ int Engine::submit_samples_dev(const float* samples_dev, int64_t n_each, int B, 
             sl.d_ovf = ar.take<int>(1);
             float* d_feats = ar.take<float>((int64_t)B * n_fl);
             float* d_x = ar.take<float>((int64_t)B * L);
-            FbankArgs a{samples_dev, n_each, n_each, B, nf, d_feats, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift,
+            const float* src = samples_dev;
+            if (samples_host) {
+                float* d_s = ar.take<float>((int64_t)B * n_each);
+                src = d_s;
+                if (!c.dry) {
+                    hipStream_t cs = own ? c.stream : sl.stream;
+                    K2_HIP(hipMemcpyAsync(d_s, samples_host, sizeof(float) * (size_t)B * n_each, hipMemcpyHostToDevice, cs));
+                    if (!own) {
+                        K2_HIP(hipEventRecord(sl.h2d_done, cs));
+                        K2_HIP(hipStreamWaitEvent(c.stream, sl.h2d_done, 0));
+                    }
+                }
+            }
+            FbankArgs a{src, n_each, n_each, B, nf, d_feats, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift,
                         f.preemph, f.input_scale, f.remove_dc};
             a.melrange = model_->d_melrange;
-        fbank(c, a);
+            fbank(c, a);
             pad_logfloor_dense(c, d_feats, n_fl, d_x, B, L);
             int Tp = 0;
             float* enc = encoder_forward(c, d_x, B, T, &Tp, -1, nullptr, nullptr, nullptr);
@@ -902,8 +937,9 @@ void Engine::wait_ticket(int ticket, int64_t* tokens, int32_t* ts, int32_t* n_to
     sl.busy = false;
     const int64_t nb_tok = (int64_t)sl.B * sl.max_tokens * 8, nb_ts = (int64_t)sl.B * sl.max_tokens * 4, nb_n = (int64_t)sl.B * 4;
     const char* pin = static_cast<const char*>(sl.pin);
-    if (*reinterpret_cast<const int*>(pin + nb_tok + nb_ts + nb_n))
-        failf(K2HIP_ERR_CAPACITY, "a stream emitted more than max_tokens=%d symbols", sl.max_tokens);
+    const int ovf = *reinterpret_cast<const int*>(pin + nb_tok + nb_ts + nb_n);
+    if (ovf == 2) failf(K2HIP_ERR_HIP, "greedy search: the vocabulary-parallel exchange timed out (a workgroup never arrived)");
+    if (ovf) failf(K2HIP_ERR_CAPACITY, "a stream emitted more than max_tokens=%d symbols", sl.max_tokens);
     memcpy(tokens, pin, nb_tok);
     memcpy(ts, pin + nb_tok, nb_ts);
     memcpy(n_tokens, pin + nb_tok + nb_ts, nb_n);
@@ -951,6 +987,16 @@ void Engine::dev_free(void* p) {
 void Engine::dev_upload(void* dst, const void* src, int64_t bytes) {
     K2_HIP(hipSetDevice(device_));
     K2_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+}
+void* Engine::host_alloc(int64_t bytes) {
+    K2_HIP(hipSetDevice(device_));
+    void* p = nullptr;
+    K2_HIP(hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault));
+    return p;
+}
+void Engine::host_free(void* p) {
+    K2_HIP(hipSetDevice(device_));
+    K2_HIP(hipHostFree(p));
 }
 void Engine::synchronize() {
     K2_HIP(hipSetDevice(device_));

@@ -65,6 +65,7 @@ class Engine {
     // encoder of batch i+1.  At most kSlots batches may be outstanding.
     static constexpr int kSlots = 2;
     int submit_samples_dev(const float* samples_dev, int64_t n_each, int B, int max_tokens);
+    int submit_samples_host(const float* samples_host, int64_t n_each, int B, int max_tokens);
     void wait_ticket(int ticket, int64_t* tokens, int32_t* ts, int32_t* n_tokens);
 
     // ---- streaming (OnlineRecognizer) path: online_engine.cpp ----
@@ -92,6 +93,8 @@ class Engine {
     void* dev_alloc(int64_t bytes);
     void dev_free(void* p);
     void dev_upload(void* dst, const void* src, int64_t bytes);
+    void* host_alloc(int64_t bytes);
+    void host_free(void* p);
     void synchronize();
 
   private:
@@ -148,6 +151,7 @@ class Engine {
     // run `body` once dry to size the arena, then for real
     template <typename F>
     void run_sized(F&& body);
+    int submit_impl(const float* samples_dev, const float* samples_host, int64_t n_each, int B, int max_tokens);
     void finish_tokens(const long long* d_tok, const int* d_ts, const int* d_n, const int* d_ovf, int B, int max_tokens,
                        int64_t* tokens, int32_t* ts, int32_t* n_tokens);
     Ctx make_ctx(bool dry);
@@ -159,7 +163,7 @@ class Engine {
     Arena* cur_arena_ = &arena_;
     struct Slot {
         Arena arena;
-        hipEvent_t enc_done = nullptr, done = nullptr;
+        hipEvent_t enc_done = nullptr, done = nullptr, h2d_done = nullptr;
         hipStream_t stream = nullptr;  // pipe mode 1: the slot's whole pipeline (fbank .. search .. D2H) runs here
         void* pin = nullptr;
         int64_t pin_cap = 0;

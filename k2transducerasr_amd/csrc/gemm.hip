@@ -588,7 +588,7 @@ void launch_mode(const Ctx& ctx, const GemmArgs& a, int cfg) {
     }
 }
 
-int g_forced_cfg = getenv("K2HIP_GEMM_CFG") ? atoi(getenv("K2HIP_GEMM_CFG")) : -1;  // tuning only
+int g_forced_cfg = -1;  // debug_force_gemm_cfg (tuning hook); K2HIP_GEMM_CFG comes through tunables()
 
 // Tile choice, from tools/gemm_tune.py on the benchmark's shapes (gpurun_out/gemm_tune_*.txt):
 // on this path K is short (192..2560), so a launch is dominated by how well the prologue /
@@ -599,6 +599,7 @@ int g_forced_cfg = getenv("K2HIP_GEMM_CFG") ? atoi(getenv("K2HIP_GEMM_CFG")) : -
 //   cfg 2:  64x64,  4 waves (32x32 per wave)
 int choose_cfg(const GemmArgs& a) {
     if (g_forced_cfg >= 0) return g_forced_cfg;
+    if (tunables().gemm_cfg >= 0) return tunables().gemm_cfg;
     if (a.N <= 64) return 2;    // 64x64 tiles, 4 waves
     if (a.M <= 64) return 3;    // a handful of rows (per-frame recurrent products, batched over layers): 64x64 tiles, K step 64
     // few output tiles (streaming chunks: 256..2048 rows): the launch is one latency-bound K sweep per
@@ -623,9 +624,9 @@ int choose_cfg(const GemmArgs& a) {
 }  // namespace
 
 int g_ablate = 0;
-int g_use_dma = getenv("K2HIP_GEMM_NO_DMA") ? 0 : 1;
+int g_use_dma = 1;
 void debug_force_gemm_cfg(int cfg) {
-    static const int dma_default = g_use_dma;
+    const int dma_default = 1;
     g_forced_cfg = cfg < 0 ? -1 : (cfg & 0x3f);
     g_ablate = cfg < 0 ? 0 : (cfg >> 8);
     g_use_dma = (cfg >= 0 && (cfg & 0x40)) ? 0 : dma_default;  // +64: classic (register-staged) kernel
@@ -652,11 +653,12 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         ctx.gemm_log->push_back({a.M, a.N, a.K, a.nb0 * a.nb1, a.act, a.res != nullptr, a.cv_Fout > 0 ? 1 : (a.w_kn ? 2 : 0), 0.f});
     // (a) N <= 96: few columns; (b) small problems (streaming chunks, beam search: a 128x64 grid would leave most CUs idle and
     // every workgroup would walk K serially): the same kernel over column chunks of 96
-    static const bool no_skinny = getenv("K2HIP_GEMM_NO_SKINNY") != nullptr;
+    const Tunables& tn = tunables();
+    const bool no_skinny = tn.gemm_no_skinny != 0, forced = g_forced_cfg >= 0 || tn.gemm_cfg >= 0, use_dma = g_use_dma && !tn.gemm_no_dma;
     const bool plain = a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.K % 64 == 0 && a.K >= 64;
     // (16-row workgroups re-read the weight chunk M/16 times: with many rows and a short K the 64x64 tiles are better)
     const bool few_tiles = (long long)cdiv(a.M, 128) * cdiv(a.N, 64) < 144 && a.M <= 4096 && !(a.M >= 2048 && a.K <= 256 && a.N > 272);
-    const bool skinny_ok = g_forced_cfg < 0 && !no_skinny && plain && !a.mul && ((a.N <= 96 && a.M >= 512) || few_tiles);
+    const bool skinny_ok = !forced && !no_skinny && plain && !a.mul && ((a.N <= 96 && a.M >= 512) || few_tiles);
     if (skinny_ok) {
         if (a.N <= 48) hipLaunchKernelGGL(gemm_f32_mfma_skinny<3>, dim3(cdiv(a.M, 16), 1), dim3(256), 0, ctx.stream, b);
         else if (a.K % 128 == 0 && ((a.K >= 1024 && (long long)cdiv(a.M, 16) * cdiv(a.N, 96) <= 384) ||
@@ -669,7 +671,7 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         return;
     }
     const bool dma_ok = a.cv_Fout == 0 && !a.w_kn && a.K % 32 == 0 && a.K >= 64 && a.lda % 4 == 0 && !a.mul && a.res_div == 1 && !a.act_after_res;
-    if (dma_ok && g_use_dma && g_forced_cfg < 0 && a.nb0 * a.nb1 > 1 && a.M <= 64) {
+    if (dma_ok && use_dma && !forced && a.nb0 * a.nb1 > 1 && a.M <= 64) {
         // a handful of rows against many layers' weight matrices (LSTM wavefront): a weight-streaming problem -- 64x64 tiles, three
         // 16 KB stages in flight per workgroup
         // enough workgroups to keep ~3 per CU streaming (bytes in flight are what sets the rate): 32-column tiles when 64-column
@@ -682,13 +684,13 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         return;
     }
     // (batched launches too -- the Conformer's per-(head, stream) score products -- as long as the tile choice is one of the DMA kernel's)
-    if (dma_ok && g_use_dma && (cfg == 5 || cfg == 0 || (cfg >= 7 && cfg <= 11))) {
+    if (dma_ok && use_dma && (cfg == 5 || cfg == 0 || (cfg >= 7 && cfg <= 11))) {
         if (cfg == 11) launch_dma<64, 96, 32, 32, 2>(ctx, b);        // 64x96 tiles (6 waves): N % 96 == 0 outputs that 128x64 quantises badly
         else if (cfg == 9) launch_dma<64, 64, 32, 32, 2>(ctx, b);    // tuning: 64x64 tiles, 2 stages
         else if (cfg == 10) launch_dma<64, 64, 32, 32, 3>(ctx, b);   // tuning: 64x64 tiles, 3 stages
         else if (cfg == 7) launch_dma<128, 64, 32, 32, 2>(ctx, b);  // tuning: 2 stages, 3 workgroups per CU
         else if (cfg == 8) launch_dma<128, 64, 32, 32, 4>(ctx, b);  // tuning: 4 stages, 1 workgroup per CU
-        else if (cfg == 5 && !getenv("K2HIP_GEMM_NST3")) launch_dma<128, 64, 32, 32, 2>(ctx, b);  // 2 stages: 3 workgroups per CU
+        else if (cfg == 5 && !tn.gemm_nst3) launch_dma<128, 64, 32, 32, 2>(ctx, b);  // 2 stages: 3 workgroups per CU
         else if (cfg == 5) launch_dma<128, 64, 32, 32>(ctx, b);
         else launch_dma<128, 128, 64, 32>(ctx, b);
         K2_HIP(hipGetLastError());

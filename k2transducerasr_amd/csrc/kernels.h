@@ -6,6 +6,28 @@
 
 namespace k2hip {
 
+// Development switches (tunables.cpp): the K2HIP_* environment read once at the first model creation.
+struct Tunables {
+    int gemm_cfg = -1;            // K2HIP_GEMM_CFG: force one tile configuration (tuning)
+    int gemm_no_dma = 0;          // K2HIP_GEMM_NO_DMA: register-staged kernels only
+    int gemm_no_skinny = 0;       // K2HIP_GEMM_NO_SKINNY
+    int gemm_nst3 = 0;            // K2HIP_GEMM_NST3: three-stage ring for the 128x64 LDS-DMA kernel
+    int gemm_v1 = 0;              // K2HIP_GEMM_V1: the round-1 LDS-DMA pipeline (barrier at the top of every K step)
+    int attn_long = 0;            // K2HIP_ATTN_LONG: two-pass attention scores for every length
+    int no_fused_av = 0;          // K2HIP_NO_FUSED_AV: attention apply + out_proj as two GEMMs
+    int conformer_gemm_scores = 0;  // K2HIP_CONFORMER_GEMM_SCORES: two batched GEMMs + gather/softmax
+    int dw7_simple = 0;           // K2HIP_DW7_SIMPLE: untiled 7x7 depthwise convolution
+    int lstm_seq = 0;             // K2HIP_LSTM_SEQ: layer-by-layer LSTM instead of the layer wavefront
+    int greedy_one_part = 0;      // K2HIP_GREEDY_ONE_PART: one workgroup per stream in the search
+    int greedy_parts = 0;         // K2HIP_GREEDY_PARTS: vocabulary slabs per stream (0 = automatic)
+    int pipe_mode = 0;            // K2HIP_PIPE_MODE: 1 = every pipeline slot owns a stream
+    int max_streams = 0;          // K2HIP_MAX_STREAMS: slots of the streaming state pool (0 = 256)
+    int online_split = 0;         // K2HIP_ONLINE_SPLIT: 1 = never split a chunk step over two HIP streams, 2 = always (0 = automatic)
+};
+void tunables_init_from_env();            // idempotent; called by k2hip_model_create
+const Tunables& tunables();
+bool tunables_set(const char* env_name, int value);  // test hook (k2hip_debug_set_switch)
+
 struct GemmStats {
     double flops = 0;       // algorithmic, 2*M*N*K per launch
     double total_flops = 0; // + non-GEMM matrix work (attention scores, convs)

@@ -133,7 +133,7 @@ float* Engine::lstm_forward(const Ctx& c, const float* x, int B, int T, int* Tp,
                                    "norm_final.eps"};
     const float* base[10];
     long long LS = 0;
-    bool even = !getenv("K2HIP_LSTM_SEQ");
+    bool even = !tunables().lstm_seq;
     for (int k = 0; k < 10 && even; k++) {
         base[k] = m.wf("encoder.encoder.layers.0.%s", kNames[k]);
         for (int l = 1; l < L && even; l++) {

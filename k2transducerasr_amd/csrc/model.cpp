@@ -1,10 +1,5 @@
 #include "model.h"
 
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <unistd.h>
-
 #include <cmath>
 #include <cstdlib>
 
@@ -25,46 +20,16 @@ std::vector<int> csv_ints(const std::string& s) {
     return v;
 }
 
-template <typename T>
-T rd(const uint8_t* p, size_t& q) {
-    T v;
-    memcpy(&v, p + q, sizeof(T));
-    q += sizeof(T);
-    return v;
-}
-
 // MelScale in f64 (rounded once to f32 below): see add_repacks
 double mel_scale(double f) { return 1127.0 * log(1.0 + f / 700.0); }
 
 }  // namespace
 
-Model::Model(const std::string& path, const char* overrides, int device) : device_(device) {
-    int fd = open(path.c_str(), O_RDONLY);
-    if (fd < 0) failf(K2HIP_ERR_IO, "cannot open weights file %s", path.c_str());
-    struct stat st;
-    fstat(fd, &st);
-    map_size_ = (size_t)st.st_size;
-    map_ = mmap(nullptr, map_size_, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (map_ == MAP_FAILED) {
-        map_ = nullptr;
-        failf(K2HIP_ERR_IO, "mmap failed for %s", path.c_str());
-    }
-    const uint8_t* p = static_cast<const uint8_t*>(map_);
-    if (map_size_ < 24 || memcmp(p, "K2W1", 4) != 0) failf(K2HIP_ERR_IO, "%s: not a K2W1 container", path.c_str());
-    size_t q = 4;
-    uint32_t version = rd<uint32_t>(p, q), n_meta = rd<uint32_t>(p, q), n_tensors = rd<uint32_t>(p, q);
-    uint64_t data_off = rd<uint64_t>(p, q);
-    if (version != 1) failf(K2HIP_ERR_IO, "%s: unsupported K2W version %u", path.c_str(), version);
-    for (uint32_t i = 0; i < n_meta; i++) {
-        uint32_t kl = rd<uint32_t>(p, q), vl = rd<uint32_t>(p, q);
-        if (q + kl + vl > map_size_) failf(K2HIP_ERR_IO, "%s: truncated metadata", path.c_str());
-        std::string k((const char*)p + q, kl);
-        q += kl;
-        std::string v((const char*)p + q, vl);
-        q += vl;
-        meta_[k] = v;
-    }
+Model::Model(const std::string& path, const char* overrides) {
+    // Every resource acquired below is owned by a member (file_: mmap, blob_: device memory), so a throw anywhere in this
+    // constructor releases them (members are destroyed; ~Model itself does not run for a half-built object).
+    file_.reset(new K2wFile(path));
+    meta_ = file_->meta;
     if (overrides && *overrides) {
         std::string s(overrides);
         size_t a = 0;
@@ -78,50 +43,40 @@ Model::Model(const std::string& path, const char* overrides, int device) : devic
             a = b + 1;
         }
     }
-    struct Raw {
-        std::string name;
-        int ndim;
-        int64_t dims[4];
-        uint64_t off, nbytes;
-    };
-    std::vector<Raw> raws;
-    for (uint32_t i = 0; i < n_tensors; i++) {
-        uint32_t nl = rd<uint32_t>(p, q);
-        Raw r;
-        r.name.assign((const char*)p + q, nl);
-        q += nl;
-        uint32_t dtype = rd<uint32_t>(p, q);
-        r.ndim = (int)rd<uint32_t>(p, q);
-        for (int k = 0; k < 4; k++) r.dims[k] = (int64_t)rd<uint64_t>(p, q);
-        r.off = rd<uint64_t>(p, q);
-        r.nbytes = rd<uint64_t>(p, q);
-        if (dtype != 0) failf(K2HIP_ERR_IO, "%s: tensor %s has unsupported dtype %u", path.c_str(), r.name.c_str(), dtype);
-        if (data_off + r.off + r.nbytes > map_size_) failf(K2HIP_ERR_IO, "%s: tensor %s out of file bounds", path.c_str(), r.name.c_str());
-        raws.push_back(r);
-    }
-    for (auto& r : raws) {
+    const uint8_t* data = file_->data();
+    // tensors the engine never reads (an ONNX export's int64 shape constants that slipped through an importer) stay in
+    // the table but are not views: only f32 entries become Tensors
+    for (const K2wTensorRec& r : file_->tensors) {
+        if (r.dtype != 0) continue;
         Tensor t;
         t.ndim = r.ndim;
         for (int k = 0; k < 4; k++) t.dims[k] = r.dims[k];
-        t.host = reinterpret_cast<const float*>(p + data_off + r.off);
+        t.host = reinterpret_cast<const float*>(data + r.off);
         t_[r.name] = t;
     }
     parse_config();
+    validate_shapes();  // before anything indexes a tensor by the CONFIG's dimensions
+    add_repacks(extra_, extra_shapes_);  // repacked copies (host side)
+}
 
-    // repacked copies
-    std::vector<std::pair<std::string, std::vector<float>>> extra;
-    std::vector<std::pair<std::string, std::vector<int64_t>>> shapes;
-    add_repacks(extra, shapes);
-
+// Second phase: everything above is host-only, so a bad container is reported (K2HIP_ERR_IO / _INVALID) on a machine without a
+// GPU too; the upload needs the device.
+void Model::upload(int device) {
+    device_ = device;
+    auto& extra = extra_;
+    auto& shapes = extra_shapes_;
+    const uint8_t* data = file_->data();
     // device upload: [file data region | repacks]
     K2_HIP(hipSetDevice(device_));
-    size_t file_bytes = map_size_ - data_off;
+    size_t file_bytes = file_->data_bytes();
     size_t extra_bytes = 0;
     for (auto& e : extra) extra_bytes += (size_t)align_up((int64_t)e.second.size() * 4, 256);
     size_t total = (size_t)align_up((int64_t)file_bytes, 256) + extra_bytes;
-    K2_HIP(hipMalloc(&dev_blob_, total));
-    K2_HIP(hipMemcpy(dev_blob_, p + data_off, file_bytes, hipMemcpyHostToDevice));
-    for (auto& r : raws) t_[r.name].dev = reinterpret_cast<float*>(static_cast<char*>(dev_blob_) + r.off);
+    blob_.alloc(device_, total);
+    void* dev_blob_ = blob_.p;
+    K2_HIP(hipMemcpy(dev_blob_, data, file_bytes, hipMemcpyHostToDevice));
+    for (const K2wTensorRec& r : file_->tensors)
+        if (r.dtype == 0) t_[r.name].dev = reinterpret_cast<float*>(static_cast<char*>(dev_blob_) + r.off);
     size_t off = (size_t)align_up((int64_t)file_bytes, 256);
     for (size_t i = 0; i < extra.size(); i++) {
         auto& e = extra[i];
@@ -138,14 +93,52 @@ Model::Model(const std::string& path, const char* overrides, int device) : devic
     d_window = w("#fbank.window");
     d_melw = w("#fbank.melw");
     d_melrange = w("#fbank.melrange");
+    extra_.clear();
+    extra_shapes_.clear();
 }
 
-Model::~Model() {
-    if (dev_blob_) {
-        (void)hipSetDevice(device_);
-        (void)hipFree(dev_blob_);
+Model::~Model() = default;  // file_ unmaps, blob_ frees
+
+void Model::DevBlob::alloc(int device, size_t bytes) {
+    dev = device;
+    K2_HIP(hipMalloc(&p, bytes));
+}
+Model::DevBlob::~DevBlob() {
+    if (p) {
+        (void)hipSetDevice(dev);
+        (void)hipFree(p);
     }
-    if (map_) munmap(map_, map_size_);
+}
+
+// The tensors whose shapes the kernels take from the CONFIG (metadata) rather than from the tensor: a container whose
+// metadata and weights disagree must fail here (K2HIP_ERR_IO), not read out of bounds on the device.
+void Model::validate_shapes() const {
+    const Config& c = cfg_;
+    auto want = [&](const char* name, std::initializer_list<int64_t> dims) {
+        if (!has(name)) return;
+        const Tensor& t = tensor(name);
+        bool ok = t.ndim == (int)dims.size();
+        int k = 0;
+        for (int64_t d : dims) ok = ok && t.dims[k++] == d;
+        if (!ok)
+            failf(K2HIP_ERR_IO, "tensor %s is [%lld,%lld,%lld,%lld] (ndim %d), which does not match the metadata", name, (long long)t.dims[0],
+                  (long long)t.dims[1], (long long)t.dims[2], (long long)t.dims[3], t.ndim);
+    };
+    want("decoder.embedding.weight", {c.V, c.DD});
+    want("joiner.decoder_proj.weight", {c.J, c.DD});
+    want("joiner.decoder_proj.bias", {c.J});
+    want("joiner.output_linear.weight", {c.V, c.J});
+    want("joiner.output_linear.bias", {c.V});
+    want("joiner.encoder_proj.bias", {c.J});
+    if (has("joiner.encoder_proj.weight")) {
+        const Tensor& t = tensor("joiner.encoder_proj.weight");
+        if (t.ndim != 2 || t.dims[0] != c.J) failf(K2HIP_ERR_IO, "joiner.encoder_proj.weight has %lld rows, joiner_dim is %d", (long long)t.dims[0], c.J);
+    }
+    if (c.ctc) {
+        want("ctc_output.1.bias", {c.V});
+        if (has("ctc_output.1.weight") && tensor("ctc_output.1.weight").dims[0] != c.V)
+            failf(K2HIP_ERR_IO, "ctc_output.1.weight has %lld rows, vocab_size is %d", (long long)tensor("ctc_output.1.weight").dims[0], c.V);
+    }
 }
 
 const Tensor& Model::tensor(const std::string& name) const {

@@ -10,7 +10,10 @@
 #include <string>
 #include <unordered_map>
 
+#include <memory>
+
 #include "common.h"
+#include "k2w_file.h"
 
 namespace k2hip {
 
@@ -63,7 +66,8 @@ struct Config {
 
 class Model {
   public:
-    Model(const std::string& path, const char* overrides, int device);
+    Model(const std::string& path, const char* overrides);  // host only: parse, validate, repack
+    void upload(int device);                                 // copy everything into HBM of `device`
     ~Model();
     Model(const Model&) = delete;
     Model& operator=(const Model&) = delete;
@@ -87,10 +91,17 @@ class Model {
     void parse_config();
     void add_repacks(std::vector<std::pair<std::string, std::vector<float>>>& extra,
                      std::vector<std::pair<std::string, std::vector<int64_t>>>& shapes);
-    int device_;
-    void* map_ = nullptr;
-    size_t map_size_ = 0;
-    void* dev_blob_ = nullptr;
+    void validate_shapes() const;
+    int device_ = -1;
+    std::vector<std::pair<std::string, std::vector<float>>> extra_;            // repacks waiting for upload()
+    std::vector<std::pair<std::string, std::vector<int64_t>>> extra_shapes_;
+    std::unique_ptr<K2wFile> file_;  // the mapped container (host views of the tensors point into it)
+    struct DevBlob {                 // [file data region | repacked tensors] in HBM
+        void* p = nullptr;
+        int dev = 0;
+        void alloc(int device, size_t bytes);
+        ~DevBlob();
+    } blob_;
     std::map<std::string, std::string> meta_;
     std::unordered_map<std::string, Tensor> t_;
     std::vector<std::vector<float>> host_keep_;

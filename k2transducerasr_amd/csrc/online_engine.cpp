@@ -19,7 +19,7 @@ void Engine::online_ensure_pool() {
         L.nl = c.nlayer[0];
         L.floats_per_stream = ((long long)c.nlayer[0] * (c.left[0] + c.kern[0] - 1) * c.dim[0] + 63) / 64 * 64;
         online_cap_ = 256;
-        if (const char* e = getenv("K2HIP_MAX_STREAMS")) online_cap_ = std::max(1, atoi(e));
+        if (tunables().max_streams > 0) online_cap_ = tunables().max_streams;
         K2_HIP(hipSetDevice(device_));
         K2_HIP(hipMalloc(&online_pool_, sizeof(float) * (size_t)L.floats_per_stream * online_cap_));
         for (int i = online_cap_ - 1; i >= 0; i--) free_slots_.push_back(i);
@@ -29,7 +29,7 @@ void Engine::online_ensure_pool() {
         L.nl = c.nlayer[0];
         L.floats_per_stream = ((long long)c.nlayer[0] * (c.dim[0] + c.rnn_hidden) + 63) / 64 * 64;
         online_cap_ = 256;
-        if (const char* e = getenv("K2HIP_MAX_STREAMS")) online_cap_ = std::max(1, atoi(e));
+        if (tunables().max_streams > 0) online_cap_ = tunables().max_streams;
         K2_HIP(hipSetDevice(device_));
         K2_HIP(hipMalloc(&online_pool_, sizeof(float) * (size_t)L.floats_per_stream * online_cap_));
         for (int i = online_cap_ - 1; i >= 0; i--) free_slots_.push_back(i);
@@ -55,7 +55,7 @@ void Engine::online_ensure_pool() {
             }
         L.floats_per_stream = (off + 63) / 64 * 64;
         online_cap_ = 256;
-        if (const char* e = getenv("K2HIP_MAX_STREAMS")) online_cap_ = std::max(1, atoi(e));
+        if (tunables().max_streams > 0) online_cap_ = tunables().max_streams;
         K2_HIP(hipSetDevice(device_));
         K2_HIP(hipMalloc(&online_pool_, sizeof(float) * (size_t)L.floats_per_stream * online_cap_));
         for (int i = online_cap_ - 1; i >= 0; i--) free_slots_.push_back(i);
@@ -79,7 +79,7 @@ void Engine::online_ensure_pool() {
     off += 128 * 3 * 19;
     L.floats_per_stream = (off + 63) / 64 * 64;
     online_cap_ = 256;
-    if (const char* e = getenv("K2HIP_MAX_STREAMS")) online_cap_ = std::max(1, atoi(e));
+    if (tunables().max_streams > 0) online_cap_ = tunables().max_streams;
     K2_HIP(hipSetDevice(device_));
     K2_HIP(hipMalloc(&online_pool_, sizeof(float) * (size_t)L.floats_per_stream * online_cap_));
     for (int i = online_cap_ - 1; i >= 0; i--) free_slots_.push_back(i);

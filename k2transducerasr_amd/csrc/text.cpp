@@ -19,7 +19,7 @@
 #include <string>
 #include <vector>
 
-#include "common.h"
+#include "errors.h"
 #include "text.h"
 
 namespace k2hip {
@@ -280,5 +280,10 @@ std::string decode_tokens(const TokenTable& tab, const int64_t* ids, int n, bool
     for (uint32_t& c : cp) c = to_lower(c);
     return utf8_encode(cp);
 }
+
+// BYTE_TO_BCHAR / BCHAR_TO_BYTE of the reference (ByteDataHelper.cs:27-306) as this file generates them; pinned against the
+// reference's own 256-entry table by tests/test_text.py::test_bbpe_alphabet_equals_reference_table
+int bbpe_char_of_byte(int b) { return (b < 0 || b > 255) ? -1 : (int)alphabet().b2c[b]; }
+int bbpe_byte_of_char(uint32_t cp) { return alphabet().byte_of(cp); }
 
 }  // namespace k2hip

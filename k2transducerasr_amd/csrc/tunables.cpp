@@ -1,0 +1,57 @@
+// Development switches of libk2hip.  They select alternative kernels for the same math (used by the parity tests to compare
+// both paths) or tuning variants.  The K2HIP_* environment is read exactly ONCE, when the first model of the process is created;
+// after that the launch paths only read this struct (no libc lookups per launch, no behaviour change from a setenv mid-run).
+// k2hip_debug_set_switch is the test-only way to flip one afterwards.
+#include <cstdlib>
+#include <cstring>
+
+#include "kernels.h"
+
+namespace k2hip {
+
+namespace {
+Tunables g_t;
+bool g_init = false;
+struct Entry {
+    const char* env;
+    int Tunables::*field;
+    bool flag;  // presence of the variable means 1
+};
+const Entry kEntries[] = {
+    {"K2HIP_GEMM_CFG", &Tunables::gemm_cfg, false},
+    {"K2HIP_GEMM_NO_DMA", &Tunables::gemm_no_dma, true},
+    {"K2HIP_GEMM_NO_SKINNY", &Tunables::gemm_no_skinny, true},
+    {"K2HIP_GEMM_NST3", &Tunables::gemm_nst3, true},
+    {"K2HIP_GEMM_V1", &Tunables::gemm_v1, true},
+    {"K2HIP_ATTN_LONG", &Tunables::attn_long, true},
+    {"K2HIP_NO_FUSED_AV", &Tunables::no_fused_av, true},
+    {"K2HIP_CONFORMER_GEMM_SCORES", &Tunables::conformer_gemm_scores, true},
+    {"K2HIP_DW7_SIMPLE", &Tunables::dw7_simple, true},
+    {"K2HIP_LSTM_SEQ", &Tunables::lstm_seq, true},
+    {"K2HIP_GREEDY_ONE_PART", &Tunables::greedy_one_part, true},
+    {"K2HIP_GREEDY_PARTS", &Tunables::greedy_parts, false},
+    {"K2HIP_PIPE_MODE", &Tunables::pipe_mode, false},
+    {"K2HIP_MAX_STREAMS", &Tunables::max_streams, false},
+    {"K2HIP_ONLINE_SPLIT", &Tunables::online_split, false},
+};
+}  // namespace
+
+void tunables_init_from_env() {
+    if (g_init) return;
+    g_init = true;
+    for (const Entry& e : kEntries)
+        if (const char* v = getenv(e.env)) g_t.*(e.field) = e.flag ? 1 : atoi(v);
+}
+
+const Tunables& tunables() { return g_t; }
+
+bool tunables_set(const char* env_name, int value) {
+    for (const Entry& e : kEntries)
+        if (!strcmp(e.env, env_name)) {
+            g_t.*(e.field) = value;
+            return true;
+        }
+    return false;
+}
+
+}  // namespace k2hip

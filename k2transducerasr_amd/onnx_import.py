@@ -250,7 +250,9 @@ def import_onnx(paths: List[str], out_path: str, extra_meta: Dict[str, str] | No
     for k, a in tensors.items():
         if a.dtype in (np.float16, np.float64):
             a = a.astype(np.float32)
-        if a.dtype == np.float32 or a.dtype == np.int64:
+        # the engine computes in f32 and reads nothing else: integer initializers of an export (int64 shape / axes constants such as
+        # '/encoder/encoders.0/Constant_output_0') are listed, not stored
+        if a.dtype == np.float32:
             keep[k] = a if a.ndim > 0 else a.reshape(1)
         else:
             unmapped.append(k + f" (dtype {a.dtype})")

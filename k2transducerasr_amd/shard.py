@@ -21,6 +21,16 @@ def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def batches_of(lo: int, hi: int, batch: int) -> List[Tuple[int, int]]:
+    """The GetResults batches of one shard: consecutive runs of `batch` utterances, [(first id, count)].  A shard is
+    decoded exactly as the reference would decode these lists (padding length and the first-emission context switch are
+    per batch, OfflineRecognizer.cs:213-216,278-286), so the same (total, world, batch) always gives the same batches
+    whichever process runs them."""
+    if batch <= 0:
+        raise ValueError("batch must be positive")
+    return [(a, min(batch, hi - a)) for a in range(lo, hi, batch)]
+
+
 def gather_results(dist, local: Sequence, world: int, rank: int) -> List:
     """Concatenate per-rank result lists in rank order on every rank (host-side, tiny)."""
     if dist is None or world == 1:

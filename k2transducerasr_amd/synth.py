@@ -20,10 +20,10 @@ AUDIO_SEED_BASE = 0x2A50000
 # Joiner blank-bias per preset, frozen from tools/calibrate_blank_bias.py so that
 # roughly a quarter to a tenth of the frames emit a symbol on synth_utterance().
 BLANK_BIAS = {
-    "zipformer2-large-en": 3.656,
+    "zipformer2-large-en": 3.551,     # tools/calibrate_blank_bias.py: ~20 % of the frames of 10 s utterances emit under greedy
     "zipformer2-small-en": 2.849,
     "zipformer2-tiny-test": 1.033,
-    "zipformer2-streaming-zh": 3.0,
+    "zipformer2-streaming-zh": 2.261,  # ~20 % emission under the online greedy loop
     "zipformer2-streaming-tiny-test": 1.0,
     "conformer-zh": 2.615,
     "conformer-streaming-zh": 2.615,

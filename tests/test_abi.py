@@ -108,3 +108,36 @@ def test_header_is_plain_c_and_a_c_host_links(tmp_path):
     subprocess.run([gcc, "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), "-L", lib, "-lk2hip", "-Wl,-rpath," + lib], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, env={**os.environ, "LD_LIBRARY_PATH": lib + ":" + os.environ.get("LD_LIBRARY_PATH", "")})
     assert out.returncode == 0 and out.stdout.strip()
+
+
+def test_bad_containers_are_io_errors_through_the_abi(tiny_model_path, tmp_path):
+    """k2hip_model_create parses and validates the container on the host before it asks for a device, so a damaged or
+    mismatched weights file is K2HIP_ERR_IO (-2) here as on a GPU box -- never a crash (the error contract of
+    OfflineProjOfTransducer.cs:87-90; the parser itself is fuzzed under ASan/UBSan in tests/test_sanitizers.py)."""
+    import struct
+    import numpy as np
+    from k2transducerasr_amd import K2HipError, Model
+    from k2transducerasr_amd.k2w import read_k2w, write_k2w
+    raw = open(tiny_model_path, "rb").read()
+    (data_off,) = struct.unpack_from("<Q", raw, 16)
+    for name, blob in {"truncated_header": raw[: data_off - 100], "truncated_data": raw[: len(raw) // 2], "garbage": os.urandom(4096),
+                       "wrapping_offset": raw[:16] + struct.pack("<Q", 2**64 - 64) + raw[24:]}.items():
+        p = tmp_path / f"{name}.k2w"
+        p.write_bytes(blob)
+        with pytest.raises(K2HipError) as e:
+            Model(str(p), 0)
+        assert e.value.code == -2, (name, str(e.value))
+    # metadata and weights that disagree: vocab_size says 37, the embedding has 30 rows
+    meta, tensors = read_k2w(tiny_model_path)
+    bad = str(tmp_path / "mismatch.k2w")
+    write_k2w(bad, meta, [(n, np.ascontiguousarray(a[:30]) if n == "decoder.embedding.weight" else a) for n, a in tensors.items()])
+    with pytest.raises(K2HipError) as e:
+        Model(bad, 0)
+    assert e.value.code == -2 and "decoder.embedding.weight" in str(e.value)
+    # an int64 tensor in the table (an ONNX shape constant that slipped through an importer) is ignored, not fatal
+    extra = str(tmp_path / "with_i64.k2w")
+    write_k2w(extra, meta, list(tensors.items()) + [("/encoder/Constant_output_0", np.arange(4, dtype=np.int64))])
+    try:
+        Model(extra, 0).close()
+    except K2HipError as e2:
+        assert e2.code == -3, str(e2)     # no GPU here: the file itself was accepted

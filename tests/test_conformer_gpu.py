@@ -183,8 +183,7 @@ def test_conformer_shortest_inputs(hip_conformer, oracle_conformer):
 def test_fused_and_gemm_attention_scores_agree(tmp_path_factory, utts):
     """K2HIP_CONFORMER_GEMM_SCORES selects the two-GEMM + gather form of the attention scores; both forms against the oracle and
     against each other, for lengths that are / are not multiples of the 32-row strip."""
-    import os
-    from k2transducerasr_amd import Model
+    from k2transducerasr_amd import Model, set_switch
     from k2transducerasr_amd.synth import write_synthetic_model
     from oracle import Oracle
     from parity import ACT_TOL
@@ -196,10 +195,10 @@ def test_fused_and_gemm_attention_scores_agree(tmp_path_factory, utts):
         x = rng.standard_normal((3, T, 80)).astype(np.float32)
         want = ora.encoder(x)
         fused = hip.encoder_proj(x)
-        os.environ["K2HIP_CONFORMER_GEMM_SCORES"] = "1"
+        set_switch("K2HIP_CONFORMER_GEMM_SCORES", 1)
         try:
             gemm = hip.encoder_proj(x)
         finally:
-            del os.environ["K2HIP_CONFORMER_GEMM_SCORES"]
+            set_switch("K2HIP_CONFORMER_GEMM_SCORES", 0)
         np.testing.assert_allclose(fused, want, atol=ACT_TOL, rtol=0, err_msg=f"fused T={T}")
         np.testing.assert_allclose(gemm, want, atol=ACT_TOL, rtol=0, err_msg=f"gemm T={T}")

@@ -60,3 +60,68 @@ def test_two_ranks_gloo():
     for rank, allr, t in got:
         assert allr == want          # rank order == utterance order, nothing lost or duplicated
         assert t == 2.0              # max over ranks
+
+
+# ---- bench.py's own launcher: `python bench.py --gpus N` with no WORLD_SIZE starts N ranks itself -------------------
+def _bench(*argv, env=None, timeout=240):
+    import subprocess
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_spawns_its_own_ranks():
+    """No GPU needed: --launch-check stops after the rendezvous and the shard bookkeeping."""
+    import json
+    r = _bench("--gpus", "2", "--dist-backend", "gloo", "--launch-check", "--total-utts", "7", "--batch", "2")
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["total_utts"] == 7
+    # rank order == utterance order; every utterance in exactly one batch
+    assert line["shards"] == [[0, 0, 4, [[0, 2], [2, 2]]], [1, 4, 7, [[4, 2], [6, 1]]]]
+    r = _bench("--gpus", "3", "--dist-backend", "gloo", "--launch-check")   # weak default: one batch of 32 per rank
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 0 and line["n_gpus"] == 3 and [s[1:3] for s in line["shards"]] == [[0, 32], [32, 64], [64, 96]]
+
+
+def test_bench_fails_when_a_rank_fails_or_the_world_is_wrong():
+    r = _bench("--gpus", "2", "--dist-backend", "gloo", "--launch-check", env={"K2HIP_BENCH_FAIL_RANK": "1"}, timeout=120)
+    assert r.returncode != 0 and r.stdout.strip() == ""           # no JSON line for a job that lost a rank
+    # under an external launcher whose world differs from --gpus the bench refuses instead of mislabelling the line
+    r = _bench("--gpus", "4", "--launch-check", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and r.stdout.strip() == ""
+
+
+def test_batches_of():
+    from k2transducerasr_amd.shard import batches_of, shard_range
+    assert batches_of(0, 0, 4) == []
+    assert batches_of(3, 10, 4) == [(3, 4), (7, 3)]
+    for total, world, b in ((256, 8, 32), (64, 8, 8), (7, 2, 3)):
+        ids = []
+        for r in range(world):
+            for first, cnt in batches_of(*shard_range(total, world, r), b):
+                ids += list(range(first, first + cnt))
+        assert ids == list(range(total))
+
+
+@pytest.mark.gpu
+def test_two_ranks_through_the_product_equal_one_process(tmp_path):
+    """Two gloo ranks sharing device 0, each decoding its shard through libk2hip.so (bench.py's own launcher), against one
+    process decoding the same batches: rank-order concatenation == the single-process result, for greedy and for beam 4."""
+    import json
+    common = ["--preset", "zipformer2-tiny-test", "--total-utts", "6", "--batch", "3", "--seconds", "1.2", "--steps", "1",
+              "--warmup", "0", "--no-cpu-baseline"]
+    for extra in ([], ["--beam", "4"]):
+        one, two = str(tmp_path / "one.json"), str(tmp_path / "two.json")
+        r1 = _bench("--gpus", "1", *common, *extra, "--dump-results", one)
+        assert r1.returncode == 0, r1.stderr[-2000:]
+        r2 = _bench("--gpus", "2", "--dist-backend", "gloo", *common, *extra, "--dump-results", two)
+        assert r2.returncode == 0, r2.stderr[-2000:]
+        l1, l2 = (json.loads(r.stdout.strip().splitlines()[-1]) for r in (r1, r2))
+        assert l1["n_gpus"] == 1 and l2["n_gpus"] == 2 and l2["scaling"] == "strong"
+        a, b = json.load(open(one)), json.load(open(two))
+        assert a["batches_per_rank"] == 2 and b["batches_per_rank"] == 1
+        assert len(a["results"]) == 6 and a["results"] == b["results"]
+        assert l1["results_sha1"] == l2["results_sha1"] and l1["tokens_emitted_per_step"] > 0

@@ -108,8 +108,9 @@ def test_lstm_wavefront_split_k_and_sequential_fallback(tmp_path_factory, utts):
     for T in (9, 13, 20):   # fewer frames than layers: the wavefront never has all layers active
         xs = np.random.default_rng(T).standard_normal((2, T, 80)).astype(np.float32)
         np.testing.assert_allclose(hip.encoder_proj(xs), ora.encoder(xs), atol=ACT_TOL, rtol=0)
-    os.environ["K2HIP_LSTM_SEQ"] = "1"
+    from k2transducerasr_amd import set_switch
+    set_switch("K2HIP_LSTM_SEQ", 1)
     try:
         np.testing.assert_allclose(hip.encoder_proj(x), got, atol=ACT_TOL, rtol=0)
     finally:
-        del os.environ["K2HIP_LSTM_SEQ"]
+        set_switch("K2HIP_LSTM_SEQ", 0)

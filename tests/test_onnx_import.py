@@ -128,3 +128,19 @@ def test_int8_dynamic_quantised_weights_are_dequantised(tmp_path):
     np.testing.assert_array_equal(t["joiner.encoder_proj.weight"], want)
     np.testing.assert_array_equal(t["encoder.encoders.0.layers.1.feed_forward1.in_proj.weight"], (sq.astype(np.float32) * 0.5).T)   # no zero point
     assert set(t) == {"joiner.encoder_proj.weight", "joiner.encoder_proj.bias", "encoder.encoders.0.layers.1.feed_forward1.in_proj.weight"}
+
+
+def test_int64_initializers_are_listed_not_stored(tmp_path):
+    """An export carries int64 shape / axes constants beside the weights; one whose name looks like a state-dict entry used to be
+    written into the container, which the engine's loader then rejected as a whole.  They are reported in `unmapped` and the
+    container holds f32 tensors only."""
+    w = np.ones((4, 3), np.float32)
+    p = tmp_path / "m.onnx"
+    p.write_bytes(ow.model({"model_type": "zipformer2"},
+                           [ow.tensor("onnx::MatMul_7", w), ow.tensor("/encoder/encoders.0/Constant_output_0", np.array([1, -1], np.int64)),
+                            ow.tensor("encoder.encoders.0.downsample.index", np.arange(3, dtype=np.int64), raw=False)],
+                           [ow.node("/encoder_proj/MatMul", "MatMul", ["x", "onnx::MatMul_7"], ["y"])]))
+    rep = import_onnx([str(p)], str(tmp_path / "o.k2w"))
+    _, t = read_k2w(str(tmp_path / "o.k2w"))
+    assert set(t) == {"joiner.encoder_proj.weight"} and all(a.dtype == np.float32 for a in t.values())
+    assert any("Constant_output_0" in u for u in rep["unmapped"]) and any("downsample.index" in u and "int64" in u for u in rep["unmapped"])

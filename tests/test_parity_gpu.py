@@ -319,17 +319,25 @@ def test_random_ragged_batches_match_oracle(hip_tiny, oracle_tiny):
 
 def test_alternative_kernel_paths_agree(hip_tiny, oracle_tiny, utts):
     """The switches of INTEGRATION.md select other kernels for the same math: attention apply + out_proj as two GEMMs
-    (K2HIP_NO_FUSED_AV) and the two-pass attention-scores kernel (K2HIP_ATTN_LONG is read at first use, so it is covered by
-    test_large_gpu instead).  Same input, both paths, against each other and against the oracle."""
+    (K2HIP_NO_FUSED_AV) and the two-pass attention-scores kernel (K2HIP_ATTN_LONG; test_large_gpu covers it at lengths that need it).  Same input, both paths, against each other and against the oracle."""
     import os
     x = oracle_tiny.pad_sequence([oracle_tiny.fbank(u) for u in utts]).reshape(len(utts), -1, 80)
     want = oracle_tiny.encoder(x)
     fused = hip_tiny.encoder_proj(x)
-    os.environ["K2HIP_NO_FUSED_AV"] = "1"
+    from k2transducerasr_amd import set_switch
+    set_switch("K2HIP_NO_FUSED_AV", 1)
     try:
         plain = hip_tiny.encoder_proj(x)
     finally:
-        del os.environ["K2HIP_NO_FUSED_AV"]
+        set_switch("K2HIP_NO_FUSED_AV", 0)
     np.testing.assert_allclose(fused, want, atol=ACT_TOL, rtol=0)
     np.testing.assert_allclose(plain, want, atol=ACT_TOL, rtol=0)
     np.testing.assert_allclose(fused, plain, atol=ACT_TOL, rtol=0)
+    set_switch("K2HIP_ATTN_LONG", 1)     # two-pass attention scores at a length the in-LDS strip would also take
+    try:
+        np.testing.assert_allclose(hip_tiny.encoder_proj(x), want, atol=ACT_TOL, rtol=0)
+    finally:
+        set_switch("K2HIP_ATTN_LONG", 0)
+    from k2transducerasr_amd import K2HipError
+    with pytest.raises(K2HipError):
+        set_switch("K2HIP_NO_SUCH_SWITCH", 1)

@@ -1,0 +1,94 @@
+"""CPU sanitizer build (AddressSanitizer + UBSan) of libk2hip's pure-host units that read untrusted bytes: the .k2w container
+parser (csrc/k2w_file.cpp) and the token -> text stage (csrc/text.cpp).  GPU sanitizers do not exist on this pool, and this is
+where a malformed input could hurt: a truncated, corrupted or mismatched file must come back as K2HIP_ERR_IO, never as a crash
+(the reference's contract: every failure of the operator is an exception, OfflineProjOfTransducer.cs:87-90)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "tests", "native", "k2hip_san_driver")
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+
+
+@pytest.fixture(scope="module")
+def driver():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "k2transducerasr_amd", "csrc"), "-s", "san"])
+    return DRIVER
+
+
+def run(driver, *args):
+    r = subprocess.run([driver, *args], capture_output=True, text=True, env=ENV, timeout=300)
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    return r.stdout.strip()
+
+
+def test_parser_accepts_the_writer_and_rejects_damage(driver, tiny_model_path, tmp_path):
+    out = run(driver, "k2w", tiny_model_path)
+    assert out.startswith("OK ")
+    raw = open(tiny_model_path, "rb").read()
+    (data_off,) = struct.unpack_from("<Q", raw, 16)
+    cases = {
+        "empty": b"",
+        "magic": b"K2W2" + raw[4:],
+        "version": raw[:4] + struct.pack("<I", 2) + raw[8:],
+        "short_header": raw[:20],
+        "cut_in_metadata": raw[:100],
+        "cut_in_table": raw[: data_off - 40],
+        "cut_in_data": raw[: data_off + 1000],
+        "data_off_past_eof": raw[:16] + struct.pack("<Q", len(raw) + 64) + raw[24:],
+        "data_off_wraps": raw[:16] + struct.pack("<Q", 2**64 - 8) + raw[24:],
+        "huge_counts": raw[:8] + struct.pack("<II", 2**31, 2**31) + raw[16:],
+    }
+    for name, blob in cases.items():
+        p = tmp_path / f"{name}.k2w"
+        p.write_bytes(blob)
+        assert run(driver, "k2w", str(p)).startswith("ERR -2 "), name     # K2HIP_ERR_IO
+    assert run(driver, "k2w", str(tmp_path / "missing.k2w")).startswith("ERR -2 ")
+
+
+def test_tensor_records_are_range_checked(driver, tmp_path):
+    from k2transducerasr_amd.k2w import write_k2w
+    p = str(tmp_path / "m.k2w")
+    write_k2w(p, {"model_type": "zipformer2"}, [("a.weight", np.arange(12, dtype=np.float32).reshape(3, 4)), ("b.idx", np.arange(5, dtype=np.int64))])
+    assert run(driver, "k2w", p).startswith("OK 1 2")
+    raw = bytearray(open(p, "rb").read())
+    at = raw.index(b"a.weight") + len(b"a.weight")          # -> dtype, ndim, dims[4], off, nbytes
+    def patched(off, fmt, val):
+        b = bytearray(raw)
+        struct.pack_into(fmt, b, at + off, val)
+        q = tmp_path / "x.k2w"
+        q.write_bytes(bytes(b))
+        return run(driver, "k2w", str(q))
+    assert patched(0, "<I", 7).startswith("ERR -2")          # unknown dtype
+    assert patched(4, "<I", 5).startswith("ERR -2")          # ndim > 4
+    assert patched(8, "<Q", 2**62).startswith("ERR -2")      # dims overflow
+    assert patched(8, "<Q", 4).startswith("ERR -2")          # nbytes != numel * 4
+    assert patched(40, "<Q", 2**64 - 16).startswith("ERR -2")  # offset + nbytes wraps
+    assert patched(40, "<Q", 2**20).startswith("ERR -2")     # offset past the file
+    assert patched(40, "<Q", 2).startswith("ERR -2")         # misaligned
+    assert patched(48, "<Q", 2**40).startswith("ERR -2")     # nbytes too large
+
+
+def test_fuzzed_containers_never_crash(driver, tiny_model_path, tmp_path):
+    import shutil
+    p = str(tmp_path / "f.k2w")
+    shutil.copy(tiny_model_path, p)
+    out = run(driver, "fuzz", p, "20240607", "400")
+    ok, err, other = (int(x.split("=")[1]) for x in out.split()[1:])
+    assert other == 0 and err > 100 and ok + err == 400, out
+
+
+def test_text_stage_under_sanitizers(driver, tmp_path):
+    p = tmp_path / "tokens.txt"
+    p.write_text("<blk> 0\n<sos/eos> 1\n<unk> 2\n▁HE 3\nLLO 4\n<0xE4> 5\n<0xBD> 6\n<0xA0> 7\n▁ 8\n<0xZZ> 9\n<0xE 10\n", encoding="utf-8")
+    assert run(driver, "text", str(p), "0", "3", "4") == "hello"
+    assert run(driver, "text", str(p), "0", "-1", "0", "5", "6", "7").endswith("你")
+    assert run(driver, "text", str(p), "0", "5", "6").strip() != ""             # an incomplete UTF-8 run: U+FFFD, no crash
+    run(driver, "text", str(p), "0", "9", "10", "8")                            # malformed hex tokens
+    assert run(driver, "text", str(p), "0", "99").startswith("ERR -1")          # id outside tokens.txt -> K2HIP_ERR_INVALID
+    assert run(driver, "text", str(tmp_path / "none.txt"), "0", "1").startswith("ERR -2")
