@@ -45,6 +45,17 @@ namespace K2TransducerAsr.Hip
         [DllImport(Lib)] internal static extern int k2hip_online_stream_get_timestamps(IntPtr stream, int[] timestamps, int cap);
         [DllImport(Lib)] internal static extern int k2hip_online_stream_get_hyp(IntPtr stream, long[] hyp2);
 
+        [DllImport(Lib)] internal static extern int k2hip_model_meta(IntPtr model, string key, byte[] buf, int cap);
+
+        // CustomMetadataMap[key] of the weights container; null when the key is absent (k2hip_model_meta -> K2HIP_ERR_INVALID)
+        internal static string Meta(IntPtr model, string key)
+        {
+            var buf = new byte[4096];
+            if (k2hip_model_meta(model, key, buf, buf.Length) != 0) return null;
+            int n = Array.IndexOf(buf, (byte)0);
+            return System.Text.Encoding.UTF8.GetString(buf, 0, n < 0 ? buf.Length : n);
+        }
+
         internal static void Check(int rc, string what)
         {
             if (rc != 0)

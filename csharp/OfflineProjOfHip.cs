@@ -24,7 +24,12 @@ namespace K2TransducerAsr
             _customMetadata.Context_size = _info.context_size;   // OfflineModel.cs:33-38
             _customMetadata.Vocab_size = _info.vocab_size;
             _customMetadata.Joiner_dim = _info.joiner_dim;       // OfflineModel.cs:43-45
-            _customMetadata.Model_type = "zipformer2";
+            // OfflineModel.cs:49-71 reads model_type / version / model_author / comment from the encoder's metadata map; the .k2w
+            // container carries the same keys (conformer, lstm, zipformer, zipformer2ctc models route through this operator too)
+            _customMetadata.Model_type = K2Hip.Meta(_model, "model_type") ?? "zipformer2";
+            _customMetadata.Version = K2Hip.Meta(_model, "version");
+            _customMetadata.Model_author = K2Hip.Meta(_model, "model_author");
+            _customMetadata.Comment = K2Hip.Meta(_model, "comment");
         }
 
         internal IntPtr Handle => _model;
