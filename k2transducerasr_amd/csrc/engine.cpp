@@ -45,6 +45,13 @@ Engine::~Engine() {
         sl.arena.release();
     }
     if (stream2_) (void)hipStreamDestroy(stream2_);
+    for (auto& s : subs_) {
+        if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamDestroy(s.stream); }
+        for (auto& e : s.ev) if (e) (void)hipEventDestroy(e);
+        for (auto& e : s.evpool) (void)hipEventDestroy(e);
+        if (s.pin) (void)hipHostFree(s.pin);
+        s.arena.release();
+    }
     for (auto& kv : pe_cache_) (void)hipFree(kv.second);
     for (auto& kv : pp_cache_) (void)hipFree(kv.second);
     for (auto& kv : sinus_cache_) (void)hipFree(kv.second);
@@ -119,6 +126,7 @@ const float* Engine::pos_emb(int T) {
 }
 
 DecJoinW Engine::decjoin() {
+    std::lock_guard<std::mutex> lk(cache_mu_);
     const Config& c = model_->cfg();
     DecJoinW w;
     w.emb = model_->w("decoder.embedding.weight");
@@ -198,6 +206,7 @@ float* Engine::encoder_embed(const Ctx& c, const float* x, int B, int T, int* T5
 
 const float* Engine::pos_proj_cached(const Ctx& c, int layer, const float* pe, int pe_dim, const float* W, int rows, int ncols) {
     if (c.dry) return nullptr;
+    std::lock_guard<std::mutex> lk(cache_mu_);
     const auto key = std::make_pair(layer, rows);
     auto it = pp_cache_.find(key);
     if (it != pp_cache_.end()) return it->second;

@@ -2,6 +2,9 @@
 // host-side orchestration of the offline path (pad -> Zipformer2 -> greedy).
 #pragma once
 #include <array>
+#include <condition_variable>
+#include <functional>
+#include <thread>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -25,6 +28,26 @@ struct OnlineLayout {
 struct OfflineResult {
     std::vector<std::vector<int64_t>> tokens;   // emitted symbols per stream
     std::vector<std::vector<int32_t>> timestamps;
+};
+
+// Fork-join over a few persistent host threads: the sub-batches of a streaming chunk step are enqueued concurrently, each on its
+// own HIP stream (a chunk step is ~450 short, latency-bound launches; two or four independent chains fill each other's gaps on
+// the GPU, and one host thread could not enqueue them fast enough to keep the chains abreast).
+class ForkJoin {
+  public:
+    ~ForkJoin();
+    // run fn(0..n-1): fn(0) on the calling thread, the rest on workers; rethrows the first exception after all have finished
+    void run(int n, const std::function<void(int)>& fn);
+
+  private:
+    void worker(int id, int seen);
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int gen_ = 0, active_ = 0, pending_ = 0;
+    bool stop_ = false;
+    std::vector<std::exception_ptr> err_;
 };
 
 class Engine {
@@ -145,6 +168,29 @@ class Engine {
     float* encoder_embed_stream(const Ctx& c, const float* x, const int* d_slots, int B, int T, int* Tc);
     void encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x, const float* pe, const int* d_slots,
                               const long long* d_plen, int B, int Tc, int L);
+    // one sub-batch of a streaming chunk step: its own stream, arena, pinned staging, events and GEMM statistics
+    struct OnlineSub {
+        Arena arena;
+        hipStream_t stream = nullptr;
+        hipEvent_t ev[6] = {nullptr};
+        GemmStats stats;
+        std::vector<hipEvent_t> evpool;
+        std::vector<GemmLaunchRec> log;
+        int evused = 0;
+        char* pin = nullptr;        // [chunks | slots | plens | hyps] in, [tok | ts | n | ovf] out
+        int64_t pin_cap = 0;
+        int64_t out_off = 0;
+        float gemm_ms = 0;
+    };
+    static constexpr int kMaxSubs = 4;
+    OnlineSub subs_[kMaxSubs];
+    ForkJoin fork_;
+    std::mutex cache_mu_;  // pos_proj / pos_emb / decjoin tables are built lazily, possibly from several sub-batch threads
+    void online_sub_step(OnlineSub& s, const int* slots, const float* chunks, const long long* hyps, const long long* plens, int B, int B_all);
+    void online_step_split(const int* slots, const float* chunks, const long long* hyps, const long long* plens, int B, int K,
+                           int64_t* tokens, int32_t* ts, int32_t* n_tokens);
+    float* online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_slots, const long long* d_plen, int B);
+    bool subs_warm_ = false;
     DecJoinW decjoin();
     float* d_ptab_ = nullptr;  // [2][V][DD] per-token decoder-conv table (groups = 1 models), built on first use
 

@@ -258,6 +258,9 @@ struct GreedyArgs {
     int* overflow;      // device flag
     // online loop: per-stream starting context (stream.Hyp, OnlineRecognizer.cs:109,122-126); null = offline
     const long long* init_ctx = nullptr;  // [B][2]
+    // streams searched CONCURRENTLY on the chip by sibling launches (sub-batches of one chunk step), this launch included; the
+    // parts of a stream wait for each other, so parts x concurrent streams must stay within the co-residency budget.  0 = B
+    int b_concurrent = 0;
     // vocabulary-parallel form (set by greedy_loop): `parts` workgroups per stream, each sweeping a slab of the joiner
     // matrix; per round they exchange their per-frame (max, argmax) through tagged 8-byte granules
     int parts = 1;

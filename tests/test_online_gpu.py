@@ -279,3 +279,50 @@ def test_streaming_128_concurrent_slots_zh(tmp_path_factory):
         for kind in KINDS:
             np.testing.assert_allclose(a.state(15, kind), hs[u].state(15, kind), atol=1e-5, rtol=0)
         a.close()
+
+
+@pytest.mark.parametrize("split", [2, 3, 4])
+def test_split_chunk_step_equals_single_stream_step(stream_model_path, ora, split):
+    """A chunk step over many streams is enqueued as sub-batches on their own HIP streams (K2HIP_ONLINE_SPLIT; automatic from 24
+    ready streams up).  Streams are independent, so the split must not change anything: same tokens / timestamps / Hyp as the
+    unsplit step and as the oracle after every call, same cached states, with ragged readiness (streams run out at different
+    calls, so the sub-batch boundaries move)."""
+    from k2transducerasr_amd import OnlineRecognizer, set_switch
+    from k2transducerasr_amd.synth import synth_utterance
+    ra, rb = OnlineRecognizer(stream_model_path), OnlineRecognizer(stream_model_path)
+    N = 7
+    feats = [ora.fbank(synth_utterance(500 + u, 0.9 + 0.25 * (u % 4))) for u in range(N)]
+    sa = [ra.create_online_stream() for _ in range(N)]
+    sb = [rb.create_online_stream() for _ in range(N)]
+    so = [ora.create_stream() for _ in range(N)]
+    for a, b, f in zip(sa, sb, feats):
+        a.add_features(f)
+        b.add_features(f)
+    T, S = ra.chunk_length, ra.shift_length
+    pos = [0] * N
+    calls = 0
+    try:
+        while True:
+            ready = [u for u in range(N) if pos[u] + T <= feats[u].shape[0]]
+            set_switch("K2HIP_ONLINE_SPLIT", 1)
+            da, na = ra.get_results(sa)
+            set_switch("K2HIP_ONLINE_SPLIT", split)
+            db, nb = rb.get_results(sb)
+            assert da == db and na == nb and [u for u in range(N) if da[u]] == ready
+            if not ready:
+                break
+            ora.step([so[u] for u in ready], [feats[u][pos[u] : pos[u] + T] for u in ready])
+            for u in ready:
+                pos[u] += S
+            for u in range(N):
+                assert sa[u].tokens == sb[u].tokens == so[u].tokens, (calls, u)
+                assert sa[u].timestamps == sb[u].timestamps == so[u].timestamps and sa[u].hyp == sb[u].hyp == so[u].hyp
+            calls += 1
+    finally:
+        set_switch("K2HIP_ONLINE_SPLIT", 0)
+    assert calls >= 3 and sum(len(s.tokens) - 2 for s in so) > 0
+    for u in (0, 3, 6):
+        for l in range(so[u].num_layers):
+            for k in KINDS:
+                np.testing.assert_allclose(sb[u].state(l, k), sa[u].state(l, k), atol=1e-6, rtol=0)
+        np.testing.assert_allclose(sb[u].state(0, "embed"), sa[u].state(0, "embed"), atol=1e-6, rtol=0)
