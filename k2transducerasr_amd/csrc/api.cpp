@@ -670,9 +670,28 @@ __attribute__((visibility("default"))) int32_t k2hip_debug_gemm(k2hip_model_t* m
     return guard([&] {
         NEED(model); NEED(ms);
         std::lock_guard<std::mutex> lk(model->engine.mutex());
-        debug_force_gemm_cfg(cfg);
-        *ms = model->engine.debug_gemm(M, N, K, act, with_res != 0, iters);
-        debug_force_gemm_cfg(-1);
+        *ms = model->engine.debug_gemm(M, N, K, act, with_res != 0, iters, cfg, nullptr);
+    });
+}
+// the same, and max_err = largest |difference| from the register-staged kernel on the same operands
+__attribute__((visibility("default"))) int32_t k2hip_debug_gemm_check(k2hip_model_t* model, int32_t M, int32_t N, int32_t K,
+                                                                       int32_t act, int32_t with_res, int32_t cfg, int32_t iters, float* ms,
+                                                                       float* max_err) {
+    return guard([&] {
+        NEED(model); NEED(ms); NEED(max_err);
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        *ms = model->engine.debug_gemm(M, N, K, act, with_res != 0, iters, cfg, max_err);
+    });
+}
+
+__attribute__((visibility("default"))) int32_t k2hip_debug_gemm_trace(k2hip_model_t* model, int32_t M, int32_t N, int32_t K, int32_t act,
+                                                                       int32_t with_res, int32_t cfg, unsigned long long* out, int64_t cap,
+                                                                       int32_t* n_wg, int32_t* n_waves) {
+    return guard([&] {
+        NEED(model); NEED(out); NEED(n_wg); NEED(n_waves);
+        K2_REQUIRE(cfg >= 100, "trace: ring configurations only (cfg >= 100)");
+        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        model->engine.debug_gemm_trace(M, N, K, act, with_res != 0, cfg, out, cap, n_wg, n_waves);
     });
 }
 

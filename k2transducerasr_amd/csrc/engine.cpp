@@ -954,17 +954,74 @@ void Engine::wait_ticket(int ticket, int64_t* tokens, int32_t* ts, int32_t* n_to
     memcpy(n_tokens, pin + nb_tok + nb_ts, nb_n);
 }
 
-// tuning hook: average time of one Linear-shaped GEMM on uniform random data
-float Engine::debug_gemm(int M, int N, int K, int act, bool with_res, int iters) {
+// tuning hook: average time of one Linear-shaped GEMM on uniform random data under the forced configuration `cfg`; max_err
+// (optional) = largest |difference| from the register-staged 64x64 kernel on the same operands
+float Engine::debug_gemm(int M, int N, int K, int act, bool with_res, int iters, int cfg, float* max_err) {
+    K2_HIP(hipSetDevice(device_));
+    std::vector<float> h((size_t)std::max((int64_t)M * K, std::max((int64_t)N * K, (int64_t)M * N)));
+    uint32_t s = 12345u;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) * (1.0f / 8388608.0f)) - 1.0f; }
+    float *A, *W, *C, *C2, *Rb, *b;
+    K2_HIP(hipMalloc(&A, sizeof(float) * (size_t)M * K));
+    K2_HIP(hipMalloc(&W, sizeof(float) * (size_t)N * K));
+    K2_HIP(hipMalloc(&C, sizeof(float) * (size_t)M * N));
+    K2_HIP(hipMalloc(&C2, sizeof(float) * (size_t)M * N));
+    K2_HIP(hipMalloc(&Rb, sizeof(float) * (size_t)M * N));
+    K2_HIP(hipMalloc(&b, sizeof(float) * (size_t)N));
+    K2_HIP(hipMemcpy(A, h.data(), sizeof(float) * (size_t)M * K, hipMemcpyHostToDevice));
+    K2_HIP(hipMemcpy(W, h.data() + 7, sizeof(float) * ((size_t)N * K - 7), hipMemcpyHostToDevice));
+    K2_HIP(hipMemcpy(Rb, h.data() + 3, sizeof(float) * ((size_t)M * N - 3), hipMemcpyHostToDevice));
+    K2_HIP(hipMemcpy(b, h.data() + 11, sizeof(float) * (size_t)N, hipMemcpyHostToDevice));
+    Ctx c = make_ctx(false);
+    c.instrument = false;
+    c.stats = nullptr;
+    float ms = 0;
+    try {
+        debug_force_gemm_cfg(cfg);
+        for (int i = 0; i < 3; i++) linear(c, A, K, W, b, C, N, M, K, N, act, with_res ? Rb : nullptr, N);
+        K2_HIP(hipEventRecord(ev_[6], stream_));
+        for (int i = 0; i < iters; i++) linear(c, A, K, W, b, C, N, M, K, N, act, with_res ? Rb : nullptr, N);
+        K2_HIP(hipEventRecord(ev_[7], stream_));
+        K2_HIP(hipStreamSynchronize(stream_));
+        K2_HIP(hipEventElapsedTime(&ms, ev_[6], ev_[7]));
+        if (max_err) {
+            debug_force_gemm_cfg(2 + 64);
+            linear(c, A, K, W, b, C2, N, M, K, N, act, with_res ? Rb : nullptr, N);
+            K2_HIP(hipStreamSynchronize(stream_));
+            std::vector<float> h1((size_t)M * N), h2((size_t)M * N);
+            K2_HIP(hipMemcpy(h1.data(), C, sizeof(float) * h1.size(), hipMemcpyDeviceToHost));
+            K2_HIP(hipMemcpy(h2.data(), C2, sizeof(float) * h2.size(), hipMemcpyDeviceToHost));
+            float e = 0;
+            for (size_t i = 0; i < h1.size(); i++) {
+                const float d = fabsf(h1[i] - h2[i]);
+                e = (d > e || d != d) ? (d != d ? INFINITY : d) : e;
+            }
+            *max_err = e;
+        }
+    } catch (...) {
+        debug_force_gemm_cfg(-1);
+        (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipFree(C2); (void)hipFree(Rb); (void)hipFree(b);
+        throw;
+    }
+    debug_force_gemm_cfg(-1);
+    (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipFree(C2); (void)hipFree(Rb); (void)hipFree(b);
+    return ms / iters;
+}
+
+// tuning hook: ONE launch of the ring kernel `cfg` (>= 100) with in-kernel s_memtime stamps; out [n_wg][n_waves][64]
+void Engine::debug_gemm_trace(int M, int N, int K, int act, bool with_res, int cfg, unsigned long long* out, int64_t cap, int* n_wg, int* n_waves) {
     K2_HIP(hipSetDevice(device_));
     std::vector<float> h((size_t)std::max((int64_t)M * K, std::max((int64_t)N * K, (int64_t)M * N)));
     uint32_t s = 12345u;
     for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) * (1.0f / 8388608.0f)) - 1.0f; }
     float *A, *W, *C, *b;
+    unsigned long long* dbg;
     K2_HIP(hipMalloc(&A, sizeof(float) * (size_t)M * K));
     K2_HIP(hipMalloc(&W, sizeof(float) * (size_t)N * K));
     K2_HIP(hipMalloc(&C, sizeof(float) * (size_t)M * N));
     K2_HIP(hipMalloc(&b, sizeof(float) * (size_t)N));
+    K2_HIP(hipMalloc(&dbg, sizeof(unsigned long long) * (size_t)cap));
+    K2_HIP(hipMemset(dbg, 0, sizeof(unsigned long long) * (size_t)cap));
     K2_HIP(hipMemcpy(A, h.data(), sizeof(float) * (size_t)M * K, hipMemcpyHostToDevice));
     K2_HIP(hipMemcpy(W, h.data(), sizeof(float) * (size_t)N * K, hipMemcpyHostToDevice));
     K2_HIP(hipMemcpy(C, h.data(), sizeof(float) * (size_t)M * N, hipMemcpyHostToDevice));
@@ -972,15 +1029,28 @@ float Engine::debug_gemm(int M, int N, int K, int act, bool with_res, int iters)
     Ctx c = make_ctx(false);
     c.instrument = false;
     c.stats = nullptr;
-    for (int i = 0; i < 3; i++) linear(c, A, K, W, b, C, N, M, K, N, act, with_res ? C : nullptr, N);
-    K2_HIP(hipEventRecord(ev_[6], stream_));
-    for (int i = 0; i < iters; i++) linear(c, A, K, W, b, C, N, M, K, N, act, with_res ? C : nullptr, N);
-    K2_HIP(hipEventRecord(ev_[7], stream_));
-    K2_HIP(hipStreamSynchronize(stream_));
-    float ms = 0;
-    K2_HIP(hipEventElapsedTime(&ms, ev_[6], ev_[7]));
-    (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipFree(b);
-    return ms / iters;
+    try {
+        debug_force_gemm_cfg(cfg);
+        GemmArgs g;
+        g.A = A; g.lda = K; g.W = W; g.ldw = K; g.bias = b; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
+        g.res = with_res ? C : nullptr; g.ldr = N;
+        for (int i = 0; i < 5; i++) gemm(c, g);   // steady state (caches, clocks)
+        int bm = 0, bn = 0, nw = 0;
+        debug_ring_shape(cfg - 100, &bm, &bn, &nw);
+        *n_wg = cdiv(M, bm) * cdiv(N, bn);
+        *n_waves = nw;
+        K2_REQUIRE((int64_t)*n_wg * nw * 64 <= cap, "trace buffer too small: need %lld words", (long long)*n_wg * nw * 64);
+        g.dbg = dbg;
+        gemm(c, g);
+        K2_HIP(hipStreamSynchronize(stream_));
+        K2_HIP(hipMemcpy(out, dbg, sizeof(unsigned long long) * (size_t)*n_wg * nw * 64, hipMemcpyDeviceToHost));
+    } catch (...) {
+        debug_force_gemm_cfg(-1);
+        (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipFree(b); (void)hipFree(dbg);
+        throw;
+    }
+    debug_force_gemm_cfg(-1);
+    (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipFree(b); (void)hipFree(dbg);
 }
 
 void* Engine::dev_alloc(int64_t bytes) {

@@ -112,7 +112,8 @@ class Engine {
     const std::vector<float>& last_scores() const { return last_scores_; }
     const k2hip_timing& timing() const { return timing_; }
 
-    float debug_gemm(int M, int N, int K, int act, bool with_res, int iters);
+    float debug_gemm(int M, int N, int K, int act, bool with_res, int iters, int cfg, float* max_err);
+    void debug_gemm_trace(int M, int N, int K, int act, bool with_res, int cfg, unsigned long long* out, int64_t cap, int* n_wg, int* n_waves);
     void* dev_alloc(int64_t bytes);
     void dev_free(void* p);
     void dev_upload(void* dst, const void* src, int64_t bytes);

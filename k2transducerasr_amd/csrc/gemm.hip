@@ -23,6 +23,7 @@
 //   - MODE_CONV: implicit-conv row/k mapping for A over an NHWC tensor;
 //     MODE_WKN: [K,N] B operand (transposed while staging) for attention-weights x
 //     values products.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -484,6 +485,298 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
 }
 
 // ---------------------------------------------------------------------------------------
+// Ring variant of the LDS-DMA kernel (plain Linear, K % (32 KS) == 0).  Same tile image and swizzle as above; what changes is
+// the pipeline and the K split:
+//   * the fragments of a K tile are read from LDS into a SECOND register set while the MFMAs of the previous tile run, so
+//     after a barrier a wave continues straight into MFMAs whose operands are already in registers.  The barrier of
+//     iteration kt then only says "everyone holds tile kt in registers, and tile kt+1 has landed for everyone": it sits in
+//     the middle of matrix work instead of in front of an LDS round trip, and the stage of tile kt is free the moment it
+//     passes -- NST stages keep NST - 1 tiles in flight (the kernel above: NST - 1 stages in flight, one LDS latency and
+//     the DMA issue exposed per K step).
+//   * KS wave groups split each 32 KS-deep K step inside the workgroup (group g multiplies k in [32 g, 32 g + 32) of the
+//     step), so a problem with few output tiles (streaming chunks: 256 .. 2048 rows) still puts 8 - 16 waves on a CU and
+//     walks K in K / (32 KS) steps.  The groups' partial tiles meet in LDS after the loop and are summed in the fixed order
+//     g = 0 .. KS - 1 (deterministic); each group finishes 16 / KS of the accumulator registers.
+template <int BM, int BN, int KS, int NST, int LW, int PF = 0>
+__global__ __launch_bounds__(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)) void gemm_f32_mfma_ring(GemmArgs g) {
+    constexpr int BK = 32;
+    constexpr int WCOLS = BN / 32;
+    constexpr int TW = (BM / 32) * (BN / 32);  // waves per K group = 32x32 output tiles of the workgroup
+    constexpr int NW = TW * KS;                // consumer waves; waves NW .. NW+LW-1 are loaders (LW == 0: consumers load)
+    constexpr int NINST = (BM + BN) / 8;       // 1 KB wave-instructions per K group and stage
+    // who issues the DMA of a stage: LW == 0 -- wave tw of every K group issues instructions tw, tw + TW, ... of its own group;
+    // LW > 0 -- loader j issues instructions j, j + LW, ... of the KS * NINST instructions of the whole stage
+    constexpr int ISS = LW > 0 ? LW : TW;                 // issuers sharing one instruction list
+    constexpr int NLIST = LW > 0 ? KS * NINST : NINST;    // length of that list
+    constexpr int IPW = (NLIST + ISS - 1) / ISS;
+    constexpr int NFULL = NLIST % ISS == 0 ? ISS : NLIST % ISS;  // issuers 0..NFULL-1 issue IPW, the others IPW - 1
+    constexpr int SUB = (BM + BN) * BK;        // floats per K group and stage: A rows then W rows
+    constexpr int STAGE = SUB * KS;
+    constexpr int RPG = 16 / KS;               // accumulator registers each group finishes
+    static_assert(NST >= 2 && (KS == 1 || KS == 2 || KS == 4), "ring: NST >= 2, KS in {1, 2, 4}");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [NST][KS][SUB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = LW > 0 && wave >= NW;
+    const int kg = loader ? 0 : wave / TW, tw = loader ? 0 : wave % TW;
+    const int wr = tw / WCOLS, wc = tw % WCOLS;
+    const int li = lane & 31, lh = lane >> 5;
+    const int z0 = blockIdx.z % g.nb0, z1 = blockIdx.z / g.nb0;
+    const float* __restrict__ A = g.A + z0 * g.sA0 + z1 * g.sA1;
+    const float* __restrict__ W = g.W + z0 * g.sW0 + z1 * g.sW1;
+    float* __restrict__ C = g.C + z0 * g.sC0 + z1 * g.sC1;
+    const float* __restrict__ R = g.res ? g.res + z0 * g.sR0 + z1 * g.sR1 : nullptr;
+    int mb_, nb_;
+    xcd_tile(mb_, nb_);
+    const int m0 = mb_ * BM, n0 = nb_ * BN;
+    const int nk = g.K / (BK * KS);
+
+    // tuning only (g.dbg != nullptr): lane 0 of every wave stamps s_memtime at the phases of the pipeline
+    unsigned long long* stamp = g.dbg ? g.dbg + ((size_t)(blockIdx.x + blockIdx.y * gridDim.x) * (NW + LW + PF) + wave) * 64 : nullptr;
+    int nstamp = 0;
+#define K2_STAMP()                                                                     \
+    if (stamp && lane == 0 && nstamp < 60) stamp[nstamp++] = __builtin_amdgcn_s_memtime();
+    if (stamp && lane == 0) stamp[60] = __builtin_amdgcn_s_memrealtime();
+    K2_STAMP()
+
+    // ---- DMA issue (the loaders, or every consumer when LW == 0)
+    const int me = LW > 0 ? wave - NW : tw;  // index among the issuers of my list
+    const float* src[IPW];
+    unsigned dst0[IPW];
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    if (LW == 0 || loader) {
+#pragma unroll
+        for (int q = 0; q < IPW; q++) {
+            const int idx = min(me + q * ISS, NLIST - 1);
+            const int gi = LW > 0 ? idx / NINST : kg, inst = LW > 0 ? idx % NINST : idx;  // K group and instruction within it
+            const int slot = inst * 64 + lane;
+            const int r = slot >> 3, cp = slot & 7;
+            const int c = cp ^ ((r >> 1) & 7);
+            if (inst < BM / 8) src[q] = A + (long long)min(m0 + r, g.M - 1) * g.lda + 4 * c + BK * gi;
+            else src[q] = W + (long long)min(n0 + (r - BM), g.N - 1) * g.ldw + 4 * c + BK * gi;
+            dst0[q] = lds_base + (gi * SUB + inst * 256) * 4;
+        }
+    }
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int q = 0; q < IPW; q++) {
+            if (me + q * ISS >= NLIST) break;  // wave-uniform
+            const unsigned dst = __builtin_amdgcn_readfirstlane(dst0[q] + (kt % NST) * (STAGE * 4));
+            const float* gp = src[q] + kt * (BK * KS);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(gp), "s"(dst)
+                         : "memory");
+        }
+    };
+    // my share of tile kt_next has landed when at most `behind` newer tiles of mine are pending
+#define K2_RING_WAIT(behind_)                                                                               \
+    {                                                                                                       \
+        if ((behind_) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
+        else if (me < NFULL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((behind_) * IPW > 63 ? 63 : (behind_) * IPW) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((behind_) * (IPW - 1) > 63 ? 63 : (behind_) * (IPW - 1)) : "memory");     \
+    }
+
+    if (PF > 0 && wave == NW + LW) {
+        // ---- L2 prefetch wave.  Every workgroup of a launch walks K in lockstep, so a tile's lines are requested by all its
+        // sharers (the gridDim.x workgroups of a row of tiles for A, the row tiles of the same XCD for W) at the same moment:
+        // one request goes to the Infinity Cache / HBM and the others wait on the same miss -- every DMA pays the full miss
+        // latency (~900 cycles), and a CU holds only ~9 KB of misses in flight: ~9 B/clk/CU, below the 12 B/clk a 128x64 tile
+        // needs.  This wave touches ONE dword of each line of its 1/sharers share of the tile that the DMA will ask for in the
+        // NEXT iteration, so that those DMA requests find the lines in the XCD's L2 (~300 cycles).
+        const int gx = gridDim.x, nwg = gx * gridDim.y;
+        const int sa = min(gx, BM), ra = (BM + sa - 1) / sa;             // A: sharers, rows of my share
+        const int sw = max(1, min((nwg >> 3) / max(gx, 1), BN)), rw = (BN + sw - 1) / sw;  // W: row tiles per XCD
+        const int a0 = (nb_ % sa) * ra, w0 = (mb_ % sw) * rw;
+        const int nline = (ra + rw) * KS;  // lines per K step of my share (one 128-byte line = 32 floats of a row)
+        __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt + 1 < nk; kt++) {
+            __builtin_amdgcn_s_barrier();
+            const int t = kt + NST + 1;  // the DMA of tile kt + NST + 1 goes out one iteration from now
+            if (t < nk) {
+                for (int l = lane; l < nline; l += 64) {
+                    const int rr = l / KS, kgi = l % KS;
+                    const float* p = rr < ra ? A + (long long)min(m0 + min(a0 + rr, BM - 1), g.M - 1) * g.lda
+                                             : W + (long long)min(n0 + min(w0 + rr - ra, BN - 1), g.N - 1) * g.ldw;
+                    // LDS-destination form (256 scratch bytes behind the ring): no VGPR is written when the data arrives, so
+                    // nothing the compiler has since reused can be clobbered
+                    constexpr int SINK = NST * STAGE > (KS > 1 ? KS * TW * 1024 : 0) ? NST * STAGE : KS * TW * 1024;  // floats: behind the ring AND the reduce area
+                    const unsigned sink = __builtin_amdgcn_readfirstlane(lds_base + SINK * 4);
+                    const float* pp = p + (long long)t * (BK * KS) + BK * kgi;
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep)
+                                 : "v"(pp), "s"(sink)
+                                 : "memory");
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    if (loader) {
+        // ---- loader wave: keeps NST - 1 tiles in flight ahead of the tile being multiplied; one barrier per tile with the
+        // consumers ("tile kt+1 has landed" one way, "tile kt is in your registers, its stage is free" the other way)
+#pragma unroll
+        for (int p = 0; p < NST; p++)
+            if (p < nk) issue(p);
+        if (nk >= NST) K2_RING_WAIT(NST - 1) else K2_RING_WAIT(0)
+        __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt + 1 < nk; kt++) {
+            if (kt + NST - 1 < nk && NST > 2) K2_RING_WAIT(NST - 2) else K2_RING_WAIT(0)
+            __builtin_amdgcn_s_barrier();
+            if (kt + NST < nk) issue(kt + NST);
+        }
+        return;
+    }
+
+    f32x16 acc, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = acc1[r] = 0.f;
+
+    const int arow = wr * 32 + li, brow = wc * 32 + li;
+    const int swa = (arow >> 1) & 7, swb = ((BM + brow) >> 1) & 7;
+    // this lane's fragment addresses inside a stage (float offsets), one per 8-k group
+    const float* fbase = smem + kg * SUB;
+    int offa[4], offb[4];
+#pragma unroll
+    for (int gk = 0; gk < 4; gk++) {
+        offa[gk] = arow * BK + (((2 * gk + lh) ^ swa) << 2);
+        offb[gk] = (BM + brow) * BK + (((2 * gk + lh) ^ swb) << 2);
+    }
+
+    float4 fa[2][4], fb[2][4];
+#define K2_RING_READ(set_, st_, gk_)                                                   \
+    {                                                                                  \
+        fa[set_][gk_] = *reinterpret_cast<const float4*>(fbase + (st_) + offa[gk_]);   \
+        fb[set_][gk_] = *reinterpret_cast<const float4*>(fbase + (st_) + offb[gk_]);   \
+    }
+    // meet the other waves: everyone holds the current tile in registers and the next tile has landed (own DMA: wait for it first)
+#define K2_RING_SYNC(kt_)                                                                                        \
+    {                                                                                                            \
+        if (LW == 0) {                                                                                           \
+            if ((kt_) + NST - 1 < nk && NST > 2) K2_RING_WAIT(NST - 2) else K2_RING_WAIT(0)                      \
+        }                                                                                                        \
+        __builtin_amdgcn_s_barrier();                                                                            \
+    }
+    // one K tile out of register set cu_; MORE_: the next tile's fragments are read into set nx_ between the MFMAs, and the DMA
+    // of tile kt_ + NST goes out behind the first MFMA (the matrix pipe is busy meanwhile)
+#define K2_RING_STEP(cu_, nx_, kt_, MORE_)                                                                              \
+    {                                                                                                                   \
+        const int st_next = (((kt_) + 1) % NST) * STAGE;                                                                \
+        _Pragma("unroll") for (int gk = 0; gk < 4; gk++) {                                                              \
+            _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                             \
+                const float av = e == 0 ? fa[cu_][gk].x : e == 1 ? fa[cu_][gk].y : e == 2 ? fa[cu_][gk].z : fa[cu_][gk].w; \
+                const float bv = e == 0 ? fb[cu_][gk].x : e == 1 ? fb[cu_][gk].y : e == 2 ? fb[cu_][gk].z : fb[cu_][gk].w; \
+                if (!(g.ablate & 2)) {                                                                                  \
+                    if (e & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc1, 0, 0, 0);                      \
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);                              \
+                } else if (e == 0) {                                                                                    \
+                    acc[0] += av * bv; /* keep the fragment reads alive */                                             \
+                }                                                                                                       \
+                if (MORE_ && e == 0) {                                                                                  \
+                    __builtin_amdgcn_sched_barrier(0);                                                                  \
+                    if (LW == 0 && gk == 0 && (kt_) + NST < nk && !(g.ablate & 1)) issue((kt_) + NST);                  \
+                    K2_RING_READ(nx_, st_next, gk)                                                                      \
+                    __builtin_amdgcn_sched_barrier(0);                                                                  \
+                }                                                                                                       \
+            }                                                                                                           \
+        }                                                                                                               \
+    }
+
+    if (LW == 0) {
+#pragma unroll
+        for (int p = 0; p < NST; p++)
+            if (p < nk) issue(p);
+        K2_STAMP()
+        // tile 0 landed for this wave once at most the NST - 1 newer tiles are pending (fewer exist when K is short: drain)
+        if (nk >= NST) K2_RING_WAIT(NST - 1) else K2_RING_WAIT(0)
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int gk = 0; gk < 4; gk++) K2_RING_READ(0, 0, gk)
+
+    K2_STAMP()
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {  // two tiles per trip, so that the register-set index is a compile-time constant
+        K2_RING_SYNC(kt)
+        K2_STAMP()
+        K2_RING_STEP(0, 1, kt, true)
+        K2_STAMP()
+        K2_RING_SYNC(kt + 1)
+        K2_STAMP()
+        K2_RING_STEP(1, 0, kt + 1, true)
+        K2_STAMP()
+    }
+    if (kt + 1 < nk) {  // two tiles left
+        K2_RING_SYNC(kt)
+        K2_RING_STEP(0, 1, kt, true)
+        K2_RING_STEP(1, 0, kt + 1, false)
+    } else {            // one tile left
+        K2_RING_STEP(0, 1, kt, false)
+    }
+#undef K2_RING_STEP
+#undef K2_RING_SYNC
+#undef K2_RING_READ
+#undef K2_RING_WAIT
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] += acc1[r];
+    K2_STAMP()
+
+    // ---- the K groups' partial tiles meet in LDS; group g finishes registers [g RPG, (g+1) RPG)
+    float fin[RPG];
+    if (KS > 1) {
+        __syncthreads();  // every wave is done with the ring
+        float4* red = reinterpret_cast<float4*>(smem);  // [KS][TW][4][64] float4
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++)
+            red[((kg * TW + tw) * 4 + q4) * 64 + lane] = make_float4(acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]);
+        __syncthreads();
+        const float* redf = smem;
+#pragma unroll
+        for (int rr = 0; rr < RPG; rr++) {
+            const int r = kg * RPG + rr;
+            float v = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; s++) v += redf[((((s * TW + tw) * 4 + (r >> 2)) * 64 + lane) << 2) + (r & 3)];
+            fin[rr] = v;
+        }
+    } else {
+#pragma unroll
+        for (int rr = 0; rr < RPG; rr++) fin[rr] = acc[rr];
+    }
+
+    const int col = n0 + wc * 32 + li;
+    if (col < g.N) {
+        const float bv = g.bias ? g.bias[z0 * g.sBias0 + col] : 0.f;
+        const int act = (g.act_cols == 0 || col < g.act_cols) ? g.act : (int)ACT_NONE;
+#pragma unroll
+        for (int rr = 0; rr < RPG; rr++) {
+            const int r = kg * RPG + rr;
+            const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < g.M) {
+                float v = apply_act(fin[rr] + bv, act);
+                if (R) v += R[(long long)row * g.ldr + col];
+                if (g.byp_orig) {
+                    const float o = g.byp_orig[(long long)row * g.ld_orig + col];
+                    v = o + (v - o) * g.byp_scale[col];
+                }
+                C[(long long)row * g.ldc + col] = v;
+            }
+        }
+    }
+    K2_STAMP()
+    if (stamp && lane == 0) {
+        stamp[62] = (unsigned long long)nstamp;
+        stamp[63] = __builtin_amdgcn_s_memrealtime();
+    }
+#undef K2_STAMP
+}
+
+// ---------------------------------------------------------------------------------------
 // Skinny-N variant (N <= 96, K % 64 == 0): the value projections of the attention modules
 // (N = 12 x heads).  With so few columns a tiled launch is a handful of workgroups, each walking
 // the whole K serially (22 us for 4064 x 48 x 512).  Here a workgroup owns 16 rows x all N, its
@@ -566,6 +859,38 @@ void launch_dma(const Ctx& ctx, const GemmArgs& a) {
     hipLaunchKernelGGL((gemm_f32_mfma_dma<BM, BN, WM, WN, NST>), grid, dim3(64 * (BM / WM) * (BN / WN)), lds, ctx.stream, a);
 }
 
+template <int BM, int BN, int KS, int NST, int LW, int PF = 0>
+void launch_ring(const Ctx& ctx, const GemmArgs& a) {
+    dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.nb0 * a.nb1);
+    // the ring, or the K groups' partial tiles after the loop, whichever is larger
+    size_t lds = sizeof(float) * std::max((size_t)NST * KS * (BM + BN) * 32, KS > 1 ? (size_t)KS * (BM / 32) * (BN / 32) * 1024 : (size_t)0) + (PF ? 256 : 0);
+    static LdsAttrOnce lds_attr;
+    lds_attr.ensure(gemm_f32_mfma_ring<BM, BN, KS, NST, LW, PF>, (int)lds);
+    hipLaunchKernelGGL((gemm_f32_mfma_ring<BM, BN, KS, NST, LW, PF>), grid, dim3(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)), lds, ctx.stream, a);
+}
+
+// tuning table of the ring kernel: k2hip_debug_gemm cfg = 100 + index
+struct RingCfg { int BM, BN, KS, NST, LW, PF; };
+#define K2_RING_TABLE(X)                                                                                        \
+    X(0, 128, 64, 1, 2, 0, 0) X(1, 128, 64, 1, 3, 0, 0) X(2, 128, 64, 1, 2, 0, 1) X(3, 128, 64, 1, 3, 0, 1) X(4, 128, 64, 1, 4, 0, 1)   \
+    X(5, 64, 64, 1, 3, 0, 0) X(6, 64, 64, 1, 3, 0, 1) X(7, 64, 64, 1, 4, 0, 1) X(8, 64, 64, 2, 3, 0, 0) X(9, 64, 64, 2, 3, 0, 1)      \
+    X(10, 64, 64, 4, 2, 0, 0) X(11, 64, 64, 4, 2, 0, 1) X(12, 32, 64, 2, 3, 0, 0) X(13, 32, 64, 4, 3, 0, 0) X(14, 32, 64, 4, 3, 0, 1)  \
+    X(15, 32, 32, 4, 3, 0, 0) X(16, 32, 32, 4, 4, 0, 1) X(17, 64, 32, 4, 3, 0, 0) X(18, 128, 128, 1, 2, 0, 0) X(19, 128, 128, 1, 2, 0, 1) \
+    X(20, 64, 128, 1, 3, 0, 0) X(21, 64, 128, 1, 3, 0, 1) X(22, 64, 96, 1, 3, 0, 0) X(23, 64, 96, 1, 3, 0, 1) X(24, 128, 96, 1, 2, 0, 1) \
+    X(25, 128, 64, 1, 3, 2, 0) X(26, 128, 64, 1, 3, 2, 1) X(27, 128, 64, 2, 2, 0, 1)
+#define X(i, bm, bn, ks, nst, lw, pf) {bm, bn, ks, nst, lw, pf},
+const RingCfg kRing[] = {K2_RING_TABLE(X)};
+#undef X
+bool launch_ring_idx(const Ctx& ctx, const GemmArgs& a, int idx) {
+    switch (idx) {
+#define X(i, bm, bn, ks, nst, lw, pf) case i: launch_ring<bm, bn, ks, nst, lw, pf>(ctx, a); break;
+        K2_RING_TABLE(X)
+#undef X
+        default: return false;
+    }
+    return true;
+}
+
 template <int BM, int BN, int WM, int WN, int BK, int MODE>
 void launch_cfg(const Ctx& ctx, const GemmArgs& a) {
     constexpr int LDSK = BK + 4;
@@ -625,8 +950,22 @@ int choose_cfg(const GemmArgs& a) {
 
 int g_ablate = 0;
 int g_use_dma = 1;
+void debug_ring_shape(int idx, int* bm, int* bn, int* waves) {
+    K2_REQUIRE(idx >= 0 && idx < (int)(sizeof(kRing) / sizeof(kRing[0])), "no ring cfg %d", idx);
+    *bm = kRing[idx].BM;
+    *bn = kRing[idx].BN;
+    *waves = (kRing[idx].BM / 32) * (kRing[idx].BN / 32) * kRing[idx].KS + kRing[idx].LW + kRing[idx].PF;
+}
+int g_forced_ring = -1;
 void debug_force_gemm_cfg(int cfg) {
     const int dma_default = 1;
+    g_forced_ring = cfg >= 100 ? ((cfg - 100) & 0xff) : -1;
+    if (cfg >= 100) {
+        g_ablate = (cfg - 100) >> 8;
+        g_forced_cfg = -1;
+        g_use_dma = dma_default;
+        return;
+    }
     g_forced_cfg = cfg < 0 ? -1 : (cfg & 0x3f);
     g_ablate = cfg < 0 ? 0 : (cfg >> 8);
     g_use_dma = (cfg >= 0 && (cfg & 0x40)) ? 0 : dma_default;  // +64: classic (register-staged) kernel
@@ -653,12 +992,40 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         ctx.gemm_log->push_back({a.M, a.N, a.K, a.nb0 * a.nb1, a.act, a.res != nullptr, a.cv_Fout > 0 ? 1 : (a.w_kn ? 2 : 0), 0.f});
     // (a) N <= 96: few columns; (b) small problems (streaming chunks, beam search: a 128x64 grid would leave most CUs idle and
     // every workgroup would walk K serially): the same kernel over column chunks of 96
+    if (g_forced_ring >= 0) {  // tuning hook
+        const RingCfg& rc = kRing[g_forced_ring];
+        K2_REQUIRE(a.cv_Fout == 0 && !a.w_kn && !a.mul && a.res_div == 1 && !a.act_after_res && a.K % (32 * rc.KS) == 0 && a.K >= 32 * rc.KS,
+                   "ring cfg %d does not fit this GEMM", g_forced_ring);
+        K2_REQUIRE(launch_ring_idx(ctx, b, g_forced_ring), "no ring cfg %d", g_forced_ring);
+        K2_HIP(hipGetLastError());
+        if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
+        return;
+    }
     const Tunables& tn = tunables();
     const bool no_skinny = tn.gemm_no_skinny != 0, forced = g_forced_cfg >= 0 || tn.gemm_cfg >= 0, use_dma = g_use_dma && !tn.gemm_no_dma;
     const bool plain = a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.K % 64 == 0 && a.K >= 64;
     // (16-row workgroups re-read the weight chunk M/16 times: with many rows and a short K the 64x64 tiles are better)
     const bool few_tiles = (long long)cdiv(a.M, 128) * cdiv(a.N, 64) < 144 && a.M <= 4096 && !(a.M >= 2048 && a.K <= 256 && a.N > 272);
     const bool skinny_ok = !forced && !no_skinny && plain && !a.mul && ((a.N <= 96 && a.M >= 512) || few_tiles);
+    // Small problems with more than a handful of columns (the streaming chunk step: 256 .. 2048 rows): small ring tiles with the
+    // K step split over four (two) wave groups of the workgroup put 4 - 8 waves on ~200 CUs and walk K in K / 128 (K / 64) steps
+    // through coalesced LDS-DMA tiles, where the 16-row skinny kernel re-reads the weight chunk M / 16 times straight into
+    // fragment layout (half-used cache lines; it is bound by the texture-address path, not by latency).  Choice by grid size,
+    // from tools/gemm_lab.py streaming (gpurun_out/lab_str1.txt): 17 % less GEMM time over the chunk step's shapes.
+    if (skinny_ok && few_tiles && a.N > 96 && !tn.gemm_v1 && a.res_div == 1 && !a.act_after_res) {
+        const long long g32 = (long long)cdiv(a.M, 32) * cdiv(a.N, 32), g6432 = (long long)cdiv(a.M, 64) * cdiv(a.N, 32);
+        int ring = -1;
+        if (a.K % 128 == 0 && g32 <= 256) ring = 16;          // 32x32 tiles, KS 4, 4 stages + L2 prefetch wave
+        else if (a.K % 128 == 0 && g6432 <= 256) ring = 17;   // 64x32 tiles, KS 4, 3 stages
+        else if (a.K % 64 == 0 && (long long)cdiv(a.M, 64) * cdiv(a.N, 64) >= 96) ring = 8;  // 64x64 tiles, KS 2, 3 stages
+        if (ring >= 0) {
+            launch_ring_idx(ctx, b, ring);
+            K2_HIP(hipGetLastError());
+            if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 64;
+            if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
+            return;
+        }
+    }
     if (skinny_ok) {
         if (a.N <= 48) hipLaunchKernelGGL(gemm_f32_mfma_skinny<3>, dim3(cdiv(a.M, 16), 1), dim3(256), 0, ctx.stream, b);
         else if (a.K % 128 == 0 && ((a.K >= 1024 && (long long)cdiv(a.M, 16) * cdiv(a.N, 96) <= 384) ||

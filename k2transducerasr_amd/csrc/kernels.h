@@ -22,7 +22,7 @@ struct Tunables {
     int greedy_parts = 0;         // K2HIP_GREEDY_PARTS: vocabulary slabs per stream (0 = automatic)
     int pipe_mode = 0;            // K2HIP_PIPE_MODE: 1 = every pipeline slot owns a stream
     int max_streams = 0;          // K2HIP_MAX_STREAMS: slots of the streaming state pool (0 = 256)
-    int online_split = 0;         // K2HIP_ONLINE_SPLIT: 1 = never split a chunk step over two HIP streams, 2 = always (0 = automatic)
+    int online_split = 0;         // K2HIP_ONLINE_SPLIT: 2..4 = enqueue a chunk step as that many sub-batches on their own HIP streams (0 / 1: one chain)
 };
 void tunables_init_from_env();            // idempotent; called by k2hip_model_create
 const Tunables& tunables();
@@ -108,10 +108,12 @@ struct GemmArgs {
     const float* byp_orig = nullptr;
     const float* byp_scale = nullptr;
     int ld_orig = 0;
+    unsigned long long* dbg = nullptr;  // tuning only: in-kernel s_memtime stamps of the ring kernel, [workgroup][wave][64]
     int ablate = 0;  // tuning only: 1 = skip in-loop global loads, 2 = skip MFMAs, 4 = skip epilogue stores
 };
 void gemm(const Ctx& ctx, const GemmArgs& a);
 void debug_force_gemm_cfg(int cfg);  // tuning hook: -1 = automatic
+void debug_ring_shape(int idx, int* bm, int* bn, int* waves);  // tile and waves of ring table entry idx
 // convenience: plain Linear  C = act(A W^T + b) (+res)
 void linear(const Ctx& ctx, const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int K,
             int N, int act = ACT_NONE, const float* res = nullptr, int ldr = 0);

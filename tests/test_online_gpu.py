@@ -283,8 +283,8 @@ def test_streaming_128_concurrent_slots_zh(tmp_path_factory):
 
 @pytest.mark.parametrize("split", [2, 3, 4])
 def test_split_chunk_step_equals_single_stream_step(stream_model_path, ora, split):
-    """A chunk step over many streams is enqueued as sub-batches on their own HIP streams (K2HIP_ONLINE_SPLIT; automatic from 24
-    ready streams up).  Streams are independent, so the split must not change anything: same tokens / timestamps / Hyp as the
+    """A chunk step over many streams can be enqueued as sub-batches on their own HIP streams (K2HIP_ONLINE_SPLIT = 2..4; off by
+    default: measured, the chains do not overlap usefully -- DESIGN.md).  Streams are independent, so the split must not change anything: same tokens / timestamps / Hyp as the
     unsplit step and as the oracle after every call, same cached states, with ragged readiness (streams run out at different
     calls, so the sub-batch boundaries move)."""
     from k2transducerasr_amd import OnlineRecognizer, set_switch
@@ -324,5 +324,6 @@ def test_split_chunk_step_equals_single_stream_step(stream_model_path, ora, spli
     for u in (0, 3, 6):
         for l in range(so[u].num_layers):
             for k in KINDS:
-                np.testing.assert_allclose(sb[u].state(l, k), sa[u].state(l, k), atol=1e-6, rtol=0)
-        np.testing.assert_allclose(sb[u].state(0, "embed"), sa[u].state(0, "embed"), atol=1e-6, rtol=0)
+                # a sub-batch has fewer rows, so its GEMMs may take another tile configuration: same math, another summation order
+                np.testing.assert_allclose(sb[u].state(l, k), sa[u].state(l, k), atol=2e-5, rtol=0)
+        np.testing.assert_allclose(sb[u].state(0, "embed"), sa[u].state(0, "embed"), atol=2e-5, rtol=0)
