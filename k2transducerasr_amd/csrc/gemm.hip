@@ -633,9 +633,11 @@ __global__ __launch_bounds__(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)) void g
         return;
     }
 
-    f32x16 acc, acc1;
+    // (one accumulator per wave: a second, independent chain for alternate k steps was measured and changes nothing -- a lone wave
+    // issues dependent v_mfma_f32_32x32x2_f32 at the full 64-cycle rate, tools/probes/mfma_loop_probe.hip)
+    f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = acc1[r] = 0.f;
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
 
     const int arow = wr * 32 + li, brow = wc * 32 + li;
     const int swa = (arow >> 1) & 7, swb = ((BM + brow) >> 1) & 7;
@@ -671,15 +673,10 @@ __global__ __launch_bounds__(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)) void g
             _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                             \
                 const float av = e == 0 ? fa[cu_][gk].x : e == 1 ? fa[cu_][gk].y : e == 2 ? fa[cu_][gk].z : fa[cu_][gk].w; \
                 const float bv = e == 0 ? fb[cu_][gk].x : e == 1 ? fb[cu_][gk].y : e == 2 ? fb[cu_][gk].z : fb[cu_][gk].w; \
-                if (!(g.ablate & 2)) {                                                                                  \
-                    if (e & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc1, 0, 0, 0);                      \
-                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);                              \
-                } else if (e == 0) {                                                                                    \
-                    acc[0] += av * bv; /* keep the fragment reads alive */                                             \
-                }                                                                                                       \
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);                                       \
                 if (MORE_ && e == 0) {                                                                                  \
                     __builtin_amdgcn_sched_barrier(0);                                                                  \
-                    if (LW == 0 && gk == 0 && (kt_) + NST < nk && !(g.ablate & 1)) issue((kt_) + NST);                  \
+                    if (LW == 0 && gk == 0 && (kt_) + NST < nk) issue((kt_) + NST);                                     \
                     K2_RING_READ(nx_, st_next, gk)                                                                      \
                     __builtin_amdgcn_sched_barrier(0);                                                                  \
                 }                                                                                                       \
@@ -722,8 +719,6 @@ __global__ __launch_bounds__(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)) void g
 #undef K2_RING_SYNC
 #undef K2_RING_READ
 #undef K2_RING_WAIT
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] += acc1[r];
     K2_STAMP()
 
     // ---- the K groups' partial tiles meet in LDS; group g finishes registers [g RPG, (g+1) RPG)
@@ -1049,6 +1044,24 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 16;
         if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
         return;
+    }
+    // Single-round grids of large tiles (fewer operand bytes per MFMA: a CU's fetch rate, not the matrix pipe, bounds these
+    // launches -- tools/probes/mfma_loop_probe.hip): 128x96 tiles when they cover the output in 218 .. 256 workgroups, 128x128
+    // (16 waves) when they fill whole rounds of the 256 CUs and K is long enough to amortise the larger prologue
+    // (tools/gemm_lab.py offline, gpurun_out/lab_off5.txt: -14 % on 2048x1536x768, -15 % on 16160x192x2432, -3 .. -7 % on the others)
+    if (dma_ok && use_dma && !forced && !tn.gemm_v1 && a.nb0 * a.nb1 == 1 && a.M >= 1024) {
+        const long long t96 = a.N % 96 == 0 ? (long long)cdiv(a.M, 128) * (a.N / 96) : 0;
+        const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128);
+        int ring = -1;
+        if (t96 >= 218 && t96 <= 256) ring = 24;                                                    // 128x96, 2 stages + L2 prefetch wave
+        else if (a.K >= 512 && a.N >= 500 && t128 * 100 >= cdiv(t128, 256) * 256 * 85) ring = 18;   // 128x128, 2 stages
+        if (ring >= 0) {
+            launch_ring_idx(ctx, b, ring);
+            K2_HIP(hipGetLastError());
+            if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 64;
+            if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
+            return;
+        }
     }
     // (batched launches too -- the Conformer's per-(head, stream) score products -- as long as the tile choice is one of the DMA kernel's)
     if (dma_ok && use_dma && (cfg == 5 || cfg == 0 || (cfg >= 7 && cfg <= 11))) {

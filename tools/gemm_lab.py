@@ -31,9 +31,58 @@ def layer_shapes(M, D, F, H):
             (M, 12 * H, D, 0, 0, 2), (M, 2 * D, D, 0, 0, 2), (M, D, D, 0, 1, 2)]
 
 
+# the plain-GEMM launches of one B = 32 x 10 s batch of zipformer2-large-en, from an instrumented pass (tools/gemm_profile.py):
+# (M, N, K, act, res), launches per batch
+OFFLINE_REAL = [((4064, 1024, 512, 0, 0), 16), ((4064, 1920, 512, 1, 0), 8), ((4064, 512, 1920, 0, 1), 8), ((2048, 1536, 768, 0, 0), 10),
+                ((4064, 1536, 512, 1, 0), 8), ((4064, 1424, 512, 1, 0), 8), ((4064, 512, 1536, 0, 1), 8), ((4064, 1152, 512, 0, 0), 8),
+                ((2048, 768, 2560, 0, 1), 5), ((4064, 512, 512, 0, 1), 16), ((2048, 2560, 768, 1, 0), 5), ((2048, 768, 2048, 0, 1), 5),
+                ((2048, 2080, 768, 1, 0), 5), ((4064, 512, 1152, 0, 1), 8), ((307040, 384, 128, 1, 0), 1), ((2048, 768, 768, 0, 1), 10),
+                ((2048, 2048, 768, 1, 0), 5), ((2048, 1728, 768, 0, 0), 5), ((2048, 768, 1536, 0, 1), 5), ((307040, 128, 384, 0, 1), 1),
+                ((8096, 512, 256, 0, 0), 8), ((2048, 96, 768, 0, 0), 10), ((8096, 960, 256, 1, 0), 4), ((8096, 848, 256, 1, 0), 4),
+                ((4064, 48, 512, 0, 0), 16), ((4064, 512, 384, 0, 1), 8), ((8096, 256, 960, 0, 1), 4), ((16160, 192, 2432, 0, 0), 1),
+                ((8096, 256, 256, 0, 1), 8), ((8096, 256, 768, 0, 1), 4), ((8096, 768, 256, 1, 0), 4), ((8096, 576, 256, 0, 0), 4),
+                ((2048, 768, 576, 0, 1), 5), ((16160, 384, 192, 0, 0), 4), ((16160, 656, 192, 1, 0), 2), ((8096, 256, 576, 0, 1), 4),
+                ((16160, 192, 640, 0, 1), 2), ((16160, 640, 192, 1, 0), 2), ((16160, 192, 512, 0, 1), 2), ((16160, 192, 192, 0, 1), 4),
+                ((16160, 512, 192, 1, 0), 2), ((8096, 48, 256, 0, 0), 8), ((16160, 432, 192, 0, 0), 2), ((16160, 192, 384, 0, 1), 2),
+                ((8096, 256, 192, 0, 1), 4), ((8096, 512, 768, 0, 0), 1), ((16160, 48, 192, 0, 0), 4), ((8096, 500, 512, 0, 0), 1)]
+
+
+def streaming_real():
+    """plain-GEMM launches of one 128-stream chunk step of zipformer2-streaming-zh, from an instrumented step"""
+    import numpy as np
+    from collections import Counter
+    from k2transducerasr_amd.synth import synth_utterance
+    wpath = "/tmp/k2hip_bench_zipformer2-streaming-zh.k2w"
+    if not os.path.exists(wpath):
+        write_synthetic_model(wpath, "zipformer2-streaming-zh")
+    rec = pkg.OnlineRecognizer(wpath)
+    ss = [rec.create_online_stream() for _ in range(128)]
+    wave = np.stack([synth_utterance(1000 + u, 1.0) for u in range(128)])
+    need = (rec.chunk_length - 1) * 160 + 400
+    rec.add_samples_batch(ss, wave[:, :need])
+    rec.get_results(ss)
+    rec.add_samples_batch(ss, wave[:, need : need + 32 * 160])
+    rec.model.set_instrument(True)
+    rec.get_results(ss)
+    rows = rec.model.gemm_profile()
+    rec.model.set_instrument(False)
+    c = Counter()
+    for r in rows:
+        Mr, Nr, Kr, bat, act, res, kind = (int(x) for x in r[:7])
+        if bat == 1 and (kind & 3) == 0 and Kr % 32 == 0:
+            c[(Mr, Nr, Kr, act if act in (0, 1, 2) else 0, res)] += 1
+    for s_ in ss:
+        s_.close()
+    return sorted(c.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2])
+
+
 which = sys.argv[1] if len(sys.argv) > 1 else "offline"
 shapes = []
-if which in ("offline", "all"):
+if which == "offline":
+    shapes = list(OFFLINE_REAL)
+if which == "streaming-real":
+    shapes = streaming_real()
+if which in ("offline-synth", "all"):
     for M, D, F, H, nl in ((16160, 192, 512, 4, 2), (8096, 256, 768, 4, 4), (4064, 512, 1536, 4, 8), (2048, 768, 2048, 8, 5)):
         shapes += [(s[:5], s[5] * nl) for s in layer_shapes(M, D, F, H)]
     shapes += [((307040, 384, 128, 1, 0), 1), ((307040, 128, 384, 0, 1), 1), ((16160, 192, 2432, 0, 0), 1), ((8096, 512, 768, 0, 0), 1)]
