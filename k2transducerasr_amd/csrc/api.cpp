@@ -2,6 +2,7 @@
 // OfflineStream / OfflineRecognizer bookkeeping (K2TransducerAsr/OfflineStream.cs,
 // OfflineRecognizer.cs:77-91,289-296).
 #include <algorithm>
+#include <map>
 #include <new>
 
 #include "text.h"
@@ -30,7 +31,13 @@ struct k2hip_online_stream {
     k2hip_model* model;
     int slot = -1;
     std::vector<float> speech;     // OnlineInputEntity.Speech (feature FIFO)
-    std::vector<float> remainder;  // streaming fbank state
+    std::vector<float> remainder;  // streaming fbank state: samples of the last, incomplete frame shift
+    // Samples accepted since the features were last materialised.  AddSamples only appends here; the fbank of
+    // [remainder ; pending] runs when somebody needs the frames (the next chunk step, IsFinished, a feature read) -- for all
+    // streams of a step in ONE batched launch instead of one launch per 50 ms push.  Frames depend only on their own samples
+    // (no dither, no cross-frame state), so Speech is what per-call fbank would have appended; SpeechLength counts the frames
+    // the pending samples will give.
+    std::vector<float> pending;
     long long hyp[2] = {K2HIP_BLANK_ID, K2HIP_BLANK_ID};                 // :44
     std::vector<int64_t> tokens{K2HIP_BLANK_ID, K2HIP_BLANK_ID};         // :45
     std::vector<int32_t> timestamps;
@@ -473,20 +480,59 @@ int32_t k2hip_online_chunk_info(const k2hip_model_t* model, int32_t* chunk_lengt
     });
 }
 static void online_add_samples(k2hip_online_stream* s, const float* samples, int64_t n) {
-    Engine& e = s->model->engine;
+    if (n > 0) s->pending.insert(s->pending.end(), samples, samples + n);  // OnlineStream.AddSamples (:57-79), fbank deferred
+}
+// frames the stream's pending samples will add to Speech
+static int64_t online_pending_frames(const k2hip_online_stream* s) {
+    return s->pending.empty() ? 0 : s->model->engine.fbank_num_frames((int64_t)(s->remainder.size() + s->pending.size()));
+}
+static int64_t online_logical_floats(const k2hip_online_stream* s) {
+    return (int64_t)s->speech.size() + online_pending_frames(s) * s->model->engine.model().cfg().feat;
+}
+// run the deferred fbank of `n` streams of one model: streams at the same position share one batched launch
+static void online_materialize(k2hip_online_stream* const* streams, int n) {
+    if (n <= 0) return;
+    Engine& e = streams[0]->model->engine;
     const Config& c = e.model().cfg();
-    std::vector<float> wav(s->remainder);
-    wav.insert(wav.end(), samples, samples + n);
-    int64_t nf = e.fbank_num_frames((int64_t)wav.size());
-    if (nf > 0) {   // OnlineStream.cs:67: only when the fbank produced frames
-        size_t old = s->speech.size();
-        s->speech.resize(old + (size_t)nf * c.feat);
-        int64_t got = 0;
-        std::lock_guard<std::mutex> lk(e.mutex());
-        e.fbank_host(wav.data(), (int64_t)wav.size(), s->speech.data() + old, nf, &got);
-        s->remainder.assign(wav.begin() + (size_t)nf * c.fbank.frame_shift, wav.end());
-    } else {
-        s->remainder.swap(wav);
+    std::map<int64_t, std::vector<k2hip_online_stream*>> groups;  // by length of [remainder ; pending]
+    for (int i = 0; i < n; i++) {
+        k2hip_online_stream* s = streams[i];
+        if (s->pending.empty()) continue;
+        groups[(int64_t)(s->remainder.size() + s->pending.size())].push_back(s);
+    }
+    for (auto& kv : groups) {
+        const int64_t len = kv.first, nf = e.fbank_num_frames(len);
+        std::vector<k2hip_online_stream*>& g = kv.second;
+        const int G = (int)g.size();
+        if (nf == 0) {  // OnlineStream.cs:67: nothing is appended until the fbank produces a frame
+            for (k2hip_online_stream* s : g) {
+                s->remainder.insert(s->remainder.end(), s->pending.begin(), s->pending.end());
+                s->pending.clear();
+            }
+            continue;
+        }
+        std::vector<float> wav((size_t)G * len), feats((size_t)G * nf * c.feat);
+        for (int i = 0; i < G; i++) {
+            float* w = wav.data() + (size_t)i * len;
+            memcpy(w, g[i]->remainder.data(), sizeof(float) * g[i]->remainder.size());
+            memcpy(w + g[i]->remainder.size(), g[i]->pending.data(), sizeof(float) * g[i]->pending.size());
+        }
+        {
+            std::lock_guard<std::mutex> lk(e.mutex());
+            if (G == 1) {
+                int64_t got = 0;
+                e.fbank_host(wav.data(), len, feats.data(), nf, &got);
+            } else {
+                e.fbank_host_batch(wav.data(), len, G, feats.data(), nf);
+            }
+        }
+        for (int i = 0; i < G; i++) {
+            k2hip_online_stream* s = g[i];
+            s->speech.insert(s->speech.end(), feats.begin() + (size_t)i * nf * c.feat, feats.begin() + (size_t)(i + 1) * nf * c.feat);
+            const float* w = wav.data() + (size_t)i * len;
+            s->remainder.assign(w + (size_t)nf * c.fbank.frame_shift, w + len);
+            s->pending.clear();
+        }
     }
 }
 int32_t k2hip_online_stream_accept_samples(k2hip_online_stream_t* s, const float* samples, int64_t n) {
@@ -501,36 +547,10 @@ int32_t k2hip_online_accept_samples_batch(k2hip_model_t* model, k2hip_online_str
     return guard([&] {
         NEED(model); NEED(streams); NEED(samples); NEED(n);
         K2_REQUIRE(B > 0, "accept_samples_batch: empty list");
-        Engine& e = model->engine;
-        const Config& c = e.model().cfg();
-        bool uniform = true;
         for (int i = 0; i < B; i++) {
             NEED(streams[i]);
             if (n[i] > 0) NEED(samples[i]);
-            uniform = uniform && n[i] == n[0] && streams[i]->remainder.size() == streams[0]->remainder.size();
-        }
-        const int64_t len = (int64_t)streams[0]->remainder.size() + n[0];
-        const int64_t nf = uniform ? e.fbank_num_frames(len) : 0;
-        if (!uniform || nf == 0) {
-            for (int i = 0; i < B; i++) online_add_samples(streams[i], samples[i], n[i]);
-            return;
-        }
-        // all streams at the same position: one [B, len] buffer, one launch
-        std::vector<float> wav((size_t)B * len), feats((size_t)B * nf * c.feat);
-        for (int i = 0; i < B; i++) {
-            float* w = wav.data() + (size_t)i * len;
-            memcpy(w, streams[i]->remainder.data(), sizeof(float) * streams[i]->remainder.size());
-            memcpy(w + streams[i]->remainder.size(), samples[i], sizeof(float) * n[i]);
-        }
-        {
-            std::lock_guard<std::mutex> lk(e.mutex());
-            e.fbank_host_batch(wav.data(), len, B, feats.data(), nf);
-        }
-        for (int i = 0; i < B; i++) {
-            k2hip_online_stream* s = streams[i];
-            s->speech.insert(s->speech.end(), feats.begin() + (size_t)i * nf * c.feat, feats.begin() + (size_t)(i + 1) * nf * c.feat);
-            const float* w = wav.data() + (size_t)i * len;
-            s->remainder.assign(w + (size_t)nf * c.fbank.frame_shift, w + len);
+            online_add_samples(streams[i], samples[i], n[i]);
         }
     });
 }
@@ -539,10 +559,11 @@ int32_t k2hip_online_stream_accept_features(k2hip_online_stream_t* s, const floa
         NEED(s);
         if (n_frames > 0) NEED(feats);
         const int feat = s->model->engine.model().cfg().feat;
+        online_materialize(&s, 1);  // frames of samples accepted earlier come first
         s->speech.insert(s->speech.end(), feats, feats + n_frames * feat);
     });
 }
-int64_t k2hip_online_stream_speech_length(const k2hip_online_stream_t* s) { return s ? (int64_t)s->speech.size() : -1; }
+int64_t k2hip_online_stream_speech_length(const k2hip_online_stream_t* s) { return s ? online_logical_floats(s) : -1; }
 // OnlineStream.IsFinished (:124-161)
 int32_t k2hip_online_stream_is_finished(k2hip_online_stream_t* s, int32_t is_endpoint, int32_t* finished) {
     return guard([&] {
@@ -550,6 +571,7 @@ int32_t k2hip_online_stream_is_finished(k2hip_online_stream_t* s, int32_t is_end
         const Config& c = s->model->engine.model().cfg();
         *finished = 0;
         if (!is_endpoint) return;
+        online_materialize(&s, 1);  // the test below looks at the feature VALUES
         const size_t oLen = s->speech.size();
         if (oLen == 0) { *finished = 1; return; }
         double sum = 0.0;   // LINQ Average() over float[] accumulates in double and returns float
@@ -578,7 +600,7 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
             K2_REQUIRE(streams[i]->model == model, "stream %d belongs to another model", i);
             decoded[i] = 0;
             n_new_tokens[i] = 0;
-            if (streams[i]->speech.size() >= chunk_floats) idx.push_back(i);   // GetDecodeChunk (:82-100)
+            if ((size_t)online_logical_floats(streams[i]) >= chunk_floats) idx.push_back(i);   // GetDecodeChunk (:82-100)
         }
         {   // one stream twice in the list would consume two chunks against one state slot in the same launch
             std::vector<const k2hip_online_stream*> seen(streams, streams + B);
@@ -586,6 +608,11 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
             K2_REQUIRE(std::adjacent_find(seen.begin(), seen.end()) == seen.end(), "GetResults: the same stream appears twice in the list");
         }
         if (idx.empty()) return;   // :113-116
+        {   // the deferred fbank of the streams that decode now: one batched launch when they are at the same position
+            std::vector<k2hip_online_stream*> ready(idx.size());
+            for (size_t r = 0; r < idx.size(); r++) ready[r] = streams[idx[r]];
+            online_materialize(ready.data(), (int)ready.size());
+        }
         const int R = (int)idx.size(), Tp = e.online_frames_per_chunk();
         std::vector<float> chunks((size_t)R * chunk_floats);
         std::vector<int> slots(R);

@@ -553,8 +553,11 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     // workgroups must be co-resident (they wait for each other), so stay within half the chip (more parts shorten the search but cost the overlapped encoder more: 22 parts 11.4 / 22.8 ms against 16 parts 12.0 / 21.4 ms search / pipelined step on conformer-zh)
     const int ncg = w.Vp >> 2, pass = (GT / 64) * 8;
     const int bc = std::max(a.b_concurrent > 0 ? a.b_concurrent : a.B, 1);
-    int parts = std::min({(ncg + pass - 1) / pass, kMaxParts, 128 / bc});
-    if (tunables().greedy_parts > 0) parts = std::max(1, std::min({tunables().greedy_parts, kMaxParts, 128 / bc}));  // tuning only
+    // co-residency budget: half the chip offline (the search runs under the next batch's encoder), the whole chip for a streaming
+    // chunk step (nothing else is in flight; one 150 KB workgroup per CU)
+    const int budget = a.init_ctx ? 256 : 128;
+    int parts = std::min({(ncg + pass - 1) / pass, kMaxParts, budget / bc});
+    if (tunables().greedy_parts > 0) parts = std::max(1, std::min({tunables().greedy_parts, kMaxParts, budget / bc}));  // tuning only
     if (parts < 2 || tunables().greedy_one_part) parts = 1;
     a.parts = parts;
     const size_t gran_words = (size_t)a.B * 2 * parts * GF * 2;
