@@ -42,6 +42,7 @@ struct k2hip_online_stream {
     std::vector<int64_t> tokens{K2HIP_BLANK_ID, K2HIP_BLANK_ID};         // :45
     std::vector<int32_t> timestamps;
     long long processed_len = 0;   // processed_lens state (16 per chunk)
+    long long chunks_done = 0;     // chunks decoded so far: position of the stream's attention rings in its device slot
 };
 
 namespace {
@@ -617,6 +618,7 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
         std::vector<float> chunks((size_t)R * chunk_floats);
         std::vector<int> slots(R);
         std::vector<long long> hyps(2 * (size_t)R), plens(R);
+        std::vector<int> nch(R);
         for (int r = 0; r < R; r++) {
             k2hip_online_stream* s = streams[idx[r]];
             memcpy(chunks.data() + (size_t)r * chunk_floats, s->speech.data(), sizeof(float) * chunk_floats);
@@ -624,18 +626,21 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
             hyps[2 * r] = s->hyp[0];
             hyps[2 * r + 1] = s->hyp[1];
             plens[r] = s->processed_len;
+            nch[r] = (int)(s->chunks_done % (1LL << 30));  // the kernels only need it modulo the ring lengths; (1 << 30) % KL drift is
+                                                           // irrelevant before 2^30 chunks (~10 years of audio)
         }
         std::vector<int64_t> tok((size_t)R * Tp);
         std::vector<int32_t> ts((size_t)R * Tp), n(R);
         {
             std::lock_guard<std::mutex> lk(e.mutex());
-            e.online_step(slots.data(), chunks.data(), hyps.data(), plens.data(), R, tok.data(), ts.data(), n.data());
+            e.online_step(slots.data(), chunks.data(), hyps.data(), plens.data(), nch.data(), R, tok.data(), ts.data(), n.data());
         }
         // RemoveChunk (:102-117) only now: if the step above threw (a HIP failure, a search timeout), every stream still holds
         // its chunk and nothing host-side has moved -- the caller may retry or drop the streams
         for (int r = 0; r < R; r++) {
             k2hip_online_stream* s = streams[idx[r]];
             s->speech.erase(s->speech.begin(), s->speech.begin() + shift_floats);
+            s->chunks_done++;
             for (int k = 0; k < n[r]; k++) {
                 s->tokens.push_back(tok[(size_t)r * Tp + k]);          // :183
                 s->timestamps.push_back(ts[(size_t)r * Tp + k]);       // :184 (chunk-relative frame index)
@@ -680,7 +685,7 @@ int32_t k2hip_online_stream_state(k2hip_online_stream_t* s, int32_t layer, int32
     return guard([&] {
         NEED(s); NEED(n);
         std::lock_guard<std::mutex> lk(s->model->engine.mutex());
-        s->model->engine.online_read_state(s->slot, layer, kind, out, cap, n);
+        s->model->engine.online_read_state(s->slot, layer, kind, s->chunks_done, out, cap, n);
     });
 }
 

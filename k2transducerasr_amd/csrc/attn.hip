@@ -249,22 +249,39 @@ __global__ __launch_bounds__(256) void k_attn_scores_softmax_long(const float* _
 // ---------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// RING: streaming form -- the stream's values live in a ring of KL rows inside its slot of the state pool (RingRef, kernels.h), aw's
+// columns are in ring order, and the chunk's T new value rows (newrows [B*T, HV]) are written into the ring by this workgroup before
+// it reads them (every column slice of a stream writes the same bytes; nobody reads those rows before its own copy is stored).
+template <bool RING>
 __global__ __launch_bounds__(256) void k_attn_av_out(const float* __restrict__ aw, const float* __restrict__ v,
                                                      const float* __restrict__ wout, const float* __restrict__ bias,
                                                      float* __restrict__ x, int B, int T, int KL, int Tp, int Tk, int H, int vh,
-                                                     int D, int tiles_per_z) {
+                                                     int D, int tiles_per_z, RingRef ring, const float* __restrict__ newrows) {
     extern __shared__ float avs[];  // [16][HV + 1]
     const int HV = H * vh, AS = HV + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, i0 = blockIdx.x * 16;
     const int n = lane & 15, kq = lane >> 4;
+    if (RING) {
+        float* rb = ring.pool + (long long)ring.slots[b] * ring.slot_stride + ring.off;
+        const int head = (int)(((long long)ring.chunks[b] * T) % KL), h4 = HV >> 2;
+        for (int e = tid; e < T * h4; e += 256) {
+            const int r = e / h4, c = (e % h4) * 4;
+            *reinterpret_cast<float4*>(rb + (long long)((head + r) % KL) * HV + c) =
+                *reinterpret_cast<const float4*>(newrows + ((long long)b * T + r) * HV + c);
+        }
+        __syncthreads();
+        v = rb;  // this stream's ring: rows 0 .. KL-1
+    } else {
+        v += (long long)b * KL * HV;
+    }
     // ---- phase A: 64 keys per step = 4 groups of 16; lane (n, kq) holds keys k0 + 16 g + 4 kq + {0..3} of row i0 + n (A operand,
     // one float4 of aw) and of value column h*vh + n (B operand, four scalar loads: the stream's values, T x HV floats, stay in L2).
     const int row_a = min(i0 + n, T - 1);  // clamped rows are computed and dropped
     const bool ncol = n < vh;
     for (int h = wave; h < H; h += 4) {
         const float* arow = aw + (((long long)h * B + b) * T + row_a) * Tp + 4 * kq;
-        const float* vb = v + ((long long)b * KL + 4 * kq) * HV + h * vh + (ncol ? n : 0);
+        const float* vb = v + (long long)(4 * kq) * HV + h * vh + (ncol ? n : 0);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         float4 a4[4], a4n[4];
         float bv[4][4], bvn[4][4];
@@ -415,8 +432,28 @@ bool attn_av_out(const Ctx& ctx, const float* aw, const float* v, const float* w
     const int tiles_per_z = cdiv(ntile, cs);
     cs = cdiv(ntile, tiles_per_z);
     const size_t lds = sizeof(float) * 16 * (HV + 1);
-    hipLaunchKernelGGL(k_attn_av_out, dim3(cdiv(T, 16), B, cs), dim3(256), lds, ctx.stream, aw, v, wout, bias, x, B, T, KL, Tp, Tk, H, vh,
-                       D, tiles_per_z);
+    hipLaunchKernelGGL(k_attn_av_out<false>, dim3(cdiv(T, 16), B, cs), dim3(256), lds, ctx.stream, aw, v, wout, bias, x, B, T, KL, Tp, Tk, H, vh,
+                       D, tiles_per_z, RingRef(), nullptr);
+    K2_HIP(hipGetLastError());
+    return true;
+}
+
+bool attn_av_out_ring(const Ctx& ctx, const float* aw, const RingRef& vals, const float* newrows, const float* wout, const float* bias, float* x,
+                      int B, int T, int KL, int Tp, int H, int vh, int D) {
+    const int HV = H * vh, Tk = (KL + 63) & ~63;
+    // (no GEMM fallback in the ring form: the shapes of the streaming recipe always fit; anything else is refused)
+    K2_REQUIRE(vh <= 16 && HV % 4 == 0 && HV <= 128 && D % 16 == 0 && Tp % 4 == 0 && Tp >= KL && T <= 16,
+               "attn_av_out_ring: shape H=%d vh=%d D=%d T=%d KL=%d unsupported", H, vh, D, T, KL);
+    ctx.add_flops(0.0, 2.0 * B * (double)T * HV * (KL + D), 0);
+    if (ctx.dry) return true;
+    const int strips = B, ntile = D / 16;
+    int cs = std::max(1, std::min(4, 512 / std::max(1, strips)));
+    cs = std::min(cs, ntile);
+    const int tiles_per_z = cdiv(ntile, cs);
+    cs = cdiv(ntile, tiles_per_z);
+    const size_t lds = sizeof(float) * 16 * (HV + 1);
+    hipLaunchKernelGGL(k_attn_av_out<true>, dim3(1, B, cs), dim3(256), lds, ctx.stream, aw, nullptr, wout, bias, x, B, T, KL, Tp, Tk, H, vh, D,
+                       tiles_per_z, vals, newrows);
     K2_HIP(hipGetLastError());
     return true;
 }

@@ -94,10 +94,12 @@ class Engine {
     // ---- streaming (OnlineRecognizer) path: online_engine.cpp ----
     int online_alloc_slot();   // GetEncoderInitStates: a zeroed slot of the device state pool
     void online_free_slot(int slot);
-    void online_read_state(int slot, int layer, int kind, float* out, int64_t cap, int64_t* n);
+    void online_read_state(int slot, int layer, int kind, long long chunks_done, float* out, int64_t cap, int64_t* n);
+    int online_tc50() const;
     int online_frames_per_chunk() const;
     // one tick over B streams that each have a full chunk: chunks [B][T*feat] (host), hyps [B][2], plens [B]
-    void online_step(const int* slots, const float* chunks, const long long* hyps, const long long* plens, int B,
+    // nchunks [B]: chunks each stream has decoded before this step (position of its attention rings)
+    void online_step(const int* slots, const float* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
                      int64_t* tokens, int32_t* ts, int32_t* n_tokens);
 
     void set_instrument(bool on) { instrument_ = on; }
@@ -168,7 +170,7 @@ class Engine {
     void online_ensure_pool();
     float* encoder_embed_stream(const Ctx& c, const float* x, const int* d_slots, int B, int T, int* Tc);
     void encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x, const float* pe, const int* d_slots,
-                              const long long* d_plen, int B, int Tc, int L);
+                              const long long* d_plen, const int* d_chunks, int B, int Tc, int L);
     // one sub-batch of a streaming chunk step: its own stream, arena, pinned staging, events and GEMM statistics
     struct OnlineSub {
         Arena arena;
@@ -187,10 +189,11 @@ class Engine {
     OnlineSub subs_[kMaxSubs];
     ForkJoin fork_;
     std::mutex cache_mu_;  // pos_proj / pos_emb / decjoin tables are built lazily, possibly from several sub-batch threads
-    void online_sub_step(OnlineSub& s, const int* slots, const float* chunks, const long long* hyps, const long long* plens, int B, int B_all);
-    void online_step_split(const int* slots, const float* chunks, const long long* hyps, const long long* plens, int B, int K,
-                           int64_t* tokens, int32_t* ts, int32_t* n_tokens);
-    float* online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_slots, const long long* d_plen, int B);
+    void online_sub_step(OnlineSub& s, const int* slots, const float* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
+                         int B_all);
+    void online_step_split(const int* slots, const float* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
+                           int K, int64_t* tokens, int32_t* ts, int32_t* n_tokens);
+    float* online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_slots, const long long* d_plen, const int* d_chunks, int B);
     bool subs_warm_ = false;
     DecJoinW decjoin();
     float* d_ptab_ = nullptr;  // [2][V][DD] per-token decoder-conv table (groups = 1 models), built on first use

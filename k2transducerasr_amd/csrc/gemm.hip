@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
     const int z = blockIdx.z;
     const int z0 = z % g.nb0, z1 = z / g.nb0;
     const float* __restrict__ A = g.A + z0 * g.sA0 + z1 * g.sA1;
-    const float* __restrict__ W = g.W + z0 * g.sW0 + z1 * g.sW1;
+    const float* __restrict__ W = g.W + (MODE == MODE_WKN && g.wz_map ? (long long)g.wz_map[z0] : (long long)z0) * g.sW0 + z1 * g.sW1;
     float* __restrict__ C = g.C + z0 * g.sC0 + z1 * g.sC1;
     const float* __restrict__ R = g.res ? g.res + z0 * g.sR0 + z1 * g.sR1 : nullptr;
 
@@ -968,6 +968,7 @@ void debug_force_gemm_cfg(int cfg) {
 
 void gemm(const Ctx& ctx, const GemmArgs& a) {
     K2_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty shape %dx%dx%d", a.M, a.N, a.K);
+    K2_REQUIRE(!a.wz_map || a.w_kn, "gemm: wz_map is for the [K,N] operand form");
     K2_REQUIRE(a.cv_Fout > 0 || a.lda % 4 == 0, "gemm: lda %d must be a multiple of 4", a.lda);
     K2_REQUIRE(a.K >= 4 || (a.w_kn && a.K >= 1), "gemm: K=%d too small", a.K);  // [K,N] form: A rows are zero-padded to 4, W rows k >= K masked
     K2_REQUIRE(a.w_kn || a.K % 4 == 0, "gemm: K %d must be a multiple of 4", a.K);

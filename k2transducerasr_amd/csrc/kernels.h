@@ -88,6 +88,7 @@ struct GemmArgs {
     int w_kn = 0;
     // batching over blockIdx.z = z0 + nb0 * z1
     int nb0 = 1, nb1 = 1;
+    const int* wz_map = nullptr;  // [K,N] form only: batch z0 reads W + wz_map[z0] * sW0 (stream slots of the state pool)
     long long sA0 = 0, sA1 = 0, sW0 = 0, sW1 = 0, sC0 = 0, sC1 = 0, sR0 = 0, sR1 = 0;
     long long sBias0 = 0;  // bias + z0 * sBias0 (batched launches over layers, each with its own bias)
     // implicit-conv gather of A over an NHWC tensor [B, Tin, Fin, C]:
@@ -118,6 +119,18 @@ void debug_ring_shape(int idx, int* bm, int* bn, int* waves);  // tile and waves
 void linear(const Ctx& ctx, const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int K,
             int N, int act = ACT_NONE, const float* res = nullptr, int ldr = 0);
 
+// A per-stream cache kept as a RING of KL = L + Tc rows inside the stream's slot of the state pool (streaming Zipformer2): the
+// chunk's Tc new rows overwrite the Tc oldest ones in place, nothing is rolled.  Chunk n of a stream writes its row r to ring row
+// (head + r) % KL, head = (n * Tc) % KL; in the order of the reference's [cache ; chunk] concatenation (j = 0 oldest .. KL - 1
+// newest) row j is at (head + Tc + j) % KL.
+struct RingRef {
+    float* pool = nullptr;         // state pool
+    long long slot_stride = 0;     // floats per stream
+    long long off = 0;             // float offset of this ring inside a slot
+    const int* slots = nullptr;    // [B] slot of each stream of the step
+    const int* chunks = nullptr;   // [B] chunks each stream has decoded before this step
+};
+
 // ---- attention ------------------------------------------------------------
 // qkp: [B*T, ld] rows = (q[H*32] | k[H*32] | p[H*4]); pp: [2T-1, H*4];
 // aw out: [H][B][T][Tp] (Tp = T rounded up to 4, pad columns zeroed)
@@ -131,6 +144,10 @@ void attn_scores_softmax(const Ctx& ctx, const float* qkp, int ld, const float* 
 // returns false (nothing launched, nothing tallied) when the shape does not fit the kernel -- the caller then takes the GEMM path
 bool attn_av_out(const Ctx& ctx, const float* aw, const float* v, const float* wout, const float* bias, float* x, int B, int T, int KL, int Tp,
                  int H, int vh, int D);
+// streaming ring form: values of the left context come from the ring (rows in ring order, like aw's columns); the chunk's value
+// rows (newrows [B*T, H*vh]) are written into the ring by the kernel itself before it reads them.  T <= 16 (one row strip).
+bool attn_av_out_ring(const Ctx& ctx, const float* aw, const RingRef& vals, const float* newrows, const float* wout, const float* bias, float* x,
+                      int B, int T, int KL, int Tp, int H, int vh, int D);
 
 // ---- elementwise / small -----------------------------------------------------
 // packed: all streams' features back to back; d_off/d_len: per-stream start and float count (device)
@@ -301,8 +318,16 @@ void convnext_cat(const Ctx& ctx, const float* a3, const float* pool, long long 
 void convnext_cache_update(const Ctx& ctx, const float* a3, float* pool, long long slot_stride, long long embed_off,
                            const int* slots, int B, int T3, int Tc, int F, int C);
 // tanh_gated: the new rows are formed as x[width + c] * tanh(x[c]) from rows of >= 2*width floats (NonlinAttention's gated input)
+// the chunk's new rows (newrows [B*Tc, ldn], `width` columns; gated: x[width + c] * tanh(x[c]) of rows of >= 2 * width floats,
+// NonlinAttention's cached input) into their ring rows
+void ring_put(const Ctx& ctx, const RingRef& ring, const float* newrows, int ldn, int B, int L, int Tc, int width, bool tanh_gated);
 void cat_shift(const Ctx& ctx, float* pool, long long slot_stride, long long off, const int* slots, const float* newrows,
                int ldn, float* cat, int B, int L, int Tc, int width, bool tanh_gated = false);
+// ring form: the keys of the left context are read from the ring, the chunk's own key rows (columns [32 H, 64 H) of qkp) are
+// written into it first; aw columns are in RING order (column p = the key stored in ring row p), which is also the order the
+// value rings are read in -- a weighted sum does not care.
+void attn_stream_ring(const Ctx& ctx, const float* qkp, int ld, const RingRef& keys, const float* pp, const long long* plen,
+                      float* aw, int B, int Tc, int L, int KLp, int H, int ds, int left50);
 void attn_stream(const Ctx& ctx, const float* qkp, int ld, const float* kcat, const float* pp, const long long* plen,
                  float* aw, int B, int Tc, int L, int KLp, int H, int ds, int left50);
 void glu_causal_conv(const Ctx& ctx, const float* x2, float* pool, long long slot_stride, long long off, const int* slots,

@@ -104,6 +104,86 @@ __global__ void k_cat_shift(float* __restrict__ pool, long long slot_stride, lon
     }
 }
 
+template <bool GATE>
+__global__ void k_ring_put(RingRef ring, const float* __restrict__ newrows, int ldn, int B, int L, int Tc, int width) {
+    const int w4 = width >> 2, KL = L + Tc;
+    const long long n = (long long)B * Tc * w4;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % w4) * 4;
+    const long long br = i / w4;
+    const int r = (int)(br % Tc), b = (int)(br / Tc);
+    const int head = (int)(((long long)ring.chunks[b] * Tc) % KL);
+    const float* p = newrows + ((long long)b * Tc + r) * ldn + c;
+    float4 v = *reinterpret_cast<const float4*>(GATE ? p + width : p);
+    if (GATE) {
+        const float4 sg = *reinterpret_cast<const float4*>(p);
+        v = make_float4(v.x * tanhf(sg.x), v.y * tanhf(sg.y), v.z * tanhf(sg.z), v.w * tanhf(sg.w));
+    }
+    *reinterpret_cast<float4*>(ring.pool + (long long)ring.slots[b] * ring.slot_stride + ring.off + (long long)((head + r) % KL) * width + c) = v;
+}
+
+// RelPositionMultiheadAttentionWeights.streaming_forward for one (stream, head), keys in the stream's ring (RingRef): the
+// chunk's own key rows go into the ring first (this workgroup's 32 columns of them; nobody else reads or writes those), then every
+// key is read from ring row p.  Column p of aw = ring row p; the reference's key index of that row (for the positional term and the
+// left-context mask) is j = (p - head - Tc) mod KL.
+__global__ __launch_bounds__(256) void k_attn_stream_ring(const float* __restrict__ qkp, int ld, RingRef keys, const float* __restrict__ pp,
+                                                          const long long* __restrict__ plen, float* __restrict__ aw, int B, int Tc,
+                                                          int L, int KLp, int H, int ds, int left50) {
+    extern __shared__ float S[];  // [Tc][KL]
+    const int b = blockIdx.x, h = blockIdx.y, KL = L + Tc;
+    const int QH = 32, PH = 4;
+    const long long pl = plen[b];
+    const int head = (int)(((long long)keys.chunks[b] * Tc) % KL);
+    float* ring = keys.pool + (long long)keys.slots[b] * keys.slot_stride + keys.off;
+    for (int e = threadIdx.x; e < Tc * (QH / 4); e += blockDim.x) {
+        const int r = e / (QH / 4), c = (e % (QH / 4)) * 4;
+        *reinterpret_cast<float4*>(ring + (long long)((head + r) % KL) * (H * QH) + h * QH + c) =
+            *reinterpret_cast<const float4*>(qkp + ((long long)b * Tc + r) * ld + H * QH + h * QH + c);
+    }
+    __syncthreads();  // this workgroup's stores are visible to its own loads below (no line of the ring was cached before them)
+    for (int e = threadIdx.x; e < Tc * KL; e += blockDim.x) {
+        const int i = e / KL, p = e - i * KL;
+        int j = (p - head - Tc) % KL;
+        if (j < 0) j += KL;
+        const float* q = qkp + ((long long)b * Tc + i) * ld + h * QH;
+        const float* pq = qkp + ((long long)b * Tc + i) * ld + 2 * H * QH + h * PH;
+        const float* k = ring + (long long)p * (H * QH) + h * QH;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < QH; d += 4) {
+            float4 a = *reinterpret_cast<const float4*>(q + d), c = *reinterpret_cast<const float4*>(k + d);
+            s += a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+        }
+        float4 pv = *reinterpret_cast<const float4*>(pq);
+        float4 ev = *reinterpret_cast<const float4*>(pp + (long long)(Tc - 1 - i + j) * (H * PH) + h * PH);
+        s += pv.x * ev.x + pv.y * ev.y + pv.z * ev.z + pv.w * ev.w;
+        // src_key_padding_mask[..., ::ds]: left-context slot j (50 Hz slot j*ds) is valid only once processed
+        if (j < L && pl <= (long long)(left50 - 1 - j * ds)) s = -1000.0f;
+        S[e] = s;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* out = aw + (((long long)h * B + b) * Tc) * KLp;
+    for (int i = wave; i < Tc; i += 4) {
+        float* row = S + i * KL;
+        float mx = -INFINITY;
+        for (int j = lane; j < KL; j += 64) mx = fmaxf(mx, row[j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int j = lane; j < KL; j += 64) {
+            float e = __expf(row[j] - mx);
+            row[j] = e;
+            sum += e;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        float inv = 1.0f / sum;
+        for (int j = lane; j < KLp; j += 64) out[(long long)i * KLp + j] = j < KL ? row[j] * inv : 0.f;
+    }
+}
+
 // RelPositionMultiheadAttentionWeights.streaming_forward for one (stream, head):
 //   scores[i,j] = q_i.k_j + p_i.pos[Tc-1-i+j]; key j < L masked (-1000) while the left context is not
 //   yet filled (processed_lens); softmax over j.  aw: [H][B][Tc][KLp]
@@ -255,6 +335,22 @@ void cat_shift(const Ctx& ctx, float* pool, long long slot_stride, long long off
         hipLaunchKernelGGL(k_cat_shift<true>, grid, dim3(256), 0, ctx.stream, pool, slot_stride, off, slots, newrows, ldn, cat, B, L, Tc, width);
     else
         hipLaunchKernelGGL(k_cat_shift<false>, grid, dim3(256), 0, ctx.stream, pool, slot_stride, off, slots, newrows, ldn, cat, B, L, Tc, width);
+    K2_HIP(hipGetLastError());
+}
+void ring_put(const Ctx& ctx, const RingRef& ring, const float* newrows, int ldn, int B, int L, int Tc, int width, bool tanh_gated) {
+    K2_REQUIRE(width % 4 == 0 && ldn % 4 == 0, "ring_put: width %d / ld %d must be multiples of 4", width, ldn);
+    if (ctx.dry) return;
+    const dim3 grid(nb((long long)B * Tc * (width / 4), 256));
+    if (tanh_gated) hipLaunchKernelGGL(k_ring_put<true>, grid, dim3(256), 0, ctx.stream, ring, newrows, ldn, B, L, Tc, width);
+    else hipLaunchKernelGGL(k_ring_put<false>, grid, dim3(256), 0, ctx.stream, ring, newrows, ldn, B, L, Tc, width);
+    K2_HIP(hipGetLastError());
+}
+void attn_stream_ring(const Ctx& ctx, const float* qkp, int ld, const RingRef& keys, const float* pp, const long long* plen, float* aw, int B,
+                      int Tc, int L, int KLp, int H, int ds, int left50) {
+    ctx.add_flops(0.0, 2.0 * 36 * (double)Tc * (L + Tc) * B * H, 0);
+    if (ctx.dry) return;
+    size_t lds = sizeof(float) * Tc * (L + Tc);
+    hipLaunchKernelGGL(k_attn_stream_ring, dim3(B, H), dim3(256), lds, ctx.stream, qkp, ld, keys, pp, plen, aw, B, Tc, L, KLp, H, ds, left50);
     K2_HIP(hipGetLastError());
 }
 void attn_stream(const Ctx& ctx, const float* qkp, int ld, const float* kcat, const float* pp, const long long* plen,

@@ -61,13 +61,17 @@ void Engine::online_ensure_pool() {
         for (int i = online_cap_ - 1; i >= 0; i--) free_slots_.push_back(i);
         return;
     }
+    // The four attention caches of a layer are RINGS of KL = left + Tc rows (kernels.h: RingRef): a chunk's rows overwrite the oldest
+    // ones in place instead of the whole cache being rolled every chunk.  What GetEncoderInitStates / unstack_states define -- the
+    // newest `left` rows in order -- is what online_read_state returns.
+    const int tc50 = online_tc50();
     for (int si = 0; si < c.ns; si++) {
-        const int D = c.dim[si], H = c.heads[si], left = c.left[si];
+        const int D = c.dim[si], H = c.heads[si], left = c.left[si], kl = left + (tc50 + c.ds[si] - 1) / c.ds[si];
         for (int li = 0; li < c.nlayer[si]; li++) {
-            put(L.key, (long long)left * c.qhd[si] * H);
-            put(L.nonlin, (long long)left * (3 * D / 4));
-            put(L.val1, (long long)left * c.vhd[si] * H);
-            put(L.val2, (long long)left * c.vhd[si] * H);
+            put(L.key, (long long)kl * c.qhd[si] * H);
+            put(L.nonlin, (long long)kl * (3 * D / 4));
+            put(L.val1, (long long)kl * c.vhd[si] * H);
+            put(L.val2, (long long)kl * c.vhd[si] * H);
             put(L.conv1, (long long)D * (c.kern[si] / 2));
             put(L.conv2, (long long)D * (c.kern[si] / 2));
             L.sizes.push_back({(long long)left * c.qhd[si] * H, (long long)left * (3 * D / 4), (long long)left * c.vhd[si] * H,
@@ -101,7 +105,13 @@ void Engine::online_free_slot(int slot) {
     if (slot >= 0) free_slots_.push_back(slot);
 }
 
-void Engine::online_read_state(int slot, int layer, int kind, float* out, int64_t cap, int64_t* n) {
+// frames of one chunk after Conv2dSubsampling + ConvNeXt (50 Hz): T = 45 -> 16
+int Engine::online_tc50() const {
+    const int T = model_->cfg().chunk_T, T1 = T - 2, T2 = (T1 - 3) / 2 + 1, T3 = T2 - 2;
+    return T3 - 3;
+}
+
+void Engine::online_read_state(int slot, int layer, int kind, long long chunks_done, float* out, int64_t cap, int64_t* n) {
     online_ensure_pool();
     K2_REQUIRE(slot >= 0 && slot < online_cap_, "bad slot %d", slot);
     long long off, cnt;
@@ -135,6 +145,24 @@ void Engine::online_read_state(int slot, int layer, int kind, float* out, int64_
     if (cnt > cap) failf(K2HIP_ERR_CAPACITY, "state needs %lld floats", cnt);
     K2_HIP(hipSetDevice(device_));
     K2_HIP(hipStreamSynchronize(stream_));
+    const Config& cfz = model_->cfg();
+    if (!cfz.conformer && !cfz.lstm && !cfz.zip1 && kind >= 0 && kind < 4) {
+        // attention caches are rings: the cache the reference would hold after `chunks_done` chunks is rows Tc .. KL-1 of the last
+        // [cache ; chunk] concatenation, i.e. ring rows (head + 2 Tc + j) % KL, j = 0 .. left-1, head = ((chunks_done - 1) Tc) % KL
+        int si = 0, acc = 0;
+        while (si < cfz.ns && layer >= acc + cfz.nlayer[si]) acc += cfz.nlayer[si++];
+        const int left = cfz.left[si], tc = (online_tc50() + cfz.ds[si] - 1) / cfz.ds[si], kl = left + tc;
+        const long long width = cnt / left;
+        std::vector<float> ring((size_t)kl * width);
+        K2_HIP(hipMemcpy(ring.data(), online_pool_ + (size_t)slot * lay_.floats_per_stream + off, sizeof(float) * ring.size(), hipMemcpyDeviceToHost));
+        // before the first chunk the ring is all zeros and any rotation of it is the reference's zero cache
+        const long long head = chunks_done > 0 ? ((chunks_done - 1) * tc) % kl : 0;
+        for (int j = 0; j < left; j++) {
+            const long long p = (head + 2LL * tc + j) % kl;
+            memcpy(out + (size_t)j * width, ring.data() + (size_t)p * width, sizeof(float) * (size_t)width);
+        }
+        return;
+    }
     K2_HIP(hipMemcpy(out, online_pool_ + (size_t)slot * lay_.floats_per_stream + off, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost));
 }
 
@@ -228,7 +256,7 @@ float* Engine::encoder_embed_stream(const Ctx& c, const float* x, const int* d_s
 
 // Zipformer2EncoderLayer.streaming_forward, in place on x [B*Tc, D]; l = global layer index
 void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x, const float* pe, const int* d_slots,
-                                  const long long* d_plen, int B, int Tc, int L) {
+                                  const long long* d_plen, const int* d_chunks, int B, int Tc, int L) {
     const Model& m = *model_;
     const Config& cf = m.cfg();
     const int D = cf.dim[si], F = cf.ff[si], H = cf.heads[si], vh = cf.vhd[si], K = cf.kern[si], qh = cf.qhd[si], ph = cf.phd[si];
@@ -241,19 +269,29 @@ void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x,
     int64_t mark = ar.mark();
     const long long SS = lay_.floats_per_stream;
 
-    float* qkp = ar.take<float>((int64_t)M * inproj);
-    linear(c, x, D, w("self_attn_weights.in_proj.weight"), w("self_attn_weights.in_proj.bias"), qkp, inproj, M, D, inproj);
-    float* kcat = ar.take<float>((int64_t)B * KL * qh * H);
-    cat_shift(c, online_pool_, SS, lay_.key[l], d_slots, qkp + qh * H, inproj, kcat, B, L, Tc, qh * H);
+    // [ff1.in_proj | attention-weights in_proj] of the layer input in one GEMM, as in the offline layer (model.cpp stacks the
+    // two weight matrices): one launch fewer per layer
+    const int F1 = F * 3 / 4, ldcat = F1 + inproj;
+    float* cat = ar.take<float>((int64_t)M * ldcat);
+    {
+        GemmArgs g;
+        g.A = x; g.lda = D; g.W = w("#ff1_attn_in.weight"); g.ldw = D; g.bias = w("#ff1_attn_in.bias");
+        g.C = cat; g.ldc = ldcat; g.M = M; g.N = ldcat; g.K = D; g.act = ACT_SWOOSH_L; g.act_cols = F1;
+        gemm(c, g);
+    }
+    const float* qkp = cat + F1;
+    auto ring = [&](long long off) {
+        RingRef r;
+        r.pool = online_pool_; r.slot_stride = SS; r.off = off; r.slots = d_slots; r.chunks = d_chunks;
+        return r;
+    };
     const float* pp = pos_proj_cached(c, 1000 + l, pe, cf.pos_dim, w("self_attn_weights.linear_pos.weight"), n2, ph * H);
-    float* aw = ar.take<float>((int64_t)H * B * Tc * KLp);
-    attn_stream(c, qkp, inproj, kcat, pp, d_plen, aw, B, Tc, L, KLp, H, cf.ds[si], left50);
+    float* aw = ar.take<float>((int64_t)H * B * Tc * KLp);  // columns in ring order
+    attn_stream_ring(c, qkp, ldcat, ring(lay_.key[l]), pp, d_plen, aw, B, Tc, L, KLp, H, cf.ds[si], left50);
 
     float* src = ar.take<float>((int64_t)M * D);
     float* hid = ar.take<float>((int64_t)M * std::max({F * 5 / 4, 3 * Hc, 2 * D}));
-    float* tmp = ar.take<float>((int64_t)M * std::max(D, Hc));
     float* tmp2 = ar.take<float>((int64_t)M * std::max(D, Hc));
-    float* vcat = ar.take<float>((int64_t)B * KL * std::max(Hc, HV));
 
     auto feed_forward = [&](int k, int Fk, const float* in, float* out) {
         char a[48], b[48], cc[48], d[48];
@@ -264,14 +302,14 @@ void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x,
         linear(c, in, D, w(a), w(b), hid, Fk, M, D, Fk, ACT_SWOOSH_L);
         linear(c, hid, Fk, w(cc), w(d), out, D, M, Fk, D, ACT_NONE, in, D);
     };
-    // out[b, :, col0:col0+n] = aw[h][b] (Tc x KL) . cat[b] (KL x width)[:, col0:col0+n]
-    auto attn_apply = [&](const float* cat, int width, float* out, int ldo, int nheads, int ncols, const float* gate = nullptr, int ldg = 0) {
+    // out[b] = aw[0][b] (Tc x KL, ring order) . ring[slot_b] (KL x width), times the gate in the epilogue
+    auto attn_apply_ring = [&](long long off, int width, float* out, const float* gate, int ldg) {
         GemmArgs g;
-        if (gate) { g.mul = gate; g.ldm = ldg; g.sM0 = (long long)Tc * ldg; }  // out *= gate in the epilogue
+        g.mul = gate; g.ldm = ldg; g.sM0 = (long long)Tc * ldg;
         g.A = aw; g.lda = KLp; g.sA0 = (long long)Tc * KLp; g.sA1 = (long long)B * Tc * KLp;
-        g.W = cat; g.w_kn = 1; g.ldw = width; g.sW0 = (long long)KL * width; g.sW1 = ncols;
-        g.C = out; g.ldc = ldo; g.sC0 = (long long)Tc * ldo; g.sC1 = ncols;
-        g.M = Tc; g.N = ncols; g.K = KL; g.nb0 = B; g.nb1 = nheads;
+        g.W = online_pool_ + off; g.w_kn = 1; g.ldw = width; g.sW0 = SS; g.wz_map = d_slots;
+        g.C = out; g.ldc = width; g.sC0 = (long long)Tc * width;
+        g.M = Tc; g.N = width; g.K = KL; g.nb0 = B; g.nb1 = 1;
         gemm(c, g);
     };
     auto self_attn = [&](int k, long long cache_off) {
@@ -281,10 +319,8 @@ void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x,
         snprintf(cc, sizeof cc, "self_attn%d.out_proj.weight", k);
         snprintf(d, sizeof d, "self_attn%d.out_proj.bias", k);
         linear(c, src, D, w(a), w(b), hid, HV, M, D, HV);
-        cat_shift(c, online_pool_, SS, cache_off, d_slots, hid, HV, vcat, B, L, Tc, HV);
-        if (attn_av_out(c, aw, vcat, w(cc), w(d), src, B, Tc, KL, KLp, H, vh, D)) return;  // fused apply + out_proj + residual
-        attn_apply(vcat, HV, tmp, HV, H, vh);
-        linear(c, tmp, HV, w(cc), w(d), src, D, M, HV, D, ACT_NONE, src, D);
+        // fused: chunk rows into the value ring, attention apply over the ring, out_proj, residual
+        attn_av_out_ring(c, aw, ring(cache_off), hid, w(cc), w(d), src, B, Tc, KL, KLp, H, vh, D);
     };
     auto conv_module = [&](int k, long long cache_off) {
         char a[80], b[80], e[80], f[80], n1[96], n2_[96], n3[96], n4[96], n5[96];
@@ -302,11 +338,12 @@ void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x,
         linear(c, tmp2, D, w(e), w(f), src, D, M, D, D, ACT_NONE, src, D);
     };
 
-    feed_forward(1, F * 3 / 4, x, src);
+    // src = x + ff1(x): the hidden activations are the first F1 columns of `cat`
+    linear(c, cat, ldcat, w("feed_forward1.out_proj.weight"), w("feed_forward1.out_proj.bias"), src, D, M, F1, D, ACT_NONE, x, D);
     {   // NonlinAttention.streaming_forward
         linear(c, src, D, w("nonlin_attention.in_proj.weight"), w("nonlin_attention.in_proj.bias"), hid, 3 * Hc, M, D, 3 * Hc);
-        cat_shift(c, online_pool_, SS, lay_.nonlin[l], d_slots, hid, 3 * Hc, vcat, B, L, Tc, Hc, /*tanh_gated=*/true);  // x * tanh(s) on the fly
-        attn_apply(vcat, Hc, tmp2, Hc, 1, Hc, hid + 2 * Hc, 3 * Hc);  // x * y (the third chunk of in_proj) in the epilogue
+        ring_put(c, ring(lay_.nonlin[l]), hid, 3 * Hc, B, L, Tc, Hc, /*tanh_gated=*/true);  // x * tanh(s) into the ring rows of this chunk
+        attn_apply_ring(lay_.nonlin[l], Hc, tmp2, hid + 2 * Hc, 3 * Hc);  // x * y (the third chunk of in_proj) in the epilogue
         linear(c, tmp2, Hc, w("nonlin_attention.out_proj.weight"), w("nonlin_attention.out_proj.bias"), src, D, M, Hc, D, ACT_NONE, src, D);
     }
     self_attn(1, lay_.val1[l]);
@@ -328,7 +365,7 @@ void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x,
 
 // The streaming Zipformer2 encoder of one (sub-)batch: x [B, T, feat] (log-floored) -> encoder_out [B*Tp, enc_dim]; caches of
 // the B slots advanced in place (OnlineProjOfZipformer2.EncoderProj :491-618 without stack / unstack)
-float* Engine::online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_slots, const long long* d_plen, int B) {
+float* Engine::online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_slots, const long long* d_plen, const int* d_chunks, int B) {
     const Model& m = *model_;
     const Config& cf = m.cfg();
     Arena& ar = *c.arena;
@@ -349,7 +386,7 @@ float* Engine::online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_
         Dcur = D;
         if (ds == 1) {
             const float* pe = c.dry ? nullptr : pos_emb_stream(Tc, L);
-            for (int li = 0; li < cf.nlayer[si]; li++, l++) encoder_layer_stream(c, si, li, l, xi, pe, d_slots, d_plen, B, Tc, L);
+            for (int li = 0; li < cf.nlayer[si]; li++, l++) encoder_layer_stream(c, si, li, l, xi, pe, d_slots, d_plen, d_chunks, B, Tc, L);
             x = xi;
         } else {
             const int Td = (Tc + ds - 1) / ds;
@@ -358,7 +395,7 @@ float* Engine::online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_
             float* xd = ar.take<float>((int64_t)B * Td * D);
             downsample(c, xi, m.wf("encoder.encoders.%d.downsample.bias", si), xd, B, Tc, D, ds);
             const float* pe = c.dry ? nullptr : pos_emb_stream(Td, L);
-            for (int li = 0; li < cf.nlayer[si]; li++, l++) encoder_layer_stream(c, si, li, l, xd, pe, d_slots, d_plen, B, Td, L);
+            for (int li = 0; li < cf.nlayer[si]; li++, l++) encoder_layer_stream(c, si, li, l, xd, pe, d_slots, d_plen, d_chunks, B, Td, L);
             upsample_combine(c, xi, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y, B, Tc, Td, D, ds);
             ar.rewind(mark);
             x = y;
@@ -390,7 +427,7 @@ float* Engine::online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_
     return enc;
 }
 
-void Engine::online_step(const int* slots, const float* chunks, const long long* hyps, const long long* plens, int B,
+void Engine::online_step(const int* slots, const float* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
                          int64_t* tokens, int32_t* ts, int32_t* n_tokens) {
     online_ensure_pool();
     K2_REQUIRE(B > 0, "online_step: no ready stream");
@@ -405,7 +442,7 @@ void Engine::online_step(const int* slots, const float* chunks, const long long*
         int K = sw >= 2 ? std::min(sw, kMaxSubs) : 1;
         if (cf.lstm || cf.conformer || cf.zip1 || cf.ctc) K = 1;
         if (K > 1) {
-            online_step_split(slots, chunks, hyps, plens, B, K, tokens, ts, n_tokens);
+            online_step_split(slots, chunks, hyps, plens, nchunks, B, K, tokens, ts, n_tokens);
             return;
         }
     }
@@ -421,10 +458,12 @@ void Engine::online_step(const int* slots, const float* chunks, const long long*
         int* d_slots = ar.take<int>(B);
         long long* d_plen = ar.take<long long>(B);
         long long* d_hyp = ar.take<long long>(2 * B);
+        int* d_chunks = ar.take<int>(B);
         if (!c.dry) {
             K2_HIP(hipEventRecord(ev_[0], c.stream));
             K2_HIP(hipMemcpyAsync(d_x, chunks, sizeof(float) * (size_t)B * T * cf.feat, hipMemcpyHostToDevice, c.stream));
             K2_HIP(hipMemcpyAsync(d_slots, slots, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
+            K2_HIP(hipMemcpyAsync(d_chunks, nchunks, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
             K2_HIP(hipMemcpyAsync(d_plen, plens, sizeof(long long) * B, hipMemcpyHostToDevice, c.stream));
             K2_HIP(hipMemcpyAsync(d_hyp, hyps, sizeof(long long) * 2 * B, hipMemcpyHostToDevice, c.stream));
         }
@@ -444,7 +483,7 @@ void Engine::online_step(const int* slots, const float* chunks, const long long*
             if (!c.dry) K2_HIP(hipEventRecord(ev_[4], c.stream));
             return;
         }
-        float* enc = online_encoder_zip2(c, d_x, d_slots, d_plen, B);
+        float* enc = online_encoder_zip2(c, d_x, d_slots, d_plen, d_chunks, B);
         if (!c.dry) {
             K2_HIP(hipEventRecord(ev_[3], c.stream));
             K2_HIP(hipMemsetAsync(d_ovf, 0, sizeof(int), c.stream));
@@ -537,8 +576,8 @@ void ForkJoin::run(int n, const std::function<void(int)>& fn) {
 
 // One sub-batch: stage the inputs in the sub's pinned buffer, size the arena with a dry pass, enqueue H2D + log-floor + encoder +
 // search + D2H on the sub's stream and record ev[5].  Nothing here waits for the GPU.
-void Engine::online_sub_step(OnlineSub& s, const int* slots, const float* chunks, const long long* hyps, const long long* plens, int B,
-                             int B_all) {
+void Engine::online_sub_step(OnlineSub& s, const int* slots, const float* chunks, const long long* hyps, const long long* plens,
+                             const int* nchunks, int B, int B_all) {
     const Config& cf = model_->cfg();
     const int T = cf.chunk_T, Tp = online_frames_per_chunk();
     K2_HIP(hipSetDevice(device_));
@@ -549,7 +588,7 @@ void Engine::online_sub_step(OnlineSub& s, const int* slots, const float* chunks
     const int64_t nb_x = (int64_t)sizeof(float) * B * T * cf.feat, nb_sl = align_up((int64_t)sizeof(int) * B, 16),
                   nb_pl = (int64_t)sizeof(long long) * B, nb_hy = (int64_t)sizeof(long long) * 2 * B;
     const int64_t nb_tok = (int64_t)B * Tp * 8, nb_ts = (int64_t)B * Tp * 4, nb_n = (int64_t)B * 4;
-    const int64_t in_bytes = align_up(nb_x + nb_sl + nb_pl + nb_hy, 64), total = in_bytes + nb_tok + nb_ts + nb_n + 64;
+    const int64_t in_bytes = align_up(nb_x + nb_sl + nb_pl + nb_hy + nb_sl, 64), total = in_bytes + nb_tok + nb_ts + nb_n + 64;
     if (total > s.pin_cap) {
         if (s.pin) K2_HIP(hipHostFree(s.pin));
         s.pin = nullptr;
@@ -563,6 +602,7 @@ void Engine::online_sub_step(OnlineSub& s, const int* slots, const float* chunks
     memcpy(pin + nb_x, slots, sizeof(int) * B);
     memcpy(pin + nb_x + nb_sl, plens, (size_t)nb_pl);
     memcpy(pin + nb_x + nb_sl + nb_pl, hyps, (size_t)nb_hy);
+    memcpy(pin + nb_x + nb_sl + nb_pl + nb_hy, nchunks, sizeof(int) * B);
     long long* d_tok = nullptr;
     int *d_ts = nullptr, *d_n = nullptr, *d_ovf = nullptr;
     auto body = [&](const Ctx& c) {
@@ -575,7 +615,9 @@ void Engine::online_sub_step(OnlineSub& s, const int* slots, const float* chunks
         int* d_slots = ar.take<int>(B);
         long long* d_plen = ar.take<long long>(B);
         long long* d_hyp = ar.take<long long>(2 * B);
+        int* d_chunks = ar.take<int>(B);
         if (!c.dry) {
+            K2_HIP(hipMemcpyAsync(d_chunks, pin + nb_x + nb_sl + nb_pl + nb_hy, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
             K2_HIP(hipEventRecord(s.ev[0], c.stream));
             K2_HIP(hipMemcpyAsync(d_x, pin, (size_t)nb_x, hipMemcpyHostToDevice, c.stream));
             K2_HIP(hipMemcpyAsync(d_slots, pin + nb_x, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
@@ -583,7 +625,7 @@ void Engine::online_sub_step(OnlineSub& s, const int* slots, const float* chunks
             K2_HIP(hipMemcpyAsync(d_hyp, pin + nb_x + nb_sl + nb_pl, (size_t)nb_hy, hipMemcpyHostToDevice, c.stream));
         }
         logfloor_inplace(c, d_x, (long long)B * T * cf.feat);  // online PadSequence (PadHelper.cs:9-13,58)
-        float* enc = online_encoder_zip2(c, d_x, d_slots, d_plen, B);
+        float* enc = online_encoder_zip2(c, d_x, d_slots, d_plen, d_chunks, B);
         if (!c.dry) {
             K2_HIP(hipEventRecord(s.ev[3], c.stream));
             K2_HIP(hipMemsetAsync(d_ovf, 0, sizeof(int), c.stream));
@@ -635,8 +677,8 @@ void Engine::online_sub_step(OnlineSub& s, const int* slots, const float* chunks
     K2_HIP(hipEventRecord(s.ev[5], s.stream));
 }
 
-void Engine::online_step_split(const int* slots, const float* chunks, const long long* hyps, const long long* plens, int B, int K,
-                               int64_t* tokens, int32_t* ts, int32_t* n_tokens) {
+void Engine::online_step_split(const int* slots, const float* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
+                               int K, int64_t* tokens, int32_t* ts, int32_t* n_tokens) {
     const Config& cf = model_->cfg();
     const int T = cf.chunk_T, Tp = online_frames_per_chunk();
     K = std::min(K, B);
@@ -644,7 +686,7 @@ void Engine::online_step_split(const int* slots, const float* chunks, const long
     for (int k = 0; k <= K; k++) lo[k] = (int)((long long)B * k / K);
     K2_HIP(hipStreamSynchronize(stream_));  // slot zero-fills and earlier single-stream steps are on stream_
     auto one = [&](int k) {
-        online_sub_step(subs_[k], slots + lo[k], chunks + (size_t)lo[k] * T * cf.feat, hyps + 2 * (size_t)lo[k], plens + lo[k], lo[k + 1] - lo[k], B);
+        online_sub_step(subs_[k], slots + lo[k], chunks + (size_t)lo[k] * T * cf.feat, hyps + 2 * (size_t)lo[k], plens + lo[k], nchunks + lo[k], lo[k + 1] - lo[k], B);
     };
     if (!subs_warm_) {
         // first split step of this engine: one sub-batch after the other on the calling thread, so that every lazily built table
