@@ -512,26 +512,33 @@ static void online_materialize(k2hip_online_stream* const* streams, int n) {
             }
             continue;
         }
-        std::vector<float> wav((size_t)G * len), feats((size_t)G * nf * c.feat);
-        for (int i = 0; i < G; i++) {
-            float* w = wav.data() + (size_t)i * len;
-            memcpy(w, g[i]->remainder.data(), sizeof(float) * g[i]->remainder.size());
-            memcpy(w + g[i]->remainder.size(), g[i]->pending.data(), sizeof(float) * g[i]->pending.size());
-        }
-        {
-            std::lock_guard<std::mutex> lk(e.mutex());
-            if (G == 1) {
-                int64_t got = 0;
-                e.fbank_host(wav.data(), len, feats.data(), nf, &got);
-            } else {
-                e.fbank_host_batch(wav.data(), len, G, feats.data(), nf);
-            }
-        }
+        // [remainder ; pending] of every stream goes straight into the engine's pinned staging buffer, the frames come straight
+        // out of it into the streams' Speech
+        std::vector<const float*> hp(G), tp(G);
+        std::vector<int64_t> hn(G), tn(G);
+        std::vector<float*> dst(G);
         for (int i = 0; i < G; i++) {
             k2hip_online_stream* s = g[i];
-            s->speech.insert(s->speech.end(), feats.begin() + (size_t)i * nf * c.feat, feats.begin() + (size_t)(i + 1) * nf * c.feat);
-            const float* w = wav.data() + (size_t)i * len;
-            s->remainder.assign(w + (size_t)nf * c.fbank.frame_shift, w + len);
+            hp[i] = s->remainder.data(); hn[i] = (int64_t)s->remainder.size();
+            tp[i] = s->pending.data(); tn[i] = (int64_t)s->pending.size();
+            const size_t old = s->speech.size();
+            s->speech.resize(old + (size_t)nf * c.feat);
+            dst[i] = s->speech.data() + old;
+        }
+        try {
+            std::lock_guard<std::mutex> lk(e.mutex());
+            e.fbank_host_gather(hp.data(), hn.data(), tp.data(), tn.data(), len, G, dst.data(), nf);
+        } catch (...) {
+            for (k2hip_online_stream* s : g) s->speech.resize(s->speech.size() - (size_t)nf * c.feat);  // nothing was appended
+            throw;
+        }
+        const int64_t used = nf * c.fbank.frame_shift;  // samples consumed by whole frame shifts
+        for (int i = 0; i < G; i++) {
+            k2hip_online_stream* s = g[i];
+            std::vector<float> rem((size_t)(len - used));
+            // the new remainder is the tail of [remainder ; pending]
+            for (int64_t k = used; k < len; k++) rem[(size_t)(k - used)] = k < hn[i] ? s->remainder[(size_t)k] : s->pending[(size_t)(k - hn[i])];
+            s->remainder.swap(rem);
             s->pending.clear();
         }
     }
@@ -615,13 +622,13 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
             online_materialize(ready.data(), (int)ready.size());
         }
         const int R = (int)idx.size(), Tp = e.online_frames_per_chunk();
-        std::vector<float> chunks((size_t)R * chunk_floats);
+        std::vector<const float*> chunks(R);   // GetDecodeChunk: the first ChunkLength frames of each FIFO
         std::vector<int> slots(R);
         std::vector<long long> hyps(2 * (size_t)R), plens(R);
         std::vector<int> nch(R);
         for (int r = 0; r < R; r++) {
             k2hip_online_stream* s = streams[idx[r]];
-            memcpy(chunks.data() + (size_t)r * chunk_floats, s->speech.data(), sizeof(float) * chunk_floats);
+            chunks[r] = s->speech.data();
             slots[r] = s->slot;
             hyps[2 * r] = s->hyp[0];
             hyps[2 * r + 1] = s->hyp[1];

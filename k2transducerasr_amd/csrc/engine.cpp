@@ -61,8 +61,20 @@ Engine::~Engine() {
         if (e) (void)hipEventDestroy(e);
     for (auto& e : evpool_) (void)hipEventDestroy(e);
     if (pin_) (void)hipHostFree(pin_);
+    if (pin_in_) (void)hipHostFree(pin_in_);
     arena_.release();
     if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void* Engine::pinned_in(int64_t bytes) {
+    if (bytes > pin_in_cap_) {
+        if (pin_in_) K2_HIP(hipHostFree(pin_in_));
+        pin_in_ = nullptr;
+        pin_in_cap_ = 0;
+        K2_HIP(hipHostMalloc(&pin_in_, (size_t)(bytes + bytes / 4), hipHostMallocDefault));
+        pin_in_cap_ = bytes + bytes / 4;
+    }
+    return pin_in_;
 }
 
 void* Engine::pinned(int64_t bytes) {
@@ -578,6 +590,33 @@ void Engine::fbank_host_batch(const float* samples, int64_t n, int n_utts, float
     K2_HIP(hipMemcpyAsync(pin + nb_in, d_out, nb_out, hipMemcpyDeviceToHost, stream_));
     K2_HIP(hipStreamSynchronize(stream_));
     memcpy(feats, pin + nb_in, nb_out);
+}
+
+void Engine::fbank_host_gather(const float* const* head, const int64_t* n_head, const float* const* tail, const int64_t* n_tail, int64_t n, int G,
+                               float* const* dst, int64_t nf) {
+    const FbankOpts& f = model_->cfg().fbank;
+    K2_REQUIRE(nf == fbank_num_frames(n) && nf > 0 && G > 0, "fbank_host_gather: bad shape");
+    const size_t nb_in = sizeof(float) * (size_t)n * G, per_out = sizeof(float) * (size_t)nf * f.num_bins, nb_out = per_out * G;
+    char* pin = static_cast<char*>(pinned((int64_t)(nb_in + nb_out + 64)));
+    float* w = reinterpret_cast<float*>(pin);
+    for (int g = 0; g < G; g++) {
+        K2_REQUIRE(n_head[g] + n_tail[g] == n, "fbank_host_gather: signal %d has %lld + %lld samples, expected %lld", g, (long long)n_head[g],
+                   (long long)n_tail[g], (long long)n);
+        if (n_head[g]) memcpy(w + (size_t)g * n, head[g], sizeof(float) * (size_t)n_head[g]);
+        if (n_tail[g]) memcpy(w + (size_t)g * n + n_head[g], tail[g], sizeof(float) * (size_t)n_tail[g]);
+    }
+    float* d_out = nullptr;
+    run_sized([&](const Ctx& c) {
+        float* d_s = c.arena->take<float>(n * G);
+        d_out = c.arena->take<float>(nf * f.num_bins * G);
+        if (!c.dry) K2_HIP(hipMemcpyAsync(d_s, pin, nb_in, hipMemcpyHostToDevice, c.stream));
+        FbankArgs a{d_s, n, n, G, nf, d_out, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift, f.preemph, f.input_scale, f.remove_dc};
+        a.melrange = model_->d_melrange;
+        fbank(c, a);
+    });
+    K2_HIP(hipMemcpyAsync(pin + nb_in, d_out, nb_out, hipMemcpyDeviceToHost, stream_));
+    K2_HIP(hipStreamSynchronize(stream_));
+    for (int g = 0; g < G; g++) memcpy(dst[g], pin + nb_in + (size_t)g * per_out, per_out);
 }
 
 void Engine::pad_host(const float* const* speech, const int64_t* n_floats, int B, int tail, float* out, int64_t cap, int64_t* Lout) {

@@ -66,6 +66,11 @@ class Engine {
     void fbank_host(const float* samples, int64_t n, float* feats, int64_t cap_frames, int64_t* n_frames);
     // n_utts equal-length signals [n_utts, n] -> feats [n_utts, nf, feat] in one launch
     void fbank_host_batch(const float* samples, int64_t n, int n_utts, float* feats, int64_t nf);
+    // the same for G signals that each arrive in two pieces ([head_g ; tail_g], n_head[g] + n_tail[g] == n for all g) and whose
+    // frames go to G separate destinations: gathered straight into the pinned staging buffer and scattered straight out of it
+    // (one host copy each way instead of three)
+    void fbank_host_gather(const float* const* head, const int64_t* n_head, const float* const* tail, const int64_t* n_tail, int64_t n, int G,
+                           float* const* dst, int64_t nf);
     void pad_host(const float* const* speech, const int64_t* n_floats, int B, int tail, float* out, int64_t cap, int64_t* L);
     void encoder_host(const float* x, int B, int T, float* enc_out, int64_t cap, int* Tp);
     void encoder_tap_host(const float* x, int B, int T, int tap, float* out, int64_t cap, int64_t* n);
@@ -99,7 +104,8 @@ class Engine {
     int online_frames_per_chunk() const;
     // one tick over B streams that each have a full chunk: chunks [B][T*feat] (host), hyps [B][2], plens [B]
     // nchunks [B]: chunks each stream has decoded before this step (position of its attention rings)
-    void online_step(const int* slots, const float* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
+    // chunks: [B] pointers to each stream's T*feat chunk floats (gathered into pinned staging by the engine)
+    void online_step(const int* slots, const float* const* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
                      int64_t* tokens, int32_t* ts, int32_t* n_tokens);
 
     void set_instrument(bool on) { instrument_ = on; }
@@ -189,9 +195,9 @@ class Engine {
     OnlineSub subs_[kMaxSubs];
     ForkJoin fork_;
     std::mutex cache_mu_;  // pos_proj / pos_emb / decjoin tables are built lazily, possibly from several sub-batch threads
-    void online_sub_step(OnlineSub& s, const int* slots, const float* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
+    void online_sub_step(OnlineSub& s, const int* slots, const float* const* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
                          int B_all);
-    void online_step_split(const int* slots, const float* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
+    void online_step_split(const int* slots, const float* const* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
                            int K, int64_t* tokens, int32_t* ts, int32_t* n_tokens);
     float* online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_slots, const long long* d_plen, const int* d_chunks, int B);
     bool subs_warm_ = false;
@@ -251,6 +257,9 @@ class Engine {
     void* pin_ = nullptr;
     int64_t pin_cap_ = 0;
     void* pinned(int64_t bytes);
+    void* pin_in_ = nullptr;   // pinned staging of a step's inputs (chunks), separate from the result staging above
+    int64_t pin_in_cap_ = 0;
+    void* pinned_in(int64_t bytes);
 };
 
 template <typename F>

@@ -427,7 +427,7 @@ float* Engine::online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_
     return enc;
 }
 
-void Engine::online_step(const int* slots, const float* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
+void Engine::online_step(const int* slots, const float* const* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
                          int64_t* tokens, int32_t* ts, int32_t* n_tokens) {
     online_ensure_pool();
     K2_REQUIRE(B > 0, "online_step: no ready stream");
@@ -448,6 +448,11 @@ void Engine::online_step(const int* slots, const float* chunks, const long long*
     }
     long long* d_tok = nullptr;
     int *d_ts = nullptr, *d_n = nullptr, *d_ovf = nullptr;
+    // the streams' chunks, gathered once into pinned staging (one host copy; the H2D below is then a real asynchronous DMA)
+    const size_t chunk_floats = (size_t)T * cf.feat;
+    K2_HIP(hipSetDevice(device_));
+    float* stage = static_cast<float*>(pinned_in((int64_t)(sizeof(float) * chunk_floats * B)));
+    for (int b = 0; b < B; b++) memcpy(stage + (size_t)b * chunk_floats, chunks[b], sizeof(float) * chunk_floats);
     run_sized([&](const Ctx& c) {
         Arena& ar = *c.arena;
         d_tok = ar.take<long long>((int64_t)B * Tp);
@@ -461,7 +466,7 @@ void Engine::online_step(const int* slots, const float* chunks, const long long*
         int* d_chunks = ar.take<int>(B);
         if (!c.dry) {
             K2_HIP(hipEventRecord(ev_[0], c.stream));
-            K2_HIP(hipMemcpyAsync(d_x, chunks, sizeof(float) * (size_t)B * T * cf.feat, hipMemcpyHostToDevice, c.stream));
+            K2_HIP(hipMemcpyAsync(d_x, stage, sizeof(float) * (size_t)B * T * cf.feat, hipMemcpyHostToDevice, c.stream));
             K2_HIP(hipMemcpyAsync(d_slots, slots, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
             K2_HIP(hipMemcpyAsync(d_chunks, nchunks, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
             K2_HIP(hipMemcpyAsync(d_plen, plens, sizeof(long long) * B, hipMemcpyHostToDevice, c.stream));
@@ -576,7 +581,7 @@ void ForkJoin::run(int n, const std::function<void(int)>& fn) {
 
 // One sub-batch: stage the inputs in the sub's pinned buffer, size the arena with a dry pass, enqueue H2D + log-floor + encoder +
 // search + D2H on the sub's stream and record ev[5].  Nothing here waits for the GPU.
-void Engine::online_sub_step(OnlineSub& s, const int* slots, const float* chunks, const long long* hyps, const long long* plens,
+void Engine::online_sub_step(OnlineSub& s, const int* slots, const float* const* chunks, const long long* hyps, const long long* plens,
                              const int* nchunks, int B, int B_all) {
     const Config& cf = model_->cfg();
     const int T = cf.chunk_T, Tp = online_frames_per_chunk();
@@ -598,7 +603,7 @@ void Engine::online_sub_step(OnlineSub& s, const int* slots, const float* chunks
     }
     s.out_off = in_bytes;
     char* pin = s.pin;
-    memcpy(pin, chunks, (size_t)nb_x);
+    for (int b = 0; b < B; b++) memcpy(pin + (size_t)b * sizeof(float) * T * cf.feat, chunks[b], sizeof(float) * (size_t)T * cf.feat);
     memcpy(pin + nb_x, slots, sizeof(int) * B);
     memcpy(pin + nb_x + nb_sl, plens, (size_t)nb_pl);
     memcpy(pin + nb_x + nb_sl + nb_pl, hyps, (size_t)nb_hy);
@@ -677,16 +682,15 @@ void Engine::online_sub_step(OnlineSub& s, const int* slots, const float* chunks
     K2_HIP(hipEventRecord(s.ev[5], s.stream));
 }
 
-void Engine::online_step_split(const int* slots, const float* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
+void Engine::online_step_split(const int* slots, const float* const* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
                                int K, int64_t* tokens, int32_t* ts, int32_t* n_tokens) {
-    const Config& cf = model_->cfg();
-    const int T = cf.chunk_T, Tp = online_frames_per_chunk();
+    const int Tp = online_frames_per_chunk();
     K = std::min(K, B);
     std::vector<int> lo(K + 1);
     for (int k = 0; k <= K; k++) lo[k] = (int)((long long)B * k / K);
     K2_HIP(hipStreamSynchronize(stream_));  // slot zero-fills and earlier single-stream steps are on stream_
     auto one = [&](int k) {
-        online_sub_step(subs_[k], slots + lo[k], chunks + (size_t)lo[k] * T * cf.feat, hyps + 2 * (size_t)lo[k], plens + lo[k], nchunks + lo[k], lo[k + 1] - lo[k], B);
+        online_sub_step(subs_[k], slots + lo[k], chunks + lo[k], hyps + 2 * (size_t)lo[k], plens + lo[k], nchunks + lo[k], lo[k + 1] - lo[k], B);
     };
     if (!subs_warm_) {
         // first split step of this engine: one sub-batch after the other on the calling thread, so that every lazily built table
