@@ -294,6 +294,9 @@ int32_t k2hip_online_stream_accept_samples(k2hip_online_stream_t* s, const float
 int32_t k2hip_online_accept_samples_batch(k2hip_model_t* model, k2hip_online_stream_t* const* streams, int32_t B,
                                           const float* const* samples, const int64_t* n);
 /* ... or push ready-made feature frames ([n_frames, feature_dim]) */
+/* the same over the rows of one [B, n] sample matrix (row_stride in floats) */
+int32_t k2hip_online_accept_samples_matrix(k2hip_model_t* model, k2hip_online_stream_t* const* streams, int32_t B, const float* samples,
+                                           int64_t row_stride, int64_t n);
 int32_t k2hip_online_stream_accept_features(k2hip_online_stream_t* s, const float* feats, int64_t n_frames);
 /* OnlineInputEntity.SpeechLength (floats buffered) */
 int64_t k2hip_online_stream_speech_length(const k2hip_online_stream_t* s);

@@ -563,6 +563,7 @@ def _bind_online(L):
     L.k2hip_online_stream_accept_samples.argtypes = [vp, fp, C.c_int64]
     L.k2hip_online_stream_accept_features.argtypes = [vp, fp, C.c_int64]
     L.k2hip_online_accept_samples_batch.argtypes = [vp, C.POINTER(vp), C.c_int32, C.POINTER(fp), lp]
+    L.k2hip_online_accept_samples_matrix.argtypes = [vp, C.POINTER(vp), C.c_int32, vp, C.c_int64, C.c_int64]
     L.k2hip_online_stream_speech_length.restype = C.c_int64
     L.k2hip_online_stream_speech_length.argtypes = [vp]
     L.k2hip_online_stream_is_finished.argtypes = [vp, C.c_int32, ip]
@@ -673,13 +674,11 @@ class OnlineRecognizer:
     def add_samples_batch(self, streams: Sequence[OnlineStream], samples: Sequence[np.ndarray]):
         """B AddSamples calls in one (one fbank launch when all streams are at the same position)."""
         B = len(streams)
-        arr = (C.c_void_p * B)(*[s._h for s in streams])
-        if isinstance(samples, np.ndarray) and samples.ndim == 2 and samples.dtype == np.float32 and samples.strides[1] == 4:
-            # one [B, n] matrix (rows contiguous, any row stride): pointer arithmetic instead of B ctypes conversions
-            base, rs = samples.ctypes.data, samples.strides[0]
-            ptrs = (C.c_void_p * B)(*[base + i * rs for i in range(B)])
-            n = np.full(B, samples.shape[1], np.int64)
-            self.model._chk(self.model._L.k2hip_online_accept_samples_batch(self.model.handle, arr, B, C.cast(ptrs, C.POINTER(fp)), _l(n)))
+        arr = self._handles(streams)
+        if isinstance(samples, np.ndarray) and samples.ndim == 2 and samples.dtype == np.float32 and samples.strides[1] == 4 and samples.strides[0] % 4 == 0:
+            # one [B, n] matrix (rows contiguous, any row stride): one call, no per-stream pointers
+            self.model._chk(self.model._L.k2hip_online_accept_samples_matrix(self.model.handle, arr, B, C.c_void_p(samples.ctypes.data),
+                                                                             samples.strides[0] // 4, samples.shape[1]))
             return
         ss = [_f32(x).reshape(-1) for x in samples]
         ptrs = (fp * B)(*[_f(x) for x in ss])
@@ -689,8 +688,16 @@ class OnlineRecognizer:
     def get_results(self, streams: Sequence[OnlineStream]):
         """GetResults :76-84 (tokens, not text).  Returns (decoded flags, new-token counts)."""
         B = len(streams)
-        arr = (C.c_void_p * B)(*[s._h for s in streams])
+        arr = self._handles(streams)
         dec = np.zeros(B, np.int32)
         n = np.zeros(B, np.int32)
         self.model._chk(self.model._L.k2hip_online_step(self.model.handle, arr, B, _i(dec), _i(n)))
         return dec.tolist(), n.tolist()
+
+    def _handles(self, streams):
+        """ctypes array of the streams' handles; rebuilt only when the list changes (a serving loop passes the same list every 50 ms)"""
+        key = tuple(s._h.value for s in streams)
+        if getattr(self, "_hkey", None) != key:
+            self._hkey = key
+            self._harr = (C.c_void_p * len(streams))(*key)
+        return self._harr

@@ -562,6 +562,20 @@ int32_t k2hip_online_accept_samples_batch(k2hip_model_t* model, k2hip_online_str
         }
     });
 }
+// B AddSamples calls over the rows of one [B, n] matrix (row stride in floats): what a host that receives audio in lock step
+// holds anyway; saves building B pointers per 50 ms push
+int32_t k2hip_online_accept_samples_matrix(k2hip_model_t* model, k2hip_online_stream_t* const* streams, int32_t B, const float* samples,
+                                           int64_t row_stride, int64_t n) {
+    return guard([&] {
+        NEED(model); NEED(streams);
+        K2_REQUIRE(B > 0 && n >= 0 && row_stride >= n, "accept_samples_matrix: bad shape");
+        if (n > 0) NEED(samples);
+        for (int i = 0; i < B; i++) {
+            NEED(streams[i]);
+            online_add_samples(streams[i], samples + (size_t)i * row_stride, n);
+        }
+    });
+}
 int32_t k2hip_online_stream_accept_features(k2hip_online_stream_t* s, const float* feats, int64_t n_frames) {
     return guard([&] {
         NEED(s);
