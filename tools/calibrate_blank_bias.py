@@ -7,7 +7,11 @@ per frame, skip blank / unk -- OfflineRecognizer.cs:127-179) run in numpy on the
 outputs (test infrastructure); the constant is then frozen in k2transducerasr_amd/synth.py:BLANK_BIAS and checked with the
 oracle's own batch loop.  Not part of the product.
 
-usage: calibrate_blank_bias.py <preset> [seconds] [target emission rate] [streaming: 0|1]
+usage: calibrate_blank_bias.py <preset> [seconds] [target emission rate]
+       calibrate_blank_bias.py <preset> <seconds> <target> batch <B>   offline presets: bisect on the emission rate of the ORACLE'S OWN
+                                                                       batch loop over the benchmark's B utterances (the first-emission
+                                                                       context switch couples the streams of a batch); the bias is
+                                                                       patched in place in the weights file between evaluations
 """
 import os
 import sys
@@ -21,6 +25,54 @@ from oracle import Oracle  # noqa: E402
 preset = sys.argv[1]
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 target = float(sys.argv[3]) if len(sys.argv) > 3 else 0.2
+if len(sys.argv) > 5 and sys.argv[4] == "batch":
+    import struct
+    B = int(sys.argv[5])
+    path = f"/tmp/calib_{preset}_b{B}.k2w"
+    write_synthetic_model(path, preset, blank_bias=0.0)
+    raw = open(path, "rb").read(1 << 22)
+    _, n_meta, n_t, data_off = struct.unpack_from("<IIIQ", raw, 4)
+    p = 24
+    for _ in range(n_meta):
+        kl, vl = struct.unpack_from("<II", raw, p)
+        p += 8 + kl + vl
+    off0 = None
+    for _ in range(n_t):
+        (nl,) = struct.unpack_from("<I", raw, p)
+        p += 4
+        name = raw[p : p + nl].decode()
+        p += nl
+        off = struct.unpack_from("<II4QQQ", raw, p)[6]
+        p += 56
+        if name == "joiner.output_linear.bias":
+            off0 = data_off + off
+    with open(path, "rb") as f:
+        f.seek(off0)
+        base = struct.unpack("<f", f.read(4))[0]
+    o = Oracle(path)
+    feats = [o.fbank(synth_utterance(u, secs)) for u in range(B)]
+    enc = o.encoder(o.pad_sequence(feats).reshape(B, -1, 80))
+    o.close()
+
+    def rate(bias):
+        with open(path, "r+b") as f:
+            f.seek(off0)
+            f.write(struct.pack("<f", base + bias))
+        oo = Oracle(path)
+        res = oo.greedy_batch(enc)
+        oo.close()
+        return sum(len(r[0]) for r in res) / (B * enc.shape[1])
+
+    lo, hi = 0.0, 12.0
+    for _ in range(16):
+        mid = 0.5 * (lo + hi)
+        if rate(mid) > target:
+            lo = mid
+        else:
+            hi = mid
+    b = round(0.5 * (lo + hi), 3)
+    print(f"{preset}, batch of {B} x {secs:g} s: blank_bias {b} -> emission {rate(b):.3f} (target {target}); +-0.02: {rate(b - 0.02):.3f} / {rate(b + 0.02):.3f}")
+    sys.exit(0)
 NUTT = 4
 path = f"/tmp/calib_{preset}.k2w"
 meta = write_synthetic_model(path, preset, blank_bias=0.0)
