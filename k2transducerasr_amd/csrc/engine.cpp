@@ -490,7 +490,10 @@ void Engine::greedy_device(const Ctx& c, const float* enc, int B, int Tp, bool s
     a.enc = enc; a.B = B; a.Tp = Tp; a.t0 = d_t0; a.skip1 = 0;
     a.max_sym = single ? 1000 : INT_MAX;  // OfflineRecognizer.cs:122
     a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = max_tokens; a.overflow = d_overflow;
-    greedy_loop(c, w, a);
+    // batch path: rounds of whole-chip GEMMs (they interleave with the next batch's encoder instead of pinning CUs for the whole
+    // search); the single-stream path (1000-symbol cap, B = 1) keeps the persistent kernel
+    if (!single && tunables().search_rounds == 1) greedy_rounds(c, w, model_->w("joiner.output_linear.weight"), a);
+    else greedy_loop(c, w, a);
 }
 
 // ForwardBatchGreedySearchCTC (OfflineRecognizer.cs:366-424): first-index argmax per frame (parallel), then per stream drop

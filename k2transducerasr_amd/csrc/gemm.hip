@@ -99,6 +99,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
     constexpr int PA = BM / RPP;  // float4 loads per thread for the A tile
     constexpr int PB = BN / RPP;
 
+    if (g.skip_if_zero && *g.skip_if_zero == 0) return;  // uniform: every wave of every workgroup leaves
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                        // [2][BM][LDSK]
     float* sB = smem + 2 * BM * LDSK;        // [2][BN][LDSK]
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
     constexpr int NFULL = NINST % NW == 0 ? NW : NINST % NW;  // waves 0..NFULL-1 issue IPW instructions, the others IPW - 1
     constexpr int STAGE = (BM + BN) * BK;      // floats per stage
 
+    if (g.skip_if_zero && *g.skip_if_zero == 0) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [NST][STAGE]: A rows then W rows
 
     const int tid = threadIdx.x;
@@ -515,6 +517,7 @@ __global__ __launch_bounds__(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)) void g
     constexpr int RPG = 16 / KS;               // accumulator registers each group finishes
     static_assert(NST >= 2 && (KS == 1 || KS == 2 || KS == 4), "ring: NST >= 2, KS in {1, 2, 4}");
 
+    if (g.skip_if_zero && *g.skip_if_zero == 0) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [NST][KS][SUB]
 
     const int tid = threadIdx.x;
@@ -783,6 +786,7 @@ __global__ __launch_bounds__(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)) void g
 // streaming chunk step: the launch is one chain of K / (32 NW) dependent load rounds per wave)
 template <int NT, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gemm_f32_mfma_skinny(GemmArgs g) {
+    if (g.skip_if_zero && *g.skip_if_zero == 0) return;
     __shared__ __attribute__((aligned(16))) float red[NW][NT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;

@@ -506,7 +506,176 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
     if (tid == 0 && part == 0) a.n_tokens[b] = n_tok < a.max_tokens ? n_tok : a.max_tokens;
 }
 
+// ---- batched rounds (greedy_rounds) ------------------------------------------------------------------------------
+struct RoundsState {
+    const float* enc;         // [B, Tp, J]
+    int B, Tp, S;
+    const int* t0;            // device scalar (offline batch quirk) or nullptr
+    int skip1;
+    const long long* init_ctx;  // [B][2] (online) or nullptr
+    long long* tokens;
+    int* timestamps;
+    int* n_tokens;
+    int max_tokens;
+    int* overflow;
+    int* next;                // [B] next frame to decide
+    int* nemit;               // [B] symbols emitted so far
+    long long* ctx;           // [B][2] context the stream's dec row was computed with
+    int* win;                 // [B] frames of the current window
+    float* dec;               // [B][J]
+    float* act;               // [B*S][J] joiner input of the current windows
+    const float* logits;      // [B*S][ldl]
+    int ldl;
+    int* active;              // [rounds + 1]: streams still running at the start of each round
+};
+
+// r < 0: set up every stream and its first window; r >= 0: decide round r's windows and set up the next ones
+__global__ __launch_bounds__(GT) void k_rounds_step(DecJoinW w, RoundsState a, int r) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* h = sm;                                   // [3*DD]
+    float* scratch = h + 3 * w.DD;                   // [8*max(J, DD)]
+    float* decl = scratch + 8 * max(w.J, w.DD);      // [J]
+    int* toks = reinterpret_cast<int*>(decl + w.J);  // [S]
+    __shared__ int s_t, s_n, s_changed;
+    __shared__ long long s_y0, s_y1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int t0 = a.t0 ? *a.t0 : INT_MAX;
+    int t, n;
+    long long y0, y1;
+    bool have_dec;  // dec[b] holds decoder(ctx[b])
+    if (r < 0) {
+        t = 0; n = 0;
+        have_dec = false;
+        if (a.init_ctx) { y0 = a.init_ctx[2 * b]; y1 = a.init_ctx[2 * b + 1]; }
+        else { y0 = -1; y1 = K2HIP_BLANK_ID; }
+    } else {
+        t = a.next[b];
+        if (t >= a.Tp) return;  // finished in an earlier round (uniform for the workgroup)
+        n = a.nemit[b];
+        y0 = a.ctx[2 * b];
+        y1 = a.ctx[2 * b + 1];
+        have_dec = true;
+        const int wl = a.win[b];
+        // argmax of each window row, one wave per row (S <= 8 = waves): later index wins ties, as the reference's loop
+        for (int s = wave; s < wl; s += GT / 64) {
+            const float* row = a.logits + (long long)(b * a.S + s) * a.ldl;
+            float bv = -INFINITY;
+            int bi = -1;
+            for (int j = lane; j < w.V; j += 64) amax_merge(bv, bi, row[j], j);
+            amax_wave(bv, bi);
+            if (lane == 0) toks[s] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int adv = wl, changed = 0;
+            for (int s = 0; s < wl; s++) {
+                const int y = toks[s];
+                if (y != K2HIP_BLANK_ID && y != K2HIP_UNK_ID && !(a.skip1 && y == 1)) {
+                    if (n < a.max_tokens) {
+                        a.tokens[(long long)b * a.max_tokens + n] = y;
+                        a.timestamps[(long long)b * a.max_tokens + n] = t + s;
+                    } else {
+                        *a.overflow = 1;
+                    }
+                    n++;
+                    y0 = y1;
+                    y1 = y;
+                    adv = s + 1;
+                    changed = 1;
+                    break;
+                }
+            }
+            s_t = t + adv; s_n = n; s_y0 = y0; s_y1 = y1; s_changed = changed;
+        }
+        __syncthreads();
+        t = s_t; n = s_n; y0 = s_y0; y1 = s_y1;
+        if (s_changed) have_dec = false;
+    }
+    // a stream of the offline batch that has not emitted yet decodes frames <= t0 under [-1, blank] and frames > t0 under
+    // [blank, blank] (the batch's first emission re-runs the decoder for every stream on its seeded blanks, OfflineRecognizer.cs
+    // :250-258,278-286); its windows never straddle t0
+    const bool own = n > 0 || a.init_ctx != nullptr;
+    if (!own && t < a.Tp) {
+        const long long w0 = t > t0 ? K2HIP_BLANK_ID : -1;
+        if (w0 != y0) { y0 = w0; y1 = K2HIP_BLANK_ID; have_dec = false; }
+    }
+    if (tid == 0) {
+        a.next[b] = t;
+        a.nemit[b] = n;
+        a.n_tokens[b] = n < a.max_tokens ? n : a.max_tokens;
+        a.ctx[2 * b] = y0;
+        a.ctx[2 * b + 1] = y1;
+    }
+    if (t >= a.Tp) return;
+    int wl = min(a.S, a.Tp - t);
+    // (t0 == INT_MAX: no scalar, or no stream of the batch ever emits; t0 - t + 1 would overflow)
+    if (!own && t0 != INT_MAX && t <= t0) wl = min(wl, t0 - t + 1);
+    if (tid == 0) {
+        a.win[b] = wl;
+        atomicAdd(&a.active[r + 2], 1);  // r = -1 fills active[1]... see greedy_rounds: slot k+1 counts the streams alive in round k
+    }
+    if (!have_dec) {
+        decoder_block_wide(w, y0, y1, h, scratch, decl);
+        for (int k = tid; k < w.J; k += GT) a.dec[(long long)b * w.J + k] = decl[k];
+    } else {
+        for (int k = tid; k < w.J; k += GT) decl[k] = a.dec[(long long)b * w.J + k];
+        __syncthreads();
+    }
+    const float* enc = a.enc + (long long)b * a.Tp * w.J;
+    for (int idx = tid; idx < a.S * (w.J >> 2); idx += GT) {
+        const int s = idx / (w.J >> 2), k = (idx - s * (w.J >> 2)) * 4;
+        const int row = min(t + s, a.Tp - 1);  // rows past the window are computed on a valid frame and ignored
+        const float4 e = *reinterpret_cast<const float4*>(enc + (long long)row * w.J + k);
+        *reinterpret_cast<float4*>(a.act + (long long)(b * a.S + s) * w.J + k) =
+            make_float4(tanhf(e.x + decl[k]), tanhf(e.y + decl[k + 1]), tanhf(e.z + decl[k + 2]), tanhf(e.w + decl[k + 3]));
+    }
+}
+
 }  // namespace
+
+void greedy_rounds(const Ctx& ctx, const DecJoinW& w, const float* out_w, const GreedyArgs& a0) {
+    if (a0.B <= 0) return;
+    const int B = a0.B, Tp = a0.Tp, S = std::min(GF, Tp), R = Tp;  // a round advances every running stream by >= 1 frame
+    Arena& ar = *ctx.arena;
+    RoundsState st;
+    st.enc = a0.enc; st.B = B; st.Tp = Tp; st.S = S; st.t0 = a0.t0; st.skip1 = a0.skip1; st.init_ctx = a0.init_ctx;
+    st.tokens = a0.tokens; st.timestamps = a0.timestamps; st.n_tokens = a0.n_tokens; st.max_tokens = a0.max_tokens; st.overflow = a0.overflow;
+    st.next = ar.take<int>(B);
+    st.nemit = ar.take<int>(B);
+    st.ctx = ar.take<long long>(2 * B);
+    st.win = ar.take<int>(B);
+    st.dec = ar.take<float>((int64_t)B * w.J);
+    st.act = ar.take<float>((int64_t)B * S * w.J);
+    st.ldl = w.Vp;
+    float* logits = ar.take<float>((int64_t)B * S * st.ldl);
+    st.logits = logits;
+    st.active = ar.take<int>(R + 2);
+    const size_t lds = sizeof(float) * (3 * (size_t)w.DD + 8 * (size_t)std::max(w.J, w.DD) + w.J + 16);
+    if (!ctx.dry) {
+        K2_REQUIRE(w.J % 4 == 0 && w.DD % 4 == 0 && S <= GT / 64, "greedy_rounds: joiner %d / decoder %d widths must be multiples of 4", w.J, w.DD);
+        K2_HIP(hipMemsetAsync(st.active, 0, sizeof(int) * (R + 2), ctx.stream));
+        static LdsAttrOnce lds_attr;
+        lds_attr.ensure(k_rounds_step, (int)lds);
+        hipLaunchKernelGGL(k_rounds_step, dim3(B), dim3(GT), lds, ctx.stream, w, st, -1);  // counts the streams of round 0 into active[1]
+        K2_HIP(hipGetLastError());
+    }
+    ctx.add_flops(0.0, 2.0 * B * (double)Tp * w.J * w.V, 0);  // one joiner evaluation per frame, as the frame-by-frame loop
+    Ctx q = ctx;  // the rounds' GEMMs are not part of the encoder-GEMM statistics (most of them return at once)
+    q.stats = nullptr;
+    q.instrument = false;
+    q.gemm_log = nullptr;
+    for (int r = 0; r < R; r++) {
+        GemmArgs g;
+        g.A = st.act; g.lda = w.J; g.W = out_w; g.ldw = w.J; g.bias = w.out_b; g.C = logits; g.ldc = st.ldl;
+        g.M = B * S; g.N = w.V; g.K = w.J;
+        g.skip_if_zero = st.active + r + 1;
+        gemm(q, g);
+        if (!ctx.dry) {
+            hipLaunchKernelGGL(k_rounds_step, dim3(B), dim3(GT), lds, ctx.stream, w, st, r);
+            K2_HIP(hipGetLastError());
+        }
+    }
+}
 
 void decoder(const Ctx& ctx, const DecJoinW& w, const long long* y, int N, float* dec_out) {
     if (ctx.dry || N <= 0) return;

@@ -22,6 +22,9 @@ struct Tunables {
     int greedy_parts = 0;         // K2HIP_GREEDY_PARTS: vocabulary slabs per stream (0 = automatic)
     int pipe_mode = 0;            // K2HIP_PIPE_MODE: 1 = every pipeline slot owns a stream
     int max_streams = 0;          // K2HIP_MAX_STREAMS: slots of the streaming state pool (0 = 256)
+    int search_rounds = -1;       // K2HIP_SEARCH_ROUNDS: 1 = every multi-stream search as rounds of joiner GEMMs (greedy_rounds),
+                                  // 0 = always the persistent kernel (k_greedy), -1 = measured default: rounds for the streaming
+                                  // tick (0.58 -> 0.45 ms at 128 streams), persistent for the offline batch (17.00 vs 17.10 ms)
     int online_split = 0;         // K2HIP_ONLINE_SPLIT: 2..4 = enqueue a chunk step as that many sub-batches on their own HIP streams (0 / 1: one chain)
 };
 void tunables_init_from_env();            // idempotent; called by k2hip_model_create
@@ -88,6 +91,8 @@ struct GemmArgs {
     int w_kn = 0;
     // batching over blockIdx.z = z0 + nb0 * z1
     int nb0 = 1, nb1 = 1;
+    // device flag: the launch does nothing when *skip_if_zero == 0 (rounds of the batched search after every stream has finished)
+    const int* skip_if_zero = nullptr;
     const int* wz_map = nullptr;  // [K,N] form only: batch z0 reads W + wz_map[z0] * sW0 (stream slots of the state pool)
     long long sA0 = 0, sA1 = 0, sW0 = 0, sW1 = 0, sC0 = 0, sC1 = 0, sR0 = 0, sR1 = 0;
     long long sBias0 = 0;  // bias + z0 * sBias0 (batched launches over layers, each with its own bias)
@@ -286,6 +291,13 @@ struct GreedyArgs {
     unsigned long long* gran = nullptr;  // [B][2 (round parity)][parts][GF][2], zeroed per call
 };
 void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a);
+// The same search as batched ROUNDS instead of one persistent workgroup pair per stream: every round evaluates the next S frames
+// of every stream under the stream's current context with ONE joiner GEMM over all B x S rows, then a per-stream step accepts
+// frames up to and including the first emission, updates the context, runs the decoder if it changed and forms the next
+// window's tanh(enc + dec) rows.  Exactly the frame-by-frame loop (frames behind an emission are re-evaluated in the next round);
+// max(Tp) rounds are enqueued up front, rounds after the last stream has finished return at their first instruction.
+// out_w: joiner.output_linear.weight [V, J] (torch layout, for the GEMM).  Batch / online semantics only (no max_sym cap).
+void greedy_rounds(const Ctx& ctx, const DecJoinW& w, const float* out_w, const GreedyArgs& a);
 
 // ---- modified beam search (beam.hip) ------------------------------------------------------------
 constexpr int kMaxBeam = 8;

@@ -484,7 +484,8 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
             GreedyArgs a;
             a.enc = enc; a.B = B; a.Tp = Tp; a.t0 = nullptr; a.skip1 = 1; a.max_sym = INT_MAX;
             a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = Tp; a.overflow = d_ovf; a.init_ctx = d_hyp;
-            greedy_loop(c, decjoin(), a);
+            if (tunables().search_rounds == 0) greedy_loop(c, decjoin(), a);
+            else greedy_rounds(c, decjoin(), model_->w("joiner.output_linear.weight"), a);
             if (!c.dry) K2_HIP(hipEventRecord(ev_[4], c.stream));
             return;
         }
@@ -503,7 +504,8 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
         GreedyArgs a;
         a.enc = enc; a.B = B; a.Tp = Tp; a.t0 = nullptr; a.skip1 = 1; a.max_sym = INT_MAX;
         a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = Tp; a.overflow = d_ovf; a.init_ctx = d_hyp;
-        greedy_loop(c, decjoin(), a);
+        if (tunables().search_rounds == 0) greedy_loop(c, decjoin(), a);
+            else greedy_rounds(c, decjoin(), model_->w("joiner.output_linear.weight"), a);
         if (!c.dry) K2_HIP(hipEventRecord(ev_[4], c.stream));
     });
     finish_tokens(d_tok, d_ts, d_n, d_ovf, B, Tp, tokens, ts, n_tokens);
@@ -640,7 +642,8 @@ void Engine::online_sub_step(OnlineSub& s, const int* slots, const float* const*
         a.enc = enc; a.B = B; a.Tp = Tp; a.t0 = nullptr; a.skip1 = 1; a.max_sym = INT_MAX;
         a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = Tp; a.overflow = d_ovf; a.init_ctx = d_hyp;
         a.b_concurrent = B_all;
-        greedy_loop(c, decjoin(), a);
+        if (tunables().search_rounds == 0) greedy_loop(c, decjoin(), a);
+            else greedy_rounds(c, decjoin(), model_->w("joiner.output_linear.weight"), a);
         if (!c.dry) K2_HIP(hipEventRecord(s.ev[4], c.stream));
     };
     Ctx c;

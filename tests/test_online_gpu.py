@@ -327,3 +327,42 @@ def test_split_chunk_step_equals_single_stream_step(stream_model_path, ora, spli
                 # a sub-batch has fewer rows, so its GEMMs may take another tile configuration: same math, another summation order
                 np.testing.assert_allclose(sb[u].state(l, k), sa[u].state(l, k), atol=2e-5, rtol=0)
         np.testing.assert_allclose(sb[u].state(0, "embed"), sa[u].state(0, "embed"), atol=2e-5, rtol=0)
+
+
+def test_streaming_search_forms_agree(stream_model_path, ora):
+    """The tick's search over the ready streams runs as rounds of joiner GEMMs by default (greedy_rounds) and as one persistent
+    kernel with K2HIP_SEARCH_ROUNDS=0.  Both carry each stream's Hyp context across chunks; tokens, timestamps and Hyp must be
+    the oracle's after every call from either form."""
+    from k2transducerasr_amd import OnlineRecognizer, set_switch
+    from k2transducerasr_amd.synth import synth_utterance
+    ra, rb = OnlineRecognizer(stream_model_path), OnlineRecognizer(stream_model_path)
+    N = 5
+    feats = [ora.fbank(synth_utterance(700 + u, 1.0 + 0.3 * (u % 3))) for u in range(N)]
+    sa = [ra.create_online_stream() for _ in range(N)]
+    sb = [rb.create_online_stream() for _ in range(N)]
+    so = [ora.create_stream() for _ in range(N)]
+    for a, b, f in zip(sa, sb, feats):
+        a.add_features(f)
+        b.add_features(f)
+    T, S = ra.chunk_length, ra.shift_length
+    pos = [0] * N
+    calls = 0
+    try:
+        while True:
+            ready = [u for u in range(N) if pos[u] + T <= feats[u].shape[0]]
+            set_switch("K2HIP_SEARCH_ROUNDS", 1)
+            ra.get_results(sa)
+            set_switch("K2HIP_SEARCH_ROUNDS", 0)
+            rb.get_results(sb)
+            if not ready:
+                break
+            ora.step([so[u] for u in ready], [feats[u][pos[u] : pos[u] + T] for u in ready])
+            for u in ready:
+                pos[u] += S
+            for u in range(N):
+                assert sa[u].tokens == sb[u].tokens == so[u].tokens, (calls, u)
+                assert sa[u].timestamps == sb[u].timestamps == so[u].timestamps and sa[u].hyp == sb[u].hyp == so[u].hyp
+            calls += 1
+    finally:
+        set_switch("K2HIP_SEARCH_ROUNDS", -1)
+    assert calls >= 3 and sum(len(s.tokens) - 2 for s in so) > 0

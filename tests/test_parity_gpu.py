@@ -341,3 +341,33 @@ def test_alternative_kernel_paths_agree(hip_tiny, oracle_tiny, utts):
     from k2transducerasr_amd import K2HipError
     with pytest.raises(K2HipError):
         set_switch("K2HIP_NO_SUCH_SWITCH", 1)
+
+
+def test_search_as_rounds_equals_persistent_kernel(hip_tiny, oracle_tiny, utts, kat_hip):
+    """The multi-stream search has two forms: one persistent kernel (k_greedy, the offline default) and rounds of joiner GEMMs +
+    a per-stream step (greedy_rounds, the streaming default); K2HIP_SEARCH_ROUNDS forces either.  Same tokens and timestamps
+    from both, on the tiny model (ragged batch, with the first-emission context switch, and a batch where no stream ever
+    emits) and on the hand-derived cases (tie-break, skip set, negative ids, the switch itself)."""
+    from k2transducerasr_amd import set_switch
+    from kat_model import CASES
+    feats = [oracle_tiny.fbank(u) for u in utts]
+    x = oracle_tiny.pad_sequence(feats).reshape(len(utts), -1, 80)
+    enc = oracle_tiny.encoder(x)
+    want = oracle_tiny.greedy_batch(enc)
+    silent = np.zeros((2, 4, enc.shape[2]), np.float32)
+
+    def run():
+        return (hip_tiny.greedy_batch(enc), hip_tiny.greedy_batch(enc[1:2]),  # batch of one: no t0 pre-pass
+                hip_tiny.greedy_batch(silent),
+                {name: kat_hip.greedy_batch(np.stack(case["streams"])) for name, case in CASES.items()})
+    try:
+        set_switch("K2HIP_SEARCH_ROUNDS", 1)
+        rounds = run()
+        set_switch("K2HIP_SEARCH_ROUNDS", 0)
+        persistent = run()
+    finally:
+        set_switch("K2HIP_SEARCH_ROUNDS", -1)
+    assert rounds[0] == persistent[0] == want
+    assert rounds[1:3] == persistent[1:3]
+    for name, case in sorted(CASES.items()):
+        assert rounds[3][name] == case["batch"] == persistent[3][name], name
