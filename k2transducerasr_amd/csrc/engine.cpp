@@ -1026,6 +1026,7 @@ float Engine::debug_gemm(int M, int N, int K, int act, bool with_res, int iters,
         K2_HIP(hipEventRecord(ev_[7], stream_));
         K2_HIP(hipStreamSynchronize(stream_));
         K2_HIP(hipEventElapsedTime(&ms, ev_[6], ev_[7]));
+        K2_REQUIRE(!gemm_sk_take_error(), "stream-K exchange timed out (cfg %d)", cfg);
         if (max_err) {
             debug_force_gemm_cfg(2 + 64);
             linear(c, A, K, W, b, C2, N, M, K, N, act, with_res ? Rb : nullptr, N);
@@ -1078,8 +1079,12 @@ void Engine::debug_gemm_trace(int M, int N, int K, int act, bool with_res, int c
         g.res = with_res ? C : nullptr; g.ldr = N;
         for (int i = 0; i < 5; i++) gemm(c, g);   // steady state (caches, clocks)
         int bm = 0, bn = 0, nw = 0;
-        debug_ring_shape(cfg - 100, &bm, &bn, &nw);
-        *n_wg = cdiv(M, bm) * cdiv(N, bn);
+        if (cfg >= 1000) {
+            debug_sk_shape(cfg, M, N, K, n_wg, &nw);
+        } else {
+            debug_ring_shape(cfg - 100, &bm, &bn, &nw);
+            *n_wg = cdiv(M, bm) * cdiv(N, bn);
+        }
         *n_waves = nw;
         K2_REQUIRE((int64_t)*n_wg * nw * 64 <= cap, "trace buffer too small: need %lld words", (long long)*n_wg * nw * 64);
         g.dbg = dbg;

@@ -114,11 +114,17 @@ struct GemmArgs {
     const float* byp_orig = nullptr;
     const float* byp_scale = nullptr;
     int ld_orig = 0;
+    // stream-K launches (filled in by gemm()): partial-tile workspace of the launch's HIP stream, its sequence number, error flag
+    unsigned long long* sk_ws = nullptr;
+    unsigned sk_epoch = 0;
+    int* sk_err = nullptr;
     unsigned long long* dbg = nullptr;  // tuning only: in-kernel s_memtime stamps of the ring kernel, [workgroup][wave][64]
     int ablate = 0;  // tuning only: 1 = skip in-loop global loads, 2 = skip MFMAs, 4 = skip epilogue stores
 };
 void gemm(const Ctx& ctx, const GemmArgs& a);
 void debug_force_gemm_cfg(int cfg);  // tuning hook: -1 = automatic
+int gemm_sk_take_error();            // 1 if a stream-K launch since the last call timed out waiting for a partial tile (and clears it)
+void debug_sk_shape(int cfg, int M, int N, int K, int* n_wg, int* waves);  // grid and waves of stream-K cfg (>= 1000) on a shape
 void debug_ring_shape(int idx, int* bm, int* bn, int* waves);  // tile and waves of ring table entry idx
 // convenience: plain Linear  C = act(A W^T + b) (+res)
 void linear(const Ctx& ctx, const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int K,

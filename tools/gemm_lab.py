@@ -92,11 +92,18 @@ if which in ("streaming", "all"):
 cfgs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [-1, 100, 101, 103, 104]
 
 
+_tab2 = _src[_src.index("#define K2_SK_TABLE(X)") : _src.index("#define X(i, bm, bn, wm, wn, nst) {bm")]
+SK = [tuple(int(v) for v in t[1:]) for t in sorted((tuple(int(x) for x in t) for t in re.findall(r"X\((\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\)", _tab2)))]
+
+
 def name(c):
+    if c >= 1000:
+        bm, bn, wm, wn, nst = SK[(c - 1000) // 10]
+        return "sk%dx%d.%dx%d.%d/%d" % (bm, bn, wm, wn, nst, (c - 1000) % 10)
     return "auto" if c < 0 else f"c{c}" if c < 100 else "r%dx%d.%d.%d.%d%s" % (RING[c - 100][:5] + ("p" if RING[c - 100][5] else "",))
 
 
-print(f"{'M':>7} {'N':>5} {'K':>5} a r  n |" + "".join(f"{name(c):>14}" for c in cfgs) + " | best")
+print(f"{'M':>7} {'N':>5} {'K':>5} a r  n |" + "".join(f"{name(c):>18}" for c in cfgs) + " | best")
 tot = [0.0] * len(cfgs)
 best_tot = 0.0
 for (M, N, K, act, res), cnt in shapes:
@@ -104,21 +111,21 @@ for (M, N, K, act, res), cnt in shapes:
     row = []
     for ci, cfg in enumerate(cfgs):
         ms, err = C.c_float(), C.c_float()
-        ks = RING[cfg - 100][2] if cfg >= 100 else 1
-        if cfg >= 100 and (K % (32 * ks) or K < 32 * ks):
+        ks = RING[cfg - 100][2] if 100 <= cfg < 1000 else 1
+        if 100 <= cfg < 1000 and (K % (32 * ks) or K < 32 * ks):
             row.append(None)
-            line += f"{'-':>14}"
+            line += f"{'-':>18}"
             continue
         rc = L.k2hip_debug_gemm_check(m.handle, M, N, K, act, res, cfg, 20, C.byref(ms), C.byref(err))
         if rc != 0:
             row.append(None)
-            line += f"{'ERR':>14}"
+            line += f"{'ERR':>18}"
             continue
         us = ms.value * 1e3
         row.append(us)
         tot[ci] += us * cnt
         bad = err.value > 2e-3 * max(1.0, K ** 0.5 / 8)
-        line += f"{us:9.1f}{'!%.0e' % err.value if bad else '     '}"
+        line += f"{us:13.1f}{'!%.0e' % err.value if bad else '     '}"
     ok = [u for u in row if u is not None]
     b = min(ok) if ok else 0
     best_tot += b * cnt
