@@ -742,7 +742,8 @@ __attribute__((visibility("default"))) int32_t k2hip_debug_gemm_trace(k2hip_mode
                                                                        int32_t* n_wg, int32_t* n_waves) {
     return guard([&] {
         NEED(model); NEED(out); NEED(n_wg); NEED(n_waves);
-        K2_REQUIRE(cfg >= 100, "trace: ring (cfg >= 100) and stream-K (cfg >= 1000) configurations only");
+        K2_REQUIRE(cfg >= 100 || cfg == 0 || cfg == 5 || cfg == 7 || (cfg >= 9 && cfg <= 11),
+                   "trace: LDS-DMA (0, 5, 7, 9, 10, 11), ring (100+) and stream-K (1000+) configurations only");
         std::lock_guard<std::mutex> lk(model->engine.mutex());
         model->engine.debug_gemm_trace(M, N, K, act, with_res != 0, cfg, out, cap, n_wg, n_waves);
     });

@@ -1079,8 +1079,15 @@ void Engine::debug_gemm_trace(int M, int N, int K, int act, bool with_res, int c
         g.res = with_res ? C : nullptr; g.ldr = N;
         for (int i = 0; i < 5; i++) gemm(c, g);   // steady state (caches, clocks)
         int bm = 0, bn = 0, nw = 0;
-        if (cfg >= 1000) {
+        if (cfg >= 2000) {
+            debug_pipe_shape(cfg, M, N, n_wg, &nw);
+        } else if (cfg >= 1000) {
             debug_sk_shape(cfg, M, N, K, n_wg, &nw);
+        } else if (cfg < 100) {  // LDS-DMA kernel: 5 / 7 = 128x64 (8 waves), 9 = 64x64 (4 waves), 0 = 128x128 (8 waves), 11 = 64x96 (6 waves)
+            bm = cfg == 9 || cfg == 10 || cfg == 11 ? 64 : 128;
+            bn = cfg == 0 ? 128 : cfg == 11 ? 96 : 64;
+            nw = cfg == 9 || cfg == 10 ? 4 : cfg == 11 ? 6 : 8;
+            *n_wg = cdiv(M, bm) * cdiv(N, bn);
         } else {
             debug_ring_shape(cfg - 100, &bm, &bn, &nw);
             *n_wg = cdiv(M, bm) * cdiv(N, bn);

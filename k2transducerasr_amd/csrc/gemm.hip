@@ -415,6 +415,14 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
     int mb_, nb_;
     xcd_tile(mb_, nb_);
     const int m0 = mb_ * BM, n0 = nb_ * BN;
+    // tuning only (g.dbg != nullptr): lane 0 of every wave stamps s_memtime: entry | prologue issued | per K step: barrier passed
+    // (first 40) | loop done | end; [62] = stamps, [60]/[63] = s_memrealtime
+    unsigned long long* stamp = g.dbg ? g.dbg + ((size_t)(blockIdx.x + blockIdx.y * gridDim.x) * NW + wave) * 64 : nullptr;
+    int nstamp = 0;
+#define K2_DMA_STAMP() \
+    if (stamp && lane == 0 && nstamp < 60) stamp[nstamp++] = __builtin_amdgcn_s_memtime();
+    if (stamp && lane == 0) stamp[60] = __builtin_amdgcn_s_memrealtime();
+    K2_DMA_STAMP()
 
     // this lane's source pointer for each of the wave's DMA instructions (advances by BK per tile)
     const float* src[IPW];
@@ -482,6 +490,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
                 }
         }
     }
+    K2_DMA_STAMP()
     for (int kt = 0; kt < nk; kt++) {
         // tile kt landed for this wave once at most the PF-1 newer tiles' instructions are pending
         if (R && kt < PF && kt + PF - 1 < nk) {
@@ -496,6 +505,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();  // ... and for every wave; also: everyone is done reading the stage about to be refilled
+        if (kt < 40) { K2_DMA_STAMP() }
         if (kt + PF < nk) issue(kt + PF);
         const float* sa = smem + (kt % NST) * STAGE + arow * BK;
         const float* sb = smem + (kt % NST) * STAGE + (BM + brow) * BK;
@@ -534,6 +544,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
         }
     }
 
+    K2_DMA_STAMP()
 #pragma unroll
     for (int j = 0; j < NT; j++)
 #pragma unroll
@@ -544,6 +555,269 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
             epilogue_rows<16, Rows32>(g, vals, m0 + wr * WM + i * 32 + 4 * lh, n0 + wc * WN + j * 32 + li, C, nullptr, rres[i][j], R != nullptr,
                                       nullptr, g.bias ? g.bias + z0 * g.sBias0 : nullptr);
         }
+    K2_DMA_STAMP()
+    if (stamp && lane == 0) {
+        stamp[62] = nstamp;
+        stamp[63] = __builtin_amdgcn_s_memrealtime();
+    }
+#undef K2_DMA_STAMP
+}
+
+// ---------------------------------------------------------------------------------------
+// Pipelined variant of the LDS-DMA kernel (plain Linear, K % 32 == 0): the same tile image, swizzle and fragment reads, with a
+// K loop that contains nothing but MFMAs, LDS reads, LDS-DMAs and scalar bookkeeping.
+//
+// What the measurements said (tools/probes/vmem_vs_mfma_probe.hip, tools/gemm_dma_trace.py):
+//   * a wave streaming v_mfma_f32_32x32x2_f32 keeps the 64-cycle rate with six LDS-DMAs, global loads or ds_read_b128 per 16 MFMAs
+//     in its instruction stream -- they cost nothing -- but every VECTOR-ALU instruction between two MFMAs costs matrix time: a
+//     per-lane 64-bit address add in front of each DMA took the loop from 64.1 to 71 - 74 cycles per MFMA, saving / restoring M0
+//     around it another 3;
+//   * the compiled K loop of gemm_f32_mfma_dma carries ~30 such instructions per K step and wave (pointer + kt * 32, the XOR
+//     swizzle of every fragment read, kt % NST, select chains for wave-uniform conditions) and a dozen branches: 2671 cycles per
+//     2048 cycles of MFMA work in its in-kernel stamps, whatever the pipeline order.
+// So here every address is settled BEFORE the loop:
+//   * fragment reads: one LDS byte address per (stage, 8-deep k group) and operand in VGPRs (2 x 4 NST registers), the 32-row
+//     block of the wave tile in the instruction's immediate offset;
+//   * LDS-DMA: global_load_lds_dwordx4 in its SGPR-base + 32-bit VGPR-offset form -- the per-lane offset (row * ld + swizzled
+//     chunk) never changes, the base advances by 128 bytes per K step with scalar adds; M0 = a per-instruction SGPR + the stage's
+//     constant;
+//   * the K loop is unrolled by NST so that the stage is a compile-time constant; neither its steady state nor the straight-line
+//     copies of the last steps test anything (K >= 32 (NST - 1): the launcher checks);
+//   * pipeline: fragments double-buffered per k group, the last group of a step reads the first group of the next one; the wait
+//     for step kt+1's DMA and the step's one barrier sit between groups 2 and 3, behind queued MFMAs; the DMA of step kt+NST-1
+//     is issued behind that barrier, spread over group 3's MFMA slots.
+// Wave tiles of 32 MT x 32 NT; NINST % waves == 0 (every wave issues the same number of DMAs, so the counted waits are constants).
+// The per-lane byte offsets stay below 2^31: the launcher requires M * lda and N * ldw below 2^29 floats.
+template <int BM, int BN, int WM, int WN, int NST>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe(GemmArgs g) {
+    constexpr int BK = 32;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int WCOLS = BN / WN;
+    constexpr int NW = (BM / WM) * (BN / WN);
+    constexpr int NINST = (BM + BN) / 8;
+    constexpr int IPW = NINST / NW;
+    constexpr int STAGE = (BM + BN) * BK;
+    constexpr int DPE = (IPW + 3) / 4;  // DMA instructions issued behind each of group 3's four MFMA steps
+    static_assert(NST == 3 || NST == 4, "pipe: three or four stages");
+    static_assert(NINST % NW == 0, "pipe: every wave issues the same number of DMA instructions");
+    static_assert((NST - 2) * IPW <= 63 && MT <= 4 && NT <= 2, "pipe: counted wait / wave tile out of range");
+
+    if (g.skip_if_zero && *g.skip_if_zero == 0) return;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [NST][STAGE]: A rows then W rows
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WCOLS, wc = wave % WCOLS;
+    const int li = lane & 31, lh = lane >> 5;
+    float* __restrict__ C = g.C;
+    const float* __restrict__ R = g.res;
+    int mb_, nb_;
+    xcd_tile(mb_, nb_);
+    const int m0 = mb_ * BM, n0 = nb_ * BN;
+    const int nk = g.K / BK;
+
+    unsigned long long* stamp = g.dbg ? g.dbg + ((size_t)(blockIdx.x + blockIdx.y * gridDim.x) * NW + wave) * 64 : nullptr;
+    int nstamp = 0;
+#define K2_PIPE_STAMP()                                                    \
+    if (stamp) { /* wave-uniform test and counter: no vector work when off */ \
+        if (lane == 0) stamp[nstamp] = __builtin_amdgcn_s_memtime();       \
+        nstamp++;                                                          \
+    }
+    if (stamp && lane == 0) stamp[60] = __builtin_amdgcn_s_memrealtime();
+    K2_PIPE_STAMP()
+
+    // residual operand first: older than every DMA, so the counted waits below never have to account for it (vmcnt retires in
+    // issue order; its latency overlaps the prologue's DMAs all the same)
+    float rres[MT][NT][16];
+    if (R) {
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int col = min(n0 + wc * WN + j * 32 + li, g.N - 1);
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = min(m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
+                    rres[i][j][r] = R[(long long)row * g.ldr + col];
+                }
+        }
+    }
+
+    // ---- addresses, once ----
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    unsigned voff[IPW];            // per-lane byte offset of this wave's q-th DMA from its operand's base (constant over K)
+    unsigned long long sb[IPW];    // that operand's base (wave-uniform: A for instructions < BM / 8, else W)
+    unsigned mq[IPW];              // LDS byte address of the instruction's 1 KB inside stage 0
+#pragma unroll
+    for (int q = 0; q < IPW; q++) {
+        const int inst = wave + q * NW;  // wave-uniform
+        const int slot = inst * 64 + lane;
+        const int r = slot >> 3, cp = slot & 7;
+        const int c = cp ^ ((r >> 1) & 7);
+        const bool is_a = inst < BM / 8;
+        const long long row = is_a ? min(m0 + r, g.M - 1) : min(n0 + (r - BM), g.N - 1);
+        voff[q] = (unsigned)((row * (is_a ? g.lda : g.ldw) + 4 * c) * 4);
+        const unsigned long long base = (unsigned long long)(is_a ? g.A : g.W);
+        // (readfirstlane returns int: without the casts a low half with bit 31 set sign-extends over the high half)
+        sb[q] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
+        mq[q] = __builtin_amdgcn_readfirstlane(lds_base + inst * 1024);
+    }
+    const int arow = wr * WM + li, brow = wc * WN + li;
+    const int swa = (arow >> 1) & 7, swb = ((BM + brow) >> 1) & 7;
+    unsigned ra[NST][4], rb[NST][4];  // fragment read addresses: stage, k group
+#pragma unroll
+    for (int st = 0; st < NST; st++)
+#pragma unroll
+        for (int gk = 0; gk < 4; gk++) {
+            ra[st][gk] = lds_base + (st * STAGE + arow * BK + (((2 * gk + lh) ^ swa) << 2)) * 4;
+            rb[st][gk] = lds_base + (st * STAGE + (BM + brow) * BK + (((2 * gk + lh) ^ swb) << 2)) * 4;
+        }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    f32x4 fa[2][MT], fb[2][NT];
+
+// instruction q_ of K step KT_ (stage ST_, a literal): M0 = its LDS destination, source = operand base + 128 KT_ bytes + lane offset
+#define K2_PIPE_DMA(ST_, KT_, q_)                                                                                          \
+    {                                                                                                                      \
+        const unsigned long long src_ = sb[q_] + (unsigned long long)(KT_) * (BK * 4);                                    \
+        asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                    \
+                     :                                                                                                     \
+                     : "v"(voff[q_]), "s"(src_), "s"(mq[q_]), "n"((ST_) * STAGE * 4)                                       \
+                     : "memory");                                                                                          \
+    }
+// fragments of k group G_ of stage ST_ into register set SET_ (the 32-row blocks of the wave tile: 4096 bytes apart)
+#define K2_PIPE_READ(SET_, ST_, G_)                                                                                        \
+    {                                                                                                                      \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[SET_][0]) : "v"(ra[ST_][G_]) : "memory");                             \
+        if (MT > 1) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fa[SET_][MT > 1 ? 1 : 0]) : "v"(ra[ST_][G_]) : "memory");  \
+        if (MT > 2) asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(fa[SET_][MT > 2 ? 2 : 0]) : "v"(ra[ST_][G_]) : "memory");  \
+        if (MT > 3) asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(fa[SET_][MT > 3 ? 3 : 0]) : "v"(ra[ST_][G_]) : "memory"); \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fb[SET_][0]) : "v"(rb[ST_][G_]) : "memory");                             \
+        if (NT > 1) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fb[SET_][NT > 1 ? 1 : 0]) : "v"(rb[ST_][G_]) : "memory");  \
+    }
+// the reads into SET_ have returned (they were issued one k group ago); the empty asms tie the registers to the wait
+#define K2_PIPE_FRAGS_READY(SET_)                                                                                          \
+    {                                                                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) asm volatile("" : "+v"(fa[SET_][i]));                               \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) asm volatile("" : "+v"(fb[SET_][j]));                               \
+    }
+// one K step.  ST_: its stage (literal).  HAS_NEXT_: step KT_+1 exists; DO_ISSUE_: step KT_+NST-1 exists (both `true` in the steady
+// state); WAIT_: the vmcnt wait in front of the barrier (instructions of newer steps that may stay in flight)
+#define K2_PIPE_STEP(ST_, KT_, HAS_NEXT_, DO_ISSUE_, WAIT_)                                                                \
+    _Pragma("unroll") for (int gk = 0; gk < 4; gk++) {                                                                     \
+        const int cu = gk & 1;                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        K2_PIPE_FRAGS_READY(cu)                                                                                            \
+        _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                                    \
+            _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++)                  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cu][i][e], fb[cu][j][e], acc[i][j], 0, 0, 0);          \
+            if (e == 0) {                                                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                                         \
+                if (gk == 0) K2_PIPE_READ(1, ST_, 1)                                                                       \
+                if (gk == 1) K2_PIPE_READ(0, ST_, 2)                                                                       \
+                if (gk == 2) K2_PIPE_READ(1, ST_, 3)                                                                       \
+                if (gk == 3 && (HAS_NEXT_)) K2_PIPE_READ(0, ((ST_) + 1) % NST, 0)                                          \
+                __builtin_amdgcn_sched_barrier(0);                                                                         \
+            }                                                                                                              \
+            if (gk == 3 && (DO_ISSUE_)) {                                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                                         \
+                _Pragma("unroll") for (int q = e * DPE; q < (e + 1) * DPE && q < IPW; q++)                                 \
+                    K2_PIPE_DMA(((ST_) + NST - 1) % NST, (KT_) + NST - 1, q)                                               \
+                __builtin_amdgcn_sched_barrier(0);                                                                         \
+            }                                                                                                              \
+        }                                                                                                                  \
+        if (gk == 2 && (HAS_NEXT_)) { /* step KT_+1 has landed for everyone; everyone has left step KT_-1's stage */       \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            WAIT_                                                                                                          \
+            __builtin_amdgcn_s_barrier();                                                                                  \
+            if ((KT_) < 40) { K2_PIPE_STAMP() }                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+        }                                                                                                                  \
+    }
+#define K2_PIPE_WAIT_STEADY asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 3) * IPW) : "memory");
+#define K2_PIPE_WAIT_DRAIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- prologue: K steps 0 .. NST-2 in flight, step 0 landed, its first fragments on their way ----
+#pragma unroll
+    for (int p = 0; p < NST - 1; p++)
+        if (p < nk) {
+#pragma unroll
+            for (int q = 0; q < IPW; q++) {
+                if (p == 0) K2_PIPE_DMA(0, 0, q)
+                if (p == 1) K2_PIPE_DMA(1, 1, q)
+                if (p == 2) K2_PIPE_DMA(2, 2, q)
+            }
+        }
+    K2_PIPE_STAMP()
+    if (nk >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * IPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    K2_PIPE_READ(0, 0, 0)
+    K2_PIPE_STAMP()
+
+    int kt = 0;
+    const int nsteady = nk - (NST - 1);  // steps whose step kt+NST-1 exists
+    for (; kt + NST <= nsteady; kt += NST) {  // kt % NST == 0 here: the stage of step kt + s is s
+        K2_PIPE_STEP(0, kt, true, true, K2_PIPE_WAIT_STEADY)
+        K2_PIPE_STEP(1, kt + 1, true, true, K2_PIPE_WAIT_STEADY)
+        K2_PIPE_STEP(2, kt + 2, true, true, K2_PIPE_WAIT_STEADY)
+        if (NST == 4) { K2_PIPE_STEP(NST == 4 ? 3 : 0, kt + 3, true, true, K2_PIPE_WAIT_STEADY) }
+    }
+    // What is left starts at a multiple of NST, so the stages stay literals: rs = 0 .. NST-1 more steady steps, then the last NST-1
+    // steps (nothing left to issue; the very last has no successor).  One straight-line copy per rs, no flags at run time.
+#define K2_PIPE_S(j_) K2_PIPE_STEP((j_) % NST, kt + (j_), true, true, K2_PIPE_WAIT_STEADY)
+#define K2_PIPE_T(j_) K2_PIPE_STEP((j_) % NST, kt + (j_), true, false, K2_PIPE_WAIT_DRAIN)
+#define K2_PIPE_L(j_) K2_PIPE_STEP((j_) % NST, kt + (j_), false, false, K2_PIPE_WAIT_DRAIN)
+    const int rs = nsteady - kt;
+    if (NST == 3) {
+        switch (rs) {
+            case 0: K2_PIPE_T(0) K2_PIPE_L(1) break;
+            case 1: K2_PIPE_S(0) K2_PIPE_T(1) K2_PIPE_L(2) break;
+            default: K2_PIPE_S(0) K2_PIPE_S(1) K2_PIPE_T(2) K2_PIPE_L(3) break;
+        }
+    } else {
+        switch (rs) {
+            case 0: K2_PIPE_T(0) K2_PIPE_T(1) K2_PIPE_L(2) break;
+            case 1: K2_PIPE_S(0) K2_PIPE_T(1) K2_PIPE_T(2) K2_PIPE_L(3) break;
+            case 2: K2_PIPE_S(0) K2_PIPE_S(1) K2_PIPE_T(2) K2_PIPE_T(3) K2_PIPE_L(4) break;
+            default: K2_PIPE_S(0) K2_PIPE_S(1) K2_PIPE_S(2) K2_PIPE_T(3) K2_PIPE_T(4) K2_PIPE_L(5) break;
+        }
+    }
+#undef K2_PIPE_S
+#undef K2_PIPE_T
+#undef K2_PIPE_L
+    K2_PIPE_STAMP()
+#undef K2_PIPE_WAIT_DRAIN
+#undef K2_PIPE_WAIT_STEADY
+#undef K2_PIPE_STEP
+#undef K2_PIPE_FRAGS_READY
+#undef K2_PIPE_READ
+#undef K2_PIPE_DMA
+
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            float vals[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) vals[r] = acc[i][j][r];
+            epilogue_rows<16, Rows32>(g, vals, m0 + wr * WM + i * 32 + 4 * lh, n0 + wc * WN + j * 32 + li, C, nullptr, rres[i][j], R != nullptr,
+                                      nullptr, g.bias);
+        }
+    K2_PIPE_STAMP()
+    if (stamp && lane == 0) {
+        stamp[62] = nstamp;
+        stamp[63] = __builtin_amdgcn_s_memrealtime();
+    }
+#undef K2_PIPE_STAMP
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1215,6 +1489,35 @@ bool launch_sk_idx(const Ctx& ctx, const GemmArgs& a, int idx, int wg_per_cu) {
     return true;
 }
 
+template <int BM, int BN, int WM, int WN, int NST>
+void launch_pipe(const Ctx& ctx, const GemmArgs& a) {
+    dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), 1);
+    size_t lds = sizeof(float) * NST * (BM + BN) * 32;
+    static LdsAttrOnce lds_attr;
+    lds_attr.ensure(gemm_f32_mfma_pipe<BM, BN, WM, WN, NST>, (int)lds);
+    K2_REQUIRE((long long)a.M * a.lda < (1ll << 29) && (long long)a.N * a.ldw < (1ll << 29), "pipe: operand too large for 31-bit lane byte offsets");
+    K2_REQUIRE(a.K % 32 == 0 && a.K >= 32 * (NST - 1), "pipe: K %d too short for %d stages", a.K, NST);
+    hipLaunchKernelGGL((gemm_f32_mfma_pipe<BM, BN, WM, WN, NST>), grid, dim3(64 * (BM / WM) * (BN / WN)), lds, ctx.stream, a);
+}
+// tuning table of the pipelined kernel: k2hip_debug_gemm cfg = 2000 + index
+struct PipeCfg { int BM, BN, WM, WN, NST; };
+#define K2_PIPE_TABLE(X)                                                                                                       \
+    X(0, 128, 64, 64, 32, 3) X(1, 128, 64, 32, 32, 3) X(2, 128, 128, 64, 64, 3) X(3, 128, 128, 64, 32, 3) X(4, 128, 64, 64, 32, 4)  \
+    X(5, 64, 64, 32, 32, 3) X(6, 128, 128, 64, 64, 4) X(7, 64, 128, 32, 64, 3) X(8, 128, 128, 32, 32, 3) X(9, 128, 64, 32, 32, 4) \
+    X(10, 64, 64, 64, 32, 3) X(11, 64, 64, 32, 64, 3) X(12, 128, 64, 128, 32, 3) X(13, 128, 32, 32, 32, 3) X(14, 128, 32, 64, 32, 3)
+#define X(i, bm, bn, wm, wn, nst) {bm, bn, wm, wn, nst},
+const PipeCfg kPipe[] = {K2_PIPE_TABLE(X)};
+#undef X
+bool launch_pipe_idx(const Ctx& ctx, const GemmArgs& a, int idx) {
+    switch (idx) {
+#define X(i, bm, bn, wm, wn, nst) case i: launch_pipe<bm, bn, wm, wn, nst>(ctx, a); break;
+        K2_PIPE_TABLE(X)
+#undef X
+        default: return false;
+    }
+    return true;
+}
+
 // tuning table of the ring kernel: k2hip_debug_gemm cfg = 100 + index
 struct RingCfg { int BM, BN, KS, NST, LW, PF; };
 #define K2_RING_TABLE(X)                                                                                        \
@@ -1311,6 +1614,13 @@ void debug_ring_shape(int idx, int* bm, int* bn, int* waves) {
 }
 int g_forced_ring = -1;
 int g_forced_sk = -1, g_forced_sk_occ = 1;
+int g_forced_pipe = -1;
+void debug_pipe_shape(int cfg, int M, int N, int* n_wg, int* waves) {
+    const int idx = cfg - 2000;
+    K2_REQUIRE(idx >= 0 && idx < (int)(sizeof(kPipe) / sizeof(kPipe[0])), "no pipe cfg %d", idx);
+    *n_wg = cdiv(M, kPipe[idx].BM) * cdiv(N, kPipe[idx].BN);
+    *waves = (kPipe[idx].BM / kPipe[idx].WM) * (kPipe[idx].BN / kPipe[idx].WN);
+}
 int gemm_sk_take_error() {
     std::lock_guard<std::mutex> lk(g_sk_mu);
     if (!g_sk_err_host) return 0;
@@ -1321,6 +1631,15 @@ int gemm_sk_take_error() {
 void debug_force_gemm_cfg(int cfg) {
     const int dma_default = 1;
     g_forced_sk = -1;
+    g_forced_pipe = -1;
+    if (cfg >= 2000) {  // pipelined kernel table
+        g_forced_pipe = cfg - 2000;
+        g_forced_ring = -1;
+        g_forced_cfg = -1;
+        g_ablate = 0;
+        g_use_dma = dma_default;
+        return;
+    }
     if (cfg >= 1000) {  // stream-K table
         g_forced_sk = (cfg - 1000) / 10;
         g_forced_sk_occ = std::max(1, (cfg - 1000) % 10);
@@ -1364,6 +1683,14 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         ctx.gemm_log->push_back({a.M, a.N, a.K, a.nb0 * a.nb1, a.act, a.res != nullptr, a.cv_Fout > 0 ? 1 : (a.w_kn ? 2 : 0), 0.f});
     // (a) N <= 96: few columns; (b) small problems (streaming chunks, beam search: a 128x64 grid would leave most CUs idle and
     // every workgroup would walk K serially): the same kernel over column chunks of 96
+    if (g_forced_pipe >= 0) {  // tuning hook
+        K2_REQUIRE(a.cv_Fout == 0 && !a.w_kn && !a.mul && a.res_div == 1 && !a.act_after_res && a.K % 32 == 0 && a.K >= 64 && a.nb0 * a.nb1 == 1,
+                   "pipe cfg %d does not fit this GEMM", g_forced_pipe);
+        K2_REQUIRE(launch_pipe_idx(ctx, b, g_forced_pipe), "no pipe cfg %d", g_forced_pipe);
+        K2_HIP(hipGetLastError());
+        if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
+        return;
+    }
     if (g_forced_sk >= 0) {  // tuning hook
         K2_REQUIRE(a.cv_Fout == 0 && !a.w_kn && !a.mul && a.res_div == 1 && !a.act_after_res && a.K % 32 == 0 && a.K >= 64 && a.nb0 * a.nb1 == 1,
                    "stream-K cfg %d does not fit this GEMM", g_forced_sk);
@@ -1430,11 +1757,35 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
         return;
     }
-    // Single-round grids of large tiles (fewer operand bytes per MFMA: a CU's fetch rate, not the matrix pipe, bounds these
-    // launches -- tools/probes/mfma_loop_probe.hip): 128x96 tiles when they cover the output in 218 .. 256 workgroups, 128x128
-    // (16 waves) when they fill whole rounds of the 256 CUs and K is long enough to amortise the larger prologue
-    // (tools/gemm_lab.py offline, gpurun_out/lab_off5.txt: -14 % on 2048x1536x768, -15 % on 16160x192x2432, -3 .. -7 % on the others)
-    if (dma_ok && use_dma && !forced && !tn.gemm_v1 && a.nb0 * a.nb1 == 1 && a.M >= 1024) {
+    // One problem per launch, K % 32 == 0: the pipelined kernel, tile by a small cost model fitted to tools/gemm_lab.py offline
+    // (gpurun_out/lab_pipe3.txt).  The busiest CU runs ceil(tiles / 256) tiles; a tile costs its K steps plus a fixed part (prologue,
+    // last steps, epilogue -- less of it is exposed when several small workgroups share the CU), small tiles pay a few percent
+    // for their extra operand traffic.  Examples it reproduces: 4064 x 512 -> 128x64 (256 tiles, one round); 4064 x 1152,
+    // 2048 x 2560 / 2080 -> 64x64 (1152 / 1280 / 1056 tiles: 4.5 / 5 / 4.1 rounds of 4096 instead of 2.25 / 2.5 / 2.1 -> 3 of 8192);
+    // 4064 x 1024 / 1920, 2048 x 2048 -> 128x128; 16160 x 192 -> 64x64 or 128x32 (3 rounds of 4096 instead of 2 of 8192).
+    if (dma_ok && use_dma && !forced && !tn.gemm_v1 && a.nb0 * a.nb1 == 1 && a.K >= 64 && a.M >= 256 &&
+        (long long)a.M * a.lda < (1ll << 29) && (long long)a.N * a.ldw < (1ll << 29)) {
+        struct Cand { int idx, bm, bn; double fixed_steps, penalty; };
+        static const Cand cands[] = {{8, 128, 128, 3.5, 0.0}, {1, 128, 64, 3.3, 0.02}, {5, 64, 64, 2.0, 0.08}, {13, 128, 32, 2.5, 0.08}};
+        const double nk = a.K / 32.0;
+        int best = -1;
+        double best_cost = 0;
+        for (const Cand& c : cands) {
+            const long long tiles = (long long)cdiv(a.M, c.bm) * cdiv(a.N, c.bn);
+            const double cost = (double)cdiv(tiles, 256) * c.bm * c.bn * (nk + c.fixed_steps) * (1.0 + c.penalty);
+            if (best < 0 || cost < best_cost) {
+                best = c.idx;
+                best_cost = cost;
+            }
+        }
+        launch_pipe_idx(ctx, b, best);
+        K2_HIP(hipGetLastError());
+        if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 128;
+        if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
+        return;
+    }
+    // (K2HIP_GEMM_V1: the round-1 / round-2 tile rules below)
+    if (dma_ok && use_dma && !forced && a.nb0 * a.nb1 == 1 && a.M >= 1024) {
         const long long t96 = a.N % 96 == 0 ? (long long)cdiv(a.M, 128) * (a.N / 96) : 0;
         const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128);
         int ring = -1;

@@ -12,7 +12,7 @@ struct Tunables {
     int gemm_no_dma = 0;          // K2HIP_GEMM_NO_DMA: register-staged kernels only
     int gemm_no_skinny = 0;       // K2HIP_GEMM_NO_SKINNY
     int gemm_nst3 = 0;            // K2HIP_GEMM_NST3: three-stage ring for the 128x64 LDS-DMA kernel
-    int gemm_v1 = 0;              // K2HIP_GEMM_V1: the round-1 LDS-DMA pipeline (barrier at the top of every K step)
+    int gemm_v1 = 0;              // K2HIP_GEMM_V1: the earlier LDS-DMA kernels and tile rules (barrier at the top of every K step) instead of gemm_f32_mfma_pipe
     int attn_long = 0;            // K2HIP_ATTN_LONG: two-pass attention scores for every length
     int no_fused_av = 0;          // K2HIP_NO_FUSED_AV: attention apply + out_proj as two GEMMs
     int conformer_gemm_scores = 0;  // K2HIP_CONFORMER_GEMM_SCORES: two batched GEMMs + gather/softmax
@@ -124,6 +124,7 @@ struct GemmArgs {
 void gemm(const Ctx& ctx, const GemmArgs& a);
 void debug_force_gemm_cfg(int cfg);  // tuning hook: -1 = automatic
 int gemm_sk_take_error();            // 1 if a stream-K launch since the last call timed out waiting for a partial tile (and clears it)
+void debug_pipe_shape(int cfg, int M, int N, int* n_wg, int* waves);  // grid and waves of pipe cfg (>= 2000) on a shape
 void debug_sk_shape(int cfg, int M, int N, int K, int* n_wg, int* waves);  // grid and waves of stream-K cfg (>= 1000) on a shape
 void debug_ring_shape(int idx, int* bm, int* bn, int* waves);  // tile and waves of ring table entry idx
 // convenience: plain Linear  C = act(A W^T + b) (+res)

@@ -96,7 +96,13 @@ _tab2 = _src[_src.index("#define K2_SK_TABLE(X)") : _src.index("#define X(i, bm,
 SK = [tuple(int(v) for v in t[1:]) for t in sorted((tuple(int(x) for x in t) for t in re.findall(r"X\((\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\)", _tab2)))]
 
 
+_tab3 = _src[_src.index("#define K2_PIPE_TABLE(X)") : _src.index("const PipeCfg kPipe[]")]
+PIPE = [tuple(int(v) for v in t[1:]) for t in sorted((tuple(int(x) for x in t) for t in re.findall(r"X\((\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\)", _tab3)))]
+
+
 def name(c):
+    if c >= 2000:
+        return "p%dx%d.%dx%d.%d" % PIPE[c - 2000]
     if c >= 1000:
         bm, bn, wm, wn, nst = SK[(c - 1000) // 10]
         return "sk%dx%d.%dx%d.%d/%d" % (bm, bn, wm, wn, nst, (c - 1000) % 10)

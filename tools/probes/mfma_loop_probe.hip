@@ -22,7 +22,7 @@ __global__ __launch_bounds__(64 * WAVES) void probe(float* out, int iters, unsig
     // DMA: every wave issues NDMA global_load_lds_dwordx4 (1 KB each) per iteration into a scratch ring behind the fragment area and
     // waits (counted vmcnt) for the ones issued two iterations earlier -- the traffic of a 128x64x32 GEMM tile when NDMA = 3, WAVES = 8
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sm;
-    const long long span = DMA == 1 ? 64 * 1024 : big_floats;  // floats this launch walks through (1: L2-resident, 2: streaming)
+    const long long span = (DMA == 1 || DMA == 3 || DMA >= 5) ? 64 * 1024 : big_floats;  // floats this launch walks through (1: L2-resident, 2: streaming)
     long long pos = ((long long)blockIdx.x * WAVES + wave) * 256 * NDMA % (span > 0 ? span : 1);
     auto dma = [&](int it) {
         _Pragma("unroll") for (int q = 0; q < NDMA; q++) {
@@ -34,7 +34,31 @@ __global__ __launch_bounds__(64 * WAVES) void probe(float* out, int iters, unsig
         }
         pos = (pos + (long long)gridDim.x * WAVES * 256 * NDMA) % span;
     };
-    if (DMA) { dma(0); dma(1); }
+    // DMA == 3: the same bytes register-staged (global_load_dwordx4 -> VGPR, ds_write_b128 one iteration later), as the vendor
+    // library's fp32 kernels do
+    float4 stage[NDMA];
+    _Pragma("unroll") for (int q = 0; q < NDMA; q++) stage[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto staged = [&](int it) {
+        _Pragma("unroll") for (int q = 0; q < NDMA; q++) {
+            *(float4*)(sm + 12288 + ((it % 3) * WAVES * NDMA + wave * NDMA + q) * 256 + lane * 4) = stage[q];
+            stage[q] = *(const float4*)(big + (pos + q * 256 + lane * 4) % span);
+        }
+        pos = (pos + (long long)gridDim.x * WAVES * 256 * NDMA) % span;
+    };
+    // DMA == 5: as 1 but M0 is not saved / restored around each DMA (clobbered);  DMA == 6: as 5 and the NDMA instructions of an
+    // iteration are issued one per MFMA slot (after MFMAs 0, 1, 2, ...) instead of back to back
+    auto dma1 = [&](int it, int q) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (12288 + ((it % 3) * WAVES * NDMA + wave * NDMA + q) * 256) * 4);
+        const float* gp = big + (pos + q * 256 + lane * 4) % span;
+        if (DMA == 8) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(gp), "s"(dst) : "memory", "m0");
+        else if (DMA == 9) {
+            const unsigned off = (unsigned)(((pos + q * 256 + lane * 4) % span) * 4);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(off), "s"(dst), "s"(big) : "memory", "m0");
+        } else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gp), "s"(dst) : "memory", "m0");
+        if (q == NDMA - 1) pos = (pos + (long long)gridDim.x * WAVES * 256 * NDMA) % span;
+    };
+    if (DMA >= 5) { _Pragma("unroll") for (int q = 0; q < NDMA; q++) dma1(0, q); _Pragma("unroll") for (int q = 0; q < NDMA; q++) dma1(1, q); }
+    if (DMA == 1 || DMA == 2) { dma(0); dma(1); }
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #define STEP(cu, nx, st)                                                                                       \
     _Pragma("unroll") for (int g = 0; g < 4; g++) {                                                            \
@@ -42,7 +66,10 @@ __global__ __launch_bounds__(64 * WAVES) void probe(float* out, int iters, unsig
             const float av = e == 0 ? fa[cu][g].x : e == 1 ? fa[cu][g].y : e == 2 ? fa[cu][g].z : fa[cu][g].w; \
             const float bv = e == 0 ? fb[cu][g].x : e == 1 ? fb[cu][g].y : e == 2 ? fb[cu][g].z : fb[cu][g].w; \
             acc[NACC == 2 ? (e & 1) : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[NACC == 2 ? (e & 1) : 0], 0, 0, 0); \
-            if (e == 0 && g == 0 && DMA) { __builtin_amdgcn_sched_barrier(0); dma(it + 2 + ((st) == 0)); }       \
+            if (e == 0 && g == 0 && (DMA == 1 || DMA == 2)) { __builtin_amdgcn_sched_barrier(0); dma(it + 2 + ((st) == 0)); } \
+            if (e == 0 && g == 0 && (DMA == 5 || DMA >= 7)) { __builtin_amdgcn_sched_barrier(0); _Pragma("unroll") for (int q = 0; q < NDMA; q++) dma1(it + 2 + ((st) == 0), q); __builtin_amdgcn_sched_barrier(0); } \
+            if (DMA == 6 && g * 4 + e < NDMA) { __builtin_amdgcn_sched_barrier(0); dma1(it + 2 + ((st) == 0), g * 4 + e); __builtin_amdgcn_sched_barrier(0); } \
+            if (e == 0 && g == 0 && (DMA == 3 || DMA == 4)) { __builtin_amdgcn_sched_barrier(0); staged(it + 2 + ((st) == 0)); __builtin_amdgcn_sched_barrier(0); } \
             if (e == 0 && LDSREAD) {                                                                           \
                 __builtin_amdgcn_sched_barrier(0);                                                             \
                 fa[nx][g] = *(const float4*)(base + (st) + 8 * g);                                             \
@@ -52,10 +79,10 @@ __global__ __launch_bounds__(64 * WAVES) void probe(float* out, int iters, unsig
         }                                                                                                      \
     }
     for (int it = 0; it < iters; it += 2) {
-        if (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        if (DMA == 1 || DMA == 2 || (DMA >= 5 && DMA != 7)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
         if (BARRIER) __builtin_amdgcn_s_barrier();
         STEP(0, 1, 6144)
-        if (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        if (DMA == 1 || DMA == 2 || (DMA >= 5 && DMA != 7)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
         if (BARRIER) __builtin_amdgcn_s_barrier();
         STEP(1, 0, 0)
     }
@@ -63,6 +90,7 @@ __global__ __launch_bounds__(64 * WAVES) void probe(float* out, int iters, unsig
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0;
     for (int r = 0; r < 16; r++) s += acc[0][r] + acc[1][r];
+    _Pragma("unroll") for (int q = 0; q < NDMA; q++) s += stage[q].x;
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (lane == 0) cyc[blockIdx.x * WAVES + wave] = t1 - t0;
 }
@@ -100,7 +128,45 @@ void run(const char* name) {
     hipFree(out); hipFree(cyc);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) {  // round 2: what does the operand fetch cost, by mechanism
+        if (argv[1][0] == 'i') {  // is it the issue of the instruction, the wait, or the bytes?
+            run<4, true, true, 2, false, 5, 6>("4 waves + 6 LDS-DMA b128, counted wait");
+            run<4, true, true, 2, false, 7, 6>("4 waves + 6 LDS-DMA b128, NO wait in the loop");
+            run<4, true, true, 2, false, 8, 6>("4 waves + 6 LDS-DMA b32 (a quarter of the bytes), counted wait");
+            run<4, true, true, 2, false, 9, 6>("4 waves + 6 LDS-DMA b128, SGPR base + 32-bit VGPR offset");
+            run<4, false, true, 2, false, 5, 6>("4 waves + 6 LDS-DMA b128, counted wait, NO barrier");
+            run<8, true, true, 2, false, 7, 3>("8 waves + 3 LDS-DMA b128, NO wait in the loop");
+            run<8, true, true, 2, false, 8, 3>("8 waves + 3 LDS-DMA b32, counted wait");
+            run<8, true, true, 2, false, 9, 3>("8 waves + 3 LDS-DMA b128, SGPR base + 32-bit VGPR offset");
+            return 0;
+        }
+        if (argv[1][0] == 'm') {  // M0 handling and placement of the LDS-DMA issue
+            run<4, true, true, 2, false, 1, 2>("4 waves + 2 LDS-DMA/wave/iter from L2, m0 saved/restored");
+            run<4, true, true, 2, false, 5, 2>("4 waves + 2 LDS-DMA/wave/iter from L2, m0 clobbered");
+            run<4, true, true, 2, false, 6, 2>("4 waves + 2 LDS-DMA/wave/iter from L2, m0 clobbered, one per MFMA slot");
+            run<4, true, true, 2, false, 1, 6>("4 waves + 6 LDS-DMA/wave/iter from L2, m0 saved/restored");
+            run<4, true, true, 2, false, 5, 6>("4 waves + 6 LDS-DMA/wave/iter from L2, m0 clobbered");
+            run<4, true, true, 2, false, 6, 6>("4 waves + 6 LDS-DMA/wave/iter from L2, m0 clobbered, one per MFMA slot");
+            run<8, true, true, 2, false, 1, 3>("8 waves + 3 LDS-DMA/wave/iter from L2, m0 saved/restored");
+            run<8, true, true, 2, false, 5, 3>("8 waves + 3 LDS-DMA/wave/iter from L2, m0 clobbered");
+            run<8, true, true, 2, false, 6, 3>("8 waves + 3 LDS-DMA/wave/iter from L2, m0 clobbered, one per MFMA slot");
+            return 0;
+        }
+        run<8, true, true, 2>("8 waves, barrier, lds reads, 2 acc (no fetch)");
+        run<8, true, true, 2, false, 1, 3>("8 waves + 3 LDS-DMA/wave/iter from L2");
+        run<8, true, false, 2, false, 1, 3>("8 waves + 3 LDS-DMA/wave/iter from L2, NO lds reads");
+        run<8, true, true, 2, false, 3, 3>("8 waves + 3 register-staged loads/wave/iter from L2");
+        run<8, true, true, 2, false, 4, 3>("8 waves + 3 register-staged loads/wave/iter streaming");
+        run<8, true, true, 2, false, 2, 3>("8 waves + 3 LDS-DMA/wave/iter streaming");
+        run<4, true, true, 2>("4 waves, barrier, lds reads, 2 acc (no fetch)");
+        run<4, true, true, 2, false, 1, 6>("4 waves + 6 LDS-DMA/wave/iter from L2");
+        run<4, true, true, 2, false, 3, 6>("4 waves + 6 register-staged loads/wave/iter from L2");
+        run<4, true, true, 2, false, 1, 3>("4 waves + 3 LDS-DMA/wave/iter from L2 (12 KB per 1024 cycles)");
+        run<4, true, true, 2, false, 3, 3>("4 waves + 3 register-staged loads/wave/iter from L2");
+        run<4, true, true, 2, false, 1, 2>("4 waves + 2 LDS-DMA/wave/iter from L2 (8 KB per 1024 cycles)");
+        return 0;
+    }
     run<4, false, false, 1>("4 waves, no barrier, no lds, 1 acc");
     run<4, false, true, 1>("4 waves, no barrier, lds reads, 1 acc");
     run<4, false, true, 2>("4 waves, no barrier, lds reads, 2 acc");
