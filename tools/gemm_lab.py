@@ -101,6 +101,8 @@ PIPE = [tuple(int(v) for v in t[1:]) for t in sorted((tuple(int(x) for x in t) f
 
 
 def name(c):
+    if c >= 2100:
+        return "q%dx%d.%dx%d.%d" % PIPE[c - 2100]
     if c >= 2000:
         return "p%dx%d.%dx%d.%d" % PIPE[c - 2000]
     if c >= 1000:
