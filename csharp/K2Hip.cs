@@ -39,6 +39,10 @@ namespace K2TransducerAsr.Hip
         [DllImport(Lib)] internal static extern int k2hip_online_stream_accept_features(IntPtr stream, float[] feats, long nFrames);
         [DllImport(Lib)] internal static extern int k2hip_online_stream_is_finished(IntPtr stream, int isEndpoint, out int finished);
         [DllImport(Lib)] internal static extern int k2hip_online_step(IntPtr model, IntPtr[] streams, int B, int[] decoded, int[] nNewTokens);
+        [DllImport(Lib)] internal static extern int k2hip_online_state_create(IntPtr model, out IntPtr state);
+        [DllImport(Lib)] internal static extern int k2hip_online_state_destroy(IntPtr state);
+        [DllImport(Lib)] internal static extern long k2hip_online_state_processed_len(IntPtr state);
+        [DllImport(Lib)] internal static extern int k2hip_online_encoder(IntPtr model, IntPtr[] states, int B, float[] feats, float[] encoderOut, long capFloats);
         [DllImport(Lib)] internal static extern int k2hip_online_stream_num_tokens(IntPtr stream);
         [DllImport(Lib)] internal static extern int k2hip_online_stream_num_timestamps(IntPtr stream);
         [DllImport(Lib)] internal static extern int k2hip_online_stream_get_tokens(IntPtr stream, long[] tokens, int cap);

@@ -312,6 +312,21 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
                           int32_t* n_new_tokens);
 /* the stream's processed_lens state as the reference holds it between steps (Zipformer2: frames consumed; Conformer: 2 at
  * creation, then the batch size of its last step -- OnlineProjOfConformer.cs:77,229) */
+/* ---- operator level of the streaming path: IOnlineProj (IOnlineProj.cs:65-71) ----------------------------------------
+ * For a host that keeps the reference's OnlineRecognizer loop unchanged and swaps only the operator (csharp/OnlineProjOfHip.cs).
+ * A k2hip_online_state_t is ONE stream's encoder caches: a slot of the device state pool plus processed_lens.  It replaces the
+ * List<List<float[]>> of GetEncoderInitStates (OnlineProjOfZipformer2.cs:144-238); stack_states / unstack_states (:240-489)
+ * are the identity on handles because EncoderProj advances the caches in place.  Streaming Zipformer2 transducer models only. */
+typedef struct k2hip_online_state k2hip_online_state_t;
+int32_t k2hip_online_state_create(k2hip_model_t* model, k2hip_online_state_t** out);
+int32_t k2hip_online_state_destroy(k2hip_online_state_t* state);
+int64_t k2hip_online_state_processed_len(const k2hip_online_state_t* state);
+/* EncoderProj (OnlineProjOfZipformer2.cs:491-618): feats [B, ChunkLength, FeatureDim] raw fbank frames (OnlineInputEntity.Speech of
+ * each stream's GetDecodeChunk), encoder_out [B, T', joiner_dim] (T' = k2hip_online_chunk_info's frames_per_chunk).  Decoder and
+ * joiner are k2hip_decoder / k2hip_joiner.  K2HIP_ERR_CAPACITY if cap_floats is too small; nothing advances on failure. */
+int32_t k2hip_online_encoder(k2hip_model_t* model, k2hip_online_state_t* const* states, int32_t B, const float* feats, float* encoder_out,
+                             int64_t cap_floats);
+
 int64_t k2hip_online_stream_processed_len(const k2hip_online_stream_t* s);
 int32_t k2hip_online_stream_num_tokens(const k2hip_online_stream_t* s);
 int32_t k2hip_online_stream_num_timestamps(const k2hip_online_stream_t* s);

@@ -15,6 +15,7 @@ from .binding import (  # noqa: F401
     Model,
     OfflineRecognizer,
     OfflineStream,
+    OnlineProj,
     OnlineRecognizer,
     OnlineStream,
     TokenTable,
@@ -29,6 +30,7 @@ __all__ = [
     "Model",
     "OfflineRecognizer",
     "OfflineStream",
+    "OnlineProj",
     "OnlineRecognizer",
     "OnlineStream",
     "TokenTable",

@@ -568,6 +568,11 @@ def _bind_online(L):
     L.k2hip_online_stream_speech_length.argtypes = [vp]
     L.k2hip_online_stream_is_finished.argtypes = [vp, C.c_int32, ip]
     L.k2hip_online_step.argtypes = [vp, C.POINTER(vp), C.c_int32, ip, ip]
+    L.k2hip_online_state_create.argtypes = [vp, C.POINTER(vp)]
+    L.k2hip_online_state_destroy.argtypes = [vp]
+    L.k2hip_online_state_processed_len.restype = C.c_int64
+    L.k2hip_online_state_processed_len.argtypes = [vp]
+    L.k2hip_online_encoder.argtypes = [vp, C.POINTER(vp), C.c_int32, fp, fp, C.c_int64]
     L.k2hip_online_stream_num_tokens.argtypes = [vp]
     L.k2hip_online_stream_num_timestamps.argtypes = [vp]
     L.k2hip_online_stream_get_tokens.argtypes = [vp, lp, C.c_int32]
@@ -648,6 +653,43 @@ class OnlineStream:
         out = np.empty(n.value, np.float32)
         self._m._chk(self._L.k2hip_online_stream_state(self._h, layer, _STATE_KINDS[kind], _f(out), n.value, C.byref(n)))
         return out
+
+
+class OnlineProj:
+    """IOnlineProj (IOnlineProj.cs:65-71) on the HIP backend: the operator a host swaps in when it keeps the reference's own
+    OnlineRecognizer loop.  States are handles (a slot of the device pool each); stack_states / unstack_states are the identity."""
+
+    def __init__(self, weights_path: str, device: int = 0):
+        self.model = Model(weights_path, device)
+        _bind_online(self.model._L)
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self.model._chk(self.model._L.k2hip_online_chunk_info(self.model.handle, C.byref(a), C.byref(b), C.byref(c)))
+        self.chunk_length, self.shift_length, self.frames_per_chunk = a.value, b.value, c.value
+
+    def get_encoder_init_states(self):  # GetEncoderInitStates, one stream
+        h = C.c_void_p()
+        self.model._chk(self.model._L.k2hip_online_state_create(self.model.handle, C.byref(h)))
+        return h
+
+    def free_states(self, state):
+        self.model._chk(self.model._L.k2hip_online_state_destroy(state))
+
+    def processed_len(self, state) -> int:
+        return int(self.model._L.k2hip_online_state_processed_len(state))
+
+    def encoder_proj(self, feats, states) -> np.ndarray:  # EncoderProj: the states advance in place
+        B = len(states)
+        x = _f32(feats).reshape(B, self.chunk_length, -1)
+        out = np.empty((B, self.frames_per_chunk, self.model.joiner_dim), np.float32)
+        arr = (C.c_void_p * B)(*[s.value for s in states])
+        self.model._chk(self.model._L.k2hip_online_encoder(self.model.handle, arr, B, _f(x), _f(out), out.size))
+        return out
+
+    def decoder_proj(self, y) -> np.ndarray:
+        return self.model.decoder_proj(y)
+
+    def joiner_proj(self, enc, dec) -> np.ndarray:
+        return self.model.joiner_proj(enc, dec)
 
 
 class OnlineRecognizer:

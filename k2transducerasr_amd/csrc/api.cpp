@@ -45,6 +45,15 @@ struct k2hip_online_stream {
     long long chunks_done = 0;     // chunks decoded so far: position of the stream's attention rings in its device slot
 };
 
+// one stream's encoder caches as the operator-level API sees them (IOnlineProj's List<List<float[]>>): a slot of the device pool
+// plus the two scalars of the state that live on the host (processed_lens, ring position)
+struct k2hip_online_state {
+    k2hip_model* model;
+    int slot = -1;
+    long long processed_len = 0;
+    long long chunks_done = 0;
+};
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -678,6 +687,75 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
         }
     });
 }
+// ---- operator level of the streaming path (IOnlineProj.cs:65-71) --------------------------------------------------------------
+// GetEncoderInitStates for ONE stream (OnlineProjOfZipformer2.cs:144-238): a zeroed slot
+int32_t k2hip_online_state_create(k2hip_model_t* model, k2hip_online_state_t** out) {
+    return guard([&] {
+        NEED(model); NEED(out);
+        const Config& c = model->engine.model().cfg();
+        K2_REQUIRE(c.streaming && !c.lstm && !c.conformer && !c.zip1 && !c.ctc, "online states: streaming Zipformer2 transducer models only");
+        auto* st = new k2hip_online_state();
+        st->model = model;
+        try {
+            std::lock_guard<std::mutex> lk(model->engine.mutex());
+            st->slot = model->engine.online_alloc_slot();
+        } catch (...) {
+            delete st;
+            throw;
+        }
+        *out = st;
+    });
+}
+int32_t k2hip_online_state_destroy(k2hip_online_state_t* st) {
+    return guard([&] {
+        if (!st) return;
+        {
+            std::lock_guard<std::mutex> lk(st->model->engine.mutex());
+            st->model->engine.online_free_slot(st->slot);
+        }
+        delete st;
+    });
+}
+int64_t k2hip_online_state_processed_len(const k2hip_online_state_t* st) { return st ? (int64_t)st->processed_len : -1; }
+// EncoderProj (OnlineProjOfZipformer2.cs:491-618) over B states: feats [B, ChunkLength, FeatureDim] (raw fbank: the log floor of the
+// online PadSequence is applied inside), encoder_out [B, T', joiner_dim]; the states advance in place, so stack_states /
+// unstack_states (:240-489) are the identity on the handles
+int32_t k2hip_online_encoder(k2hip_model_t* model, k2hip_online_state_t* const* states, int32_t B, const float* feats, float* encoder_out,
+                             int64_t cap_floats) {
+    return guard([&] {
+        NEED(model); NEED(states); NEED(feats); NEED(encoder_out);
+        K2_REQUIRE(B > 0, "EncoderProj: empty batch");
+        Engine& e = model->engine;
+        const Config& c = e.model().cfg();
+        const int Tp = e.online_frames_per_chunk();
+        if (cap_floats < (int64_t)B * Tp * c.enc_dim()) failf(K2HIP_ERR_CAPACITY, "encoder_out needs %lld floats", (long long)B * Tp * c.enc_dim());
+        std::vector<int> slots(B), nch(B);
+        std::vector<long long> plens(B);
+        {
+            std::vector<const k2hip_online_state*> seen(states, states + B);
+            for (int b = 0; b < B; b++) {
+                NEED(states[b]);
+                K2_REQUIRE(states[b]->model == model, "state %d belongs to another model", b);
+            }
+            std::sort(seen.begin(), seen.end());
+            K2_REQUIRE(std::adjacent_find(seen.begin(), seen.end()) == seen.end(), "EncoderProj: the same state appears twice in the batch");
+        }
+        for (int b = 0; b < B; b++) {
+            slots[b] = states[b]->slot;
+            plens[b] = states[b]->processed_len;
+            nch[b] = (int)(states[b]->chunks_done % (1LL << 30));
+        }
+        {
+            std::lock_guard<std::mutex> lk(e.mutex());
+            e.online_encoder(slots.data(), feats, plens.data(), nch.data(), B, encoder_out);
+        }
+        for (int b = 0; b < B; b++) {  // only after success, as in k2hip_online_step
+            states[b]->chunks_done++;
+            states[b]->processed_len += (c.chunk_T - 7) / 2 - 3;
+        }
+    });
+}
+
 int64_t k2hip_online_stream_processed_len(const k2hip_online_stream_t* s) { return s ? (int64_t)s->processed_len : -1; }
 int32_t k2hip_online_stream_num_tokens(const k2hip_online_stream_t* s) { return s ? (int32_t)s->tokens.size() : -1; }
 int32_t k2hip_online_stream_num_timestamps(const k2hip_online_stream_t* s) { return s ? (int32_t)s->timestamps.size() : -1; }

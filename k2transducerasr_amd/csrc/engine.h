@@ -105,6 +105,8 @@ class Engine {
     // one tick over B streams that each have a full chunk: chunks [B][T*feat] (host), hyps [B][2], plens [B]
     // nchunks [B]: chunks each stream has decoded before this step (position of its attention rings)
     // chunks: [B] pointers to each stream's T*feat chunk floats (gathered into pinned staging by the engine)
+    // operator level (IOnlineProj.EncoderProj): one chunk of the streaming Zipformer2 encoder for B state slots, encoder_out to host
+    void online_encoder(const int* slots, const float* feats, const long long* plens, const int* nchunks, int B, float* enc_out);
     void online_step(const int* slots, const float* const* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
                      int64_t* tokens, int32_t* ts, int32_t* n_tokens);
 

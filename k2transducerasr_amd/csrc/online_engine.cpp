@@ -518,6 +518,39 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
     timing_.total_ms = el(0, 5);
 }
 
+// IOnlineProj.EncoderProj (OnlineProjOfZipformer2.cs:491-618) as an operator: feats [B, chunk_T, feat] host, the B slots' caches
+// advance in place, encoder_out [B, T', joiner_dim] to host.  The search is the caller's (DecoderProj / JoinerProj).
+void Engine::online_encoder(const int* slots, const float* feats, const long long* plens, const int* nchunks, int B, float* enc_out) {
+    online_ensure_pool();
+    K2_REQUIRE(B > 0, "online_encoder: empty batch");
+    const Config& cf = model_->cfg();
+    K2_REQUIRE(cf.streaming && !cf.lstm && !cf.conformer && !cf.zip1 && !cf.ctc, "online_encoder: streaming Zipformer2 transducer models only");
+    const int T = cf.chunk_T, Tp = online_frames_per_chunk();
+    K2_HIP(hipSetDevice(device_));
+    const size_t in_bytes = sizeof(float) * (size_t)B * T * cf.feat;
+    float* stage = static_cast<float*>(pinned_in((int64_t)in_bytes));
+    memcpy(stage, feats, in_bytes);
+    float* d_enc = nullptr;
+    run_sized([&](const Ctx& c) {
+        Arena& ar = *c.arena;
+        float* d_x = ar.take<float>((int64_t)B * T * cf.feat);
+        int* d_slots = ar.take<int>(B);
+        long long* d_plen = ar.take<long long>(B);
+        int* d_chunks = ar.take<int>(B);
+        if (!c.dry) {
+            K2_HIP(hipMemcpyAsync(d_x, stage, in_bytes, hipMemcpyHostToDevice, c.stream));
+            K2_HIP(hipMemcpyAsync(d_slots, slots, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
+            K2_HIP(hipMemcpyAsync(d_chunks, nchunks, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
+            K2_HIP(hipMemcpyAsync(d_plen, plens, sizeof(long long) * B, hipMemcpyHostToDevice, c.stream));
+        }
+        logfloor_inplace(c, d_x, (long long)B * T * cf.feat);
+        d_enc = online_encoder_zip2(c, d_x, d_slots, d_plen, d_chunks, B);
+    });
+    K2_HIP(hipMemcpyAsync(enc_out, d_enc, sizeof(float) * (size_t)B * Tp * cf.enc_dim(), hipMemcpyDeviceToHost, stream_));
+    K2_HIP(hipStreamSynchronize(stream_));
+    K2_REQUIRE(!gemm_sk_take_error(), "stream-K exchange timed out");
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // split chunk step
 // ---------------------------------------------------------------------------------------------------------------

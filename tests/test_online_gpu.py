@@ -366,3 +366,57 @@ def test_streaming_search_forms_agree(stream_model_path, ora):
     finally:
         set_switch("K2HIP_SEARCH_ROUNDS", -1)
     assert calls >= 3 and sum(len(s.tokens) - 2 for s in so) > 0
+
+
+def test_operator_level_online_proj_runs_the_reference_loop(stream_model_path, ora):
+    """IOnlineProj as an operator (IOnlineProj.cs:65-71; csharp/OnlineProjOfHip.cs): the host keeps the reference's own
+    ForwardBatchGreedySearch loop (OnlineRecognizer.cs:85-219, transcribed below: EncoderProj over the ready streams, DecoderProj on
+    their Hyps, T' JoinerProj steps with the host-side argmax and skip set {0, 2, 1}) and only the three operators run on the GPU.
+    Tokens, timestamps and Hyp must be the oracle's after every call; the states are handles and advance in place."""
+    from k2transducerasr_amd import OnlineProj
+    from k2transducerasr_amd.synth import synth_utterance
+    proj = OnlineProj(stream_model_path)
+    N = 4
+    feats = [ora.fbank(synth_utterance(900 + u, 1.0 + 0.35 * (u % 3))) for u in range(N)]
+    so = [ora.create_stream() for _ in range(N)]
+    T, S, Tp = proj.chunk_length, proj.shift_length, proj.frames_per_chunk
+    states = [proj.get_encoder_init_states() for _ in range(N)]
+    hyp = [[0, 0] for _ in range(N)]
+    tokens = [[0, 0] for _ in range(N)]
+    stamps = [[] for _ in range(N)]
+    pos = [0] * N
+    calls = 0
+    try:
+        while True:
+            ready = [u for u in range(N) if pos[u] + T <= feats[u].shape[0]]
+            if not ready:
+                break
+            x = np.stack([feats[u][pos[u] : pos[u] + T] for u in ready])
+            enc = proj.encoder_proj(x, [states[u] for u in ready])                      # :121-131
+            dec = proj.decoder_proj(np.array([hyp[u] for u in ready], np.int64))        # :135-147
+            for t in range(Tp):                                                         # :149-202
+                logits = proj.joiner_proj(enc[:, t], dec)
+                emitted = False
+                for r, u in enumerate(ready):
+                    row = logits[r]
+                    y = int(len(row) - 1 - np.argmax(row[::-1]))                        # later index wins ties (`>=` scan)
+                    if y not in (0, 2, 1):
+                        tokens[u].append(y)
+                        stamps[u].append(t)
+                        emitted = True
+                if emitted:
+                    dec = proj.decoder_proj(np.array([tokens[u][-2:] for u in ready], np.int64))
+            for u in ready:
+                hyp[u] = tokens[u][-2:]                                                # :208
+                pos[u] += S
+            ora.step([so[u] for u in ready], [feats[u][pos[u] - S : pos[u] - S + T] for u in ready])
+            for u in range(N):
+                assert tokens[u] == so[u].tokens and stamps[u] == so[u].timestamps and hyp[u] == list(so[u].hyp), (calls, u)
+            calls += 1
+        assert calls >= 3 and sum(len(t) - 2 for t in tokens) > 0
+        assert proj.processed_len(states[0]) == so[0].processed_len
+        with pytest.raises(Exception):
+            proj.encoder_proj(np.zeros((2, T, 80), np.float32), [states[0], states[0]])   # one state twice in a batch
+    finally:
+        for st in states:
+            proj.free_states(st)
