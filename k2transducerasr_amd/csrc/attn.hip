@@ -343,41 +343,66 @@ __global__ __launch_bounds__(256) void k_attn_av_out(const float* __restrict__ a
         for (int c = 0; c < MAXC; c++)
             dst[c] = (c < nch && 16 * c + 4 * kq < HV) ? *reinterpret_cast<const float4*>(wr + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    if (ct0 + wave < ct1) load_w(wc, ct0 + wave);
-    for (int ct = ct0 + wave; ct < ct1; ct += 4) {
-        if (ct + 4 < ct1) load_w(wn, ct + 4);
+    // Two register sets, no copies: a tile's weights, residual and bias are loaded one tile ahead, i.e. IN FRONT of the previous
+    // tile's stores (vmcnt retires in issue order: a load issued behind those stores would make its wait drain them too, and the
+    // tiles of a wave would run a store round trip apart).
+    float xa[4], xb[4], ba = 0.f, bb = 0.f;
+    auto load_x = [&](float* dst, float& bdst, int ct) {
         const int col = ct * 16 + n;
-        const float bv = bias[col];
-        float xr[4];  // residual, fetched under the MFMAs
+        bdst = bias[col];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int i = i0 + 4 * kq + e;
-            xr[e] = i < T ? x[((long long)b * T + i) * D + col] : 0.f;
+            dst[e] = i < T ? x[((long long)b * T + i) * D + col] : 0.f;
         }
+    };
+    auto tile = [&](const float4* w, const float* xr, float bv, int ct) {
+        const int col = ct * 16 + n;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < MAXC; c++) {
             if (c < nch) {
                 if (c & 1) {
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].x, wc[c].x, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].y, wc[c].y, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].z, wc[c].z, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].w, wc[c].w, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].x, w[c].x, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].y, w[c].y, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].z, w[c].z, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].w, w[c].w, acc1, 0, 0, 0);
                 } else {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].x, wc[c].x, acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].y, wc[c].y, acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].z, wc[c].z, acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].w, wc[c].w, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].x, w[c].x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].y, w[c].y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].z, w[c].z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[c].w, w[c].w, acc0, 0, 0, 0);
                 }
             }
         }
+        float o[4];  // all four values first, then four stores with nothing loaded in between (else: a vmcnt(0) per store)
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int i = i0 + 4 * kq + e;
-            if (i < T) x[((long long)b * T + i) * D + col] = acc0[e] + acc1[e] + bv + xr[e];
+        for (int e = 0; e < 4; e++) o[e] = acc0[e] + acc1[e] + bv + xr[e];
+        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));  // (keeps the sums out of the conditional store blocks)
+        float* xp = x + ((long long)b * T + i0 + 4 * kq) * D + col;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (i0 + 4 * kq + e < T) xp[(long long)e * D] = o[e];
+    };
+    int ct = ct0 + wave;
+    if (ct < ct1) {
+        load_w(wc, ct);
+        load_x(xa, ba, ct);
+    }
+    while (ct < ct1) {
+        if (ct + 4 < ct1) {
+            load_w(wn, ct + 4);
+            load_x(xb, bb, ct + 4);
         }
-#pragma unroll
-        for (int c = 0; c < MAXC; c++) wc[c] = wn[c];
+        tile(wc, xa, ba, ct);
+        ct += 4;
+        if (ct >= ct1) break;
+        if (ct + 4 < ct1) {
+            load_w(wc, ct + 4);
+            load_x(xa, ba, ct + 4);
+        }
+        tile(wn, xb, bb, ct);
+        ct += 4;
     }
 }
 
