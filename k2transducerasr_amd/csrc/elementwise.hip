@@ -293,7 +293,7 @@ __global__ void k_mul_cols(float* __restrict__ a, const float* __restrict__ x, i
 //  quad, so every LDS read of a wave is one conflict-free 1 KB row segment.
 constexpr int DW_TT = 8;                 // outputs per thread
 constexpr int DW_ROWS = 4 * DW_TT;       // output frames per workgroup
-template <bool DSWISH>
+template <bool DSWISH, bool GLU = true>
 __global__ __launch_bounds__(256) void k_glu_dwconv1d(const float* __restrict__ x2, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y, int B, int T,
                                                       int D, int K) {
@@ -312,9 +312,9 @@ __global__ __launch_bounds__(256) void k_glu_dwconv1d(const float* __restrict__ 
             const int r = r0 + 4 * i, u = t0 - half + r;
             ok[i] = cok && r < nrows && u >= 0 && u < T;
             if (ok[i]) {
-                const float* row = x2 + ((long long)b * T + u) * 2 * D;
+                const float* row = x2 + ((long long)b * T + u) * (GLU ? 2 * D : D);  // !GLU: the gate has been applied upstream
                 a[i] = *reinterpret_cast<const float4*>(row + c);
-                sg[i] = *reinterpret_cast<const float4*>(row + D + c);
+                if (GLU) sg[i] = *reinterpret_cast<const float4*>(row + D + c);
             }
         }
 #pragma unroll
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_glu_dwconv1d(const float* __restrict__ 
             const int r = r0 + 4 * i;
             if (r < nrows) {
                 float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok[i]) g = make_float4(a[i].x * sigm(sg[i].x), a[i].y * sigm(sg[i].y), a[i].z * sigm(sg[i].z), a[i].w * sigm(sg[i].w));
+                if (ok[i]) g = GLU ? make_float4(a[i].x * sigm(sg[i].x), a[i].y * sigm(sg[i].y), a[i].z * sigm(sg[i].z), a[i].w * sigm(sg[i].w)) : a[i];
                 *reinterpret_cast<float4*>(sx + r * 256 + lane * 4) = g;
             }
         }
@@ -500,6 +500,17 @@ static void glu_dwconv1d_any(const Ctx& ctx, const float* x2, const float* w_kd,
     static LdsAttrOnce lds_attr;
     lds_attr.ensure(k_glu_dwconv1d<DSWISH>, 128 * 1024);
     hipLaunchKernelGGL(k_glu_dwconv1d<DSWISH>, grid, dim3(256), lds, ctx.stream, x2, w_kd, b, y, B, T, D, K);
+    K2_HIP(hipGetLastError());
+}
+void dwconv1d_swoosh(const Ctx& ctx, const float* x, const float* w_kd, const float* b, float* y, int B, int T, int D, int K) {
+    K2_REQUIRE(D % 4 == 0, "dwconv1d: D=%d", D);
+    size_t lds = sizeof(float) * (size_t)(DW_ROWS + K - 1) * 256;
+    dim3 grid(cdiv(D, 256), cdiv(T, DW_ROWS), B);
+    ctx.add_flops(0.0, 2.0 * B * T * (double)D * K, 0);
+    if (ctx.dry) return;
+    static LdsAttrOnce lds_attr;
+    lds_attr.ensure(k_glu_dwconv1d<false, false>, 128 * 1024);
+    hipLaunchKernelGGL((k_glu_dwconv1d<false, false>), grid, dim3(256), lds, ctx.stream, x, w_kd, b, y, B, T, D, K);
     K2_HIP(hipGetLastError());
 }
 void glu_dwconv1d_swoosh(const Ctx& ctx, const float* x2, const float* w_kd, const float* b, float* y, int B, int T, int D,

@@ -311,8 +311,18 @@ void Engine::encoder_layer(const Ctx& c, int si, int li, float* x, const float* 
         snprintf(d, sizeof d, "conv_module%d.depthwise_conv.bias", k);
         snprintf(e, sizeof e, "conv_module%d.out_proj.weight", k);
         snprintf(f, sizeof f, "conv_module%d.out_proj.bias", k);
-        linear(c, src, D, w(a), w(b), hid, 2 * D, M, D, 2 * D);
-        glu_dwconv1d_swoosh(c, hid, w(cc), w(d), tmp2, B, T, D, K);
+        if (M >= 256 && !tunables().no_glu_epilogue) {
+            // in_proj with the GLU in its epilogue (weights interleaved at load): hid is [M, D], not [M, 2D]
+            GemmArgs g;
+            std::string wa = std::string(a) + "#glu", wb = std::string(b) + "#glu";
+            g.A = src; g.lda = D; g.W = w(wa.c_str()); g.ldw = D; g.bias = w(wb.c_str()); g.C = hid; g.ldc = D;
+            g.M = M; g.N = 2 * D; g.K = D; g.glu = 1;
+            gemm(c, g);
+            dwconv1d_swoosh(c, hid, w(cc), w(d), tmp2, B, T, D, K);
+        } else {
+            linear(c, src, D, w(a), w(b), hid, 2 * D, M, D, 2 * D);
+            glu_dwconv1d_swoosh(c, hid, w(cc), w(d), tmp2, B, T, D, K);
+        }
         linear(c, tmp2, D, w(e), w(f), src, D, M, D, D, ACT_NONE, src, D);
     };
 

@@ -118,6 +118,20 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, float (&v)[NV],
     }
 #pragma unroll
     for (int n = 0; n < NV; n++) v[n] += bv;
+    if (g.glu) {  // columns 32 q .. 32 q + 15 are values, + 16 their gates: the partner is 16 lanes away (col = lane & 31 in these layouts)
+        float* cp = C + (long long)row0 * g.ldc + ((col >> 5) << 4) + (col & 15);
+        const bool is_value = (col & 16) == 0;
+#pragma unroll
+        for (int n = 0; n < NV; n++) {
+            const float other = __shfl_xor(v[n], 16, 64);
+            v[n] = v[n] * (1.0f / (1.0f + __expf(-other)));
+        }
+        if (!is_value || (g.ablate & 4)) return;
+#pragma unroll
+        for (int n = 0; n < NV; n++)
+            if (row0 + ROWS::off(n) < g.M) cp[(long long)ROWS::off(n) * g.ldc] = v[n];
+        return;
+    }
     if (g.act_after_res && has_res) {
 #pragma unroll
         for (int n = 0; n < NV; n++) v[n] += rv[n];
@@ -1950,6 +1964,8 @@ void debug_force_gemm_cfg(int cfg) {
 void gemm(const Ctx& ctx, const GemmArgs& a) {
     K2_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty shape %dx%dx%d", a.M, a.N, a.K);
     K2_REQUIRE(!a.wz_map || a.w_kn, "gemm: wz_map is for the [K,N] operand form");
+    K2_REQUIRE(!a.glu || (a.N % 32 == 0 && a.N > 96 && !a.res && !a.mul && !a.byp_orig && a.act == ACT_NONE && a.nb0 * a.nb1 == 1),
+               "gemm: the GLU epilogue needs N %% 32 == 0, N > 96 and no other epilogue term");
     K2_REQUIRE(a.cv_Fout > 0 || a.lda % 4 == 0, "gemm: lda %d must be a multiple of 4", a.lda);
     K2_REQUIRE(a.K >= 4 || (a.w_kn && a.K >= 1), "gemm: K=%d too small", a.K);  // [K,N] form: A rows are zero-padded to 4, W rows k >= K masked
     K2_REQUIRE(a.w_kn || a.K % 4 == 0, "gemm: K %d must be a multiple of 4", a.K);
@@ -2000,6 +2016,7 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     // (16-row workgroups re-read the weight chunk M/16 times: with many rows and a short K the 64x64 tiles are better)
     const bool few_tiles = (long long)cdiv(a.M, 128) * cdiv(a.N, 64) < 144 && a.M <= 4096 && !(a.M >= 2048 && a.K <= 256 && a.N > 272);
     const bool skinny_ok = !forced && !no_skinny && plain && !a.mul && ((a.N <= 96 && a.M >= 512) || few_tiles);
+    const bool skinny16_ok = skinny_ok && !a.glu;  // the 16-column C/D layout of gemm_f32_mfma_skinny has no lane pair 16 apart
     // Small problems with more than a handful of columns (the streaming chunk step: 256 .. 2048 rows): small ring tiles with the
     // K step split over four (two) wave groups of the workgroup put 4 - 8 waves on ~200 CUs and walk K in K / 128 (K / 64) steps
     // through coalesced LDS-DMA tiles, where the 16-row skinny kernel re-reads the weight chunk M / 16 times straight into
@@ -2019,7 +2036,7 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
             return;
         }
     }
-    if (skinny_ok) {
+    if (skinny16_ok) {
         if (a.N <= 48) hipLaunchKernelGGL(gemm_f32_mfma_skinny<3>, dim3(cdiv(a.M, 16), 1), dim3(256), 0, ctx.stream, b);
         else if (a.K % 128 == 0 && ((a.K >= 1024 && (long long)cdiv(a.M, 16) * cdiv(a.N, 96) <= 384) ||
                                     (a.K >= 512 && (long long)cdiv(a.M, 16) * cdiv(a.N, 96) <= 128)))
@@ -2064,7 +2081,7 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
                 best_cost = cost;
             }
         }
-        launch_pipe_idx(ctx, b, tn.gemm_mfma16 && pipe16_ok(b) ? best + 100 : best);
+        launch_pipe_idx(ctx, b, tn.gemm_mfma16 && pipe16_ok(b) && !b.glu ? best + 100 : best);
         K2_HIP(hipGetLastError());
         if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 128;
         if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));

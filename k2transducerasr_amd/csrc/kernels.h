@@ -12,6 +12,7 @@ struct Tunables {
     int gemm_no_dma = 0;          // K2HIP_GEMM_NO_DMA: register-staged kernels only
     int gemm_no_skinny = 0;       // K2HIP_GEMM_NO_SKINNY
     int gemm_nst3 = 0;            // K2HIP_GEMM_NST3: three-stage ring for the 128x64 LDS-DMA kernel
+    int no_glu_epilogue = 0;      // K2HIP_NO_GLU_EPILOGUE: conv modules' GLU in the depthwise kernel (round 1 form) instead of the in_proj GEMM's epilogue
     int gemm_mfma16 = 0;          // K2HIP_GEMM_MFMA16: the v_mfma_f32_16x16x4_f32 form of the pipelined kernel (less power per flop, more instructions)
     int gemm_v1 = 0;              // K2HIP_GEMM_V1: the earlier LDS-DMA kernels and tile rules (barrier at the top of every K step) instead of gemm_f32_mfma_pipe
     int attn_long = 0;            // K2HIP_ATTN_LONG: two-pass attention scores for every length
@@ -109,6 +110,9 @@ struct GemmArgs {
     //   act_after_res: v = act(acc + bias + res) instead of act(acc + bias) + res          -- the joiner's tanh(enc + dec)
     int res_div = 1;
     int act_after_res = 0;
+    // glu: the N output columns are blocks of 32 = 16 values | their 16 gates (weights interleaved at load, "#glu"); the epilogue
+    // writes value * sigmoid(gate) to N / 2 columns of C (ldc counts those).  32-column C/D layouts only (not the skinny kernel).
+    int glu = 0;
     const float* mul = nullptr;
     int ldm = 0;
     long long sM0 = 0, sM1 = 0;
@@ -183,6 +187,8 @@ void glu_sigmoid(const Ctx& ctx, const float* x, float* y, int M, int D);       
 void tanh_gate(const Ctx& ctx, const float* x, float* y, int M, int Hc);           // y = x[:, Hc:2Hc] * tanh(x[:, :Hc])
 void mul_cols(const Ctx& ctx, float* a, const float* x, int ldx, int col0, int M, int N);  // a[m,n] *= x[m, col0+n]
 // y = SwooshR(dwconv1d(glu(x2)) + b);  x2: [B,T,2D] value|gate
+// the same on an input whose GLU has already run (x: [B,T,D]): GemmArgs.glu
+void dwconv1d_swoosh(const Ctx& ctx, const float* x, const float* w_kd, const float* b, float* y, int B, int T, int D, int K);
 void glu_dwconv1d_swoosh(const Ctx& ctx, const float* x2, const float* w_kd, const float* b, float* y, int B, int T, int D,
                           int K);
 // same with DoubleSwish (Conformer ConvolutionModule)

@@ -402,6 +402,31 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
                     for (int kk = 0; kk < K; kk++) v[(size_t)kk * D + d] = t.host[(size_t)d * K + kk];
                 push(std::string(nm) + "#kd", std::move(v), {K, D});
             }
+    // conv_module in_proj [2D, D] (value rows | gate rows) -> rows interleaved in blocks of 16 channels: new row 32 q + p = value of
+    // channel 16 q + p, row 32 q + 16 + p = its gate, so that one 32-column block of the GEMM output holds 16 channels' values and
+    // gates and the GLU runs in the GEMM's epilogue (a lane pair 16 apart), halving what the conv kernel has to read back
+    for (int si = 0; si < (c.streaming ? 0 : c.ns); si++)
+        for (int li = 0; li < c.nlayer[si]; li++)
+            for (int k = 1; k <= 2; k++) {
+                char nm[192], nb[192];
+                snprintf(nm, sizeof nm, "encoder.encoders.%d.layers.%d.conv_module%d.in_proj.weight", si, li, k);
+                snprintf(nb, sizeof nb, "encoder.encoders.%d.layers.%d.conv_module%d.in_proj.bias", si, li, k);
+                const Tensor& tw = tensor(nm);
+                const Tensor& tb = tensor(nb);
+                const int D = c.dim[si];
+                K2_REQUIRE((int)tw.dims[0] == 2 * D && (int)tw.dims[1] == D && (int)tb.dims[0] == 2 * D && D % 16 == 0,
+                           "%s: expected [%d,%d] with D %% 16 == 0", nm, 2 * D, D);
+                std::vector<float> vw((size_t)2 * D * D), vb((size_t)2 * D);
+                for (int ch = 0; ch < D; ch++) {
+                    const int rv = 32 * (ch / 16) + ch % 16, rg = rv + 16;
+                    memcpy(&vw[(size_t)rv * D], &tw.host[(size_t)ch * D], sizeof(float) * D);
+                    memcpy(&vw[(size_t)rg * D], &tw.host[(size_t)(D + ch) * D], sizeof(float) * D);
+                    vb[rv] = tb.host[ch];
+                    vb[rg] = tb.host[D + ch];
+                }
+                push(std::string(nm) + "#glu", std::move(vw), {2 * D, D});
+                push(std::string(nb) + "#glu", std::move(vb), {2 * D});
+            }
     // [feed_forward1.in_proj ; self_attn_weights.in_proj] stacked: both read the layer input, so the engine runs them as ONE GEMM
     // (SwooshL on the first F1 columns only) -- one launch and one pass over x instead of two
     for (int si = 0; si < c.ns; si++)

@@ -24,6 +24,7 @@ const Entry kEntries[] = {
     {"K2HIP_GEMM_NST3", &Tunables::gemm_nst3, true},
     {"K2HIP_GEMM_V1", &Tunables::gemm_v1, true},
     {"K2HIP_GEMM_MFMA16", &Tunables::gemm_mfma16, true},
+    {"K2HIP_NO_GLU_EPILOGUE", &Tunables::no_glu_epilogue, true},
     {"K2HIP_ATTN_LONG", &Tunables::attn_long, true},
     {"K2HIP_NO_FUSED_AV", &Tunables::no_fused_av, true},
     {"K2HIP_CONFORMER_GEMM_SCORES", &Tunables::conformer_gemm_scores, true},
