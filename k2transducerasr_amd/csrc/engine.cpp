@@ -329,14 +329,25 @@ void Engine::encoder_layer(const Ctx& c, int si, int li, float* x, const float* 
     // src = x + ff1(x): the hidden activations are the first F1 columns of `cat`
     linear(c, cat, ldcat, w("feed_forward1.out_proj.weight"), w("feed_forward1.out_proj.bias"), src, D, M, F1, D, ACT_NONE, x, D);
     {   // src += NonlinAttention(src, aw[0])
-        linear(c, src, D, w("nonlin_attention.in_proj.weight"), w("nonlin_attention.in_proj.bias"), hid, 3 * Hc, M, D, 3 * Hc);
-        tanh_gate(c, hid, tmp, M, Hc);
         GemmArgs g;
         g.A = aw; g.lda = Tp; g.sA0 = (long long)T * Tp;
-        g.W = tmp; g.w_kn = 1; g.ldw = Hc; g.sW0 = (long long)T * Hc;
+        g.w_kn = 1;
         g.C = tmp2; g.ldc = Hc; g.sC0 = (long long)T * Hc;
         g.M = T; g.N = Hc; g.K = T; g.nb0 = B; g.nb1 = 1;
-        g.mul = hid + 2 * Hc; g.ldm = 3 * Hc; g.sM0 = (long long)T * 3 * Hc;  // x * y (the third chunk of in_proj) in the epilogue
+        if (M >= 256 && Hc % 16 == 0 && !tunables().no_glu_epilogue) {
+            // in_proj with x * tanh(s) in its epilogue (weights interleaved at load): hid = [M, 2 Hc] = (gated | y)
+            GemmArgs p;
+            p.A = src; p.lda = D; p.W = w("nonlin_attention.in_proj.weight#glu"); p.ldw = D; p.bias = w("nonlin_attention.in_proj.bias#glu");
+            p.C = hid; p.ldc = 2 * Hc; p.M = M; p.N = 3 * Hc; p.K = D; p.glu = 2; p.glu_cols = 2 * Hc;
+            gemm(c, p);
+            g.W = hid; g.ldw = 2 * Hc; g.sW0 = (long long)T * 2 * Hc;
+            g.mul = hid + Hc; g.ldm = 2 * Hc; g.sM0 = (long long)T * 2 * Hc;  // x * y (the third chunk of in_proj) in the epilogue
+        } else {
+            linear(c, src, D, w("nonlin_attention.in_proj.weight"), w("nonlin_attention.in_proj.bias"), hid, 3 * Hc, M, D, 3 * Hc);
+            tanh_gate(c, hid, tmp, M, Hc);
+            g.W = tmp; g.ldw = Hc; g.sW0 = (long long)T * Hc;
+            g.mul = hid + 2 * Hc; g.ldm = 3 * Hc; g.sM0 = (long long)T * 3 * Hc;  // x * y (the third chunk of in_proj) in the epilogue
+        }
         gemm(c, g);
         linear(c, tmp2, Hc, w("nonlin_attention.out_proj.weight"), w("nonlin_attention.out_proj.bias"), src, D, M, Hc, D,
                ACT_NONE, src, D);

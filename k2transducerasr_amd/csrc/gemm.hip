@@ -118,15 +118,22 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, float (&v)[NV],
     }
 #pragma unroll
     for (int n = 0; n < NV; n++) v[n] += bv;
-    if (g.glu) {  // columns 32 q .. 32 q + 15 are values, + 16 their gates: the partner is 16 lanes away (col = lane & 31 in these layouts)
-        float* cp = C + (long long)row0 * g.ldc + ((col >> 5) << 4) + (col & 15);
+    if (g.glu) {
+        // The first glu_cols columns (all N when 0) come in blocks of 32 = 16 values | their 16 gates (weights interleaved at load):
+        // the partner is 16 lanes away (col = lane & 31 in these layouts); value * sigmoid(gate) (1) or value * tanh(gate) (2) goes
+        // to column 16 q + p of C.  Columns from glu_cols on pass through to C columns glu_cols / 2 + (col - glu_cols).
+        const int gc = g.glu_cols > 0 ? g.glu_cols : g.N;
+        const bool paired = col < gc;  // uniform over a 32-column block (gc % 32 == 0)
         const bool is_value = (col & 16) == 0;
+        const int ccol = paired ? ((col >> 5) << 4) + (col & 15) : (gc >> 1) + (col - gc);
+        float* cp = C + (long long)row0 * g.ldc + ccol;
 #pragma unroll
         for (int n = 0; n < NV; n++) {
             const float other = __shfl_xor(v[n], 16, 64);
-            v[n] = v[n] * (1.0f / (1.0f + __expf(-other)));
+            const float gate = g.glu == 2 ? apply_act(other, ACT_TANH) : 1.0f / (1.0f + __expf(-other));
+            v[n] = paired ? v[n] * gate : v[n];
         }
-        if (!is_value || (g.ablate & 4)) return;
+        if ((paired && !is_value) || (g.ablate & 4)) return;
 #pragma unroll
         for (int n = 0; n < NV; n++)
             if (row0 + ROWS::off(n) < g.M) cp[(long long)ROWS::off(n) * g.ldc] = v[n];
@@ -1964,8 +1971,9 @@ void debug_force_gemm_cfg(int cfg) {
 void gemm(const Ctx& ctx, const GemmArgs& a) {
     K2_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty shape %dx%dx%d", a.M, a.N, a.K);
     K2_REQUIRE(!a.wz_map || a.w_kn, "gemm: wz_map is for the [K,N] operand form");
-    K2_REQUIRE(!a.glu || (a.N % 32 == 0 && a.N > 96 && !a.res && !a.mul && !a.byp_orig && a.act == ACT_NONE && a.nb0 * a.nb1 == 1),
-               "gemm: the GLU epilogue needs N %% 32 == 0, N > 96 and no other epilogue term");
+    K2_REQUIRE(!a.glu || ((a.glu_cols > 0 ? a.glu_cols : a.N) % 32 == 0 && a.glu_cols <= a.N && a.N > 96 && !a.res && !a.mul && !a.byp_orig &&
+                          a.act == ACT_NONE && a.nb0 * a.nb1 == 1),
+               "gemm: the gated epilogue needs its paired columns in whole blocks of 32, N > 96 and no other epilogue term");
     K2_REQUIRE(a.cv_Fout > 0 || a.lda % 4 == 0, "gemm: lda %d must be a multiple of 4", a.lda);
     K2_REQUIRE(a.K >= 4 || (a.w_kn && a.K >= 1), "gemm: K=%d too small", a.K);  // [K,N] form: A rows are zero-padded to 4, W rows k >= K masked
     K2_REQUIRE(a.w_kn || a.K % 4 == 0, "gemm: K %d must be a multiple of 4", a.K);

@@ -112,7 +112,8 @@ struct GemmArgs {
     int act_after_res = 0;
     // glu: the N output columns are blocks of 32 = 16 values | their 16 gates (weights interleaved at load, "#glu"); the epilogue
     // writes value * sigmoid(gate) to N / 2 columns of C (ldc counts those).  32-column C/D layouts only (not the skinny kernel).
-    int glu = 0;
+    int glu = 0;       // 1: value * sigmoid(gate) (conv modules), 2: value * tanh(gate) (NonlinAttention)
+    int glu_cols = 0;  // > 0: only the first glu_cols GEMM columns are (value | gate) blocks; the rest pass through behind them
     const float* mul = nullptr;
     int ldm = 0;
     long long sM0 = 0, sM1 = 0;

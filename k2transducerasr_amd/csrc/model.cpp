@@ -402,6 +402,31 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
                     for (int kk = 0; kk < K; kk++) v[(size_t)kk * D + d] = t.host[(size_t)d * K + kk];
                 push(std::string(nm) + "#kd", std::move(v), {K, D});
             }
+    // nonlin_attention in_proj [3 Hc, D] (s | x | y): tmp = x * tanh(s) in the GEMM's epilogue -- rows 32 q + p = x of channel
+    // 16 q + p (the value), 32 q + 16 + p = its s (the gate), y rows unchanged behind them
+    for (int si = 0; si < (c.streaming ? 0 : c.ns); si++)
+        for (int li = 0; li < c.nlayer[si]; li++) {
+            char nm[192], nb[192];
+            snprintf(nm, sizeof nm, "encoder.encoders.%d.layers.%d.nonlin_attention.in_proj.weight", si, li);
+            snprintf(nb, sizeof nb, "encoder.encoders.%d.layers.%d.nonlin_attention.in_proj.bias", si, li);
+            const Tensor& tw = tensor(nm);
+            const Tensor& tb = tensor(nb);
+            const int D = c.dim[si], Hc = (int)tw.dims[0] / 3;
+            K2_REQUIRE((int)tw.dims[0] == 3 * Hc && (int)tw.dims[1] == D && (int)tb.dims[0] == 3 * Hc, "%s: expected [3 Hc, %d]", nm, D);
+            if (Hc % 16 != 0) continue;  // the engine then keeps the separate gate kernel
+            std::vector<float> vw((size_t)3 * Hc * D), vb((size_t)3 * Hc);
+            for (int ch = 0; ch < Hc; ch++) {
+                const int rv = 32 * (ch / 16) + ch % 16, rg = rv + 16;
+                memcpy(&vw[(size_t)rv * D], &tw.host[(size_t)(Hc + ch) * D], sizeof(float) * D);  // x
+                memcpy(&vw[(size_t)rg * D], &tw.host[(size_t)ch * D], sizeof(float) * D);         // s
+                vb[rv] = tb.host[Hc + ch];
+                vb[rg] = tb.host[ch];
+            }
+            memcpy(&vw[(size_t)2 * Hc * D], &tw.host[(size_t)2 * Hc * D], sizeof(float) * (size_t)Hc * D);
+            memcpy(&vb[(size_t)2 * Hc], &tb.host[(size_t)2 * Hc], sizeof(float) * Hc);
+            push(std::string(nm) + "#glu", std::move(vw), {3 * Hc, D});
+            push(std::string(nb) + "#glu", std::move(vb), {3 * Hc});
+        }
     // conv_module in_proj [2D, D] (value rows | gate rows) -> rows interleaved in blocks of 16 channels: new row 32 q + p = value of
     // channel 16 q + p, row 32 q + 16 + p = its gate, so that one 32-column block of the GEMM output holds 16 channels' values and
     // gates and the GLU runs in the GEMM's epilogue (a lane pair 16 apart), halving what the conv kernel has to read back
