@@ -686,13 +686,18 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
     }
     const int arow = wr * WM + li, brow = wc * WN + li;
     const int swa = (arow >> 1) & 7, swb = ((BM + brow) >> 1) & 7;
-    unsigned ra[NST][4], rb[NST][4];  // fragment read addresses: stage, k group
+    // fragment read pointers: stage, k group.  Plain LDS loads through them (NOT inline-asm ds_reads): the compiler then knows
+    // the destination registers are pending until ITS lgkmcnt wait.  With asm reads + a hand-placed wait it was free to copy a
+    // fragment register (a phi copy at a loop edge) before the data had arrived -- results changed on rare runs when a second
+    // process shared the GPU and LDS returns came late (tools/determinism_stress.py).
+    const float* ra[NST][4];
+    const float* rb[NST][4];
 #pragma unroll
     for (int st = 0; st < NST; st++)
 #pragma unroll
         for (int gk = 0; gk < 4; gk++) {
-            ra[st][gk] = lds_base + (st * STAGE + arow * BK + (((2 * gk + lh) ^ swa) << 2)) * 4;
-            rb[st][gk] = lds_base + (st * STAGE + (BM + brow) * BK + (((2 * gk + lh) ^ swb) << 2)) * 4;
+            ra[st][gk] = smem + st * STAGE + arow * BK + (((2 * gk + lh) ^ swa) << 2);
+            rb[st][gk] = smem + st * STAGE + (BM + brow) * BK + (((2 * gk + lh) ^ swb) << 2);
         }
 
     f32x16 acc[MT][NT];
@@ -713,23 +718,14 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
                      : "v"(voff[q_]), "s"(src_), "s"(mq[q_]), "n"((ST_) * STAGE * 4)                                       \
                      : "memory");                                                                                          \
     }
-// fragments of k group G_ of stage ST_ into register set SET_ (the 32-row blocks of the wave tile: 4096 bytes apart)
+// fragments of k group G_ of stage ST_ into register set SET_ (the 32-row blocks of the wave tile: 32 * BK floats apart -> the
+// instruction's immediate offset)
 #define K2_PIPE_READ(SET_, ST_, G_)                                                                                        \
     {                                                                                                                      \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[SET_][0]) : "v"(ra[ST_][G_]) : "memory");                             \
-        if (MT > 1) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fa[SET_][MT > 1 ? 1 : 0]) : "v"(ra[ST_][G_]) : "memory");  \
-        if (MT > 2) asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(fa[SET_][MT > 2 ? 2 : 0]) : "v"(ra[ST_][G_]) : "memory");  \
-        if (MT > 3) asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(fa[SET_][MT > 3 ? 3 : 0]) : "v"(ra[ST_][G_]) : "memory"); \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fb[SET_][0]) : "v"(rb[ST_][G_]) : "memory");                             \
-        if (NT > 1) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fb[SET_][NT > 1 ? 1 : 0]) : "v"(rb[ST_][G_]) : "memory");  \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) fa[SET_][i] = *reinterpret_cast<const f32x4*>(ra[ST_][G_] + i * 32 * BK); \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) fb[SET_][j] = *reinterpret_cast<const f32x4*>(rb[ST_][G_] + j * 32 * BK); \
     }
-// the reads into SET_ have returned (they were issued one k group ago); the empty asms tie the registers to the wait
-#define K2_PIPE_FRAGS_READY(SET_)                                                                                          \
-    {                                                                                                                      \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
-        _Pragma("unroll") for (int i = 0; i < MT; i++) asm volatile("" : "+v"(fa[SET_][i]));                               \
-        _Pragma("unroll") for (int j = 0; j < NT; j++) asm volatile("" : "+v"(fb[SET_][j]));                               \
-    }
+#define K2_PIPE_FRAGS_READY(SET_) {}
 // one K step.  ST_: its stage (literal).  HAS_NEXT_: step KT_+1 exists; DO_ISSUE_: step KT_+NST-1 exists (both `true` in the steady
 // state); WAIT_: the vmcnt wait in front of the barrier (instructions of newer steps that may stay in flight)
 #define K2_PIPE_STEP(ST_, KT_, HAS_NEXT_, DO_ISSUE_, WAIT_)                                                                \
@@ -924,13 +920,14 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
     }
     // fragment read addresses: (stage, 16-deep k group); the 16-row blocks of the wave tile are 2048 bytes apart and share the swizzle
     const int sw = (r16 >> 1) & 7;
-    unsigned ra[NST][2], rb[NST][2];
+    const float* ra[NST][2];  // plain LDS loads through these (see gemm_f32_mfma_pipe: asm reads + hand-placed waits are not safe)
+    const float* rb[NST][2];
 #pragma unroll
     for (int st = 0; st < NST; st++)
 #pragma unroll
         for (int gq = 0; gq < 2; gq++) {
-            ra[st][gq] = lds_base + (st * STAGE + (wr * WM + r16) * BK) * 4 + (((4 * gq + kq) ^ sw) << 4);
-            rb[st][gq] = lds_base + (st * STAGE + (BM + wc * WN + r16) * BK) * 4 + (((4 * gq + kq) ^ sw) << 4);
+            ra[st][gq] = smem + st * STAGE + (wr * WM + r16) * BK + (((4 * gq + kq) ^ sw) << 2);
+            rb[st][gq] = smem + st * STAGE + (BM + wc * WN + r16) * BK + (((4 * gq + kq) ^ sw) << 2);
         }
 
     f32x4 acc[MB][NB];
@@ -950,21 +947,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
     }
 #define K2_P16_READ(SET_, ST_, G_)                                                                                         \
     {                                                                                                                      \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[SET_][0]) : "v"(ra[ST_][G_]) : "memory");                             \
-        if (MB > 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(fa[SET_][MB > 1 ? 1 : 0]) : "v"(ra[ST_][G_]) : "memory"); \
-        if (MB > 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fa[SET_][MB > 2 ? 2 : 0]) : "v"(ra[ST_][G_]) : "memory"); \
-        if (MB > 3) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(fa[SET_][MB > 3 ? 3 : 0]) : "v"(ra[ST_][G_]) : "memory"); \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fb[SET_][0]) : "v"(rb[ST_][G_]) : "memory");                             \
-        if (NB > 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(fb[SET_][NB > 1 ? 1 : 0]) : "v"(rb[ST_][G_]) : "memory"); \
-        if (NB > 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fb[SET_][NB > 2 ? 2 : 0]) : "v"(rb[ST_][G_]) : "memory"); \
-        if (NB > 3) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(fb[SET_][NB > 3 ? 3 : 0]) : "v"(rb[ST_][G_]) : "memory"); \
+        _Pragma("unroll") for (int i = 0; i < MB; i++) fa[SET_][i] = *reinterpret_cast<const f32x4*>(ra[ST_][G_] + i * 16 * BK); \
+        _Pragma("unroll") for (int j = 0; j < NB; j++) fb[SET_][j] = *reinterpret_cast<const f32x4*>(rb[ST_][G_] + j * 16 * BK); \
     }
-#define K2_P16_FRAGS_READY(SET_)                                                                                           \
-    {                                                                                                                      \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
-        _Pragma("unroll") for (int i = 0; i < MB; i++) asm volatile("" : "+v"(fa[SET_][i]));                               \
-        _Pragma("unroll") for (int j = 0; j < NB; j++) asm volatile("" : "+v"(fb[SET_][j]));                               \
-    }
+#define K2_P16_FRAGS_READY(SET_) {}
 // one K step = two 16-deep k groups (register sets 0 and 1).  The wait for step KT_+1 and the barrier sit between them; the first
 // fragments of step KT_+1 and the DMA of step KT_+NST-1 go out behind the MFMA steps of the second group.
 #define K2_P16_STEP(ST_, KT_, HAS_NEXT_, DO_ISSUE_, WAIT_)                                                                 \
@@ -2030,7 +2016,7 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     // through coalesced LDS-DMA tiles, where the 16-row skinny kernel re-reads the weight chunk M / 16 times straight into
     // fragment layout (half-used cache lines; it is bound by the texture-address path, not by latency).  Choice by grid size,
     // from tools/gemm_lab.py streaming (gpurun_out/lab_str1.txt): 17 % less GEMM time over the chunk step's shapes.
-    if (skinny_ok && few_tiles && a.N > 96 && !tn.gemm_v1 && a.res_div == 1 && !a.act_after_res) {
+    if (skinny_ok && few_tiles && a.N > 96 && !(tn.gemm_v1 & 5) && a.res_div == 1 && !a.act_after_res) {
         const long long g32 = (long long)cdiv(a.M, 32) * cdiv(a.N, 32), g6432 = (long long)cdiv(a.M, 64) * cdiv(a.N, 32);
         int ring = -1;
         if (a.K % 128 == 0 && g32 <= 256) ring = 16;          // 32x32 tiles, KS 4, 4 stages + L2 prefetch wave
@@ -2074,7 +2060,7 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     // for their extra operand traffic.  Examples it reproduces: 4064 x 512 -> 128x64 (256 tiles, one round); 4064 x 1152,
     // 2048 x 2560 / 2080 -> 64x64 (1152 / 1280 / 1056 tiles: 4.5 / 5 / 4.1 rounds of 4096 instead of 2.25 / 2.5 / 2.1 -> 3 of 8192);
     // 4064 x 1024 / 1920, 2048 x 2048 -> 128x128; 16160 x 192 -> 64x64 or 128x32 (3 rounds of 4096 instead of 2 of 8192).
-    if (dma_ok && use_dma && !forced && !tn.gemm_v1 && a.nb0 * a.nb1 == 1 && a.K >= 64 && a.M >= 256 &&
+    if (dma_ok && use_dma && !forced && !(tn.gemm_v1 & 3) && a.nb0 * a.nb1 == 1 && a.K >= 64 && a.M >= 256 &&
         (long long)a.M * a.lda < (1ll << 29) && (long long)a.N * a.ldw < (1ll << 29)) {
         struct Cand { int idx, bm, bn; double fixed_steps, penalty; };
         static const Cand cands[] = {{8, 128, 128, 3.5, 0.0}, {1, 128, 64, 3.3, 0.02}, {5, 64, 64, 4.0, 0.12}, {13, 128, 32, 5.5, 0.08}};
