@@ -90,9 +90,11 @@ struct Rows16 {  // v_mfma_f32_16x16x4_f32: register e of lane (r, q) is row 4 q
 template <int NV, typename ROWS>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, float (&v)[NV], int row0, int col, float* __restrict__ C,
                                               const float* __restrict__ R, const float (&rres)[NV], bool use_rres,
-                                              const float* __restrict__ mulp, const float* __restrict__ biasp) {
+                                              const float* __restrict__ mulp, const float* __restrict__ biasp, bool bias_loaded = false,
+                                              float bias_value = 0.f) {
     if (col >= g.N) return;
-    const float bv = biasp ? biasp[col] : 0.f;
+    // (bias_loaded: the caller fetched this column's bias before its K loop -- the load's latency is then not part of the epilogue)
+    const float bv = bias_loaded ? bias_value : (biasp ? biasp[col] : 0.f);
     const bool act_on = g.act_cols == 0 || col < g.act_cols;
     float rv[NV], mv[NV], ov[NV];
     float bs = 0.f;
@@ -664,6 +666,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
         }
     }
 
+    float bias_pre[NT];  // this lane's bias values, fetched now (older than every DMA, like the residual) instead of in the epilogue
+#pragma unroll
+    for (int j = 0; j < NT; j++) bias_pre[j] = g.bias ? g.bias[min(n0 + wc * WN + j * 32 + li, g.N - 1)] : 0.f;
+
     // ---- addresses, once ----
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
     unsigned voff[IPW];            // per-lane byte offset of this wave's q-th DMA from its operand's base (constant over K)
@@ -827,7 +833,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
 #pragma unroll
             for (int r = 0; r < 16; r++) vals[r] = acc[i][j][r];
             epilogue_rows<16, Rows32>(g, vals, m0 + wr * WM + i * 32 + 4 * lh, n0 + wc * WN + j * 32 + li, C, nullptr, rres[i][j], R != nullptr,
-                                      nullptr, g.bias);
+                                      nullptr, g.bias, true, bias_pre[j]);
         }
     K2_PIPE_STAMP()
     if (stamp && lane == 0) {
