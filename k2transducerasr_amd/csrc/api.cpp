@@ -43,6 +43,11 @@ struct k2hip_online_stream {
     std::vector<int32_t> timestamps;
     long long processed_len = 0;   // processed_lens state (16 per chunk)
     long long chunks_done = 0;     // chunks decoded so far: position of the stream's attention rings in its device slot
+    // Device mirror of `speech` (Engine::kFifoFrames ring rows in the stream's slot): while mir_ok the ring holds exactly the frames of
+    // `speech`, frame 0 at ring row mir_head, so a chunk step gathers its input on the device.  It goes stale only if the FIFO would
+    // outgrow the ring; the step then reads `speech` as before, and the mirror is valid again once the FIFO has drained.
+    bool mir_ok = true;
+    int mir_head = 0;
 };
 
 // one stream's encoder caches as the operator-level API sees them (IOnlineProj's List<List<float[]>>): a slot of the device pool
@@ -526,17 +531,22 @@ static void online_materialize(k2hip_online_stream* const* streams, int n) {
         std::vector<const float*> hp(G), tp(G);
         std::vector<int64_t> hn(G), tn(G);
         std::vector<float*> dst(G);
+        std::vector<int> fslot(G), fpos(G);
         for (int i = 0; i < G; i++) {
             k2hip_online_stream* s = g[i];
             hp[i] = s->remainder.data(); hn[i] = (int64_t)s->remainder.size();
             tp[i] = s->pending.data(); tn[i] = (int64_t)s->pending.size();
             const size_t old = s->speech.size();
+            const int64_t have = (int64_t)(old / (size_t)c.feat);
+            if (s->mir_ok && have + nf > Engine::kFifoFrames) s->mir_ok = false;  // the FIFO outgrows its device mirror
+            fslot[i] = s->slot;
+            fpos[i] = s->mir_ok ? (int)((s->mir_head + have) % Engine::kFifoFrames) : -1;
             s->speech.resize(old + (size_t)nf * c.feat);
             dst[i] = s->speech.data() + old;
         }
         try {
             std::lock_guard<std::mutex> lk(e.mutex());
-            e.fbank_host_gather(hp.data(), hn.data(), tp.data(), tn.data(), len, G, dst.data(), nf);
+            e.fbank_host_gather(hp.data(), hn.data(), tp.data(), tn.data(), len, G, dst.data(), nf, fslot.data(), fpos.data());
         } catch (...) {
             for (k2hip_online_stream* s : g) s->speech.resize(s->speech.size() - (size_t)nf * c.feat);  // nothing was appended
             throw;
@@ -591,6 +601,15 @@ int32_t k2hip_online_stream_accept_features(k2hip_online_stream_t* s, const floa
         if (n_frames > 0) NEED(feats);
         const int feat = s->model->engine.model().cfg().feat;
         online_materialize(&s, 1);  // frames of samples accepted earlier come first
+        if (n_frames > 0) {
+            const int64_t have = (int64_t)(s->speech.size() / (size_t)feat);
+            if (s->mir_ok && have + n_frames > Engine::kFifoFrames) s->mir_ok = false;
+            if (s->mir_ok) {
+                Engine& e = s->model->engine;
+                std::lock_guard<std::mutex> lk(e.mutex());
+                e.online_fifo_write(s->slot, (int)((s->mir_head + have) % Engine::kFifoFrames), feats, n_frames);
+            }
+        }
         s->speech.insert(s->speech.end(), feats, feats + n_frames * feat);
     });
 }
@@ -648,9 +667,12 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
         std::vector<const float*> chunks(R);   // GetDecodeChunk: the first ChunkLength frames of each FIFO
         std::vector<int> slots(R);
         std::vector<long long> hyps(2 * (size_t)R), plens(R);
-        std::vector<int> nch(R);
+        std::vector<int> nch(R), heads(R);
+        bool all_mirrored = true;
         for (int r = 0; r < R; r++) {
             k2hip_online_stream* s = streams[idx[r]];
+            heads[r] = s->mir_head;
+            all_mirrored = all_mirrored && s->mir_ok;
             chunks[r] = s->speech.data();
             slots[r] = s->slot;
             hyps[2 * r] = s->hyp[0];
@@ -663,13 +685,19 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
         std::vector<int32_t> ts((size_t)R * Tp), n(R);
         {
             std::lock_guard<std::mutex> lk(e.mutex());
-            e.online_step(slots.data(), chunks.data(), hyps.data(), plens.data(), nch.data(), R, tok.data(), ts.data(), n.data());
+            e.online_step(slots.data(), chunks.data(), hyps.data(), plens.data(), nch.data(), R, tok.data(), ts.data(), n.data(),
+                          all_mirrored ? heads.data() : nullptr);
         }
         // RemoveChunk (:102-117) only now: if the step above threw (a HIP failure, a search timeout), every stream still holds
         // its chunk and nothing host-side has moved -- the caller may retry or drop the streams
         for (int r = 0; r < R; r++) {
             k2hip_online_stream* s = streams[idx[r]];
             s->speech.erase(s->speech.begin(), s->speech.begin() + shift_floats);
+            s->mir_head = (s->mir_head + c.shift) % Engine::kFifoFrames;
+            if (!s->mir_ok && s->speech.empty()) {  // drained: the mirror of an empty FIFO is valid again
+                s->mir_ok = true;
+                s->mir_head = 0;
+            }
             s->chunks_done++;
             for (int k = 0; k < n[r]; k++) {
                 s->tokens.push_back(tok[(size_t)r * Tp + k]);          // :183

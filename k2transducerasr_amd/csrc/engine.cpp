@@ -617,12 +617,19 @@ void Engine::fbank_host_batch(const float* samples, int64_t n, int n_utts, float
 }
 
 void Engine::fbank_host_gather(const float* const* head, const int64_t* n_head, const float* const* tail, const int64_t* n_tail, int64_t n, int G,
-                               float* const* dst, int64_t nf) {
+                               float* const* dst, int64_t nf, const int* fifo_slots, const int* fifo_pos) {
     const FbankOpts& f = model_->cfg().fbank;
     K2_REQUIRE(nf == fbank_num_frames(n) && nf > 0 && G > 0, "fbank_host_gather: bad shape");
     const size_t nb_in = sizeof(float) * (size_t)n * G, per_out = sizeof(float) * (size_t)nf * f.num_bins, nb_out = per_out * G;
-    char* pin = static_cast<char*>(pinned((int64_t)(nb_in + nb_out + 64)));
+    const bool mirror = fifo_slots && fifo_pos && online_fifo_;
+    const size_t nb_idx = mirror ? sizeof(int) * 2 * (size_t)G : 0;
+    char* pin = static_cast<char*>(pinned((int64_t)(nb_in + nb_out + nb_idx + 64)));
     float* w = reinterpret_cast<float*>(pin);
+    int* h_idx = reinterpret_cast<int*>(pin + nb_in + nb_out);
+    if (mirror) {
+        memcpy(h_idx, fifo_slots, sizeof(int) * G);
+        memcpy(h_idx + G, fifo_pos, sizeof(int) * G);
+    }
     for (int g = 0; g < G; g++) {
         K2_REQUIRE(n_head[g] + n_tail[g] == n, "fbank_host_gather: signal %d has %lld + %lld samples, expected %lld", g, (long long)n_head[g],
                    (long long)n_tail[g], (long long)n);
@@ -637,6 +644,11 @@ void Engine::fbank_host_gather(const float* const* head, const int64_t* n_head, 
         FbankArgs a{d_s, n, n, G, nf, d_out, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift, f.preemph, f.input_scale, f.remove_dc};
         a.melrange = model_->d_melrange;
         fbank(c, a);
+        if (mirror) {  // the same frames into the streams' device FIFOs: the chunk step then needs no host copy of them
+            int* d_idx = c.arena->take<int>(2 * G);
+            if (!c.dry) K2_HIP(hipMemcpyAsync(d_idx, h_idx, nb_idx, hipMemcpyHostToDevice, c.stream));
+            fifo_append(c, online_fifo_, kFifoFrames, f.num_bins, d_out, d_idx, d_idx + G, G, (int)nf);
+        }
     });
     K2_HIP(hipMemcpyAsync(pin + nb_in, d_out, nb_out, hipMemcpyDeviceToHost, stream_));
     K2_HIP(hipStreamSynchronize(stream_));

@@ -69,8 +69,12 @@ class Engine {
     // the same for G signals that each arrive in two pieces ([head_g ; tail_g], n_head[g] + n_tail[g] == n for all g) and whose
     // frames go to G separate destinations: gathered straight into the pinned staging buffer and scattered straight out of it
     // (one host copy each way instead of three)
+    // device mirror of the streams' feature FIFOs (see kernels.h fifo_*): rings of kFifoFrames frames per slot
+    static constexpr int kFifoFrames = 512;
+    void online_fifo_write(int slot, int pos, const float* feats, int64_t n_frames);  // host frames -> ring rows pos ..
+    // (fifo_slots / fifo_pos: when given, the frames of signal g are also appended to slot fifo_slots[g]'s ring at fifo_pos[g] (< 0: not))
     void fbank_host_gather(const float* const* head, const int64_t* n_head, const float* const* tail, const int64_t* n_tail, int64_t n, int G,
-                           float* const* dst, int64_t nf);
+                           float* const* dst, int64_t nf, const int* fifo_slots = nullptr, const int* fifo_pos = nullptr);
     void pad_host(const float* const* speech, const int64_t* n_floats, int B, int tail, float* out, int64_t cap, int64_t* L);
     void encoder_host(const float* x, int B, int T, float* enc_out, int64_t cap, int* Tp);
     void encoder_tap_host(const float* x, int B, int T, int tap, float* out, int64_t cap, int64_t* n);
@@ -107,8 +111,10 @@ class Engine {
     // chunks: [B] pointers to each stream's T*feat chunk floats (gathered into pinned staging by the engine)
     // operator level (IOnlineProj.EncoderProj): one chunk of the streaming Zipformer2 encoder for B state slots, encoder_out to host
     void online_encoder(const int* slots, const float* feats, const long long* plens, const int* nchunks, int B, float* enc_out);
+    // fifo_heads (optional): ring row of every stream's first FIFO frame in the device mirror -- the chunk inputs are then gathered
+    // on the device and `chunks` is not read
     void online_step(const int* slots, const float* const* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
-                     int64_t* tokens, int32_t* ts, int32_t* n_tokens);
+                     int64_t* tokens, int32_t* ts, int32_t* n_tokens, const int* fifo_heads = nullptr);
 
     void set_instrument(bool on) { instrument_ = on; }
     void set_pipe_mode(int m) { pipe_mode_ = m; }
@@ -237,6 +243,7 @@ class Engine {
     // stream, so two whole batches run concurrently and each other's GEMM prologues / epilogues / tails are filled
     int pipe_mode_ = 0;
     float* online_pool_ = nullptr;
+    float* online_fifo_ = nullptr;  // [online_cap_][kFifoFrames][feat]
     int online_cap_ = 0;
     std::vector<int> free_slots_;
     OnlineLayout lay_;

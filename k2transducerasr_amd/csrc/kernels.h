@@ -360,6 +360,11 @@ void attn_stream(const Ctx& ctx, const float* qkp, int ld, const float* kcat, co
 void glu_causal_conv(const Ctx& ctx, const float* x2, float* pool, long long slot_stride, long long off, const int* slots,
                      const float* wc, const float* bc, const float* ww, const float* bw, const float* sc, float* y, int B,
                      int Tc, int D, int K);
+// Device mirror of the streams' feature FIFOs (OnlineStream's Speech): fifo [slots][cap][feat] rings.
+//   fifo_append: frames [g][0 .. nf) of `src` go to ring rows (pos[g] + i) % cap of slot slots[g] (pos[g] < 0: skipped)
+//   fifo_gather: x[b][t] = ring row (head[b] + t) % cap of slot slots[b], t < T  -- the chunk input of a step, no host round trip
+void fifo_append(const Ctx& ctx, float* fifo, int cap, int feat, const float* src, const int* slots, const int* pos, int G, int nf);
+void fifo_gather(const Ctx& ctx, const float* fifo, int cap, int feat, const int* slots, const int* head, float* x, int B, int T);
 void zero_floats(const Ctx& ctx, float* p, long long n);
 // ---- streaming Zipformer v1 (zipformer1.hip; OnlineProjOfZipformer) ------------------------------
 // running mean over every frame seen so far: out [B*Tc, D]; cached_avg (avg_off, [D]) and cached_len (len_off, 1 float) per slot

@@ -296,6 +296,29 @@ __global__ __launch_bounds__(64) void k_glu_causal_conv(const float* __restrict_
     }
 }
 
+// ---- device mirror of the feature FIFOs: float4 per lane along the feature dimension (feat % 4 == 0)
+__global__ void k_fifo_append(float* __restrict__ fifo, int cap, int f4, const float* __restrict__ src, const int* __restrict__ slots,
+                              const int* __restrict__ pos, int nf) {
+    const int g = blockIdx.y, p0 = pos[g];
+    if (p0 < 0) return;
+    const long long n = (long long)nf * f4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int fr = (int)(i / f4), q = (int)(i % f4);
+        reinterpret_cast<float4*>(fifo)[((long long)slots[g] * cap + (p0 + fr) % cap) * f4 + q] =
+            reinterpret_cast<const float4*>(src)[((long long)g * nf + fr) * f4 + q];
+    }
+}
+__global__ void k_fifo_gather(const float* __restrict__ fifo, int cap, int f4, const int* __restrict__ slots, const int* __restrict__ head,
+                              float* __restrict__ x, int T) {
+    const int b = blockIdx.y, h = head[b];
+    const long long n = (long long)T * f4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(i / f4), q = (int)(i % f4);
+        reinterpret_cast<float4*>(x)[((long long)b * T + t) * f4 + q] =
+            reinterpret_cast<const float4*>(fifo)[((long long)slots[b] * cap + (h + t) % cap) * f4 + q];
+    }
+}
+
 // zero one stream's slot (GetEncoderInitStates: all caches start at 0)
 __global__ void k_zero(float* __restrict__ p, long long n) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -376,6 +399,20 @@ void glu_causal_conv(const Ctx& ctx, const float* x2, float* pool, long long slo
         default: K2_GCC(0); break;
     }
 #undef K2_GCC
+    K2_HIP(hipGetLastError());
+}
+void fifo_append(const Ctx& ctx, float* fifo, int cap, int feat, const float* src, const int* slots, const int* pos, int G, int nf) {
+    K2_REQUIRE(feat % 4 == 0, "fifo: feature dimension %d", feat);
+    if (ctx.dry || G <= 0 || nf <= 0) return;
+    hipLaunchKernelGGL(k_fifo_append, dim3(std::max(1, std::min(8, (nf * (feat / 4) + 255) / 256)), G), dim3(256), 0, ctx.stream, fifo, cap, feat / 4, src,
+                       slots, pos, nf);
+    K2_HIP(hipGetLastError());
+}
+void fifo_gather(const Ctx& ctx, const float* fifo, int cap, int feat, const int* slots, const int* head, float* x, int B, int T) {
+    K2_REQUIRE(feat % 4 == 0, "fifo: feature dimension %d", feat);
+    if (ctx.dry || B <= 0) return;
+    hipLaunchKernelGGL(k_fifo_gather, dim3(std::max(1, std::min(8, (T * (feat / 4) + 255) / 256)), B), dim3(256), 0, ctx.stream, fifo, cap, feat / 4,
+                       slots, head, x, T);
     K2_HIP(hipGetLastError());
 }
 void zero_floats(const Ctx& ctx, float* p, long long n) {

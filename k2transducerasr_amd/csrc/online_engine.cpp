@@ -91,6 +91,10 @@ void Engine::online_ensure_pool() {
 
 int Engine::online_alloc_slot() {
     online_ensure_pool();
+    if (!online_fifo_ && model_->cfg().feat % 4 == 0) {  // device mirror of the feature FIFOs (42 MB for 256 slots x 512 frames x 80)
+        K2_HIP(hipSetDevice(device_));
+        K2_HIP(hipMalloc(&online_fifo_, sizeof(float) * (size_t)online_cap_ * kFifoFrames * model_->cfg().feat));
+    }
     if (free_slots_.empty())
         failf(K2HIP_ERR_CAPACITY, "all %d stream slots are in use (raise K2HIP_MAX_STREAMS before creating the model)", online_cap_);
     int slot = free_slots_.back();
@@ -100,6 +104,17 @@ int Engine::online_alloc_slot() {
     K2_HIP(hipMemsetAsync(online_pool_ + (size_t)slot * lay_.floats_per_stream, 0, sizeof(float) * (size_t)lay_.floats_per_stream, stream_));
     K2_HIP(hipStreamSynchronize(stream_));
     return slot;
+}
+// host frames into ring rows pos, pos + 1, ... (mod kFifoFrames) of a slot's device FIFO (OnlineStream fed with ready-made features)
+void Engine::online_fifo_write(int slot, int pos, const float* feats, int64_t n_frames) {
+    if (!online_fifo_ || n_frames <= 0) return;
+    K2_REQUIRE(slot >= 0 && slot < online_cap_ && pos >= 0 && pos < kFifoFrames && n_frames <= kFifoFrames, "fifo write out of range");
+    const int feat = model_->cfg().feat;
+    K2_HIP(hipSetDevice(device_));
+    const int64_t first = std::min<int64_t>(n_frames, kFifoFrames - pos);
+    float* base = online_fifo_ + (size_t)slot * kFifoFrames * feat;
+    K2_HIP(hipMemcpy(base + (size_t)pos * feat, feats, sizeof(float) * (size_t)first * feat, hipMemcpyHostToDevice));
+    if (n_frames > first) K2_HIP(hipMemcpy(base, feats + (size_t)first * feat, sizeof(float) * (size_t)(n_frames - first) * feat, hipMemcpyHostToDevice));
 }
 void Engine::online_free_slot(int slot) {
     if (slot >= 0) free_slots_.push_back(slot);
@@ -428,7 +443,7 @@ float* Engine::online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_
 }
 
 void Engine::online_step(const int* slots, const float* const* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
-                         int64_t* tokens, int32_t* ts, int32_t* n_tokens) {
+                         int64_t* tokens, int32_t* ts, int32_t* n_tokens, const int* fifo_heads) {
     online_ensure_pool();
     K2_REQUIRE(B > 0, "online_step: no ready stream");
     const Model& m = *model_;
@@ -451,8 +466,11 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
     // the streams' chunks, gathered once into pinned staging (one host copy; the H2D below is then a real asynchronous DMA)
     const size_t chunk_floats = (size_t)T * cf.feat;
     K2_HIP(hipSetDevice(device_));
-    float* stage = static_cast<float*>(pinned_in((int64_t)(sizeof(float) * chunk_floats * B)));
-    for (int b = 0; b < B; b++) memcpy(stage + (size_t)b * chunk_floats, chunks[b], sizeof(float) * chunk_floats);
+    const bool from_fifo = fifo_heads != nullptr && online_fifo_ != nullptr;  // the chunks are already on the device (FIFO mirror)
+    float* stage = static_cast<float*>(pinned_in((int64_t)(from_fifo ? sizeof(int) * B : sizeof(float) * chunk_floats * B)));
+    if (from_fifo) memcpy(stage, fifo_heads, sizeof(int) * B);
+    else
+        for (int b = 0; b < B; b++) memcpy(stage + (size_t)b * chunk_floats, chunks[b], sizeof(float) * chunk_floats);
     run_sized([&](const Ctx& c) {
         Arena& ar = *c.arena;
         d_tok = ar.take<long long>((int64_t)B * Tp);
@@ -464,14 +482,17 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
         long long* d_plen = ar.take<long long>(B);
         long long* d_hyp = ar.take<long long>(2 * B);
         int* d_chunks = ar.take<int>(B);
+        int* d_heads = ar.take<int>(B);
         if (!c.dry) {
             K2_HIP(hipEventRecord(ev_[0], c.stream));
-            K2_HIP(hipMemcpyAsync(d_x, stage, sizeof(float) * (size_t)B * T * cf.feat, hipMemcpyHostToDevice, c.stream));
+            if (from_fifo) K2_HIP(hipMemcpyAsync(d_heads, stage, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
+            else K2_HIP(hipMemcpyAsync(d_x, stage, sizeof(float) * (size_t)B * T * cf.feat, hipMemcpyHostToDevice, c.stream));
             K2_HIP(hipMemcpyAsync(d_slots, slots, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
             K2_HIP(hipMemcpyAsync(d_chunks, nchunks, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
             K2_HIP(hipMemcpyAsync(d_plen, plens, sizeof(long long) * B, hipMemcpyHostToDevice, c.stream));
             K2_HIP(hipMemcpyAsync(d_hyp, hyps, sizeof(long long) * 2 * B, hipMemcpyHostToDevice, c.stream));
         }
+        if (from_fifo) fifo_gather(c, online_fifo_, kFifoFrames, cf.feat, d_slots, d_heads, d_x, B, T);
         logfloor_inplace(c, d_x, (long long)B * T * cf.feat);  // online PadSequence (PadHelper.cs:9-13,58)
         if (cf.lstm || cf.conformer || cf.zip1) {
             int tc = Tp;

@@ -420,3 +420,49 @@ def test_operator_level_online_proj_runs_the_reference_loop(stream_model_path, o
     finally:
         for st in states:
             proj.free_states(st)
+
+
+def test_feature_fifo_device_mirror_wraps_overflows_and_recovers(rec, ora):
+    """The feature FIFO of a stream is mirrored in a 512-frame ring on the device so that a chunk step gathers its input there
+    (no host copy of the features on the critical path).  Three streams in one batch: one whose FIFO stays small but whose ring
+    position wraps (fed 40 frames at a time, ~1100 frames in total), one that is handed 700 frames at once (outgrows the ring:
+    the step falls back to the host copy for the whole batch until that FIFO has drained, then the mirror is valid again), and one
+    fed with samples (frames produced on the device go into the ring directly).  Tokens / timestamps / Hyp against the oracle
+    after every call."""
+    from k2transducerasr_amd.synth import synth_utterance
+    T, S = rec.chunk_length, rec.shift_length
+    wav = [synth_utterance(950 + u, d) for u, d in enumerate([11.0, 7.0, 6.0])]
+    feats = [ora.fbank(w) for w in wav]
+    hs = [rec.create_online_stream() for _ in range(3)]
+    so = [ora.create_stream() for _ in range(3)]
+    fed = [0, 0, 0]          # frames handed to the HIP stream so far (stream 2: samples, counted in frames of 160)
+    pos = [0, 0, 0]
+    hs[1].add_features(feats[1][:700])   # outgrows the ring at once
+    fed[1] = 700
+    calls = 0
+    while True:
+        if fed[0] < feats[0].shape[0]:   # small pieces: the ring position wraps twice over the utterance
+            n = min(40, feats[0].shape[0] - fed[0])
+            hs[0].add_features(feats[0][fed[0] : fed[0] + n])
+            fed[0] += n
+        if fed[1] < feats[1].shape[0] and pos[1] + T > fed[1]:   # the rest only after the big block has drained
+            hs[1].add_features(feats[1][fed[1] :])
+            fed[1] = feats[1].shape[0]
+        if fed[2] * 160 < wav[2].size:
+            n = min(6400, wav[2].size - fed[2] * 160)
+            hs[2].add_samples(wav[2][fed[2] * 160 : fed[2] * 160 + n])
+            fed[2] += n // 160
+        avail = [fed[0], fed[1], (fed[2] * 160 - 400) // 160 + 1 if fed[2] * 160 >= 400 else 0]
+        ready = [u for u in range(3) if pos[u] + T <= min(avail[u], feats[u].shape[0])]
+        dec, _ = rec.get_results(hs)
+        assert [u for u in range(3) if dec[u]] == ready, (calls, avail, pos)
+        if not ready and fed[0] >= feats[0].shape[0] and fed[2] * 160 >= wav[2].size:
+            break
+        if ready:
+            ora.step([so[u] for u in ready], [feats[u][pos[u] : pos[u] + T] for u in ready])
+            for u in ready:
+                pos[u] += S
+        for u in range(3):
+            assert hs[u].tokens == so[u].tokens and hs[u].timestamps == so[u].timestamps and hs[u].hyp == so[u].hyp, (calls, u)
+        calls += 1
+    assert calls >= 30 and pos[0] > 512 and sum(len(s.tokens) - 2 for s in so) > 0
