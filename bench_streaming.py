@@ -76,7 +76,7 @@ def main():
 
     def run():
         prof[:] = [0.0, 0.0, 0.0]
-        streams = [rec.create_online_stream() for _ in range(N)]
+        streams = rec.batch([rec.create_online_stream() for _ in range(N)])  # the handle array a native host would hold
         steps = 0
         t0 = time.perf_counter()
         for pos in range(0, n, 800):

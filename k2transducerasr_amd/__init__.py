@@ -18,6 +18,7 @@ from .binding import (  # noqa: F401
     OnlineProj,
     OnlineRecognizer,
     OnlineStream,
+    StreamBatch,
     TokenTable,
     build_library,
     library_path,
@@ -33,6 +34,7 @@ __all__ = [
     "OnlineProj",
     "OnlineRecognizer",
     "OnlineStream",
+    "StreamBatch",
     "TokenTable",
     "build_library",
     "library_path",

@@ -655,6 +655,23 @@ class OnlineStream:
         return out
 
 
+class StreamBatch:
+    """The handles of a fixed group of OnlineStreams as one ctypes array (what a native host keeps next to its stream objects)."""
+
+    def __init__(self, streams):
+        self.streams = list(streams)
+        self.arr = (C.c_void_p * len(self.streams))(*[s._h.value for s in self.streams])
+
+    def __len__(self):
+        return len(self.streams)
+
+    def __iter__(self):
+        return iter(self.streams)
+
+    def __getitem__(self, i):
+        return self.streams[i]
+
+
 class OnlineProj:
     """IOnlineProj (IOnlineProj.cs:65-71) on the HIP backend: the operator a host swaps in when it keeps the reference's own
     OnlineRecognizer loop.  States are handles (a slot of the device pool each); stack_states / unstack_states are the identity."""
@@ -736,8 +753,15 @@ class OnlineRecognizer:
         self.model._chk(self.model._L.k2hip_online_step(self.model.handle, arr, B, _i(dec), _i(n)))
         return dec.tolist(), n.tolist()
 
+    def batch(self, streams: Sequence[OnlineStream]) -> "StreamBatch":
+        """A fixed group of streams as the native array of handles a C# / C host would hold (IntPtr[]): pass it to
+        add_samples_batch / get_results instead of the list and no per-call scan of the streams happens."""
+        return StreamBatch(streams)
+
     def _handles(self, streams):
         """ctypes array of the streams' handles; rebuilt only when the list changes (a serving loop passes the same list every 50 ms)"""
+        if isinstance(streams, StreamBatch):
+            return streams.arr
         key = tuple(s._h.value for s in streams)
         if getattr(self, "_hkey", None) != key:
             self._hkey = key

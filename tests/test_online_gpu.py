@@ -248,8 +248,9 @@ def test_streaming_128_concurrent_slots_zh(tmp_path_factory):
     for h, f in zip(hs, feats):
         h.add_features(f)
     checked = {0: ora.create_stream(), 77: ora.create_stream()}
+    group = rec.batch(hs)   # the handle array a native host would hold (no per-call scan of the 128 stream objects)
     for k in range(nchunks):
-        dec, n_new = rec.get_results(hs)
+        dec, n_new = rec.get_results(group if k % 2 == 0 else hs)   # both ways of naming the same streams
         assert dec == [1] * N
         for u, o in checked.items():
             want = ora.step([o], [feats[u][k * S : k * S + T]])
