@@ -649,27 +649,6 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
     if (stamp && lane == 0) stamp[60] = __builtin_amdgcn_s_memrealtime();
     K2_PIPE_STAMP()
 
-    // residual operand first: older than every DMA, so the counted waits below never have to account for it (vmcnt retires in
-    // issue order; its latency overlaps the prologue's DMAs all the same)
-    float rres[MT][NT][16];
-    if (R) {
-#pragma unroll
-        for (int j = 0; j < NT; j++) {
-            const int col = min(n0 + wc * WN + j * 32 + li, g.N - 1);
-#pragma unroll
-            for (int i = 0; i < MT; i++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int row = min(m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
-                    rres[i][j][r] = R[(long long)row * g.ldr + col];
-                }
-        }
-    }
-
-    float bias_pre[NT];  // this lane's bias values, fetched now (older than every DMA, like the residual) instead of in the epilogue
-#pragma unroll
-    for (int j = 0; j < NT; j++) bias_pre[j] = g.bias ? g.bias[min(n0 + wc * WN + j * 32 + li, g.N - 1)] : 0.f;
-
     // ---- addresses, once ----
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
     unsigned voff[IPW];            // per-lane byte offset of this wave's q-th DMA from its operand's base (constant over K)
@@ -690,30 +669,6 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
                 (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
         mq[q] = __builtin_amdgcn_readfirstlane(lds_base + inst * 1024);
     }
-    const int arow = wr * WM + li, brow = wc * WN + li;
-    const int swa = (arow >> 1) & 7, swb = ((BM + brow) >> 1) & 7;
-    // fragment read pointers: stage, k group.  Plain LDS loads through them (NOT inline-asm ds_reads): the compiler then knows
-    // the destination registers are pending until ITS lgkmcnt wait.  With asm reads + a hand-placed wait it was free to copy a
-    // fragment register (a phi copy at a loop edge) before the data had arrived -- results changed on rare runs when a second
-    // process shared the GPU and LDS returns came late (tools/determinism_stress.py).
-    const float* ra[NST][4];
-    const float* rb[NST][4];
-#pragma unroll
-    for (int st = 0; st < NST; st++)
-#pragma unroll
-        for (int gk = 0; gk < 4; gk++) {
-            ra[st][gk] = smem + st * STAGE + arow * BK + (((2 * gk + lh) ^ swa) << 2);
-            rb[st][gk] = smem + st * STAGE + (BM + brow) * BK + (((2 * gk + lh) ^ swb) << 2);
-        }
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; i++)
-#pragma unroll
-        for (int j = 0; j < NT; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    f32x4 fa[2][MT], fb[2][NT];
 
 // instruction q_ of K step KT_ (stage ST_, a literal): M0 = its LDS destination, source = operand base + 128 KT_ bytes + lane offset
 #define K2_PIPE_DMA(ST_, KT_, q_)                                                                                          \
@@ -779,12 +734,58 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
                 if (p == 2) K2_PIPE_DMA(2, 2, q)
             }
         }
+    // (fragment pointers and accumulators only now: the DMAs above are already on their way)
+    const int arow = wr * WM + li, brow = wc * WN + li;
+    const int swa = (arow >> 1) & 7, swb = ((BM + brow) >> 1) & 7;
+    // fragment read pointers: stage, k group.  Plain LDS loads through them (NOT inline-asm ds_reads): the compiler then knows
+    // the destination registers are pending until ITS lgkmcnt wait.  With asm reads + a hand-placed wait it was free to copy a
+    // fragment register (a phi copy at a loop edge) before the data had arrived -- results changed on rare runs when a second
+    // process shared the GPU and LDS returns came late (tools/determinism_stress.py).
+    const float* ra[NST][4];
+    const float* rb[NST][4];
+#pragma unroll
+    for (int st = 0; st < NST; st++)
+#pragma unroll
+        for (int gk = 0; gk < 4; gk++) {
+            ra[st][gk] = smem + st * STAGE + arow * BK + (((2 * gk + lh) ^ swa) << 2);
+            rb[st][gk] = smem + st * STAGE + (BM + brow) * BK + (((2 * gk + lh) ^ swb) << 2);
+        }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    f32x4 fa[2][MT], fb[2][NT];
     K2_PIPE_STAMP()
     if (nk >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * IPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     K2_PIPE_READ(0, 0, 0)
     K2_PIPE_STAMP()
+    // Residual and bias are fetched HERE: behind the prologue's DMAs and the first barrier, so that the DMAs leave as early as the
+    // kernel can compute their addresses and this block's ~150 address instructions run while the first K steps are in flight
+    // (they used to run in front of the first DMA).  vmcnt retires in issue order: these loads are younger than K steps
+    // 0 .. NST-2 and older than every later one, so the loop's counted waits also cover them -- conservatively, never wrongly.
+    float rres[MT][NT][16];
+    if (R) {
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int col = min(n0 + wc * WN + j * 32 + li, g.N - 1);
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = min(m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
+                    rres[i][j][r] = R[(long long)row * g.ldr + col];
+                }
+        }
+    }
+    float bias_pre[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) bias_pre[j] = g.bias ? g.bias[min(n0 + wc * WN + j * 32 + li, g.N - 1)] : 0.f;
 
     int kt = 0;
     const int nsteady = nk - (NST - 1);  // steps whose step kt+NST-1 exists
