@@ -175,6 +175,18 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, float (&v)[NV],
         for (int n = 0; n < NV; n++) v[n] = ov[n] + (v[n] - ov[n]) * bs;
     }
     if (g.ablate & 4) return;
+    // address = (uniform 64-bit base + the row's uniform byte offset) + a 32-bit per-lane offset: the row offsets are scalar work and
+    // the store can take its SGPR-base form; when the lane's last row is inside M (all but the bottom tiles) no row is tested
+    const unsigned lane_off = (unsigned)(((long long)row0 * g.ldc + col) * 4);  // < 2^32: checked by the launchers that matter (M * ldc < 2^29)
+    const bool small = (long long)g.M * g.ldc < (1ll << 29);
+    if (small && row0 + ROWS::off(NV - 1) < g.M) {
+#pragma unroll
+        for (int n = 0; n < NV; n++) {
+            char* ub = reinterpret_cast<char*>(C) + (long long)ROWS::off(n) * g.ldc * 4;
+            *reinterpret_cast<float*>(ub + lane_off) = v[n];
+        }
+        return;
+    }
     float* cp = C + (long long)row0 * g.ldc + col;
 #pragma unroll
     for (int n = 0; n < NV; n++)
