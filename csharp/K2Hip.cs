@@ -35,6 +35,7 @@ namespace K2TransducerAsr.Hip
         [DllImport(Lib)] internal static extern int k2hip_online_chunk_info(IntPtr model, out int chunkLength, out int shiftLength, out int framesPerChunk);
         [DllImport(Lib)] internal static extern int k2hip_online_stream_create(IntPtr model, out IntPtr stream);
         [DllImport(Lib)] internal static extern int k2hip_online_stream_destroy(IntPtr stream);
+        [DllImport(Lib)] internal static extern int k2hip_online_stream_reset(IntPtr stream);
         [DllImport(Lib)] internal static extern int k2hip_online_stream_accept_samples(IntPtr stream, float[] samples, long n);
         [DllImport(Lib)] internal static extern int k2hip_online_stream_accept_features(IntPtr stream, float[] feats, long nFrames);
         [DllImport(Lib)] internal static extern int k2hip_online_stream_is_finished(IntPtr stream, int isEndpoint, out int finished);

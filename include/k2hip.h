@@ -283,6 +283,9 @@ int32_t k2hip_offline_stream_get_timestamps(const k2hip_offline_stream_t* s, int
  * [blank, blank]. */
 int32_t k2hip_online_stream_create(k2hip_model_t* model, k2hip_online_stream_t** out);
 int32_t k2hip_online_stream_destroy(k2hip_online_stream_t* s);
+/* the stream as if freshly created (caches zeroed in its slot; FIFO, tokens, timestamps, Hyp cleared).  No reference counterpart: a
+ * host would create a new OnlineStream (OnlineRecognizer.cs:60-64); SURVEY 8b lists it as a convenience of the C surface. */
+int32_t k2hip_online_stream_reset(k2hip_online_stream_t* s);
 /* ChunkLength = T, ShiftLength = decode_chunk_len (OnlineModel.cs:48-49); frames of encoder_out per chunk */
 int32_t k2hip_online_chunk_info(const k2hip_model_t* model, int32_t* chunk_length, int32_t* shift_length,
                                 int32_t* frames_per_chunk);

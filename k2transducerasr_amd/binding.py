@@ -559,6 +559,7 @@ def _bind_online(L):
     vp = C.c_void_p
     L.k2hip_online_stream_create.argtypes = [vp, C.POINTER(vp)]
     L.k2hip_online_stream_destroy.argtypes = [vp]
+    L.k2hip_online_stream_reset.argtypes = [vp]
     L.k2hip_online_chunk_info.argtypes = [vp, ip, ip, ip]
     L.k2hip_online_stream_accept_samples.argtypes = [vp, fp, C.c_int64]
     L.k2hip_online_stream_accept_features.argtypes = [vp, fp, C.c_int64]
@@ -592,6 +593,10 @@ class OnlineStream:
         h = C.c_void_p()
         model._chk(self._L.k2hip_online_stream_create(model.handle, C.byref(h)))
         self._h = h
+
+    def reset(self):
+        """back to a freshly created stream (same slot): for the next utterance on the same object"""
+        self._m._chk(self._L.k2hip_online_stream_reset(self._h))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -474,6 +474,23 @@ int32_t k2hip_online_stream_create(k2hip_model_t* model, k2hip_online_stream_t**
         *out = s;
     });
 }
+// Back to the state of a freshly created stream (new utterance on the same object): caches zeroed in place, FIFOs, tokens,
+// timestamps and Hyp cleared.  The reference has no such method -- a host would drop the OnlineStream and create a new one
+// (OnlineRecognizer.cs:60-64); this keeps the slot and skips the allocation.
+int32_t k2hip_online_stream_reset(k2hip_online_stream_t* s) {
+    return guard([&] {
+        NEED(s);
+        k2hip_model* model = s->model;
+        {
+            std::lock_guard<std::mutex> lk(model->engine.mutex());
+            model->engine.online_free_slot(s->slot);
+            s->slot = -1;
+            s->slot = model->engine.online_alloc_slot();  // (the slot just freed: re-zeroed like GetEncoderInitStates)
+        }
+        *s = k2hip_online_stream{model, s->slot};
+        if (model->engine.model().cfg().conformer) s->processed_len = 2;
+    });
+}
 int32_t k2hip_online_stream_destroy(k2hip_online_stream_t* s) {
     return guard([&] {
         if (!s) return;

@@ -467,3 +467,41 @@ def test_feature_fifo_device_mirror_wraps_overflows_and_recovers(rec, ora):
             assert hs[u].tokens == so[u].tokens and hs[u].timestamps == so[u].timestamps and hs[u].hyp == so[u].hyp, (calls, u)
         calls += 1
     assert calls >= 30 and pos[0] > 512 and sum(len(s.tokens) - 2 for s in so) > 0
+
+
+def test_stream_reset_equals_a_fresh_stream(rec, ora):
+    """k2hip_online_stream_reset: the same object decodes a second utterance exactly as a new stream would (caches re-zeroed in
+    its slot, FIFO / remainder / tokens / timestamps / Hyp / processed_lens cleared), while another stream of the batch keeps going."""
+    from k2transducerasr_amd.synth import synth_utterance
+    T, S = rec.chunk_length, rec.shift_length
+    f1, f2 = ora.fbank(synth_utterance(970, 1.6)), ora.fbank(synth_utterance(971, 1.4))
+    a, other = rec.create_online_stream(), rec.create_online_stream()
+    o_other = ora.create_stream()
+    f_other = ora.fbank(synth_utterance(972, 3.4))
+    other.add_features(f_other)
+    pos_other = 0
+
+    def decode_all(stream, feats):
+        nonlocal pos_other
+        o = ora.create_stream()
+        stream.add_features(feats)
+        pos = 0
+        while pos + T <= feats.shape[0]:
+            both = pos_other + T <= f_other.shape[0]
+            rec.get_results([stream, other])
+            ora.step([o] + ([o_other] if both else []), [feats[pos : pos + T]] + ([f_other[pos_other : pos_other + T]] if both else []))
+            pos += S
+            pos_other += S if both else 0
+            assert stream.tokens == o.tokens and stream.timestamps == o.timestamps and stream.hyp == o.hyp
+            assert other.tokens == o_other.tokens and other.hyp == o_other.hyp
+        return o
+
+    o1 = decode_all(a, f1)
+    a.add_samples(np.zeros(123, np.float32))   # something left in the sample remainder too
+    a.reset()
+    assert a.tokens == [0, 0] and a.timestamps == [] and a.hyp == [0, 0] and a.processed_len == 0 and a.speech_length == 0
+    o2 = decode_all(a, f2)
+    assert len(o1.tokens) + len(o2.tokens) > 4
+    for l in (0, 1):
+        for k in KINDS:
+            np.testing.assert_allclose(a.state(l, k), o2.state(l, k), atol=2e-4, rtol=0)
