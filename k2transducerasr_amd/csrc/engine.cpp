@@ -1051,6 +1051,53 @@ float Engine::debug_gemm(int M, int N, int K, int act, bool with_res, int iters,
     c.instrument = false;
     c.stats = nullptr;
     float ms = 0;
+    if (act >= 100) {  // the gated epilogue (101: value * sigmoid(gate) over all columns, 102: value * tanh(gate) over the first 2N/3,
+                       // the rest passed through) against the plain GEMM + the gating done on the host
+        const int mode = act - 100, gc = mode == 2 ? (2 * N / 3) / 32 * 32 : N, ldo = gc / 2 + (N - gc);
+        try {
+            K2_REQUIRE((mode == 1 || mode == 2) && N % 32 == 0 && gc >= 32 && max_err, "debug_gemm: gated mode needs N %% 32 == 0 and max_err");
+            GemmArgs g;
+            g.A = A; g.lda = K; g.W = W; g.ldw = K; g.bias = b; g.C = C; g.ldc = ldo; g.M = M; g.N = N; g.K = K; g.glu = mode; g.glu_cols = gc == N ? 0 : gc;
+            debug_force_gemm_cfg(cfg);
+            gemm(c, g);
+            K2_HIP(hipEventRecord(ev_[6], stream_));
+            for (int i = 0; i < iters; i++) gemm(c, g);
+            K2_HIP(hipEventRecord(ev_[7], stream_));
+            debug_force_gemm_cfg(2 + 64);
+            linear(c, A, K, W, b, C2, N, M, K, N, ACT_NONE, nullptr, 0);
+            K2_HIP(hipStreamSynchronize(stream_));
+            K2_HIP(hipEventElapsedTime(&ms, ev_[6], ev_[7]));
+            K2_REQUIRE(!gemm_sk_take_error(), "stream-K exchange timed out (cfg %d)", cfg);
+            std::vector<float> h1((size_t)M * ldo), h2((size_t)M * N);
+            K2_HIP(hipMemcpy(h1.data(), C, sizeof(float) * h1.size(), hipMemcpyDeviceToHost));
+            K2_HIP(hipMemcpy(h2.data(), C2, sizeof(float) * h2.size(), hipMemcpyDeviceToHost));
+            float e = 0;
+            for (int m = 0; m < M; m++)
+                for (int col = 0; col < N; col++) {
+                    float want;
+                    int oc;
+                    if (col < gc) {
+                        if (col & 16) continue;  // a gate column
+                        const float v = h2[(size_t)m * N + col], gt = h2[(size_t)m * N + col + 16];
+                        want = mode == 2 ? v * tanhf(gt) : v / (1.0f + expf(-gt));
+                        oc = ((col >> 5) << 4) + (col & 15);
+                    } else {
+                        want = h2[(size_t)m * N + col];
+                        oc = gc / 2 + (col - gc);
+                    }
+                    const float d = fabsf(h1[(size_t)m * ldo + oc] - want);
+                    e = (d > e || d != d) ? (d != d ? INFINITY : d) : e;
+                }
+            *max_err = e;
+        } catch (...) {
+            debug_force_gemm_cfg(-1);
+            (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipFree(C2); (void)hipFree(Rb); (void)hipFree(b);
+            throw;
+        }
+        debug_force_gemm_cfg(-1);
+        (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipFree(C2); (void)hipFree(Rb); (void)hipFree(b);
+        return ms / std::max(1, iters);
+    }
     try {
         debug_force_gemm_cfg(cfg);
         for (int i = 0; i < 3; i++) linear(c, A, K, W, b, C, N, M, K, N, act, with_res ? Rb : nullptr, N);

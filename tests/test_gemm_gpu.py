@@ -61,3 +61,24 @@ def test_every_gemm_kernel_agrees_with_the_register_staged_one(gemm_check, famil
                 assert err <= tol, (family, cfg, M, N, K, act, res, err, tol)
                 ran += 1
     assert ran >= 30
+
+
+def test_gated_epilogue_in_every_kernel_family(gemm_check):
+    """GemmArgs.glu (the conv modules' GLU and NonlinAttention's tanh gate, fused into the producing GEMM): value and gate sit 16
+    lanes apart in the 32-column accumulator layout, so every kernel family that can be asked for it is forced here and compared
+    with the PLAIN product of the register-staged kernel gated on the host (an independent path: no shared epilogue code decides
+    the expected values).  Mode 1: all columns paired, sigmoid; mode 2: the first 2N/3 paired with tanh, the rest passed through."""
+    ran = 0
+    for (M, N, K) in [(300, 128, 64), (1000, 384, 160), (257, 1152, 96), (4064, 1024, 512), (130, 96 * 4, 256)]:
+        for mode in (101, 102):
+            if mode == 102 and ((2 * N // 3) // 32 * 32) < 32:
+                continue
+            tol = 3e-5 * max(1.0, K ** 0.5)
+            for cfg in [-1, 5, 9, 100, 118, 2001, 2005, 2008, 2013, 1011, 1021]:
+                if not _fits(cfg, M, N, K):
+                    continue
+                rc, err = gemm_check(M, N, K, mode, 0, cfg)
+                assert rc == 0, (cfg, M, N, K, mode)
+                assert err <= tol, (cfg, M, N, K, mode, err, tol)
+                ran += 1
+    assert ran >= 40
