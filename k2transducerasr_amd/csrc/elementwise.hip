@@ -109,18 +109,63 @@ __global__ void k_dwconv7x7(const float* __restrict__ x, const float* __restrict
     *reinterpret_cast<float4*>(y + p * C + c) = s;
 }
 
+// The 7x7 taps of one chunk of DW7_TT output frames for one (bin, channel quad): `col` points at the lane's cell of patch row
+// slot 0 (bin fi + 0, quad cq); patch row r of the chunk sits in slot (s0 + r) mod DW7_RING, rows `rowf` floats apart; `wl` points
+// at the lane's quad of the workgroup's taps in LDS ([49][32]).  Explicit packed FMAs (v_pk_fma_f32): left to itself the compiler
+// fused the x/y halves and split the z/w halves into multiplies, adds and register moves (about twice the instructions), and
+// waited for each tap's weights from global memory right in front of its use.  Both kernels below call this, so they agree bit for bit.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int DW7_TT = 8, DW7_CG = 32, DW7_RING = 22;
+__device__ __forceinline__ void dw7_stage_taps(float* wl, const float* __restrict__ w, int C, int c0, int tid) {
+    for (int i = tid; i < 49 * 8; i += 192)
+        *reinterpret_cast<float4*>(wl + (i >> 3) * 32 + 4 * (i & 7)) = *reinterpret_cast<const float4*>(w + (long long)(i >> 3) * C + c0 + 4 * (i & 7));
+}
+__device__ __forceinline__ void dw7_chunk(const float* col, int rowf, int s0, const float* wl, f32x2 (&alo)[DW7_TT], f32x2 (&ahi)[DW7_TT]) {
+#pragma unroll 1  // fully unrolled, the compiler hoists all 147 loads and spills
+    for (int kf = 0; kf < 7; kf++) {
+        f32x2 wlo[7], whi[7];
+#pragma unroll
+        for (int kt = 0; kt < 7; kt++) {
+            const float4 t = *reinterpret_cast<const float4*>(wl + (kt * 7 + kf) * 32);
+            wlo[kt] = f32x2{t.x, t.y};
+            whi[kt] = f32x2{t.z, t.w};
+        }
+        // all 14 rows of the column in flight before the first FMA (one row at a time, each read's latency sat in front of its FMAs)
+        float4 xr[DW7_TT + 6];
+#pragma unroll
+        for (int r = 0; r < DW7_TT + 6; r++) {
+            int slot = s0 + r;
+            slot = slot >= DW7_RING ? slot - DW7_RING : slot;
+            xr[r] = *reinterpret_cast<const float4*>(col + kf * 32 + slot * rowf);
+        }
+#pragma unroll
+        for (int r = 0; r < DW7_TT + 6; r++) {
+            const f32x2 xlo{xr[r].x, xr[r].y}, xhi{xr[r].z, xr[r].w};
+#pragma unroll
+            for (int kt = 0; kt < 7; kt++) {
+                const int to = r - kt;  // output frame fed by patch row r through tap kt
+                if (to >= 0 && to < DW7_TT) {
+                    alo[to] = __builtin_elementwise_fma(wlo[kt], xlo, alo[to]);
+                    ahi[to] = __builtin_elementwise_fma(whi[kt], xhi, ahi[to]);
+                }
+            }
+        }
+    }
+}
+
 // LDS-tiled form: one workgroup = 8 output frames x all F bins x 32 channels.  The (8+6) x (F+6) x 32 input patch (zero
 // halo) is staged once; a thread owns one (bin, channel quad) column of 8 outputs and slides down the patch, so every staged
 // value is read 7 times from LDS instead of 49 times from L2 (the per-pixel kernel above fetched 11x the tensor: 1.78 GB per
 // launch against 157 MB, profiles/r01_v2_pmc_fetch_summary.csv).
-constexpr int DW7_TT = 8, DW7_CG = 32;
 __global__ __launch_bounds__(192) void k_dwconv7x7_tiled(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int Tin, int T,
                                                          int tpad, int F, int C) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [DW7_TT + 6][F + 6][32]
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [DW7_TT + 6][F + 6][32] + taps [49][32]
     const int tid = threadIdx.x, cq = tid & 7, fi = tid >> 3;
     const int c0 = blockIdx.x * DW7_CG, t0 = blockIdx.y * DW7_TT, b = blockIdx.z;
     const int FP = F + 6, ncell = (DW7_TT + 6) * FP * 8;
+    float* wl = xs + (DW7_TT + 6) * FP * 32;
+    dw7_stage_taps(wl, w, C, c0, tid);
     // five patch cells per lane in flight (one at a time, the staging was a chain of ~15 memory latencies per workgroup)
     for (int base = tid; base < ncell; base += 5 * 192) {
         float4 v[5];
@@ -143,33 +188,83 @@ __global__ __launch_bounds__(192) void k_dwconv7x7_tiled(const float* __restrict
     __syncthreads();
     if (fi >= F) return;
     const int c = c0 + 4 * cq;
-    float4 acc[DW7_TT];
     const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+    f32x2 alo[DW7_TT], ahi[DW7_TT];
 #pragma unroll
-    for (int i = 0; i < DW7_TT; i++) acc[i] = bv;
-#pragma unroll 1  // fully unrolled, the compiler hoists all 147 loads and spills
-    for (int kf = 0; kf < 7; kf++) {
-        float4 wv[7];
-#pragma unroll
-        for (int kt = 0; kt < 7; kt++) wv[kt] = *reinterpret_cast<const float4*>(w + (kt * 7 + kf) * C + c);
-        const float* col = xs + (fi + kf) * 32 + 4 * cq;
-#pragma unroll
-        for (int r = 0; r < DW7_TT + 6; r++) {
-            const float4 xv = *reinterpret_cast<const float4*>(col + r * FP * 32);
-#pragma unroll
-            for (int kt = 0; kt < 7; kt++) {
-                const int to = r - kt;  // output frame fed by patch row r through tap kt
-                if (to >= 0 && to < DW7_TT) {
-                    acc[to].x += wv[kt].x * xv.x; acc[to].y += wv[kt].y * xv.y;
-                    acc[to].z += wv[kt].z * xv.z; acc[to].w += wv[kt].w * xv.w;
-                }
-            }
-        }
+    for (int i = 0; i < DW7_TT; i++) {
+        alo[i] = f32x2{bv.x, bv.y};
+        ahi[i] = f32x2{bv.z, bv.w};
     }
+    dw7_chunk(xs + fi * 32 + 4 * cq, FP * 32, 0, wl + 4 * cq, alo, ahi);
 #pragma unroll
     for (int i = 0; i < DW7_TT; i++) {
         const int t = t0 + i;
-        if (t < T) *reinterpret_cast<float4*>(y + (((long long)b * T + t) * F + fi) * C + c) = acc[i];
+        if (t < T) *reinterpret_cast<float4*>(y + (((long long)b * T + t) * F + fi) * C + c) = make_float4(alo[i].x, alo[i].y, ahi[i].x, ahi[i].y);
+    }
+}
+
+// Sliding form for long inputs: a workgroup walks DW7_TR output frames of one (utterance, 32-channel group) in chunks of 8, keeping
+// the 14 patch rows of the current chunk and the 8 new rows of the next one in a 22-row LDS ring.  The new rows arrive by LDS-DMA
+// (global_load_lds_dwordx4: a row's F x 32 floats are contiguous by lane in LDS, 128 B per bin in memory) while the current chunk
+// is computed, so the input is fetched (TR + 6) / TR times instead of 14 / 8 (274 MB against a 157 MB tensor per launch of the
+// tiled kernel, profiles/r01_v5_pmc_fetch_summary.csv) and no fetch latency sits in front of a chunk.  Wave w issues part w of every
+// row (cells 64 w .. 64 w + 63 of its F x 8 float4 cells); the halo bins are zeroed once and never written again; a row outside
+// the input is zeroed by plain stores when its ring slot comes up.  Sums run in the tiled kernel's order: bit-identical results.
+__global__ __launch_bounds__(192) void k_dwconv7x7_slide(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int Tin, int T,
+                                                         int tpad, int F, int C, int TR) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [DW7_RING][F + 6][32] + taps [49][32]
+    const int tid = threadIdx.x, cq = tid & 7, fi = tid >> 3, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = blockIdx.x * DW7_CG, tbeg = blockIdx.y * TR, b = blockIdx.z;
+    const int tend = min(T, tbeg + TR), nch = (tend - tbeg + DW7_TT - 1) / DW7_TT;
+    const int FP = F + 6, rowf = FP * 32;
+    // halo bins of every ring row
+    for (int i = tid; i < DW7_RING * 6 * 8; i += 192) {
+        const int q = i & 7, hb = (i >> 3) % 6, r = i / 48;
+        *reinterpret_cast<float4*>(xs + r * rowf + (hb < 3 ? hb : F + hb) * 32 + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float* wl = xs + DW7_RING * rowf;
+    dw7_stage_taps(wl, w, C, c0, tid);
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)xs;
+    const int ci = 64 * wv + lane;           // this lane's cell of a row: bin ci / 8, channel quad ci % 8
+    const bool cell_ok = ci < F * 8;
+    const unsigned voff = (unsigned)(((lane >> 3) * C + (lane & 7) * 4) * 4);
+    // patch row pr (0 = input frame tbeg - tpad) -> ring slot pr % DW7_RING
+    auto fetch_row = [&](int pr) {
+        const int tt = tbeg - tpad + pr, slot = pr % DW7_RING;
+        if (tt >= 0 && tt < Tin) {
+            const unsigned long long src = (unsigned long long)(x + (((long long)b * Tin + tt) * F + 8 * wv) * C + c0);
+            const unsigned m0v = lds_base + (unsigned)((slot * rowf + 96 + 256 * wv) * 4);
+            if (cell_ok) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src), "s"(m0v) : "memory");
+        } else if (cell_ok) {
+            *reinterpret_cast<float4*>(xs + slot * rowf + 96 + 4 * ci) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    for (int pr = 0; pr < DW7_TT + 6; pr++) fetch_row(pr);
+    const int c = c0 + 4 * cq;
+    const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+    const bool mine = fi < F;
+    const float* lanep = xs + (mine ? fi : 0) * 32 + 4 * cq;
+    for (int n = 0; n < nch; n++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's rows have landed (and the previous chunk's stores retired)
+        __syncthreads();                                    // ... for every wave; and every wave is done with chunk n - 1
+        if (n + 1 < nch)
+            for (int k = 0; k < DW7_TT; k++) fetch_row(DW7_TT * (n + 1) + 6 + k);
+        if (mine) {
+            f32x2 alo[DW7_TT], ahi[DW7_TT];
+#pragma unroll
+            for (int i = 0; i < DW7_TT; i++) {
+                alo[i] = f32x2{bv.x, bv.y};
+                ahi[i] = f32x2{bv.z, bv.w};
+            }
+            dw7_chunk(lanep, rowf, (DW7_TT * n) % DW7_RING, wl + 4 * cq, alo, ahi);
+            const int t0 = tbeg + DW7_TT * n;
+#pragma unroll
+            for (int i = 0; i < DW7_TT; i++)
+                if (t0 + i < tend)
+                    *reinterpret_cast<float4*>(y + (((long long)b * T + t0 + i) * F + fi) * C + c) = make_float4(alo[i].x, alo[i].y, ahi[i].x, ahi[i].y);
+        }
     }
 }
 
@@ -453,9 +548,20 @@ void basicnorm(const Ctx& ctx, const float* x, const float* log_eps, float* y, i
 void dwconv7x7(const Ctx& ctx, const float* x, const float* w_kc, const float* b, float* y, int B, int Tin, int T, int tpad,
                int F, int C) {
     ctx.add_flops(0.0, 2.0 * B * T * (double)F * C * 49, 0);
+    if (C % DW7_CG == 0 && F <= 24 && !tunables().dw7_simple && !tunables().dw7_tiled && T >= 48 && (long long)F * C * 4 < (1ll << 31)) {
+        if (ctx.dry) return;
+        const int TR = T >= 256 ? 64 : 32;
+        size_t lds = sizeof(float) * ((size_t)DW7_RING * (F + 6) * 32 + 49 * 32);
+        static LdsAttrOnce lds_attr;
+        lds_attr.ensure(k_dwconv7x7_slide, 96 * 1024);
+        hipLaunchKernelGGL(k_dwconv7x7_slide, dim3(C / DW7_CG, cdiv(T, TR), B), dim3(192), lds, ctx.stream, x, w_kc, b, y, Tin, T, tpad, F,
+                           C, TR);
+        K2_HIP(hipGetLastError());
+        return;
+    }
     if (C % DW7_CG == 0 && F <= 24 && !tunables().dw7_simple) {
         if (ctx.dry) return;
-        size_t lds = sizeof(float) * (size_t)(DW7_TT + 6) * (F + 6) * 32;
+        size_t lds = sizeof(float) * ((size_t)(DW7_TT + 6) * (F + 6) * 32 + 49 * 32);
         hipLaunchKernelGGL(k_dwconv7x7_tiled, dim3(C / DW7_CG, cdiv(T, DW7_TT), B), dim3(192), lds, ctx.stream, x, w_kc, b, y, Tin, T,
                            tpad, F, C);
         K2_HIP(hipGetLastError());

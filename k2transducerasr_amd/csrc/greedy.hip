@@ -68,9 +68,20 @@ __device__ void decoder_conv_narrow(const DecJoinW& w, long long y0, long long y
 __device__ void decoder_block(const DecJoinW& w, long long y0, long long y1, float* h, float* out) {
     const int tid = threadIdx.x;
     decoder_conv_narrow(w, y0, y1, h, h + w.DD);
+    // eight weight loads in flight per thread; the sum keeps its k-ascending order (one dependent load per k made the single
+    // workgroup of the t0 pre-pass a 118 us kernel)
     for (int n = tid; n < w.J; n += blockDim.x) {
         float s = w.dproj_b[n];
-        for (int k = 0; k < w.DD; k++) s += h[k] * w.dproj_kn[(long long)k * w.J + n];
+        const float* __restrict__ wk = w.dproj_kn + n;
+        int k = 0;
+        for (; k + 8 <= w.DD; k += 8) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) wv[u] = wk[(long long)(k + u) * w.J];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += h[k + u] * wv[u];
+        }
+        for (; k < w.DD; k++) s += h[k] * wk[(long long)k * w.J];
         out[n] = s;
     }
     __syncthreads();

@@ -60,6 +60,14 @@ def test_large_encoder_and_tokens_match_oracle(hip_large, oracle_large):
         set_switch("K2HIP_NO_GLU_EPILOGUE", 0)
     np.testing.assert_allclose(enc_g, enc_h, atol=2e-5, rtol=0)
     np.testing.assert_allclose(enc_g, enc_o, atol=5e-4, rtol=0)
+    # the 7x7 depthwise convolution of the embed: the sliding LDS-DMA kernel (inputs of >= 48 frames) against the one-shot tiled
+    # kernel -- the same sums in the same order, so the whole encoder output is bit-identical
+    set_switch("K2HIP_DW7_TILED", 1)
+    try:
+        enc_t = hip_large.encoder_proj(x)
+    finally:
+        set_switch("K2HIP_DW7_TILED", 0)
+    np.testing.assert_array_equal(enc_t, enc_h)
 
 
 def test_full_size_batch_properties(hip_large):
