@@ -58,14 +58,23 @@ __global__ __launch_bounds__(512, 4) void k_attn_scores_softmax(const float* __r
     __syncthreads();
 
     const int njt = (T + 31) / 32;
+    // the next key tile's fragments are requested before this tile's MFMAs and positional adds
+    float4 fkn[NG];
+    auto load_keys = [&](int jt) {
+        const int j = jt * 32 + li;
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            fkn[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (jt < njt && j < T) fkn[g] = *reinterpret_cast<const float4*>(base + (long long)j * ld + koff + 8 * g + 4 * lh);
+        }
+    };
+    load_keys(wave);
     for (int jt = wave; jt < njt; jt += 8) {
         int j = jt * 32 + li;  // this lane's key (as B-operand column and as accumulator column)
         float4 fk[NG];
 #pragma unroll
-        for (int g = 0; g < NG; g++) {
-            fk[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < T) fk[g] = *reinterpret_cast<const float4*>(base + (long long)j * ld + koff + 8 * g + 4 * lh);
-        }
+        for (int g = 0; g < NG; g++) fk[g] = fkn[g];
+        load_keys(jt + 8);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
@@ -95,6 +104,58 @@ __global__ __launch_bounds__(512, 4) void k_attn_scores_softmax(const float* __r
 
     // row softmax: wave w (of 8) owns rows 4w..4w+3
     float* out = aw + (((long long)h * B + b) * T) * Tp;
+    if (Tp <= 1024) {
+        // the row passes through registers once: lane = columns 4 lane + 256 k (float4 LDS reads, float4 stores); max, exp, sum and
+        // the scaling happen in between, and all four rows' reads are in flight before the first reduction (the in-place form below
+        // walked every row three times through LDS, one dependent read -> exp -> write chain per 64 columns)
+        float4 v[4][4];
+        const int nk = (Tp + 255) >> 8;  // 256-column chunks in use (wave-uniform)
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const float* srow = S + (wave * 4 + rr) * lds_stride;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j4 = lane * 4 + 256 * k;
+                v[rr][k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                if (k < nk && j4 < T) {  // (the strip is padded to a multiple of 4 columns; columns >= T are masked here)
+                    const float4 t = *reinterpret_cast<const float4*>(srow + j4);
+                    v[rr][k].x = t.x;
+                    if (j4 + 1 < T) v[rr][k].y = t.y;
+                    if (j4 + 2 < T) v[rr][k].z = t.z;
+                    if (j4 + 3 < T) v[rr][k].w = t.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int i = i0 + wave * 4 + rr;
+            if (i >= T) break;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (k < nk) mx = fmaxf(fmaxf(fmaxf(mx, v[rr][k].x), fmaxf(v[rr][k].y, v[rr][k].z)), v[rr][k].w);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (k >= nk) break;
+                v[rr][k].x = __expf(v[rr][k].x - mx); v[rr][k].y = __expf(v[rr][k].y - mx);
+                v[rr][k].z = __expf(v[rr][k].z - mx); v[rr][k].w = __expf(v[rr][k].w - mx);
+                sum += (v[rr][k].x + v[rr][k].y) + (v[rr][k].z + v[rr][k].w);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float inv = 1.0f / sum;
+            float* orow = out + (long long)i * Tp;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j4 = lane * 4 + 256 * k;
+                if (k < nk && j4 < Tp) *reinterpret_cast<float4*>(orow + j4) = make_float4(v[rr][k].x * inv, v[rr][k].y * inv, v[rr][k].z * inv, v[rr][k].w * inv);
+            }
+        }
+        return;
+    }
     for (int rr = 0; rr < 4; rr++) {
         int rl = wave * 4 + rr, i = i0 + rl;
         if (i >= T) break;

@@ -386,18 +386,28 @@ __global__ void k_mul_cols(float* __restrict__ a, const float* __restrict__ x, i
 //  One workgroup = 4 waves = 32 output frames x 256 channels.  The GLU'd input strip
 //  (32 + K - 1 frames) is staged once in LDS with 1 KB coalesced row loads; lane = channel
 //  quad, so every LDS read of a wave is one conflict-free 1 KB row segment.
-constexpr int DW_TT = 8;                 // outputs per thread
-constexpr int DW_ROWS = 4 * DW_TT;       // output frames per workgroup
-template <bool DSWISH, bool GLU = true>
+//  DW_TT = outputs per thread (8, or 4 / 2 when 32-frame workgroups would leave CUs idle: at B x T = 4064 rows x 512 channels there
+//  are 256 of them, one per CU, and the launch is one workgroup's stage -> compute -> store chain); 4 DW_TT output frames per workgroup
+template <bool DSWISH, bool GLU = true, int DW_TT = 8>
 __global__ __launch_bounds__(256) void k_glu_dwconv1d(const float* __restrict__ x2, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y, int B, int T,
                                                       int D, int K) {
     extern __shared__ __attribute__((aligned(16))) float sx[];  // [DW_ROWS + K - 1][256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = blockIdx.x * 256 + lane * 4;
+    constexpr int DW_ROWS = 4 * DW_TT;
     const int t0 = blockIdx.y * DW_ROWS, b = blockIdx.z;
     const int half = K >> 1, nrows = DW_ROWS + K - 1;
     const bool cok = c < D;
+    // K <= 32 (every recipe: 31, 15): all taps of the lane's channel quad are requested before the staging loop, so that their
+    // latency lies under the staging instead of in front of every group of 8 taps (4 x ~0.7 us of a ~10 us launch)
+    const bool pre = K <= 32;
+    float4 wp[32];
+    if (pre) {
+#pragma unroll
+        for (int q = 0; q < 32; q++)
+            wp[q] = (cok && q < K) ? *reinterpret_cast<const float4*>(w + q * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     // four rows (eight 16-byte loads) in flight per lane: one row at a time made the staging a chain of ~16 memory latencies
     for (int r0 = wave; r0 < nrows; r0 += 16) {
         float4 a[4], sg[4];
@@ -424,13 +434,30 @@ __global__ __launch_bounds__(256) void k_glu_dwconv1d(const float* __restrict__ 
     }
     __syncthreads();
     if (!cok) return;
-    float4 acc[DW_TT];
+    f32x2 alo[DW_TT], ahi[DW_TT];  // explicit packed FMAs (see dw7_chunk)
     const float4 bv = *reinterpret_cast<const float4*>(bias + c);
 #pragma unroll
-    for (int i = 0; i < DW_TT; i++) acc[i] = bv;
+    for (int i = 0; i < DW_TT; i++) {
+        alo[i] = f32x2{bv.x, bv.y};
+        ahi[i] = f32x2{bv.z, bv.w};
+    }
     const float* base = sx + (wave * DW_TT) * 256 + lane * 4;
-    // taps in groups of 8: the 8 weight loads are in flight together (one load per tap inside the loop was a chain of K latencies)
-    for (int kb = 0; kb < K; kb += 8) {
+    if (pre) {
+#pragma unroll
+        for (int q = 0; q < 32; q++) {
+            if (q < K) {
+                const f32x2 wlo{wp[q].x, wp[q].y}, whi{wp[q].z, wp[q].w};
+#pragma unroll
+                for (int i = 0; i < DW_TT; i++) {
+                    const float4 xv = *reinterpret_cast<const float4*>(base + (i + q) * 256);
+                    alo[i] = __builtin_elementwise_fma(wlo, f32x2{xv.x, xv.y}, alo[i]);
+                    ahi[i] = __builtin_elementwise_fma(whi, f32x2{xv.z, xv.w}, ahi[i]);
+                }
+            }
+        }
+    }
+    // longer kernels: taps in groups of 8, the 8 weight loads in flight together
+    for (int kb = 0; !pre && kb < K; kb += 8) {
         float4 wv[8];
 #pragma unroll
         for (int q = 0; q < 8; q++)
@@ -438,10 +465,12 @@ __global__ __launch_bounds__(256) void k_glu_dwconv1d(const float* __restrict__ 
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             if (kb + q < K) {
+                const f32x2 wlo{wv[q].x, wv[q].y}, whi{wv[q].z, wv[q].w};
 #pragma unroll
                 for (int i = 0; i < DW_TT; i++) {
                     const float4 xv = *reinterpret_cast<const float4*>(base + (i + kb + q) * 256);
-                    acc[i].x += wv[q].x * xv.x; acc[i].y += wv[q].y * xv.y; acc[i].z += wv[q].z * xv.z; acc[i].w += wv[q].w * xv.w;
+                    alo[i] = __builtin_elementwise_fma(wlo, f32x2{xv.x, xv.y}, alo[i]);
+                    ahi[i] = __builtin_elementwise_fma(whi, f32x2{xv.z, xv.w}, ahi[i]);
                 }
             }
         }
@@ -451,8 +480,8 @@ __global__ __launch_bounds__(256) void k_glu_dwconv1d(const float* __restrict__ 
         const int t = t0 + wave * DW_TT + i;
         if (t < T)
             *reinterpret_cast<float4*>(y + ((long long)b * T + t) * D + c) =
-                DSWISH ? make_float4(dswish(acc[i].x), dswish(acc[i].y), dswish(acc[i].z), dswish(acc[i].w))
-                       : make_float4(swoosh_r(acc[i].x), swoosh_r(acc[i].y), swoosh_r(acc[i].z), swoosh_r(acc[i].w));
+                DSWISH ? make_float4(dswish(alo[i].x), dswish(alo[i].y), dswish(ahi[i].x), dswish(ahi[i].y))
+                       : make_float4(swoosh_r(alo[i].x), swoosh_r(alo[i].y), swoosh_r(ahi[i].x), swoosh_r(ahi[i].y));
     }
 }
 
@@ -595,37 +624,44 @@ void mul_cols(const Ctx& ctx, float* a, const float* x, int ldx, int col0, int M
     long long n4 = (long long)M * N / 4;
     LAUNCH(k_mul_cols, dim3(nblocks(n4, 256)), dim3(256), a, x, ldx, col0, n4, N / 4);
 }
-template <bool DSWISH>
+// outputs per thread by grid size: 32-frame workgroups unless they would number fewer than ~2 per CU
+static int dw1d_tt(int B, int T, int D) {
+    const long long g8 = (long long)cdiv(D, 256) * cdiv(T, 32) * B;
+    const int force = tunables().dw1d_tt;
+    if (force == 8 || force == 4 || force == 2) return force;
+    return g8 >= 512 ? 8 : 4;  // (2: measured slower everywhere)
+}
+template <bool DSWISH, bool GLU, int TT>
+static void launch_dw1d(const Ctx& ctx, const float* x, const float* w_kd, const float* b, float* y, int B, int T, int D, int K) {
+    size_t lds = sizeof(float) * (size_t)(4 * TT + K - 1) * 256;
+    dim3 grid(cdiv(D, 256), cdiv(T, 4 * TT), B);
+    static LdsAttrOnce lds_attr;
+    lds_attr.ensure(k_glu_dwconv1d<DSWISH, GLU, TT>, 128 * 1024);
+    hipLaunchKernelGGL((k_glu_dwconv1d<DSWISH, GLU, TT>), grid, dim3(256), lds, ctx.stream, x, w_kd, b, y, B, T, D, K);
+    K2_HIP(hipGetLastError());
+}
+template <bool DSWISH, bool GLU>
 static void glu_dwconv1d_any(const Ctx& ctx, const float* x2, const float* w_kd, const float* b, float* y, int B, int T, int D,
                              int K) {
     K2_REQUIRE(D % 4 == 0, "dwconv1d: D=%d", D);
-    size_t lds = sizeof(float) * (size_t)(DW_ROWS + K - 1) * 256;
-    dim3 grid(cdiv(D, 256), cdiv(T, DW_ROWS), B);
     ctx.add_flops(0.0, 2.0 * B * T * (double)D * K, 0);
     if (ctx.dry) return;
-    static LdsAttrOnce lds_attr;
-    lds_attr.ensure(k_glu_dwconv1d<DSWISH>, 128 * 1024);
-    hipLaunchKernelGGL(k_glu_dwconv1d<DSWISH>, grid, dim3(256), lds, ctx.stream, x2, w_kd, b, y, B, T, D, K);
-    K2_HIP(hipGetLastError());
+    switch (dw1d_tt(B, T, D)) {
+        case 8: launch_dw1d<DSWISH, GLU, 8>(ctx, x2, w_kd, b, y, B, T, D, K); break;
+        case 4: launch_dw1d<DSWISH, GLU, 4>(ctx, x2, w_kd, b, y, B, T, D, K); break;
+        default: launch_dw1d<DSWISH, GLU, 2>(ctx, x2, w_kd, b, y, B, T, D, K); break;
+    }
 }
 void dwconv1d_swoosh(const Ctx& ctx, const float* x, const float* w_kd, const float* b, float* y, int B, int T, int D, int K) {
-    K2_REQUIRE(D % 4 == 0, "dwconv1d: D=%d", D);
-    size_t lds = sizeof(float) * (size_t)(DW_ROWS + K - 1) * 256;
-    dim3 grid(cdiv(D, 256), cdiv(T, DW_ROWS), B);
-    ctx.add_flops(0.0, 2.0 * B * T * (double)D * K, 0);
-    if (ctx.dry) return;
-    static LdsAttrOnce lds_attr;
-    lds_attr.ensure(k_glu_dwconv1d<false, false>, 128 * 1024);
-    hipLaunchKernelGGL((k_glu_dwconv1d<false, false>), grid, dim3(256), lds, ctx.stream, x, w_kd, b, y, B, T, D, K);
-    K2_HIP(hipGetLastError());
+    glu_dwconv1d_any<false, false>(ctx, x, w_kd, b, y, B, T, D, K);
 }
 void glu_dwconv1d_swoosh(const Ctx& ctx, const float* x2, const float* w_kd, const float* b, float* y, int B, int T, int D,
                           int K) {
-    glu_dwconv1d_any<false>(ctx, x2, w_kd, b, y, B, T, D, K);
+    glu_dwconv1d_any<false, true>(ctx, x2, w_kd, b, y, B, T, D, K);
 }
 void glu_dwconv1d_dswish(const Ctx& ctx, const float* x2, const float* w_kd, const float* b, float* y, int B, int T, int D,
                           int K) {
-    glu_dwconv1d_any<true>(ctx, x2, w_kd, b, y, B, T, D, K);
+    glu_dwconv1d_any<true, true>(ctx, x2, w_kd, b, y, B, T, D, K);
 }
 void downsample(const Ctx& ctx, const float* x, const float* bias, float* y, int B, int T, int D, int ds) {
     int Td = (T + ds - 1) / ds;
