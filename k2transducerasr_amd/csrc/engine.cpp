@@ -547,14 +547,22 @@ void Engine::beam_device(const Ctx& c, const float* enc, int B, int Tp, long lon
 void Engine::finish_tokens(const long long* d_tok, const int* d_ts, const int* d_n, const int* d_ovf, int B, int max_tokens,
                            int64_t* tokens, int32_t* ts, int32_t* n_tokens) {
     int64_t nb_tok = (int64_t)B * max_tokens * 8, nb_ts = (int64_t)B * max_tokens * 4, nb_n = (int64_t)B * 4;
-    char* pin = static_cast<char*>(pinned(nb_tok + nb_ts + nb_n + 64));
-    K2_HIP(hipMemcpyAsync(pin, d_tok, nb_tok, hipMemcpyDeviceToHost, stream_));
-    K2_HIP(hipMemcpyAsync(pin + nb_tok, d_ts, nb_ts, hipMemcpyDeviceToHost, stream_));
-    K2_HIP(hipMemcpyAsync(pin + nb_tok + nb_ts, d_n, nb_n, hipMemcpyDeviceToHost, stream_));
-    K2_HIP(hipMemcpyAsync(pin + nb_tok + nb_ts + nb_n, d_ovf, 4, hipMemcpyDeviceToHost, stream_));
+    char* pin0 = static_cast<char*>(pinned(nb_tok + nb_ts + nb_n + 64));
+    char* pin = pin0 + 16;  // [flag (16 B) | tokens | timestamps | counts]
+    const char* t8 = reinterpret_cast<const char*>(d_tok);
+    if (reinterpret_cast<const char*>(d_ovf) + 16 == t8 && reinterpret_cast<const char*>(d_ts) == t8 + nb_tok &&
+        reinterpret_cast<const char*>(d_n) == t8 + nb_tok + nb_ts) {
+        // the caller laid the four out as one block (the streaming chunk step): one copy
+        K2_HIP(hipMemcpyAsync(pin0, d_ovf, (size_t)(16 + nb_tok + nb_ts + nb_n), hipMemcpyDeviceToHost, stream_));
+    } else {
+        K2_HIP(hipMemcpyAsync(pin, d_tok, nb_tok, hipMemcpyDeviceToHost, stream_));
+        K2_HIP(hipMemcpyAsync(pin + nb_tok, d_ts, nb_ts, hipMemcpyDeviceToHost, stream_));
+        K2_HIP(hipMemcpyAsync(pin + nb_tok + nb_ts, d_n, nb_n, hipMemcpyDeviceToHost, stream_));
+        K2_HIP(hipMemcpyAsync(pin0, d_ovf, 4, hipMemcpyDeviceToHost, stream_));
+    }
     K2_HIP(hipEventRecord(ev_[5], stream_));
     K2_HIP(hipStreamSynchronize(stream_));
-    int ovf = *reinterpret_cast<int*>(pin + nb_tok + nb_ts + nb_n);
+    int ovf = *reinterpret_cast<int*>(pin0);
     if (ovf == 2) failf(K2HIP_ERR_HIP, "greedy search: the vocabulary-parallel exchange timed out (a workgroup never arrived)");
     if (ovf) failf(K2HIP_ERR_CAPACITY, "a stream emitted more than max_tokens=%d symbols", max_tokens);
     memcpy(tokens, pin, nb_tok);

@@ -467,30 +467,42 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
     const size_t chunk_floats = (size_t)T * cf.feat;
     K2_HIP(hipSetDevice(device_));
     const bool from_fifo = fifo_heads != nullptr && online_fifo_ != nullptr;  // the chunks are already on the device (FIFO mirror)
-    float* stage = static_cast<float*>(pinned_in((int64_t)(from_fifo ? sizeof(int) * B : sizeof(float) * chunk_floats * B)));
-    if (from_fifo) memcpy(stage, fifo_heads, sizeof(int) * B);
-    else
-        for (int b = 0; b < B; b++) memcpy(stage + (size_t)b * chunk_floats, chunks[b], sizeof(float) * chunk_floats);
+    // ONE upload per tick: [chunks' frames (only when they are not on the device yet) | plens | hyps | slots | chunk counts | FIFO heads |
+    // overflow flag = 0], packed in pinned staging in the device block's layout (five small copies from pageable memory + a memset were
+    // six blit launches of ~4 us each at the head of the step); ONE download: [tokens | timestamps | counts | overflow flag]
+    const int64_t nb_x = from_fifo ? 0 : (int64_t)sizeof(float) * chunk_floats * B;
+    const int64_t o_plen = align_up(nb_x, 16), o_hyp = o_plen + 8 * (int64_t)B, o_slots = o_hyp + 16 * (int64_t)B, o_chunks = o_slots + 4 * (int64_t)B,
+                  o_heads = o_chunks + 4 * (int64_t)B, o_ovf = align_up(o_heads + 4 * (int64_t)B, 16), in_bytes = o_ovf + 16;
+    char* stage = static_cast<char*>(pinned_in(in_bytes));
+    if (!from_fifo)
+        for (int b = 0; b < B; b++) memcpy(stage + (size_t)b * chunk_floats * sizeof(float), chunks[b], sizeof(float) * chunk_floats);
+    memcpy(stage + o_plen, plens, sizeof(long long) * B);
+    memcpy(stage + o_hyp, hyps, sizeof(long long) * 2 * B);
+    memcpy(stage + o_slots, slots, sizeof(int) * B);
+    memcpy(stage + o_chunks, nchunks, sizeof(int) * B);
+    if (from_fifo) memcpy(stage + o_heads, fifo_heads, sizeof(int) * B);
+    else memset(stage + o_heads, 0, sizeof(int) * B);
+    memset(stage + o_ovf, 0, 16);
+    const int64_t nb_tok = (int64_t)B * Tp * 8, nb_ts = (int64_t)B * Tp * 4, nb_n = (int64_t)B * 4;
     run_sized([&](const Ctx& c) {
         Arena& ar = *c.arena;
-        d_tok = ar.take<long long>((int64_t)B * Tp);
-        d_ts = ar.take<int>((int64_t)B * Tp);
-        d_n = ar.take<int>(B);
-        d_ovf = ar.take<int>(1);
-        float* d_x = ar.take<float>((int64_t)B * T * cf.feat);
-        int* d_slots = ar.take<int>(B);
-        long long* d_plen = ar.take<long long>(B);
-        long long* d_hyp = ar.take<long long>(2 * B);
-        int* d_chunks = ar.take<int>(B);
-        int* d_heads = ar.take<int>(B);
+        // one device block: the inputs, the overflow flag (uploaded as zero: the last 16 bytes of the input part), the outputs right
+        // behind it -- [flag | tokens | timestamps | counts] is the layout finish_tokens downloads in one copy
+        char* d_in = ar.take<char>(in_bytes + nb_tok + nb_ts + nb_n);
+        char* d_out = d_in + in_bytes;
+        d_tok = reinterpret_cast<long long*>(d_out);
+        d_ts = reinterpret_cast<int*>(d_out + nb_tok);
+        d_n = reinterpret_cast<int*>(d_out + nb_tok + nb_ts);
+        d_ovf = reinterpret_cast<int*>(d_in + o_ovf);
+        float* d_x = from_fifo ? ar.take<float>((int64_t)B * T * cf.feat) : reinterpret_cast<float*>(d_in);
+        long long* d_plen = reinterpret_cast<long long*>(d_in + o_plen);
+        long long* d_hyp = reinterpret_cast<long long*>(d_in + o_hyp);
+        int* d_slots = reinterpret_cast<int*>(d_in + o_slots);
+        int* d_chunks = reinterpret_cast<int*>(d_in + o_chunks);
+        int* d_heads = reinterpret_cast<int*>(d_in + o_heads);
         if (!c.dry) {
             K2_HIP(hipEventRecord(ev_[0], c.stream));
-            if (from_fifo) K2_HIP(hipMemcpyAsync(d_heads, stage, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
-            else K2_HIP(hipMemcpyAsync(d_x, stage, sizeof(float) * (size_t)B * T * cf.feat, hipMemcpyHostToDevice, c.stream));
-            K2_HIP(hipMemcpyAsync(d_slots, slots, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
-            K2_HIP(hipMemcpyAsync(d_chunks, nchunks, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
-            K2_HIP(hipMemcpyAsync(d_plen, plens, sizeof(long long) * B, hipMemcpyHostToDevice, c.stream));
-            K2_HIP(hipMemcpyAsync(d_hyp, hyps, sizeof(long long) * 2 * B, hipMemcpyHostToDevice, c.stream));
+            K2_HIP(hipMemcpyAsync(d_in, stage, (size_t)in_bytes, hipMemcpyHostToDevice, c.stream));
         }
         if (from_fifo) fifo_gather(c, online_fifo_, kFifoFrames, cf.feat, d_slots, d_heads, d_x, B, T);
         logfloor_inplace(c, d_x, (long long)B * T * cf.feat);  // online PadSequence (PadHelper.cs:9-13,58)
@@ -498,10 +510,7 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
             int tc = Tp;
             float* enc = cf.lstm ? lstm_chunk(c, d_x, d_slots, B) : cf.zip1 ? zip1_chunk(c, d_x, d_slots, B, &tc) : conformer_chunk(c, d_x, d_slots, d_plen, B, &tc);
             K2_REQUIRE(tc == Tp, "internal: chunk yields %d frames, expected %d", tc, Tp);
-            if (!c.dry) {
-                K2_HIP(hipEventRecord(ev_[3], c.stream));
-                K2_HIP(hipMemsetAsync(d_ovf, 0, sizeof(int), c.stream));
-            }
+            if (!c.dry) K2_HIP(hipEventRecord(ev_[3], c.stream));
             GreedyArgs a;
             a.enc = enc; a.B = B; a.Tp = Tp; a.t0 = nullptr; a.skip1 = 1; a.max_sym = INT_MAX;
             a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = Tp; a.overflow = d_ovf; a.init_ctx = d_hyp;
@@ -511,10 +520,7 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
             return;
         }
         float* enc = online_encoder_zip2(c, d_x, d_slots, d_plen, d_chunks, B);
-        if (!c.dry) {
-            K2_HIP(hipEventRecord(ev_[3], c.stream));
-            K2_HIP(hipMemsetAsync(d_ovf, 0, sizeof(int), c.stream));
-        }
+        if (!c.dry) K2_HIP(hipEventRecord(ev_[3], c.stream));
         if (cf.ctc) {
             // OnlineRecognizer.ForwardBatchGreedySearchCTC (:220-313): per-chunk CTC collapse, prev_id reset per chunk
             ctc_device(c, enc, B, Tp, d_tok, d_ts, d_n, Tp, d_ovf);

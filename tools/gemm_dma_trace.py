@@ -31,7 +31,12 @@ st = t[:, :, :ns]
 life = (st[:, :, -1] - st[:, :, 0]).astype(np.float64)
 t0 = st[:, :, 0].min()
 print(f"{M}x{N}x{K} cfg {cfg}: {nwg.value} workgroups x {nw.value} waves, {ns} stamps; ticks per ns {np.median(life / rt):.3f}; wave lifetime median {np.median(rt) / 1e3:.2f} us")
-print(f"kernel span {st.max() - t0} ticks = {(st.max() - t0) / np.median(life / rt) / 1e3:.2f} us; entry spread {st[:, :, 0].max() - t0}; lifetime mean {life.mean():.0f} min {life.min():.0f} max {life.max():.0f}")
+print(f"wave lifetime (ticks): mean {life.mean():.0f} min {life.min():.0f} max {life.max():.0f}")
+# s_memtime counts per XCD (the bases differ), s_memrealtime (stamps 60 / 63: entry / exit, 10 ns) is chip-wide: launch geometry from it
+e_rt, x_rt = t[:, :, 60].astype(np.float64) * 10.0, t[:, :, 63].astype(np.float64) * 10.0
+z = e_rt.min()
+print("chip-wide (s_memrealtime, us): wave entry p0/p50/p90/p100 " + " ".join(f"{np.percentile(e_rt - z, q) / 1e3:.2f}" for q in (0, 50, 90, 100)) +
+      " | wave exit p0/p10/p50/p100 " + " ".join(f"{np.percentile(x_rt - z, q) / 1e3:.2f}" for q in (0, 10, 50, 100)))
 d = np.diff(st, axis=2)
 nk = min(K // 32, 40)
 print(f"  prologue (entry -> DMA + residual issued)  mean {d[:, :, 0].mean():7.0f}  p95 {np.percentile(d[:, :, 0], 95):7.0f}")
