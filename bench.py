@@ -227,6 +227,9 @@ def main():
     model = pkg.Model(weights, device)  # no fallback: raises without a GPU / library
     if args.beam > 0:
         model.set_decoding_method("modified_beam_search", args.beam)
+    # batches in flight (k2hip.h K2HIP_MAX_BATCHES_IN_FLIGHT = 3): two for the greedy search (it hides under the next encoder); three for
+    # the beam search, whose per-frame launches take longer than an encoder pass when they share the GPU with one
+    depth = 3 if args.beam > 0 else 2
     n_each = int(round(secs * 16000))
     # utterance u is the same signal whichever rank decodes it (seed = u)
     host, dev = [], []
@@ -245,7 +248,7 @@ def main():
         return model.offline_submit_samples(host[i], None) if from_host else model.offline_submit_samples_dev(dev[i], n_each, cnt)
 
     def run_steps(n, from_host=False):
-        """n passes over the rank's batches, software-pipelined two deep: the next batch is submitted before the previous one's
+        """n passes over the rank's batches, software-pipelined `depth` deep: the next batch(es) are submitted before the oldest one's
         tokens are collected, so its encoder (and, from host memory, its H2D copy) overlaps that batch's search.  Every batch's
         tokens are back in host memory before this returns; the last pass's results are returned in utterance order."""
         last = [None] * nb
@@ -257,12 +260,14 @@ def main():
                     last[i] = model.offline_wait(submit(i, from_host))
             return last
         seq = [i for _ in range(n) for i in range(nb)]
-        tk = submit(seq[0], from_host)
-        for k in range(1, len(seq)):
-            nxt = submit(seq[k], from_host)
-            last[seq[k - 1]] = model.offline_wait(tk)
-            tk = nxt
-        last[seq[-1]] = model.offline_wait(tk)
+        pending = []  # (batch index, ticket), oldest first: `depth` batches in flight
+        for k in range(len(seq)):
+            pending.append((seq[k], submit(seq[k], from_host)))
+            if len(pending) == depth:
+                i0, tk = pending.pop(0)
+                last[i0] = model.offline_wait(tk)
+        for i0, tk in pending:
+            last[i0] = model.offline_wait(tk)
         return last
 
     def timed(from_host):
@@ -328,7 +333,8 @@ def main():
                 "utt_seconds": secs,
                 "parallelism": f"utterance-sharded x{world} ({'one rank per GPU, RCCL' if args.dist_backend == 'nccl' else 'gloo rehearsal, ranks share GPUs'}), "
                                "no data-path collective",
-                "pipeline": "synchronous" if args.no_pipeline else "2 batches in flight (search of batch i overlaps encoder of i+1)",
+                "pipeline": "synchronous" if args.no_pipeline else ("2 batches in flight (search of batch i overlaps encoder of i+1)" if depth == 2 else
+                             "3 batches in flight (the beam searches of batches i and i+1 overlap each other and the encoder of i+2)"),
                 "weights": f"seeded random init of the {args.preset} architecture (no checkpoints available)",
             },
             "tokens_emitted_per_step": n_tok,

@@ -173,11 +173,15 @@ int32_t k2hip_offline_greedy_from_samples_dev(k2hip_model_t* model, const float*
                                               int32_t max_tokens);
 
 /* Pipelined form of the same call, for throughput serving: submit() enqueues the batch and
- * returns a ticket, wait() blocks until THAT batch's tokens are in host memory.  Up to two
- * batches may be in flight: the greedy loop of batch i (latency-bound, 32 workgroups) then
- * overlaps the encoder of batch i+1 on a second HIP stream.  Results are identical to the
+ * returns a ticket, wait() blocks until THAT batch's tokens are in host memory.  Up to
+ * K2HIP_MAX_BATCHES_IN_FLIGHT batches may be in flight: with two, the greedy loop of batch i
+ * (latency-bound, 32 workgroups) overlaps the encoder of batch i+1 on a second HIP stream; the
+ * third is for the modified beam search (k2hip_set_beam), whose per-frame launches take longer
+ * than an encoder pass once they share the GPU with one -- the searches of batches i and i+1
+ * then run beside the encoder of batch i+2.  Results are identical to the
  * synchronous call (the reference is synchronous: GetResults returns when the batch is done,
  * OfflineRecognizer.cs:85-91; a host that wants that simply calls wait right after submit). */
+#define K2HIP_MAX_BATCHES_IN_FLIGHT 3
 int32_t k2hip_offline_submit_samples_dev(k2hip_model_t* model, const float* samples_dev, int64_t n_samples_each,
                                          int32_t B, int32_t max_tokens, int32_t* ticket);
 int32_t k2hip_offline_wait(k2hip_model_t* model, int32_t ticket, int64_t* tokens, int32_t* timestamps,

@@ -94,8 +94,11 @@ class Engine {
     // submit() enqueues fbank + pad + encoder on the encoder stream and the greedy loop + D2H
     // on a second stream, then returns; wait() blocks on that batch only.  With two batches in
     // flight the latency-bound greedy loop (32 workgroups) of batch i overlaps the MFMA-bound
-    // encoder of batch i+1.  At most kSlots batches may be outstanding.
-    static constexpr int kSlots = 2;
+    // encoder of batch i+1.  At most kSlots batches may be outstanding.  The third slot is for searches that are LONGER than an
+    // encoder pass once they share the GPU with one (modified beam search: 4 launches per frame, each waiting for workgroup slots
+    // between the encoder's whole-chip launches): every slot's search then runs on the slot's own stream, so the searches of
+    // batches i and i+1 overlap each other and the encoder of batch i+2 (pipe mode 2, automatic with set_beam > 0).
+    static constexpr int kSlots = 3;
     int submit_samples_dev(const float* samples_dev, int64_t n_each, int B, int max_tokens);
     int submit_samples_host(const float* samples_host, int64_t n_each, int B, int max_tokens);
     void wait_ticket(int ticket, int64_t* tokens, int32_t* ts, int32_t* n_tokens);
@@ -240,7 +243,8 @@ class Engine {
     hipStream_t stream2_ = nullptr;
     hipStream_t cur_stream_ = nullptr;  // stream of the call being built (nullptr = stream_)
     // submit/wait overlap: 0 = search of batch i (stream2) under the encoder of batch i+1 (stream); 1 = every slot owns a
-    // stream, so two whole batches run concurrently and each other's GEMM prologues / epilogues / tails are filled
+    // stream, so whole batches run concurrently and each other's GEMM prologues / epilogues / tails are filled; 2 = encoders in
+    // order on `stream`, every slot's search on the slot's stream (chosen by itself for the beam search)
     int pipe_mode_ = 0;
     float* online_pool_ = nullptr;
     float* online_fifo_ = nullptr;  // [online_cap_][kFifoFrames][feat]

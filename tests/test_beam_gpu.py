@@ -83,3 +83,44 @@ def test_beam_search_conformer_large_vocab(hip_conformer, oracle_conformer, utts
     enc = oracle_conformer.encoder(oracle_conformer.pad_sequence(f).reshape(3, -1, 80))
     want, mg = oracle_conformer.modified_beam_search(enc, 4, want_margins=True)
     _check(hip_conformer.beam_search(enc, 4), want, mg, "conformer beam")
+
+
+def test_three_batches_in_flight_with_the_beam_search(tiny_model_path):
+    """k2hip.h K2HIP_MAX_BATCHES_IN_FLIGHT: with the modified beam search every pipeline slot's search runs on the slot's own
+    stream, so three batches may be outstanding (the searches of batches i and i+1 beside the encoder of i+2); greedy search
+    keeps two.  Tokens equal the synchronous call's, tickets may be waited for in any order, a further submit is refused, and
+    switching the method back restores the two-deep pipeline."""
+    from k2transducerasr_amd import K2HipError, Model
+    from k2transducerasr_amd.synth import synth_utterance
+    m = Model(tiny_model_path, 0)
+    B, n = 3, 16000 * 2
+    batches = [np.stack([synth_utterance(900 + 10 * k + u, 2.0)[:n] for u in range(B)]) for k in range(4)]
+    ptrs = []
+    try:
+        for s in batches:
+            p = m.device_alloc(s.nbytes)
+            m.device_upload(p, s)
+            ptrs.append(p)
+        m.set_decoding_method("modified_beam_search", 4)
+        want = [m.offline_greedy_from_samples_dev(p, n, B) for p in ptrs]
+        assert any(len(tok) for r in want for tok, _ in r)
+        t = [m.offline_submit_samples_dev(ptrs[k], n, B) for k in range(3)]
+        with pytest.raises(K2HipError):
+            m.offline_submit_samples_dev(ptrs[3], n, B)
+        assert m.offline_wait(t[1]) == want[1]
+        t3 = m.offline_submit_samples_dev(ptrs[3], n, B)  # the freed slot is found wherever it is
+        assert m.offline_wait(t[0]) == want[0]
+        assert m.offline_wait(t3) == want[3]
+        assert m.offline_wait(t[2]) == want[2]
+        # from host memory too (the copies go on the idle shared stream)
+        th = [m.offline_submit_samples(batches[k], None) for k in range(3)]
+        assert [m.offline_wait(x) for x in th] == want[:3]
+        m.set_decoding_method("greedy_search")
+        g = [m.offline_greedy_from_samples_dev(p, n, B) for p in ptrs[:2]]
+        ta, tb = m.offline_submit_samples_dev(ptrs[0], n, B), m.offline_submit_samples_dev(ptrs[1], n, B)
+        with pytest.raises(K2HipError):
+            m.offline_submit_samples_dev(ptrs[2], n, B)
+        assert m.offline_wait(ta) == g[0] and m.offline_wait(tb) == g[1]
+    finally:
+        for p in ptrs:
+            m.device_free(p)

@@ -94,7 +94,7 @@ def test_full_size_batch_properties(hip_large):
     finally:
         hip_large.device_free(ptr)
     assert r1 == r2
-    # pipelined submit/wait gives the same tokens, in submission order, with two batches in flight
+    # pipelined submit/wait gives the same tokens, in submission order, with two batches in flight (greedy search: two slots)
     ptr2 = hip_large.device_alloc(s.nbytes)
     try:
         hip_large.device_upload(ptr2, s[::-1].copy())
