@@ -175,7 +175,7 @@ int32_t k2hip_offline_greedy_from_samples_dev(k2hip_model_t* model, const float*
 /* Pipelined form of the same call, for throughput serving: submit() enqueues the batch and
  * returns a ticket, wait() blocks until THAT batch's tokens are in host memory.  Up to
  * K2HIP_MAX_BATCHES_IN_FLIGHT batches may be in flight: with two, the greedy loop of batch i
- * (latency-bound, 32 workgroups) overlaps the encoder of batch i+1 on a second HIP stream; the
+ * (latency-bound, a few dozen workgroups) overlaps the encoder of batch i+1 on a second HIP stream; the
  * third is for the modified beam search (k2hip_set_beam), whose per-frame launches take longer
  * than an encoder pass once they share the GPU with one -- the searches of batches i and i+1
  * then run beside the encoder of batch i+2.  Results are identical to the

@@ -93,7 +93,7 @@ class Engine {
     // ---- pipelined (asynchronous) form of offline_greedy_samples_dev ----
     // submit() enqueues fbank + pad + encoder on the encoder stream and the greedy loop + D2H
     // on a second stream, then returns; wait() blocks on that batch only.  With two batches in
-    // flight the latency-bound greedy loop (32 workgroups) of batch i overlaps the MFMA-bound
+    // flight the latency-bound greedy loop (one or two workgroups per stream) of batch i overlaps the MFMA-bound
     // encoder of batch i+1.  At most kSlots batches may be outstanding.  The third slot is for searches that are LONGER than an
     // encoder pass once they share the GPU with one (modified beam search: 4 launches per frame, each waiting for workgroup slots
     // between the encoder's whole-chip launches): every slot's search then runs on the slot's own stream, so the searches of
