@@ -64,6 +64,7 @@ Engine::~Engine() {
     for (auto& e : ev_)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : evpool_) (void)hipEventDestroy(e);
+    if (d_dec_start_) (void)hipFree(d_dec_start_);
     if (pin_) (void)hipHostFree(pin_);
     if (pin_in_) (void)hipHostFree(pin_in_);
     arena_.release();
@@ -471,6 +472,21 @@ float* Engine::encoder_forward(const Ctx& c, const float* x, int B, int T, int* 
     return enc_out;
 }
 
+// The decoder outputs of the two contexts every offline greedy search starts from are constants of the model: computed once (by the
+// search kernel's own routine), then shared by the t0 pre-pass and every search workgroup (a 70 us single-workgroup launch per
+// batch, and two decoder passes at the head of every search workgroup before).
+const float* Engine::decoder_start(const Ctx& c) {
+    if (c.dry) return d_dec_start_;
+    if (!d_dec_start_) {
+        float* p = nullptr;
+        K2_HIP(hipMalloc(&p, sizeof(float) * 2 * (size_t)model_->cfg().J));
+        decoder_start_contexts(c, decjoin(), p);
+        K2_HIP(hipStreamSynchronize(c.stream));  // other streams of this engine read it from now on
+        d_dec_start_ = p;
+    }
+    return d_dec_start_;
+}
+
 // ---------------------------------------------------------------------------
 // greedy search on device
 // ---------------------------------------------------------------------------
@@ -493,13 +509,10 @@ void Engine::greedy_device(const Ctx& c, const float* enc, int B, int Tp, bool s
     DecJoinW w = decjoin();
     int* d_t0 = nullptr;
     if (!c.dry) K2_HIP(hipMemsetAsync(d_overflow, 0, sizeof(int), c.stream));
+    const float* dec_start = decoder_start(c);
     if (!single && B > 1) {
         // parallel pass under the initial context [-1, blank]: which frame is the batch's first emission?
-        long long* d_hyp = ar.take<long long>(2);
-        static const long long h_init[2] = {-1, K2HIP_BLANK_ID};
-        if (!c.dry) K2_HIP(hipMemcpyAsync(d_hyp, h_init, sizeof h_init, hipMemcpyHostToDevice, c.stream));
-        float* dec_a = ar.take<float>(cf.J);
-        decoder(c, w, d_hyp, 1, dec_a);
+        const float* dec_a = dec_start;
         const int N = B * Tp;
         float* act = ar.take<float>((int64_t)N * cf.J);
         tanh_add(c, enc, dec_a, 0, act, N, cf.J);
@@ -515,6 +528,7 @@ void Engine::greedy_device(const Ctx& c, const float* enc, int B, int Tp, bool s
     a.enc = enc; a.B = B; a.Tp = Tp; a.t0 = d_t0; a.skip1 = 0;
     a.max_sym = single ? 1000 : INT_MAX;  // OfflineRecognizer.cs:122
     a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = max_tokens; a.overflow = d_overflow;
+    a.dec_init = dec_start;
     // batch path: rounds of whole-chip GEMMs (they interleave with the next batch's encoder instead of pinning CUs for the whole
     // search); the single-stream path (1000-symbol cap, B = 1) keeps the persistent kernel
     if (!single && tunables().search_rounds == 1) greedy_rounds(c, w, model_->w("joiner.output_linear.weight"), a);

@@ -259,6 +259,8 @@ class Engine {
     int *d_trail_ = nullptr, *d_any_ = nullptr;
     std::vector<int> last_trail_, last_any_;
     float* d_scores_ = nullptr;
+    float* d_dec_start_ = nullptr;  // [2][J]: decoder outputs of the start contexts [-1, blank], [blank, blank] (model constants)
+    const float* decoder_start(const Ctx& c);
     std::vector<float> last_scores_;
     GemmStats stats_;
     k2hip_timing timing_{};

@@ -347,6 +347,9 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
         y1 = a.init_ctx[2 * b + 1];
         own = true;
         decoder_block_wide(w, y0, y1, h, actT, dec_own);
+    } else if (a.dec_init) {
+        for (int k = tid; k < 2 * w.J; k += GT) dec_a[k] = a.dec_init[k];  // dec_a | dec_b are adjacent
+        __syncthreads();
     } else {
         decoder_block_wide(w, -1, K2HIP_BLANK_ID, h, actT, dec_a);
         if (a.t0) decoder_block_wide(w, K2HIP_BLANK_ID, K2HIP_BLANK_ID, h, actT, dec_b);
@@ -522,6 +525,17 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
     if (tid == 0 && part == 0) a.n_tokens[b] = n_tok < a.max_tokens ? n_tok : a.max_tokens;
 }
 
+// decoder outputs of the offline loops' two start contexts, by k_greedy's own routine (so a kernel that loads them computes exactly
+// what it would have computed itself)
+__global__ __launch_bounds__(GT) void k_decoder_start(DecJoinW w, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* scratch = sm;                       // >= 8 max(J, DD)
+    float* h = sm + 8 * max(w.J, w.DD);        // [3 DD]
+    float* o = h + 3 * w.DD;                   // [J]
+    decoder_block_wide(w, blockIdx.x == 0 ? -1 : K2HIP_BLANK_ID, K2HIP_BLANK_ID, h, scratch, o);
+    for (int k = threadIdx.x; k < w.J; k += GT) out[(long long)blockIdx.x * w.J + k] = o[k];
+}
+
 // ---- batched rounds (greedy_rounds) ------------------------------------------------------------------------------
 struct RoundsState {
     const float* enc;         // [B, Tp, J]
@@ -693,6 +707,12 @@ void greedy_rounds(const Ctx& ctx, const DecJoinW& w, const float* out_w, const 
     }
 }
 
+void decoder_start_contexts(const Ctx& ctx, const DecJoinW& w, float* out) {
+    if (ctx.dry) return;
+    const size_t lds = sizeof(float) * (8 * (size_t)std::max(w.J, w.DD) + 3 * (size_t)w.DD + w.J);
+    hipLaunchKernelGGL(k_decoder_start, dim3(2), dim3(GT), lds, ctx.stream, w, out);
+    K2_HIP(hipGetLastError());
+}
 void decoder(const Ctx& ctx, const DecJoinW& w, const long long* y, int N, float* dec_out) {
     if (ctx.dry || N <= 0) return;
     hipLaunchKernelGGL(k_decoder, dim3(N), dim3(256), sizeof(float) * 3 * w.DD, ctx.stream, w, y, dec_out);

@@ -273,6 +273,8 @@ struct DecJoinW {
     int V, Vp, DD, J, ctx;
 };
 void decoder(const Ctx& ctx, const DecJoinW& w, const long long* y, int N, float* dec_out);
+// out[2][J] = the search kernel's own decoder routine on [-1, blank] and [blank, blank] (bit-identical to what k_greedy computes itself)
+void decoder_start_contexts(const Ctx& ctx, const DecJoinW& w, float* out);
 void tanh_add(const Ctx& ctx, const float* enc, const float* dec, int dec_stride, float* y, int N, int J);
 // row argmax with the reference tie-break (later index wins) -> emit flag (token not in {0,2} [,1])
 void argmax_rows(const Ctx& ctx, const float* logits, int ld, int N, int V, int* tok);
@@ -306,6 +308,9 @@ struct GreedyArgs {
     // matrix; per round they exchange their per-frame (max, argmax) through tagged 8-byte granules
     int parts = 1;
     unsigned long long* gran = nullptr;  // [B][2 (round parity)][parts][GF][2], zeroed per call
+    // decoder outputs of the two start contexts [-1, blank] and [blank, blank] ([2][J], from decoder_start_contexts): constants of
+    // the model, so every workgroup of every batch loads them instead of running the decoder twice (null: computed in the kernel)
+    const float* dec_init = nullptr;
 };
 void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a);
 // The same search as batched ROUNDS instead of one persistent workgroup pair per stream: every round evaluates the next S frames
