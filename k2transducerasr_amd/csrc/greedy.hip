@@ -258,7 +258,8 @@ __device__ void gemv_kn_wide(const float* x, int K, const float* __restrict__ W,
 }
 
 // h: LDS [3*DD] (h | stacked embeddings); scratch: LDS >= 8*max(J, DD) floats
-__device__ void decoder_block_wide(const DecJoinW& w, long long y0, long long y1, float* h, float* scratch, float* out) {
+// the decoder's front end (embedding + grouped Conv1d(k = 2) + ReLU) -> h[DD]
+__device__ void decoder_conv_wide(const DecJoinW& w, long long y0, long long y1, float* h, float* scratch) {
     const int tid = threadIdx.x;
     if (w.cpg <= 4) {
         for (int co = tid; co < w.DD; co += GT) {
@@ -287,6 +288,9 @@ __device__ void decoder_block_wide(const DecJoinW& w, long long y0, long long y1
         __syncthreads();
         gemv_kn_wide(xe, 2 * w.DD, w.conv, nullptr, w.DD, scratch, h, true);
     }
+}
+__device__ void decoder_block_wide(const DecJoinW& w, long long y0, long long y1, float* h, float* scratch, float* out) {
+    decoder_conv_wide(w, y0, y1, h, scratch);
     gemv_kn_wide(h, w.DD, w.dproj_kn, w.dproj_b, w.J, scratch, out, false);
 }
 
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ks = lane >> 3, cgl = lane & 7;  // k slice (8 per wave), column group within the wave's 8
     const int G = a.parts, b = blockIdx.x / G, part = blockIdx.x - b * G;
-    unsigned epoch = 0;
+    unsigned epoch = 0, epoch2 = 0;
     if (tid == 0) xf[0] = 0;
     const float* enc = a.enc + (long long)b * a.Tp * w.J;
     const int t0 = a.t0 ? *a.t0 : INT_MAX;
@@ -519,8 +523,59 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
             }
         }
         t += adv;
-        if (emitted) decoder_block_wide(w, y0, y1, h, actT, dec_own);
-        else __syncthreads();  // actT / fin are rewritten by the next round
+        if (emitted && G > 1) {
+            // Every part takes the same decision, so the decoder update is shared out as well: a part computes its J / G outputs of
+            // decoder_proj (the same k slices summed in the same order as gemv_kn_wide: bit-identical values), publishes them as
+            // {emission epoch, value} granules and collects the whole vector.  (Each of the 16 parts of a V = 5537 stream pulling
+            // the whole 1 MB matrix through its CU for every emission was ~40 % of that search.)
+            decoder_conv_wide(w, y0, y1, h, actT);
+            const int ncgJ = w.J >> 2, ca = (part * ncgJ) / G, nc = ((part + 1) * ncgJ) / G - ca, kslice = (w.DD + 7) >> 3;
+            for (int u = tid; u < 8 * nc; u += GT) {
+                const int ksl = u / nc, cgi = u - ksl * nc;
+                const int k0 = ksl * kslice, k1 = min(k0 + kslice, w.DD);
+                float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int kb = k0; kb < k1; kb += 16) {
+                    float4 wv[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) wv[i] = *reinterpret_cast<const float4*>(w.dproj_kn + (long long)min(kb + i, k1 - 1) * w.J + 4 * (ca + cgi));
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const float hv = (kb + i < k1) ? h[kb + i] : 0.f;
+                        sacc.x += hv * wv[i].x; sacc.y += hv * wv[i].y; sacc.z += hv * wv[i].z; sacc.w += hv * wv[i].w;
+                    }
+                }
+                *reinterpret_cast<float4*>(actT + ksl * (4 * nc) + 4 * cgi) = sacc;
+            }
+            __syncthreads();
+            unsigned long long* g2 = a.gran2 + ((long long)b * 2 + (epoch2 & 1)) * w.J;
+            for (int n = tid; n < 4 * nc; n += GT) {
+                float sv = w.dproj_b[4 * ca + n];
+#pragma unroll
+                for (int q = 0; q < 8; q++) sv += actT[q * (4 * nc) + n];
+                store_granule(g2 + 4 * ca + n, epoch2 + 1, __float_as_uint(sv));
+            }
+            epoch2++;
+            bool ok = true;
+            for (int n = tid; n < w.J; n += GT) {
+                unsigned long long x = load_granule(g2 + n);
+                for (unsigned spins = 0; (unsigned)(x >> 32) != epoch2 && spins < kSpinLimit; spins++) {
+                    __builtin_amdgcn_s_sleep(1);
+                    x = load_granule(g2 + n);
+                }
+                ok = ok && (unsigned)(x >> 32) == epoch2;
+                dec_own[n] = __uint_as_float((unsigned)x);
+            }
+            if (!ok) xf[0] = 1;
+            __syncthreads();
+            if (xf[0]) {
+                if (tid == 0) *a.overflow = 2;
+                return;
+            }
+        } else if (emitted) {
+            decoder_block_wide(w, y0, y1, h, actT, dec_own);
+        } else {
+            __syncthreads();  // actT / fin are rewritten by the next round
+        }
     }
     if (tid == 0 && part == 0) a.n_tokens[b] = n_tok < a.max_tokens ? n_tok : a.max_tokens;
 }
@@ -755,18 +810,23 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     if (a0.B <= 0) return;
     GreedyArgs a = a0;
     // parts per stream: enough that a part's slab is about one pass of the workgroup's (GT / 64) * 8 column groups; all B*parts
-    // workgroups must be co-resident (they wait for each other), so stay within half the chip (more parts shorten the search but cost the overlapped encoder more: 22 parts 11.4 / 22.8 ms against 16 parts 12.0 / 21.4 ms search / pipelined step on conformer-zh)
+    // workgroups must be co-resident (they wait for each other), and offline the search runs under the next batch's encoder, which
+    // gets no workgroup onto a CU that hosts one: a quarter of the chip.  Measured, pipelined step / search alone: conformer-zh
+    // (V = 5537, B = 8) 4 parts 25.7 / 22.6 ms, 6: 21.3 / 18.9, 8: 16.7 / 13.9, 10: 18.1 / 14.2, 12: 17.1 / 11.7, 16: 17.05 / 10.0;
+    // zipformer2-large-en (V = 500, B = 32) 1 part 15.13 / 5.45, 2: 14.44 / 3.79, 3: 14.57 / 3.67, 4: 14.56 / 3.35.
     const int ncg = w.Vp >> 2, pass = (GT / 64) * 8;
     const int bc = std::max(a.b_concurrent > 0 ? a.b_concurrent : a.B, 1);
-    // co-residency budget: half the chip offline (the search runs under the next batch's encoder), the whole chip for a streaming
-    // chunk step (nothing else is in flight; one 150 KB workgroup per CU)
-    const int budget = a.init_ctx ? 256 : 128;
+    // co-residency budget: 64 workgroups offline, the whole chip for a streaming chunk step (nothing else is in flight; one 150 KB
+    // workgroup per CU)
+    const int budget = a.init_ctx ? 256 : 64;
     int parts = std::min({(ncg + pass - 1) / pass, kMaxParts, budget / bc});
     if (tunables().greedy_parts > 0) parts = std::max(1, std::min({tunables().greedy_parts, kMaxParts, budget / bc}));  // tuning only
     if (parts < 2 || tunables().greedy_one_part) parts = 1;
     a.parts = parts;
     const size_t gran_words = (size_t)a.B * 2 * parts * GF * 2;
     a.gran = parts > 1 ? ctx.arena->take<unsigned long long>((int64_t)gran_words) : nullptr;
+    const size_t gran2_words = (size_t)a.B * 2 * w.J;
+    a.gran2 = parts > 1 ? ctx.arena->take<unsigned long long>((int64_t)gran2_words) : nullptr;
     if (ctx.dry) return;
     K2_REQUIRE(w.J % 8 == 0, "greedy: joiner_dim %d must be a multiple of 8", w.J);
     K2_REQUIRE(w.DD % 4 == 0 && 8 * w.DD <= w.J * GF, "greedy: decoder_dim %d too wide for the LDS scratch", w.DD);
@@ -775,7 +835,10 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     K2_REQUIRE(lds <= 150 * 1024, "greedy: vocab %d / joiner %d need %zu B of LDS", w.V, w.J, lds);
     static LdsAttrOnce lds_attr;
     lds_attr.ensure(k_greedy, 150 * 1024);
-    if (parts > 1) K2_HIP(hipMemsetAsync(a.gran, 0, sizeof(unsigned long long) * gran_words, ctx.stream));
+    if (parts > 1) {
+        K2_HIP(hipMemsetAsync(a.gran, 0, sizeof(unsigned long long) * gran_words, ctx.stream));
+        K2_HIP(hipMemsetAsync(a.gran2, 0, sizeof(unsigned long long) * gran2_words, ctx.stream));
+    }
     hipLaunchKernelGGL(k_greedy, dim3(a.B * parts), dim3(GT), lds, ctx.stream, w, a);
     K2_HIP(hipGetLastError());
 }

@@ -308,6 +308,7 @@ struct GreedyArgs {
     // matrix; per round they exchange their per-frame (max, argmax) through tagged 8-byte granules
     int parts = 1;
     unsigned long long* gran = nullptr;  // [B][2 (round parity)][parts][GF][2], zeroed per call
+    unsigned long long* gran2 = nullptr;  // [B][2 (emission parity)][J]: the parts' slices of a decoder update, zeroed per call
     // decoder outputs of the two start contexts [-1, blank] and [blank, blank] ([2][J], from decoder_start_contexts): constants of
     // the model, so every workgroup of every batch loads them instead of running the decoder twice (null: computed in the kernel)
     const float* dec_init = nullptr;
