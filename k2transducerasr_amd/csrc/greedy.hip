@@ -117,6 +117,24 @@ __device__ __forceinline__ void amax_wave(float& v, int& i) {
     }
 }
 
+// Data-parallel-primitive lane moves (row = 16 lanes): no LDS crossbar, unlike __shfl_xor's ds_bpermute_b32.  The search kernel's
+// per-round reductions were 288 bpermutes per wave and round: ~11 us of a ~50 us round for the argmax alone.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppRor8 = 0x128;  // quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_ror:8
+// (value, index) max over each aligned group of 8 lanes, result in all 8 (the order of the merges does not matter: a total order)
+__device__ __forceinline__ void amax_8lanes(float& v, int& i) {
+    amax_merge(v, i, dpp_f<kDppXor1>(v), dpp_i<kDppXor1>(i));
+    amax_merge(v, i, dpp_f<kDppXor2>(v), dpp_i<kDppXor2>(i));
+    amax_merge(v, i, dpp_f<kDppHalfMirror>(v), dpp_i<kDppHalfMirror>(i));
+}
+
 // one wave per row; FIRST = false: later index wins ties (transducer loops); true: first index (CTC, Array.IndexOf)
 template <bool FIRST>
 __global__ void k_argmax_rows(const float* __restrict__ logits, int ld, int N, int V, int* __restrict__ tok) {
@@ -421,9 +439,9 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     float v = acc[f][j];
-                    v += __shfl_xor(v, 8);
-                    v += __shfl_xor(v, 16);
-                    v += __shfl_xor(v, 32);
+                    v += dpp_f<kDppRor8>(v);  // lane ^ 8 within the row of 16 (the same operands as __shfl_xor(v, 8))
+                    v += __shfl_xor(v, 16);  // (gfx950's v_permlane16/32_swap do these two without the LDS crossbar -- bit-identical, but no
+                    v += __shfl_xor(v, 32);  // faster here: tools/probes/permlane_swap_probe.hip)
                     acc[f][j] = v;
                 }
             if (valid && ks == 0) {
@@ -438,9 +456,10 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
                 }
             }
         }
+        // only the ks == 0 lanes (lanes 0..7 of the wave) carry candidates: an 8-lane reduction
 #pragma unroll
         for (int f = 0; f < GF; f++) {
-            amax_wave(bestv[f], besti[f]);
+            amax_8lanes(bestv[f], besti[f]);
             if (lane == 0) { redv[wave * GF + f] = bestv[f]; redi[wave * GF + f] = besti[f]; }
         }
         __syncthreads();
