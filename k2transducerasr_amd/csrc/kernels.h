@@ -20,6 +20,7 @@ struct Tunables {
     int conformer_gemm_scores = 0;  // K2HIP_CONFORMER_GEMM_SCORES: two batched GEMMs + gather/softmax
     int dw7_simple = 0;           // K2HIP_DW7_SIMPLE: untiled 7x7 depthwise convolution
     int dw1d_tt = 0;              // K2HIP_DW1D_TT: outputs per thread of the depthwise Conv1d (8 / 4 / 2; 0 = by grid size)
+    int causal_conv_lds = 0;      // K2HIP_CAUSAL_CONV_LDS: the streaming conv modules' depthwise kernel with its column in LDS (any chunk length)
     int dw7_tiled = 0;            // K2HIP_DW7_TILED: the one-shot LDS-tiled form also for long inputs (default: the sliding LDS-DMA form)
     int lstm_seq = 0;             // K2HIP_LSTM_SEQ: layer-by-layer LSTM instead of the layer wavefront
     int greedy_one_part = 0;      // K2HIP_GREEDY_ONE_PART: one workgroup per stream in the search

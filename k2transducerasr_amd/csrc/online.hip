@@ -296,6 +296,64 @@ __global__ __launch_bounds__(64) void k_glu_causal_conv(const float* __restrict_
     }
 }
 
+// The same with the chunk length a compile-time constant too: the lane's whole column (cache + chunk, pad + TC values) stays in
+// registers, the frame loop is unrolled and no value goes through LDS (the LDS form reads one word per FMA: 47 per frame and lane
+// at K = 31).  Same sums in the same order: bit-identical outputs and caches.
+template <int KT, int TC>
+__global__ __launch_bounds__(64) void k_glu_causal_conv_reg(const float* __restrict__ x2, float* __restrict__ pool,
+                                                            long long slot_stride, long long off, const int* __restrict__ slots,
+                                                            const float* __restrict__ wc, const float* __restrict__ bc,
+                                                            const float* __restrict__ ww, const float* __restrict__ bw,
+                                                            const float* __restrict__ sc, float* __restrict__ y, int B, int D) {
+    constexpr int K = KT, pad = K >> 1, Kc = (K + 1) >> 1, Tc = TC;
+    const int c = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
+    if (c >= D) return;
+    float* cache = pool + (long long)slots[b] * slot_stride + off + (long long)c * pad;
+    float col[pad + Tc];
+#pragma unroll
+    for (int r = 0; r < pad; r++) col[r] = cache[r];
+    float xv[Tc], gv[Tc];
+#pragma unroll
+    for (int t = 0; t < Tc; t++) {
+        const float* row = x2 + ((long long)b * Tc + t) * 2 * D;
+        xv[t] = row[c];
+        gv[t] = row[D + c];
+    }
+    float wcr[Kc], wwr[K];
+#pragma unroll
+    for (int k = 0; k < Kc; k++) wcr[k] = wc[c * Kc + k];
+#pragma unroll
+    for (int k = 0; k < K; k++) wwr[k] = ww[c * K + k];
+    const float bcv = bc[c], bwv = bw[c];
+    float le[Tc], re[Tc];
+#pragma unroll
+    for (int t = 0; t < Tc; t++) {
+        if (Tc < K) {
+            le[t] = sc[(long long)c * K + t];
+            re[t] = sc[(long long)D * K + (long long)c * K + (K - Tc) + t];
+        } else {
+            le[t] = t < K ? sc[(long long)c * K + t] : 0.f;
+            re[t] = t >= Tc - K ? sc[(long long)D * K + (long long)c * K + (t - (Tc - K))] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < Tc; t++) col[pad + t] = xv[t] * sigm(gv[t]);
+#pragma unroll
+    for (int r = 0; r < pad; r++) cache[r] = col[Tc + r];  // cache = cat[..., -pad:]
+#pragma unroll
+    for (int t = 0; t < Tc; t++) {
+        float xc = bcv, xw = bwv;
+#pragma unroll
+        for (int k = 0; k < Kc; k++) xc += wcr[k] * col[t + k];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int tt = t + k - pad;
+            if (tt >= 0 && tt < Tc) xw += wwr[k] * col[pad + tt];
+        }
+        y[((long long)b * Tc + t) * D + c] = swoosh_r(xw * (1.0f + (le[t] + re[t])) + xc);
+    }
+}
+
 // ---- device mirror of the feature FIFOs: float4 per lane along the feature dimension (feat % 4 == 0)
 __global__ void k_fifo_append(float* __restrict__ fifo, int cap, int f4, const float* __restrict__ src, const int* __restrict__ slots,
                               const int* __restrict__ pos, int nf) {
@@ -391,6 +449,17 @@ void glu_causal_conv(const Ctx& ctx, const float* x2, float* pool, long long slo
     if (ctx.dry) return;
     size_t lds = sizeof(float) * (K / 2 + Tc) * 64;
     const dim3 grid(cdiv(D, 64), B);
+    if (!tunables().causal_conv_lds) {
+#define K2_GCR(KT, TC)                                                                                                              \
+    if (K == KT && Tc == TC) {                                                                                                      \
+        hipLaunchKernelGGL((k_glu_causal_conv_reg<KT, TC>), grid, dim3(64), 0, ctx.stream, x2, pool, slot_stride, off, slots, wc, bc, ww, bw, \
+                           sc, y, B, D);                                                                                            \
+        K2_HIP(hipGetLastError());                                                                                                  \
+        return;                                                                                                                     \
+    }
+        K2_GCR(31, 16) K2_GCR(31, 8) K2_GCR(31, 4) K2_GCR(31, 2) K2_GCR(15, 16) K2_GCR(15, 8) K2_GCR(15, 4) K2_GCR(15, 2)
+#undef K2_GCR
+    }
 #define K2_GCC(KT) hipLaunchKernelGGL(k_glu_causal_conv<KT>, grid, dim3(64), lds, ctx.stream, x2, pool, slot_stride, off, slots, wc, bc, ww, bw, sc, y, B, Tc, D, K)
     switch (K) {
         case 31: K2_GCC(31); break;

@@ -30,6 +30,7 @@ const Entry kEntries[] = {
     {"K2HIP_CONFORMER_GEMM_SCORES", &Tunables::conformer_gemm_scores, true},
     {"K2HIP_DW7_SIMPLE", &Tunables::dw7_simple, true},
     {"K2HIP_DW7_TILED", &Tunables::dw7_tiled, true},
+    {"K2HIP_CAUSAL_CONV_LDS", &Tunables::causal_conv_lds, true},
     {"K2HIP_DW1D_TT", &Tunables::dw1d_tt, false},
     {"K2HIP_LSTM_SEQ", &Tunables::lstm_seq, true},
     {"K2HIP_GREEDY_ONE_PART", &Tunables::greedy_one_part, true},
