@@ -410,19 +410,24 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
             if (valid) {
                 const float* wp = w.out_kn + (long long)(ks * kper) * w.Vp + 4 * cg;
                 const float* ap = actT + (ks * kper) * GF + ks * APAD;
+                const bool whole = kper % GL == 0;  // (J / 8 a multiple of GL: no clamped rows, no masks -- J = 512: 64 / 8)
                 for (int kb = 0; kb < kper; kb += GL) {
                     // GL weight loads in flight per thread before any FMA: the sweep is L2-latency bound
                     float4 wv[GL];
 #pragma unroll
                     for (int i = 0; i < GL; i++)
-                        wv[i] = *reinterpret_cast<const float4*>(wp + (long long)min(kb + i, kper - 1) * w.Vp);
+                        wv[i] = *reinterpret_cast<const float4*>(wp + (long long)(whole ? kb + i : min(kb + i, kper - 1)) * w.Vp);
 #pragma unroll
                     for (int i = 0; i < GL; i++) {
-                        const int k = min(kb + i, kper - 1);
-                        const float m = (kb + i < kper) ? 1.f : 0.f;
+                        const int k = whole ? kb + i : min(kb + i, kper - 1);
+                        const float m = (whole || kb + i < kper) ? 1.f : 0.f;
                         const float4 a0 = *reinterpret_cast<const float4*>(ap + k * GF);
                         const float4 a1 = *reinterpret_cast<const float4*>(ap + k * GF + 4);
-                        const float av[GF] = {a0.x * m, a0.y * m, a0.z * m, a0.w * m, a1.x * m, a1.y * m, a1.z * m, a1.w * m};
+                        float av[GF] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                        if (!whole) {
+#pragma unroll
+                            for (int f = 0; f < GF; f++) av[f] *= m;
+                        }
 #pragma unroll
                         for (int f = 0; f < GF; f++) {
                             acc[f][0] += av[f] * wv[i].x;
