@@ -74,7 +74,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the second timing with samples in host memory")
     ap.add_argument("--no-pipeline", action="store_true", help="one synchronous call per batch (no batch overlap)")
-    ap.add_argument("--cpu-utts", type=int, default=32)
+    ap.add_argument("--cpu-utts", type=int, default=0, help="utterances of the CPU-baseline sample (default: one batch)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the bounded configs[2] / [3] / [4] legs that follow the headline run on one GPU")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal of the N > 1 path on one GPU)")
     ap.add_argument("--beam", type=int, default=0, help="0 = greedy_search (headline metric); K = modified_beam_search with beam K (BASELINE configs[2])")
     ap.add_argument("--depth", type=int, default=0, help="batches in flight (0: 2, or 3 with --beam; 3 needs K2HIP_PIPE_MODE=2 for the greedy search)")
@@ -126,9 +127,10 @@ def ensure_weights(path, preset, rank, barrier):
     barrier()
 
 
-def cpu_baseline(weights, n_utts, seconds):
-    """The CPU restatement (oracle/, 'port') of the same path on this box's host cores,
-    on a bounded sample of the same workload."""
+def cpu_baseline(weights, n_utts, seconds, beam=0):
+    """The CPU restatement (oracle/, 'port') of the same path on this box's host cores, on a bounded sample of the same workload:
+    the first `n_utts` utterances as ONE GetResults batch.  Returns the baseline record and the oracle's (tokens, timestamps) per
+    utterance, which the caller holds against what the GPU returned for the same batch (`oracle_match`)."""
     from k2transducerasr_amd.synth import synth_utterance
     from oracle import Oracle
 
@@ -139,6 +141,9 @@ def cpu_baseline(weights, n_utts, seconds):
 
     def run():
         feats = [ora.fbank(u) for u in utts]
+        if beam > 0:   # icefall modified_beam_search over the oracle's own encoder output (oracle/k2_oracle_beam.c)
+            x = ora.pad_sequence(feats).reshape(len(feats), -1, ora.feature_dim)
+            return ora.modified_beam_search(ora.encoder(x), beam)
         return ora.recognize_batch(feats)
 
     run_one = [synth_utterance(0, 1.0)]
@@ -152,8 +157,59 @@ def cpu_baseline(weights, n_utts, seconds):
         "cores": cores,
         "kind": "port",
         "sample": f"{n_utts} x {seconds:g} s utterances of the same synthetic workload as one batch through oracle/ "
-                  f"(C + OpenMP restatement; the reference's ONNXRuntime path cannot run here), {dt:.2f} s wall",
+                  f"(C + OpenMP restatement{', modified beam search beam=%d' % beam if beam else ''}; the reference's ONNXRuntime path cannot run here), {dt:.2f} s wall",
     }, res
+
+
+def pmc_mfma_busy():
+    """MFMA-pipe utilisation of the GEMM kernels from the committed rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES against
+    SQ_BUSY_CU_CYCLES; counters need their own profiler run, so this cannot be read live)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_mfma_busy.json")))
+    if not files:
+        return None, "no MFMA PMC summary under profiles/"
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return d["mfma_busy"], f"from {os.path.relpath(files[-1], ROOT)}: {d['method']}"
+
+
+def run_secondary(timeout_s=240):
+    """Bounded legs for BASELINE configs[2], [3], [4] (one GPU's share each), run as child programs AFTER the headline model has
+    been closed, one at a time; each child prints its own JSON line (with its own cpu_baseline and oracle_match), condensed here."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    legs = {
+        "beam4_c2_shard": [sys.executable, os.path.join(here, "bench.py"), "--beam", "4", "--steps", "6", "--warmup", "2",
+                           "--no-host-leg", "--no-secondary"],
+        "conformer_zh_c4_shard": [sys.executable, os.path.join(here, "bench.py"), "--preset", "conformer-zh", "--batch", "8",
+                                  "--seconds", "30", "--steps", "6", "--warmup", "2", "--no-host-leg", "--no-secondary"],
+        "streaming_c3": [sys.executable, os.path.join(here, "bench_streaming.py"), "--check", "8"],
+    }
+    out = {}
+    for name, cmd in legs.items():
+        t = time.time()
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if not line:
+                out[name] = {"error": f"exit {p.returncode}: {p.stderr[-400:]}"}
+                continue
+            d = json.loads(line[-1])
+            out[name] = {
+                "metric": d["metric"], "value": d["value"], "unit": d["unit"],
+                "ms_per_step": d.get("ms_per_step", d.get("ms_per_chunk_step")),
+                "workload": d["config"]["workload"],
+                "roofline": {k: d["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac") if k in d.get("roofline", {})},
+                "cpu_baseline": d.get("cpu_baseline"),
+                "oracle_match": d.get("oracle_match"),
+                "emission_rate": d.get("emission_rate"),
+                "exit_code": p.returncode,
+                "wall_s": round(time.time() - t, 1),
+            }
+            if "tick" in d.get("roofline", {}):
+                out[name]["roofline"]["tick_frac_of_mfma_peak"] = d["roofline"]["tick"]["frac_of_mfma_peak"]
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": f"timed out after {timeout_s} s"}
+    return out
 
 
 def baseline_config_of(args, world, total):
@@ -303,6 +359,7 @@ def main():
         it = model.timing()
         model.set_instrument(False)
 
+    bad_match = False
     if rank == 0:
         assert len(allres) == total, f"gathered {len(allres)} results for {total} utterances"
         audio = args.steps * total * secs
@@ -361,19 +418,38 @@ def main():
                 "all_matrix_flops_per_batch": it["total_flops"],
             }
             out["stages_ms_one_synchronous_batch"] = {k: round(stages[k], 3) for k in ("total_ms", "fbank_ms", "pad_ms", "encoder_ms", "greedy_ms", "d2h_ms")}
+            mb, mb_note = pmc_mfma_busy() if default_workload else (None, "PMC passes exist for the default workload only")
+            out["roofline"]["mfma_busy"] = mb
+            out["roofline"]["mfma_busy_note"] = mb_note
         if world == 1 and not args.no_cpu_baseline:
-            cb, _ = cpu_baseline(weights, args.cpu_utts, secs)
+            n_cpu = args.cpu_utts or my_batches[0][1]
+            cb, ores = cpu_baseline(weights, n_cpu, secs, args.beam)
             out["cpu_baseline"] = cb
+            # the oracle's results for the sample against what the timed legs returned for the same batch (outside the timed region)
+            if my_batches[0] == (0, n_cpu):
+                exact = sum(1 for g, w in zip(allres[:n_cpu], ores) if [list(g[0]), list(g[1])] == [list(w[0]), list(w[1])])
+                out["oracle_match"] = {"streams": n_cpu, "exact": exact,
+                                       "what": "tokens and timestamps of the timed legs' first batch == oracle/ on the same batch"}
+                bad_match = exact < n_cpu
+            else:
+                out["oracle_match"] = {"streams": 0, "exact": 0, "what": "the CPU sample is not one of the timed batches"}
         if args.dump_results:
             with open(args.dump_results, "w") as f:
                 json.dump({"results": allres, "batches_per_rank": nb, "n_gpus": world}, f)
-        print(json.dumps(out), flush=True)
     for h, d in zip(host, dev):
         model.device_free(d)
         model.host_free(h)
     model.close()
+    if rank == 0:
+        if world == 1 and default_workload and not args.no_secondary:
+            out["secondary"] = run_secondary()   # the GPU is free again: one child program per leg
+            bad_match = bad_match or any(("error" in v) or v.get("exit_code") for v in out["secondary"].values())
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0 and bad_match:
+        log("[bench] oracle_match failed (or a secondary leg failed): see the JSON line")
+        sys.exit(5)
 
 
 if __name__ == "__main__":

@@ -18,7 +18,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def cpu_baseline(weights, n_streams, seconds):
     """The CPU restatement (oracle/k2_oracle_online.c, 'port') of the same streaming path on this box's host cores, on a
-    bounded sample: n_streams concurrent streams of `seconds` s each (+ the 30 x 400 zero tail), one batched step per chunk."""
+    bounded sample: the first n_streams streams of the workload, `seconds` s each (+ the 30 x 400 zero tail), one batched step per
+    chunk.  Returns the record and each stream's token list (compared with the GPU's for the same streams by the caller)."""
     from k2transducerasr_amd.synth import synth_utterance
     from oracle.online import OnlineOracle
 
@@ -42,7 +43,7 @@ def cpu_baseline(weights, n_streams, seconds):
         "sample": f"{n_streams} concurrent streams x {seconds:g} s of the same synthetic workload ({k} chunk steps) through oracle/ "
                   f"(C + OpenMP restatement of fbank + the streaming encoder + the online greedy loop; the reference's ONNXRuntime path "
                   f"cannot run here), {dt:.2f} s wall",
-    }
+    }, [(o.tokens, o.timestamps) for o in ss]
 
 
 def main():
@@ -50,7 +51,8 @@ def main():
     ap.add_argument("--streams", type=int, default=128)
     ap.add_argument("--seconds", type=float, default=20.0)
     ap.add_argument("--preset", default="zipformer2-streaming-zh")
-    ap.add_argument("--check", type=int, default=0, help="verify the first K streams against the CPU oracle")
+    ap.add_argument("--check", type=int, default=0, help="verify the first K streams (tokens and timestamps) against the CPU oracle: the "
+                    "CPU-baseline sample then IS those K streams at full length, and the line carries oracle_match")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-streams", type=int, default=8, help="streams of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="audio seconds per stream of the CPU-baseline sample")
@@ -113,7 +115,7 @@ def main():
     audio = N * args.seconds
     t = rec.model.timing()
     tokens = int(sum(len(s.tokens) - 2 for s in streams))
-    checked_tokens = [streams[u].tokens for u in range(args.check)]
+    checked = [(streams[u].tokens, streams[u].timestamps) for u in range(args.check)]
     for s in streams:
         s.close()
 
@@ -174,7 +176,19 @@ def main():
                      "state_bytes_per_stream": 4 * state_floats, "weight_bytes": weight_bytes},
         },
     }
-    if args.check:
+    bad = False
+    if args.check and "conformer" not in args.preset and "lstm" not in args.preset:
+        # Zipformer streams are independent of their batch mates: the oracle steps the K checked streams as one batch (that run is
+        # also the CPU baseline), and every token and timestamp must equal what the GPU gave the same streams among the other N - K
+        cb, want = cpu_baseline(weights, args.check, args.seconds)
+        exact = sum(1 for g, w in zip(checked, want) if g == w)
+        out["oracle_match"] = {"streams": args.check, "exact": exact,
+                               "what": "tokens and timestamps of the timed run's first streams == oracle/ on the same streams"}
+        out["oracle_checked_streams"] = args.check
+        bad = exact < args.check
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cb
+    elif args.check:
         from oracle.online import OnlineOracle
         ora = OnlineOracle(weights)
         for u in range(args.check):
@@ -183,11 +197,14 @@ def main():
             o = ora.create_stream()
             for k in range((f.shape[0] - rec.chunk_length) // rec.shift_length + 1):
                 ora.step([o], [f[k * rec.shift_length : k * rec.shift_length + rec.chunk_length]])
-            assert o.tokens == checked_tokens[u], f"stream {u} differs from the oracle"
+            assert o.tokens == checked[u][0], f"stream {u} differs from the oracle"
         out["oracle_checked_streams"] = args.check
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(weights, args.cpu_streams, args.cpu_seconds)
+    if "cpu_baseline" not in out and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(weights, args.cpu_streams, args.cpu_seconds)[0]
     print(json.dumps(out), flush=True)
+    if bad:
+        print("[bench_streaming] oracle_match failed", file=sys.stderr)
+        sys.exit(5)
 
 
 if __name__ == "__main__":

@@ -31,6 +31,11 @@
 
 #include "kernels.h"
 
+// The LDS-DMA inline asm of the pipelined kernels writes M0 (the LDS destination) and SCC (s_add_u32) and says so in its clobber
+// list.  M0 is a reserved register for the compiler, which is why clang remarks on seeing it there; the declaration is still what
+// keeps the backend from carrying an M0 / SCC value of its own across the statement.
+#pragma clang diagnostic ignored "-Winline-asm"
+
 namespace k2hip {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -689,7 +694,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
         asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                    \
                      :                                                                                                     \
                      : "v"(voff[q_]), "s"(src_), "s"(mq[q_]), "n"((ST_) * STAGE * 4)                                       \
-                     : "memory");                                                                                          \
+                     : "memory", "m0", "scc");                                                                                          \
     }
 // fragments of k group G_ of stage ST_ into register set SET_ (the 32-row blocks of the wave tile: 32 * BK floats apart -> the
 // instruction's immediate offset)
@@ -962,7 +967,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
         asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                    \
                      :                                                                                                     \
                      : "v"(voff[q_]), "s"(src_), "s"(mq[q_]), "n"((ST_) * STAGE * 4)                                       \
-                     : "memory");                                                                                          \
+                     : "memory", "m0", "scc");                                                                                          \
     }
 #define K2_P16_READ(SET_, ST_, G_)                                                                                         \
     {                                                                                                                      \

@@ -129,6 +129,37 @@ def test_conformer_zh_full_size_properties(hip_zh):
     assert sum(len(t) for t, _ in r1) > 0
 
 
+def test_conformer_zh_full_size_matches_oracle(hip_zh, oracle_zh):
+    """BASELINE configs[4] per-GPU shard at its own size against the oracle, strictly: 8 x 30 s -> T = 3017, T' = 753, V = 5537
+    (6 024 argmax decisions over 16 column slabs per stream).  Fused entry (synchronous and pipelined) against `recognize_batch`;
+    two rows of the encoder output (5e-4) and their logits (1e-3)."""
+    from k2transducerasr_amd.synth import synth_utterance
+    B = 8
+    s = np.stack([synth_utterance(400 + u, 30.0) for u in range(B)])
+    feats = [oracle_zh.fbank(s[b]) for b in range(B)]
+    x = oracle_zh.pad_sequence(feats).reshape(B, -1, 80)
+    enc_o = oracle_zh.encoder(x)
+    want, mg = oracle_zh.greedy_batch(enc_o, want_margins=True)
+    assert sum(len(w[0]) for w in want) > 8 * 753 // 20
+    assert_tokens_match(hip_zh.offline_greedy_from_samples(list(s)), want, mg, what="configs[4] shard full size, synchronous")
+    ptr = hip_zh.device_alloc(s.nbytes)
+    try:
+        hip_zh.device_upload(ptr, s)
+        ta = hip_zh.offline_submit_samples_dev(ptr, s.shape[1], B)
+        tb = hip_zh.offline_submit_samples_dev(ptr, s.shape[1], B)
+        assert_tokens_match(hip_zh.offline_wait(ta), want, mg, what="configs[4] shard full size, pipelined slot 0")
+        assert_tokens_match(hip_zh.offline_wait(tb), want, mg, what="configs[4] shard full size, pipelined slot 1")
+    finally:
+        hip_zh.device_free(ptr)
+    enc_h = hip_zh.encoder_proj(x)
+    dec = oracle_zh.decoder(np.array([[-1, 0]], np.int64))
+    for b in (0, 5):
+        np.testing.assert_allclose(enc_h[b], enc_o[b], atol=5e-4, rtol=0)
+        lo = oracle_zh.joiner(enc_o[b], np.repeat(dec, enc_o.shape[1], 0))
+        lh = hip_zh.joiner_proj(enc_h[b], np.repeat(dec, enc_o.shape[1], 0))
+        assert float(np.abs(lo - lh).max()) < LOGIT_TOL
+
+
 # ---------------------------------------------------------------- streaming (OnlineProjOfConformer)
 def test_streaming_conformer_matches_oracle(tmp_path_factory):
     """chunk_forward on the GPU against the oracle: tokens, timestamps, hyp, every cache, and the reference's processed_lens

@@ -119,6 +119,49 @@ def test_full_size_batch_properties(hip_large):
         assert all(t not in (0, 2) and 0 < t < 500 for t in tok)
 
 
+def test_full_size_matches_oracle(hip_large, oracle_large):
+    """BASELINE configs[1] at its own size against the oracle, strictly: B = 32 x 10 s (8 096 argmax decisions, ~1 600 emissions per
+    batch; OfflineRecognizer.cs:189-303).  The large grids select kernel paths the short-utterance tests never reach (128 x 128
+    tiles, GLU epilogue on >= 256-row stacks, two-slab search, pipeline slots), so the property tests alone cannot see a
+    wrong-but-deterministic path.  Synchronous entry AND pipelined submit / wait (device-resident and host-memory samples) against
+    `recognize_batch`; three rows of the encoder output (5e-4) and their joiner logits (north-star 1e-3)."""
+    from k2transducerasr_amd.synth import synth_utterance
+    B = 32
+    s = np.stack([synth_utterance(u, 10.0) for u in range(B)])
+    feats = [oracle_large.fbank(s[b]) for b in range(B)]
+    want = oracle_large.recognize_batch(feats)
+    assert sum(len(w[0]) for w in want) > 32 * 253 // 10          # the calibrated ~20 % emission rate: a real token load
+    ptr = hip_large.device_alloc(s.nbytes)
+    try:
+        hip_large.device_upload(ptr, s)
+        got = hip_large.offline_greedy_from_samples_dev(ptr, s.shape[1], B)
+        assert_tokens_match(got, want, what="configs[1] full size, synchronous")
+        ta = hip_large.offline_submit_samples_dev(ptr, s.shape[1], B)
+        tb = hip_large.offline_submit_samples_dev(ptr, s.shape[1], B)
+        assert_tokens_match(hip_large.offline_wait(ta), want, what="configs[1] full size, pipelined slot 0")
+        assert_tokens_match(hip_large.offline_wait(tb), want, what="configs[1] full size, pipelined slot 1")
+    finally:
+        hip_large.device_free(ptr)
+    h = hip_large.host_alloc(s.shape)
+    try:
+        h[:] = s
+        assert_tokens_match(hip_large.offline_wait(hip_large.offline_submit_samples(h)), want, what="configs[1] full size, from host memory")
+    finally:
+        hip_large.host_free(h)
+    # encoder output of the whole batch through the full-size grids, three rows against the oracle
+    x = oracle_large.pad_sequence(feats).reshape(B, -1, 80)
+    assert x.shape[1] == 1017
+    enc_h = hip_large.encoder_proj(x)
+    rows = (0, 13, 31)
+    enc_o = oracle_large.encoder(x[list(rows)])   # rows are independent (Q3), so the oracle needs only these three
+    dec = oracle_large.decoder(np.array([[-1, 0]], np.int64))
+    for i, b in enumerate(rows):
+        np.testing.assert_allclose(enc_h[b], enc_o[i], atol=5e-4, rtol=0)
+        lo = oracle_large.joiner(enc_o[i], np.repeat(dec, enc_o.shape[1], 0))
+        lh = hip_large.joiner_proj(enc_h[b], np.repeat(dec, enc_o.shape[1], 0))
+        assert float(np.abs(lo - lh).max()) < LOGIT_TOL
+
+
 def test_long_utterances_beyond_the_lds_strip(hip_tiny, oracle_tiny, hip_conformer, oracle_conformer):
     """Attention for sequences longer than the in-LDS score strip (Zipformer2: > ~1120 frames at 50 Hz, i.e. > 22 s; Conformer:
     > 2048 frames at 25 Hz) takes the two-pass kernels; same numbers, no length limit."""
@@ -194,3 +237,30 @@ def test_full_size_beam4_properties(hip_large):
         assert len(tok) == len(ts) and all(0 <= t < 253 for t in ts) and ts == sorted(ts)
         assert all(t not in (0, 2) and 0 < t < 500 for t in tok)      # blank / unk never enter ys
     assert np.isfinite(sc1).all() and (sc1 < 0).all()                 # log-probabilities
+
+
+def test_full_size_beam4_matches_oracle(hip_large, oracle_large):
+    """One GPU's shard of configs[2] at its own size against the oracle: 32 x 10 s, beam 4 -- tokens and timestamps exact, scores
+    within 2e-3 (sums of <= 253 log-probabilities whose logits carry the 1e-3 tolerance), through the fused samples -> tokens
+    entry and the three-slot pipeline."""
+    from parity import assert_beam_match
+    from k2transducerasr_amd.synth import synth_utterance
+    B = 32
+    s = np.stack([synth_utterance(u, 10.0) for u in range(B)])
+    feats = [oracle_large.fbank(s[b]) for b in range(B)]
+    enc_o = oracle_large.encoder(oracle_large.pad_sequence(feats).reshape(B, -1, 80))
+    want, mg, sc = oracle_large.modified_beam_search(enc_o, 4, want_margins=True, want_scores=True)
+    assert sum(len(w[0]) for w in want) > 32 * 253 // 10
+    ptr = hip_large.device_alloc(s.nbytes)
+    hip_large.set_decoding_method("modified_beam_search", 4)
+    try:
+        hip_large.device_upload(ptr, s)
+        got = hip_large.offline_greedy_from_samples_dev(ptr, s.shape[1], B)
+        assert_beam_match(got, want, mg, what="configs[2] shard full size, synchronous")
+        np.testing.assert_allclose(hip_large.last_scores(B), sc, atol=2e-3, rtol=0)
+        tk = [hip_large.offline_submit_samples_dev(ptr, s.shape[1], B) for _ in range(3)]
+        for i, t in enumerate(tk):
+            assert_beam_match(hip_large.offline_wait(t), want, mg, what=f"configs[2] shard full size, pipelined slot {i}")
+    finally:
+        hip_large.set_decoding_method("greedy_search")
+        hip_large.device_free(ptr)

@@ -282,6 +282,47 @@ def test_streaming_128_concurrent_slots_zh(tmp_path_factory):
         a.close()
 
 
+def test_streaming_128_slots_16_streams_against_oracle_zh(tmp_path_factory):
+    """BASELINE configs[3] at its own size, more of it held to the oracle: 128 concurrent streams of the zh streaming architecture,
+    16 DISTINCT utterances (slots 0..15) each followed chunk by chunk by its own oracle stream over 7 chunks -- tokens, timestamps,
+    Hyp after every tick, every cache of three layers at the end -- while the other 112 slots carry copies that must agree exactly
+    with their originals (OnlineRecognizer.cs:85-219, one GetResults call per tick)."""
+    from k2transducerasr_amd import OnlineRecognizer
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    from oracle.online import OnlineOracle
+    p = str(tmp_path_factory.mktemp("szh128b") / "szh.k2w")
+    write_synthetic_model(p, "zipformer2-streaming-zh")
+    rec, ora = OnlineRecognizer(p), OnlineOracle(p)
+    N, DISTINCT = 128, 16
+    T, S = rec.chunk_length, rec.shift_length
+    base = [ora.fbank(synth_utterance(900 + u, 2.5)) for u in range(DISTINCT)]
+    nchunks = (base[0].shape[0] - T) // S + 1
+    assert nchunks >= 6
+    feats = [base[u % DISTINCT] for u in range(N)]
+    hs = [rec.create_online_stream() for _ in range(N)]
+    for h, f in zip(hs, feats):
+        h.add_features(f)
+    os_ = [ora.create_stream() for _ in range(DISTINCT)]
+    group = rec.batch(hs)
+    for k in range(nchunks):
+        dec, n_new = rec.get_results(group)
+        assert dec == [1] * N
+        want = ora.step(os_, [base[u][k * S : k * S + T] for u in range(DISTINCT)])
+        for u, o in enumerate(os_):
+            assert n_new[u] == want[u], (k, u)
+            assert hs[u].tokens == o.tokens and hs[u].timestamps == o.timestamps and hs[u].hyp == o.hyp, (k, u)
+    import parity
+    parity.COMPARED[0] += DISTINCT
+    assert sum(len(h.tokens) - 2 for h in hs[:DISTINCT]) > DISTINCT
+    for u in (0, 7, 15):
+        for l in (0, 8, 15):
+            for kind in KINDS:
+                np.testing.assert_allclose(hs[u].state(l, kind), os_[u].state(l, kind), atol=5e-4, rtol=0)
+    for u in range(DISTINCT, N):
+        r = u % DISTINCT
+        assert hs[u].tokens == hs[r].tokens and hs[u].timestamps == hs[r].timestamps, u
+
+
 @pytest.mark.parametrize("split", [2, 3, 4])
 def test_split_chunk_step_equals_single_stream_step(stream_model_path, ora, split):
     """A chunk step over many streams can be enqueued as sub-batches on their own HIP streams (K2HIP_ONLINE_SPLIT = 2..4; off by
