@@ -35,7 +35,11 @@ extern "C" {
 #define K2HIP_ERR_INVALID (-1)   /* bad argument / shape */
 #define K2HIP_ERR_IO (-2)        /* weight file missing or malformed */
 #define K2HIP_ERR_NO_DEVICE (-3) /* no usable HIP device */
-#define K2HIP_ERR_HIP (-4)       /* a HIP runtime call failed */
+#define K2HIP_ERR_HIP (-4)       /* a HIP runtime call failed.  Also: the greedy search's vocabulary-parallel exchange timed out TWICE -- its
+                                  * workgroups wait for each other and need to be resident together; on a timeout (a GPU shared with other
+                                  * processes / models) the library repeats the search with one workgroup per stream, which waits for nobody,
+                                  * so a call under load gets slower instead of failing; only if that repeat also reports a timeout (it cannot,
+                                  * short of a device fault) does the call return this code */
 #define K2HIP_ERR_CAPACITY (-5)  /* caller buffer too small */
 #define K2HIP_ERR_UNSUPPORTED (-6)
 
@@ -314,7 +318,10 @@ int32_t k2hip_online_stream_is_finished(k2hip_online_stream_t* s, int32_t is_end
  * every stream with a full chunk buffered (GetDecodeChunk :82-100) is decoded for that chunk
  * (RemoveChunk :102-117 drops ShiftLength frames), its Hyp / Tokens / Timestamps / caches are updated;
  * decoded[i] = 1 for those, 0 for streams that had no chunk (the reference removes them from the
- * caller's list, :117-120); n_new_tokens[i] = symbols emitted in this chunk. */
+ * caller's list, :117-120); n_new_tokens[i] = symbols emitted in this chunk.
+ * On failure no stream's host-side state has moved (no chunk removed, no token appended), but the DEVICE caches of the streams
+ * that were being decoded may have advanced in place; those streams are marked and every later k2hip_online_step that names one
+ * returns K2HIP_ERR_INVALID until k2hip_online_stream_reset -- the same chunk is never fed into caches that already moved. */
 int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* streams, int32_t B, int32_t* decoded,
                           int32_t* n_new_tokens);
 /* the stream's processed_lens state as the reference holds it between steps (Zipformer2: frames consumed; Conformer: 2 at
@@ -330,7 +337,9 @@ int32_t k2hip_online_state_destroy(k2hip_online_state_t* state);
 int64_t k2hip_online_state_processed_len(const k2hip_online_state_t* state);
 /* EncoderProj (OnlineProjOfZipformer2.cs:491-618): feats [B, ChunkLength, FeatureDim] raw fbank frames (OnlineInputEntity.Speech of
  * each stream's GetDecodeChunk), encoder_out [B, T', joiner_dim] (T' = k2hip_online_chunk_info's frames_per_chunk).  Decoder and
- * joiner are k2hip_decoder / k2hip_joiner.  K2HIP_ERR_CAPACITY if cap_floats is too small; nothing advances on failure. */
+ * joiner are k2hip_decoder / k2hip_joiner.  K2HIP_ERR_CAPACITY if cap_floats is too small (checked before any work: nothing
+ * advances).  If the device work itself fails, processed_lens does not advance but the states' caches may have been updated in
+ * place: those states are marked, later calls that name one return K2HIP_ERR_INVALID; destroy and re-create them. */
 int32_t k2hip_online_encoder(k2hip_model_t* model, k2hip_online_state_t* const* states, int32_t B, const float* feats, float* encoder_out,
                              int64_t cap_floats);
 

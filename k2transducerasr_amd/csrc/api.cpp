@@ -48,6 +48,10 @@ struct k2hip_online_stream {
     // outgrow the ring; the step then reads `speech` as before, and the mirror is valid again once the FIFO has drained.
     bool mir_ok = true;
     int mir_head = 0;
+    // A chunk step that failed part-way (a HIP error) may already have advanced the slot's convolution / embed caches in place (the
+    // attention rings are idempotent: their position comes from chunks_done); feeding the same chunk again would then silently
+    // corrupt the transcript.  Such a stream refuses every further step until k2hip_online_stream_reset.
+    bool poisoned = false;
 };
 
 // one stream's encoder caches as the operator-level API sees them (IOnlineProj's List<List<float[]>>): a slot of the device pool
@@ -57,6 +61,7 @@ struct k2hip_online_state {
     int slot = -1;
     long long processed_len = 0;
     long long chunks_done = 0;
+    bool poisoned = false;  // as k2hip_online_stream::poisoned: a failed EncoderProj leaves the caches undefined; destroy and re-create
 };
 
 namespace {
@@ -142,7 +147,7 @@ int32_t k2hip_model_meta(const k2hip_model_t* model, const char* key, char* buf,
 int32_t k2hip_get_gemm_profile(k2hip_model_t* model, float* rows, int32_t cap_rows, int32_t* n_rows) {
     return guard([&] {
         NEED(model); NEED(n_rows);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         const auto& lg = model->engine.gemm_log();
         *n_rows = (int32_t)lg.size();
         if (!rows) return;
@@ -157,7 +162,7 @@ int32_t k2hip_get_gemm_profile(k2hip_model_t* model, float* rows, int32_t cap_ro
 int32_t k2hip_set_instrument(k2hip_model_t* model, int32_t on) {
     return guard([&] {
         NEED(model);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         model->engine.set_instrument(on != 0);
     });
 }
@@ -180,7 +185,7 @@ int32_t k2hip_fbank(k2hip_model_t* model, const float* samples, int64_t n_sample
         NEED(n_frames);
         if (n_samples > 0) NEED(samples);
         if (cap_frames > 0) NEED(feats);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         model->engine.fbank_host(samples, n_samples, feats, cap_frames, n_frames);
     });
 }
@@ -192,7 +197,7 @@ int32_t k2hip_pad_sequence(k2hip_model_t* model, const float* const* speech, con
         NEED(n_floats);
         NEED(out);
         NEED(padded_len);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         model->engine.pad_host(speech, n_floats, B, tail_frames, out, cap_floats, padded_len);
     });
 }
@@ -208,7 +213,7 @@ int32_t k2hip_offline_encoder(k2hip_model_t* model, const float* x, const int64_
         NEED(enc_out);
         NEED(Tprime);
         (void)x_lens;  // always T in the reference (OfflineProjOfTransducer.cs:66-70); no masking on this path
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         int tp = 0;
         model->engine.encoder_host(x, B, T, enc_out, cap_floats, &tp);
         *Tprime = tp;
@@ -223,7 +228,7 @@ int32_t k2hip_offline_encoder_tap(k2hip_model_t* model, const float* x, int32_t 
         NEED(x);
         NEED(out);
         NEED(n_floats);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         model->engine.encoder_tap_host(x, B, T, tap, out, cap_floats, n_floats);
     });
 }
@@ -231,7 +236,7 @@ int32_t k2hip_decoder(k2hip_model_t* model, const int64_t* y, int32_t N, float* 
     return guard([&] {
         NEED(model);
         NEED(dec_out);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         model->engine.decoder_host(y, N, dec_out);
     });
 }
@@ -241,7 +246,7 @@ int32_t k2hip_joiner(k2hip_model_t* model, const float* enc, const float* dec, i
         NEED(enc);
         NEED(dec);
         NEED(logits);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         model->engine.joiner_host(enc, dec, N, logits);
     });
 }
@@ -249,7 +254,7 @@ int32_t k2hip_greedy_batch(k2hip_model_t* model, const float* enc_out, int32_t B
                            int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens) {
     return guard([&] {
         NEED(model); NEED(enc_out); NEED(tokens); NEED(timestamps); NEED(n_tokens);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         model->engine.greedy_host(enc_out, B, Tprime, false, tokens, timestamps, n_tokens, max_tokens);
     });
 }
@@ -257,7 +262,7 @@ int32_t k2hip_greedy_single(k2hip_model_t* model, const float* enc_out, int32_t 
                             int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens) {
     return guard([&] {
         NEED(model); NEED(enc_out); NEED(tokens); NEED(timestamps); NEED(n_tokens);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         model->engine.greedy_host(enc_out, 1, Tprime, true, tokens, timestamps, n_tokens, max_tokens);
     });
 }
@@ -301,7 +306,7 @@ int32_t k2hip_ctc_greedy(k2hip_model_t* model, const float* log_probs, int32_t B
         NEED(model); NEED(log_probs); NEED(tokens); NEED(timestamps); NEED(n_tokens);
         Engine& e = model->engine;
         K2_REQUIRE(e.model().cfg().ctc, "ctc_greedy: model_type '%s' has no CTC head", e.model().cfg().model_type.c_str());
-        std::lock_guard<std::mutex> lk(e.mutex());
+        EngineLock lk(e);
         e.greedy_host(log_probs, B, Tprime, false, tokens, timestamps, n_tokens, max_tokens);
         for (int b = 0; b < B; b++) {
             if (frame_offsets)
@@ -320,7 +325,7 @@ int32_t k2hip_offline_stream_get_ctc_state(const k2hip_offline_stream_t* s, int3
 int32_t k2hip_set_decoding_method(k2hip_model_t* model, const char* method, int32_t beam) {
     return guard([&] {
         NEED(model); NEED(method);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         if (!strcmp(method, "greedy_search")) {
             model->engine.set_beam(0);
         } else if (!strcmp(method, "modified_beam_search")) {
@@ -337,7 +342,7 @@ int32_t k2hip_beam_search(k2hip_model_t* model, const float* enc_out, int32_t B,
         NEED(model); NEED(enc_out); NEED(tokens); NEED(timestamps); NEED(n_tokens);
         K2_REQUIRE(beam >= 1 && beam <= kMaxBeam, "beam search: beam %d out of range [1,%d]", beam, kMaxBeam);
         Engine& e = model->engine;
-        std::lock_guard<std::mutex> lk(e.mutex());
+        EngineLock lk(e);
         struct Restore {
             Engine& e; int old;
             ~Restore() { e.set_beam(old); }
@@ -350,7 +355,7 @@ int32_t k2hip_beam_search(k2hip_model_t* model, const float* enc_out, int32_t B,
 int32_t k2hip_last_scores(k2hip_model_t* model, float* scores, int32_t B) {
     return guard([&] {
         NEED(model); NEED(scores);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         K2_REQUIRE((size_t)B == model->engine.last_scores().size(), "last_scores: the last beam-search call had %zu streams, not %d",
                    model->engine.last_scores().size(), B);
         memcpy(scores, model->engine.last_scores().data(), sizeof(float) * B);
@@ -360,7 +365,7 @@ int32_t k2hip_offline_greedy(k2hip_model_t* model, const float* const* feats, co
                              int64_t* tokens, int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens) {
     return guard([&] {
         NEED(model); NEED(feats); NEED(n_floats); NEED(tokens); NEED(timestamps); NEED(n_tokens);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         model->engine.offline_greedy_feats(feats, n_floats, B, false, tokens, timestamps, n_tokens, max_tokens);
     });
 }
@@ -368,7 +373,7 @@ int32_t k2hip_offline_greedy_single(k2hip_model_t* model, const float* feats, in
                                     int32_t* timestamps, int32_t* n_tokens, int32_t max_tokens) {
     return guard([&] {
         NEED(model); NEED(feats); NEED(tokens); NEED(timestamps); NEED(n_tokens);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         const float* p[1] = {feats};
         int64_t n[1] = {n_floats};
         model->engine.offline_greedy_feats(p, n, 1, true, tokens, timestamps, n_tokens, max_tokens);
@@ -379,7 +384,7 @@ int32_t k2hip_offline_greedy_from_samples(k2hip_model_t* model, const float* con
                                           int32_t max_tokens) {
     return guard([&] {
         NEED(model); NEED(samples); NEED(n_samples); NEED(tokens); NEED(timestamps); NEED(n_tokens);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         model->engine.offline_greedy_samples(samples, n_samples, B, tokens, timestamps, n_tokens, max_tokens);
     });
 }
@@ -388,7 +393,7 @@ int32_t k2hip_offline_greedy_from_samples_dev(k2hip_model_t* model, const float*
                                               int32_t max_tokens) {
     return guard([&] {
         NEED(model); NEED(samples_dev); NEED(tokens); NEED(timestamps); NEED(n_tokens);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         model->engine.offline_greedy_samples_dev(samples_dev, n_samples_each, B, tokens, timestamps, n_tokens, max_tokens);
     });
 }
@@ -397,7 +402,7 @@ int32_t k2hip_offline_submit_samples_dev(k2hip_model_t* model, const float* samp
                                          int32_t max_tokens, int32_t* ticket) {
     return guard([&] {
         NEED(model); NEED(samples_dev); NEED(ticket);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         *ticket = model->engine.submit_samples_dev(samples_dev, n_samples_each, B, max_tokens);
     });
 }
@@ -405,7 +410,7 @@ int32_t k2hip_offline_submit_samples(k2hip_model_t* model, const float* samples_
                                      int32_t max_tokens, int32_t* ticket) {
     return guard([&] {
         NEED(model); NEED(samples_host); NEED(ticket);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         *ticket = model->engine.submit_samples_host(samples_host, n_samples_each, B, max_tokens);
     });
 }
@@ -425,7 +430,7 @@ int32_t k2hip_host_free(k2hip_model_t* model, void* host_ptr) {
 int32_t k2hip_offline_wait(k2hip_model_t* model, int32_t ticket, int64_t* tokens, int32_t* timestamps, int32_t* n_tokens) {
     return guard([&] {
         NEED(model); NEED(tokens); NEED(timestamps); NEED(n_tokens);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         model->engine.wait_ticket(ticket, tokens, timestamps, n_tokens);
     });
 }
@@ -460,7 +465,7 @@ int32_t k2hip_online_stream_create(k2hip_model_t* model, k2hip_online_stream_t**
     return guard([&] {
         NEED(model); NEED(out);
         *out = nullptr;
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         auto* s = new k2hip_online_stream();
         s->model = model;
         try {
@@ -482,7 +487,7 @@ int32_t k2hip_online_stream_reset(k2hip_online_stream_t* s) {
         NEED(s);
         k2hip_model* model = s->model;
         {
-            std::lock_guard<std::mutex> lk(model->engine.mutex());
+            EngineLock lk(model->engine);
             model->engine.online_free_slot(s->slot);
             s->slot = -1;
             s->slot = model->engine.online_alloc_slot();  // (the slot just freed: re-zeroed like GetEncoderInitStates)
@@ -495,7 +500,7 @@ int32_t k2hip_online_stream_destroy(k2hip_online_stream_t* s) {
     return guard([&] {
         if (!s) return;
         {
-            std::lock_guard<std::mutex> lk(s->model->engine.mutex());
+            EngineLock lk(s->model->engine);
             s->model->engine.online_free_slot(s->slot);
         }
         delete s;
@@ -562,7 +567,7 @@ static void online_materialize(k2hip_online_stream* const* streams, int n) {
             dst[i] = s->speech.data() + old;
         }
         try {
-            std::lock_guard<std::mutex> lk(e.mutex());
+            EngineLock lk(e);
             e.fbank_host_gather(hp.data(), hn.data(), tp.data(), tn.data(), len, G, dst.data(), nf, fslot.data(), fpos.data());
         } catch (...) {
             for (k2hip_online_stream* s : g) s->speech.resize(s->speech.size() - (size_t)nf * c.feat);  // nothing was appended
@@ -623,7 +628,7 @@ int32_t k2hip_online_stream_accept_features(k2hip_online_stream_t* s, const floa
             if (s->mir_ok && have + n_frames > Engine::kFifoFrames) s->mir_ok = false;
             if (s->mir_ok) {
                 Engine& e = s->model->engine;
-                std::lock_guard<std::mutex> lk(e.mutex());
+                EngineLock lk(e);
                 e.online_fifo_write(s->slot, (int)((s->mir_head + have) % Engine::kFifoFrames), feats, n_frames);
             }
         }
@@ -665,6 +670,7 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
         for (int i = 0; i < B; i++) {
             NEED(streams[i]);
             K2_REQUIRE(streams[i]->model == model, "stream %d belongs to another model", i);
+            K2_REQUIRE(!streams[i]->poisoned, "stream %d took part in a chunk step that failed: its caches are undefined, reset it first", i);
             decoded[i] = 0;
             n_new_tokens[i] = 0;
             if ((size_t)online_logical_floats(streams[i]) >= chunk_floats) idx.push_back(i);   // GetDecodeChunk (:82-100)
@@ -700,20 +706,28 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
         }
         std::vector<int64_t> tok((size_t)R * Tp);
         std::vector<int32_t> ts((size_t)R * Tp), n(R);
-        {
-            std::lock_guard<std::mutex> lk(e.mutex());
+        try {
+            EngineLock lk(e);
             e.online_step(slots.data(), chunks.data(), hyps.data(), plens.data(), nch.data(), R, tok.data(), ts.data(), n.data(),
                           all_mirrored ? heads.data() : nullptr);
+        } catch (...) {
+            // Host-side nothing has moved (RemoveChunk happens below), but the device caches of these streams may have: the step
+            // updates the conv / embed caches in place.  A search exchange timeout is retried inside the engine and does not come
+            // here; what does is a HIP failure.  The streams are unusable until reset.
+            for (int r = 0; r < R; r++) streams[idx[r]]->poisoned = true;
+            throw;
         }
-        // RemoveChunk (:102-117) only now: if the step above threw (a HIP failure, a search timeout), every stream still holds
-        // its chunk and nothing host-side has moved -- the caller may retry or drop the streams
+        // RemoveChunk (:102-117) only after success
+        std::vector<k2hip_online_stream*> remirror;
         for (int r = 0; r < R; r++) {
             k2hip_online_stream* s = streams[idx[r]];
             s->speech.erase(s->speech.begin(), s->speech.begin() + shift_floats);
             s->mir_head = (s->mir_head + c.shift) % Engine::kFifoFrames;
-            if (!s->mir_ok && s->speech.empty()) {  // drained: the mirror of an empty FIFO is valid again
-                s->mir_ok = true;
-                s->mir_head = 0;
+            if (!s->mir_ok && s->speech.size() / (size_t)c.feat <= (size_t)Engine::kFifoFrames) {
+                // the FIFO fits its device ring again (a host that pushed a whole file before decoding, as the reference's example
+                // does, never drains it to empty: a step needs ChunkLength frames and removes only ShiftLength): re-upload what is
+                // left at ring row 0 and the stream is back on the one-upload-per-tick path
+                remirror.push_back(s);
             }
             s->chunks_done++;
             for (int k = 0; k < n[r]; k++) {
@@ -730,6 +744,15 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
             decoded[idx[r]] = 1;
             n_new_tokens[idx[r]] = n[r];
         }
+        if (!remirror.empty()) {
+            EngineLock lk(e);
+            for (k2hip_online_stream* s : remirror) {
+                const int64_t have = (int64_t)(s->speech.size() / (size_t)c.feat);
+                if (have > 0) e.online_fifo_write(s->slot, 0, s->speech.data(), have);
+                s->mir_head = 0;
+                s->mir_ok = true;
+            }
+        }
     });
 }
 // ---- operator level of the streaming path (IOnlineProj.cs:65-71) --------------------------------------------------------------
@@ -742,7 +765,7 @@ int32_t k2hip_online_state_create(k2hip_model_t* model, k2hip_online_state_t** o
         auto* st = new k2hip_online_state();
         st->model = model;
         try {
-            std::lock_guard<std::mutex> lk(model->engine.mutex());
+            EngineLock lk(model->engine);
             st->slot = model->engine.online_alloc_slot();
         } catch (...) {
             delete st;
@@ -755,7 +778,7 @@ int32_t k2hip_online_state_destroy(k2hip_online_state_t* st) {
     return guard([&] {
         if (!st) return;
         {
-            std::lock_guard<std::mutex> lk(st->model->engine.mutex());
+            EngineLock lk(st->model->engine);
             st->model->engine.online_free_slot(st->slot);
         }
         delete st;
@@ -781,6 +804,7 @@ int32_t k2hip_online_encoder(k2hip_model_t* model, k2hip_online_state_t* const* 
             for (int b = 0; b < B; b++) {
                 NEED(states[b]);
                 K2_REQUIRE(states[b]->model == model, "state %d belongs to another model", b);
+                K2_REQUIRE(!states[b]->poisoned, "state %d took part in an EncoderProj call that failed: its caches are undefined, re-create it", b);
             }
             std::sort(seen.begin(), seen.end());
             K2_REQUIRE(std::adjacent_find(seen.begin(), seen.end()) == seen.end(), "EncoderProj: the same state appears twice in the batch");
@@ -790,9 +814,12 @@ int32_t k2hip_online_encoder(k2hip_model_t* model, k2hip_online_state_t* const* 
             plens[b] = states[b]->processed_len;
             nch[b] = (int)(states[b]->chunks_done % (1LL << 30));
         }
-        {
-            std::lock_guard<std::mutex> lk(e.mutex());
+        try {
+            EngineLock lk(e);
             e.online_encoder(slots.data(), feats, plens.data(), nch.data(), B, encoder_out);
+        } catch (...) {
+            for (int b = 0; b < B; b++) states[b]->poisoned = true;  // the conv / embed caches may have advanced in place
+            throw;
         }
         for (int b = 0; b < B; b++) {  // only after success, as in k2hip_online_step
             states[b]->chunks_done++;
@@ -828,8 +855,32 @@ int32_t k2hip_online_stream_get_hyp(const k2hip_online_stream_t* s, int64_t* hyp
 int32_t k2hip_online_stream_state(k2hip_online_stream_t* s, int32_t layer, int32_t kind, float* out, int64_t cap, int64_t* n) {
     return guard([&] {
         NEED(s); NEED(n);
-        std::lock_guard<std::mutex> lk(s->model->engine.mutex());
+        EngineLock lk(s->model->engine);
         s->model->engine.online_read_state(s->slot, layer, kind, s->chunks_done, out, cap, n);
+    });
+}
+
+// one-part repeats of the vocabulary-parallel search since the model was created (test / monitoring hook, not part of include/k2hip.h)
+__attribute__((visibility("default"))) int32_t k2hip_debug_search_retries(k2hip_model_t* model, int32_t* n) {
+    return guard([&] {
+        NEED(model); NEED(n);
+        EngineLock lk(model->engine);
+        *n = model->engine.search_retries();
+    });
+}
+// test hook (not part of include/k2hip.h): mark a stream as if a chunk step over it had failed on the device
+__attribute__((visibility("default"))) int32_t k2hip_debug_poison_stream(k2hip_online_stream_t* s) {
+    return guard([&] {
+        NEED(s);
+        s->poisoned = true;
+    });
+}
+
+// test hook (not part of include/k2hip.h): does the stream's device mirror of its feature FIFO hold the FIFO right now?
+__attribute__((visibility("default"))) int32_t k2hip_debug_stream_mirrored(const k2hip_online_stream_t* s, int32_t* ok) {
+    return guard([&] {
+        NEED(s); NEED(ok);
+        *ok = s->mir_ok ? 1 : 0;
     });
 }
 
@@ -845,7 +896,7 @@ __attribute__((visibility("default"))) int32_t k2hip_debug_gemm(k2hip_model_t* m
                                                                  int32_t act, int32_t with_res, int32_t cfg, int32_t iters, float* ms) {
     return guard([&] {
         NEED(model); NEED(ms);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         *ms = model->engine.debug_gemm(M, N, K, act, with_res != 0, iters, cfg, nullptr);
     });
 }
@@ -855,7 +906,7 @@ __attribute__((visibility("default"))) int32_t k2hip_debug_gemm_check(k2hip_mode
                                                                        float* max_err) {
     return guard([&] {
         NEED(model); NEED(ms); NEED(max_err);
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        EngineLock lk(model->engine);
         *ms = model->engine.debug_gemm(M, N, K, act, with_res != 0, iters, cfg, max_err);
     });
 }
@@ -865,9 +916,9 @@ __attribute__((visibility("default"))) int32_t k2hip_debug_gemm_trace(k2hip_mode
                                                                        int32_t* n_wg, int32_t* n_waves) {
     return guard([&] {
         NEED(model); NEED(out); NEED(n_wg); NEED(n_waves);
-        K2_REQUIRE(cfg >= 100 || cfg == 0 || cfg == 5 || cfg == 7 || (cfg >= 9 && cfg <= 11),
-                   "trace: LDS-DMA (0, 5, 7, 9, 10, 11), ring (100+) and stream-K (1000+) configurations only");
-        std::lock_guard<std::mutex> lk(model->engine.mutex());
+        K2_REQUIRE((cfg >= 100 && cfg < 1000) || cfg >= 2000 || cfg == 0 || cfg == 5 || cfg == 7 || (cfg >= 9 && cfg <= 11),
+                   "trace: LDS-DMA (0, 5, 7, 9, 10, 11), ring (100+) and pipelined (2000+) configurations only");
+        EngineLock lk(model->engine);
         model->engine.debug_gemm_trace(M, N, K, act, with_res != 0, cfg, out, cap, n_wg, n_waves);
     });
 }
@@ -899,7 +950,7 @@ int32_t k2hip_offline_stream_accept_samples(k2hip_offline_stream_t* s, const flo
             size_t old = s->speech.size();
             s->speech.resize(old + (size_t)nf * c.feat);
             int64_t got = 0;
-            std::lock_guard<std::mutex> lk(e.mutex());
+            EngineLock lk(e);
             e.fbank_host(wav.data(), (int64_t)wav.size(), s->speech.data() + old, nf, &got);
             // streaming framing: the next frame starts nf*shift samples in
             size_t consumed = (size_t)nf * c.fbank.frame_shift;
@@ -943,7 +994,7 @@ int32_t k2hip_offline_recognizer_get_results(k2hip_model_t* model, k2hip_offline
         std::vector<int64_t> tok((size_t)B * max_tokens);
         std::vector<int32_t> ts((size_t)B * max_tokens), n(B);
         {
-            std::lock_guard<std::mutex> lk(e.mutex());
+            EngineLock lk(e);
             e.offline_greedy_feats(ptrs.data(), nfl.data(), B, false, tok.data(), ts.data(), n.data(), max_tokens);
         }
         if (c.ctc) {
@@ -994,7 +1045,7 @@ int32_t k2hip_offline_recognizer_get_result(k2hip_model_t* model, k2hip_offline_
         const float* p[1] = {s->speech.data()};
         int64_t nfl[1] = {(int64_t)s->speech.size()};
         {
-            std::lock_guard<std::mutex> lk(e.mutex());
+            EngineLock lk(e);
             e.offline_greedy_feats(p, nfl, 1, true, tok.data(), ts.data(), &n, max_tokens);
         }
         s->tokens = {-1, K2HIP_BLANK_ID};  // hypList (:115-117, :180); the CTC single path seeds the same pair (:318-320)

@@ -38,6 +38,20 @@ struct LdsAttrOnce {
     }
 };
 
+// compute units of the calling thread's current device (256 on MI355X), cached per device
+inline int device_cu_count() {
+    static int n[64] = {0};
+    int dev = 0;
+    K2_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return 256;
+    if (!n[dev]) {
+        int v = 0;
+        K2_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        n[dev] = v > 0 ? v : 256;
+    }
+    return n[dev];
+}
+
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

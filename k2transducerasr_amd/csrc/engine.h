@@ -30,26 +30,6 @@ struct OfflineResult {
     std::vector<std::vector<int32_t>> timestamps;
 };
 
-// Fork-join over a few persistent host threads: the sub-batches of a streaming chunk step are enqueued concurrently, each on its
-// own HIP stream (a chunk step is ~450 short, latency-bound launches; two or four independent chains fill each other's gaps on
-// the GPU, and one host thread could not enqueue them fast enough to keep the chains abreast).
-class ForkJoin {
-  public:
-    ~ForkJoin();
-    // run fn(0..n-1): fn(0) on the calling thread, the rest on workers; rethrows the first exception after all have finished
-    void run(int n, const std::function<void(int)>& fn);
-
-  private:
-    void worker(int id, int seen);
-    std::vector<std::thread> threads_;
-    std::mutex mu_;
-    std::condition_variable cv_, done_cv_;
-    const std::function<void(int)>* fn_ = nullptr;
-    int gen_ = 0, active_ = 0, pending_ = 0;
-    bool stop_ = false;
-    std::vector<std::exception_ptr> err_;
-};
-
 class Engine {
   public:
     Engine(const std::string& weights, const char* overrides, int device);
@@ -57,6 +37,8 @@ class Engine {
 
     const Model& model() const { return *model_; }
     std::mutex& mutex() { return mu_; }
+    int device() const { return device_; }
+    int search_retries() const { return search_retries_; }
     hipStream_t stream() const { return stream_; }
 
     int encoder_out_frames(int T) const;
@@ -188,30 +170,8 @@ class Engine {
     float* encoder_embed_stream(const Ctx& c, const float* x, const int* d_slots, int B, int T, int* Tc);
     void encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x, const float* pe, const int* d_slots,
                               const long long* d_plen, const int* d_chunks, int B, int Tc, int L);
-    // one sub-batch of a streaming chunk step: its own stream, arena, pinned staging, events and GEMM statistics
-    struct OnlineSub {
-        Arena arena;
-        hipStream_t stream = nullptr;
-        hipEvent_t ev[6] = {nullptr};
-        GemmStats stats;
-        std::vector<hipEvent_t> evpool;
-        std::vector<GemmLaunchRec> log;
-        int evused = 0;
-        char* pin = nullptr;        // [chunks | slots | plens | hyps] in, [tok | ts | n | ovf] out
-        int64_t pin_cap = 0;
-        int64_t out_off = 0;
-        float gemm_ms = 0;
-    };
-    static constexpr int kMaxSubs = 4;
-    OnlineSub subs_[kMaxSubs];
-    ForkJoin fork_;
-    std::mutex cache_mu_;  // pos_proj / pos_emb / decjoin tables are built lazily, possibly from several sub-batch threads
-    void online_sub_step(OnlineSub& s, const int* slots, const float* const* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
-                         int B_all);
-    void online_step_split(const int* slots, const float* const* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
-                           int K, int64_t* tokens, int32_t* ts, int32_t* n_tokens);
+    std::mutex cache_mu_;  // pos_proj / pos_emb / decjoin tables are built lazily
     float* online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_slots, const long long* d_plen, const int* d_chunks, int B);
-    bool subs_warm_ = false;
     DecJoinW decjoin();
     float* d_ptab_ = nullptr;  // [2][V][DD] per-token decoder-conv table (groups = 1 models), built on first use
 
@@ -238,7 +198,11 @@ class Engine {
         int *d_ts = nullptr, *d_n = nullptr, *d_ovf = nullptr;
         int B = 0, max_tokens = 0;
         bool busy = false;
+        GreedyLaunch greedy;            // the slot's search launch, kept for the one-part retry
+        hipStream_t search_stream = nullptr;
     } slots_[kSlots];
+    GreedyLaunch last_greedy_;          // the same for the synchronous entries (searches on stream_)
+    int search_retries_ = 0;            // one-part retries since the model was created (k2hip_debug_search_retries)
     int next_slot_ = 0;
     hipStream_t stream2_ = nullptr;
     hipStream_t cur_stream_ = nullptr;  // stream of the call being built (nullptr = stream_)
@@ -275,6 +239,18 @@ class Engine {
     void* pin_in_ = nullptr;   // pinned staging of a step's inputs (chunks), separate from the result staging above
     int64_t pin_in_cap_ = 0;
     void* pinned_in(int64_t bytes);
+};
+
+// What every C-ABI entry holds while it works on a model: the model's mutex (calls on one handle are serialised) AND the model's
+// device made current on the calling thread -- BEFORE anything is created lazily (slot streams, pinned staging, pool growth), so a
+// host thread whose current device is another GPU (the C# "8 handles from 8 pool threads" story, IOnlineProj.cs:65-71 /
+// SURVEY 8b "hipSetDevice per call") can never place a stream or a buffer on the wrong card.
+class EngineLock {
+  public:
+    explicit EngineLock(Engine& e) : lk_(e.mutex()) { K2_HIP(hipSetDevice(e.device())); }
+
+  private:
+    std::lock_guard<std::mutex> lk_;
 };
 
 template <typename F>

@@ -84,7 +84,7 @@ __device__ __forceinline__ float4 sel4(bool ok, float4 v) {
 // around the element loop, and nothing loads between two stores.  (With the loads and a per-element activation switch inside the
 // element loop the compiler drains vmcnt(0) in front of every element, so each store waited for the previous store's round trip:
 // ~500 cycles x 16 per 32x32 block -- 8.6k of the 50k cycles a 128x64 tile with K = 512 takes; in-kernel stamps,
-// tools/gemm_sk_trace.py.)
+// tools/gemm_dma_trace.py.)
 struct Rows32 {  // C/D layout of v_mfma_f32_32x32x2_f32: register r of lane (li, lh) is row (r & 3) + 8 (r >> 2) + 4 lh
     static __device__ __forceinline__ int off(int r) { return (r & 3) + 8 * (r >> 2); }
 };
@@ -1112,252 +1112,6 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
 }
 
 // ---------------------------------------------------------------------------------------
-// Stream-K variant of the LDS-DMA kernel (plain Linear, K % 32 == 0, one launch = one problem): a PERSISTENT grid of G
-// workgroups (a multiple of the 256 CUs) shares the launch's ntiles * K/32 tile-steps EQUALLY, so the output never quantises
-// into rounds of tiles: a 128 x 128 tile (8 operand bytes per CU-cycle instead of the 12 of 128 x 64) can be used whatever the
-// tile count is.  Workgroup v owns the contiguous step range [i0, i1) of the row-major tile order; a tile cut by a range
-// boundary is finished by the workgroup that holds its LAST k step:
-//   * a workgroup whose range ends inside a tile multiplies that head part FIRST and publishes the partial accumulators in its
-//     slot of the workspace as {epoch, value} granules (relaxed agent-scope 64-bit stores: write-through, the tag is the flag,
-//     no fence, nothing to reset between launches -- the epoch is the launch's sequence number on its HIP stream);
-//   * then its whole tiles; and LAST the tile its range starts inside: it adds the partials of the workgroups v-1, v-2, ... that
-//     cover the tile's earlier k steps (in that fixed order: the sum is deterministic for a given shape and G) and runs the
-//     epilogue.  By then its producers have long published; a consumer only ever waits on lower virtual indices, which the
-//     dispatcher started before it (per-XCD in-order), so there is no cycle.  The wait is bounded all the same: on a timeout the
-//     kernel raises the workspace's error flag (checked by the engine at its next synchronisation point) instead of hanging.
-//   * virtual index v = (b % 8) * G/8 + b / 8: the workgroups of one XCD own one contiguous band of tiles (A band + W in its L2).
-template <int BM, int BN, int WM, int WN, int NST>
-__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_sk(GemmArgs g) {
-    constexpr int BK = 32, PF = NST - 1;
-    constexpr int MT = WM / 32, NT = WN / 32;
-    constexpr int WCOLS = BN / WN;
-    constexpr int NW = (BM / WM) * (BN / WN);
-    constexpr int NINST = (BM + BN) / 8;
-    constexpr int IPW = (NINST + NW - 1) / NW;
-    constexpr int NFULL = NINST % NW == 0 ? NW : NINST % NW;
-    constexpr int STAGE = (BM + BN) * BK;
-    constexpr int SPIN_LIMIT = 1 << 22;
-
-    if (g.skip_if_zero && *g.skip_if_zero == 0) return;
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [NST][STAGE]: A rows then W rows
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / WCOLS, wc = wave % WCOLS;
-    const int li = lane & 31, lh = lane >> 5;
-    const float* __restrict__ A = g.A;
-    const float* __restrict__ W = g.W;
-    float* __restrict__ C = g.C;
-    const float* __restrict__ R = g.res;
-
-    const int tiles_n = (g.N + BN - 1) / BN, nk = g.K / BK;
-    const long long total = (long long)tiles_n * ((g.M + BM - 1) / BM) * nk;
-    const int G = gridDim.x;
-    const int v = (G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
-    const long long per = total / G;
-    const int rem = (int)(total % G);
-    auto start_of = [&](int u) { return u * per + min(u, rem); };
-    const long long i0 = start_of(v), i1 = start_of(v + 1);
-    if (i0 >= i1) return;  // (the launcher keeps G <= total)
-    const int t_a = (int)(i0 / nk), ka = (int)(i0 - (long long)t_a * nk);
-    const int t_b = (int)((i1 - 1) / nk), kb = (int)(i1 - (long long)t_b * nk);
-    const int count = t_b - t_a + 1;
-
-    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
-    const int arow = wr * WM + li, brow = wc * WN + li;
-    const int swa = (arow >> 1) & 7, swb = ((BM + brow) >> 1) & 7;
-    bool timed_out = false;
-    // tuning only (g.dbg != nullptr): lane 0 of every wave stamps s_memtime; [virtual workgroup][wave][64], per segment: start,
-    // pipeline primed (first K step landed), K loop done, epilogue / publish done; [62] = stamps, [60]/[63] = s_memrealtime
-    unsigned long long* stamp = g.dbg ? g.dbg + ((size_t)v * NW + wave) * 64 : nullptr;
-    int nstamp = 0;
-#define K2_SK_STAMP() \
-    if (stamp && lane == 0 && nstamp < 60) stamp[nstamp++] = __builtin_amdgcn_s_memtime();
-    if (stamp && lane == 0) stamp[60] = __builtin_amdgcn_s_memrealtime();
-
-    for (int s = 0; s < count; s++) {
-        // processing order: the tile the range ends in (published), whole tiles, the tile the range starts in (finished here)
-        const int tile = count == 1 ? t_a : (s == 0 ? t_b : (s == count - 1 ? t_a : t_a + s));
-        const int k0 = (count == 1 || s == count - 1) ? ka : 0;
-        const int k1 = (count == 1 || s == 0) ? kb : nk;
-        const int nkl = k1 - k0;
-        const bool finishes = k1 == nk;
-        const int mb = tile / tiles_n, nb = tile - mb * tiles_n;
-        const int m0 = mb * BM, n0 = nb * BN;
-
-        // the stores of the previous segment's epilogue count in vmcnt like the DMA loads: retire them first; the barrier says every
-        // wave has left the previous segment's last LDS stage
-        K2_SK_STAMP()
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-
-        const float* src[IPW];
-#pragma unroll
-        for (int q = 0; q < IPW; q++) {
-            const int inst = min(wave + q * NW, NINST - 1);
-            const int slot = inst * 64 + lane;
-            const int r = slot >> 3, cp = slot & 7;
-            const int c = cp ^ ((r >> 1) & 7);
-            if (inst < BM / 8) src[q] = A + (long long)min(m0 + r, g.M - 1) * g.lda + 4 * c + k0 * BK;
-            else src[q] = W + (long long)min(n0 + (r - BM), g.N - 1) * g.ldw + 4 * c + k0 * BK;
-        }
-        auto issue = [&](int kl) {
-#pragma unroll
-            for (int q = 0; q < IPW; q++) {
-                const int inst = wave + q * NW;
-                if (inst >= NINST) break;
-                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + ((kl % NST) * STAGE + inst * 256) * 4);
-                const float* gp = src[q] + kl * BK;
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep)
-                             : "v"(gp), "s"(dst)
-                             : "memory");
-            }
-        };
-
-        f32x16 acc[MT][NT];
-#pragma unroll
-        for (int i = 0; i < MT; i++)
-#pragma unroll
-            for (int j = 0; j < NT; j++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-        float rres[MT][NT][16];
-        // residual rows of a tile this workgroup finishes: loaded while the last K steps multiply (they are ordinary VMEM loads, younger
-        // than every DMA of the segment, so the counted waits below stay correct -- merely conservative at the tail)
-        // (`z` is an opaque zero made at the point of use: without it the compiler hoists the 16 MT NT row addresses out of the K loop
-        // -- and those of the publish / consume code below out of the segment loop -- and keeps them in registers throughout)
-        const int res_at = max(nkl - 1 - PF, 0);
-        auto load_res = [&]() {
-            int z = 0;
-            asm volatile("" : "+v"(z));
-#pragma unroll
-            for (int j = 0; j < NT; j++) {
-                const int col = min(n0 + wc * WN + j * 32 + li, g.N - 1);
-#pragma unroll
-                for (int i = 0; i < MT; i++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int row = min(m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh + z, g.M - 1);
-                        rres[i][j][r] = R[(long long)row * g.ldr + col];
-                    }
-            }
-        };
-
-#pragma unroll
-        for (int p = 0; p < PF; p++)
-            if (p < nkl) issue(p);
-        for (int kl = 0; kl < nkl; kl++) {
-            if (kl + PF - 1 < nkl && (PF - 1) * (IPW - 1) > 0 && !(R && finishes && kl > res_at)) {
-                if (wave < NFULL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * IPW) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * (IPW - 1)) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            if (kl == 0) { K2_SK_STAMP() }
-            if (kl + PF < nkl) issue(kl + PF);
-            if (R && finishes && kl == res_at) load_res();
-            const float* sa = smem + (kl % NST) * STAGE + arow * BK;
-            const float* sb = smem + (kl % NST) * STAGE + (BM + brow) * BK;
-            float4 fa[2][MT], fb[2][NT];
-#pragma unroll
-            for (int i = 0; i < MT; i++) fa[0][i] = *reinterpret_cast<const float4*>(sa + i * 32 * BK + (((0 + lh) ^ swa) << 2));
-#pragma unroll
-            for (int j = 0; j < NT; j++) fb[0][j] = *reinterpret_cast<const float4*>(sb + j * 32 * BK + (((0 + lh) ^ swb) << 2));
-#pragma unroll
-            for (int gk = 0; gk < 4; gk++) {
-                const int cu = gk & 1, nx = cu ^ 1;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-#pragma unroll
-                    for (int i = 0; i < MT; i++)
-#pragma unroll
-                        for (int j = 0; j < NT; j++) {
-                            const float av = e == 0 ? fa[cu][i].x : e == 1 ? fa[cu][i].y : e == 2 ? fa[cu][i].z : fa[cu][i].w;
-                            const float bv = e == 0 ? fb[cu][j].x : e == 1 ? fb[cu][j].y : e == 2 ? fb[cu][j].z : fb[cu][j].w;
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-                        }
-                    if (e == 0 && gk < 3) {
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int i = 0; i < MT; i++)
-                            fa[nx][i] = *reinterpret_cast<const float4*>(sa + i * 32 * BK + (((2 * (gk + 1) + lh) ^ swa) << 2));
-#pragma unroll
-                        for (int j = 0; j < NT; j++)
-                            fb[nx][j] = *reinterpret_cast<const float4*>(sb + j * 32 * BK + (((2 * (gk + 1) + lh) ^ swb) << 2));
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-        }
-
-        K2_SK_STAMP()
-        if (!finishes) {  // publish the partial tile: slot v, granule ((wave * MT*NT + i*NT + j) * 16 + r) * 64 + lane
-            int z = 0;
-            asm volatile("" : "+v"(z));
-            unsigned long long* slot = g.sk_ws + (size_t)v * (BM * BN) + (size_t)wave * (MT * NT * 1024) + (lane + z);
-#pragma unroll
-            for (int i = 0; i < MT; i++)
-#pragma unroll
-                for (int j = 0; j < NT; j++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        __hip_atomic_store(slot + ((i * NT + j) * 16 + r) * 64,
-                                           ((unsigned long long)g.sk_epoch << 32) | __float_as_uint(acc[i][j][r]), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-            K2_SK_STAMP()
-            continue;
-        }
-        if (k0 > 0) {  // add the earlier k parts of this tile, nearest producer first
-            const long long tile_start = (long long)tile * nk;
-            for (int u = v - 1; u >= 0 && start_of(u + 1) > tile_start; u--) {
-                int z = 0;
-                asm volatile("" : "+v"(z));
-                const unsigned long long* slot = g.sk_ws + (size_t)u * (BM * BN) + (size_t)wave * (MT * NT * 1024) + (lane + z);
-#pragma unroll
-                for (int i = 0; i < MT; i++)
-#pragma unroll
-                    for (int j = 0; j < NT; j++)
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            unsigned long long* p = const_cast<unsigned long long*>(slot) + ((i * NT + j) * 16 + r) * 64;
-                            unsigned long long x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            int spins = 0;
-                            while ((unsigned)(x >> 32) != g.sk_epoch && !timed_out) {
-                                __builtin_amdgcn_s_sleep(2);
-                                x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (++spins > SPIN_LIMIT) timed_out = true;
-                            }
-                            acc[i][j][r] += __uint_as_float((unsigned)x);
-                        }
-            }
-            if (timed_out) __hip_atomic_store(g.sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        int ze = 0;
-        asm volatile("" : "+v"(ze));
-#pragma unroll
-        for (int j = 0; j < NT; j++)
-#pragma unroll
-            for (int i = 0; i < MT; i++) {
-                float vals[16];
-#pragma unroll
-                for (int r = 0; r < 16; r++) vals[r] = acc[i][j][r];
-                epilogue_rows<16, Rows32>(g, vals, m0 + wr * WM + i * 32 + 4 * lh, n0 + wc * WN + j * 32 + li + ze, C, nullptr,
-                                          rres[i][j], R != nullptr, nullptr, g.bias);
-            }
-        K2_SK_STAMP()
-    }
-    if (stamp && lane == 0) {
-        stamp[62] = nstamp;
-        stamp[63] = __builtin_amdgcn_s_memrealtime();
-    }
-#undef K2_SK_STAMP
-}
-
-// ---------------------------------------------------------------------------------------
 // Ring variant of the LDS-DMA kernel (plain Linear, K % (32 KS) == 0).  Same tile image and swizzle as above; what changes is
 // the pipeline and the K split:
 //   * the fragments of a K tile are read from LDS into a SECOND register set while the MFMAs of the previous tile run, so
@@ -1713,73 +1467,6 @@ void launch_ring(const Ctx& ctx, const GemmArgs& a) {
     hipLaunchKernelGGL((gemm_f32_mfma_ring<BM, BN, KS, NST, LW, PF>), grid, dim3(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)), lds, ctx.stream, a);
 }
 
-// ---- stream-K launches: one workspace (partial-tile slots + launch counter) per HIP stream ------------------------------------
-// Launches on one stream are serialised, so they can share a workspace; two streams never do (a slot overwritten under another
-// launch's epoch would leave its consumer waiting).  Created on a stream's first stream-K launch, never freed (a handful of
-// streams per process).  The error flag lives in mapped host memory: the kernel raises it on a wait timeout, the engine reads
-// it where it synchronises anyway (gemm_sk_take_error).
-constexpr int SK_MAX_G = 1024;
-constexpr size_t SK_SLOT = 128 * 128;  // granules per workgroup slot (largest tile)
-struct SkWorkspace {
-    unsigned long long* ws = nullptr;
-    unsigned epoch = 0;
-};
-std::mutex g_sk_mu;
-std::map<std::pair<int, hipStream_t>, SkWorkspace> g_sk;
-int* g_sk_err_host = nullptr;  // mapped, shared by all workspaces
-int* g_sk_err_dev = nullptr;
-
-void sk_prepare(const Ctx& ctx, GemmArgs& a) {
-    std::lock_guard<std::mutex> lk(g_sk_mu);
-    int dev = 0;
-    K2_HIP(hipGetDevice(&dev));
-    if (!g_sk_err_host) {
-        K2_HIP(hipHostMalloc((void**)&g_sk_err_host, sizeof(int), hipHostMallocMapped));
-        *g_sk_err_host = 0;
-        K2_HIP(hipHostGetDevicePointer((void**)&g_sk_err_dev, g_sk_err_host, 0));
-    }
-    SkWorkspace& w = g_sk[{dev, ctx.stream}];
-    if (!w.ws) {
-        K2_HIP(hipMalloc((void**)&w.ws, SK_MAX_G * SK_SLOT * sizeof(unsigned long long)));
-        K2_HIP(hipMemset(w.ws, 0, SK_MAX_G * SK_SLOT * sizeof(unsigned long long)));  // epoch 0 is never a launch's
-    }
-    if (++w.epoch == 0) w.epoch = 1;
-    a.sk_ws = w.ws;
-    a.sk_epoch = w.epoch;
-    a.sk_err = g_sk_err_dev;
-}
-
-template <int BM, int BN, int WM, int WN, int NST>
-void launch_sk(const Ctx& ctx, const GemmArgs& a0, int wg_per_cu) {
-    static_assert(BM * BN <= (int)SK_SLOT, "stream-K slot too small");
-    GemmArgs a = a0;
-    sk_prepare(ctx, a);
-    const long long total = (long long)cdiv(a.M, BM) * cdiv(a.N, BN) * (a.K / 32);
-    const int G = (int)std::min<long long>(std::min(256 * wg_per_cu, SK_MAX_G), total);
-    size_t lds = sizeof(float) * NST * (BM + BN) * 32;
-    static LdsAttrOnce lds_attr;
-    lds_attr.ensure(gemm_f32_mfma_sk<BM, BN, WM, WN, NST>, (int)lds);
-    hipLaunchKernelGGL((gemm_f32_mfma_sk<BM, BN, WM, WN, NST>), dim3(G), dim3(64 * (BM / WM) * (BN / WN)), lds, ctx.stream, a);
-}
-
-// tuning table of the stream-K kernel: k2hip_debug_gemm cfg = 1000 + 10 * index + workgroups per CU
-struct SkCfg { int BM, BN, WM, WN, NST; };
-#define K2_SK_TABLE(X)                                                                                                   \
-    X(0, 128, 128, 64, 64, 2) X(1, 128, 128, 64, 32, 2) X(2, 128, 64, 32, 32, 2) X(3, 128, 64, 64, 32, 2) X(4, 64, 128, 32, 64, 2) \
-    X(5, 128, 128, 64, 64, 3) X(6, 128, 128, 32, 32, 2) X(7, 128, 64, 32, 32, 3) X(8, 64, 64, 32, 32, 3) X(9, 128, 96, 32, 32, 2)
-#define X(i, bm, bn, wm, wn, nst) {bm, bn, wm, wn, nst},
-const SkCfg kSk[] = {K2_SK_TABLE(X)};
-#undef X
-bool launch_sk_idx(const Ctx& ctx, const GemmArgs& a, int idx, int wg_per_cu) {
-    switch (idx) {
-#define X(i, bm, bn, wm, wn, nst) case i: launch_sk<bm, bn, wm, wn, nst>(ctx, a, wg_per_cu); break;
-        K2_SK_TABLE(X)
-#undef X
-        default: return false;
-    }
-    return true;
-}
-
 // float4 epilogue of the 16x16x4 kernels
 bool pipe16_ok(const GemmArgs& a) {
     auto al16 = [](const void* p) { return ((unsigned long long)p & 15) == 0; };
@@ -1916,13 +1603,6 @@ int choose_cfg(const GemmArgs& a) {
 
 int g_ablate = 0;
 int g_use_dma = 1;
-void debug_sk_shape(int cfg, int M, int N, int K, int* n_wg, int* waves) {
-    const int idx = (cfg - 1000) / 10, occ = std::max(1, (cfg - 1000) % 10);
-    K2_REQUIRE(idx >= 0 && idx < (int)(sizeof(kSk) / sizeof(kSk[0])), "no stream-K cfg %d", idx);
-    const long long total = (long long)cdiv(M, kSk[idx].BM) * cdiv(N, kSk[idx].BN) * (K / 32);
-    *n_wg = (int)std::min<long long>(std::min(256 * occ, SK_MAX_G), total);
-    *waves = (kSk[idx].BM / kSk[idx].WM) * (kSk[idx].BN / kSk[idx].WN);
-}
 void debug_ring_shape(int idx, int* bm, int* bn, int* waves) {
     K2_REQUIRE(idx >= 0 && idx < (int)(sizeof(kRing) / sizeof(kRing[0])), "no ring cfg %d", idx);
     *bm = kRing[idx].BM;
@@ -1930,7 +1610,6 @@ void debug_ring_shape(int idx, int* bm, int* bn, int* waves) {
     *waves = (kRing[idx].BM / 32) * (kRing[idx].BN / 32) * kRing[idx].KS + kRing[idx].LW + kRing[idx].PF;
 }
 int g_forced_ring = -1;
-int g_forced_sk = -1, g_forced_sk_occ = 1;
 int g_forced_pipe = -1;
 void debug_pipe_shape(int cfg, int M, int N, int* n_wg, int* waves) {
     const int idx = (cfg - 2000) % 100;
@@ -1938,28 +1617,11 @@ void debug_pipe_shape(int cfg, int M, int N, int* n_wg, int* waves) {
     *n_wg = cdiv(M, kPipe[idx].BM) * cdiv(N, kPipe[idx].BN);
     *waves = (kPipe[idx].BM / kPipe[idx].WM) * (kPipe[idx].BN / kPipe[idx].WN);
 }
-int gemm_sk_take_error() {
-    std::lock_guard<std::mutex> lk(g_sk_mu);
-    if (!g_sk_err_host) return 0;
-    const int e = *(volatile int*)g_sk_err_host;
-    *(volatile int*)g_sk_err_host = 0;
-    return e;
-}
 void debug_force_gemm_cfg(int cfg) {
     const int dma_default = 1;
-    g_forced_sk = -1;
     g_forced_pipe = -1;
     if (cfg >= 2000) {  // pipelined kernel table
         g_forced_pipe = cfg - 2000;
-        g_forced_ring = -1;
-        g_forced_cfg = -1;
-        g_ablate = 0;
-        g_use_dma = dma_default;
-        return;
-    }
-    if (cfg >= 1000) {  // stream-K table
-        g_forced_sk = (cfg - 1000) / 10;
-        g_forced_sk_occ = std::max(1, (cfg - 1000) % 10);
         g_forced_ring = -1;
         g_forced_cfg = -1;
         g_ablate = 0;
@@ -2007,14 +1669,6 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         K2_REQUIRE(a.cv_Fout == 0 && !a.w_kn && !a.mul && a.res_div == 1 && !a.act_after_res && a.K % 32 == 0 && a.K >= 64 && a.nb0 * a.nb1 == 1,
                    "pipe cfg %d does not fit this GEMM", g_forced_pipe);
         K2_REQUIRE(launch_pipe_idx(ctx, b, g_forced_pipe), "no pipe cfg %d", g_forced_pipe);
-        K2_HIP(hipGetLastError());
-        if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
-        return;
-    }
-    if (g_forced_sk >= 0) {  // tuning hook
-        K2_REQUIRE(a.cv_Fout == 0 && !a.w_kn && !a.mul && a.res_div == 1 && !a.act_after_res && a.K % 32 == 0 && a.K >= 64 && a.nb0 * a.nb1 == 1,
-                   "stream-K cfg %d does not fit this GEMM", g_forced_sk);
-        K2_REQUIRE(launch_sk_idx(ctx, b, g_forced_sk, g_forced_sk_occ), "no stream-K cfg %d", g_forced_sk);
         K2_HIP(hipGetLastError());
         if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
         return;

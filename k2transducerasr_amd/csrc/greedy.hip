@@ -839,10 +839,12 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     // (V = 5537, B = 8) 4 parts 25.7 / 22.6 ms, 6: 21.3 / 18.9, 8: 16.7 / 13.9, 10: 18.1 / 14.2, 12: 17.1 / 11.7, 16: 17.05 / 10.0;
     // zipformer2-large-en (V = 500, B = 32) 1 part 15.13 / 5.45, 2: 14.44 / 3.79, 3: 14.57 / 3.67, 4: 14.56 / 3.35.
     const int ncg = w.Vp >> 2, pass = (GT / 64) * 8;
-    const int bc = std::max(a.b_concurrent > 0 ? a.b_concurrent : a.B, 1);
-    // co-residency budget: 64 workgroups offline, the whole chip for a streaming chunk step (nothing else is in flight; one 150 KB
-    // workgroup per CU)
-    const int budget = a.init_ctx ? 256 : 64;
+    const int bc = std::max(a.B, 1);
+    // co-residency budget: a quarter of the chip's CUs offline, the whole chip for a streaming chunk step (nothing else is in
+    // flight; one 150 KB workgroup per CU).  From the device's own CU count (256 on MI355X -> 64 / 256); a GPU shared with other
+    // processes can still leave the parts of a stream apart: then the bounded waits time out and the engine repeats the search with
+    // one part per stream (greedy_relaunch_one_part).
+    const int budget = a.init_ctx ? device_cu_count() : std::max(device_cu_count() / 4, 1);
     int parts = std::min({(ncg + pass - 1) / pass, kMaxParts, budget / bc});
     if (tunables().greedy_parts > 0) parts = std::max(1, std::min({tunables().greedy_parts, kMaxParts, budget / bc}));  // tuning only
     if (parts < 2 || tunables().greedy_one_part) parts = 1;
@@ -864,6 +866,26 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
         K2_HIP(hipMemsetAsync(a.gran2, 0, sizeof(unsigned long long) * gran2_words, ctx.stream));
     }
     hipLaunchKernelGGL(k_greedy, dim3(a.B * parts), dim3(GT), lds, ctx.stream, w, a);
+    K2_HIP(hipGetLastError());
+    if (ctx.greedy_rec) {
+        ctx.greedy_rec->valid = parts > 1;
+        ctx.greedy_rec->w = w;
+        ctx.greedy_rec->a = a;
+    }
+    if (parts > 1 && tunables().test_greedy_timeout) K2_HIP(hipMemsetD32Async((hipDeviceptr_t)a.overflow, 2, 1, ctx.stream));
+}
+
+void greedy_relaunch_one_part(hipStream_t stream, const GreedyLaunch& rec) {
+    K2_REQUIRE(rec.valid, "greedy retry: no repeatable launch on record");
+    GreedyArgs a = rec.a;
+    a.parts = 1;
+    a.gran = nullptr;
+    a.gran2 = nullptr;
+    const DecJoinW& w = rec.w;
+    const size_t lds = sizeof(float) * ((size_t)w.J * GF + 8 * APAD + 3 * (size_t)w.J + 3 * (size_t)w.DD + 32 * GF + GF + 8 +
+                                       2 * kMaxParts * GF + 4);
+    K2_HIP(hipMemsetAsync(a.overflow, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(k_greedy, dim3(a.B), dim3(GT), lds, stream, w, a);
     K2_HIP(hipGetLastError());
 }
 

@@ -25,12 +25,12 @@ struct Tunables {
     int lstm_seq = 0;             // K2HIP_LSTM_SEQ: layer-by-layer LSTM instead of the layer wavefront
     int greedy_one_part = 0;      // K2HIP_GREEDY_ONE_PART: one workgroup per stream in the search
     int greedy_parts = 0;         // K2HIP_GREEDY_PARTS: vocabulary slabs per stream (0 = automatic)
+    int test_greedy_timeout = 0;  // K2HIP_TEST_GREEDY_TIMEOUT: test hook -- every parts > 1 search reports an exchange timeout, so the one-part retry runs
     int pipe_mode = 0;            // K2HIP_PIPE_MODE: 1 = every pipeline slot owns a stream
     int max_streams = 0;          // K2HIP_MAX_STREAMS: slots of the streaming state pool (0 = 256)
     int search_rounds = -1;       // K2HIP_SEARCH_ROUNDS: 1 = every multi-stream search as rounds of joiner GEMMs (greedy_rounds),
                                   // 0 = always the persistent kernel (k_greedy), -1 = measured default: rounds for the streaming
                                   // tick (0.58 -> 0.45 ms at 128 streams), persistent for the offline batch (17.00 vs 17.10 ms)
-    int online_split = 0;         // K2HIP_ONLINE_SPLIT: 2..4 = enqueue a chunk step as that many sub-batches on their own HIP streams (0 / 1: one chain)
 };
 void tunables_init_from_env();            // idempotent; called by k2hip_model_create
 const Tunables& tunables();
@@ -48,8 +48,10 @@ struct GemmLaunchRec {  // one row per GEMM launch of an instrumented call
     float us;
 };
 
+struct GreedyLaunch;
 struct Ctx {
     std::vector<GemmLaunchRec>* gemm_log = nullptr;  // instrumented runs only
+    GreedyLaunch* greedy_rec = nullptr;  // greedy_loop notes its launch here, so that the engine can repeat it with one part per stream
     hipStream_t stream = nullptr;
     Arena* arena = nullptr;
     bool dry = false;
@@ -123,18 +125,12 @@ struct GemmArgs {
     const float* byp_orig = nullptr;
     const float* byp_scale = nullptr;
     int ld_orig = 0;
-    // stream-K launches (filled in by gemm()): partial-tile workspace of the launch's HIP stream, its sequence number, error flag
-    unsigned long long* sk_ws = nullptr;
-    unsigned sk_epoch = 0;
-    int* sk_err = nullptr;
     unsigned long long* dbg = nullptr;  // tuning only: in-kernel s_memtime stamps of the ring kernel, [workgroup][wave][64]
     int ablate = 0;  // tuning only: 1 = skip in-loop global loads, 2 = skip MFMAs, 4 = skip epilogue stores
 };
 void gemm(const Ctx& ctx, const GemmArgs& a);
 void debug_force_gemm_cfg(int cfg);  // tuning hook: -1 = automatic
-int gemm_sk_take_error();            // 1 if a stream-K launch since the last call timed out waiting for a partial tile (and clears it)
 void debug_pipe_shape(int cfg, int M, int N, int* n_wg, int* waves);  // grid and waves of pipe cfg (>= 2000) on a shape
-void debug_sk_shape(int cfg, int M, int N, int K, int* n_wg, int* waves);  // grid and waves of stream-K cfg (>= 1000) on a shape
 void debug_ring_shape(int idx, int* bm, int* bn, int* waves);  // tile and waves of ring table entry idx
 // convenience: plain Linear  C = act(A W^T + b) (+res)
 void linear(const Ctx& ctx, const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int K,
@@ -302,9 +298,6 @@ struct GreedyArgs {
     int* overflow;      // device flag
     // online loop: per-stream starting context (stream.Hyp, OnlineRecognizer.cs:109,122-126); null = offline
     const long long* init_ctx = nullptr;  // [B][2]
-    // streams searched CONCURRENTLY on the chip by sibling launches (sub-batches of one chunk step), this launch included; the
-    // parts of a stream wait for each other, so parts x concurrent streams must stay within the co-residency budget.  0 = B
-    int b_concurrent = 0;
     // vocabulary-parallel form (set by greedy_loop): `parts` workgroups per stream, each sweeping a slab of the joiner
     // matrix; per round they exchange their per-frame (max, argmax) through tagged 8-byte granules
     int parts = 1;
@@ -315,6 +308,16 @@ struct GreedyArgs {
     const float* dec_init = nullptr;
 };
 void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a);
+// The vocabulary-parallel search waits on its sibling workgroups (bounded spins; a timeout raises *overflow = 2).  All B x parts
+// workgroups must be resident together for that, which a GPU shared with other processes or models does not promise.  The engine
+// therefore keeps the launch (inputs are read-only, outputs are rewritten from scratch) and, on a timeout, runs it again with ONE
+// workgroup per stream -- no inter-workgroup wait, same tokens -- instead of failing the call.
+struct GreedyLaunch {
+    bool valid = false;  // a parts > 1 launch that can be repeated
+    DecJoinW w;
+    GreedyArgs a;
+};
+void greedy_relaunch_one_part(hipStream_t stream, const GreedyLaunch& rec);
 // The same search as batched ROUNDS instead of one persistent workgroup pair per stream: every round evaluates the next S frames
 // of every stream under the stream's current context with ONE joiner GEMM over all B x S rows, then a per-stream step accepts
 // frames up to and including the first emission, updates the context, runs the decoder if it changed and forms the next

@@ -449,18 +449,6 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
     const Model& m = *model_;
     const Config& cf = m.cfg();
     const int T = cf.chunk_T, Tp = online_frames_per_chunk();
-    {   // Sub-batches on their own HIP streams (Zipformer2 transducer): a chunk step is a chain of ~450 short launches, each a
-        // single latency-bound round of workgroups; independent chains over disjoint streams fill each other's gaps.
-        const int sw = tunables().online_split;
-        // (default: one chain.  Measured on 128 streams, 2 / 4 sub-batches: 8.0 / 9.2 ms per step against 7.4 -- the step's
-        // kernels are throughput-bound on operand fetch, not idle-latency-bound, so concurrent chains only contend.)
-        int K = sw >= 2 ? std::min(sw, kMaxSubs) : 1;
-        if (cf.lstm || cf.conformer || cf.zip1 || cf.ctc) K = 1;
-        if (K > 1) {
-            online_step_split(slots, chunks, hyps, plens, nchunks, B, K, tokens, ts, n_tokens);
-            return;
-        }
-    }
     long long* d_tok = nullptr;
     int *d_ts = nullptr, *d_n = nullptr, *d_ovf = nullptr;
     // the streams' chunks, gathered once into pinned staging (one host copy; the H2D below is then a real asynchronous DMA)
@@ -575,241 +563,6 @@ void Engine::online_encoder(const int* slots, const float* feats, const long lon
     });
     K2_HIP(hipMemcpyAsync(enc_out, d_enc, sizeof(float) * (size_t)B * Tp * cf.enc_dim(), hipMemcpyDeviceToHost, stream_));
     K2_HIP(hipStreamSynchronize(stream_));
-    K2_REQUIRE(!gemm_sk_take_error(), "stream-K exchange timed out");
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// split chunk step
-// ---------------------------------------------------------------------------------------------------------------
-ForkJoin::~ForkJoin() {
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        stop_ = true;
-    }
-    cv_.notify_all();
-    for (auto& t : threads_) t.join();
-}
-
-void ForkJoin::worker(int id, int seen) {
-    for (;;) {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
-        if (stop_) return;
-        seen = gen_;
-        const bool mine = id < active_;
-        const std::function<void(int)>* fn = fn_;
-        lk.unlock();
-        if (!mine) continue;
-        try {
-            (*fn)(id + 1);
-        } catch (...) {
-            err_[id + 1] = std::current_exception();
-        }
-        lk.lock();
-        if (--pending_ == 0) done_cv_.notify_all();
-    }
-}
-
-void ForkJoin::run(int n, const std::function<void(int)>& fn) {
-    if (n <= 1) {
-        fn(0);
-        return;
-    }
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        while ((int)threads_.size() < n - 1) {
-            const int id = (int)threads_.size();
-            threads_.emplace_back(&ForkJoin::worker, this, id, gen_);
-        }
-        err_.assign(n, nullptr);
-        fn_ = &fn;
-        active_ = pending_ = n - 1;
-        gen_++;
-    }
-    cv_.notify_all();
-    try {
-        fn(0);
-    } catch (...) {
-        err_[0] = std::current_exception();
-    }
-    {
-        std::unique_lock<std::mutex> lk(mu_);
-        done_cv_.wait(lk, [&] { return pending_ == 0; });
-        fn_ = nullptr;
-    }
-    for (auto& e : err_)
-        if (e) std::rethrow_exception(e);
-}
-
-// One sub-batch: stage the inputs in the sub's pinned buffer, size the arena with a dry pass, enqueue H2D + log-floor + encoder +
-// search + D2H on the sub's stream and record ev[5].  Nothing here waits for the GPU.
-void Engine::online_sub_step(OnlineSub& s, const int* slots, const float* const* chunks, const long long* hyps, const long long* plens,
-                             const int* nchunks, int B, int B_all) {
-    const Config& cf = model_->cfg();
-    const int T = cf.chunk_T, Tp = online_frames_per_chunk();
-    K2_HIP(hipSetDevice(device_));
-    if (!s.stream) {
-        K2_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        for (auto& e : s.ev) K2_HIP(hipEventCreate(&e));
-    }
-    const int64_t nb_x = (int64_t)sizeof(float) * B * T * cf.feat, nb_sl = align_up((int64_t)sizeof(int) * B, 16),
-                  nb_pl = (int64_t)sizeof(long long) * B, nb_hy = (int64_t)sizeof(long long) * 2 * B;
-    const int64_t nb_tok = (int64_t)B * Tp * 8, nb_ts = (int64_t)B * Tp * 4, nb_n = (int64_t)B * 4;
-    const int64_t in_bytes = align_up(nb_x + nb_sl + nb_pl + nb_hy + nb_sl, 64), total = in_bytes + nb_tok + nb_ts + nb_n + 64;
-    if (total > s.pin_cap) {
-        if (s.pin) K2_HIP(hipHostFree(s.pin));
-        s.pin = nullptr;
-        s.pin_cap = 0;
-        K2_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.pin), (size_t)(total + total / 4), hipHostMallocDefault));
-        s.pin_cap = total + total / 4;
-    }
-    s.out_off = in_bytes;
-    char* pin = s.pin;
-    for (int b = 0; b < B; b++) memcpy(pin + (size_t)b * sizeof(float) * T * cf.feat, chunks[b], sizeof(float) * (size_t)T * cf.feat);
-    memcpy(pin + nb_x, slots, sizeof(int) * B);
-    memcpy(pin + nb_x + nb_sl, plens, (size_t)nb_pl);
-    memcpy(pin + nb_x + nb_sl + nb_pl, hyps, (size_t)nb_hy);
-    memcpy(pin + nb_x + nb_sl + nb_pl + nb_hy, nchunks, sizeof(int) * B);
-    long long* d_tok = nullptr;
-    int *d_ts = nullptr, *d_n = nullptr, *d_ovf = nullptr;
-    auto body = [&](const Ctx& c) {
-        Arena& ar = *c.arena;
-        d_tok = ar.take<long long>((int64_t)B * Tp);
-        d_ts = ar.take<int>((int64_t)B * Tp);
-        d_n = ar.take<int>(B);
-        d_ovf = ar.take<int>(1);
-        float* d_x = ar.take<float>((int64_t)B * T * cf.feat);
-        int* d_slots = ar.take<int>(B);
-        long long* d_plen = ar.take<long long>(B);
-        long long* d_hyp = ar.take<long long>(2 * B);
-        int* d_chunks = ar.take<int>(B);
-        if (!c.dry) {
-            K2_HIP(hipMemcpyAsync(d_chunks, pin + nb_x + nb_sl + nb_pl + nb_hy, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
-            K2_HIP(hipEventRecord(s.ev[0], c.stream));
-            K2_HIP(hipMemcpyAsync(d_x, pin, (size_t)nb_x, hipMemcpyHostToDevice, c.stream));
-            K2_HIP(hipMemcpyAsync(d_slots, pin + nb_x, sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
-            K2_HIP(hipMemcpyAsync(d_plen, pin + nb_x + nb_sl, (size_t)nb_pl, hipMemcpyHostToDevice, c.stream));
-            K2_HIP(hipMemcpyAsync(d_hyp, pin + nb_x + nb_sl + nb_pl, (size_t)nb_hy, hipMemcpyHostToDevice, c.stream));
-        }
-        logfloor_inplace(c, d_x, (long long)B * T * cf.feat);  // online PadSequence (PadHelper.cs:9-13,58)
-        float* enc = online_encoder_zip2(c, d_x, d_slots, d_plen, d_chunks, B);
-        if (!c.dry) {
-            K2_HIP(hipEventRecord(s.ev[3], c.stream));
-            K2_HIP(hipMemsetAsync(d_ovf, 0, sizeof(int), c.stream));
-        }
-        // OnlineRecognizer.cs:135-202: decoder on the streams' hyps, T' joiner steps, skip {blank, unk, 1}
-        GreedyArgs a;
-        a.enc = enc; a.B = B; a.Tp = Tp; a.t0 = nullptr; a.skip1 = 1; a.max_sym = INT_MAX;
-        a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = Tp; a.overflow = d_ovf; a.init_ctx = d_hyp;
-        a.b_concurrent = B_all;
-        if (tunables().search_rounds == 0) greedy_loop(c, decjoin(), a);
-            else greedy_rounds(c, decjoin(), model_->w("joiner.output_linear.weight"), a);
-        if (!c.dry) K2_HIP(hipEventRecord(s.ev[4], c.stream));
-    };
-    Ctx c;
-    c.stream = s.stream;
-    c.arena = &s.arena;
-    c.stats = &s.stats;
-    c.evpool = &s.evpool;
-    c.evused = &s.evused;
-    c.gemm_log = &s.log;
-    s.stats = GemmStats();
-    s.arena.reset();
-    s.arena.set_dry(true);
-    c.dry = true;
-    c.instrument = false;
-    try {
-        body(c);
-    } catch (...) {
-        s.arena.set_dry(false);
-        s.arena.reset();
-        throw;
-    }
-    s.arena.set_dry(false);
-    const int64_t need = s.arena.high_water();
-    s.arena.reset();
-    if (need > s.arena.capacity()) {
-        K2_HIP(hipStreamSynchronize(s.stream));
-        s.arena.reserve(need + need / 8);
-    }
-    c.dry = false;
-    c.instrument = instrument_;
-    s.evused = 0;
-    s.log.clear();
-    body(c);
-    char* out = pin + s.out_off;
-    K2_HIP(hipMemcpyAsync(out, d_tok, (size_t)nb_tok, hipMemcpyDeviceToHost, s.stream));
-    K2_HIP(hipMemcpyAsync(out + nb_tok, d_ts, (size_t)nb_ts, hipMemcpyDeviceToHost, s.stream));
-    K2_HIP(hipMemcpyAsync(out + nb_tok + nb_ts, d_n, (size_t)nb_n, hipMemcpyDeviceToHost, s.stream));
-    K2_HIP(hipMemcpyAsync(out + nb_tok + nb_ts + nb_n, d_ovf, 4, hipMemcpyDeviceToHost, s.stream));
-    K2_HIP(hipEventRecord(s.ev[5], s.stream));
-}
-
-void Engine::online_step_split(const int* slots, const float* const* chunks, const long long* hyps, const long long* plens, const int* nchunks, int B,
-                               int K, int64_t* tokens, int32_t* ts, int32_t* n_tokens) {
-    const int Tp = online_frames_per_chunk();
-    K = std::min(K, B);
-    std::vector<int> lo(K + 1);
-    for (int k = 0; k <= K; k++) lo[k] = (int)((long long)B * k / K);
-    K2_HIP(hipStreamSynchronize(stream_));  // slot zero-fills and earlier single-stream steps are on stream_
-    auto one = [&](int k) {
-        online_sub_step(subs_[k], slots + lo[k], chunks + lo[k], hyps + 2 * (size_t)lo[k], plens + lo[k], nchunks + lo[k], lo[k + 1] - lo[k], B);
-    };
-    if (!subs_warm_) {
-        // first split step of this engine: one sub-batch after the other on the calling thread, so that every lazily built table
-        // (positional projections, decoder tables, per-kernel LDS attributes) exists before threads share them
-        for (int k = 0; k < K; k++) {
-            one(k);
-            K2_HIP(hipStreamSynchronize(subs_[k].stream));
-        }
-        subs_warm_ = true;
-    } else {
-        fork_.run(K, one);
-    }
-    GemmStats st;
-    float gemm_ms = 0, enc_ms = 0, gr_ms = 0, d2h_ms = 0, tot_ms = 0;
-    gemm_log_.clear();
-    int ovf_any = 0;
-    for (int k = 0; k < K; k++) {
-        OnlineSub& s = subs_[k];
-        K2_HIP(hipEventSynchronize(s.ev[5]));
-        const int b = lo[k + 1] - lo[k];
-        const int64_t nb_tok = (int64_t)b * Tp * 8, nb_ts = (int64_t)b * Tp * 4, nb_n = (int64_t)b * 4;
-        const char* out = s.pin + s.out_off;
-        memcpy(tokens + (size_t)lo[k] * Tp, out, (size_t)nb_tok);
-        memcpy(ts + (size_t)lo[k] * Tp, out + nb_tok, (size_t)nb_ts);
-        memcpy(n_tokens + lo[k], out + nb_tok + nb_ts, (size_t)nb_n);
-        ovf_any = std::max(ovf_any, *reinterpret_cast<const int*>(out + nb_tok + nb_ts + nb_n));
-        auto el = [&](int a, int bb) { float ms = 0; (void)hipEventElapsedTime(&ms, s.ev[a], s.ev[bb]); return ms; };
-        enc_ms = std::max(enc_ms, el(0, 3));
-        gr_ms = std::max(gr_ms, el(3, 4));
-        d2h_ms = std::max(d2h_ms, el(4, 5));
-        tot_ms = std::max(tot_ms, el(0, 5));
-        st.flops += s.stats.flops;
-        st.total_flops += s.stats.total_flops;
-        st.launches += s.stats.launches;
-        if (instrument_) {
-            for (int i = 0; i + 1 < s.evused; i += 2) {
-                float ms = 0;
-                K2_HIP(hipEventElapsedTime(&ms, s.evpool[i], s.evpool[i + 1]));
-                gemm_ms += ms;
-                if ((size_t)(i / 2) < s.log.size()) s.log[i / 2].us = ms * 1e3f;
-            }
-            gemm_log_.insert(gemm_log_.end(), s.log.begin(), s.log.end());
-        }
-    }
-    if (ovf_any == 2) failf(K2HIP_ERR_HIP, "greedy search: the vocabulary-parallel exchange timed out (a workgroup never arrived)");
-    if (ovf_any) failf(K2HIP_ERR_CAPACITY, "a stream emitted more than max_tokens=%d symbols", Tp);
-    timing_.fbank_ms = 0;
-    timing_.pad_ms = 0;
-    timing_.encoder_ms = enc_ms;
-    timing_.greedy_ms = gr_ms;
-    timing_.d2h_ms = d2h_ms;
-    timing_.total_ms = tot_ms;
-    timing_.gemm_ms = gemm_ms;  // summed over the concurrent sub-batches (their launches overlap in time)
-    timing_.gemm_launches = st.launches;
-    timing_.gemm_flops = st.flops;
-    timing_.total_flops = st.total_flops;
 }
 
 }  // namespace k2hip

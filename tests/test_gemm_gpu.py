@@ -1,5 +1,5 @@
-"""The fp32 MFMA GEMM has several kernels for the same math (register-staged, LDS-DMA, ring, pipelined 32x32x2 and 16x16x4,
-stream-K); the product's dispatcher picks by shape.  Here every family is forced (k2hip_debug_gemm_check's tuning hook) over ragged
+"""The fp32 MFMA GEMM has several kernels for the same math (register-staged, LDS-DMA, ring, pipelined 32x32x2 and 16x16x4);
+the product's dispatcher picks by shape.  Here every family is forced (k2hip_debug_gemm_check's tuning hook) over ragged
 and edge shapes and compared with the register-staged kernel on the same operands: same fp32 products, another summation order,
 so the tolerance is that of an fp32 dot product of K terms in [-1, 1)."""
 import ctypes as C
@@ -9,13 +9,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 # (M, N, K): rows / columns that are no multiple of any tile, the shortest K each pipeline depth accepts, a K walk with a ragged
-# tail of steps (K / 32 = 2 .. 9 covers every remainder of the unrolled loops for 3 and 4 stages), a few-tile long-K case that
-# stream-K splits, and the headline's most common shape with activation and residual
+# tail of steps (K / 32 = 2 .. 9 covers every remainder of the unrolled loops for 3 and 4 stages), a few-tile long-K case,
+# and the headline's most common shape with activation and residual
 SHAPES = [(130, 100, 64), (257, 36, 96), (1000, 500, 160), (64, 64, 64), (333, 260, 128), (2048, 192, 192), (515, 132, 224),
           (700, 96, 256), (129, 520, 288), (300, 1000, 2432 // 4), (4064, 512, 512), (256, 768, 2560)]
 PIPE = [2001, 2005, 2008, 2013, 2002, 2004, 2009, 2012]          # 32x32x2 form: 128x64, 64x64, 128x128 (16 waves), 128x32, 128x128 (4 waves), 4 stages, 256x64
 PIPE16 = [c + 100 for c in (2001, 2005, 2008, 2002, 2009)]        # 16x16x4 form of the same table entries
-STREAMK = [1011, 1021, 1022, 1001, 1091]                          # 128x128 / 128x64 (one, two workgroups per CU), 64x64 wave tiles, 128x96
 OTHER = [-1, 5, 9, 100, 108, 118]                                 # the dispatcher's own choice, LDS-DMA 128x64 / 64x64, ring tiles
 
 
@@ -39,15 +38,13 @@ def _fits(cfg, M, N, K):
     if cfg >= 2000:                      # pipelined: K >= 32 (stages - 1)
         stages = 4 if (cfg % 100) in (4, 6, 9) else 3
         return K % 32 == 0 and K >= 32 * (stages - 1)
-    if cfg >= 1000:
-        return K % 32 == 0 and K >= 64
     if cfg >= 100:                       # ring: K a multiple of 32 x its in-workgroup K split
         ks = {100: 1, 108: 2, 118: 1}[cfg]
         return K % (32 * ks) == 0 and K >= 32 * ks
     return K % 32 == 0 and K >= 64
 
 
-@pytest.mark.parametrize("family,cfgs", [("pipe", PIPE), ("pipe16", PIPE16), ("stream-k", STREAMK), ("other", OTHER)])
+@pytest.mark.parametrize("family,cfgs", [("pipe", PIPE), ("pipe16", PIPE16), ("other", OTHER)])
 def test_every_gemm_kernel_agrees_with_the_register_staged_one(gemm_check, family, cfgs):
     ran = 0
     for (M, N, K) in SHAPES:
@@ -74,11 +71,11 @@ def test_gated_epilogue_in_every_kernel_family(gemm_check):
             if mode == 102 and ((2 * N // 3) // 32 * 32) < 32:
                 continue
             tol = 3e-5 * max(1.0, K ** 0.5)
-            for cfg in [-1, 5, 9, 100, 118, 2001, 2005, 2008, 2013, 1011, 1021]:
+            for cfg in [-1, 5, 9, 100, 118, 2001, 2005, 2008, 2013]:
                 if not _fits(cfg, M, N, K):
                     continue
                 rc, err = gemm_check(M, N, K, mode, 0, cfg)
                 assert rc == 0, (cfg, M, N, K, mode)
                 assert err <= tol, (cfg, M, N, K, mode, err, tol)
                 ran += 1
-    assert ran >= 40
+    assert ran >= 32

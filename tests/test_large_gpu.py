@@ -264,3 +264,43 @@ def test_full_size_beam4_matches_oracle(hip_large, oracle_large):
     finally:
         hip_large.set_decoding_method("greedy_search")
         hip_large.device_free(ptr)
+
+
+def test_search_exchange_timeout_is_retried_with_one_part(hip_large):
+    """The vocabulary-parallel search (two column-slab workgroups per stream here) spins on its sibling with a bounded wait; on a
+    shared GPU the siblings may not be resident together.  A timeout is not an error any more: the engine repeats the search
+    with one workgroup per stream (no waits) on the same encoder output.  K2HIP_TEST_GREEDY_TIMEOUT makes every two-part search
+    report a timeout: synchronous and pipelined entries must return exactly the normal result, and count one retry each."""
+    import ctypes as C
+    from k2transducerasr_amd import load_library, set_switch
+    from k2transducerasr_amd.synth import synth_utterance
+    L = load_library()
+    L.k2hip_debug_search_retries.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+
+    def retries():
+        n = C.c_int32(-1)
+        assert L.k2hip_debug_search_retries(hip_large.handle, C.byref(n)) == 0
+        return n.value
+
+    B = 8
+    s = np.stack([synth_utterance(500 + u, 4.0) for u in range(B)])
+    ptr = hip_large.device_alloc(s.nbytes)
+    try:
+        hip_large.device_upload(ptr, s)
+        want = hip_large.offline_greedy_from_samples_dev(ptr, s.shape[1], B)
+        assert sum(len(t) for t, _ in want) > 0
+        r0 = retries()
+        set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 1)
+        try:
+            got = hip_large.offline_greedy_from_samples_dev(ptr, s.shape[1], B)
+            assert retries() == r0 + 1
+            ta = hip_large.offline_submit_samples_dev(ptr, s.shape[1], B)
+            tb = hip_large.offline_submit_samples_dev(ptr, s.shape[1], B)
+            ga, gb = hip_large.offline_wait(ta), hip_large.offline_wait(tb)
+            assert retries() == r0 + 3
+        finally:
+            set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 0)
+        assert got == want and ga == want and gb == want
+        assert hip_large.offline_greedy_from_samples_dev(ptr, s.shape[1], B) == want and retries() == r0 + 3
+    finally:
+        hip_large.device_free(ptr)

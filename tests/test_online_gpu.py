@@ -323,54 +323,6 @@ def test_streaming_128_slots_16_streams_against_oracle_zh(tmp_path_factory):
         assert hs[u].tokens == hs[r].tokens and hs[u].timestamps == hs[r].timestamps, u
 
 
-@pytest.mark.parametrize("split", [2, 3, 4])
-def test_split_chunk_step_equals_single_stream_step(stream_model_path, ora, split):
-    """A chunk step over many streams can be enqueued as sub-batches on their own HIP streams (K2HIP_ONLINE_SPLIT = 2..4; off by
-    default: measured, the chains do not overlap usefully -- DESIGN.md).  Streams are independent, so the split must not change anything: same tokens / timestamps / Hyp as the
-    unsplit step and as the oracle after every call, same cached states, with ragged readiness (streams run out at different
-    calls, so the sub-batch boundaries move)."""
-    from k2transducerasr_amd import OnlineRecognizer, set_switch
-    from k2transducerasr_amd.synth import synth_utterance
-    ra, rb = OnlineRecognizer(stream_model_path), OnlineRecognizer(stream_model_path)
-    N = 7
-    feats = [ora.fbank(synth_utterance(500 + u, 0.9 + 0.25 * (u % 4))) for u in range(N)]
-    sa = [ra.create_online_stream() for _ in range(N)]
-    sb = [rb.create_online_stream() for _ in range(N)]
-    so = [ora.create_stream() for _ in range(N)]
-    for a, b, f in zip(sa, sb, feats):
-        a.add_features(f)
-        b.add_features(f)
-    T, S = ra.chunk_length, ra.shift_length
-    pos = [0] * N
-    calls = 0
-    try:
-        while True:
-            ready = [u for u in range(N) if pos[u] + T <= feats[u].shape[0]]
-            set_switch("K2HIP_ONLINE_SPLIT", 1)
-            da, na = ra.get_results(sa)
-            set_switch("K2HIP_ONLINE_SPLIT", split)
-            db, nb = rb.get_results(sb)
-            assert da == db and na == nb and [u for u in range(N) if da[u]] == ready
-            if not ready:
-                break
-            ora.step([so[u] for u in ready], [feats[u][pos[u] : pos[u] + T] for u in ready])
-            for u in ready:
-                pos[u] += S
-            for u in range(N):
-                assert sa[u].tokens == sb[u].tokens == so[u].tokens, (calls, u)
-                assert sa[u].timestamps == sb[u].timestamps == so[u].timestamps and sa[u].hyp == sb[u].hyp == so[u].hyp
-            calls += 1
-    finally:
-        set_switch("K2HIP_ONLINE_SPLIT", 0)
-    assert calls >= 3 and sum(len(s.tokens) - 2 for s in so) > 0
-    for u in (0, 3, 6):
-        for l in range(so[u].num_layers):
-            for k in KINDS:
-                # a sub-batch has fewer rows, so its GEMMs may take another tile configuration: same math, another summation order
-                np.testing.assert_allclose(sb[u].state(l, k), sa[u].state(l, k), atol=2e-5, rtol=0)
-        np.testing.assert_allclose(sb[u].state(0, "embed"), sa[u].state(0, "embed"), atol=2e-5, rtol=0)
-
-
 def test_streaming_search_forms_agree(stream_model_path, ora):
     """The tick's search over the ready streams runs as rounds of joiner GEMMs by default (greedy_rounds) and as one persistent
     kernel with K2HIP_SEARCH_ROUNDS=0.  Both carry each stream's Hyp context across chunks; tokens, timestamps and Hyp must be
@@ -468,7 +420,9 @@ def test_feature_fifo_device_mirror_wraps_overflows_and_recovers(rec, ora):
     """The feature FIFO of a stream is mirrored in a 512-frame ring on the device so that a chunk step gathers its input there
     (no host copy of the features on the critical path).  Three streams in one batch: one whose FIFO stays small but whose ring
     position wraps (fed 40 frames at a time, ~1100 frames in total), one that is handed 700 frames at once (outgrows the ring:
-    the step falls back to the host copy for the whole batch until that FIFO has drained, then the mirror is valid again), and one
+    the step falls back to the host copy for the whole batch until that FIFO fits the ring again -- 700 - 512 frames later, not
+    when it is empty, which a FIFO that is decoded chunk by chunk never is -- then what is left is re-uploaded and the mirror is
+    valid again), and one
     fed with samples (frames produced on the device go into the ring directly).  Tokens / timestamps / Hyp against the oracle
     after every call."""
     from k2transducerasr_amd.synth import synth_utterance
@@ -481,6 +435,18 @@ def test_feature_fifo_device_mirror_wraps_overflows_and_recovers(rec, ora):
     pos = [0, 0, 0]
     hs[1].add_features(feats[1][:700])   # outgrows the ring at once
     fed[1] = 700
+    import ctypes as C
+    from k2transducerasr_amd import load_library
+    L = load_library()
+    L.k2hip_debug_stream_mirrored.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+
+    def mirrored(h):
+        ok = C.c_int32(-1)
+        assert L.k2hip_debug_stream_mirrored(h._h, C.byref(ok)) == 0
+        return ok.value
+
+    assert mirrored(hs[1]) == 0 and mirrored(hs[0]) == 1
+    recovered_at = None
     calls = 0
     while True:
         if fed[0] < feats[0].shape[0]:   # small pieces: the ring position wraps twice over the utterance
@@ -506,8 +472,12 @@ def test_feature_fifo_device_mirror_wraps_overflows_and_recovers(rec, ora):
                 pos[u] += S
         for u in range(3):
             assert hs[u].tokens == so[u].tokens and hs[u].timestamps == so[u].timestamps and hs[u].hyp == so[u].hyp, (calls, u)
+        if recovered_at is None and mirrored(hs[1]) == 1:
+            recovered_at = pos[1]
         calls += 1
     assert calls >= 30 and pos[0] > 512 and sum(len(s.tokens) - 2 for s in so) > 0
+    # the big block was back on the device path as soon as it fitted: after ceil((700 - 512) / 32) = 6 chunks, long before it drained
+    assert recovered_at == 6 * S, recovered_at
 
 
 def test_stream_reset_equals_a_fresh_stream(rec, ora):
@@ -546,3 +516,33 @@ def test_stream_reset_equals_a_fresh_stream(rec, ora):
     for l in (0, 1):
         for k in KINDS:
             np.testing.assert_allclose(a.state(l, k), o2.state(l, k), atol=2e-4, rtol=0)
+
+
+def test_failed_step_poisons_its_streams_until_reset(rec, ora):
+    """A chunk step that fails on the device may already have advanced the conv / embed caches of its streams in place; feeding the
+    same chunk again would corrupt the transcript silently.  Such streams refuse further steps until k2hip_online_stream_reset
+    (IOnlineProj.cs:65-71 has no such failure mode because ONNXRuntime copies every state in and out)."""
+    import ctypes as C
+    from k2transducerasr_amd import K2HipError, load_library
+    from k2transducerasr_amd.synth import synth_utterance
+    L = load_library()
+    L.k2hip_debug_poison_stream.argtypes = [C.c_void_p]
+    f = ora.fbank(synth_utterance(31, 1.2))
+    a, b = rec.create_online_stream(), rec.create_online_stream()
+    a.add_features(f)
+    b.add_features(f)
+    assert rec.get_results([a, b])[0] == [1, 1]
+    assert L.k2hip_debug_poison_stream(a._h) == 0
+    tok_b = list(b.tokens)
+    with pytest.raises(K2HipError, match="reset it first"):
+        rec.get_results([a, b])
+    assert b.tokens == tok_b                      # the refused call moved nothing
+    assert rec.get_results([b])[0] == [1]         # the healthy stream goes on alone
+    a.reset()
+    a.add_features(f)
+    o = ora.create_stream()
+    T, S = rec.chunk_length, rec.shift_length
+    for k in range((f.shape[0] - T) // S + 1):
+        assert rec.get_results([a])[0] == [1]
+        ora.step([o], [f[k * S : k * S + T]])
+        assert a.tokens == o.tokens and a.timestamps == o.timestamps

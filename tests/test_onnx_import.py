@@ -10,53 +10,7 @@ from k2transducerasr_amd.onnx_import import import_onnx, read_onnx
 from k2transducerasr_amd.synth import tensor_specs
 
 
-def _export(meta, tensors, tmp_path):
-    """split like icefall's export-onnx.py: encoder (+ encoder_proj), decoder (+ decoder_proj), joiner (output_linear)"""
-    files = {"encoder": ([], []), "decoder": ([], []), "joiner": ([], [])}
-    anon = 0
-    for name, arr in tensors.items():
-        arr = np.asarray(arr)
-        if name.startswith("joiner.encoder_proj."):
-            f, local = "encoder", name[len("joiner."):]
-        elif name.startswith("joiner.decoder_proj."):
-            f, local = "decoder", name[len("joiner."):]
-        elif name.startswith("joiner.output_linear."):
-            f, local = "joiner", name[len("joiner."):]
-        elif name.startswith("decoder."):
-            f, local = "decoder", name
-        else:
-            f, local = "encoder", name
-        inits, nodes = files[f]
-        if local.endswith(".weight") and arr.ndim == 2 and "embedding" not in local:
-            # Linear -> MatMul with an anonymous, transposed initializer
-            anon += 1
-            iname = f"onnx::MatMul_{1000 + anon}"
-            inits.append(ow.tensor(iname, np.ascontiguousarray(arr.T), raw=(anon % 2 == 0)))
-            scope = "/" + "/".join(_scope_parts(local[: -len(".weight")]))
-            nodes.append(ow.node(scope + "/MatMul", "MatMul", [f"x{anon}", iname], [f"y{anon}"]))
-        else:
-            inits.append(ow.tensor(local, arr))
-    paths = []
-    for f, (inits, nodes) in files.items():
-        p = tmp_path / f"{f}.onnx"
-        md = meta if f == "encoder" else {k: meta[k] for k in ("context_size", "vocab_size", "joiner_dim") if k in meta}
-        p.write_bytes(ow.model(md, inits, nodes))
-        paths.append(str(p))
-    return paths
-
-
-def _scope_parts(mod: str):
-    """module path -> scope components as torch names them: child modules of a ModuleList keep 'name.index' together"""
-    parts, out = mod.split("."), []
-    i = 0
-    while i < len(parts):
-        if i + 1 < len(parts) and parts[i + 1].isdigit():
-            out.append(parts[i] + "." + parts[i + 1])
-            i += 2
-        else:
-            out.append(parts[i])
-            i += 1
-    return out
+_export = ow.export_triple
 
 
 @pytest.mark.parametrize("preset", ["zipformer2-tiny-test", "conformer-tiny-test", "zipformer-tiny-test", "zipformer-streaming-tiny-test",
@@ -144,3 +98,24 @@ def test_int64_initializers_are_listed_not_stored(tmp_path):
     _, t = read_k2w(str(tmp_path / "o.k2w"))
     assert set(t) == {"joiner.encoder_proj.weight"} and all(a.dtype == np.float32 for a in t.values())
     assert any("Constant_output_0" in u for u in rep["unmapped"]) and any("downsample.index" in u and "int64" in u for u in rep["unmapped"])
+
+
+@pytest.mark.parametrize("preset", ["zipformer2-tiny-test", "zipformer2-streaming-tiny-test"])
+def test_int8_triple_of_a_whole_model_imports(tmp_path, preset):
+    """The whole model as quantize_dynamic leaves it: every Linear comes back within half a quantisation step of the original,
+    everything else bit-identical, nothing unmapped or missing (the GPU leg of this is tests/test_onnx_import_gpu.py)."""
+    from k2transducerasr_amd.synth import write_synthetic_model
+    src = str(tmp_path / "src.k2w")
+    meta = write_synthetic_model(src, preset)
+    meta0, t0 = read_k2w(src)
+    dst = str(tmp_path / "dst.k2w")
+    rep = import_onnx(ow.export_triple(meta0, t0, tmp_path, int8=True), dst, required=[n for n, _, _ in tensor_specs(meta)])
+    assert rep["unmapped"] == [] and rep["missing"] == []
+    meta1, t1 = read_k2w(dst)
+    assert meta1 == meta0 and set(t1) == set(t0)
+    for k, w in t0.items():
+        if k.endswith(".weight") and w.ndim == 2 and "embedding" not in k:
+            scale = (max(float(w.max()), 0.0) - min(float(w.min()), 0.0)) / 255.0
+            assert float(np.abs(t1[k] - w).max()) <= 0.5 * scale * (1 + 1e-5) + 1e-12, k
+        else:
+            assert np.array_equal(t1[k], w), k

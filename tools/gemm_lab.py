@@ -92,8 +92,6 @@ if which in ("streaming", "all"):
 cfgs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [-1, 100, 101, 103, 104]
 
 
-_tab2 = _src[_src.index("#define K2_SK_TABLE(X)") : _src.index("#define X(i, bm, bn, wm, wn, nst) {bm")]
-SK = [tuple(int(v) for v in t[1:]) for t in sorted((tuple(int(x) for x in t) for t in re.findall(r"X\((\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\)", _tab2)))]
 
 
 _tab3 = _src[_src.index("#define K2_PIPE_TABLE(X)") : _src.index("const PipeCfg kPipe[]")]
@@ -105,9 +103,6 @@ def name(c):
         return "q%dx%d.%dx%d.%d" % PIPE[c - 2100]
     if c >= 2000:
         return "p%dx%d.%dx%d.%d" % PIPE[c - 2000]
-    if c >= 1000:
-        bm, bn, wm, wn, nst = SK[(c - 1000) // 10]
-        return "sk%dx%d.%dx%d.%d/%d" % (bm, bn, wm, wn, nst, (c - 1000) % 10)
     return "auto" if c < 0 else f"c{c}" if c < 100 else "r%dx%d.%d.%d.%d%s" % (RING[c - 100][:5] + ("p" if RING[c - 100][5] else "",))
 
 
