@@ -26,9 +26,9 @@ def main():
         "write_bytes_per_launch": int(tw / nw),
         "hbm_bytes_per_launch": int(tf / nf + tw / nw),
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 2 --warmup 1 "
-                  "--no-cpu-baseline`; KB x 1024; FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B, MI355X_MICROARCH.md HBM "
+                  "--no-cpu-baseline --no-secondary`; KB x 1024; FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B, MI355X_MICROARCH.md HBM "
                   "section); WRITE_SIZE as read",
-        "source": [fetch, write],
+        "source": ["profiles/" + fetch.rsplit("/", 1)[-1], "profiles/" + write.rsplit("/", 1)[-1]],
     }
     json.dump(d, open(out, "w"), indent=1)
     print(json.dumps(d))
