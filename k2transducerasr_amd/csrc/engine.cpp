@@ -1099,6 +1099,8 @@ float Engine::debug_gemm(int M, int N, int K, int act, bool with_res, int iters,
     K2_HIP(hipMalloc(&C2, sizeof(float) * (size_t)M * N));
     K2_HIP(hipMalloc(&Rb, sizeof(float) * (size_t)M * N));
     K2_HIP(hipMalloc(&b, sizeof(float) * (size_t)N));
+    K2_HIP(hipMemset(W, 0, sizeof(float) * (size_t)N * K));   // (the last 7 / 3 elements below are not covered by the shifted copies)
+    K2_HIP(hipMemset(Rb, 0, sizeof(float) * (size_t)M * N));
     K2_HIP(hipMemcpy(A, h.data(), sizeof(float) * (size_t)M * K, hipMemcpyHostToDevice));
     K2_HIP(hipMemcpy(W, h.data() + 7, sizeof(float) * ((size_t)N * K - 7), hipMemcpyHostToDevice));
     K2_HIP(hipMemcpy(Rb, h.data() + 3, sizeof(float) * ((size_t)M * N - 3), hipMemcpyHostToDevice));
