@@ -467,6 +467,136 @@ __global__ __launch_bounds__(256) void k_attn_av_out(const float* __restrict__ a
     }
 }
 
+
+// ---- NonlinAttention.streaming_forward behind its in_proj, one launch (k_ring_put + a batched [T, KL] x [KL, Hc] GEMM + the out_proj
+// GEMM before: three launches per layer).  One workgroup per (stream, slice of out_proj's column tiles):
+//   0. the chunk's rows x * tanh(s) go into this stream's ring rows (hid row = s | x | y, Hc columns each);
+//   A. ctx[T, Hc] = aw_head0[T, KL] . ring[KL, Hc] (ring order on both sides), times the gate y, into LDS -- 16x16x4 MFMAs, a wave per
+//      16-column tile, the weight row of a lane as float4 (keys contiguous), the ring values as scalars (L2);
+//   C. x[T, D] += ctx . wout^T + bias: the column tiles of this slice over the four waves, K = Hc walked in 64-deep trips.
+// Every slice of a stream repeats 0 and A (identical values: benign), as in k_attn_av_out.
+template <int NS, int NT>  // NS = 64-key steps (all of a tile's loads are issued before its first MFMA), NT = threads
+__global__ __launch_bounds__(NT) void k_nonlin_av_out(const float* __restrict__ aw, const float* __restrict__ hid, int ldh,
+                                                      const float* __restrict__ wout, const float* __restrict__ bias,
+                                                      float* __restrict__ x, int B, int T, int KL, int Tp, int Hc, int D,
+                                                      int tiles_per_z, RingRef ring) {
+    extern __shared__ float cs_[];  // [16][Hc rounded up to 16, + 4]; the pad columns hold zeros
+    constexpr int NWV = NT / 64;
+    const int CS = ((Hc + 15) & ~15) + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int n = lane & 15, kq = lane >> 4;
+    float* rb = ring.pool + (long long)ring.slots[b] * ring.slot_stride + ring.off;
+    {
+        const int head = (int)(((long long)ring.chunks[b] * T) % KL), h4 = Hc >> 2;
+        for (int e = tid; e < T * h4; e += NT) {
+            const int r = e / h4, c = (e % h4) * 4;
+            const float* p = hid + ((long long)b * T + r) * ldh + c;
+            const float4 sg = *reinterpret_cast<const float4*>(p), v = *reinterpret_cast<const float4*>(p + Hc);
+            *reinterpret_cast<float4*>(rb + (long long)((head + r) % KL) * Hc + c) =
+                make_float4(v.x * tanhf(sg.x), v.y * tanhf(sg.y), v.z * tanhf(sg.z), v.w * tanhf(sg.w));
+        }
+    }
+    __syncthreads();
+    // ---- phase A: a tile is one latency deep -- the ring rows of a stream were written chunks ago and come from HBM / MALL (~1 us a
+    // round trip): with the loads of one 64-key step at a time and four waves the kernel was a chain of 18 such round trips (15 us)
+    const int row_a = min(n, T - 1);  // clamped rows are computed and dropped
+    const float* arow = aw + ((long long)b * T + row_a) * Tp + 4 * kq;   // head 0: aw[0][b][row][.]
+    for (int ct = wave; ct * 16 < Hc; ct += NWV) {
+        const bool cok = ct * 16 + n < Hc;  // (Hc % 16 != 0: the last tile is partial)
+        const float* vb = rb + (long long)(4 * kq) * Hc + (cok ? ct * 16 + n : 0);
+        float4 a4[NS][4];
+        float bv[NS][4][4];
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int kb = 64 * s + 16 * g + 4 * kq;
+                a4[s][g] = kb < Tp ? *reinterpret_cast<const float4*>(arow + 64 * s + 16 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int m = 0; m < 4; m++) bv[s][g][m] = (cok && kb + m < KL) ? vb[(long long)(64 * s + 16 * g + m) * Hc] : 0.f;
+            }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                if (g & 1) {
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s][g].x, bv[s][g][0], acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s][g].y, bv[s][g][1], acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s][g].z, bv[s][g][2], acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s][g].w, bv[s][g][3], acc1, 0, 0, 0);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s][g].x, bv[s][g][0], acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s][g].y, bv[s][g][1], acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s][g].z, bv[s][g][2], acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s][g].w, bv[s][g][3], acc0, 0, 0, 0);
+                }
+            }
+        // C layout: col = lane & 15, row = 4 * (lane >> 4) + e; the gate y of (row, col) multiplies here; rows >= T hold zeros
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int r = 4 * kq + e;
+            const float gate = (cok && r < T) ? hid[((long long)b * T + r) * ldh + 2 * Hc + ct * 16 + n] : 0.f;
+            cs_[r * CS + ct * 16 + n] = (acc0[e] + acc1[e]) * gate;
+        }
+    }
+    __syncthreads();
+    if (!wout) {  // the gated context rows themselves: x is [B*T, Hc] here and out_proj runs as a GEMM over all streams' rows
+        const int h4 = Hc >> 2;
+        for (int e = tid; e < T * h4; e += NT) {
+            const int r = e / h4, c = (e % h4) * 4;
+            *reinterpret_cast<float4*>(x + ((long long)b * T + r) * Hc + c) = *reinterpret_cast<const float4*>(cs_ + r * CS + c);
+        }
+        return;
+    }
+    // ---- phase C
+    const int ct0 = blockIdx.z * tiles_per_z, ct1 = min(D >> 4, ct0 + tiles_per_z);
+    const float* ar = cs_ + n * CS + 4 * kq;
+    for (int ct = ct0 + wave; ct < ct1; ct += NWV) {
+        const int col = ct * 16 + n;
+        const float* wr = wout + (long long)col * Hc + 4 * kq;
+        const float bvv = bias[col];
+        float xr[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = 4 * kq + e;
+            xr[e] = i < T ? x[((long long)b * T + i) * D + col] : 0.f;
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < Hc; c0 += 64) {  // Hc % 4 == 0: a lane's float4 is wholly inside or outside the row
+            float4 w4[4], a4[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const bool ok = c0 + 16 * g + 4 * kq < Hc;
+                w4[g] = ok ? *reinterpret_cast<const float4*>(wr + c0 + 16 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a4[g] = ok ? *reinterpret_cast<const float4*>(ar + c0 + 16 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                if (g & 1) {
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].x, w4[g].x, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].y, w4[g].y, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].z, w4[g].z, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].w, w4[g].w, acc1, 0, 0, 0);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].x, w4[g].x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].y, w4[g].y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].z, w4[g].z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].w, w4[g].w, acc0, 0, 0, 0);
+                }
+            }
+        }
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = acc0[e] + acc1[e] + bvv + xr[e];
+        float* xp = x + ((long long)b * T + 4 * kq) * D + col;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (4 * kq + e < T) xp[(long long)e * D] = o[e];
+    }
+}
+
 }  // namespace
 
 template <int NG>
@@ -542,6 +672,37 @@ bool attn_av_out_ring(const Ctx& ctx, const float* aw, const RingRef& vals, cons
                        tiles_per_z, vals, newrows);
     K2_HIP(hipGetLastError());
     return true;
+}
+
+void nonlin_av_out_ring(const Ctx& ctx, const float* aw, const RingRef& cache, const float* hid, int ldh, const float* wout, const float* bias,
+                        float* x, int B, int T, int KL, int Tp, int Hc, int D) {
+    K2_REQUIRE(Hc % 4 == 0 && D % 16 == 0 && Tp % 4 == 0 && Tp >= KL && T <= 16 && ldh % 4 == 0 && ldh >= 3 * Hc,
+               "nonlin_av_out_ring: shape Hc=%d D=%d T=%d KL=%d unsupported", Hc, D, T, KL);
+    ctx.add_flops(0.0, 2.0 * B * (double)T * Hc * (KL + D), 0);
+    if (ctx.dry) return;
+    const int ntile = D / 16;
+    int cs = std::max(1, std::min(4, 512 / std::max(1, B)));
+    cs = std::min(cs, ntile);
+    if (!wout) cs = 1;  // context rows only: nothing to slice
+    const int tiles_per_z = cdiv(ntile, cs);
+    cs = cdiv(ntile, tiles_per_z);
+    const size_t lds = sizeof(float) * 16 * (((Hc + 15) & ~15) + 4);
+    K2_REQUIRE(lds <= 64 * 1024, "nonlin_av_out_ring: Hc=%d too wide", Hc);
+    const int ns = (KL + 63) / 64;
+    K2_REQUIRE(ns >= 1 && ns <= 4, "nonlin_av_out_ring: %d keys unsupported (<= 256)", KL);
+    // 16-column tiles of the context over the waves: 16 waves when there are that many tiles (the 50 / 25 Hz stacks), else 8
+    const bool wide = (Hc + 15) / 16 > 8;
+#define K2_NONLIN_LAUNCH(NS_, NT_)                                                                                                   \
+    hipLaunchKernelGGL((k_nonlin_av_out<NS_, NT_>), dim3(1, B, cs), dim3(NT_), lds, ctx.stream, aw, hid, ldh, wout, bias, x, B, T, KL, Tp, Hc, \
+                       D, tiles_per_z, cache)
+    switch (ns) {
+        case 1: if (wide) K2_NONLIN_LAUNCH(1, 1024); else K2_NONLIN_LAUNCH(1, 512); break;
+        case 2: if (wide) K2_NONLIN_LAUNCH(2, 1024); else K2_NONLIN_LAUNCH(2, 512); break;
+        case 3: if (wide) K2_NONLIN_LAUNCH(3, 1024); else K2_NONLIN_LAUNCH(3, 512); break;
+        default: K2_NONLIN_LAUNCH(4, 512); break;  // (193 .. 256 keys: 16 waves would spill)
+    }
+#undef K2_NONLIN_LAUNCH
+    K2_HIP(hipGetLastError());
 }
 
 }  // namespace k2hip

@@ -486,8 +486,9 @@ __global__ __launch_bounds__(256) void k_glu_dwconv1d(const float* __restrict__ 
 }
 
 // ---- SimpleDownsample: softmax(bias)-weighted sum of ds frames, last frame repeated
+// x rows are Din4 float4 wide: a narrower (wider) input is zero-extended (truncated) to D4 on the fly (convert_channels)
 __global__ void k_downsample(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ y, int B,
-                             int T, int Td, int D4, int ds) {
+                             int T, int Td, int D4, int ds, int Din4) {
     long long n = (long long)B * Td * D4;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -501,22 +502,47 @@ __global__ void k_downsample(const float* __restrict__ x, const float* __restric
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = 0; k < ds; k++) {
         int tt = min(t * ds + k, T - 1);
-        float4 v = reinterpret_cast<const float4*>(x)[((long long)b * T + tt) * D4 + q];
+        float4 v = q < Din4 ? reinterpret_cast<const float4*>(x)[((long long)b * T + tt) * Din4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
         s.x += v.x * wgt[k]; s.y += v.y * wgt[k]; s.z += v.z * wgt[k]; s.w += v.w * wgt[k];
     }
     reinterpret_cast<float4*>(y)[i] = s;
 }
 // SimpleUpsample (repeat) + truncate + out_combiner bypass
+// _get_full_dim_output + the final SimpleDownsample in one pass: column c of the full-width row comes from the LAST stack output that
+// is wider than c (segments sorted by column: [col0, col1) from src with row width ld); y[b, t', c] = sum_k softmax(bias)_k full[b, ds t' + k, c]
+__global__ void k_downsample_full(FullDimSegs segs, const float* __restrict__ bias, float* __restrict__ y, int B, int T, int Td, int D4, int ds) {
+    long long n = (long long)B * Td * D4;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float wgt[16], mx = -INFINITY, sum = 0.f;
+    for (int k = 0; k < ds; k++) mx = fmaxf(mx, bias[k]);
+    for (int k = 0; k < ds; k++) { wgt[k] = expf(bias[k] - mx); sum += wgt[k]; }
+    for (int k = 0; k < ds; k++) wgt[k] /= sum;
+    int q = (int)(i % D4);
+    long long bt = i / D4;
+    int t = (int)(bt % Td), b = (int)(bt / Td);
+    int sg = 0;
+    while (sg + 1 < segs.n && 4 * q >= segs.col1[sg]) sg++;
+    const float* src = segs.src[sg];
+    const int ld4 = segs.ld[sg] >> 2;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < ds; k++) {
+        int tt = min(t * ds + k, T - 1);
+        float4 v = reinterpret_cast<const float4*>(src)[((long long)b * T + tt) * ld4 + q];
+        s.x += v.x * wgt[k]; s.y += v.y * wgt[k]; s.z += v.z * wgt[k]; s.w += v.w * wgt[k];
+    }
+    reinterpret_cast<float4*>(y)[i] = s;
+}
 __global__ void k_upsample_combine(const float* __restrict__ orig, const float* __restrict__ xd,
                                    const float* __restrict__ scale, float* __restrict__ y, int B, int T, int Td, int D4,
-                                   int ds) {
+                                   int ds, int Do4) {  // orig rows are Do4 float4 wide (zero-extended / truncated to D4)
     long long n = (long long)B * T * D4;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int q = (int)(i % D4);
     long long bt = i / D4;
     int t = (int)(bt % T), b = (int)(bt / T);
-    float4 o = reinterpret_cast<const float4*>(orig)[i];
+    float4 o = q < Do4 ? reinterpret_cast<const float4*>(orig)[bt * Do4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 u = reinterpret_cast<const float4*>(xd)[((long long)b * Td + t / ds) * D4 + q];
     float4 s = reinterpret_cast<const float4*>(scale)[q];
     reinterpret_cast<float4*>(y)[i] = make_float4(o.x + (u.x - o.x) * s.x, o.y + (u.y - o.y) * s.y,
@@ -663,15 +689,20 @@ void glu_dwconv1d_dswish(const Ctx& ctx, const float* x2, const float* w_kd, con
                           int K) {
     glu_dwconv1d_any<true, true>(ctx, x2, w_kd, b, y, B, T, D, K);
 }
-void downsample(const Ctx& ctx, const float* x, const float* bias, float* y, int B, int T, int D, int ds) {
+void downsample(const Ctx& ctx, const float* x, const float* bias, float* y, int B, int T, int D, int ds, int Din) {
     int Td = (T + ds - 1) / ds;
     long long n = (long long)B * Td * (D / 4);
-    LAUNCH(k_downsample, dim3(nblocks(n, 256)), dim3(256), x, bias, y, B, T, Td, D / 4, ds);
+    LAUNCH(k_downsample, dim3(nblocks(n, 256)), dim3(256), x, bias, y, B, T, Td, D / 4, ds, (Din > 0 ? Din : D) / 4);
+}
+void downsample_full(const Ctx& ctx, const FullDimSegs& segs, const float* bias, float* y, int B, int T, int D, int ds) {
+    int Td = (T + ds - 1) / ds;
+    long long n = (long long)B * Td * (D / 4);
+    LAUNCH(k_downsample_full, dim3(nblocks(n, 256)), dim3(256), segs, bias, y, B, T, Td, D / 4, ds);
 }
 void upsample_combine(const Ctx& ctx, const float* orig, const float* xd, const float* scale, float* y, int B, int T,
-                      int Td, int D, int ds) {
+                      int Td, int D, int ds, int Dorig) {
     long long n = (long long)B * T * (D / 4);
-    LAUNCH(k_upsample_combine, dim3(nblocks(n, 256)), dim3(256), orig, xd, scale, y, B, T, Td, D / 4, ds);
+    LAUNCH(k_upsample_combine, dim3(nblocks(n, 256)), dim3(256), orig, xd, scale, y, B, T, Td, D / 4, ds, (Dorig > 0 ? Dorig : D) / 4);
 }
 void convert_channels(const Ctx& ctx, const float* x, float* y, int M, int Din, int Dout) {
     long long n = (long long)M * (Dout / 4);

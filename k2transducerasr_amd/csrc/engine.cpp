@@ -369,7 +369,25 @@ void Engine::encoder_layer(const Ctx& c, int si, int li, float* x, const float* 
 }
 
 // Zipformer2.forward stacks; returns full-dim output [B*T50, Dmax]
-float* Engine::encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, float** tap_ptr, int* tap_dim, bool* tapped) {
+
+// which stack output supplies which columns of the full-width row (Zipformer2._get_full_dim_output): the last stack's output, then,
+// walking back, every stack that is wider than what is covered so far contributes its extra columns
+static FullDimSegs full_dim_segments(const Config& cf, float* const* outputs) {
+    FullDimSegs s;
+    int cur = cf.dim[cf.ns - 1];
+    s.src[0] = outputs[cf.ns - 1]; s.ld[0] = cur; s.col1[0] = cur; s.n = 1;
+    for (int i = cf.ns - 2; i >= 0; i--) {
+        const int d = cf.dim[i];
+        if (d > cur) {
+            K2_REQUIRE(s.n < 8, "too many stack widths");
+            s.src[s.n] = outputs[i]; s.ld[s.n] = d; s.col1[s.n] = d; s.n++;
+            cur = d;
+        }
+    }
+    return s;
+}
+
+float* Engine::encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, float** tap_ptr, int* tap_dim, bool* tapped, FullDimSegs* segs_out) {
     const Model& m = *model_;
     const Config& cf = m.cfg();
     Arena& ar = *c.arena;
@@ -379,14 +397,17 @@ float* Engine::encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, 
     int Dcur = cf.dim[0];
     for (int si = 0; si < cf.ns; si++) {
         const int D = cf.dim[si], ds = cf.ds[si];
-        float* xi = ar.take<float>((int64_t)M * D);
-        if (D == Dcur) {
-            if (!c.dry) K2_HIP(hipMemcpyAsync(xi, x, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, c.stream));
-        } else {
-            convert_channels(c, x, xi, M, Dcur, D);
-        }
+        // the stack's input is the previous output zero-extended / truncated to D channels (convert_channels): a stack that runs at
+        // the input rate works in place on a converted copy (or on x itself when the width does not change); a downsampled stack
+        // never materialises it -- its downsample and its out_combiner read x at its own width
+        const int Din = Dcur;
         Dcur = D;
         if (ds == 1) {
+            float* xi = x;
+            if (D != Din) {
+                xi = ar.take<float>((int64_t)M * D);
+                convert_channels(c, x, xi, M, Din, D);
+            }
             const float* pe = c.dry ? nullptr : pos_emb(T50);
             for (int li = 0; li < cf.nlayer[si]; li++) encoder_layer(c, si, li, xi, pe, B, T50);
             x = xi;
@@ -395,10 +416,10 @@ float* Engine::encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, 
             float* y = ar.take<float>((int64_t)M * D);
             int64_t mark = ar.mark();
             float* xd = ar.take<float>((int64_t)B * Td * D);
-            downsample(c, xi, m.wf("encoder.encoders.%d.downsample.bias", si), xd, B, T50, D, ds);
+            downsample(c, x, m.wf("encoder.encoders.%d.downsample.bias", si), xd, B, T50, D, ds, Din);
             const float* pe = c.dry ? nullptr : pos_emb(Td);
             for (int li = 0; li < cf.nlayer[si]; li++) encoder_layer(c, si, li, xd, pe, B, Td);
-            upsample_combine(c, xi, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y, B, T50, Td, D, ds);
+            upsample_combine(c, x, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y, B, T50, Td, D, ds, Din);
             ar.rewind(mark);
             x = y;
         }
@@ -409,6 +430,10 @@ float* Engine::encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, 
             *tapped = true;
             return nullptr;
         }
+    }
+    if (segs_out) {  // the caller gathers the columns itself (downsample_full): no concatenated tensor
+        *segs_out = full_dim_segments(cf, outputs);
+        return nullptr;
     }
     // _get_full_dim_output
     const int Dmax = cf.dmax;
@@ -447,7 +472,8 @@ float* Engine::encoder_forward(const Ctx& c, const float* x, int B, int T, int* 
         return nullptr;
     }
     bool tapped = false;  // NB: pointers are all null in a dry run, so never test them
-    float* full = encoder_stacks(c, x0, B, T50, tap, tap_ptr, tap_dim, &tapped);
+    FullDimSegs segs;
+    float* full = encoder_stacks(c, x0, B, T50, tap, tap_ptr, tap_dim, &tapped, tap == 100 ? nullptr : &segs);
     if (tapped) return nullptr;
     if (tap == 100) {
         *tap_ptr = full;
@@ -455,7 +481,7 @@ float* Engine::encoder_forward(const Ctx& c, const float* x, int B, int T, int* 
         return nullptr;
     }
     float* dsd = ar.take<float>((int64_t)B * Tpp * cf.dmax);
-    downsample(c, full, m.w("encoder.downsample_output.bias"), dsd, B, T50, cf.dmax, 2);
+    downsample_full(c, segs, m.w("encoder.downsample_output.bias"), dsd, B, T50, cf.dmax, 2);
     if (cf.ctc) {  // CTC head: Linear(Dmax -> V) + log_softmax = the model's "log_probs" output
         linear(c, dsd, cf.dmax, m.w("ctc_output.1.weight"), m.w("ctc_output.1.bias"), enc_out, cf.V, B * Tpp, cf.dmax, cf.V);
         log_softmax_rows(c, enc_out, B * Tpp, cf.V);

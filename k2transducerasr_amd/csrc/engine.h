@@ -126,7 +126,7 @@ class Engine {
     // device-side building blocks; all take a Ctx (dry run = sizing only)
     float* encoder_embed(const Ctx& c, const float* x, int B, int T, int* T50);
     void encoder_layer(const Ctx& c, int si, int li, float* x, const float* pe, int B, int T);
-    float* encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, float** tap_ptr, int* tap_dim, bool* tapped);
+    float* encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, float** tap_ptr, int* tap_dim, bool* tapped, FullDimSegs* segs_out = nullptr);
     float* encoder_forward(const Ctx& c, const float* x, int B, int T, int* Tp, int tap, float** tap_ptr, int* tap_rows,
                            int* tap_dim);
     void greedy_device(const Ctx& c, const float* enc, int B, int Tp, bool single, long long* d_tok, int* d_ts, int* d_n,

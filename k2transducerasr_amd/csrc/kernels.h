@@ -166,6 +166,13 @@ bool attn_av_out(const Ctx& ctx, const float* aw, const float* v, const float* w
 bool attn_av_out_ring(const Ctx& ctx, const float* aw, const RingRef& vals, const float* newrows, const float* wout, const float* bias, float* x,
                       int B, int T, int KL, int Tp, int H, int vh, int D);
 
+// NonlinAttention.streaming_forward after its in_proj: hid [B*T, ldh] rows = s | x | y (Hc columns each); x * tanh(s) of the chunk's
+// rows goes into the cache ring, then ctx = (aw_head0 . ring) * y.  wout != nullptr: x[B*T, D] += out_proj(ctx) in the same launch
+// (every stream's workgroup pulls the whole out_proj matrix through its CU: only worth it for narrow stacks); wout == nullptr:
+// x [B*T, Hc] = ctx, and the caller runs out_proj as a GEMM over all streams' rows.  T <= 16.
+void nonlin_av_out_ring(const Ctx& ctx, const float* aw, const RingRef& cache, const float* hid, int ldh, const float* wout, const float* bias,
+                        float* x, int B, int T, int KL, int Tp, int Hc, int D);
+
 // ---- elementwise / small -----------------------------------------------------
 // packed: all streams' features back to back; d_off/d_len: per-stream start and float count (device)
 void pad_logfloor(const Ctx& ctx, const float* packed, const long long* d_off, const long long* d_len, float* out, int B,
@@ -232,10 +239,18 @@ void conformer_softmax_shift(const Ctx& ctx, float* ac, const float* bd, int Z, 
 // projected positional table pp [2T-1, D]; false = shape not covered (caller takes the GEMM + conformer_softmax_shift form)
 bool conformer_scores_softmax(const Ctx& ctx, const float* qu, const float* qv, const float* kmat, int ldk, const float* pp, float* aw, int B, int H,
                               int T, int Tp, int D);
-void downsample(const Ctx& ctx, const float* x, const float* bias, float* y, int B, int T, int D, int ds);
+// Din / Dorig > 0: the input rows are that wide and are zero-extended / truncated to D on the fly (convert_channels folded in)
+void downsample(const Ctx& ctx, const float* x, const float* bias, float* y, int B, int T, int D, int ds, int Din = 0);
 void upsample_combine(const Ctx& ctx, const float* orig, const float* xd, const float* scale, float* y, int B, int T,
-                      int Td, int D, int ds);
+                      int Td, int D, int ds, int Dorig = 0);
 void convert_channels(const Ctx& ctx, const float* x, float* y, int M, int Din, int Dout);
+// Zipformer2._get_full_dim_output without the concatenated tensor: columns [col1[i-1], col1[i]) of the full-width row live in src[i]
+// (row width ld[i]); downsample_full = that gather + SimpleDownsample(ds) in one launch
+struct FullDimSegs {
+    const float* src[8];
+    int ld[8], col1[8], n = 0;
+};
+void downsample_full(const Ctx& ctx, const FullDimSegs& segs, const float* bias, float* y, int B, int T, int D, int ds);
 void copy_cols(const Ctx& ctx, const float* x, int ldx, int xcol0, float* y, int ldy, int ycol0, int M, int n);
 
 // ---- fbank -----------------------------------------------------------------------
@@ -357,9 +372,6 @@ void convnext_cat(const Ctx& ctx, const float* a3, const float* pool, long long 
 void convnext_cache_update(const Ctx& ctx, const float* a3, float* pool, long long slot_stride, long long embed_off,
                            const int* slots, int B, int T3, int Tc, int F, int C);
 // tanh_gated: the new rows are formed as x[width + c] * tanh(x[c]) from rows of >= 2*width floats (NonlinAttention's gated input)
-// the chunk's new rows (newrows [B*Tc, ldn], `width` columns; gated: x[width + c] * tanh(x[c]) of rows of >= 2 * width floats,
-// NonlinAttention's cached input) into their ring rows
-void ring_put(const Ctx& ctx, const RingRef& ring, const float* newrows, int ldn, int B, int L, int Tc, int width, bool tanh_gated);
 void cat_shift(const Ctx& ctx, float* pool, long long slot_stride, long long off, const int* slots, const float* newrows,
                int ldn, float* cat, int B, int L, int Tc, int width, bool tanh_gated = false);
 // ring form: the keys of the left context are read from the ring, the chunk's own key rows (columns [32 H, 64 H) of qkp) are

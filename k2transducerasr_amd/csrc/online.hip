@@ -104,25 +104,6 @@ __global__ void k_cat_shift(float* __restrict__ pool, long long slot_stride, lon
     }
 }
 
-template <bool GATE>
-__global__ void k_ring_put(RingRef ring, const float* __restrict__ newrows, int ldn, int B, int L, int Tc, int width) {
-    const int w4 = width >> 2, KL = L + Tc;
-    const long long n = (long long)B * Tc * w4;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = (int)(i % w4) * 4;
-    const long long br = i / w4;
-    const int r = (int)(br % Tc), b = (int)(br / Tc);
-    const int head = (int)(((long long)ring.chunks[b] * Tc) % KL);
-    const float* p = newrows + ((long long)b * Tc + r) * ldn + c;
-    float4 v = *reinterpret_cast<const float4*>(GATE ? p + width : p);
-    if (GATE) {
-        const float4 sg = *reinterpret_cast<const float4*>(p);
-        v = make_float4(v.x * tanhf(sg.x), v.y * tanhf(sg.y), v.z * tanhf(sg.z), v.w * tanhf(sg.w));
-    }
-    *reinterpret_cast<float4*>(ring.pool + (long long)ring.slots[b] * ring.slot_stride + ring.off + (long long)((head + r) % KL) * width + c) = v;
-}
-
 // RelPositionMultiheadAttentionWeights.streaming_forward for one (stream, head), keys in the stream's ring (RingRef): the
 // chunk's own key rows go into the ring first (this workgroup's 32 columns of them; nobody else reads or writes those), then every
 // key is read from ring row p.  Column p of aw = ring row p; the reference's key index of that row (for the positional term and the
@@ -416,14 +397,6 @@ void cat_shift(const Ctx& ctx, float* pool, long long slot_stride, long long off
         hipLaunchKernelGGL(k_cat_shift<true>, grid, dim3(256), 0, ctx.stream, pool, slot_stride, off, slots, newrows, ldn, cat, B, L, Tc, width);
     else
         hipLaunchKernelGGL(k_cat_shift<false>, grid, dim3(256), 0, ctx.stream, pool, slot_stride, off, slots, newrows, ldn, cat, B, L, Tc, width);
-    K2_HIP(hipGetLastError());
-}
-void ring_put(const Ctx& ctx, const RingRef& ring, const float* newrows, int ldn, int B, int L, int Tc, int width, bool tanh_gated) {
-    K2_REQUIRE(width % 4 == 0 && ldn % 4 == 0, "ring_put: width %d / ld %d must be multiples of 4", width, ldn);
-    if (ctx.dry) return;
-    const dim3 grid(nb((long long)B * Tc * (width / 4), 256));
-    if (tanh_gated) hipLaunchKernelGGL(k_ring_put<true>, grid, dim3(256), 0, ctx.stream, ring, newrows, ldn, B, L, Tc, width);
-    else hipLaunchKernelGGL(k_ring_put<false>, grid, dim3(256), 0, ctx.stream, ring, newrows, ldn, B, L, Tc, width);
     K2_HIP(hipGetLastError());
 }
 void attn_stream_ring(const Ctx& ctx, const float* qkp, int ld, const RingRef& keys, const float* pp, const long long* plen, float* aw, int B,

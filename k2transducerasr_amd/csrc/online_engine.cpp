@@ -317,16 +317,6 @@ void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x,
         linear(c, in, D, w(a), w(b), hid, Fk, M, D, Fk, ACT_SWOOSH_L);
         linear(c, hid, Fk, w(cc), w(d), out, D, M, Fk, D, ACT_NONE, in, D);
     };
-    // out[b] = aw[0][b] (Tc x KL, ring order) . ring[slot_b] (KL x width), times the gate in the epilogue
-    auto attn_apply_ring = [&](long long off, int width, float* out, const float* gate, int ldg) {
-        GemmArgs g;
-        g.mul = gate; g.ldm = ldg; g.sM0 = (long long)Tc * ldg;
-        g.A = aw; g.lda = KLp; g.sA0 = (long long)Tc * KLp; g.sA1 = (long long)B * Tc * KLp;
-        g.W = online_pool_ + off; g.w_kn = 1; g.ldw = width; g.sW0 = SS; g.wz_map = d_slots;
-        g.C = out; g.ldc = width; g.sC0 = (long long)Tc * width;
-        g.M = Tc; g.N = width; g.K = KL; g.nb0 = B; g.nb1 = 1;
-        gemm(c, g);
-    };
     auto self_attn = [&](int k, long long cache_off) {
         char a[48], b[48], cc[48], d[48];
         snprintf(a, sizeof a, "self_attn%d.in_proj.weight", k);
@@ -357,8 +347,9 @@ void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x,
     linear(c, cat, ldcat, w("feed_forward1.out_proj.weight"), w("feed_forward1.out_proj.bias"), src, D, M, F1, D, ACT_NONE, x, D);
     {   // NonlinAttention.streaming_forward
         linear(c, src, D, w("nonlin_attention.in_proj.weight"), w("nonlin_attention.in_proj.bias"), hid, 3 * Hc, M, D, 3 * Hc);
-        ring_put(c, ring(lay_.nonlin[l]), hid, 3 * Hc, B, L, Tc, Hc, /*tanh_gated=*/true);  // x * tanh(s) into the ring rows of this chunk
-        attn_apply_ring(lay_.nonlin[l], Hc, tmp2, hid + 2 * Hc, 3 * Hc);  // x * y (the third chunk of in_proj) in the epilogue
+        // x * tanh(s) into the ring rows of this chunk and ctx = (aw_head0 . ring) * y in one per-stream launch (k_ring_put + a batched
+        // GEMM before), then out_proj over all rows
+        nonlin_av_out_ring(c, aw, ring(lay_.nonlin[l]), hid, 3 * Hc, nullptr, nullptr, tmp2, B, Tc, KL, KLp, Hc, D);
         linear(c, tmp2, Hc, w("nonlin_attention.out_proj.weight"), w("nonlin_attention.out_proj.bias"), src, D, M, Hc, D, ACT_NONE, src, D);
     }
     self_attn(1, lay_.val1[l]);
@@ -392,14 +383,17 @@ float* Engine::online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_
     int Dcur = cf.dim[0], l = 0;
     for (int si = 0; si < cf.ns; si++) {
         const int D = cf.dim[si], ds = cf.ds[si], L = cf.left[si];
-        float* xi = ar.take<float>((int64_t)M * D);
-        if (D == Dcur) {
-            if (!c.dry) K2_HIP(hipMemcpyAsync(xi, x, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, c.stream));
-        } else {
-            convert_channels(c, x, xi, M, Dcur, D);
-        }
+        // the stack's input is the previous output zero-extended / truncated to D channels (convert_channels): a stack that runs at
+        // the input rate works in place on a converted copy (or on x itself when the width does not change); a downsampled stack
+        // never materialises it -- its downsample and its out_combiner read x at its own width
+        const int Din = Dcur;
         Dcur = D;
         if (ds == 1) {
+            float* xi = x;
+            if (D != Din) {
+                xi = ar.take<float>((int64_t)M * D);
+                convert_channels(c, x, xi, M, Din, D);
+            }
             const float* pe = c.dry ? nullptr : pos_emb_stream(Tc, L);
             for (int li = 0; li < cf.nlayer[si]; li++, l++) encoder_layer_stream(c, si, li, l, xi, pe, d_slots, d_plen, d_chunks, B, Tc, L);
             x = xi;
@@ -408,30 +402,33 @@ float* Engine::online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_
             float* y = ar.take<float>((int64_t)M * D);
             int64_t mark = ar.mark();
             float* xd = ar.take<float>((int64_t)B * Td * D);
-            downsample(c, xi, m.wf("encoder.encoders.%d.downsample.bias", si), xd, B, Tc, D, ds);
+            downsample(c, x, m.wf("encoder.encoders.%d.downsample.bias", si), xd, B, Tc, D, ds, Din);
             const float* pe = c.dry ? nullptr : pos_emb_stream(Td, L);
             for (int li = 0; li < cf.nlayer[si]; li++, l++) encoder_layer_stream(c, si, li, l, xd, pe, d_slots, d_plen, d_chunks, B, Td, L);
-            upsample_combine(c, xi, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y, B, Tc, Td, D, ds);
+            upsample_combine(c, x, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y, B, Tc, Td, D, ds, Din);
             ar.rewind(mark);
             x = y;
         }
         outputs[si] = x;
     }
     const int Dmax = cf.dmax;
-    float* full = ar.take<float>((int64_t)M * Dmax);
-    int cur = cf.dim[cf.ns - 1];
-    copy_cols(c, outputs[cf.ns - 1], cur, 0, full, Dmax, 0, M, cur);
-    for (int i = cf.ns - 2; i >= 0; i--) {
-        int d = cf.dim[i];
-        if (d > cur) {
-            copy_cols(c, outputs[i], d, cur, full, Dmax, cur, M, d - cur);
-            cur = d;
-        }
-    }
     const int Tpp = (Tc + 1) / 2;
     K2_REQUIRE(Tpp == Tp, "internal: chunk yields %d frames, expected %d", Tpp, Tp);
     float* dsd = ar.take<float>((int64_t)B * Tp * Dmax);
-    downsample(c, full, m.w("encoder.downsample_output.bias"), dsd, B, Tc, Dmax, 2);
+    {   // _get_full_dim_output + downsample_output in one launch (no concatenated tensor)
+        FullDimSegs segs;
+        int cur = cf.dim[cf.ns - 1];
+        segs.src[0] = outputs[cf.ns - 1]; segs.ld[0] = cur; segs.col1[0] = cur; segs.n = 1;
+        for (int i = cf.ns - 2; i >= 0; i--) {
+            const int d = cf.dim[i];
+            if (d > cur) {
+                K2_REQUIRE(segs.n < 8, "too many stack widths");
+                segs.src[segs.n] = outputs[i]; segs.ld[segs.n] = d; segs.col1[segs.n] = d; segs.n++;
+                cur = d;
+            }
+        }
+        downsample_full(c, segs, m.w("encoder.downsample_output.bias"), dsd, B, Tc, Dmax, 2);
+    }
     float* enc = ar.take<float>((int64_t)B * Tp * cf.enc_dim());
     if (cf.ctc) {
         linear(c, dsd, Dmax, m.w("ctc_output.1.weight"), m.w("ctc_output.1.bias"), enc, cf.V, B * Tp, Dmax, cf.V);
