@@ -1,5 +1,8 @@
-"""CPU sanitizer build (AddressSanitizer + UBSan) of libk2hip's pure-host units that read untrusted bytes: the .k2w container
-parser (csrc/k2w_file.cpp) and the token -> text stage (csrc/text.cpp).  GPU sanitizers do not exist on this pool, and this is
+"""CPU sanitizer build (AddressSanitizer + UBSan) of libk2hip's host code: the units that read untrusted bytes -- the .k2w container
+parser (csrc/k2w_file.cpp) and the token -> text stage (csrc/text.cpp) -- and, over a CPU stand-in of the engine
+(tests/native/engine_stub.cpp), the host layer itself: csrc/api.cpp's OfflineStream / OnlineStream mirrors (feature FIFO, lazy fbank,
+RemoveChunk, IsFinished, device-mirror bookkeeping, poisoning after a failed step), argument checks and error transport, plus the
+real config parser of csrc/model.cpp.  GPU sanitizers do not exist on this pool, and this is
 where a malformed input could hurt: a truncated, corrupted or mismatched file must come back as K2HIP_ERR_IO, never as a crash
 (the reference's contract: every failure of the operator is an exception, OfflineProjOfTransducer.cs:87-90)."""
 import os
@@ -92,3 +95,45 @@ def test_text_stage_under_sanitizers(driver, tmp_path):
     run(driver, "text", str(p), "0", "9", "10", "8")                            # malformed hex tokens
     assert run(driver, "text", str(p), "0", "99").startswith("ERR -1")          # id outside tokens.txt -> K2HIP_ERR_INVALID
     assert run(driver, "text", str(tmp_path / "none.txt"), "0", "1").startswith("ERR -2")
+
+
+# ---- the host layer (csrc/api.cpp) under the sanitizers, over tests/native/engine_stub.cpp ---------------------------------------
+API_DRIVER = os.path.join(ROOT, "tests", "native", "k2hip_san_api_driver")
+
+
+@pytest.fixture(scope="module")
+def api_driver(driver):
+    return API_DRIVER
+
+
+@pytest.fixture(scope="module")
+def streaming_tiny_path(tmp_path_factory):
+    from k2transducerasr_amd.synth import write_synthetic_model
+    p = str(tmp_path_factory.mktemp("san") / "stream.k2w")
+    write_synthetic_model(p, "zipformer2-streaming-tiny-test")
+    return p
+
+
+def test_api_error_paths_poisoning_and_mirror_recovery(api_driver, streaming_tiny_path):
+    """Null arguments, a stream of another model, one stream twice in a GetResults list, a device failure inside a chunk step (nothing
+    host-side moves, the streams refuse further steps until reset), the same for the operator-level states, and the FIFO mirror's
+    return after an oversized block -- all through the C ABI, api.cpp compiled with ASan + UBSan (OnlineStream.cs:82-161,
+    IOnlineProj.cs:65-71)."""
+    assert run(api_driver, "errors", streaming_tiny_path) == "errors ok"
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_online_stream_bookkeeping_fuzz(api_driver, streaming_tiny_path, seed):
+    """4 000 random AddSamples (ragged lengths, empty pushes) / AddFeatures / GetResults over random subsets / IsFinished / Reset /
+    destroy-and-create calls over 7 streams; after every call SpeechLength, the decodable flag of every stream and the token counts
+    must equal a plain model of OnlineStream.cs:57-161 kept by the driver."""
+    out = run(api_driver, "online", streaming_tiny_path, str(seed), "4000")
+    assert out.startswith("online ok: 4000 rounds")
+    assert int(out.split(",")[1].split()[0]) > 1000          # chunk steps actually ran
+
+
+def test_offline_stream_and_pipeline_paths(api_driver, tiny_model_path):
+    """OfflineStream AddSamples in pieces, GetResult / GetResults, submit / wait with exactly-sized output buffers, a third submit and a
+    second wait refused, decoder / joiner operators (OfflineStream.cs:43-68, OfflineRecognizer.cs:77-91)."""
+    out = run(api_driver, "offline", tiny_model_path, "7", "60")
+    assert out.startswith("offline ok: 60 rounds")
