@@ -279,23 +279,32 @@ __device__ void gemv_kn_wide(const float* x, int K, const float* __restrict__ W,
 // the decoder's front end (embedding + grouped Conv1d(k = 2) + ReLU) -> h[DD]
 __device__ void decoder_conv_wide(const DecJoinW& w, long long y0, long long y1, float* h, float* scratch) {
     const int tid = threadIdx.x;
+    // (the embedding rows are loaded UNCONDITIONALLY from clamped ids and masked afterwards: a load under `y >= 0 ? ... : 0` is a
+    // branch with its own wait, and a thread's 2 cpg loads then run one after the other)
+    const long long z0 = y0 >= 0 ? y0 : 0, z1 = y1 >= 0 ? y1 : 0;
+    const float m0 = y0 >= 0 ? 1.f : 0.f, m1 = y1 >= 0 ? 1.f : 0.f;
     if (w.cpg <= 4) {
         for (int co = tid; co < w.DD; co += GT) {
             const int g0 = (co / w.cpg) * w.cpg;
+            float e0[4], e1[4];
+#pragma unroll
+            for (int ci = 0; ci < 4; ci++) {
+                const int cc = min(ci, w.cpg - 1);
+                e0[ci] = w.emb[z0 * w.DD + g0 + cc];
+                e1[ci] = w.emb[z1 * w.DD + g0 + cc];
+            }
             float s = 0.f;
             for (int ci = 0; ci < w.cpg; ci++) {
-                float e0 = y0 >= 0 ? w.emb[y0 * w.DD + g0 + ci] : 0.f;
-                float e1 = y1 >= 0 ? w.emb[y1 * w.DD + g0 + ci] : 0.f;
-                s += w.conv[(co * w.cpg + ci) * 2 + 0] * e0;
-                s += w.conv[(co * w.cpg + ci) * 2 + 1] * e1;
+                s += w.conv[(co * w.cpg + ci) * 2 + 0] * (e0[ci] * m0);
+                s += w.conv[(co * w.cpg + ci) * 2 + 1] * (e1[ci] * m1);
             }
             h[co] = fmaxf(s, 0.f);
         }
         __syncthreads();
     } else if (w.ptab) {
-        const float* p0 = w.ptab + y0 * w.DD;
-        const float* p1 = w.ptab + ((long long)w.V + y1) * w.DD;
-        for (int co = tid; co < w.DD; co += GT) h[co] = fmaxf((y0 >= 0 ? p0[co] : 0.f) + (y1 >= 0 ? p1[co] : 0.f), 0.f);
+        const float* p0 = w.ptab + z0 * w.DD;
+        const float* p1 = w.ptab + ((long long)w.V + z1) * w.DD;
+        for (int co = tid; co < w.DD; co += GT) h[co] = fmaxf(p0[co] * m0 + p1[co] * m1, 0.f);
         __syncthreads();
     } else {
         float* xe = h + w.DD;
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
         for (int k = tid; k < w.J; k += GT) {
             float e[GF];
 #pragma unroll
-            for (int f = 0; f < GF; f++) e[f] = f < nf ? enc[(long long)(t + f) * w.J + k] : 0.f;
+            for (int f = 0; f < GF; f++) e[f] = enc[(long long)min(t + f, a.Tp - 1) * w.J + k];   // (unconditional, clamped; dropped below when f >= nf)
             const float da = dec_a[k], db = a.t0 ? dec_b[k] : 0.f, dn = dec_own[k];
             float* dst = actT + k * GF + (k / kper) * APAD;
 #pragma unroll
