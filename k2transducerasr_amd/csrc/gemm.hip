@@ -862,256 +862,6 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
 }
 
 // ---------------------------------------------------------------------------------------
-// The pipelined kernel on v_mfma_f32_16x16x4_f32.  Same LDS image, DMA, addressing and pipeline as gemm_f32_mfma_pipe; what
-// changes is the instruction shape, because of POWER: a pure register-to-register stream of the 32x32x2 shape draws 1128 W at
-// 153 TFLOP/s, the 16x16x4 shape 942 W (tools/probes/mfma_shape_power_probe.hip: same flop rate, but 16 instead of 32
-// accumulator bytes through the register file per 16 flop).  With the operand traffic of a GEMM on top the 32x32 kernels sit at
-// the 1400 W package limit and run at ~2.05 - 2.3 GHz; the vendor library's fp32 kernels (all 16x16x4) run at 2.4 GHz on 1180 W.
-//   * a k group is 16 deep (two per K step): lane (r = lane & 15, kq = lane >> 4) reads 4 consecutive k of row r at k = 16 g + 4 kq as
-//     one ds_read_b128 and feeds element e to MFMA e, whose four k slots then hold k = 16 g + 4 kq + e;
-//   * the product is computed TRANSPOSED (the W fragment is the MFMA's A operand): lane (c = lane & 15, q = lane >> 4) ends up with
-//     C[row c of the block][columns 4 q .. 4 q + 3], so the epilogue loads the residual and stores the result as float4 (needs
-//     N, ldc, ldr % 4 == 0 and 16-byte aligned C / residual: the launcher checks).
-template <int BM, int BN, int WM, int WN, int NST>
-__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe16(GemmArgs g) {
-    constexpr int BK = 32;
-    constexpr int MB = WM / 16, NB = WN / 16;  // 16 x 16 blocks of the wave tile
-    constexpr int WCOLS = BN / WN;
-    constexpr int NW = (BM / WM) * (BN / WN);
-    constexpr int NINST = (BM + BN) / 8;
-    constexpr int IPW = NINST / NW;
-    constexpr int STAGE = (BM + BN) * BK;
-    constexpr int DPE = (IPW + 3) / 4;
-    static_assert(NST == 3 || NST == 4, "pipe16: three or four stages");
-    static_assert(NINST % NW == 0, "pipe16: every wave issues the same number of DMA instructions");
-    static_assert((NST - 2) * IPW <= 63 && MB <= 4 && NB <= 4 && BM % 16 == 0, "pipe16: counted wait / wave tile out of range");
-
-    if (g.skip_if_zero && *g.skip_if_zero == 0) return;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / WCOLS, wc = wave % WCOLS;
-    const int r16 = lane & 15, kq = lane >> 4;
-    float* __restrict__ C = g.C;
-    const float* __restrict__ R = g.res;
-    int mb_, nb_;
-    xcd_tile(mb_, nb_);
-    const int m0 = mb_ * BM, n0 = nb_ * BN;
-    const int nk = g.K / BK;
-
-    unsigned long long* stamp = g.dbg ? g.dbg + ((size_t)(blockIdx.x + blockIdx.y * gridDim.x) * NW + wave) * 64 : nullptr;
-    int nstamp = 0;
-#define K2_PIPE_STAMP()                                                    \
-    if (stamp) {                                                           \
-        if (lane == 0) stamp[nstamp] = __builtin_amdgcn_s_memtime();       \
-        nstamp++;                                                          \
-    }
-    if (stamp && lane == 0) stamp[60] = __builtin_amdgcn_s_memrealtime();
-    K2_PIPE_STAMP()
-
-    // residual first (older than every DMA): block (ib, jb) of this lane is row ib*16 + r16, columns jb*16 + 4 kq .. + 3
-    f32x4 rres[MB][NB];
-    if (R) {
-#pragma unroll
-        for (int ib = 0; ib < MB; ib++) {
-            const int row = min(m0 + wr * WM + ib * 16 + r16, g.M - 1);
-#pragma unroll
-            for (int jb = 0; jb < NB; jb++) {
-                const int col = min(n0 + wc * WN + jb * 16 + 4 * kq, g.N - 4);
-                rres[ib][jb] = *reinterpret_cast<const f32x4*>(R + (long long)row * g.ldr + col);
-            }
-        }
-    }
-
-    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
-    unsigned voff[IPW];
-    unsigned long long sb[IPW];
-    unsigned mq[IPW];
-#pragma unroll
-    for (int q = 0; q < IPW; q++) {
-        const int inst = wave + q * NW;
-        const int slot = inst * 64 + lane;
-        const int r = slot >> 3, cp = slot & 7;
-        const int c = cp ^ ((r >> 1) & 7);
-        const bool is_a = inst < BM / 8;
-        const long long row = is_a ? min(m0 + r, g.M - 1) : min(n0 + (r - BM), g.N - 1);
-        voff[q] = (unsigned)((row * (is_a ? g.lda : g.ldw) + 4 * c) * 4);
-        const unsigned long long base = (unsigned long long)(is_a ? g.A : g.W);
-        sb[q] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
-                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
-        mq[q] = __builtin_amdgcn_readfirstlane(lds_base + inst * 1024);
-    }
-    // fragment read addresses: (stage, 16-deep k group); the 16-row blocks of the wave tile are 2048 bytes apart and share the swizzle
-    const int sw = (r16 >> 1) & 7;
-    const float* ra[NST][2];  // plain LDS loads through these (see gemm_f32_mfma_pipe: asm reads + hand-placed waits are not safe)
-    const float* rb[NST][2];
-#pragma unroll
-    for (int st = 0; st < NST; st++)
-#pragma unroll
-        for (int gq = 0; gq < 2; gq++) {
-            ra[st][gq] = smem + st * STAGE + (wr * WM + r16) * BK + (((4 * gq + kq) ^ sw) << 2);
-            rb[st][gq] = smem + st * STAGE + (BM + wc * WN + r16) * BK + (((4 * gq + kq) ^ sw) << 2);
-        }
-
-    f32x4 acc[MB][NB];
-#pragma unroll
-    for (int ib = 0; ib < MB; ib++)
-#pragma unroll
-        for (int jb = 0; jb < NB; jb++) acc[ib][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 fa[2][MB], fb[2][NB];
-
-#define K2_P16_DMA(ST_, KT_, q_)                                                                                           \
-    {                                                                                                                      \
-        const unsigned long long src_ = sb[q_] + (unsigned long long)(KT_) * (BK * 4);                                    \
-        asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                    \
-                     :                                                                                                     \
-                     : "v"(voff[q_]), "s"(src_), "s"(mq[q_]), "n"((ST_) * STAGE * 4)                                       \
-                     : "memory", "m0", "scc");                                                                                          \
-    }
-#define K2_P16_READ(SET_, ST_, G_)                                                                                         \
-    {                                                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < MB; i++) fa[SET_][i] = *reinterpret_cast<const f32x4*>(ra[ST_][G_] + i * 16 * BK); \
-        _Pragma("unroll") for (int j = 0; j < NB; j++) fb[SET_][j] = *reinterpret_cast<const f32x4*>(rb[ST_][G_] + j * 16 * BK); \
-    }
-#define K2_P16_FRAGS_READY(SET_) {}
-// one K step = two 16-deep k groups (register sets 0 and 1).  The wait for step KT_+1 and the barrier sit between them; the first
-// fragments of step KT_+1 and the DMA of step KT_+NST-1 go out behind the MFMA steps of the second group.
-#define K2_P16_STEP(ST_, KT_, HAS_NEXT_, DO_ISSUE_, WAIT_)                                                                 \
-    _Pragma("unroll") for (int gq = 0; gq < 2; gq++) {                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        K2_P16_FRAGS_READY(gq)                                                                                             \
-        _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                                    \
-            _Pragma("unroll") for (int ib = 0; ib < MB; ib++) _Pragma("unroll") for (int jb = 0; jb < NB; jb++)            \
-                acc[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[gq][jb][e], fa[gq][ib][e], acc[ib][jb], 0, 0, 0);    \
-            if (e == 0) {                                                                                                  \
-                __builtin_amdgcn_sched_barrier(0);                                                                         \
-                if (gq == 0) K2_P16_READ(1, ST_, 1)                                                                        \
-                if (gq == 1 && (HAS_NEXT_)) K2_P16_READ(0, ((ST_) + 1) % NST, 0)                                           \
-                __builtin_amdgcn_sched_barrier(0);                                                                         \
-            }                                                                                                              \
-            if (gq == 1 && (DO_ISSUE_)) {                                                                                  \
-                __builtin_amdgcn_sched_barrier(0);                                                                         \
-                _Pragma("unroll") for (int q = e * DPE; q < (e + 1) * DPE && q < IPW; q++)                                 \
-                    K2_P16_DMA(((ST_) + NST - 1) % NST, (KT_) + NST - 1, q)                                                \
-                __builtin_amdgcn_sched_barrier(0);                                                                         \
-            }                                                                                                              \
-        }                                                                                                                  \
-        if (gq == 0 && (HAS_NEXT_)) {                                                                                      \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
-            WAIT_                                                                                                          \
-            __builtin_amdgcn_s_barrier();                                                                                  \
-            if ((KT_) < 40) { K2_PIPE_STAMP() }                                                                            \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
-        }                                                                                                                  \
-    }
-#define K2_P16_WAIT_STEADY asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 3) * IPW) : "memory");
-#define K2_P16_WAIT_DRAIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-#pragma unroll
-    for (int p = 0; p < NST - 1; p++)
-        if (p < nk) {
-#pragma unroll
-            for (int q = 0; q < IPW; q++) {
-                if (p == 0) K2_P16_DMA(0, 0, q)
-                if (p == 1) K2_P16_DMA(1, 1, q)
-                if (p == 2) K2_P16_DMA(2, 2, q)
-            }
-        }
-    K2_PIPE_STAMP()
-    if (nk >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * IPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    K2_P16_READ(0, 0, 0)
-    K2_PIPE_STAMP()
-
-    int kt = 0;
-    const int nsteady = nk - (NST - 1);
-    for (; kt + NST <= nsteady; kt += NST) {
-        K2_P16_STEP(0, kt, true, true, K2_P16_WAIT_STEADY)
-        K2_P16_STEP(1, kt + 1, true, true, K2_P16_WAIT_STEADY)
-        K2_P16_STEP(2, kt + 2, true, true, K2_P16_WAIT_STEADY)
-        if (NST == 4) { K2_P16_STEP(NST == 4 ? 3 : 0, kt + 3, true, true, K2_P16_WAIT_STEADY) }
-    }
-#define K2_P16_S(j_) K2_P16_STEP((j_) % NST, kt + (j_), true, true, K2_P16_WAIT_STEADY)
-#define K2_P16_T(j_) K2_P16_STEP((j_) % NST, kt + (j_), true, false, K2_P16_WAIT_DRAIN)
-#define K2_P16_L(j_) K2_P16_STEP((j_) % NST, kt + (j_), false, false, K2_P16_WAIT_DRAIN)
-    const int rs = nsteady - kt;
-    if (NST == 3) {
-        switch (rs) {
-            case 0: K2_P16_T(0) K2_P16_L(1) break;
-            case 1: K2_P16_S(0) K2_P16_T(1) K2_P16_L(2) break;
-            default: K2_P16_S(0) K2_P16_S(1) K2_P16_T(2) K2_P16_L(3) break;
-        }
-    } else {
-        switch (rs) {
-            case 0: K2_P16_T(0) K2_P16_T(1) K2_P16_L(2) break;
-            case 1: K2_P16_S(0) K2_P16_T(1) K2_P16_T(2) K2_P16_L(3) break;
-            case 2: K2_P16_S(0) K2_P16_S(1) K2_P16_T(2) K2_P16_T(3) K2_P16_L(4) break;
-            default: K2_P16_S(0) K2_P16_S(1) K2_P16_S(2) K2_P16_T(3) K2_P16_T(4) K2_P16_L(5) break;
-        }
-    }
-#undef K2_P16_S
-#undef K2_P16_T
-#undef K2_P16_L
-    K2_PIPE_STAMP()
-#undef K2_P16_WAIT_DRAIN
-#undef K2_P16_WAIT_STEADY
-#undef K2_P16_STEP
-#undef K2_P16_FRAGS_READY
-#undef K2_P16_READ
-#undef K2_P16_DMA
-
-    // ---- epilogue: lane (c = lane & 15, q = lane >> 4) holds C[row ib*16 + c][columns jb*16 + 4 q .. + 3] of each block ----
-    const bool has_byp = g.byp_orig != nullptr;
-#pragma unroll
-    for (int ib = 0; ib < MB; ib++) {
-        const int row = m0 + wr * WM + ib * 16 + r16;
-#pragma unroll
-        for (int jb = 0; jb < NB; jb++) {
-            const int col = n0 + wc * WN + jb * 16 + 4 * kq;
-            if (row < g.M && col < g.N) {
-                f32x4 v = acc[ib][jb];
-                f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (g.bias) bv = f32x4{g.bias[col], g.bias[col + 1], g.bias[col + 2], g.bias[col + 3]};
-                f32x4 ov = f32x4{0.f, 0.f, 0.f, 0.f}, bs = ov;
-                if (has_byp) {
-                    ov = *reinterpret_cast<const f32x4*>(g.byp_orig + (long long)row * g.ld_orig + col);
-                    bs = f32x4{g.byp_scale[col], g.byp_scale[col + 1], g.byp_scale[col + 2], g.byp_scale[col + 3]};
-                }
-                v += bv;
-                switch (g.act) {  // wave-uniform; columns >= act_cols keep their value
-#define K2_ACT_CASE(A_)                                                                                  \
-    case A_:                                                                                             \
-        _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                  \
-            const float t = apply_act(v[r], A_);                                                         \
-            v[r] = (g.act_cols == 0 || col + r < g.act_cols) ? t : v[r];                                 \
-        }                                                                                                \
-        break;
-                    K2_ACT_CASE(ACT_SWOOSH_L)
-                    K2_ACT_CASE(ACT_SWOOSH_R)
-                    K2_ACT_CASE(ACT_TANH)
-                    K2_ACT_CASE(ACT_SIGMOID)
-                    K2_ACT_CASE(ACT_RELU)
-                    K2_ACT_CASE(ACT_DOUBLE_SWISH)
-#undef K2_ACT_CASE
-                    default: break;
-                }
-                if (R) v += rres[ib][jb];
-                if (has_byp) v = ov + (v - ov) * bs;
-                *reinterpret_cast<f32x4*>(C + (long long)row * g.ldc + col) = v;
-            }
-        }
-    }
-    K2_PIPE_STAMP()
-    if (stamp && lane == 0) {
-        stamp[62] = nstamp;
-        stamp[63] = __builtin_amdgcn_s_memrealtime();
-    }
-#undef K2_PIPE_STAMP
-}
-
-// ---------------------------------------------------------------------------------------
 // Ring variant of the LDS-DMA kernel (plain Linear, K % (32 KS) == 0).  Same tile image and swizzle as above; what changes is
 // the pipeline and the K split:
 //   * the fragments of a K tile are read from LDS into a SECOND register set while the MFMAs of the previous tile run, so
@@ -1467,12 +1217,6 @@ void launch_ring(const Ctx& ctx, const GemmArgs& a) {
     hipLaunchKernelGGL((gemm_f32_mfma_ring<BM, BN, KS, NST, LW, PF>), grid, dim3(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)), lds, ctx.stream, a);
 }
 
-// float4 epilogue of the 16x16x4 kernels
-bool pipe16_ok(const GemmArgs& a) {
-    auto al16 = [](const void* p) { return ((unsigned long long)p & 15) == 0; };
-    return a.N % 4 == 0 && a.ldc % 4 == 0 && al16(a.C) && (!a.res || (a.ldr % 4 == 0 && al16(a.res))) &&
-           (!a.byp_orig || (a.ld_orig % 4 == 0 && al16(a.byp_orig)));
-}
 template <int BM, int BN, int WM, int WN, int NST>
 void launch_pipe(const Ctx& ctx, const GemmArgs& a) {
     dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), 1);
@@ -1492,27 +1236,7 @@ struct PipeCfg { int BM, BN, WM, WN, NST; };
 #define X(i, bm, bn, wm, wn, nst) {bm, bn, wm, wn, nst},
 const PipeCfg kPipe[] = {K2_PIPE_TABLE(X)};
 #undef X
-template <int BM, int BN, int WM, int WN, int NST>
-void launch_pipe16(const Ctx& ctx, const GemmArgs& a) {
-    dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), 1);
-    size_t lds = sizeof(float) * NST * (BM + BN) * 32;
-    static LdsAttrOnce lds_attr;
-    lds_attr.ensure(gemm_f32_mfma_pipe16<BM, BN, WM, WN, NST>, (int)lds);
-    K2_REQUIRE((long long)a.M * a.lda < (1ll << 29) && (long long)a.N * a.ldw < (1ll << 29), "pipe16: operand too large for 31-bit lane byte offsets");
-    K2_REQUIRE(a.K % 32 == 0 && a.K >= 32 * (NST - 1), "pipe16: K %d too short for %d stages", a.K, NST);
-    K2_REQUIRE(pipe16_ok(a), "pipe16: needs N, ldc, ldr, ld_orig %% 4 == 0 and 16-byte aligned C / residual / bypass operand");
-    hipLaunchKernelGGL((gemm_f32_mfma_pipe16<BM, BN, WM, WN, NST>), grid, dim3(64 * (BM / WM) * (BN / WN)), lds, ctx.stream, a);
-}
 bool launch_pipe_idx(const Ctx& ctx, const GemmArgs& a, int idx) {
-    if (idx >= 100) {  // the 16x16x4 form of table entry idx - 100
-        switch (idx - 100) {
-#define X(i, bm, bn, wm, wn, nst) case i: launch_pipe16<bm, bn, wm, wn, nst>(ctx, a); break;
-            K2_PIPE_TABLE(X)
-#undef X
-            default: return false;
-        }
-        return true;
-    }
     switch (idx) {
 #define X(i, bm, bn, wm, wn, nst) case i: launch_pipe<bm, bn, wm, wn, nst>(ctx, a); break;
         K2_PIPE_TABLE(X)
@@ -1753,7 +1477,7 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
                 best_cost = cost;
             }
         }
-        launch_pipe_idx(ctx, b, tn.gemm_mfma16 && pipe16_ok(b) && !b.glu ? best + 100 : best);
+        launch_pipe_idx(ctx, b, best);
         K2_HIP(hipGetLastError());
         if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 128;
         if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));

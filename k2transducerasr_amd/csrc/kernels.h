@@ -13,7 +13,6 @@ struct Tunables {
     int gemm_no_skinny = 0;       // K2HIP_GEMM_NO_SKINNY
     int gemm_nst3 = 0;            // K2HIP_GEMM_NST3: three-stage ring for the 128x64 LDS-DMA kernel
     int no_glu_epilogue = 0;      // K2HIP_NO_GLU_EPILOGUE: conv modules' GLU in the depthwise kernel (round 1 form) instead of the in_proj GEMM's epilogue
-    int gemm_mfma16 = 0;          // K2HIP_GEMM_MFMA16: the v_mfma_f32_16x16x4_f32 form of the pipelined kernel (less power per flop, more instructions)
     int gemm_v1 = 0;              // K2HIP_GEMM_V1: the earlier LDS-DMA kernels and tile rules (barrier at the top of every K step) instead of gemm_f32_mfma_pipe
     int attn_long = 0;            // K2HIP_ATTN_LONG: two-pass attention scores for every length
     int no_fused_av = 0;          // K2HIP_NO_FUSED_AV: attention apply + out_proj as two GEMMs

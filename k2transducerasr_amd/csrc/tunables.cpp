@@ -23,7 +23,6 @@ const Entry kEntries[] = {
     {"K2HIP_GEMM_NO_SKINNY", &Tunables::gemm_no_skinny, true},
     {"K2HIP_GEMM_NST3", &Tunables::gemm_nst3, true},
     {"K2HIP_GEMM_V1", &Tunables::gemm_v1, false},  // 1: everything older; 2: only the pipelined kernel off; 4: only the small ring tiles off
-    {"K2HIP_GEMM_MFMA16", &Tunables::gemm_mfma16, true},
     {"K2HIP_NO_GLU_EPILOGUE", &Tunables::no_glu_epilogue, true},
     {"K2HIP_ATTN_LONG", &Tunables::attn_long, true},
     {"K2HIP_NO_FUSED_AV", &Tunables::no_fused_av, true},

@@ -12,8 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("switch", ["", "K2HIP_GEMM_MFMA16=1"])
-def test_tokens_do_not_depend_on_timing(switch):
+def test_tokens_do_not_depend_on_timing(switch=""):
     cmd = [sys.executable, os.path.join(ROOT, "tools", "determinism_stress.py"), "60"] + ([switch] if switch else [])
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -99,8 +99,6 @@ PIPE = [tuple(int(v) for v in t[1:]) for t in sorted((tuple(int(x) for x in t) f
 
 
 def name(c):
-    if c >= 2100:
-        return "q%dx%d.%dx%d.%d" % PIPE[c - 2100]
     if c >= 2000:
         return "p%dx%d.%dx%d.%d" % PIPE[c - 2000]
     return "auto" if c < 0 else f"c{c}" if c < 100 else "r%dx%d.%d.%d.%d%s" % (RING[c - 100][:5] + ("p" if RING[c - 100][5] else "",))
