@@ -192,55 +192,74 @@ __global__ __launch_bounds__(512) void k_conformer_scores_softmax(const float* _
         }
     }
     const int njt = (T + 31) / 32;
-    // B operands of a key tile: the keys' rows and the two runs of 32 table rows
-    float4 fk[NG], p0[NG], p1[NG];
-    auto load_tile = [&](int jt, float4* k_, float4* a_, float4* b_) {
-        const int j0 = jt * 32, base = T - 1 - i0 - 31 + j0;
-        const int jr = min(j0 + li, T - 1);
-        const int n0 = min(max(base + li, 0), NP - 1), n1 = min(max(base + 32 + li, 0), NP - 1);  // out-of-table rows only meet masked entries
+    // A wave takes a RUN of consecutive key tiles.  Tile jt needs the positional products against table rows base + li (the "low" run)
+    // and base + 32 + li (the "high" run), base = T - 1 - i0 - 31 + 32 jt: the high run of tile jt IS the low run of tile jt + 1, so
+    // along a run every positional tile is computed once and used twice -- 2 tiles' worth of MFMAs per key tile instead of 3 (plus one
+    // per run).  The next tile's operands are requested as soon as this tile's MFMAs are issued: they arrive under the scatter below.
+    float4 fk[NG], ph[NG];
+    auto load_k = [&](int jt, float4* k_) {
+        const int jr = min(jt * 32 + li, T - 1);
 #pragma unroll
-        for (int g = 0; g < NG; g++) {
-            k_[g] = *reinterpret_cast<const float4*>(kmat + (rowbase + jr) * ldk + h * DK + 8 * g + 4 * lh);
-            a_[g] = *reinterpret_cast<const float4*>(pp + (long long)n0 * D + h * DK + 8 * g + 4 * lh);
-            b_[g] = *reinterpret_cast<const float4*>(pp + (long long)n1 * D + h * DK + 8 * g + 4 * lh);
-        }
+        for (int g = 0; g < NG; g++) k_[g] = *reinterpret_cast<const float4*>(kmat + (rowbase + jr) * ldk + h * DK + 8 * g + 4 * lh);
     };
-    for (int jt = wave; jt < njt; jt += 8) {
-        const int j0 = jt * 32, j = j0 + li;
-        load_tile(jt, fk, p0, p1);
-        cf32x16 acc, g0, g1;
+    auto load_p = [&](int nrow, float4* p_) {   // table row nrow (out-of-table rows only meet masked entries)
+        const int nr = min(max(nrow, 0), NP - 1);
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = g0[r] = g1[r] = 0.f;
+        for (int g = 0; g < NG; g++) p_[g] = *reinterpret_cast<const float4*>(pp + (long long)nr * D + h * DK + 8 * g + 4 * lh);
+    };
+    const int tpw = (njt + 7) >> 3, jt_beg = wave * tpw, jt_end = min(njt, jt_beg + tpw);
+    if (jt_beg < jt_end) {
+        cf32x16 acc, glo, ghi;
+        const int base0 = T - 1 - i0 - 31 + jt_beg * 32;
+        load_p(base0 + li, ph);
+        load_k(jt_beg, fk);
 #pragma unroll
-        for (int g = 0; g < NG; g++) {   // content term, and the positional term against table rows base + li / base + 32 + li
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[g].x, fk[g].x, acc, 0, 0, 0);
-            g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].x, p0[g].x, g0, 0, 0, 0);
-            g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].x, p1[g].x, g1, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[g].y, fk[g].y, acc, 0, 0, 0);
-            g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].y, p0[g].y, g0, 0, 0, 0);
-            g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].y, p1[g].y, g1, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[g].z, fk[g].z, acc, 0, 0, 0);
-            g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].z, p0[g].z, g0, 0, 0, 0);
-            g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].z, p1[g].z, g1, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[g].w, fk[g].w, acc, 0, 0, 0);
-            g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].w, p0[g].w, g0, 0, 0, 0);
-            g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].w, p1[g].w, g1, 0, 0, 0);
+        for (int r = 0; r < 16; r++) glo[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; g++) {   // the run's first low positional tile
+            glo = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].x, ph[g].x, glo, 0, 0, 0);
+            glo = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].y, ph[g].y, glo, 0, 0, 0);
+            glo = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].z, ph[g].z, glo, 0, 0, 0);
+            glo = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].w, ph[g].w, glo, 0, 0, 0);
         }
-        // C layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  The tile's 32 strip columns belong to this
-        // wave alone; LDS operations of one wave complete in order.
-        if (j < T) {
+        load_p(base0 + 32 + li, ph);
+        for (int jt = jt_beg; jt < jt_end; jt++) {
+            const int j0 = jt * 32, j = j0 + li;
 #pragma unroll
-            for (int r = 0; r < 16; r++) S[((r & 3) + 8 * (r >> 2) + 4 * lh) * lds_stride + j] = acc[r];
-        }
-        __builtin_amdgcn_wave_barrier();
+            for (int r = 0; r < 16; r++) acc[r] = ghi[r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int c0 = li - 31 + rl, c1 = li + 1 + rl;   // strip column (within the tile) fed by G[rl][li] / G[rl][32 + li]
-            if (c0 >= 0 && j0 + c0 < T) S[rl * lds_stride + j0 + c0] += g0[r];
-            if (c1 < 32 && j0 + c1 < T) S[rl * lds_stride + j0 + c1] += g1[r];
+            for (int g = 0; g < NG; g++) {   // content term, and the positional term against the high run of table rows
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[g].x, fk[g].x, acc, 0, 0, 0);
+                ghi = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].x, ph[g].x, ghi, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[g].y, fk[g].y, acc, 0, 0, 0);
+                ghi = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].y, ph[g].y, ghi, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[g].z, fk[g].z, acc, 0, 0, 0);
+                ghi = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].z, ph[g].z, ghi, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[g].w, fk[g].w, acc, 0, 0, 0);
+                ghi = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].w, ph[g].w, ghi, 0, 0, 0);
+            }
+            if (jt + 1 < jt_end) {   // (wave-uniform) the next tile's keys and high run, into the registers just consumed
+                load_k(jt + 1, fk);
+                load_p(base0 + (jt + 1 - jt_beg) * 32 + 32 + li, ph);
+            }
+            // C layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  The tile's 32 strip columns belong to
+            // this wave alone; LDS operations of one wave complete in order.
+            if (j < T) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) S[((r & 3) + 8 * (r >> 2) + 4 * lh) * lds_stride + j] = acc[r];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int c0 = li - 31 + rl, c1 = li + 1 + rl;   // strip column (within the tile) fed by G[rl][li] / G[rl][32 + li]
+                if (c0 >= 0 && j0 + c0 < T) S[rl * lds_stride + j0 + c0] += glo[r];
+                if (c1 < 32 && j0 + c1 < T) S[rl * lds_stride + j0 + c1] += ghi[r];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; r++) glo[r] = ghi[r];   // this tile's high run is the next tile's low run
         }
-        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     // row softmax: wave w owns rows 4w .. 4w+3; a row's T scores are read ONCE into registers (T <= 64 * 20)
