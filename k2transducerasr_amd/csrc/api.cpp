@@ -868,6 +868,19 @@ __attribute__((visibility("default"))) int32_t k2hip_debug_search_retries(k2hip_
         *n = model->engine.search_retries();
     });
 }
+// test hook (not part of include/k2hip.h): the all-contexts decoder table against the decoder itself on sampled contexts
+__attribute__((visibility("default"))) int32_t k2hip_debug_decoder_table_check(k2hip_model_t* model, int32_t n_samples, uint32_t seed,
+                                                                                int64_t* rows, int64_t* mismatched) {
+    return guard([&] {
+        NEED(model); NEED(rows); NEED(mismatched);
+        K2_REQUIRE(n_samples >= 0 && n_samples <= 65536, "decoder table check: %d samples", n_samples);
+        EngineLock lk(model->engine);
+        long long r = 0, m = 0;
+        model->engine.decoder_table_check(n_samples, seed, &r, &m);
+        *rows = r;
+        *mismatched = m;
+    });
+}
 // test hook (not part of include/k2hip.h): mark a stream as if a chunk step over it had failed on the device
 __attribute__((visibility("default"))) int32_t k2hip_debug_poison_stream(k2hip_online_stream_t* s) {
     return guard([&] {

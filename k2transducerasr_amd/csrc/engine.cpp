@@ -1,3 +1,4 @@
+#include <cstring>
 #include "engine.h"
 
 #include <climits>
@@ -54,6 +55,7 @@ Engine::~Engine() {
     for (auto& kv : sinus_cache_) (void)hipFree(kv.second);
     if (online_pool_) (void)hipFree(online_pool_);
     if (d_ptab_) (void)hipFree(d_ptab_);
+    if (d_dec_table_) (void)hipFree(d_dec_table_);
     for (auto& e : ev_)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : evpool_) (void)hipEventDestroy(e);
@@ -161,7 +163,70 @@ DecJoinW Engine::decjoin() {
         }
         w.ptab = d_ptab_;
     }
+    // Every context's decoder output, when the vocabulary is small enough (V = 500: 250 500 rows x 2 KB = 0.5 GB of the 288):
+    // an emission's decoder update in the search loops is then one row read instead of a 1 MB GEMV through one CU.
+    const size_t table_bytes = sizeof(float) * ((size_t)c.V + 1) * c.V * c.J;
+    if (!dec_table_tried_ && tunables().decoder_table_mb > 0 && table_bytes <= (size_t)tunables().decoder_table_mb << 20 &&
+        c.J % 4 == 0 && c.DD % 4 == 0) {
+        dec_table_tried_ = true;
+        if (hipMalloc(&d_dec_table_, table_bytes) == hipSuccess) {
+            Ctx t;
+            t.stream = stream_;
+            decoder_table(t, w, d_dec_table_);
+            K2_HIP(hipStreamSynchronize(stream_));
+        } else {
+            (void)hipGetLastError();   // no room: the loops run the decoder themselves
+            d_dec_table_ = nullptr;
+        }
+    }
+    w.dec_table = d_dec_table_;
     return w;
+}
+
+void Engine::decoder_table_check(int n_samples, unsigned seed, long long* rows, long long* mismatched) {
+    const DecJoinW w = decjoin();
+    *rows = 0;
+    *mismatched = 0;
+    if (!w.dec_table) return;
+    const long long V = w.V, n_ctx = (V + 1) * V;
+    *rows = n_ctx;
+    std::vector<long long> y;
+    auto add = [&](long long y0, long long y1) { y.push_back(y0); y.push_back(y1); };
+    add(-1, K2HIP_BLANK_ID);
+    add(K2HIP_BLANK_ID, K2HIP_BLANK_ID);
+    add(-1, V - 1);
+    add(V - 1, V - 1);
+    unsigned long long st = seed * 6364136223846793005ull + 1442695040888963407ull;
+    for (int i = 0; i < n_samples; i++) {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        const long long cx = (long long)((st >> 20) % (unsigned long long)n_ctx);
+        add(cx / V - 1, cx % V);
+    }
+    const int N = (int)(y.size() / 2);
+    long long* d_y = nullptr;
+    float* d_out = nullptr;
+    K2_HIP(hipMalloc(&d_y, sizeof(long long) * y.size()));
+    K2_HIP(hipMalloc(&d_out, sizeof(float) * (size_t)N * w.J));
+    std::vector<float> got((size_t)N * w.J), want(w.J);
+    try {
+        K2_HIP(hipMemcpyAsync(d_y, y.data(), sizeof(long long) * y.size(), hipMemcpyHostToDevice, stream_));
+        Ctx t;
+        t.stream = stream_;
+        decoder_rows_wide(t, w, d_y, N, d_out);
+        K2_HIP(hipMemcpyAsync(got.data(), d_out, sizeof(float) * got.size(), hipMemcpyDeviceToHost, stream_));
+        K2_HIP(hipStreamSynchronize(stream_));
+        for (int n = 0; n < N; n++) {
+            const long long row = (y[2 * n] + 1) * V + y[2 * n + 1];
+            K2_HIP(hipMemcpy(want.data(), w.dec_table + row * w.J, sizeof(float) * w.J, hipMemcpyDeviceToHost));
+            for (int k = 0; k < w.J; k++) *mismatched += memcmp(&want[k], &got[(size_t)n * w.J + k], sizeof(float)) != 0;
+        }
+    } catch (...) {
+        (void)hipFree(d_y);
+        (void)hipFree(d_out);
+        throw;
+    }
+    (void)hipFree(d_y);
+    (void)hipFree(d_out);
 }
 
 // ---------------------------------------------------------------------------

@@ -39,6 +39,9 @@ class Engine {
     std::mutex& mutex() { return mu_; }
     int device() const { return device_; }
     int search_retries() const { return search_retries_; }
+    // test hook: rows of the all-contexts decoder table (0: the model has none) and how many floats of `n_samples` sampled rows
+    // (+ the first, the start contexts' and the last) differ in their bits from the decoder run on those contexts
+    void decoder_table_check(int n_samples, unsigned seed, long long* rows, long long* mismatched);
     hipStream_t stream() const { return stream_; }
 
     int encoder_out_frames(int T) const;
@@ -173,6 +176,8 @@ class Engine {
     std::mutex cache_mu_;  // pos_proj / pos_emb / decjoin tables are built lazily
     float* online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_slots, const long long* d_plen, const int* d_chunks, int B);
     DecJoinW decjoin();
+    float* d_dec_table_ = nullptr;  // [(V + 1) V][J] decoder output of every context (small vocabularies), built on first use
+    bool dec_table_tried_ = false;
     float* d_ptab_ = nullptr;  // [2][V][DD] per-token decoder-conv table (groups = 1 models), built on first use
 
     // run `body` once dry to size the arena, then for real

@@ -117,24 +117,6 @@ __device__ __forceinline__ void amax_wave(float& v, int& i) {
     }
 }
 
-// Data-parallel-primitive lane moves (row = 16 lanes): no LDS crossbar, unlike __shfl_xor's ds_bpermute_b32.  The search kernel's
-// per-round reductions were 288 bpermutes per wave and round: ~11 us of a ~50 us round for the argmax alone.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
-}
-constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppRor8 = 0x128;  // quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_ror:8
-// (value, index) max over each aligned group of 8 lanes, result in all 8 (the order of the merges does not matter: a total order)
-__device__ __forceinline__ void amax_8lanes(float& v, int& i) {
-    amax_merge(v, i, dpp_f<kDppXor1>(v), dpp_i<kDppXor1>(i));
-    amax_merge(v, i, dpp_f<kDppXor2>(v), dpp_i<kDppXor2>(i));
-    amax_merge(v, i, dpp_f<kDppHalfMirror>(v), dpp_i<kDppHalfMirror>(i));
-}
-
 // one wave per row; FIRST = false: later index wins ties (transducer loops); true: first index (CTC, Array.IndexOf)
 template <bool FIRST>
 __global__ void k_argmax_rows(const float* __restrict__ logits, int ld, int N, int V, int* __restrict__ tok) {
@@ -235,8 +217,9 @@ constexpr int GT = 512;    // threads per workgroup (8 waves; 1024 spilled 65 VG
 // the 8 k slices of a wave read actT rows kper*GF floats apart (a multiple of 64 dwords: the same
 // LDS banks, an 8-way conflict on every read); skew each slice by APAD floats
 constexpr int APAD = 8;
-// weight loads in flight per thread in the joiner sweep
+// weight rows in flight per lane in the joiner sweep
 constexpr int GL = 8;
+constexpr int kPsumFloats = (GT / 64) * GF * 256;   // 64 KB
 
 // dec_out[J] = decoder_proj(relu(grouped_conv(emb[y0], emb[y1]))), GT threads, two per output
 // out[n] = f(bias[n] + sum_k x[k] * W[k*N + n]) for a k-major matrix, GT threads: 8 k slices x N/4 column
@@ -320,6 +303,80 @@ __device__ void decoder_block_wide(const DecJoinW& w, long long y0, long long y1
     decoder_conv_wide(w, y0, y1, h, scratch);
     gemv_kn_wide(h, w.DD, w.dproj_kn, w.dproj_b, w.J, scratch, out, false);
 }
+// Small vocabularies: every context's decoder output is in the model's table (decoder_table below, built by this file's own
+// arithmetic: the same bits) and a decoder update is one row read.
+__device__ __forceinline__ bool decoder_in_table(const DecJoinW& w, long long y0, long long y1) {
+    return w.dec_table && y0 >= -1 && y0 < w.V && y1 >= 0 && y1 < w.V;
+}
+__device__ void decoder_lookup(const DecJoinW& w, long long y0, long long y1, float* out) {
+    const float* row = w.dec_table + ((y0 + 1) * w.V + y1) * (long long)w.J;
+    for (int n = 4 * threadIdx.x; n < w.J; n += 4 * GT) *reinterpret_cast<float4*>(out + n) = *reinterpret_cast<const float4*>(row + n);
+    __syncthreads();
+}
+// out[J] (LDS, 16-byte aligned) = decoder(y0, y1): the table's row, or computed here
+__device__ void decoder_context(const DecJoinW& w, long long y0, long long y1, float* h, float* scratch, float* out) {
+    if (decoder_in_table(w, y0, y1)) decoder_lookup(w, y0, y1, out);
+    else decoder_block_wide(w, y0, y1, h, scratch, out);
+}
+
+// ---- the sweep on the matrix pipe ------------------------------------------------------------------
+// c += act[GF frames][rows] . W[rows][the lane's 4 columns] for the `nrows` rows of one k slice, one wave.
+// v_mfma_f32_4x4x1_16B_f32 is 16 independent 4 x 4 outer products: block = lane / 4, A[lane] = the row's activation of frame
+// lane % 4 (the same in every block: al = the slice's activations + (lane & 3), GF floats per row), B[lane] = the lane's weight, and
+// accumulator register i of a lane is frame i x the lane's column -- 8 instructions per weight row give 8 frames x 256 columns, none
+// of the shape wasted, each an fma onto the slice's running sum exactly like the vector FMAs they replace
+// (tools/probes/sweep_compute_probe.hip compares the two bit for bit).  The vector pipe needed 32 v_fma (~4 cycles each with two waves
+// on the SIMD) for what these 8 (~9 cycles each) do: 7.3 -> 5.2 us per 0.5 MB slab in the probe, 8.9 us as the compiler packed the
+// FMAs (v_pk_fma_f32 is slower than two v_fma on gfx950).
+// wp: the lane's 4 columns of the slice's first row (16-byte aligned), ldw floats between rows.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma_sweep_rows(const float* __restrict__ wp, long long ldw, const float* al, int nrows, f32x4 (&c)[2][4]) {
+    if (nrows <= 0) return;
+    // A ring of GL weight rows per lane: row k + GL is requested as soon as row k has been used, and the next row's activations are
+    // read one row ahead; the scheduling barrier keeps the compiler from sinking the requests to just before their use (which left
+    // 2-4 in flight: the whole L2 latency, ~0.5 us, per group of rows).
+    float4 wv[GL];
+#pragma unroll
+    for (int i = 0; i < GL; i++) wv[i] = *reinterpret_cast<const float4*>(wp + (long long)min(i, nrows - 1) * ldw);
+    float anext[2] = {al[0], al[4]};
+    auto row = [&](int k, int i, bool reload) {
+        const float alo = anext[0], ahi = anext[1];
+        const int kn = min(k + 1, nrows - 1);
+        anext[0] = al[kn * GF];
+        anext[1] = al[kn * GF + 4];
+        const float4 wk = wv[i];
+        if (reload) wv[i] = *reinterpret_cast<const float4*>(wp + (long long)min(k + GL, nrows - 1) * ldw);
+        c[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(alo, wk.x, c[0][0], 0, 0, 0);
+        c[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(alo, wk.y, c[0][1], 0, 0, 0);
+        c[0][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(alo, wk.z, c[0][2], 0, 0, 0);
+        c[0][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(alo, wk.w, c[0][3], 0, 0, 0);
+        c[1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(ahi, wk.x, c[1][0], 0, 0, 0);
+        c[1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(ahi, wk.y, c[1][1], 0, 0, 0);
+        c[1][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(ahi, wk.z, c[1][2], 0, 0, 0);
+        c[1][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(ahi, wk.w, c[1][3], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int kb = 0;
+    for (; kb + 2 * GL <= nrows; kb += GL) {
+#pragma unroll
+        for (int i = 0; i < GL; i++) row(kb + i, i, true);
+    }
+    for (; kb + GL <= nrows; kb += GL) {   // the last whole group: only the tail's rows are still to be requested
+#pragma unroll
+        for (int i = 0; i < GL; i++) row(kb + i, i, kb + GL + i < nrows);
+    }
+#pragma unroll
+    for (int i = 0; i < GL; i++)
+        if (kb + i < nrows) row(kb + i, i, false);   // (uniform)
+}
+// the k slices' partial sums of one pass go through LDS: psum[slice][frame][256 columns]
+__device__ __forceinline__ void psum_store(float* psum, int wave, int lane, const f32x4 (&c)[2][4]) {
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            *reinterpret_cast<float4*>(psum + ((wave * GF) + 4 * hh + i) * 256 + 4 * lane) = make_float4(c[hh][0][i], c[hh][1][i], c[hh][2][i], c[hh][3][i]);
+}
 
 // ---- vocabulary-parallel exchange ----------------------------------------------------------------
 // With a large vocabulary (V = 5537: an 11 MB joiner matrix) one workgroup per stream spends ~300 us per
@@ -341,24 +398,22 @@ __device__ __forceinline__ unsigned long long load_granule(const unsigned long l
     return __hip_atomic_load((gu64*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// LDS: actT[J][GF] | dec_a[J] | dec_b[J] | dec_own[J] | h[3*DD] (h | stacked embeddings) | redv[16][GF] | redi[16][GF] | fin[GF]
+// LDS: actT[J][GF] | psum[8][GF][256] | dec_a[J] | dec_b[J] | dec_own[J] | h[3*DD] (h | stacked embeddings) | fin[GF]
 __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* actT = sm;
-    float* dec_a = actT + w.J * GF + 8 * APAD;
+    float* psum = actT + w.J * GF + 8 * APAD;   // the k slices' partial sums of one pass (kPsumFloats)
+    float* dec_a = psum + kPsumFloats;
     float* dec_b = dec_a + w.J;
     float* dec_own = dec_b + w.J;
     float* h = dec_own + w.J;
-    float* redv = h + 3 * w.DD;
-    int* redi = reinterpret_cast<int*>(redv + 16 * GF);
-    int* fin = redi + 16 * GF;
+    int* fin = reinterpret_cast<int*>(h + 3 * w.DD);
     // exchange scratch lives in the dynamic region too (static LDS would shift its 16-byte alignment)
     float* pv = reinterpret_cast<float*>(fin + GF + 8);
     int* pi = reinterpret_cast<int*>(pv + kMaxParts * GF);
     int* xf = pi + kMaxParts * GF;  // [0] = exchange timed out
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ks = lane >> 3, cgl = lane & 7;  // k slice (8 per wave), column group within the wave's 8
     const int G = a.parts, b = blockIdx.x / G, part = blockIdx.x - b * G;
     unsigned epoch = 0, epoch2 = 0;
     if (tid == 0) xf[0] = 0;
@@ -377,13 +432,13 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
         y0 = a.init_ctx[2 * b];
         y1 = a.init_ctx[2 * b + 1];
         own = true;
-        decoder_block_wide(w, y0, y1, h, actT, dec_own);
+        decoder_context(w, y0, y1, h, actT, dec_own);
     } else if (a.dec_init) {
         for (int k = tid; k < 2 * w.J; k += GT) dec_a[k] = a.dec_init[k];  // dec_a | dec_b are adjacent
         __syncthreads();
     } else {
-        decoder_block_wide(w, -1, K2HIP_BLANK_ID, h, actT, dec_a);
-        if (a.t0) decoder_block_wide(w, K2HIP_BLANK_ID, K2HIP_BLANK_ID, h, actT, dec_b);
+        decoder_context(w, -1, K2HIP_BLANK_ID, h, actT, dec_a);
+        if (a.t0) decoder_context(w, K2HIP_BLANK_ID, K2HIP_BLANK_ID, h, actT, dec_b);
     }
 
     while (t < a.Tp && n_tok < a.max_sym) {
@@ -404,88 +459,51 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
             }
         }
         __syncthreads();
-        float bestv[GF];
-        int besti[GF];
-#pragma unroll
-        for (int f = 0; f < GF; f++) { bestv[f] = -INFINITY; besti[f] = -1; }
-        for (int cgb = cg0; cgb < cg1; cgb += (GT / 64) * 8) {
-            const int cg = cgb + wave * 8 + cgl;
+        // The sweep (mfma_sweep_rows): wave = k slice (J / 8 rows), lane = 4 columns -- a pass covers 256 columns of the slab and a
+        // wave's load instruction reads 1 KB of one weight row.
+        float bestv = -INFINITY;   // wave f, after the passes: frame f's best over this part's slab
+        int besti = -1;
+        for (int cgb = cg0; cgb < cg1; cgb += 64) {
+            const int cg = cgb + lane;
             const bool valid = cg < cg1;
-            float acc[GF][4];
+            f32x4 c[2][4];
 #pragma unroll
-            for (int f = 0; f < GF; f++)
+            for (int hh = 0; hh < 2; hh++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[f][j] = 0.f;
-            if (valid) {
-                const float* wp = w.out_kn + (long long)(ks * kper) * w.Vp + 4 * cg;
-                const float* ap = actT + (ks * kper) * GF + ks * APAD;
-                const bool whole = kper % GL == 0;  // (J / 8 a multiple of GL: no clamped rows, no masks -- J = 512: 64 / 8)
-                for (int kb = 0; kb < kper; kb += GL) {
-                    // GL weight loads in flight per thread before any FMA: the sweep is L2-latency bound
-                    float4 wv[GL];
+                for (int q = 0; q < 4; q++) c[hh][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mfma_sweep_rows(w.out_kn + (long long)(wave * kper) * w.Vp + 4 * min(cg, cg1 - 1),   // (lanes past the slab: its last group, dropped below)
+                            w.Vp, actT + (wave * kper) * GF + wave * APAD + (lane & 3), kper, c);
+            psum_store(psum, wave, lane, c);
+            __syncthreads();
+            {
+                // wave f takes frame f: slices summed as the pairwise tree the lane shuffles of the vector version formed
+                float4 ps[8];
 #pragma unroll
-                    for (int i = 0; i < GL; i++)
-                        wv[i] = *reinterpret_cast<const float4*>(wp + (long long)(whole ? kb + i : min(kb + i, kper - 1)) * w.Vp);
+                for (int q = 0; q < 8; q++) ps[q] = *reinterpret_cast<const float4*>(psum + (q * GF + wave) * 256 + 4 * lane);
+                float sj[4];
 #pragma unroll
-                    for (int i = 0; i < GL; i++) {
-                        const int k = whole ? kb + i : min(kb + i, kper - 1);
-                        const float m = (whole || kb + i < kper) ? 1.f : 0.f;
-                        const float4 a0 = *reinterpret_cast<const float4*>(ap + k * GF);
-                        const float4 a1 = *reinterpret_cast<const float4*>(ap + k * GF + 4);
-                        float av[GF] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                        if (!whole) {
+                for (int j = 0; j < 4; j++) {
+                    const float p0 = (&ps[0].x)[j], p1 = (&ps[1].x)[j], p2 = (&ps[2].x)[j], p3 = (&ps[3].x)[j];
+                    const float p4 = (&ps[4].x)[j], p5 = (&ps[5].x)[j], p6 = (&ps[6].x)[j], p7 = (&ps[7].x)[j];
+                    sj[j] = ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7));
+                }
+                if (valid) {
 #pragma unroll
-                            for (int f = 0; f < GF; f++) av[f] *= m;
-                        }
-#pragma unroll
-                        for (int f = 0; f < GF; f++) {
-                            acc[f][0] += av[f] * wv[i].x;
-                            acc[f][1] += av[f] * wv[i].y;
-                            acc[f][2] += av[f] * wv[i].z;
-                            acc[f][3] += av[f] * wv[i].w;
-                        }
+                    for (int j = 0; j < 4; j++) {
+                        const int col = 4 * cg + j;
+                        if (col < w.V) amax_merge(bestv, besti, sj[j] + w.out_b[col], col);
                     }
                 }
             }
-            // sum the 8 k slices (lane bits 3..5)
-#pragma unroll
-            for (int f = 0; f < GF; f++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    float v = acc[f][j];
-                    v += dpp_f<kDppRor8>(v);  // lane ^ 8 within the row of 16 (the same operands as __shfl_xor(v, 8))
-                    v += __shfl_xor(v, 16);  // (gfx950's v_permlane16/32_swap do these two without the LDS crossbar -- bit-identical, but no
-                    v += __shfl_xor(v, 32);  // faster here: tools/probes/permlane_swap_probe.hip)
-                    acc[f][j] = v;
-                }
-            if (valid && ks == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int col = 4 * cg + j;
-                    if (col < w.V) {
-                        const float bj = w.out_b[col];
-#pragma unroll
-                        for (int f = 0; f < GF; f++) amax_merge(bestv[f], besti[f], acc[f][j] + bj, col);
-                    }
-                }
-            }
+            if (cgb + 64 < cg1) __syncthreads();   // psum is rewritten by the next pass
         }
-        // only the ks == 0 lanes (lanes 0..7 of the wave) carry candidates: an 8-lane reduction
-#pragma unroll
-        for (int f = 0; f < GF; f++) {
-            amax_8lanes(bestv[f], besti[f]);
-            if (lane == 0) { redv[wave * GF + f] = bestv[f]; redi[wave * GF + f] = besti[f]; }
-        }
-        __syncthreads();
-        if (tid < GF) {
-            float v = redv[tid];
-            int i = redi[tid];
-            for (int wv = 1; wv < GT / 64; wv++) amax_merge(v, i, redv[wv * GF + tid], redi[wv * GF + tid]);
-            fin[tid] = i;
-            if (G > 1) {  // publish this slab's candidate for frame `tid` (round parity buffer)
-                unsigned long long* gr = a.gran + ((((long long)b * 2 + (epoch & 1)) * G + part) * GF + tid) * 2;
-                store_granule(gr, epoch + 1, __float_as_uint(v));
-                store_granule(gr + 1, epoch + 1, (unsigned)i);
+        amax_wave(bestv, besti);
+        if (lane == 0) {
+            fin[wave] = besti;
+            if (G > 1) {  // publish this slab's candidate for frame `wave` (round parity buffer)
+                unsigned long long* gr = a.gran + ((((long long)b * 2 + (epoch & 1)) * G + part) * GF + wave) * 2;
+                store_granule(gr, epoch + 1, __float_as_uint(bestv));
+                store_granule(gr + 1, epoch + 1, (unsigned)besti);
             }
         }
         if (G > 1) {
@@ -556,7 +574,9 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
             }
         }
         t += adv;
-        if (emitted && G > 1) {
+        if (emitted && decoder_in_table(w, y0, y1)) {
+            decoder_lookup(w, y0, y1, dec_own);   // (every part reads the row: nothing to exchange)
+        } else if (emitted && G > 1) {
             // Every part takes the same decision, so the decoder update is shared out as well: a part computes its J / G outputs of
             // decoder_proj (the same k slices summed in the same order as gemv_kn_wide: bit-identical values), publishes them as
             // {emission epoch, value} granules and collects the whole vector.  (Each of the 16 parts of a V = 5537 stream pulling
@@ -620,7 +640,61 @@ __global__ __launch_bounds__(GT) void k_decoder_start(DecJoinW w, float* __restr
     float* scratch = sm;                       // >= 8 max(J, DD)
     float* h = sm + 8 * max(w.J, w.DD);        // [3 DD]
     float* o = h + 3 * w.DD;                   // [J]
-    decoder_block_wide(w, blockIdx.x == 0 ? -1 : K2HIP_BLANK_ID, K2HIP_BLANK_ID, h, scratch, o);
+    decoder_context(w, blockIdx.x == 0 ? -1 : K2HIP_BLANK_ID, K2HIP_BLANK_ID, h, scratch, o);
+    for (int k = threadIdx.x; k < w.J; k += GT) out[(long long)blockIdx.x * w.J + k] = o[k];
+}
+
+// ---- decoder table (small vocabularies) ----------------------------------------------------------------------
+// table[(y0 + 1) V + y1][J] = decoder(y0, y1) for every context, y0 in -1 .. V-1.  One workgroup takes GF consecutive contexts: the
+// front end of each by decoder_conv_wide itself, then decoder_proj as the search kernels' sweep with contexts in place of frames --
+// gemv_kn_wide's 8 k slices, each the same fma chain, added onto the bias in slice order: the bits decoder_block_wide gives.
+__global__ __launch_bounds__(GT) void k_decoder_table(DecJoinW w, float* __restrict__ table, long long n_ctx) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* hT = sm;                                   // [DD][GF] (+ APAD per k slice)
+    float* psum = hT + w.DD * GF + 8 * APAD;
+    float* h = psum + kPsumFloats;                    // [3 DD]
+    float* scratch = h + 3 * w.DD;                    // [8 max(J, DD)] (decoder_conv_wide's GEMV branch)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kslice = (w.DD + 7) >> 3;
+    const long long c0 = (long long)blockIdx.x * GF;
+    for (int f = 0; f < GF; f++) {
+        const long long cx = min(c0 + f, n_ctx - 1);
+        decoder_conv_wide(w, cx / w.V - 1, cx % w.V, h, scratch);
+        for (int k = tid; k < w.DD; k += GT) hT[k * GF + (k / kslice) * APAD + f] = h[k];
+        __syncthreads();
+    }
+    const int k0 = min(wave * kslice, w.DD), nrows = min(k0 + kslice, w.DD) - k0;
+    const int ncg = w.J >> 2;
+    for (int cgb = 0; cgb < ncg; cgb += 64) {
+        const int cg = cgb + lane;
+        f32x4 c[2][4];
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) c[hh][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mfma_sweep_rows(w.dproj_kn + (long long)k0 * w.J + 4 * min(cg, ncg - 1), w.J, hT + k0 * GF + wave * APAD + (lane & 3), nrows, c);
+        psum_store(psum, wave, lane, c);
+        __syncthreads();
+        if (cg < ncg && c0 + wave < n_ctx) {   // wave f: context c0 + f
+            float4 sv = *reinterpret_cast<const float4*>(w.dproj_b + 4 * cg);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const float4 ps = *reinterpret_cast<const float4*>(psum + (q * GF + wave) * 256 + 4 * lane);
+                sv.x += ps.x; sv.y += ps.y; sv.z += ps.z; sv.w += ps.w;
+            }
+            *reinterpret_cast<float4*>(table + (c0 + wave) * w.J + 4 * cg) = sv;
+        }
+        __syncthreads();
+    }
+}
+
+// out[n][J] = decoder_block_wide(y[n][0], y[n][1]) -- the search kernels' routine itself, never the table (the table's test)
+__global__ __launch_bounds__(GT) void k_decoder_rows_wide(DecJoinW w, const long long* __restrict__ y, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* scratch = sm;                       // >= 8 max(J, DD)
+    float* h = sm + 8 * max(w.J, w.DD);        // [3 DD]
+    float* o = h + 3 * w.DD;                   // [J]
+    decoder_block_wide(w, y[2 * blockIdx.x], y[2 * blockIdx.x + 1], h, scratch, o);
     for (int k = threadIdx.x; k < w.J; k += GT) out[(long long)blockIdx.x * w.J + k] = o[k];
 }
 
@@ -733,7 +807,7 @@ __global__ __launch_bounds__(GT) void k_rounds_step(DecJoinW w, RoundsState a, i
         atomicAdd(&a.active[r + 2], 1);  // r = -1 fills active[1]... see greedy_rounds: slot k+1 counts the streams alive in round k
     }
     if (!have_dec) {
-        decoder_block_wide(w, y0, y1, h, scratch, decl);
+        decoder_context(w, y0, y1, h, scratch, decl);
         for (int k = tid; k < w.J; k += GT) a.dec[(long long)b * w.J + k] = decl[k];
     } else {
         for (int k = tid; k < w.J; k += GT) decl[k] = a.dec[(long long)b * w.J + k];
@@ -795,6 +869,27 @@ void greedy_rounds(const Ctx& ctx, const DecJoinW& w, const float* out_w, const 
     }
 }
 
+void decoder_table(const Ctx& ctx, const DecJoinW& w, float* table) {
+    if (ctx.dry) return;
+    K2_REQUIRE(w.J % 4 == 0 && w.DD % 4 == 0, "decoder table: joiner %d / decoder %d widths must be multiples of 4", w.J, w.DD);
+    const long long n_ctx = ((long long)w.V + 1) * w.V;
+    const size_t lds = sizeof(float) * ((size_t)w.DD * GF + 8 * APAD + kPsumFloats + 3 * (size_t)w.DD + 8 * (size_t)std::max(w.J, w.DD));
+    K2_REQUIRE(lds <= 150 * 1024, "decoder table: joiner %d / decoder %d need %zu B of LDS", w.J, w.DD, lds);
+    static LdsAttrOnce lds_attr;
+    lds_attr.ensure(k_decoder_table, 150 * 1024);
+    DecJoinW wn = w;
+    wn.dec_table = nullptr;
+    hipLaunchKernelGGL(k_decoder_table, dim3((unsigned)((n_ctx + GF - 1) / GF)), dim3(GT), lds, ctx.stream, wn, table, n_ctx);
+    K2_HIP(hipGetLastError());
+}
+void decoder_rows_wide(const Ctx& ctx, const DecJoinW& w, const long long* y, int N, float* out) {
+    if (ctx.dry || N <= 0) return;
+    const size_t lds = sizeof(float) * (8 * (size_t)std::max(w.J, w.DD) + 3 * (size_t)w.DD + w.J);
+    static LdsAttrOnce lds_attr;
+    lds_attr.ensure(k_decoder_rows_wide, 150 * 1024);
+    hipLaunchKernelGGL(k_decoder_rows_wide, dim3(N), dim3(GT), lds, ctx.stream, w, y, out);
+    K2_HIP(hipGetLastError());
+}
 void decoder_start_contexts(const Ctx& ctx, const DecJoinW& w, float* out) {
     if (ctx.dry) return;
     const size_t lds = sizeof(float) * (8 * (size_t)std::max(w.J, w.DD) + 3 * (size_t)w.DD + w.J);
@@ -865,7 +960,7 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     if (ctx.dry) return;
     K2_REQUIRE(w.J % 8 == 0, "greedy: joiner_dim %d must be a multiple of 8", w.J);
     K2_REQUIRE(w.DD % 4 == 0 && 8 * w.DD <= w.J * GF, "greedy: decoder_dim %d too wide for the LDS scratch", w.DD);
-    size_t lds = sizeof(float) * ((size_t)w.J * GF + 8 * APAD + 3 * (size_t)w.J + 3 * (size_t)w.DD + 32 * GF + GF + 8 +
+    size_t lds = sizeof(float) * ((size_t)w.J * GF + 8 * APAD + kPsumFloats + 3 * (size_t)w.J + 3 * (size_t)w.DD + GF + 8 +
                                  2 * kMaxParts * GF + 4);
     K2_REQUIRE(lds <= 150 * 1024, "greedy: vocab %d / joiner %d need %zu B of LDS", w.V, w.J, lds);
     static LdsAttrOnce lds_attr;
@@ -891,7 +986,7 @@ void greedy_relaunch_one_part(hipStream_t stream, const GreedyLaunch& rec) {
     a.gran = nullptr;
     a.gran2 = nullptr;
     const DecJoinW& w = rec.w;
-    const size_t lds = sizeof(float) * ((size_t)w.J * GF + 8 * APAD + 3 * (size_t)w.J + 3 * (size_t)w.DD + 32 * GF + GF + 8 +
+    const size_t lds = sizeof(float) * ((size_t)w.J * GF + 8 * APAD + kPsumFloats + 3 * (size_t)w.J + 3 * (size_t)w.DD + GF + 8 +
                                        2 * kMaxParts * GF + 4);
     K2_HIP(hipMemsetAsync(a.overflow, 0, sizeof(int), stream));
     hipLaunchKernelGGL(k_greedy, dim3(a.B), dim3(GT), lds, stream, w, a);

@@ -24,6 +24,7 @@ struct Tunables {
     int lstm_seq = 0;             // K2HIP_LSTM_SEQ: layer-by-layer LSTM instead of the layer wavefront
     int greedy_one_part = 0;      // K2HIP_GREEDY_ONE_PART: one workgroup per stream in the search
     int greedy_parts = 0;         // K2HIP_GREEDY_PARTS: vocabulary slabs per stream (0 = automatic)
+    int decoder_table_mb = 1024;  // K2HIP_DECODER_TABLE_MB: build the all-contexts decoder table when it fits this many MiB (0 = never)
     int test_greedy_timeout = 0;  // K2HIP_TEST_GREEDY_TIMEOUT: test hook -- every parts > 1 search reports an exchange timeout, so the one-part retry runs
     int pipe_mode = 0;            // K2HIP_PIPE_MODE: 1 = every pipeline slot owns a stream
     int max_streams = 0;          // K2HIP_MAX_STREAMS: slots of the streaming state pool (0 = 256)
@@ -281,11 +282,18 @@ struct DecJoinW {
     const float* dproj_b;  // [J]
     const float* out_kn;   // [J, Vp]
     const float* out_b;    // [V]
+    // small vocabularies only: decoder(y0, y1) of EVERY context, row (y0 + 1) V + y1 of [(V + 1) V][J], y0 = -1 .. V-1 (decoder_table);
+    // the search kernels then read a row where they would run the decoder
+    const float* dec_table = nullptr;
     int V, Vp, DD, J, ctx;
 };
 void decoder(const Ctx& ctx, const DecJoinW& w, const long long* y, int N, float* dec_out);
 // out[2][J] = the search kernel's own decoder routine on [-1, blank] and [blank, blank] (bit-identical to what k_greedy computes itself)
 void decoder_start_contexts(const Ctx& ctx, const DecJoinW& w, float* out);
+// table[(V + 1) V][J]: the search kernels' decoder routine on every context (bit-identical to what they compute themselves)
+void decoder_table(const Ctx& ctx, const DecJoinW& w, float* table);
+// out[N][J] = that routine on the contexts y[N][2], computed (the table is not consulted): what the table's rows are checked against
+void decoder_rows_wide(const Ctx& ctx, const DecJoinW& w, const long long* y, int N, float* out);
 void tanh_add(const Ctx& ctx, const float* enc, const float* dec, int dec_stride, float* y, int N, int J);
 // row argmax with the reference tie-break (later index wins) -> emit flag (token not in {0,2} [,1])
 void argmax_rows(const Ctx& ctx, const float* logits, int ld, int N, int V, int* tok);

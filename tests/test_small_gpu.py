@@ -49,3 +49,47 @@ def test_small_en_single_utterance_get_result(small_path):
     want_b = ora.recognize_batch([f])[0]
     assert tok_b == [0, 0] + want_b[0] and ts_b == ts + [0, 0] + want_b[1]
     assert s.speech_length == 0
+
+
+def test_decoder_table_rows_are_the_decoder_bit_for_bit(tmp_path):
+    """Small vocabularies: the engine tabulates decoder(y0, y1) for EVERY context and the search loops read a row where they would
+    run the decoder.  The table (built with contexts in place of frames on the matrix pipe) must hold exactly the bits the loops'
+    own routine computes, and a search with the table must return what the search without it returns."""
+    import ctypes as C
+    import k2transducerasr_amd as pkg
+    from k2transducerasr_amd.binding import load_library
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+
+    L = load_library()
+    L.k2hip_debug_decoder_table_check.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.k2hip_debug_decoder_table_check.restype = C.c_int32
+    for preset in ("zipformer2-tiny-test", "conformer-tiny-test", "zipformer2-small-en"):
+        path = str(tmp_path / f"{preset}.k2w")
+        write_synthetic_model(path, preset)
+        rec = pkg.OfflineRecognizer(path)
+        wavs = [synth_utterance(40 + u, 3.0 + 0.5 * u) for u in range(4)]
+
+        def run(r):
+            ss = []
+            for w in wavs:
+                s = r.create_offline_stream()
+                s.add_samples(w)
+                ss.append(s)
+            return r.get_results(ss)
+
+        with_table = run(rec)
+        rows, bad = C.c_int64(), C.c_int64()
+        assert L.k2hip_debug_decoder_table_check(rec.model.handle, 500, 7, C.byref(rows), C.byref(bad)) == 0
+        V = rec.model.vocab_size
+        assert rows.value == (V + 1) * V, f"{preset}: a vocabulary of {V} must get the table"
+        assert bad.value == 0, f"{preset}: {bad.value} table values differ from the decoder's"
+        pkg.set_switch("K2HIP_DECODER_TABLE_MB", 0)
+        try:
+            rec2 = pkg.OfflineRecognizer(path)
+            assert L.k2hip_debug_decoder_table_check(rec2.model.handle, 4, 7, C.byref(rows), C.byref(bad)) == 0
+            assert rows.value == 0
+            without = run(rec2)
+        finally:
+            pkg.set_switch("K2HIP_DECODER_TABLE_MB", 1024)
+        assert with_table == without
+        assert sum(len(t) for t, _ in without) > 2 * 4 * len(wavs)
