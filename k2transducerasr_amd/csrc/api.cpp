@@ -527,8 +527,11 @@ static int64_t online_logical_floats(const k2hip_online_stream* s) {
     return (int64_t)s->speech.size() + online_pending_frames(s) * s->model->engine.model().cfg().feat;
 }
 // run the deferred fbank of `n` streams of one model: streams at the same position share one batched launch
-static void online_materialize(k2hip_online_stream* const* streams, int n) {
-    if (n <= 0) return;
+// may_defer: the caller runs a chunk step on the same engine next and collects the frames after it (Engine::fbank_gather_finish);
+// taken only when ONE batched launch covers every stream with queued samples.  Returns whether a gather was left outstanding.
+static bool online_materialize(k2hip_online_stream* const* streams, int n, bool may_defer = false) {
+    if (n <= 0) return false;
+    bool deferred = false;
     Engine& e = streams[0]->model->engine;
     const Config& c = e.model().cfg();
     std::map<int64_t, std::vector<k2hip_online_stream*>> groups;  // by length of [remainder ; pending]
@@ -568,7 +571,9 @@ static void online_materialize(k2hip_online_stream* const* streams, int n) {
         }
         try {
             EngineLock lk(e);
-            e.fbank_host_gather(hp.data(), hn.data(), tp.data(), tn.data(), len, G, dst.data(), nf, fslot.data(), fpos.data());
+            const bool defer = may_defer && groups.size() == 1;
+            e.fbank_host_gather(hp.data(), hn.data(), tp.data(), tn.data(), len, G, dst.data(), nf, fslot.data(), fpos.data(), defer);
+            deferred = defer;
         } catch (...) {
             for (k2hip_online_stream* s : g) s->speech.resize(s->speech.size() - (size_t)nf * c.feat);  // nothing was appended
             throw;
@@ -583,6 +588,7 @@ static void online_materialize(k2hip_online_stream* const* streams, int n) {
             s->pending.clear();
         }
     }
+    return deferred;
 }
 int32_t k2hip_online_stream_accept_samples(k2hip_online_stream_t* s, const float* samples, int64_t n) {
     return guard([&] {
@@ -681,10 +687,11 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
             K2_REQUIRE(std::adjacent_find(seen.begin(), seen.end()) == seen.end(), "GetResults: the same stream appears twice in the list");
         }
         if (idx.empty()) return;   // :113-116
+        bool fb_deferred = false;   // the new frames' host copy is collected after the step (one wait for the device per tick)
         {   // the deferred fbank of the streams that decode now: one batched launch when they are at the same position
             std::vector<k2hip_online_stream*> ready(idx.size());
             for (size_t r = 0; r < idx.size(); r++) ready[r] = streams[idx[r]];
-            online_materialize(ready.data(), (int)ready.size());
+            fb_deferred = online_materialize(ready.data(), (int)ready.size(), true);
         }
         const int R = (int)idx.size(), Tp = e.online_frames_per_chunk();
         std::vector<const float*> chunks(R);   // GetDecodeChunk: the first ChunkLength frames of each FIFO
@@ -706,6 +713,11 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
         }
         std::vector<int64_t> tok((size_t)R * Tp);
         std::vector<int32_t> ts((size_t)R * Tp), n(R);
+        if (fb_deferred && !all_mirrored) {   // the step reads some stream's chunk from host memory: the frames must be there
+            EngineLock lk(e);
+            e.fbank_gather_finish();
+            fb_deferred = false;
+        }
         try {
             EngineLock lk(e);
             e.online_step(slots.data(), chunks.data(), hyps.data(), plens.data(), nch.data(), R, tok.data(), ts.data(), n.data(),
@@ -715,7 +727,14 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
             // updates the conv / embed caches in place.  A search exchange timeout is retried inside the engine and does not come
             // here; what does is a HIP failure.  The streams are unusable until reset.
             for (int r = 0; r < R; r++) streams[idx[r]]->poisoned = true;
+            if (fb_deferred) {
+                try { EngineLock lk(e); e.fbank_gather_finish(); } catch (...) {}   // (the streams are poisoned either way)
+            }
             throw;
+        }
+        if (fb_deferred) {
+            EngineLock lk(e);
+            e.fbank_gather_finish();   // the step's token download has synchronised the stream: copies only
         }
         // RemoveChunk (:102-117) only after success
         std::vector<k2hip_online_stream*> remirror;

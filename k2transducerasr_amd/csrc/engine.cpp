@@ -62,6 +62,7 @@ Engine::~Engine() {
     if (d_dec_start_) (void)hipFree(d_dec_start_);
     if (pin_) (void)hipHostFree(pin_);
     if (pin_in_) (void)hipHostFree(pin_in_);
+    if (pin_fb_) (void)hipHostFree(pin_fb_);
     arena_.release();
     if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -75,6 +76,18 @@ void* Engine::pinned_in(int64_t bytes) {
         pin_in_cap_ = bytes + bytes / 4;
     }
     return pin_in_;
+}
+
+void* Engine::pinned_fb(int64_t bytes) {
+    if (bytes > pin_fb_cap_) {
+        K2_REQUIRE(!fb_pending_.active, "internal: the fbank staging buffer grows under a deferred gather");
+        if (pin_fb_) K2_HIP(hipHostFree(pin_fb_));
+        pin_fb_ = nullptr;
+        pin_fb_cap_ = 0;
+        K2_HIP(hipHostMalloc(&pin_fb_, (size_t)(bytes + bytes / 4), hipHostMallocDefault));
+        pin_fb_cap_ = bytes + bytes / 4;
+    }
+    return pin_fb_;
 }
 
 void* Engine::pinned(int64_t bytes) {
@@ -737,13 +750,14 @@ void Engine::fbank_host_batch(const float* samples, int64_t n, int n_utts, float
 }
 
 void Engine::fbank_host_gather(const float* const* head, const int64_t* n_head, const float* const* tail, const int64_t* n_tail, int64_t n, int G,
-                               float* const* dst, int64_t nf, const int* fifo_slots, const int* fifo_pos) {
+                               float* const* dst, int64_t nf, const int* fifo_slots, const int* fifo_pos, bool defer) {
     const FbankOpts& f = model_->cfg().fbank;
     K2_REQUIRE(nf == fbank_num_frames(n) && nf > 0 && G > 0, "fbank_host_gather: bad shape");
     const size_t nb_in = sizeof(float) * (size_t)n * G, per_out = sizeof(float) * (size_t)nf * f.num_bins, nb_out = per_out * G;
     const bool mirror = fifo_slots && fifo_pos && online_fifo_;
     const size_t nb_idx = mirror ? sizeof(int) * 2 * (size_t)G : 0;
-    char* pin = static_cast<char*>(pinned((int64_t)(nb_in + nb_out + nb_idx + 64)));
+    if (fb_pending_.active) fbank_gather_finish();   // (one outstanding at a time)
+    char* pin = static_cast<char*>(defer ? pinned_fb((int64_t)(nb_in + nb_out + nb_idx + 64)) : pinned((int64_t)(nb_in + nb_out + nb_idx + 64)));
     float* w = reinterpret_cast<float*>(pin);
     int* h_idx = reinterpret_cast<int*>(pin + nb_in + nb_out);
     if (mirror) {
@@ -771,9 +785,24 @@ void Engine::fbank_host_gather(const float* const* head, const int64_t* n_head, 
         }
     });
     K2_HIP(hipMemcpyAsync(pin + nb_in, d_out, nb_out, hipMemcpyDeviceToHost, stream_));
+    if (defer) {
+        fb_pending_.dst.assign(dst, dst + G);
+        fb_pending_.src = pin + nb_in;
+        fb_pending_.per_out = per_out;
+        fb_pending_.active = true;
+        return;
+    }
     K2_HIP(hipStreamSynchronize(stream_));
     for (int g = 0; g < G; g++) memcpy(dst[g], pin + nb_in + (size_t)g * per_out, per_out);
 }
+
+void Engine::fbank_gather_finish() {
+    if (!fb_pending_.active) return;
+    fb_pending_.active = false;
+    K2_HIP(hipStreamSynchronize(stream_));   // (returns at once after the step's own synchronisation)
+    for (size_t g = 0; g < fb_pending_.dst.size(); g++) memcpy(fb_pending_.dst[g], fb_pending_.src + g * fb_pending_.per_out, fb_pending_.per_out);
+}
+
 
 void Engine::pad_host(const float* const* speech, const int64_t* n_floats, int B, int tail, float* out, int64_t cap, int64_t* Lout) {
     K2_REQUIRE(B > 0, "pad: empty batch");

@@ -59,7 +59,13 @@ class Engine {
     void online_fifo_write(int slot, int pos, const float* feats, int64_t n_frames);  // host frames -> ring rows pos ..
     // (fifo_slots / fifo_pos: when given, the frames of signal g are also appended to slot fifo_slots[g]'s ring at fifo_pos[g] (< 0: not))
     void fbank_host_gather(const float* const* head, const int64_t* n_head, const float* const* tail, const int64_t* n_tail, int64_t n, int G,
-                           float* const* dst, int64_t nf, const int* fifo_slots = nullptr, const int* fifo_pos = nullptr);
+                           float* const* dst, int64_t nf, const int* fifo_slots = nullptr, const int* fifo_pos = nullptr, bool defer = false);
+    // defer = true: everything is enqueued (upload, fbank, the append to the device FIFOs, the download into pinned memory) but the
+    // frames reach `dst` only in fbank_gather_finish(), which the caller runs after the next synchronisation of the stream it enqueues
+    // on anyway (the chunk step's token download) -- a streaming tick then waits for the device once, not twice.  `dst` must stay
+    // valid until then; at most one deferred gather is outstanding.
+    void fbank_gather_finish();
+    bool fbank_gather_pending() const { return fb_pending_.active; }
     void pad_host(const float* const* speech, const int64_t* n_floats, int B, int tail, float* out, int64_t cap, int64_t* L);
     void encoder_host(const float* x, int B, int T, float* enc_out, int64_t cap, int* Tp);
     void encoder_tap_host(const float* x, int B, int T, int tap, float* out, int64_t cap, int64_t* n);
@@ -244,6 +250,15 @@ class Engine {
     void* pin_in_ = nullptr;   // pinned staging of a step's inputs (chunks), separate from the result staging above
     int64_t pin_in_cap_ = 0;
     void* pinned_in(int64_t bytes);
+    void* pin_fb_ = nullptr;   // pinned staging of a deferred fbank gather (its frames are collected after the step that follows)
+    int64_t pin_fb_cap_ = 0;
+    void* pinned_fb(int64_t bytes);
+    struct PendingFeats {
+        bool active = false;
+        std::vector<float*> dst;
+        const char* src = nullptr;
+        size_t per_out = 0;
+    } fb_pending_;
 };
 
 // What every C-ABI entry holds while it works on a model: the model's mutex (calls on one handle are serialised) AND the model's

@@ -66,8 +66,8 @@ void Engine::fbank_host(const float* samples, int64_t n, float* feats, int64_t c
     fake_frames(samples, n, model_->cfg().fbank, model_->cfg().feat, feats, nf);
 }
 void Engine::fbank_host_gather(const float* const* head, const int64_t* n_head, const float* const* tail, const int64_t* n_tail, int64_t n, int G,
-                               float* const* dst, int64_t nf, const int* fifo_slot, const int* fifo_pos) {
-    (void)fifo_slot; (void)fifo_pos;
+                               float* const* dst, int64_t nf, const int* fifo_slot, const int* fifo_pos, bool defer) {
+    (void)fifo_slot; (void)fifo_pos; (void)defer;   // (the stand-in fills dst at once: a deferred gather with nothing left to finish)
     std::vector<float> cat((size_t)n);
     for (int g = 0; g < G; g++) {
         K2_REQUIRE(n_head[g] + n_tail[g] == n, "stub: gather lengths");
@@ -76,6 +76,7 @@ void Engine::fbank_host_gather(const float* const* head, const int64_t* n_head, 
         fake_frames(cat.data(), n, model_->cfg().fbank, model_->cfg().feat, dst[g], nf);
     }
 }
+void Engine::fbank_gather_finish() {}
 void Engine::pad_host(const float* const* speech, const int64_t* n_floats, int B, int tail, float* out, int64_t cap, int64_t* Lout) {
     int64_t mx = 0;
     for (int b = 0; b < B; b++) mx = std::max(mx, n_floats[b]);
