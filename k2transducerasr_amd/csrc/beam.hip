@@ -11,6 +11,7 @@
 //   merge equal token sequences by logaddexp (first-inserted hypothesis keeps its timestamps)   k_beam_step
 // Hypotheses live in double-buffered device arrays [2][B][K][cap]; ys excludes the ctx-blank prefix.
 #include "kernels.h"
+#include "sweep.h"
 
 namespace k2hip {
 namespace {
@@ -53,28 +54,39 @@ __global__ void k_beam_embconv(DecJoinW w, const long long* __restrict__ y, floa
     h[i] = embconv1(w, y[2 * m], y[2 * m + 1], co);
 }
 
-// one workgroup per stream; `cur` = buffer holding frame t's input hypotheses
-__global__ __launch_bounds__(BT) void k_beam_step(BeamState s, const float* __restrict__ logits, int V, int t, int cur, int B) {
-    __shared__ int taken[kMaxBeam];
-    __shared__ float topv[kMaxBeam];
-    __shared__ int topi[kMaxBeam];
-    __shared__ int dupof[kMaxBeam];           // for new entry r: index of the earlier entry it merges into, or -1
-    __shared__ int same;
-    const int b = blockIdx.x, tid = threadIdx.x, K = s.K;
-    const int nA = s.nhyp[b];
-    const float* lg = logits + (long long)b * K * V;
+// One stream's hypotheses as the step sees them: frame t's input buffers (_c), the other parity's (_n), and the in-place state.
+// Global memory (k_beam_step: one launch per frame) or LDS (k_beam_loop: the whole search in one kernel).
+struct HypView {
+    int K, cap;
+    const int *ys_c, *ts_c, *n_c;
+    int *ys_n, *ts_n, *n_n;
+    float* lp;         // [K] in place: every read of it precedes (barrier-separated) tid 0's write
+    long long* ctx;    // [K][2]
+    int* nhyp;
+};
+constexpr int kStepScratchInts = 4 * kMaxBeam + 4 + 2 * kMaxBeam * kMaxBeam;
+// one workgroup of NT threads per stream; lg: the hypotheses' logits, ldl floats per row; scratch: kStepScratchInts ints of LDS
+template <int NT>
+__device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int V, int t, int* scratch) {
+    constexpr int BT = NT;
+    int* taken = scratch;
+    float* topv = reinterpret_cast<float*>(scratch + kMaxBeam);
+    int* topi = scratch + 2 * kMaxBeam;
+    int* dupof = scratch + 3 * kMaxBeam;      // for new entry r: index of the earlier entry it merges into, or -1
+    float* candv = reinterpret_cast<float*>(scratch + 4 * kMaxBeam + 4);
+    int* candi = scratch + 4 * kMaxBeam + 4 + kMaxBeam * kMaxBeam;
+    const int tid = threadIdx.x, K = hv.K;
+    const int nA = *hv.nhyp;
     // ---- one wave per hypothesis (4 waves, K <= 8): log_softmax statistics, then the hypothesis' own top `want` candidates by
     //      (score desc, token asc) with wave shuffles only; the global top `want` is the top of the union (no block-wide
     //      reductions, which is what made this step cost more than the joiner GEMM)
     const int nc = nA * V, want = min(K, nc);
     const int lane = tid & 63, wave = tid >> 6;
-    __shared__ float candv[kMaxBeam * kMaxBeam];
-    __shared__ int candi[kMaxBeam * kMaxBeam];
     if (V <= 64 * 16) {
         // the hypothesis' logits, V / 64 per lane, are read ONCE into registers: the max, the sum and the `want` selection rounds below
         // went through global memory 2 + want times before (a chain of dependent loads that made this step 20 us)
         for (int k = wave; k < nA; k += BT / 64) {
-            const float* l = lg + (long long)k * V;
+            const float* l = lg + (long long)k * ldl;
             float lv[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) lv[i] = lane + 64 * i < V ? l[lane + 64 * i] : -INFINITY;
@@ -89,7 +101,7 @@ __global__ __launch_bounds__(BT) void k_beam_step(BeamState s, const float* __re
                 if (lane + 64 * i < V) sm += expf(lv[i] - mx);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
-            const float lse = logf(sm), lpk = s.lp[b * K + k];
+            const float lse = logf(sm), lpk = hv.lp[k];
             unsigned used = 0;  // bit i: this lane's element i was already selected
             for (int r = 0; r < want; r++) {
                 float bv = -INFINITY;
@@ -113,7 +125,7 @@ __global__ __launch_bounds__(BT) void k_beam_step(BeamState s, const float* __re
         }
     } else
     for (int k = wave; k < nA; k += BT / 64) {
-        const float* l = lg + (long long)k * V;
+        const float* l = lg + (long long)k * ldl;
         float mx = -INFINITY;
         for (int v = lane; v < V; v += 64) mx = fmaxf(mx, l[v]);
 #pragma unroll
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(BT) void k_beam_step(BeamState s, const float* __re
         for (int v = lane; v < V; v += 64) sm += expf(l[v] - mx);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
-        const float lse = logf(sm), lpk = s.lp[b * K + k];
+        const float lse = logf(sm), lpk = hv.lp[k];
         int excl[kMaxBeam];
         for (int r = 0; r < want; r++) {
             float bv = -INFINITY;
@@ -164,64 +176,64 @@ __global__ __launch_bounds__(BT) void k_beam_step(BeamState s, const float* __re
     }
     __syncthreads();
     // ---- expand + merge (HypothesisList.add) into the other buffer
-    const int nxt = cur ^ 1;
-    const long long BK = (long long)B * K;
-    const int* ys_c = s.ys + ((long long)cur * BK + (long long)b * K) * s.cap;
-    const int* ts_c = s.ts + ((long long)cur * BK + (long long)b * K) * s.cap;
-    int* ys_n = s.ys + ((long long)nxt * BK + (long long)b * K) * s.cap;
-    int* ts_n = s.ts + ((long long)nxt * BK + (long long)b * K) * s.cap;
-    const int* n_c = s.n + cur * BK + b * K;
-    int* n_n = s.n + nxt * BK + b * K;
-    // sequence of candidate r = ys_c[parent_r][0..n) (+ tok_r if real)
-    for (int r = 0; r < want; r++) {
-        const int hr = topi[r] / V, tr = topi[r] % V;
-        const bool realr = tr != K2HIP_BLANK_ID && tr != K2HIP_UNK_ID;
-        const int lenr = n_c[hr] + (realr ? 1 : 0);
-        int found = -1;
-        for (int q = 0; q < r && found < 0; q++) {
-            if (dupof[q] >= 0) continue;  // q itself was merged away; its target is tested on its own
-            const int hq = topi[q] / V, tq = topi[q] % V;
-            const bool realq = tq != K2HIP_BLANK_ID && tq != K2HIP_UNK_ID;
-            const int lenq = n_c[hq] + (realq ? 1 : 0);
-            if (lenq != lenr) continue;
-            if (tid == 0) same = 1;
-            __syncthreads();
-            for (int i = tid; i < lenr; i += BT) {
-                const int a = (i < n_c[hr]) ? ys_c[(long long)hr * s.cap + i] : tr;
-                const int c = (i < n_c[hq]) ? ys_c[(long long)hq * s.cap + i] : tq;
-                if (a != c) same = 0;
+    const int *ys_c = hv.ys_c, *ts_c = hv.ts_c, *n_c = hv.n_c;
+    int *ys_n = hv.ys_n, *ts_n = hv.ts_n, *n_n = hv.n_n;
+    // sequence of candidate r = ys_c[parent_r][0..n) (+ tok_r if real).  Which candidates spell the same sequence: every pair (r, q < r)
+    // compared by a wave of its own (one barrier for all pairs; a loop over the pairs with three block barriers each was a third of
+    // the step), then tid 0 resolves the merges in insertion order
+    int* eq = candi;   // [r][q] (the per-hypothesis candidates are used up)
+    {
+        const int npairs = want * (want - 1) / 2;
+        for (int pi = wave; pi < npairs; pi += BT / 64) {
+            int r = 1, base = 0;
+            while (base + r <= pi) { base += r; r++; }
+            const int q = pi - base;
+            const int hr = topi[r] / V, tr = topi[r] % V, hq = topi[q] / V, tq = topi[q] % V;
+            const bool realr = tr != K2HIP_BLANK_ID && tr != K2HIP_UNK_ID, realq = tq != K2HIP_BLANK_ID && tq != K2HIP_UNK_ID;
+            const int lenr = n_c[hr] + (realr ? 1 : 0), lenq = n_c[hq] + (realq ? 1 : 0);
+            bool e = lenr == lenq;
+            if (e) {
+                for (int i = lane; i < lenr; i += 64) {
+                    const int x = (i < n_c[hr]) ? ys_c[(long long)hr * hv.cap + i] : tr;
+                    const int y = (i < n_c[hq]) ? ys_c[(long long)hq * hv.cap + i] : tq;
+                    e = e && x == y;
+                }
             }
-            __syncthreads();
-            if (same) found = q;
-            __syncthreads();
+            e = __all(e);
+            if (lane == 0) eq[r * kMaxBeam + q] = e ? 1 : 0;
         }
-        if (tid == 0) dupof[r] = found;
-        __syncthreads();
     }
+    __syncthreads();
     if (tid == 0) {
+        for (int r = 0; r < want; r++) {   // for new entry r: the earliest entry it merges into (one that was not merged away itself), or -1
+            int found = -1;
+            for (int q = 0; q < r && found < 0; q++)
+                if (dupof[q] < 0 && eq[r * kMaxBeam + q]) found = q;
+            dupof[r] = found;
+        }
         // slot assignment in insertion order; merged scores accumulate in candidate order (logaddexp)
         int slot_of[kMaxBeam];
         int nN = 0;
         for (int r = 0; r < want; r++) {
             if (dupof[r] < 0) {
                 slot_of[r] = nN++;
-                s.lp_next[b * K + slot_of[r]] = topv[r];
+                hv.lp[slot_of[r]] = topv[r];
             } else {
                 slot_of[r] = slot_of[dupof[r]];
-                const float a = s.lp_next[b * K + slot_of[r]], c = topv[r];
+                const float a = hv.lp[slot_of[r]], c = topv[r];
                 const float mx = fmaxf(a, c);
-                s.lp_next[b * K + slot_of[r]] = (isinf(mx) && mx < 0) ? mx : mx + log1pf(expf(-fabsf(a - c)));
+                hv.lp[slot_of[r]] = (isinf(mx) && mx < 0) ? mx : mx + log1pf(expf(-fabsf(a - c)));
             }
             taken[r] = dupof[r] < 0 ? slot_of[r] : -1;  // reuse: destination slot of a fresh hypothesis
         }
         for (int k = nN; k < K; k++) {
-            s.lp_next[b * K + k] = -INFINITY;
+            hv.lp[k] = -INFINITY;
             // empty slots still go through the batched decoder launch: give them a valid context
-            s.ctx_next[2 * (b * K + k)] = K2HIP_BLANK_ID;
-            s.ctx_next[2 * (b * K + k) + 1] = K2HIP_BLANK_ID;
+            hv.ctx[2 * k] = K2HIP_BLANK_ID;
+            hv.ctx[2 * k + 1] = K2HIP_BLANK_ID;
             n_n[k] = 0;
         }
-        s.nhyp_next[b] = nN;
+        *hv.nhyp = nN;
     }
     __syncthreads();
     for (int r = 0; r < want; r++) {
@@ -231,26 +243,165 @@ __global__ __launch_bounds__(BT) void k_beam_step(BeamState s, const float* __re
         const bool realr = tr != K2HIP_BLANK_ID && tr != K2HIP_UNK_ID;
         const int n0 = n_c[hr];
         for (int i = tid; i < n0; i += BT) {
-            ys_n[(long long)slot * s.cap + i] = ys_c[(long long)hr * s.cap + i];
-            ts_n[(long long)slot * s.cap + i] = ts_c[(long long)hr * s.cap + i];
+            ys_n[(long long)slot * hv.cap + i] = ys_c[(long long)hr * hv.cap + i];
+            ts_n[(long long)slot * hv.cap + i] = ts_c[(long long)hr * hv.cap + i];
         }
         if (tid == 0) {
             int nn = n0;
             if (realr) {
-                if (nn < s.cap) {
-                    ys_n[(long long)slot * s.cap + nn] = tr;
-                    ts_n[(long long)slot * s.cap + nn] = t;
+                if (nn < hv.cap) {
+                    ys_n[(long long)slot * hv.cap + nn] = tr;
+                    ts_n[(long long)slot * hv.cap + nn] = t;
                 }
                 nn++;
             }
             n_n[slot] = nn;
             // decoder context of the new hypothesis: last two of [blank, blank] + ys
-            long long y1 = nn >= 1 ? (realr ? tr : ys_c[(long long)hr * s.cap + n0 - 1]) : K2HIP_BLANK_ID;
+            long long y1 = nn >= 1 ? (realr ? tr : ys_c[(long long)hr * hv.cap + n0 - 1]) : K2HIP_BLANK_ID;
             long long y0 = K2HIP_BLANK_ID;
-            if (nn >= 2) y0 = realr ? ys_c[(long long)hr * s.cap + n0 - 1] : ys_c[(long long)hr * s.cap + n0 - 2];
-            s.ctx_next[2 * (b * K + slot)] = y0;
-            s.ctx_next[2 * (b * K + slot) + 1] = y1;
+            if (nn >= 2) y0 = realr ? ys_c[(long long)hr * hv.cap + n0 - 1] : ys_c[(long long)hr * hv.cap + n0 - 2];
+            hv.ctx[2 * slot] = y0;
+            hv.ctx[2 * slot + 1] = y1;
         }
+    }
+}
+
+// one workgroup per stream; `cur` = buffer holding frame t's input hypotheses
+__global__ __launch_bounds__(BT) void k_beam_step(BeamState s, const float* __restrict__ logits, int V, int t, int cur, int B) {
+    __shared__ int scratch[kStepScratchInts];
+    const int b = blockIdx.x, K = s.K, nxt = cur ^ 1;
+    const long long BK = (long long)B * K;
+    HypView hv;
+    hv.K = K; hv.cap = s.cap;
+    hv.ys_c = s.ys + ((long long)cur * BK + (long long)b * K) * s.cap;
+    hv.ts_c = s.ts + ((long long)cur * BK + (long long)b * K) * s.cap;
+    hv.ys_n = s.ys + ((long long)nxt * BK + (long long)b * K) * s.cap;
+    hv.ts_n = s.ts + ((long long)nxt * BK + (long long)b * K) * s.cap;
+    hv.n_c = s.n + cur * BK + b * K;
+    hv.n_n = s.n + nxt * BK + b * K;
+    hv.lp = s.lp + b * K;
+    hv.ctx = s.ctx + 2 * (long long)b * K;
+    hv.nhyp = s.nhyp + b;
+    beam_step_body<BT>(hv, logits + (long long)b * K * V, V, V, t, scratch);
+}
+
+// ---- the whole search of a stream in one kernel (small vocabularies: the model's all-contexts decoder table) -----------------
+// One workgroup of GT threads per stream walks the T' frames: the K hypotheses' decoder outputs are rows of the table, their
+// joiner inputs tanh(enc_t + dec_k) take the place of k_greedy's 8 speculated frames in the same sweep of the joiner matrix on the
+// matrix pipe (mfma_sweep_rows: 8 hypotheses x 256 columns per pass), the logits stay in LDS, and the step (log-softmax, top K,
+// expand, merge) is beam_step_body on hypotheses that live in LDS as well.  Replaces 4 launches per frame (1012 for the headline
+// batch, each waiting for slots between the next batch's encoder GEMMs) by one launch per batch.
+struct BeamLoopArgs {
+    const float* enc;   // [B, Tp, J]
+    int Tp, K, cap;
+    long long* tokens;
+    int* timestamps;
+    int* n_tokens;
+    float* scores;
+    int max_tokens;
+    int* overflow;
+};
+// LDS (floats): actT[J GF] | psum | lg[GF][Vp] | ctx[2 GF] (long long) | lp[GF] | n[2][GF] | nhyp, pad | scratch | ys[2][K][cap] | ts[2][K][cap]
+__host__ __device__ inline size_t beam_loop_lds_floats(int J, int Vp, int K, int cap) {
+    return (size_t)J * GF + kPsumFloats + (size_t)GF * Vp + 4 * GF + GF + 2 * GF + 4 + kStepScratchInts + 4 + 4 * (size_t)K * cap;
+}
+template <int NH>   // NH = 1: beam <= 4, the sweep forms only rows 0..3
+__global__ __launch_bounds__(GT) void k_beam_loop(DecJoinW w, BeamLoopArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* actT = sm;
+    float* psum = actT + w.J * GF;
+    float* lg = psum + kPsumFloats;
+    long long* ctx = reinterpret_cast<long long*>(lg + GF * w.Vp);   // (J GF, the psum size and GF Vp are multiples of 4 floats)
+    float* lp = reinterpret_cast<float*>(ctx + 2 * GF);
+    int* nbuf = reinterpret_cast<int*>(lp + GF);       // [2][GF]
+    int* nhyp = nbuf + 2 * GF;
+    int* scratch = nhyp + 4;
+    int* ys = scratch + kStepScratchInts + 4;
+    int* ts = ys + 2 * a.K * a.cap;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, K = a.K;
+    const float* enc = a.enc + (long long)b * a.Tp * w.J;
+    if (tid < GF) {   // k_beam_init
+        lp[tid] = tid == 0 ? 0.f : -INFINITY;
+        nbuf[tid] = 0;
+        nbuf[GF + tid] = 0;
+        ctx[2 * tid] = K2HIP_BLANK_ID;
+        ctx[2 * tid + 1] = K2HIP_BLANK_ID;
+        if (tid == 0) *nhyp = 1;
+    }
+    __syncthreads();
+    const int kper = w.J >> 3, ncg = w.Vp >> 2;
+    for (int t = 0; t < a.Tp; t++) {
+        const int nA = *nhyp, cur = t & 1;
+        // joiner inputs of the live hypotheses (row q of the sweep = hypothesis q); rows past nA are zero and ignored
+        for (int k = tid; k < w.J; k += GT) {
+            const float e = enc[(long long)t * w.J + k];
+            float d[4 * NH];
+#pragma unroll
+            for (int q = 0; q < 4 * NH; q++) {
+                const long long y0 = ctx[2 * min(q, K - 1)], y1 = ctx[2 * min(q, K - 1) + 1];   // (empty slots hold [blank, blank])
+                d[q] = w.dec_table[((y0 + 1) * w.V + y1) * (long long)w.J + k];
+            }
+#pragma unroll
+            for (int q = 0; q < GF; q++) actT[k * GF + q] = (q < 4 * NH && q < nA) ? tanhf(e + d[q < 4 * NH ? q : 0]) : 0.f;
+        }
+        __syncthreads();
+        for (int cgb = 0; cgb < ncg; cgb += 64) {
+            const int cg = cgb + lane;
+            f32x4 c[2][4];
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) c[hh][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mfma_sweep_rows<NH>(w.out_kn + (long long)(wave * kper) * w.Vp + 4 * min(cg, ncg - 1), w.Vp, actT + (wave * kper) * GF + (lane & 3), kper, c);
+            psum_store<NH>(psum, wave, lane, c);
+            __syncthreads();
+            if (cg < ncg && wave < nA) {   // wave q: hypothesis q's 256 logits of this pass, slices added in k_greedy's order
+                float4 ps[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) ps[q] = *reinterpret_cast<const float4*>(psum + (q * GF + wave) * 256 + 4 * lane);
+                float sj[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float p0 = (&ps[0].x)[j], p1 = (&ps[1].x)[j], p2 = (&ps[2].x)[j], p3 = (&ps[3].x)[j];
+                    const float p4 = (&ps[4].x)[j], p5 = (&ps[5].x)[j], p6 = (&ps[6].x)[j], p7 = (&ps[7].x)[j];
+                    const int col = 4 * cg + j;
+                    sj[j] = (((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7))) + (col < w.V ? w.out_b[col] : 0.f);
+                }
+                *reinterpret_cast<float4*>(lg + wave * w.Vp + 4 * cg) = make_float4(sj[0], sj[1], sj[2], sj[3]);
+            }
+            __syncthreads();
+        }
+        HypView hv;
+        hv.K = K; hv.cap = a.cap;
+        hv.ys_c = ys + (size_t)cur * K * a.cap; hv.ts_c = ts + (size_t)cur * K * a.cap; hv.n_c = nbuf + cur * GF;
+        hv.ys_n = ys + (size_t)(cur ^ 1) * K * a.cap; hv.ts_n = ts + (size_t)(cur ^ 1) * K * a.cap; hv.n_n = nbuf + (cur ^ 1) * GF;
+        hv.lp = lp; hv.ctx = ctx; hv.nhyp = nhyp;
+        beam_step_body<GT>(hv, lg, w.Vp, w.V, t, scratch);
+        __syncthreads();
+    }
+    // k_beam_final: max of log_prob / len(ys) (len counts the 2 ctx blanks), first maximum
+    const int fin = a.Tp & 1;
+    const int* n_f = nbuf + fin * GF;
+    int best = 0;
+    float bs = lp[0] / (float)(n_f[0] + 2);
+    for (int k = 1; k < *nhyp; k++) {
+        const float v = lp[k] / (float)(n_f[k] + 2);
+        if (v > bs) { bs = v; best = k; }
+    }
+    const int n = n_f[best];
+    if (n > a.max_tokens || n > a.cap) {
+        if (tid == 0) *a.overflow = 1;
+        return;
+    }
+    const int* ysf = ys + ((size_t)fin * K + best) * a.cap;
+    const int* tsf = ts + ((size_t)fin * K + best) * a.cap;
+    for (int i = tid; i < n; i += GT) {
+        a.tokens[(long long)b * a.max_tokens + i] = ysf[i];
+        a.timestamps[(long long)b * a.max_tokens + i] = tsf[i];
+    }
+    if (tid == 0) {
+        a.n_tokens[b] = n;
+        if (a.scores) a.scores[b] = lp[best];
     }
 }
 
@@ -290,6 +441,26 @@ void beam_search(const Ctx& ctx, const DecJoinW& w, const BeamArgs& a) {
     K2_REQUIRE(a.B > 0 && a.Tp > 0, "beam search: bad shape");
     Arena& ar = *ctx.arena;
     const int B = a.B, K = a.beam, M = B * K, cap = a.Tp + 1;
+    {
+        // the one-kernel form: needs the decoder table (small vocabulary) and the stream's logits and hypotheses in LDS
+        const size_t lds = sizeof(float) * beam_loop_lds_floats(w.J, w.Vp, K, cap);
+        if (w.dec_table && !tunables().beam_launches && lds <= 150 * 1024 && w.J % 8 == 0 && w.Vp % 4 == 0 && K <= GF) {
+            if (ctx.dry) return;
+            BeamLoopArgs la;
+            la.enc = a.enc; la.Tp = a.Tp; la.K = K; la.cap = cap;
+            la.tokens = a.tokens; la.timestamps = a.timestamps; la.n_tokens = a.n_tokens; la.scores = a.scores;
+            la.max_tokens = a.max_tokens; la.overflow = a.overflow;
+            K2_HIP(hipMemsetAsync(a.overflow, 0, sizeof(int), ctx.stream));
+            static LdsAttrOnce lds_attr;
+            static LdsAttrOnce lds_attr1;
+            lds_attr.ensure(k_beam_loop<2>, 150 * 1024);
+            lds_attr1.ensure(k_beam_loop<1>, 150 * 1024);
+            if (K <= 4) hipLaunchKernelGGL(k_beam_loop<1>, dim3(B), dim3(GT), lds, ctx.stream, w, la);
+            else hipLaunchKernelGGL(k_beam_loop<2>, dim3(B), dim3(GT), lds, ctx.stream, w, la);
+            K2_HIP(hipGetLastError());
+            return;
+        }
+    }
     BeamState s;
     s.K = K;
     s.cap = cap;
