@@ -10,6 +10,8 @@
 //   per stream: log_softmax + hyp score, top-K over K*V by (score desc, flat index asc), expand,
 //   merge equal token sequences by logaddexp (first-inserted hypothesis keeps its timestamps)   k_beam_step
 // Hypotheses live in double-buffered device arrays [2][B][K][cap]; ys excludes the ctx-blank prefix.
+#include <type_traits>
+
 #include "kernels.h"
 #include "sweep.h"
 
@@ -54,6 +56,46 @@ __global__ void k_beam_embconv(DecJoinW w, const long long* __restrict__ y, floa
     h[i] = embconv1(w, y[2 * m], y[2 * m + 1], co);
 }
 
+// ---- wave-wide reductions on data-parallel-primitive lane moves (no LDS crossbar: a ds_bpermute butterfly of 6 steps x 2 values is a
+// chain of ~900 cycles, and the step runs ~10 of them per frame) ------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;  // quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror
+// candidate order of the search: higher score first, then the LOWER flat index; index < 0 = no candidate
+__device__ __forceinline__ void best_merge(float& bv, int& bi, float ov, int oi) {
+    if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+}
+// the best (score, index) of the wave, in every lane (a total order: the sequence of merges does not matter)
+__device__ __forceinline__ void wave_best(float& bv, int& bi) {
+    best_merge(bv, bi, dpp_f<kDppXor1>(bv), dpp_i<kDppXor1>(bi));
+    best_merge(bv, bi, dpp_f<kDppXor2>(bv), dpp_i<kDppXor2>(bi));
+    best_merge(bv, bi, dpp_f<kDppHalfMirror>(bv), dpp_i<kDppHalfMirror>(bi));
+    best_merge(bv, bi, dpp_f<kDppMirror>(bv), dpp_i<kDppMirror>(bi));   // every lane: its row of 16
+    float rv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), 0));
+    int ri = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+    for (int row = 1; row < 4; row++)
+        best_merge(rv, ri, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), 16 * row)), __builtin_amdgcn_readlane(bi, 16 * row));
+    bv = rv;
+    bi = ri;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_f<kDppXor1>(v));
+    v = fmaxf(v, dpp_f<kDppXor2>(v));
+    v = fmaxf(v, dpp_f<kDppHalfMirror>(v));
+    v = fmaxf(v, dpp_f<kDppMirror>(v));
+    float r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+#pragma unroll
+    for (int row = 1; row < 4; row++) r = fmaxf(r, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16 * row)));
+    return r;
+}
+
 // One stream's hypotheses as the step sees them: frame t's input buffers (_c), the other parity's (_n), and the in-place state.
 // Global memory (k_beam_step: one launch per frame) or LDS (k_beam_loop: the whole search in one kernel).
 struct HypView {
@@ -85,51 +127,50 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
     if (V <= 64 * 16) {
         // the hypothesis' logits, V / 64 per lane, are read ONCE into registers: the max, the sum and the `want` selection rounds below
         // went through global memory 2 + want times before (a chain of dependent loads that made this step 20 us)
-        for (int k = wave; k < nA; k += BT / 64) {
-            const float* l = lg + (long long)k * ldl;
-            float lv[16];
+        auto select = [&](auto ne_tag) {
+            constexpr int NE = decltype(ne_tag)::value;   // elements per lane
+            for (int k = wave; k < nA; k += BT / 64) {
+                const float* l = lg + (long long)k * ldl;
+                float lv[NE];
 #pragma unroll
-            for (int i = 0; i < 16; i++) lv[i] = lane + 64 * i < V ? l[lane + 64 * i] : -INFINITY;
-            float mx = -INFINITY;
+                for (int i = 0; i < NE; i++) lv[i] = lane + 64 * i < V ? l[lane + 64 * i] : -INFINITY;
+                float mx = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 16; i++) mx = fmaxf(mx, lv[i]);
+                for (int i = 0; i < NE; i++) mx = fmaxf(mx, lv[i]);
+                mx = wave_max(mx);
+                float sm = 0.f;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-            float sm = 0.f;
+                for (int i = 0; i < NE; i++)
+                    if (lane + 64 * i < V) sm += expf(lv[i] - mx);
 #pragma unroll
-            for (int i = 0; i < 16; i++)
-                if (lane + 64 * i < V) sm += expf(lv[i] - mx);
+                for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+                const float lse = logf(sm), lpk = hv.lp[k];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
-            const float lse = logf(sm), lpk = hv.lp[k];
-            unsigned used = 0;  // bit i: this lane's element i was already selected
-            for (int r = 0; r < want; r++) {
-                float bv = -INFINITY;
-                int bi = -1;
+                for (int i = 0; i < NE; i++) lv[i] = (lv[i] - mx - lse) + lpk;  // the scores, in the oracle's order of operations
+                unsigned used = 0;  // bit i: this lane's element i was already selected
+                for (int r = 0; r < want; r++) {
+                    float bv = -INFINITY;
+                    int bi = -1;
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int v = lane + 64 * i;
-                    if (v >= V || (used >> i & 1)) continue;
-                    const float sc = (lv[i] - mx - lse) + lpk;  // the oracle's order of operations
-                    if (bi < 0 || sc > bv) { bv = sc; bi = v; }   // ascending v per lane: first maximum wins
+                    for (int i = 0; i < NE; i++) {
+                        const int v = lane + 64 * i;
+                        if (v >= V || (used >> i & 1)) continue;
+                        if (bi < 0 || lv[i] > bv) { bv = lv[i]; bi = v; }   // ascending v per lane: first maximum wins
+                    }
+                    wave_best(bv, bi);
+                    if (bi >= 0 && (bi & 63) == lane) used |= 1u << (bi >> 6);
+                    if (lane == 0) { candv[k * kMaxBeam + r] = bv; candi[k * kMaxBeam + r] = bi < 0 ? -1 : k * V + bi; }
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(bv, o);
-                    const int oi = __shfl_xor(bi, o);
-                    if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
-                }
-                if (bi >= 0 && (bi & 63) == lane) used |= 1u << (bi >> 6);
-                if (lane == 0) { candv[k * kMaxBeam + r] = bv; candi[k * kMaxBeam + r] = bi < 0 ? -1 : k * V + bi; }
             }
-        }
+        };
+        if (V <= 64 * 8) select(std::integral_constant<int, 8>{});
+        else select(std::integral_constant<int, 16>{});
     } else
     for (int k = wave; k < nA; k += BT / 64) {
         const float* l = lg + (long long)k * ldl;
         float mx = -INFINITY;
         for (int v = lane; v < V; v += 64) mx = fmaxf(mx, l[v]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        mx = wave_max(mx);
         float sm = 0.f;
         for (int v = lane; v < V; v += 64) sm += expf(l[v] - mx);
 #pragma unroll
@@ -146,12 +187,7 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
                 const float sc = (l[v] - mx - lse) + lpk;  // the oracle's order of operations
                 if (bi < 0 || sc > bv) { bv = sc; bi = v; }   // ascending v per lane: first maximum wins
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(bv, o);
-                const int oi = __shfl_xor(bi, o);
-                if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
-            }
+            wave_best(bv, bi);
             excl[r] = bi;
             if (lane == 0) { candv[k * kMaxBeam + r] = bv; candi[k * kMaxBeam + r] = bi < 0 ? -1 : k * V + bi; }
         }
@@ -164,12 +200,7 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
         for (int r = 0; r < want; r++) {
             float bv = myv;
             int bi = myi;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(bv, o);
-                const int oi = __shfl_xor(bi, o);
-                if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
-            }
+            wave_best(bv, bi);
             if (lane == 0) { topv[r] = bv; topi[r] = bi; taken[r] = bi; }
             if (myi == bi) myi = -1;  // that candidate is used up (flat indexes are unique)
         }
@@ -236,17 +267,17 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
         *hv.nhyp = nN;
     }
     __syncthreads();
-    for (int r = 0; r < want; r++) {
+    for (int r = wave; r < want; r += BT / 64) {   // a wave per surviving candidate (distinct destination slots)
         const int slot = taken[r];
         if (slot < 0) continue;
         const int hr = topi[r] / V, tr = topi[r] % V;
         const bool realr = tr != K2HIP_BLANK_ID && tr != K2HIP_UNK_ID;
         const int n0 = n_c[hr];
-        for (int i = tid; i < n0; i += BT) {
+        for (int i = lane; i < n0; i += 64) {
             ys_n[(long long)slot * hv.cap + i] = ys_c[(long long)hr * hv.cap + i];
             ts_n[(long long)slot * hv.cap + i] = ts_c[(long long)hr * hv.cap + i];
         }
-        if (tid == 0) {
+        if (lane == 0) {
             int nn = n0;
             if (realr) {
                 if (nn < hv.cap) {
