@@ -109,13 +109,29 @@ __global__ void k_tanh_add(const float* __restrict__ enc, const float* __restric
 __device__ __forceinline__ void amax_merge(float& v, int& i, float ov, int oi) {
     if (ov > v || (ov == v && oi > i)) { v = ov; i = oi; }
 }
+// Data-parallel-primitive lane moves (row = 16 lanes): no LDS crossbar, unlike __shfl_xor's ds_bpermute_b32 (a 6-step butterfly over
+// two values is a dependent chain of ~900 cycles)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+// the wave's (value, index) maximum in every lane (amax_merge is a total order: the sequence of merges does not matter)
 __device__ __forceinline__ void amax_wave(float& v, int& i) {
+    amax_merge(v, i, dpp_f<0xB1>(v), dpp_i<0xB1>(i));     // quad_perm [1,0,3,2]
+    amax_merge(v, i, dpp_f<0x4E>(v), dpp_i<0x4E>(i));     // quad_perm [2,3,0,1]
+    amax_merge(v, i, dpp_f<0x141>(v), dpp_i<0x141>(i));   // row_half_mirror
+    amax_merge(v, i, dpp_f<0x140>(v), dpp_i<0x140>(i));   // row_mirror: every lane holds its row of 16
+    float rv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    int ri = __builtin_amdgcn_readlane(i, 0);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        float ov = __shfl_xor(v, o);
-        int oi = __shfl_xor(i, o);
-        amax_merge(v, i, ov, oi);
-    }
+    for (int row = 1; row < 4; row++)
+        amax_merge(rv, ri, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16 * row)), __builtin_amdgcn_readlane(i, 16 * row));
+    v = rv;
+    i = ri;
 }
 
 // one wave per row; FIRST = false: later index wins ties (transducer loops); true: first index (CTC, Array.IndexOf)
