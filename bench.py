@@ -175,13 +175,14 @@ def pmc_mfma_busy():
 
 def run_secondary(timeout_s=240):
     """Bounded legs for BASELINE configs[2], [3], [4] (one GPU's share each), run as child programs AFTER the headline model has
-    been closed, one at a time; each child prints its own JSON line (with its own cpu_baseline and oracle_match), condensed here."""
+    been closed, one at a time; each child prints its own JSON line (with its own cpu_baseline and oracle_match), condensed here.
+    (16 timed steps each: the timed region ends with the last batch's search running alone, a 5 - 10 ms tail that 6 steps spread thinly.)"""
     here = os.path.dirname(os.path.abspath(__file__))
     legs = {
-        "beam4_c2_shard": [sys.executable, os.path.join(here, "bench.py"), "--beam", "4", "--steps", "6", "--warmup", "2",
+        "beam4_c2_shard": [sys.executable, os.path.join(here, "bench.py"), "--beam", "4", "--steps", "16", "--warmup", "2",
                            "--no-host-leg", "--no-secondary"],
         "conformer_zh_c4_shard": [sys.executable, os.path.join(here, "bench.py"), "--preset", "conformer-zh", "--batch", "8",
-                                  "--seconds", "30", "--steps", "6", "--warmup", "2", "--no-host-leg", "--no-secondary"],
+                                  "--seconds", "30", "--steps", "16", "--warmup", "2", "--no-host-leg", "--no-secondary"],
         "streaming_c3": [sys.executable, os.path.join(here, "bench_streaming.py"), "--check", "8"],
     }
     out = {}
