@@ -27,6 +27,26 @@ def test_beam_search_matches_oracle(hip_tiny, oracle_tiny, enc_tiny, beam):
     np.testing.assert_allclose(gsc, sc, atol=2e-3, rtol=0)
 
 
+@pytest.mark.parametrize("beam", [1, 4, 8])
+def test_beam_search_launch_form_equals_the_one_kernel_form(hip_tiny, oracle_tiny, enc_tiny, beam):
+    """A model with the all-contexts decoder table runs the whole search as one kernel per batch (k_beam_loop); without it (large
+    vocabularies) the search is four launches per frame.  K2HIP_BEAM_LAUNCHES forces the launch form on a small model: both must
+    equal the oracle, and each other in tokens and timestamps (their scores differ by float rounding only: the decoder projection
+    is the search loops' own routine in one and a GEMM in the other)."""
+    import k2transducerasr_amd as pkg
+    want, mg, sc = oracle_tiny.modified_beam_search(enc_tiny, beam, want_margins=True, want_scores=True)
+    loop, lsc = hip_tiny.beam_search(enc_tiny, beam, want_scores=True)
+    pkg.set_switch("K2HIP_BEAM_LAUNCHES", 1)
+    try:
+        launches, csc = hip_tiny.beam_search(enc_tiny, beam, want_scores=True)
+    finally:
+        pkg.set_switch("K2HIP_BEAM_LAUNCHES", 0)
+    _check(launches, want, mg, f"launch form, beam={beam}")
+    assert launches == loop
+    np.testing.assert_allclose(csc, sc, atol=2e-3, rtol=0)
+    np.testing.assert_allclose(csc, lsc, atol=1e-4, rtol=0)
+
+
 def test_beam_search_stream_independence(hip_tiny, enc_tiny):
     # x_lens = T' for all streams: each stream's search is independent of its batch mates
     full = hip_tiny.beam_search(enc_tiny, 4)
