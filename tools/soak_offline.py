@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import k2transducerasr_amd as pkg  # noqa: E402
 from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model  # noqa: E402
 from oracle import Oracle  # noqa: E402
-from parity import assert_tokens_match  # noqa: E402
+from parity import assert_beam_match, assert_tokens_match  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
@@ -26,7 +26,7 @@ for preset in presets:
     write_synthetic_model(path, preset)
     hip, ora = pkg.Model(path, 0), Oracle(path)
     rng = np.random.default_rng(seed)
-    exact = tot = skipped = 0
+    exact = tot = skipped = bexact = btot = 0
     for case in range(cases):
         B = int(rng.integers(1, 9))
         ns = [int(rng.choice(lens_pool)) if rng.random() < 0.5 else int(rng.integers(400, 40000)) for _ in range(B)]
@@ -41,5 +41,13 @@ for preset in presets:
         got = hip.offline_greedy_from_samples(utts)
         exact += assert_tokens_match(got, want, mg, what=f"{preset} case {case} (B={B}, samples={ns})", allow_tie=True)
         tot += B
+        if preset == "zipformer2-tiny-test":   # the modified beam search (one kernel per batch on this vocabulary) on the same encoder output
+            enc = ora.encoder(x)
+            beam = int(rng.choice([2, 4, 8]))
+            bwant, bmg = ora.modified_beam_search(enc, beam, want_margins=True)
+            bexact += assert_beam_match(hip.beam_search(enc, beam), bwant, bmg, what=f"{preset} case {case} beam {beam}", allow_tie=True)
+            btot += B
     print(f"{preset}: {cases - skipped} batches, {exact}/{tot} streams token-exact (the rest diverge on an oracle near-tie)", flush=True)
+    if btot:
+        print(f"{preset}: modified beam search {bexact}/{btot} streams exact", flush=True)
 print("soak ok")
