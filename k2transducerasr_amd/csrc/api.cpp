@@ -687,11 +687,25 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
             K2_REQUIRE(std::adjacent_find(seen.begin(), seen.end()) == seen.end(), "GetResults: the same stream appears twice in the list");
         }
         if (idx.empty()) return;   // :113-116
-        bool fb_deferred = false;   // the new frames' host copy is collected after the step (one wait for the device per tick)
+        // the new frames' host copy is collected after the step (one wait for the device per tick); whatever way this call ends -- an
+        // allocation failure below included -- the outstanding download is collected before the streams' Speech can move
+        struct GatherFinisher {
+            Engine& e;
+            bool armed = false;
+            void finish() {
+                if (!armed) return;
+                armed = false;
+                EngineLock lk(e);
+                e.fbank_gather_finish();
+            }
+            ~GatherFinisher() {
+                try { finish(); } catch (...) {}
+            }
+        } fb{e};
         {   // the deferred fbank of the streams that decode now: one batched launch when they are at the same position
             std::vector<k2hip_online_stream*> ready(idx.size());
             for (size_t r = 0; r < idx.size(); r++) ready[r] = streams[idx[r]];
-            fb_deferred = online_materialize(ready.data(), (int)ready.size(), true);
+            fb.armed = online_materialize(ready.data(), (int)ready.size(), true);
         }
         const int R = (int)idx.size(), Tp = e.online_frames_per_chunk();
         std::vector<const float*> chunks(R);   // GetDecodeChunk: the first ChunkLength frames of each FIFO
@@ -713,11 +727,7 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
         }
         std::vector<int64_t> tok((size_t)R * Tp);
         std::vector<int32_t> ts((size_t)R * Tp), n(R);
-        if (fb_deferred && !all_mirrored) {   // the step reads some stream's chunk from host memory: the frames must be there
-            EngineLock lk(e);
-            e.fbank_gather_finish();
-            fb_deferred = false;
-        }
+        if (!all_mirrored) fb.finish();   // the step reads some stream's chunk from host memory: the frames must be there
         try {
             EngineLock lk(e);
             e.online_step(slots.data(), chunks.data(), hyps.data(), plens.data(), nch.data(), R, tok.data(), ts.data(), n.data(),
@@ -727,15 +737,9 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
             // updates the conv / embed caches in place.  A search exchange timeout is retried inside the engine and does not come
             // here; what does is a HIP failure.  The streams are unusable until reset.
             for (int r = 0; r < R; r++) streams[idx[r]]->poisoned = true;
-            if (fb_deferred) {
-                try { EngineLock lk(e); e.fbank_gather_finish(); } catch (...) {}   // (the streams are poisoned either way)
-            }
-            throw;
+            throw;   // (fb's destructor collects the frames; the streams are poisoned either way)
         }
-        if (fb_deferred) {
-            EngineLock lk(e);
-            e.fbank_gather_finish();   // the step's token download has synchronised the stream: copies only
-        }
+        fb.finish();   // the step's token download has synchronised the stream: copies only
         // RemoveChunk (:102-117) only after success
         std::vector<k2hip_online_stream*> remirror;
         for (int r = 0; r < R; r++) {
