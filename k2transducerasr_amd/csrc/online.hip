@@ -108,6 +108,11 @@ __global__ void k_cat_shift(float* __restrict__ pool, long long slot_stride, lon
 // chunk's own key rows go into the ring first (this workgroup's 32 columns of them; nobody else reads or writes those), then every
 // key is read from ring row p.  Column p of aw = ring row p; the reference's key index of that row (for the positional term and the
 // left-context mask) is j = (p - head - Tc) mod KL.
+// a lane's value moved within its row of 16 lanes (DPP: quad_perm [1,0,3,2] 0xB1, [2,3,0,1] 0x4E, row_half_mirror 0x141, row_mirror 0x140)
+template <int CTRL>
+__device__ __forceinline__ float row16_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
 __global__ __launch_bounds__(256) void k_attn_stream_ring(const float* __restrict__ qkp, int ld, RingRef keys, const float* __restrict__ pp,
                                                           const long long* __restrict__ plen, float* __restrict__ aw, int B, int Tc,
                                                           int L, int KLp, int H, int ds, int left50) {
@@ -123,6 +128,32 @@ __global__ __launch_bounds__(256) void k_attn_stream_ring(const float* __restric
             *reinterpret_cast<const float4*>(qkp + ((long long)b * Tc + r) * ld + H * QH + h * QH + c);
     }
     __syncthreads();  // this workgroup's stores are visible to its own loads below (no line of the ring was cached before them)
+    // thread = one query row i for a column of keys p = p0, p0 + blockDim / Tc, ...: the row's q (32 floats) and positional query (4)
+    // are read once into registers (a flat (i, p) index re-read both for every score: half of the kernel's loads)
+    if (Tc <= (int)blockDim.x && blockDim.x % Tc == 0) {
+        const int i = threadIdx.x % Tc, pstep = blockDim.x / Tc;
+        const float* q = qkp + ((long long)b * Tc + i) * ld + h * QH;
+        float4 qv[QH / 4];
+#pragma unroll
+        for (int d = 0; d < QH / 4; d++) qv[d] = *reinterpret_cast<const float4*>(q + 4 * d);
+        const float4 pv = *reinterpret_cast<const float4*>(qkp + ((long long)b * Tc + i) * ld + 2 * H * QH + h * PH);
+        for (int p = threadIdx.x / Tc; p < KL; p += pstep) {
+            int j = (p - head - Tc) % KL;
+            if (j < 0) j += KL;
+            const float* k = ring + (long long)p * (H * QH) + h * QH;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < QH / 4; d++) {
+                const float4 c = *reinterpret_cast<const float4*>(k + 4 * d);
+                s += qv[d].x * c.x + qv[d].y * c.y + qv[d].z * c.z + qv[d].w * c.w;
+            }
+            const float4 ev = *reinterpret_cast<const float4*>(pp + (long long)(Tc - 1 - i + j) * (H * PH) + h * PH);
+            s += pv.x * ev.x + pv.y * ev.y + pv.z * ev.z + pv.w * ev.w;
+            // src_key_padding_mask[..., ::ds]: left-context slot j (50 Hz slot j*ds) is valid only once processed
+            if (j < L && pl <= (long long)(left50 - 1 - j * ds)) s = -1000.0f;
+            S[i * KL + p] = s;
+        }
+    } else
     for (int e = threadIdx.x; e < Tc * KL; e += blockDim.x) {
         const int i = e / KL, p = e - i * KL;
         int j = (p - head - Tc) % KL;
@@ -144,24 +175,32 @@ __global__ __launch_bounds__(256) void k_attn_stream_ring(const float* __restric
         S[e] = s;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // softmax: a row per group of 16 lanes (4 rows per wave at once; the reductions stay inside a DPP row of 16: no ds_bpermute)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sl = lane & 15;
     float* out = aw + (((long long)h * B + b) * Tc) * KLp;
-    for (int i = wave; i < Tc; i += 4) {
-        float* row = S + i * KL;
+    for (int i0 = 0; i0 < Tc; i0 += 16) {
+        const int i = i0 + wave * 4 + (lane >> 4);
+        const bool live = i < Tc;
+        float* row = S + (live ? i : 0) * KL;
         float mx = -INFINITY;
-        for (int j = lane; j < KL; j += 64) mx = fmaxf(mx, row[j]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        for (int j = sl; j < KL; j += 16) mx = fmaxf(mx, row[j]);
+        mx = fmaxf(mx, row16_f<0xB1>(mx));
+        mx = fmaxf(mx, row16_f<0x4E>(mx));
+        mx = fmaxf(mx, row16_f<0x141>(mx));
+        mx = fmaxf(mx, row16_f<0x140>(mx));
         float sum = 0.f;
-        for (int j = lane; j < KL; j += 64) {
-            float e = __expf(row[j] - mx);
-            row[j] = e;
+        for (int j = sl; j < KL; j += 16) {
+            const float e = __expf(row[j] - mx);
+            if (live) row[j] = e;
             sum += e;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        float inv = 1.0f / sum;
-        for (int j = lane; j < KLp; j += 64) out[(long long)i * KLp + j] = j < KL ? row[j] * inv : 0.f;
+        sum += row16_f<0xB1>(sum);
+        sum += row16_f<0x4E>(sum);
+        sum += row16_f<0x141>(sum);
+        sum += row16_f<0x140>(sum);
+        const float inv = 1.0f / sum;
+        if (live)
+            for (int j = sl; j < KLp; j += 16) out[(long long)i * KLp + j] = j < KL ? row[j] * inv : 0.f;
     }
 }
 
