@@ -331,10 +331,14 @@ struct BeamLoopArgs {
     float* scores;
     int max_tokens;
     int* overflow;
+    // long utterances: the hypotheses' token / timestamp arrays do not fit in LDS beside the logits and live in device memory,
+    // [B][2][K][cap] each (a workgroup reads back only what it wrote itself: one CU, one L1); null = in LDS
+    int* ys_g;
+    int* ts_g;
 };
 // LDS (floats): actT[J GF] | psum | lg[GF][Vp] | ctx[2 GF] (long long) | lp[GF] | n[2][GF] | nhyp, pad | scratch | ys[2][K][cap] | ts[2][K][cap]
-__host__ __device__ inline size_t beam_loop_lds_floats(int J, int Vp, int K, int cap) {
-    return (size_t)J * GF + kPsumFloats + (size_t)GF * Vp + 4 * GF + GF + 2 * GF + 4 + kStepScratchInts + 4 + 4 * (size_t)K * cap;
+__host__ __device__ inline size_t beam_loop_lds_floats(int J, int Vp, int K, int cap, bool hyp_in_lds) {
+    return (size_t)J * GF + kPsumFloats + (size_t)GF * Vp + 4 * GF + GF + 2 * GF + 4 + kStepScratchInts + 4 + (hyp_in_lds ? 4 * (size_t)K * cap : 0);
 }
 template <int NH>   // NH = 1: beam <= 4, the sweep forms only rows 0..3
 __global__ __launch_bounds__(GT) void k_beam_loop(DecJoinW w, BeamLoopArgs a) {
@@ -347,8 +351,8 @@ __global__ __launch_bounds__(GT) void k_beam_loop(DecJoinW w, BeamLoopArgs a) {
     int* nbuf = reinterpret_cast<int*>(lp + GF);       // [2][GF]
     int* nhyp = nbuf + 2 * GF;
     int* scratch = nhyp + 4;
-    int* ys = scratch + kStepScratchInts + 4;
-    int* ts = ys + 2 * a.K * a.cap;
+    int* ys = a.ys_g ? a.ys_g + (size_t)blockIdx.x * 2 * a.K * a.cap : scratch + kStepScratchInts + 4;
+    int* ts = a.ys_g ? a.ts_g + (size_t)blockIdx.x * 2 * a.K * a.cap : ys + 2 * a.K * a.cap;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, K = a.K;
     const float* enc = a.enc + (long long)b * a.Tp * w.J;
     if (tid < GF) {   // k_beam_init
@@ -474,13 +478,18 @@ void beam_search(const Ctx& ctx, const DecJoinW& w, const BeamArgs& a) {
     const int B = a.B, K = a.beam, M = B * K, cap = a.Tp + 1;
     {
         // the one-kernel form: needs the decoder table (small vocabulary) and the stream's logits and hypotheses in LDS
-        const size_t lds = sizeof(float) * beam_loop_lds_floats(w.J, w.Vp, K, cap);
+        // hypotheses in LDS when they fit beside the logits (T' <= ~600 at beam 4 with the large-en shapes), else in device memory
+        const bool hyp_in_lds = sizeof(float) * beam_loop_lds_floats(w.J, w.Vp, K, cap, true) <= 150 * 1024 && !tunables().beam_hyp_global;
+        const size_t lds = sizeof(float) * beam_loop_lds_floats(w.J, w.Vp, K, cap, hyp_in_lds);
         if (w.dec_table && !tunables().beam_launches && lds <= 150 * 1024 && w.J % 8 == 0 && w.Vp % 4 == 0 && K <= GF) {
+            int* ys_g = hyp_in_lds ? nullptr : ar.take<int>((int64_t)2 * M * cap);
+            int* ts_g = hyp_in_lds ? nullptr : ar.take<int>((int64_t)2 * M * cap);
             if (ctx.dry) return;
             BeamLoopArgs la;
             la.enc = a.enc; la.Tp = a.Tp; la.K = K; la.cap = cap;
             la.tokens = a.tokens; la.timestamps = a.timestamps; la.n_tokens = a.n_tokens; la.scores = a.scores;
             la.max_tokens = a.max_tokens; la.overflow = a.overflow;
+            la.ys_g = ys_g; la.ts_g = ts_g;
             K2_HIP(hipMemsetAsync(a.overflow, 0, sizeof(int), ctx.stream));
             static LdsAttrOnce lds_attr;
             static LdsAttrOnce lds_attr1;

@@ -25,6 +25,7 @@ struct Tunables {
     int greedy_one_part = 0;      // K2HIP_GREEDY_ONE_PART: one workgroup per stream in the search
     int greedy_parts = 0;         // K2HIP_GREEDY_PARTS: vocabulary slabs per stream (0 = automatic)
     int beam_launches = 0;        // K2HIP_BEAM_LAUNCHES: the modified beam search as 4 launches per frame even when the one-kernel form applies
+    int beam_hyp_global = 0;      // K2HIP_BEAM_HYP_GLOBAL: the one-kernel beam search keeps its hypotheses in device memory even when they fit in LDS (the long-utterance form, for its test)
     int decoder_table_mb = 1024;  // K2HIP_DECODER_TABLE_MB: build the all-contexts decoder table when it fits this many MiB (0 = never)
     int test_greedy_timeout = 0;  // K2HIP_TEST_GREEDY_TIMEOUT: test hook -- every parts > 1 search reports an exchange timeout, so the one-part retry runs
     int pipe_mode = 0;            // K2HIP_PIPE_MODE: 1 = every pipeline slot owns a stream

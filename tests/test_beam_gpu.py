@@ -43,6 +43,13 @@ def test_beam_search_launch_form_equals_the_one_kernel_form(hip_tiny, oracle_tin
         pkg.set_switch("K2HIP_BEAM_LAUNCHES", 0)
     _check(launches, want, mg, f"launch form, beam={beam}")
     assert launches == loop
+    # long utterances: the one-kernel form with its hypotheses in device memory instead of LDS -- the same arithmetic, the same bits
+    pkg.set_switch("K2HIP_BEAM_HYP_GLOBAL", 1)
+    try:
+        far, fsc = hip_tiny.beam_search(enc_tiny, beam, want_scores=True)
+    finally:
+        pkg.set_switch("K2HIP_BEAM_HYP_GLOBAL", 0)
+    assert far == loop and np.array_equal(fsc, lsc)
     np.testing.assert_allclose(csc, sc, atol=2e-3, rtol=0)
     np.testing.assert_allclose(csc, lsc, atol=1e-4, rtol=0)
 
