@@ -221,15 +221,13 @@ __global__ void k_first_emit(const int* __restrict__ tok, int B, int Tp, int ski
 }
 
 // ---- multi-frame greedy loop ---------------------------------------------------------
-// One workgroup of GT threads per stream.  The joiner matrix (J x V f32, 1 MB for the
-// large-en model) does not fit in LDS and streaming it from L2 once per frame made the loop
-// latency-bound (~50 us / frame).  Blank wins most frames and the decoder context only
-// changes on an emission, so each ROUND evaluates the next GF frames against the CURRENT
-// context in one sweep of the matrix (every 16-byte weight load feeds GF x 4 FMAs), then
-// accepts frames in order up to and including the first one that emits.  Frames after an
-// emission are re-evaluated in the next round under the new context, so the result is
-// exactly the frame-by-frame loop of OfflineRecognizer.cs:216-288.
-// dec_out[J] = decoder_proj(relu(grouped_conv(emb[y0], emb[y1]))), GT threads, two per output
+// One or more workgroups of GT threads per stream.  The joiner matrix (J x V f32, 1 MB for the large-en model) does not fit in
+// LDS, and sweeping it from L2 once per frame made the loop ~50 us per frame.  Blank wins most frames and the decoder context
+// only changes on an emission, so each ROUND evaluates the next GF frames against the CURRENT context in one sweep of the matrix
+// (on the matrix pipe: sweep.h), then accepts frames in order up to and including the first one that emits.  Frames after an
+// emission are re-evaluated in the next round under the new context, so the result is exactly the frame-by-frame loop of
+// OfflineRecognizer.cs:216-288.
+
 // out[n] = f(bias[n] + sum_k x[k] * W[k*N + n]) for a k-major matrix, GT threads: 8 k slices x N/4 column
 // groups, 8 float4 weight loads in flight per thread (a dependent load per FMA made this ~50 us per
 // emission), partials combined through LDS.  x: LDS [K]; scratch: LDS >= 8*N floats; N % 4 == 0.
