@@ -134,8 +134,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_scores_softmax(const float* __r
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (k < nk) mx = fmaxf(fmaxf(fmaxf(mx, v[rr][k].x), fmaxf(v[rr][k].y, v[rr][k].z)), v[rr][k].w);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            mx = wave_max_dpp(mx);
             float sum = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -162,8 +161,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_scores_softmax(const float* __r
         float* srow = S + rl * lds_stride;
         float mx = -INFINITY;
         for (int j = lane; j < T; j += 64) mx = fmaxf(mx, srow[j]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        mx = wave_max_dpp(mx);
         float sum = 0.f;
         for (int j = lane; j < T; j += 64) {
             float e = __expf(srow[j] - mx);

@@ -1,6 +1,7 @@
 // Shared host-side plumbing for libk2hip: error transport across the C ABI,
 // HIP call checking, a grow-only device arena.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -103,5 +104,25 @@ class Arena {
     int64_t cap_ = 0, off_ = 0, high_ = 0;
     bool dry_ = false;
 };
+
+
+#if defined(__HIPCC__)
+// The wave's maximum in every lane, on data-parallel-primitive moves within rows of 16 lanes + four v_readlane (no LDS crossbar: a
+// ds_bpermute butterfly is a dependent chain of ~900 cycles).  max is exact in any order, so this returns the butterfly's bits;
+// sums keep their butterfly (their rounding depends on the order).  Whole-wave call sites only.
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    auto mv = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false));
+    };
+    v = fmaxf(v, mv(v, std::integral_constant<int, 0xB1>{}));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, mv(v, std::integral_constant<int, 0x4E>{}));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, mv(v, std::integral_constant<int, 0x141>{}));   // row_half_mirror
+    v = fmaxf(v, mv(v, std::integral_constant<int, 0x140>{}));   // row_mirror
+    float r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+#pragma unroll
+    for (int row = 1; row < 4; row++) r = fmaxf(r, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16 * row)));
+    return r;
+}
+#endif
 
 }  // namespace k2hip

@@ -45,8 +45,7 @@ __global__ __launch_bounds__(256) void k_conformer_softmax_shift(float* __restri
         v[u] = j < T ? a[j] + b[j] : -INFINITY;
         mx = fmaxf(mx, v[u]);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max_dpp(mx);
     float sum = 0.f;
 #pragma unroll
     for (int u = 0; u < SM_PER_LANE; u++) {
@@ -75,8 +74,7 @@ __global__ __launch_bounds__(256) void k_conformer_softmax_shift_long(float* __r
     const float* b = bd + row * NPp + (T - 1 - i);
     float mx = -INFINITY;
     for (int j = lane; j < T; j += 64) mx = fmaxf(mx, a[j] + b[j]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max_dpp(mx);
     float sum = 0.f;
     for (int j = lane; j < T; j += 64) {
         const float e = __expf(a[j] + b[j] - mx);
@@ -109,8 +107,7 @@ __global__ __launch_bounds__(256) void k_conformer_softmax_shift_stream(float* _
         a[j] = s;
         mx = fmaxf(mx, s);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max_dpp(mx);
     float sum = 0.f;
     for (int j = lane; j < KL; j += 64) {
         const float e = __expf(a[j] - mx);
@@ -276,8 +273,7 @@ __global__ __launch_bounds__(512) void k_conformer_scores_softmax(const float* _
             v[u] = jj < T ? srow[jj] : -INFINITY;
             mx = fmaxf(mx, v[u]);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        mx = wave_max_dpp(mx);
         float sum = 0.f;
 #pragma unroll
         for (int u = 0; u < 20; u++) {

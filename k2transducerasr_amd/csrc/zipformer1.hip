@@ -66,8 +66,7 @@ __global__ __launch_bounds__(256) void k_z1_attn(const float* __restrict__ qkvp,
         float* row = S + i * KL;
         float mx = -INFINITY;
         for (int j = lane; j < KL; j += 64) mx = fmaxf(mx, row[j]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        mx = wave_max_dpp(mx);
         float sum = 0.f;
         for (int j = lane; j < KL; j += 64) {
             float e = __expf(row[j] - mx);
