@@ -114,7 +114,6 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
     int* taken = scratch;
     float* topv = reinterpret_cast<float*>(scratch + kMaxBeam);
     int* topi = scratch + 2 * kMaxBeam;
-    int* dupof = scratch + 3 * kMaxBeam;      // for new entry r: index of the earlier entry it merges into, or -1
     float* candv = reinterpret_cast<float*>(scratch + 4 * kMaxBeam + 4);
     int* candi = scratch + 4 * kMaxBeam + 4 + kMaxBeam * kMaxBeam;
     const int tid = threadIdx.x, K = hv.K;
@@ -236,27 +235,58 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
     }
     __syncthreads();
     if (tid == 0) {
-        for (int r = 0; r < want; r++) {   // for new entry r: the earliest entry it merges into (one that was not merged away itself), or -1
-            int found = -1;
-            for (int q = 0; q < r && found < 0; q++)
-                if (dupof[q] < 0 && eq[r * kMaxBeam + q]) found = q;
-            dupof[r] = found;
+        // One thread resolves the merges in insertion order.  Everything it needs is read up front (independent LDS loads) and kept in
+        // registers -- fully unrolled, selects instead of indexed arrays: as a loop over LDS this was a chain of ~40 dependent
+        // accesses, 2 us of the step.
+        float tv[kMaxBeam], lpn[kMaxBeam];
+        unsigned eqm[kMaxBeam];   // bit q of eqm[r]: candidates r and q < r spell the same sequence
+#pragma unroll
+        for (int r = 0; r < kMaxBeam; r++) {
+            tv[r] = r < want ? topv[r] : -INFINITY;
+            lpn[r] = -INFINITY;
+            eqm[r] = 0;
+#pragma unroll
+            for (int q = 0; q < r; q++)
+                if (r < want && eq[r * kMaxBeam + q]) eqm[r] |= 1u << q;
         }
-        // slot assignment in insertion order; merged scores accumulate in candidate order (logaddexp)
+        unsigned merged = 0;      // bit q: candidate q was merged into an earlier one
         int slot_of[kMaxBeam];
         int nN = 0;
-        for (int r = 0; r < want; r++) {
-            if (dupof[r] < 0) {
-                slot_of[r] = nN++;
-                hv.lp[slot_of[r]] = topv[r];
-            } else {
-                slot_of[r] = slot_of[dupof[r]];
-                const float a = hv.lp[slot_of[r]], c = topv[r];
-                const float mx = fmaxf(a, c);
-                hv.lp[slot_of[r]] = (isinf(mx) && mx < 0) ? mx : mx + log1pf(expf(-fabsf(a - c)));
+#pragma unroll
+        for (int r = 0; r < kMaxBeam; r++) {
+            if (r < want) {
+                // the earliest earlier entry with the same sequence that was not merged away itself, or none
+                const unsigned cand = eqm[r] & ~merged;
+                const int found = cand ? __ffs(cand) - 1 : -1;
+                int sl = nN;
+                if (found >= 0) {
+                    merged |= 1u << r;
+#pragma unroll
+                    for (int q = 0; q < r; q++)
+                        if (q == found) sl = slot_of[q];
+                }
+                slot_of[r] = sl;
+                // slot assignment in insertion order; merged scores accumulate in candidate order (logaddexp)
+                float cur = -INFINITY;
+#pragma unroll
+                for (int q = 0; q < kMaxBeam; q++)
+                    if (q == sl) cur = lpn[q];
+                float nv = tv[r];
+                if (found >= 0) {
+                    const float mx = fmaxf(cur, tv[r]);
+                    nv = (isinf(mx) && mx < 0) ? mx : mx + log1pf(expf(-fabsf(cur - tv[r])));
+                } else {
+                    nN++;
+                }
+#pragma unroll
+                for (int q = 0; q < kMaxBeam; q++)
+                    if (q == sl) lpn[q] = nv;
+                taken[r] = found < 0 ? sl : -1;  // reuse: destination slot of a fresh hypothesis
             }
-            taken[r] = dupof[r] < 0 ? slot_of[r] : -1;  // reuse: destination slot of a fresh hypothesis
         }
+#pragma unroll
+        for (int q = 0; q < kMaxBeam; q++)
+            if (q < nN) hv.lp[q] = lpn[q];
         for (int k = nN; k < K; k++) {
             hv.lp[k] = -INFINITY;
             // empty slots still go through the batched decoder launch: give them a valid context
