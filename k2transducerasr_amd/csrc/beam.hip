@@ -193,16 +193,21 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
     }
     __syncthreads();
     if (wave == 0) {  // merge the nA x want candidates: lane = k * kMaxBeam + r
+        // Each candidate's RANK among all of them (how many beat it: higher score, then lower flat index -- a total order, flat
+        // indexes are unique): every candidate is broadcast in turn with v_readlane and compared by all lanes at once, no dependent
+        // rounds (`want` rounds of a wave-wide best, each waiting for the one before, were 2 us of the step).
         const bool has = (lane / kMaxBeam) < nA && (lane % kMaxBeam) < want;
-        float myv = has ? candv[lane] : -INFINITY;
-        int myi = has ? candi[lane] : -1;
-        for (int r = 0; r < want; r++) {
-            float bv = myv;
-            int bi = myi;
-            wave_best(bv, bi);
-            if (lane == 0) { topv[r] = bv; topi[r] = bi; taken[r] = bi; }
-            if (myi == bi) myi = -1;  // that candidate is used up (flat indexes are unique)
-        }
+        const float myv = has ? candv[lane] : -INFINITY;
+        const int myi = has ? candi[lane] : -1;
+        int rank = 0;
+        for (int k = 0; k < nA; k++)
+            for (int r = 0; r < want; r++) {
+                const int src = k * kMaxBeam + r;   // (uniform)
+                const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), src));
+                const int oi = __builtin_amdgcn_readlane(myi, src);
+                if (oi >= 0 && (ov > myv || (ov == myv && oi < myi))) rank++;
+            }
+        if (myi >= 0 && rank < want) { topv[rank] = myv; topi[rank] = myi; taken[rank] = myi; }
     }
     __syncthreads();
     // ---- expand + merge (HypothesisList.add) into the other buffer
