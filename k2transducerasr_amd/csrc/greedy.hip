@@ -900,10 +900,10 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     if (tunables().greedy_parts > 0) parts = std::max(1, std::min({tunables().greedy_parts, kMaxParts, budget / bc}));  // tuning only
     if (parts < 2 || tunables().greedy_one_part) parts = 1;
     a.parts = parts;
-    const size_t gran_words = (size_t)a.B * 2 * parts * GF * 2;
-    a.gran = parts > 1 ? ctx.arena->take<unsigned long long>((int64_t)gran_words) : nullptr;
-    const size_t gran2_words = (size_t)a.B * 2 * w.J;
-    a.gran2 = parts > 1 ? ctx.arena->take<unsigned long long>((int64_t)gran2_words) : nullptr;
+    // (one block, one memset: the two exchange areas were two fills of ~5 us each in front of the search)
+    const size_t gran_words = (size_t)a.B * 2 * parts * GF * 2, gran2_words = (size_t)a.B * 2 * w.J;
+    a.gran = parts > 1 ? ctx.arena->take<unsigned long long>((int64_t)(gran_words + gran2_words)) : nullptr;
+    a.gran2 = parts > 1 ? a.gran + gran_words : nullptr;
     if (ctx.dry) return;
     K2_REQUIRE(w.J % 8 == 0, "greedy: joiner_dim %d must be a multiple of 8", w.J);
     K2_REQUIRE(w.DD % 4 == 0 && 8 * w.DD <= w.J * GF, "greedy: decoder_dim %d too wide for the LDS scratch", w.DD);
@@ -913,8 +913,7 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     static LdsAttrOnce lds_attr;
     lds_attr.ensure(k_greedy, 150 * 1024);
     if (parts > 1) {
-        K2_HIP(hipMemsetAsync(a.gran, 0, sizeof(unsigned long long) * gran_words, ctx.stream));
-        K2_HIP(hipMemsetAsync(a.gran2, 0, sizeof(unsigned long long) * gran2_words, ctx.stream));
+        K2_HIP(hipMemsetAsync(a.gran, 0, sizeof(unsigned long long) * (gran_words + gran2_words), ctx.stream));
     }
     hipLaunchKernelGGL(k_greedy, dim3(a.B * parts), dim3(GT), lds, ctx.stream, w, a);
     K2_HIP(hipGetLastError());
