@@ -415,6 +415,42 @@ __global__ __launch_bounds__(GT) void k_beam_loop(DecJoinW w, BeamLoopArgs a) {
             for (int q = 0; q < GF; q++) actT[k * GF + q] = (q < 4 * NH && q < nA) ? tanhf(e + d[q < 4 * NH ? q : 0]) : 0.f;
         }
         __syncthreads();
+        if (NH == 1 && ncg <= 128) {
+            // beam <= 4 and V <= 512: both 256-column chunks in ONE pass -- the 4 live rows leave half of the accumulators and of the
+            // exchange area free, so the second chunk rides along: one LDS exchange and one pair of barriers per frame instead of two
+            f32x4 c[2][4];
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) c[hh][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* wrow = w.out_kn + (long long)(wave * kper) * w.Vp;
+            mfma_sweep_rows_2c(wrow + 4 * min(lane, ncg - 1), wrow + 4 * min(64 + lane, ncg - 1), w.Vp, actT + (wave * kper) * GF + (lane & 3), kper, c);
+            // psum[slice][row 0..3][512 columns]
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    *reinterpret_cast<float4*>(psum + ((wave * 4) + i) * 512 + 256 * ch + 4 * lane) = make_float4(c[ch][0][i], c[ch][1][i], c[ch][2][i], c[ch][3][i]);
+            __syncthreads();
+            {
+                const int q = wave & 3, ch = wave >> 2, cg = 64 * ch + lane;   // wave: hypothesis q's chunk ch
+                if (cg < ncg && q < nA) {
+                    float4 ps[8];
+#pragma unroll
+                    for (int sl = 0; sl < 8; sl++) ps[sl] = *reinterpret_cast<const float4*>(psum + ((sl * 4) + q) * 512 + 256 * ch + 4 * lane);
+                    float sj[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float p0 = (&ps[0].x)[j], p1 = (&ps[1].x)[j], p2 = (&ps[2].x)[j], p3 = (&ps[3].x)[j];
+                        const float p4 = (&ps[4].x)[j], p5 = (&ps[5].x)[j], p6 = (&ps[6].x)[j], p7 = (&ps[7].x)[j];
+                        const int col = 4 * cg + j;
+                        sj[j] = (((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7))) + (col < w.V ? w.out_b[col] : 0.f);
+                    }
+                    *reinterpret_cast<float4*>(lg + q * w.Vp + 4 * cg) = make_float4(sj[0], sj[1], sj[2], sj[3]);
+                }
+            }
+            __syncthreads();
+        } else
         for (int cgb = 0; cgb < ncg; cgb += 64) {
             const int cg = cgb + lane;
             f32x4 c[2][4];

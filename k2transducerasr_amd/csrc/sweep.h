@@ -68,6 +68,49 @@ __device__ __forceinline__ void mfma_sweep_rows(const float* __restrict__ wp, lo
     for (int i = 0; i < GL; i++)
         if (kb + i < nrows) row(kb + i, i, false);   // (uniform)
 }
+// Two 256-column chunks at once for at most 4 live rows (the beam search at beam <= 4): c[ch][q] = chunk ch, column quad q, rows 0..3.
+// The same fma chains as two calls of mfma_sweep_rows<1>; one ring of 2 x GL weight rows, one activation read per row.
+__device__ __forceinline__ void mfma_sweep_rows_2c(const float* __restrict__ wp0, const float* __restrict__ wp1, long long ldw, const float* al,
+                                                   int nrows, f32x4 (&c)[2][4]) {
+    if (nrows <= 0) return;
+    float4 wa[GL], wb[GL];
+#pragma unroll
+    for (int i = 0; i < GL; i++) {
+        wa[i] = *reinterpret_cast<const float4*>(wp0 + (long long)min(i, nrows - 1) * ldw);
+        wb[i] = *reinterpret_cast<const float4*>(wp1 + (long long)min(i, nrows - 1) * ldw);
+    }
+    float anext = al[0];
+    auto row = [&](int k, int i, bool reload) {
+        const float alo = anext;
+        anext = al[min(k + 1, nrows - 1) * GF];
+        const float4 ka = wa[i], kb4 = wb[i];
+        if (reload) {
+            wa[i] = *reinterpret_cast<const float4*>(wp0 + (long long)min(k + GL, nrows - 1) * ldw);
+            wb[i] = *reinterpret_cast<const float4*>(wp1 + (long long)min(k + GL, nrows - 1) * ldw);
+        }
+        c[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(alo, ka.x, c[0][0], 0, 0, 0);
+        c[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(alo, ka.y, c[0][1], 0, 0, 0);
+        c[0][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(alo, ka.z, c[0][2], 0, 0, 0);
+        c[0][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(alo, ka.w, c[0][3], 0, 0, 0);
+        c[1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(alo, kb4.x, c[1][0], 0, 0, 0);
+        c[1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(alo, kb4.y, c[1][1], 0, 0, 0);
+        c[1][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(alo, kb4.z, c[1][2], 0, 0, 0);
+        c[1][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(alo, kb4.w, c[1][3], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int kb = 0;
+    for (; kb + 2 * GL <= nrows; kb += GL) {
+#pragma unroll
+        for (int i = 0; i < GL; i++) row(kb + i, i, true);
+    }
+    for (; kb + GL <= nrows; kb += GL) {
+#pragma unroll
+        for (int i = 0; i < GL; i++) row(kb + i, i, kb + GL + i < nrows);
+    }
+#pragma unroll
+    for (int i = 0; i < GL; i++)
+        if (kb + i < nrows) row(kb + i, i, false);   // (uniform)
+}
 // the k slices' partial sums of one pass go through LDS: psum[slice][frame][256 columns]
 template <int NH = 2>
 __device__ __forceinline__ void psum_store(float* psum, int wave, int lane, const f32x4 (&c)[2][4]) {
