@@ -292,6 +292,131 @@ __global__ __launch_bounds__(512) void k_conformer_scores_softmax(const float* _
     }
 }
 
+// The same computation on 16-row strips and 16 x 16 x 4 tiles: 4 waves, a strip of 16 x T scores (48 KB at T = 750), so THREE
+// workgroups share a CU and one strip's softmax and write-out run under the others' MFMAs (the 32-row form holds 97 KB: one workgroup
+// per CU, its matrix pipe ~55 % busy in the tile loop and idle in the softmax).  Same MFMA work per row; the positional band of a
+// 16-key tile is two 16-wide table tiles, G[r, col] belongs to key j0 + col - 15 + r.  NG = dk / 16.
+typedef float cf32x4 __attribute__((ext_vector_type(4)));
+template <int NG, int NW>   // NW waves per strip
+__global__ __launch_bounds__(64 * NW) void k_conformer_scores_softmax16(const float* __restrict__ qu, const float* __restrict__ qv,
+                                                                    const float* __restrict__ kmat, int ldk, const float* __restrict__ pp,
+                                                                    float* __restrict__ aw, int B, int H, int T, int Tp, int D,
+                                                                    int lds_stride) {
+    constexpr int DK = 16 * NG;
+    extern __shared__ __attribute__((aligned(16))) float csm[];
+    float* S = csm;                                   // [16][lds_stride]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int i0 = blockIdx.x * 16, b = blockIdx.y, h = blockIdx.z, NP = 2 * T - 1;
+    const long long rowbase = (long long)b * T;
+    // A operands: this lane's query row (strip row li), k chunks 16g + 4kq .. +3 (MFMA (g, c) takes component c of both operands: every
+    // k of the head's dk is multiplied exactly once)
+    float4 fu[NG], fv[NG];
+    {
+        const int row = i0 + li;
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            fu[g] = fv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < T) {
+                fu[g] = *reinterpret_cast<const float4*>(qu + (rowbase + row) * D + h * DK + 16 * g + 4 * kq);
+                fv[g] = *reinterpret_cast<const float4*>(qv + (rowbase + row) * D + h * DK + 16 * g + 4 * kq);
+            }
+        }
+    }
+    const int njt = (T + 15) / 16;
+    float4 fk[NG], ph[NG];
+    auto load_k = [&](int jt, float4* k_) {
+        const int jr = min(jt * 16 + li, T - 1);
+#pragma unroll
+        for (int g = 0; g < NG; g++) k_[g] = *reinterpret_cast<const float4*>(kmat + (rowbase + jr) * ldk + h * DK + 16 * g + 4 * kq);
+    };
+    auto load_p = [&](int nrow, float4* p_) {   // table row nrow (out-of-table rows only meet masked entries)
+        const int nr = min(max(nrow, 0), NP - 1);
+#pragma unroll
+        for (int g = 0; g < NG; g++) p_[g] = *reinterpret_cast<const float4*>(pp + (long long)nr * D + h * DK + 16 * g + 4 * kq);
+    };
+    auto mma = [](const float4& a, const float4& bq, cf32x4 acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc, 0, 0, 0);
+        return acc;
+    };
+    // a wave takes a RUN of consecutive key tiles: the high positional tile of key tile jt is the low one of jt + 1
+    const int tpw = (njt + NW - 1) / NW, jt_beg = wave * tpw, jt_end = min(njt, jt_beg + tpw);
+    if (jt_beg < jt_end) {
+        cf32x4 acc, glo = {0.f, 0.f, 0.f, 0.f}, ghi;
+        const int base0 = T - 1 - i0 - 15 + jt_beg * 16;
+        load_p(base0 + li, ph);
+        load_k(jt_beg, fk);
+#pragma unroll
+        for (int g = 0; g < NG; g++) glo = mma(fv[g], ph[g], glo);   // the run's first low positional tile
+        load_p(base0 + 16 + li, ph);
+        for (int jt = jt_beg; jt < jt_end; jt++) {
+            const int j0 = jt * 16, j = j0 + li;
+            acc = cf32x4{0.f, 0.f, 0.f, 0.f};
+            ghi = cf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < NG; g++) {   // content term, and the positional term against the high run of table rows
+                acc = mma(fu[g], fk[g], acc);
+                ghi = mma(fv[g], ph[g], ghi);
+            }
+            if (jt + 1 < jt_end) {   // (wave-uniform) the next tile's keys and high run, into the registers just consumed
+                load_k(jt + 1, fk);
+                load_p(base0 + (jt + 1 - jt_beg) * 16 + 16 + li, ph);
+            }
+            // C layout of 16x16: col = lane & 15, row = 4 * (lane >> 4) + e.  The tile's 16 strip columns belong to this wave alone; LDS
+            // operations of one wave complete in order.
+            if (j < T) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) S[(4 * kq + e) * lds_stride + j] = acc[e];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int rl = 4 * kq + e;
+                const int c0 = li - 15 + rl, c1 = li + 1 + rl;   // strip column (within the tile) fed by G[rl][li] / G[rl][16 + li]
+                if (c0 >= 0 && j0 + c0 < T) S[rl * lds_stride + j0 + c0] += glo[e];
+                if (c1 < 16 && j0 + c1 < T) S[rl * lds_stride + j0 + c1] += ghi[e];
+            }
+            __builtin_amdgcn_wave_barrier();
+            glo = ghi;   // this tile's high run is the next tile's low run
+        }
+    }
+    __syncthreads();
+    // row softmax: wave w owns 16 / NW rows; a row's T scores are read ONCE into registers (T <= 64 * 20)
+    float* out = aw + (((long long)b * H + h) * T) * Tp;
+    for (int rr = 0; rr < 16 / NW; rr++) {
+        const int rl = wave * (16 / NW) + rr, i = i0 + rl;
+        if (i >= T) break;
+        const float* srow = S + rl * lds_stride;
+        float v[20];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 20; u++) {
+            const int jj = lane + 64 * u;
+            v[u] = jj < T ? srow[jj] : -INFINITY;
+            mx = fmaxf(mx, v[u]);
+        }
+        mx = wave_max_dpp(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 20; u++) {
+            v[u] = lane + 64 * u < T ? __expf(v[u] - mx) : 0.f;
+            sum += v[u];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.0f / sum;
+        float* orow = out + (long long)i * Tp;
+#pragma unroll
+        for (int u = 0; u < 20; u++) {
+            const int jj = lane + 64 * u;
+            if (jj < Tp) orow[jj] = v[u] * inv;   // pad columns [T, Tp) get 0
+        }
+    }
+}
+
 }  // namespace
 
 void conformer_softmax_shift_stream(const Ctx& ctx, float* ac, const float* bd, const long long* plen, int B, int H, int Tc, int left,
@@ -352,6 +477,20 @@ static bool conformer_scores_launch(const Ctx& ctx, const float* qu, const float
     return true;
 }
 
+template <int NG>
+static bool conformer_scores_launch16(const Ctx& ctx, const float* qu, const float* qv, const float* kmat, int ldk, const float* pp, float* aw,
+                                      int B, int H, int T, int Tp, int D) {
+    const int lds_stride = Tp + 4;
+    const size_t lds = sizeof(float) * (size_t)16 * lds_stride;
+    static LdsAttrOnce lds_attr;
+    // (eight waves per strip: 222 against 205 us per launch; four it is)
+    lds_attr.ensure((k_conformer_scores_softmax16<NG, 4>), 96 * 1024);
+    hipLaunchKernelGGL((k_conformer_scores_softmax16<NG, 4>), dim3(cdiv(T, 16), B, H), dim3(256), lds, ctx.stream, qu, qv, kmat, ldk, pp, aw, B, H, T,
+                       Tp, D, lds_stride);
+    K2_HIP(hipGetLastError());
+    return true;
+}
+
 // fused scores + softmax of the offline Conformer attention; returns false (nothing launched) when the shape does not fit
 bool conformer_scores_softmax(const Ctx& ctx, const float* qu, const float* qv, const float* kmat, int ldk, const float* pp, float* aw, int B, int H,
                               int T, int Tp, int D) {
@@ -360,6 +499,11 @@ bool conformer_scores_softmax(const Ctx& ctx, const float* qu, const float* qv, 
     if (sizeof(float) * (size_t)CR * (Tp + 4) > 156 * 1024 || Tp > 64 * 20) return false;
     ctx.add_flops(0.0, 2.0 * dk * (double)T * (3.0 * T) * B * H, 0);
     if (ctx.dry) return true;
+    if (!tunables().conformer_strip32) {   // 16-row strips: three workgroups per CU
+        if (dk == 64) return conformer_scores_launch16<4>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
+        if (dk == 32) return conformer_scores_launch16<2>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
+        if (dk == 16) return conformer_scores_launch16<1>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
+    }
     switch (dk) {
         case 64: return conformer_scores_launch<8>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
         case 32: return conformer_scores_launch<4>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);

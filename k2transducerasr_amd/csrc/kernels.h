@@ -16,6 +16,7 @@ struct Tunables {
     int gemm_v1 = 0;              // K2HIP_GEMM_V1: the earlier LDS-DMA kernels and tile rules (barrier at the top of every K step) instead of gemm_f32_mfma_pipe
     int attn_long = 0;            // K2HIP_ATTN_LONG: two-pass attention scores for every length
     int no_fused_av = 0;          // K2HIP_NO_FUSED_AV: attention apply + out_proj as two GEMMs
+    int conformer_strip32 = 0;      // K2HIP_CONFORMER_STRIP32: the fused Conformer scores kernel on 32-row strips (one workgroup per CU), the earlier form
     int conformer_gemm_scores = 0;  // K2HIP_CONFORMER_GEMM_SCORES: two batched GEMMs + gather/softmax
     int dw7_simple = 0;           // K2HIP_DW7_SIMPLE: untiled 7x7 depthwise convolution
     int dw1d_tt = 0;              // K2HIP_DW1D_TT: outputs per thread of the depthwise Conv1d (8 / 4 / 2; 0 = by grid size)
