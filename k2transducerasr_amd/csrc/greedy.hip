@@ -700,7 +700,17 @@ __global__ __launch_bounds__(GT) void k_rounds_step(DecJoinW w, RoundsState a, i
             const float* row = a.logits + (long long)(b * a.S + s) * a.ldl;
             float bv = -INFINITY;
             int bi = -1;
-            for (int j = lane; j < w.V; j += 64) amax_merge(bv, bi, row[j], j);
+            if ((a.ldl & 3) == 0) {   // 16-byte loads, 4 rows' worth of them independent (the merge is a total order: any sequence)
+                for (int j4 = 4 * lane; j4 < w.V; j4 += 256) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(row + j4);
+                    amax_merge(bv, bi, t4.x, j4);
+                    if (j4 + 1 < w.V) amax_merge(bv, bi, t4.y, j4 + 1);
+                    if (j4 + 2 < w.V) amax_merge(bv, bi, t4.z, j4 + 2);
+                    if (j4 + 3 < w.V) amax_merge(bv, bi, t4.w, j4 + 3);
+                }
+            } else {
+                for (int j = lane; j < w.V; j += 64) amax_merge(bv, bi, row[j], j);
+            }
             amax_wave(bv, bi);
             if (lane == 0) toks[s] = bi;
         }
