@@ -151,3 +151,31 @@ def test_three_batches_in_flight_with_the_beam_search(tiny_model_path):
     finally:
         for p in ptrs:
             m.device_free(p)
+
+@pytest.mark.parametrize("vocab", [600, 1029])
+def test_one_kernel_beam_search_beyond_512_columns(tmp_path_factory, utts, vocab):
+    """Vocabularies that still get the decoder table but need more than the two 256-column chunks the one-pass sweep covers
+    (V = 600: three passes at beam <= 4; V = 1029: an odd size, padded columns): one-kernel form against the oracle and the launch
+    form, greedy search of the same model against the oracle (its slabs then span several chunks too)."""
+    import k2transducerasr_amd as pkg
+    from k2transducerasr_amd import Model
+    from k2transducerasr_amd.synth import write_synthetic_model
+    from oracle import Oracle
+    from parity import assert_tokens_match
+    p = str(tmp_path_factory.mktemp(f"v{vocab}") / "m.k2w")
+    write_synthetic_model(p, "zipformer2-tiny-test", meta_overrides={"vocab_size": str(vocab)})
+    hip, ora = Model(p, 0), Oracle(p)
+    feats = [ora.fbank(u) for u in utts]
+    enc = ora.encoder(ora.pad_sequence(feats).reshape(len(utts), -1, 80))
+    for beam in (4, 8):
+        want, mg = ora.modified_beam_search(enc, beam, want_margins=True)
+        loop = hip.beam_search(enc, beam)
+        _check(loop, want, mg, f"V={vocab} beam={beam}")
+        pkg.set_switch("K2HIP_BEAM_LAUNCHES", 1)
+        try:
+            assert hip.beam_search(enc, beam) == loop
+        finally:
+            pkg.set_switch("K2HIP_BEAM_LAUNCHES", 0)
+    want = ora.recognize_batch(feats)
+    _, mg = ora.greedy_batch(enc, want_margins=True)
+    assert_tokens_match(hip.offline_greedy(feats), want, mg, what=f"V={vocab} greedy")
