@@ -357,20 +357,13 @@ __global__ __launch_bounds__(BT) void k_beam_step(BeamState s, const float* __re
 // matrix pipe (mfma_sweep_rows: 8 hypotheses x 256 columns per pass), the logits stay in LDS, and the step (log-softmax, top K,
 // expand, merge) is beam_step_body on hypotheses that live in LDS as well.  Replaces 4 launches per frame (1012 for the headline
 // batch, each waiting for slots between the next batch's encoder GEMMs) by one launch per batch.
-struct BeamLoopArgs {
-    const float* enc;   // [B, Tp, J]
-    int Tp, K, cap;
-    long long* tokens;
-    int* timestamps;
-    int* n_tokens;
-    float* scores;
-    int max_tokens;
-    int* overflow;
-    // long utterances: the hypotheses' token / timestamp arrays do not fit in LDS beside the logits and live in device memory,
-    // [B][2][K][cap] each (a workgroup reads back only what it wrote itself: one CU, one L1); null = in LDS
-    int* ys_g;
-    int* ts_g;
-};
+typedef __attribute__((address_space(1))) unsigned long long bgu64;
+__device__ __forceinline__ void bstore_granule(unsigned long long* g, unsigned epoch, unsigned value) {
+    __hip_atomic_store((bgu64*)g, ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long bload_granule(const unsigned long long* g) {
+    return __hip_atomic_load((bgu64*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // LDS (floats): actT[J GF] | psum | lg[GF][Vp] | ctx[2 GF] (long long) | lp[GF] | n[2][GF] | nhyp, pad | scratch | ys[2][K][cap] | ts[2][K][cap]
 __host__ __device__ inline size_t beam_loop_lds_floats(int J, int Vp, int K, int cap, bool hyp_in_lds) {
     return (size_t)J * GF + kPsumFloats + (size_t)GF * Vp + 4 * GF + GF + 2 * GF + 4 + kStepScratchInts + 4 + (hyp_in_lds ? 4 * (size_t)K * cap : 0);
@@ -388,7 +381,10 @@ __global__ __launch_bounds__(GT) void k_beam_loop(DecJoinW w, BeamLoopArgs a) {
     int* scratch = nhyp + 4;
     int* ys = a.ys_g ? a.ys_g + (size_t)blockIdx.x * 2 * a.K * a.cap : scratch + kStepScratchInts + 4;
     int* ts = a.ys_g ? a.ts_g + (size_t)blockIdx.x * 2 * a.K * a.cap : ys + 2 * a.K * a.cap;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, K = a.K;
+    __shared__ int xfail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, K = a.K;
+    if (tid == 0) xfail = 0;
+    const int b = a.xg ? blockIdx.x >> 1 : blockIdx.x, slab = a.xg ? blockIdx.x & 1 : 0;
     const float* enc = a.enc + (long long)b * a.Tp * w.J;
     if (tid < GF) {   // k_beam_init
         lp[tid] = tid == 0 ? 0.f : -INFINITY;
@@ -415,7 +411,52 @@ __global__ __launch_bounds__(GT) void k_beam_loop(DecJoinW w, BeamLoopArgs a) {
             for (int q = 0; q < GF; q++) actT[k * GF + q] = (q < 4 * NH && q < nA) ? tanhf(e + d[q < 4 * NH ? q : 0]) : 0.f;
         }
         __syncthreads();
-        if (NH == 1 && ncg <= 128) {
+        if (NH == 1 && a.xg) {
+            // two slabs: this workgroup's 256-column chunk, then the peer's logits through tagged granules
+            f32x4 c[2][4];
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) c[hh][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int cg = 64 * slab + lane;
+            mfma_sweep_rows<1>(w.out_kn + (long long)(wave * kper) * w.Vp + 4 * min(cg, ncg - 1), w.Vp, actT + (wave * kper) * GF + (lane & 3), kper, c);
+            psum_store<1>(psum, wave, lane, c);
+            __syncthreads();
+            unsigned long long* xo = a.xg + ((((long long)b * 2 + (t & 1)) * 2 + slab) * 4) * 256;
+            const unsigned long long* xi = a.xg + ((((long long)b * 2 + (t & 1)) * 2 + (slab ^ 1)) * 4) * 256;
+            if (wave < 4) {   // wave q: hypothesis q's 256 logits of this slab (computed for every slot: the peer must not wait on nA)
+                float4 ps[8];
+#pragma unroll
+                for (int sl = 0; sl < 8; sl++) ps[sl] = *reinterpret_cast<const float4*>(psum + (sl * GF + wave) * 256 + 4 * lane);
+                float sj[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float p0 = (&ps[0].x)[j], p1 = (&ps[1].x)[j], p2 = (&ps[2].x)[j], p3 = (&ps[3].x)[j];
+                    const float p4 = (&ps[4].x)[j], p5 = (&ps[5].x)[j], p6 = (&ps[6].x)[j], p7 = (&ps[7].x)[j];
+                    const int col = 4 * min(cg, ncg - 1) + j;
+                    sj[j] = (((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7))) + (col < w.V ? w.out_b[col] : 0.f);
+                }
+                if (cg < ncg) *reinterpret_cast<float4*>(lg + wave * w.Vp + 4 * cg) = make_float4(sj[0], sj[1], sj[2], sj[3]);
+#pragma unroll
+                for (int j = 0; j < 4; j++) bstore_granule(xo + wave * 256 + 4 * lane + j, (unsigned)(t + 1), __float_as_uint(sj[j]));
+            }
+            // every thread collects 2 of the peer's 1024 granules
+            for (int e = tid; e < 4 * 256; e += GT) {
+                unsigned long long x = bload_granule(xi + e);
+                for (unsigned spins = 0; (unsigned)(x >> 32) != (unsigned)(t + 1) && spins < (1u << 22); spins++) {
+                    __builtin_amdgcn_s_sleep(1);
+                    x = bload_granule(xi + e);
+                }
+                if ((unsigned)(x >> 32) != (unsigned)(t + 1)) xfail = 1;
+                const int q = e >> 8, col = 256 * (slab ^ 1) + (e & 255);
+                if (col < w.Vp) lg[q * w.Vp + col] = __uint_as_float((unsigned)x);
+            }
+            __syncthreads();
+            if (xfail) {
+                if (tid == 0) *a.overflow = 2;
+                return;
+            }
+        } else if (NH == 1 && ncg <= 128) {
             // beam <= 4 and V <= 512: both 256-column chunks in ONE pass -- the 4 live rows leave half of the accumulators and of the
             // exchange area free, so the second chunk rides along: one LDS exchange and one pair of barriers per frame instead of two
             f32x4 c[2][4];
@@ -501,6 +542,7 @@ __global__ __launch_bounds__(GT) void k_beam_loop(DecJoinW w, BeamLoopArgs a) {
     }
     const int* ysf = ys + ((size_t)fin * K + best) * a.cap;
     const int* tsf = ts + ((size_t)fin * K + best) * a.cap;
+    if (slab != 0) return;
     for (int i = tid; i < n; i += GT) {
         a.tokens[(long long)b * a.max_tokens + i] = ysf[i];
         a.timestamps[(long long)b * a.max_tokens + i] = tsf[i];
@@ -553,25 +595,45 @@ void beam_search(const Ctx& ctx, const DecJoinW& w, const BeamArgs& a) {
         const bool hyp_in_lds = sizeof(float) * beam_loop_lds_floats(w.J, w.Vp, K, cap, true) <= 150 * 1024 && !tunables().beam_hyp_global;
         const size_t lds = sizeof(float) * beam_loop_lds_floats(w.J, w.Vp, K, cap, hyp_in_lds);
         if (w.dec_table && !tunables().beam_launches && lds <= 150 * 1024 && w.J % 8 == 0 && w.Vp % 4 == 0 && K <= GF) {
-            int* ys_g = hyp_in_lds ? nullptr : ar.take<int>((int64_t)2 * M * cap);
-            int* ts_g = hyp_in_lds ? nullptr : ar.take<int>((int64_t)2 * M * cap);
+            // Two column slabs per stream where one workgroup would sweep two chunks (beam <= 4, 256 < V <= 512) and 2 B workgroups fit
+            // the offline co-residency budget: the frame's sweep is bound by ONE CU's fetch of the 1 MB matrix, two CUs halve it, and the
+            // exchange of the 4 x 256 logits costs less than the half sweep (search alone 5.5 -> 4.45 ms for the headline batch).  The
+            // slabs wait for each other (bounded; *overflow = 2 on a timeout): the launch is kept for a repeat with one slab.
+            const bool two = tunables().beam_parts != 1 && K <= 4 && (w.Vp >> 2) <= 128 && (w.Vp >> 2) > 64 && 2 * B <= std::max(device_cu_count() / 4, 2);
+            unsigned long long* xg = two ? ar.take<unsigned long long>((int64_t)B * 2 * 2 * 4 * 256) : nullptr;
+            // (hypotheses in device memory: every workgroup keeps its own copy, so two slabs need twice the space)
+            int* ys_g = hyp_in_lds ? nullptr : ar.take<int>((int64_t)(two ? 2 : 1) * 2 * M * cap);
+            int* ts_g = hyp_in_lds ? nullptr : ar.take<int>((int64_t)(two ? 2 : 1) * 2 * M * cap);
             if (ctx.dry) return;
             BeamLoopArgs la;
             la.enc = a.enc; la.Tp = a.Tp; la.K = K; la.cap = cap;
             la.tokens = a.tokens; la.timestamps = a.timestamps; la.n_tokens = a.n_tokens; la.scores = a.scores;
             la.max_tokens = a.max_tokens; la.overflow = a.overflow;
             la.ys_g = ys_g; la.ts_g = ts_g;
+            la.xg = xg;
             K2_HIP(hipMemsetAsync(a.overflow, 0, sizeof(int), ctx.stream));
             static LdsAttrOnce lds_attr;
             static LdsAttrOnce lds_attr1;
             lds_attr.ensure(k_beam_loop<2>, 150 * 1024);
             lds_attr1.ensure(k_beam_loop<1>, 150 * 1024);
-            if (K <= 4) hipLaunchKernelGGL(k_beam_loop<1>, dim3(B), dim3(GT), lds, ctx.stream, w, la);
+            if (two) K2_HIP(hipMemsetAsync(xg, 0, sizeof(unsigned long long) * (size_t)B * 2 * 2 * 4 * 256, ctx.stream));
+            if (K <= 4) hipLaunchKernelGGL(k_beam_loop<1>, dim3(two ? 2 * B : B), dim3(GT), lds, ctx.stream, w, la);
             else hipLaunchKernelGGL(k_beam_loop<2>, dim3(B), dim3(GT), lds, ctx.stream, w, la);
             K2_HIP(hipGetLastError());
+            if (ctx.greedy_rec) {
+                ctx.greedy_rec->valid = two;
+                ctx.greedy_rec->beam = true;
+                ctx.greedy_rec->w = w;
+                ctx.greedy_rec->a.B = B;
+                ctx.greedy_rec->a.overflow = a.overflow;
+                ctx.greedy_rec->ba = la;
+                ctx.greedy_rec->beam_lds = lds;
+            }
+            if (two && tunables().test_greedy_timeout) K2_HIP(hipMemsetD32Async((hipDeviceptr_t)a.overflow, 2, 1, ctx.stream));
             return;
         }
     }
+    if (ctx.greedy_rec) ctx.greedy_rec->valid = false;
     BeamState s;
     s.K = K;
     s.cap = cap;
@@ -615,6 +677,15 @@ void beam_search(const Ctx& ctx, const DecJoinW& w, const BeamArgs& a) {
                            a.max_tokens, a.overflow);
         K2_HIP(hipGetLastError());
     }
+}
+
+void beam_relaunch_one_slab(hipStream_t stream, const GreedyLaunch& rec) {
+    K2_REQUIRE(rec.valid && rec.beam, "beam retry: no repeatable launch on record");
+    BeamLoopArgs la = rec.ba;
+    la.xg = nullptr;
+    K2_HIP(hipMemsetAsync(la.overflow, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(k_beam_loop<1>, dim3(rec.a.B), dim3(GT), rec.beam_lds, stream, rec.w, la);
+    K2_HIP(hipGetLastError());
 }
 
 }  // namespace k2hip

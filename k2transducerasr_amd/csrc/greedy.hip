@@ -929,6 +929,7 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     K2_HIP(hipGetLastError());
     if (ctx.greedy_rec) {
         ctx.greedy_rec->valid = parts > 1;
+        ctx.greedy_rec->beam = false;
         ctx.greedy_rec->w = w;
         ctx.greedy_rec->a = a;
     }
@@ -936,6 +937,10 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
 }
 
 void greedy_relaunch_one_part(hipStream_t stream, const GreedyLaunch& rec) {
+    if (rec.beam) {   // the one-kernel beam search with two slabs per stream: once more with one
+        beam_relaunch_one_slab(stream, rec);
+        return;
+    }
     K2_REQUIRE(rec.valid, "greedy retry: no repeatable launch on record");
     GreedyArgs a = rec.a;
     a.parts = 1;

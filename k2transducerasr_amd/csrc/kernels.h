@@ -26,6 +26,7 @@ struct Tunables {
     int greedy_one_part = 0;      // K2HIP_GREEDY_ONE_PART: one workgroup per stream in the search
     int greedy_parts = 0;         // K2HIP_GREEDY_PARTS: vocabulary slabs per stream (0 = automatic)
     int beam_launches = 0;        // K2HIP_BEAM_LAUNCHES: the modified beam search as 4 launches per frame even when the one-kernel form applies
+    int beam_parts = 0;           // K2HIP_BEAM_PARTS: 1 = one workgroup per stream in the one-kernel beam search even where two column slabs apply
     int beam_hyp_global = 0;      // K2HIP_BEAM_HYP_GLOBAL: the one-kernel beam search keeps its hypotheses in device memory even when they fit in LDS (the long-utterance form, for its test)
     int decoder_table_mb = 1024;  // K2HIP_DECODER_TABLE_MB: build the all-contexts decoder table when it fits this many MiB (0 = never)
     int test_greedy_timeout = 0;  // K2HIP_TEST_GREEDY_TIMEOUT: test hook -- every parts > 1 search reports an exchange timeout, so the one-part retry runs
@@ -337,11 +338,33 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a);
 // workgroups must be resident together for that, which a GPU shared with other processes or models does not promise.  The engine
 // therefore keeps the launch (inputs are read-only, outputs are rewritten from scratch) and, on a timeout, runs it again with ONE
 // workgroup per stream -- no inter-workgroup wait, same tokens -- instead of failing the call.
-struct GreedyLaunch {
-    bool valid = false;  // a parts > 1 launch that can be repeated
-    DecJoinW w;
-    GreedyArgs a;
+// arguments of the one-kernel modified beam search (beam.hip k_beam_loop); here because a repeatable launch is kept in GreedyLaunch
+struct BeamLoopArgs {
+    const float* enc;   // [B, Tp, J]
+    int Tp, K, cap;
+    long long* tokens;
+    int* timestamps;
+    int* n_tokens;
+    float* scores;
+    int max_tokens;
+    int* overflow;
+    // long utterances: the hypotheses' token / timestamp arrays do not fit in LDS beside the logits and live in device memory,
+    // [B][2][K][cap] each (a workgroup reads back only what it wrote itself: one CU, one L1); null = in LDS
+    int* ys_g;
+    int* ts_g;
+    // two column slabs per stream (beam <= 4, 256 < V <= 512): workgroup 2 b + p sweeps chunk p and the two exchange their 4 x 256
+    // logits per frame as tagged granules xg[b][frame parity][slab][4][256]; null = one workgroup per stream
+    unsigned long long* xg;
 };
+struct GreedyLaunch {
+    bool valid = false;  // a launch with inter-workgroup waits (parts > 1 / two beam slabs) that can be repeated without them
+    DecJoinW w;
+    GreedyArgs a;        // (beam: only B and overflow are meaningful)
+    bool beam = false;   // the launch was k_beam_loop with two slabs per stream: ba, beam_lds
+    BeamLoopArgs ba;
+    size_t beam_lds = 0;
+};
+void beam_relaunch_one_slab(hipStream_t stream, const GreedyLaunch& rec);
 void greedy_relaunch_one_part(hipStream_t stream, const GreedyLaunch& rec);
 // The same search as batched ROUNDS instead of one persistent workgroup pair per stream: every round evaluates the next S frames
 // of every stream under the stream's current context with ONE joiner GEMM over all B x S rows, then a per-stream step accepts

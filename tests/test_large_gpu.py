@@ -304,3 +304,50 @@ def test_search_exchange_timeout_is_retried_with_one_part(hip_large):
         assert hip_large.offline_greedy_from_samples_dev(ptr, s.shape[1], B) == want and retries() == r0 + 3
     finally:
         hip_large.device_free(ptr)
+
+def test_beam_search_two_slabs_one_slab_and_the_retry(large_path):
+    """The one-kernel beam search runs two column slabs per stream on this vocabulary (V = 500: 2 x 256 columns) -- two workgroups that
+    wait for each other's logits every frame.  K2HIP_BEAM_PARTS=1 keeps one workgroup per stream: identical results, scores bit for bit
+    (the same sums in the same order).  And as for the greedy search a timeout of the exchange is not an error: the engine repeats the
+    search with one slab (K2HIP_TEST_GREEDY_TIMEOUT reports one for every two-slab launch), synchronous and pipelined."""
+    import ctypes as C
+    from k2transducerasr_amd import Model, load_library, set_switch
+    from k2transducerasr_amd.synth import synth_utterance
+    L = load_library()
+    L.k2hip_debug_search_retries.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    m = Model(large_path, 0)
+    m.set_decoding_method("modified_beam_search", 4)
+
+    def retries():
+        n = C.c_int32(-1)
+        assert L.k2hip_debug_search_retries(m.handle, C.byref(n)) == 0
+        return n.value
+
+    B = 6
+    s = np.stack([synth_utterance(700 + u, 4.0) for u in range(B)])
+    ptr = m.device_alloc(s.nbytes)
+    try:
+        m.device_upload(ptr, s)
+        want = m.offline_greedy_from_samples_dev(ptr, s.shape[1], B)
+        wsc = m.last_scores(B).copy()
+        assert sum(len(t) for t, _ in want) > 0
+        set_switch("K2HIP_BEAM_PARTS", 1)
+        try:
+            assert m.offline_greedy_from_samples_dev(ptr, s.shape[1], B) == want
+            assert np.array_equal(m.last_scores(B), wsc)
+        finally:
+            set_switch("K2HIP_BEAM_PARTS", 0)
+        r0 = retries()
+        set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 1)
+        try:
+            got = m.offline_greedy_from_samples_dev(ptr, s.shape[1], B)
+            assert retries() == r0 + 1
+            ta = m.offline_submit_samples_dev(ptr, s.shape[1], B)
+            tb = m.offline_submit_samples_dev(ptr, s.shape[1], B)
+            ga, gb = m.offline_wait(ta), m.offline_wait(tb)
+            assert retries() == r0 + 3
+        finally:
+            set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 0)
+        assert got == want and ga == want and gb == want
+    finally:
+        m.device_free(ptr)
