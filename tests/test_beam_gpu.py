@@ -152,10 +152,10 @@ def test_three_batches_in_flight_with_the_beam_search(tiny_model_path):
         for p in ptrs:
             m.device_free(p)
 
-@pytest.mark.parametrize("vocab", [600, 1029])
-def test_one_kernel_beam_search_beyond_512_columns(tmp_path_factory, utts, vocab):
-    """Vocabularies that still get the decoder table but need more than the two 256-column chunks the one-pass sweep covers
-    (V = 600: three passes at beam <= 4; V = 1029: an odd size, padded columns): one-kernel form against the oracle and the launch
+@pytest.mark.parametrize("vocab", [400, 600, 1029])
+def test_one_kernel_beam_search_beyond_256_columns(tmp_path_factory, utts, vocab):
+    """Vocabularies that still get the decoder table and span more than one 256-column chunk (V = 400: two column slabs per stream
+    at beam <= 4, exchanging their logits every frame; V = 600: three passes; V = 1029: an odd size, padded columns): one-kernel form against the oracle and the launch
     form, greedy search of the same model against the oracle (its slabs then span several chunks too)."""
     import k2transducerasr_amd as pkg
     from k2transducerasr_amd import Model
