@@ -907,7 +907,7 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     // one part per stream (greedy_relaunch_one_part).
     const int budget = a.init_ctx ? device_cu_count() : std::max(device_cu_count() / 4, 1);
     int parts = std::min({(ncg + pass - 1) / pass, kMaxParts, budget / bc});
-    if (tunables().greedy_parts > 0) parts = std::max(1, std::min({tunables().greedy_parts, kMaxParts, device_cu_count() / bc}));  // tuning only (may exceed the budget)
+    if (tunables().greedy_parts > 0) parts = std::max(1, std::min({tunables().greedy_parts, kMaxParts, budget / bc}));  // tuning only
     if (parts < 2 || tunables().greedy_one_part) parts = 1;
     a.parts = parts;
     // (one block, one memset: the two exchange areas were two fills of ~5 us each in front of the search)
