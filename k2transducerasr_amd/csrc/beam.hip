@@ -357,6 +357,10 @@ __global__ __launch_bounds__(BT) void k_beam_step(BeamState s, const float* __re
 // matrix pipe (mfma_sweep_rows: 8 hypotheses x 256 columns per pass), the logits stay in LDS, and the step (log-softmax, top K,
 // expand, merge) is beam_step_body on hypotheses that live in LDS as well.  Replaces 4 launches per frame (1012 for the headline
 // batch, each waiting for slots between the next batch's encoder GEMMs) by one launch per batch.
+// Forms of the sweep: beam <= 4 uses the lower 4 x 4 half of each MFMA; with V <= 512 both 256-column chunks go through one pass
+// (mfma_sweep_rows_2c), or -- when 2 B workgroups fit the co-residency budget -- each chunk gets a workgroup of its own and the two
+// exchange their 4 x 256 logits per frame as tagged granules (BeamLoopArgs::xg; bounded waits, *overflow = 2 on a timeout and a repeat
+// with one workgroup per stream, as for k_greedy's parts).
 typedef __attribute__((address_space(1))) unsigned long long bgu64;
 __device__ __forceinline__ void bstore_granule(unsigned long long* g, unsigned epoch, unsigned value) {
     __hip_atomic_store((bgu64*)g, ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
