@@ -348,6 +348,18 @@ class Model:
         res = self._unpack(tok, ts, n)
         return (res, sc) if want_scores else res
 
+    def beam_trace(self):
+        """k2hip_debug_beam_trace (include/k2hip_debug.h): the per-frame selection of the last synchronous modified beam search made
+        with the switch K2HIP_BEAM_TRACE on -> dict(idx [B,T',beam] flat candidate indexes (slot * V + token) in rank order,
+        val [B,T',beam] their scores, n [B,T'] hypotheses surviving the frame, beam)"""
+        B, Tp, K = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._L.k2hip_debug_beam_trace.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int64] + [C.POINTER(C.c_int32)] * 3
+        self._chk(self._L.k2hip_debug_beam_trace(self._h, None, 0, C.byref(B), C.byref(Tp), C.byref(K)))
+        tr = np.zeros((B.value, Tp.value, 2 * K.value + 1), np.int32)
+        self._chk(self._L.k2hip_debug_beam_trace(self._h, _i(tr), tr.size, C.byref(B), C.byref(Tp), C.byref(K)))
+        k = K.value
+        return dict(idx=tr[:, :, :k].copy(), val=tr[:, :, k: 2 * k].copy().view(np.float32), n=tr[:, :, 2 * k].copy(), beam=k)
+
     def set_decoding_method(self, method: str = "greedy_search", beam: int = 4):
         """decodingMethod of the batch entry points (OfflineRecognizer.cs:54-68): greedy_search | modified_beam_search"""
         self._chk(self._L.k2hip_set_decoding_method(self._h, method.encode(), beam))

@@ -7,6 +7,7 @@
 
 #include "text.h"
 #include "engine.h"
+#include "../../include/k2hip_debug.h"
 
 using namespace k2hip;
 
@@ -883,16 +884,30 @@ int32_t k2hip_online_stream_state(k2hip_online_stream_t* s, int32_t layer, int32
     });
 }
 
-// one-part repeats of the vocabulary-parallel search since the model was created (test / monitoring hook, not part of include/k2hip.h)
-__attribute__((visibility("default"))) int32_t k2hip_debug_search_retries(k2hip_model_t* model, int32_t* n) {
+// one-part repeats of the vocabulary-parallel search since the model was created (test / monitoring hook: include/k2hip_debug.h)
+int32_t k2hip_debug_search_retries(k2hip_model_t* model, int32_t* n) {
     return guard([&] {
         NEED(model); NEED(n);
         EngineLock lk(model->engine);
         *n = model->engine.search_retries();
     });
 }
-// test hook (not part of include/k2hip.h): the all-contexts decoder table against the decoder itself on sampled contexts
-__attribute__((visibility("default"))) int32_t k2hip_debug_decoder_table_check(k2hip_model_t* model, int32_t n_samples, uint32_t seed,
+// K2HIP_BEAM_TRACE: the per-frame selection of the last synchronous modified beam search (include/k2hip_debug.h)
+int32_t k2hip_debug_beam_trace(k2hip_model_t* model, int32_t* trace, int64_t cap_words, int32_t* B, int32_t* Tprime, int32_t* beam) {
+    return guard([&] {
+        NEED(model); NEED(B); NEED(Tprime); NEED(beam);
+        EngineLock lk(model->engine);
+        int b = 0, tp = 0, k = 0;
+        const std::vector<int>& t = model->engine.last_beam_trace(&b, &tp, &k);
+        K2_REQUIRE(!t.empty(), "beam trace: no traced beam search on record (set K2HIP_BEAM_TRACE=1 before the call)");
+        *B = b; *Tprime = tp; *beam = k;
+        if (!trace) return;
+        if ((int64_t)t.size() > cap_words) failf(K2HIP_ERR_CAPACITY, "beam trace: %zu words exceed capacity %lld", t.size(), (long long)cap_words);
+        memcpy(trace, t.data(), sizeof(int) * t.size());
+    });
+}
+// test hook (include/k2hip_debug.h): the all-contexts decoder table against the decoder itself on sampled contexts
+int32_t k2hip_debug_decoder_table_check(k2hip_model_t* model, int32_t n_samples, uint32_t seed,
                                                                                 int64_t* rows, int64_t* mismatched) {
     return guard([&] {
         NEED(model); NEED(rows); NEED(mismatched);
@@ -904,23 +919,23 @@ __attribute__((visibility("default"))) int32_t k2hip_debug_decoder_table_check(k
         *mismatched = m;
     });
 }
-// test hook (not part of include/k2hip.h): mark a stream as if a chunk step over it had failed on the device
-__attribute__((visibility("default"))) int32_t k2hip_debug_poison_stream(k2hip_online_stream_t* s) {
+// test hook (include/k2hip_debug.h): mark a stream as if a chunk step over it had failed on the device
+int32_t k2hip_debug_poison_stream(k2hip_online_stream_t* s) {
     return guard([&] {
         NEED(s);
         s->poisoned = true;
     });
 }
 
-// test hook (not part of include/k2hip.h): does the stream's device mirror of its feature FIFO hold the FIFO right now?
-__attribute__((visibility("default"))) int32_t k2hip_debug_stream_mirrored(const k2hip_online_stream_t* s, int32_t* ok) {
+// test hook (include/k2hip_debug.h): does the stream's device mirror of its feature FIFO hold the FIFO right now?
+int32_t k2hip_debug_stream_mirrored(const k2hip_online_stream_t* s, int32_t* ok) {
     return guard([&] {
         NEED(s); NEED(ok);
         *ok = s->mir_ok ? 1 : 0;
     });
 }
 
-// ---- tuning hook (not part of include/k2hip.h): time one GEMM shape/config on random data
+// ---- tuning hook (include/k2hip_debug.h): time one GEMM shape/config on random data
 int32_t k2hip_debug_set_switch(const char* env_name, int32_t value) {
     return guard([&] {
         NEED(env_name);
@@ -928,7 +943,7 @@ int32_t k2hip_debug_set_switch(const char* env_name, int32_t value) {
         if (!tunables_set(env_name, value)) failf(K2HIP_ERR_INVALID, "unknown switch '%s'", env_name);
     });
 }
-__attribute__((visibility("default"))) int32_t k2hip_debug_gemm(k2hip_model_t* model, int32_t M, int32_t N, int32_t K,
+int32_t k2hip_debug_gemm(k2hip_model_t* model, int32_t M, int32_t N, int32_t K,
                                                                  int32_t act, int32_t with_res, int32_t cfg, int32_t iters, float* ms) {
     return guard([&] {
         NEED(model); NEED(ms);
@@ -937,7 +952,7 @@ __attribute__((visibility("default"))) int32_t k2hip_debug_gemm(k2hip_model_t* m
     });
 }
 // the same, and max_err = largest |difference| from the register-staged kernel on the same operands
-__attribute__((visibility("default"))) int32_t k2hip_debug_gemm_check(k2hip_model_t* model, int32_t M, int32_t N, int32_t K,
+int32_t k2hip_debug_gemm_check(k2hip_model_t* model, int32_t M, int32_t N, int32_t K,
                                                                        int32_t act, int32_t with_res, int32_t cfg, int32_t iters, float* ms,
                                                                        float* max_err) {
     return guard([&] {
@@ -947,7 +962,16 @@ __attribute__((visibility("default"))) int32_t k2hip_debug_gemm_check(k2hip_mode
     });
 }
 
-__attribute__((visibility("default"))) int32_t k2hip_debug_gemm_trace(k2hip_model_t* model, int32_t M, int32_t N, int32_t K, int32_t act,
+int32_t k2hip_debug_gemm_run(k2hip_model_t* model, const float* A, const float* W, const float* bias, const float* res, float* C, int32_t M,
+                             int32_t N, int32_t K, int32_t act, int32_t glu, int32_t glu_cols, int32_t cfg) {
+    return guard([&] {
+        NEED(model); NEED(A); NEED(W); NEED(C);
+        EngineLock lk(model->engine);
+        model->engine.debug_gemm_host(A, W, bias, res, C, M, N, K, act, glu, glu_cols, cfg);
+    });
+}
+
+int32_t k2hip_debug_gemm_trace(k2hip_model_t* model, int32_t M, int32_t N, int32_t K, int32_t act,
                                                                        int32_t with_res, int32_t cfg, unsigned long long* out, int64_t cap,
                                                                        int32_t* n_wg, int32_t* n_waves) {
     return guard([&] {

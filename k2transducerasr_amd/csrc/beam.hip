@@ -105,6 +105,9 @@ struct HypView {
     float* lp;         // [K] in place: every read of it precedes (barrier-separated) tid 0's write
     long long* ctx;    // [K][2]
     int* nhyp;
+    // debug tap (k2hip_debug.h, K2HIP_BEAM_TRACE) or null: this frame's record of this stream, 2 K + 1 words = the selected candidates'
+    // flat indexes (slot * V + token) in rank order, their scores (float bits), the number of hypotheses after the merges
+    int* trace = nullptr;
 };
 constexpr int kStepScratchInts = 4 * kMaxBeam + 4 + 2 * kMaxBeam * kMaxBeam;
 // one workgroup of NT threads per stream; lg: the hypotheses' logits, ldl floats per row; scratch: kStepScratchInts ints of LDS
@@ -300,6 +303,11 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
             n_n[k] = 0;
         }
         *hv.nhyp = nN;
+        if (hv.trace) hv.trace[2 * K] = nN;
+    }
+    if (hv.trace && tid < K) {
+        hv.trace[tid] = tid < want ? topi[tid] : -1;
+        hv.trace[K + tid] = __float_as_int(tid < want ? topv[tid] : -INFINITY);
     }
     __syncthreads();
     for (int r = wave; r < want; r += BT / 64) {   // a wave per surviving candidate (distinct destination slots)
@@ -333,7 +341,7 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
 }
 
 // one workgroup per stream; `cur` = buffer holding frame t's input hypotheses
-__global__ __launch_bounds__(BT) void k_beam_step(BeamState s, const float* __restrict__ logits, int V, int t, int cur, int B) {
+__global__ __launch_bounds__(BT) void k_beam_step(BeamState s, const float* __restrict__ logits, int V, int t, int cur, int B, int* trace, int Tp) {
     __shared__ int scratch[kStepScratchInts];
     const int b = blockIdx.x, K = s.K, nxt = cur ^ 1;
     const long long BK = (long long)B * K;
@@ -348,6 +356,7 @@ __global__ __launch_bounds__(BT) void k_beam_step(BeamState s, const float* __re
     hv.lp = s.lp + b * K;
     hv.ctx = s.ctx + 2 * (long long)b * K;
     hv.nhyp = s.nhyp + b;
+    hv.trace = trace ? trace + ((long long)b * Tp + t) * (2 * K + 1) : nullptr;
     beam_step_body<BT>(hv, logits + (long long)b * K * V, V, V, t, scratch);
 }
 
@@ -527,6 +536,7 @@ __global__ __launch_bounds__(GT) void k_beam_loop(DecJoinW w, BeamLoopArgs a) {
         hv.ys_c = ys + (size_t)cur * K * a.cap; hv.ts_c = ts + (size_t)cur * K * a.cap; hv.n_c = nbuf + cur * GF;
         hv.ys_n = ys + (size_t)(cur ^ 1) * K * a.cap; hv.ts_n = ts + (size_t)(cur ^ 1) * K * a.cap; hv.n_n = nbuf + (cur ^ 1) * GF;
         hv.lp = lp; hv.ctx = ctx; hv.nhyp = nhyp;
+        hv.trace = (a.trace && slab == 0) ? a.trace + ((long long)b * a.Tp + t) * (2 * K + 1) : nullptr;
         beam_step_body<GT>(hv, lg, w.Vp, w.V, t, scratch);
         __syncthreads();
     }
@@ -615,6 +625,7 @@ void beam_search(const Ctx& ctx, const DecJoinW& w, const BeamArgs& a) {
             la.max_tokens = a.max_tokens; la.overflow = a.overflow;
             la.ys_g = ys_g; la.ts_g = ts_g;
             la.xg = xg;
+            la.trace = a.trace;
             K2_HIP(hipMemsetAsync(a.overflow, 0, sizeof(int), ctx.stream));
             static LdsAttrOnce lds_attr;
             static LdsAttrOnce lds_attr1;
@@ -672,7 +683,7 @@ void beam_search(const Ctx& ctx, const DecJoinW& w, const BeamArgs& a) {
         }
         linear(ctx, act, w.J, a.out_w, w.out_b, logits, w.V, M, w.J, w.V);
         if (!ctx.dry) {
-            hipLaunchKernelGGL(k_beam_step, dim3(B), dim3(BT), 0, ctx.stream, s, logits, w.V, t, t & 1, B);
+            hipLaunchKernelGGL(k_beam_step, dim3(B), dim3(BT), 0, ctx.stream, s, logits, w.V, t, t & 1, B, a.trace, a.Tp);
             K2_HIP(hipGetLastError());
         }
     }

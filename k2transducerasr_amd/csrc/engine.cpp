@@ -592,6 +592,7 @@ void Engine::greedy_device(const Ctx& c, const float* enc, int B, int Tp, bool s
                            int max_tokens, int* d_overflow) {
     // by-products of the search this call runs, and of no earlier one (their arena may have been rebuilt since)
     d_scores_ = nullptr;
+    d_beam_trace_ = nullptr;
     d_trail_ = nullptr;
     d_any_ = nullptr;
     if (model_->cfg().ctc) {
@@ -657,6 +658,11 @@ void Engine::beam_device(const Ctx& c, const float* enc, int B, int Tp, long lon
     a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = max_tokens; a.overflow = d_overflow;
     d_scores_ = c.arena->take<float>(B);
     a.scores = d_scores_;
+    if (tunables().beam_trace) {
+        d_beam_trace_ = c.arena->take<int>((int64_t)B * Tp * (2 * beam_ + 1));
+        a.trace = d_beam_trace_;
+        trace_B_ = B; trace_Tp_ = Tp; trace_K_ = beam_;
+    }
     beam_search(c, decjoin(), a);
 }
 
@@ -702,6 +708,10 @@ void Engine::finish_tokens(const long long* d_tok, const int* d_ts, const int* d
     if (beam_ > 0 && d_scores_) {
         last_scores_.resize(B);
         K2_HIP(hipMemcpy(last_scores_.data(), d_scores_, sizeof(float) * B, hipMemcpyDeviceToHost));
+    }
+    if (beam_ > 0 && d_beam_trace_ && B == trace_B_) {
+        last_beam_trace_.resize((size_t)trace_B_ * trace_Tp_ * (2 * trace_K_ + 1));
+        K2_HIP(hipMemcpy(last_beam_trace_.data(), d_beam_trace_, sizeof(int) * last_beam_trace_.size(), hipMemcpyDeviceToHost));
     }
 }
 
@@ -1305,6 +1315,43 @@ float Engine::debug_gemm(int M, int N, int K, int act, bool with_res, int iters,
     debug_force_gemm_cfg(-1);
     (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipFree(C2); (void)hipFree(Rb); (void)hipFree(b);
     return ms / iters;
+}
+
+void Engine::debug_gemm_host(const float* hA, const float* hW, const float* hb, const float* hres, float* hC, int M, int N, int K, int act,
+                             int glu, int glu_cols, int cfg) {
+    K2_HIP(hipSetDevice(device_));
+    K2_REQUIRE(M > 0 && N > 0 && K > 0 && hA && hW && hC, "debug_gemm_host: bad arguments");
+    K2_REQUIRE(glu == 0 || (N % 32 == 0 && (glu_cols == 0 || (glu_cols % 32 == 0 && glu_cols <= N))), "debug_gemm_host: gated form needs N %% 32 == 0");
+    const int gc = glu ? (glu_cols ? glu_cols : N) : 0;
+    const int ldo = glu ? gc / 2 + (N - gc) : N;
+    struct Bufs {
+        float *A = nullptr, *W = nullptr, *C = nullptr, *R = nullptr, *b = nullptr;
+        ~Bufs() { (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipFree(R); (void)hipFree(b); debug_force_gemm_cfg(-1); }
+    } d;
+    K2_HIP(hipMalloc(&d.A, sizeof(float) * (size_t)M * K));
+    K2_HIP(hipMalloc(&d.W, sizeof(float) * (size_t)N * K));
+    K2_HIP(hipMalloc(&d.C, sizeof(float) * (size_t)M * ldo));
+    K2_HIP(hipMemcpy(d.A, hA, sizeof(float) * (size_t)M * K, hipMemcpyHostToDevice));
+    K2_HIP(hipMemcpy(d.W, hW, sizeof(float) * (size_t)N * K, hipMemcpyHostToDevice));
+    K2_HIP(hipMemset(d.C, 0xff, sizeof(float) * (size_t)M * ldo));   // NaN pattern: an element the kernel never writes fails the comparison
+    if (hb) {
+        K2_HIP(hipMalloc(&d.b, sizeof(float) * (size_t)N));
+        K2_HIP(hipMemcpy(d.b, hb, sizeof(float) * (size_t)N, hipMemcpyHostToDevice));
+    }
+    if (hres) {
+        K2_HIP(hipMalloc(&d.R, sizeof(float) * (size_t)M * ldo));
+        K2_HIP(hipMemcpy(d.R, hres, sizeof(float) * (size_t)M * ldo, hipMemcpyHostToDevice));
+    }
+    Ctx c = make_ctx(false);
+    c.instrument = false;
+    c.stats = nullptr;
+    GemmArgs g;
+    g.A = d.A; g.lda = K; g.W = d.W; g.ldw = K; g.bias = d.b; g.C = d.C; g.ldc = ldo; g.M = M; g.N = N; g.K = K;
+    g.act = act; g.res = d.R; g.ldr = ldo; g.glu = glu; g.glu_cols = gc == N ? 0 : gc;
+    debug_force_gemm_cfg(cfg);
+    gemm(c, g);
+    K2_HIP(hipStreamSynchronize(stream_));
+    K2_HIP(hipMemcpy(hC, d.C, sizeof(float) * (size_t)M * ldo, hipMemcpyDeviceToHost));
 }
 
 // tuning hook: ONE launch of the ring kernel `cfg` (>= 100) with in-kernel s_memtime stamps; out [n_wg][n_waves][64]

@@ -120,9 +120,18 @@ class Engine {
     const std::vector<int>& last_trail() const { return last_trail_; }
     const std::vector<int>& last_any() const { return last_any_; }
     const std::vector<float>& last_scores() const { return last_scores_; }
+    // K2HIP_BEAM_TRACE: [B][Tp][2 beam + 1] words of the last synchronous beam search (BeamArgs::trace), and its B / Tp / beam
+    const std::vector<int>& last_beam_trace(int* B, int* Tp, int* K) const {
+        *B = trace_B_; *Tp = trace_Tp_; *K = trace_K_;
+        return last_beam_trace_;
+    }
     const k2hip_timing& timing() const { return timing_; }
 
     float debug_gemm(int M, int N, int K, int act, bool with_res, int iters, int cfg, float* max_err);
+    // test hook: ONE launch of configuration `cfg` (-1 = the dispatcher's own choice) on the caller's operands, result back to the host --
+    // what tests/test_gemm_gpu.py holds against a float64 product computed on the host (k2hip_debug.h: k2hip_debug_gemm_run)
+    void debug_gemm_host(const float* A, const float* W, const float* bias, const float* res, float* C, int M, int N, int K, int act,
+                         int glu, int glu_cols, int cfg);
     void debug_gemm_trace(int M, int N, int K, int act, bool with_res, int cfg, unsigned long long* out, int64_t cap, int* n_wg, int* n_waves);
     void* dev_alloc(int64_t bytes);
     void dev_free(void* p);
@@ -234,6 +243,9 @@ class Engine {
     int *d_trail_ = nullptr, *d_any_ = nullptr;
     std::vector<int> last_trail_, last_any_;
     float* d_scores_ = nullptr;
+    int* d_beam_trace_ = nullptr;
+    int trace_B_ = 0, trace_Tp_ = 0, trace_K_ = 0;
+    std::vector<int> last_beam_trace_;
     float* d_dec_start_ = nullptr;  // [2][J]: decoder outputs of the start contexts [-1, blank], [blank, blank] (model constants)
     const float* decoder_start(const Ctx& c);
     std::vector<float> last_scores_;

@@ -134,7 +134,78 @@ __device__ __forceinline__ void amax_wave(float& v, int& i) {
     i = ri;
 }
 
-// one wave per row; FIRST = false: later index wins ties (transducer loops); true: first index (CTC, Array.IndexOf)
+// ---- the reference's argmax WITH its NaN behaviour --------------------------------------------------------------
+// OfflineRecognizer.cs:150-154 / :236-240 / OnlineRecognizer.cs:159-163 scan a row with
+//     token_num = logits[j, token_num] > logits[j, k] ? token_num : k;        (k = 1 .. V-1, token_num = 0 at the start)
+// A comparison with a NaN is false, so a NaN at index p takes the scan to p and the element behind it takes it on to p + 1 whatever
+// its value: the result is the later-wins argmax over the indexes BEHIND the row's last NaN, or that NaN's own index if it is the
+// row's last element ([5, NaN, 1] -> 2, [0, 1, NaN] -> 2, all NaN -> V - 1).  amax_merge above ignores NaNs (it is a total order over
+// the non-NaN elements, which is what lets lanes take interleaved columns); two ways to put the NaN rule on top of it:
+//   * rows that can be read again (k_argmax_rows, k_rounds_step): amax_row_fix -- the lanes also track the largest NaN index they
+//     saw; without one (every row of a healthy model) the total-order result stands, otherwise the row is scanned once more behind it;
+//   * values that exist only once (k_greedy's sweep): rmax_* -- a (value, index, saw-a-NaN) state per CONTIGUOUS index range that is
+//     the reference's scan of that range, merged in index order.
+constexpr int kRmaxNan = 1 << 30, kRmaxIdx = kRmaxNan - 1;
+// the scan's next element (ranges are scanned in increasing index); empty state: v = -inf, i = -1
+__device__ __forceinline__ void rmax_scan(float& v, int& i, float x, int col) {
+    const int seen = (i < 0 ? 0 : (i & kRmaxNan)) | ((x != x) ? kRmaxNan : 0);
+    if (!(v > x)) { v = x; i = col; }   // the reference's comparison: false for a tie (later index wins) and for a NaN on either side
+    i = (i & kRmaxIdx) | seen;
+}
+// two scanned ranges -> the scan of their union.  The ranges are disjoint and contiguous, so the states' own indexes say which is the
+// earlier one; the merge is symmetric and associative over ranges in any grouping (butterflies, trees).
+__device__ __forceinline__ void rmax_merge(float& v, int& i, float ov, int oi) {
+    if (oi < 0) return;
+    if (i < 0) { v = ov; i = oi; return; }
+    const bool o_later = (oi & kRmaxIdx) > (i & kRmaxIdx);
+    const float av = o_later ? v : ov, bv = o_later ? ov : v;   // a = earlier range, b = later range
+    const int ai = o_later ? i : oi, bi = o_later ? oi : i;
+    if (bi & kRmaxNan) { v = bv; i = bi; }                      // a NaN in the later range: nothing in front of it survives
+    else if (!(av > bv)) { v = bv; i = bi | (ai & kRmaxNan); }  // (av NaN = the earlier range ended on its NaN: the scan moves on)
+    else { v = av; i = ai; }
+}
+__device__ __forceinline__ void rmax_wave(float& v, int& i) {   // lanes = consecutive ranges; every lane gets the wave's state
+    rmax_merge(v, i, dpp_f<0xB1>(v), dpp_i<0xB1>(i));
+    rmax_merge(v, i, dpp_f<0x4E>(v), dpp_i<0x4E>(i));
+    rmax_merge(v, i, dpp_f<0x141>(v), dpp_i<0x141>(i));
+    rmax_merge(v, i, dpp_f<0x140>(v), dpp_i<0x140>(i));
+    float rv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    int ri = __builtin_amdgcn_readlane(i, 0);
+#pragma unroll
+    for (int row = 1; row < 4; row++)
+        rmax_merge(rv, ri, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16 * row)), __builtin_amdgcn_readlane(i, 16 * row));
+    v = rv;
+    i = ri;
+}
+__device__ __forceinline__ int rmax_index(int i) { return i < 0 ? i : (i & kRmaxIdx); }
+
+// the wave's largest value of a per-lane int (DPP moves, every lane gets it)
+__device__ __forceinline__ int imax_wave(int x) {
+    x = max(x, dpp_i<0xB1>(x));
+    x = max(x, dpp_i<0x4E>(x));
+    x = max(x, dpp_i<0x141>(x));
+    x = max(x, dpp_i<0x140>(x));
+    int r = __builtin_amdgcn_readlane(x, 0);
+#pragma unroll
+    for (int row = 1; row < 4; row++) r = max(r, __builtin_amdgcn_readlane(x, 16 * row));
+    return r;
+}
+// One wave, one row l[0 .. V) that can be read again: (v, idx) = the wave's NaN-ignoring later-wins argmax (amax_wave's result),
+// pnan = this lane's largest NaN index (-1: none).  Returns the reference's token (wave-uniform).
+__device__ __forceinline__ int amax_row_fix(const float* __restrict__ l, int V, int lane, int idx, int pnan) {
+    const int p = imax_wave(pnan);
+    if (p < 0) return idx;          // no NaN in the row: every row of a healthy model
+    if (p == V - 1) return p;       // the scan ends on the NaN
+    float v = -INFINITY;
+    int i2 = -1;
+    for (int k = p + 1 + lane; k < V; k += 64) amax_merge(v, i2, l[k], k);   // (NaN-free by the choice of p)
+    amax_wave(v, i2);
+    return i2;
+}
+
+// one wave per row; FIRST = false: the transducer loops' scan (later index wins ties, NaN rule above); true: CTC's
+// Array.IndexOf(row, row.Max()) (OfflineRecognizer.cs:335,396) -- the first index of the maximum; Enumerable.Max orders NaN below
+// every number, so a NaN only wins a row of nothing but NaNs, where IndexOf finds the first element
 template <bool FIRST>
 __global__ void k_argmax_rows(const float* __restrict__ logits, int ld, int N, int V, int* __restrict__ tok) {
     int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -144,16 +215,25 @@ __global__ void k_argmax_rows(const float* __restrict__ logits, int ld, int N, i
     float v = -INFINITY;
     int idx = -1;
     if (!FIRST) {
-        for (int k = lane; k < V; k += 64) amax_merge(v, idx, l[k], k);
+        int pnan = -1;
+        for (int k = lane; k < V; k += 64) {
+            const float x = l[k];
+            amax_merge(v, idx, x, k);
+            pnan = (x != x) ? k : pnan;
+        }
         amax_wave(v, idx);
+        idx = amax_row_fix(l, V, lane, idx, pnan);
     } else {
-        for (int k = lane; k < V; k += 64)
-            if (idx < 0 || l[k] > v) { v = l[k]; idx = k; }
+        for (int k = lane; k < V; k += 64) {
+            const float x = l[k];
+            if (idx < 0 || x > v || (v != v && x == x)) { v = x; idx = k; }
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             float ov = __shfl_xor(v, o);
             int oi = __shfl_xor(idx, o);
-            if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
+            const bool onan = ov != ov, mnan = v != v;
+            if (oi >= 0 && (idx < 0 || ov > v || (mnan && !onan) || ((ov == v || (mnan && onan)) && oi < idx))) { v = ov; idx = oi; }
         }
     }
     if (lane == 0) tok[row] = idx;
@@ -408,8 +488,12 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
         __syncthreads();
         // The sweep (mfma_sweep_rows): wave = k slice (J / 8 rows), lane = 4 columns -- a pass covers 256 columns of the slab and a
         // wave's load instruction reads 1 KB of one weight row.
-        float bestv = -INFINITY;   // wave f, after the passes: frame f's best over this part's slab
+        // wave f, after the passes: the reference's scan (rmax_*) of frame f's logits over this part's slab.  Lanes hold consecutive
+        // column groups within a pass and the passes walk the slab in order, so a pass is reduced over the wave before the next one
+        // joins it (slabs of one pass -- small vocabularies -- keep the single reduction behind the loop)
+        float bestv = -INFINITY;
         int besti = -1;
+        const bool one_pass = cg1 - cg0 <= 64;
         for (int cgb = cg0; cgb < cg1; cgb += 64) {
             const int cg = cgb + lane;
             const bool valid = cg < cg1;
@@ -434,19 +518,28 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
                     const float p4 = (&ps[4].x)[j], p5 = (&ps[5].x)[j], p6 = (&ps[6].x)[j], p7 = (&ps[7].x)[j];
                     sj[j] = ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7));
                 }
+                float pv_ = -INFINITY;
+                int pi_ = -1;
                 if (valid) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const int col = 4 * cg + j;
-                        if (col < w.V) amax_merge(bestv, besti, sj[j] + w.out_b[col], col);
+                        if (col < w.V) rmax_scan(pv_, pi_, sj[j] + w.out_b[col], col);
                     }
+                }
+                if (one_pass) {
+                    bestv = pv_;
+                    besti = pi_;
+                } else {
+                    rmax_wave(pv_, pi_);
+                    rmax_merge(bestv, besti, pv_, pi_);
                 }
             }
             if (cgb + 64 < cg1) __syncthreads();   // psum is rewritten by the next pass
         }
-        amax_wave(bestv, besti);
+        if (one_pass) rmax_wave(bestv, besti);
         if (lane == 0) {
-            fin[wave] = besti;
+            fin[wave] = rmax_index(besti);
             if (G > 1) {  // publish this slab's candidate for frame `wave` (round parity buffer)
                 unsigned long long* gr = a.gran + ((((long long)b * 2 + (epoch & 1)) * G + part) * GF + wave) * 2;
                 store_granule(gr, epoch + 1, __float_as_uint(bestv));
@@ -492,8 +585,8 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
             if (tid < GF) {
                 float v = pv[tid];
                 int i = pi[tid];
-                for (int p = 1; p < G; p++) amax_merge(v, i, pv[p * GF + tid], pi[p * GF + tid]);
-                fin[tid] = i;
+                for (int p = 1; p < G; p++) rmax_merge(v, i, pv[p * GF + tid], pi[p * GF + tid]);   // (the parts' slabs: consecutive ranges)
+                fin[tid] = rmax_index(i);
             }
         }
         __syncthreads();
@@ -699,7 +792,7 @@ __global__ __launch_bounds__(GT) void k_rounds_step(DecJoinW w, RoundsState a, i
         for (int s = wave; s < wl; s += GT / 64) {
             const float* row = a.logits + (long long)(b * a.S + s) * a.ldl;
             float bv = -INFINITY;
-            int bi = -1;
+            int bi = -1, pnan = -1;   // pnan: the largest NaN index this lane saw (amax_row_fix applies the reference's NaN rule)
             if ((a.ldl & 3) == 0) {   // 16-byte loads, 4 rows' worth of them independent (the merge is a total order: any sequence)
                 for (int j4 = 4 * lane; j4 < w.V; j4 += 256) {
                     const float4 t4 = *reinterpret_cast<const float4*>(row + j4);
@@ -707,11 +800,20 @@ __global__ __launch_bounds__(GT) void k_rounds_step(DecJoinW w, RoundsState a, i
                     if (j4 + 1 < w.V) amax_merge(bv, bi, t4.y, j4 + 1);
                     if (j4 + 2 < w.V) amax_merge(bv, bi, t4.z, j4 + 2);
                     if (j4 + 3 < w.V) amax_merge(bv, bi, t4.w, j4 + 3);
+                    pnan = (t4.x != t4.x) ? j4 : pnan;
+                    pnan = (j4 + 1 < w.V && t4.y != t4.y) ? j4 + 1 : pnan;
+                    pnan = (j4 + 2 < w.V && t4.z != t4.z) ? j4 + 2 : pnan;
+                    pnan = (j4 + 3 < w.V && t4.w != t4.w) ? j4 + 3 : pnan;
                 }
             } else {
-                for (int j = lane; j < w.V; j += 64) amax_merge(bv, bi, row[j], j);
+                for (int j = lane; j < w.V; j += 64) {
+                    const float x = row[j];
+                    amax_merge(bv, bi, x, j);
+                    pnan = (x != x) ? j : pnan;
+                }
             }
             amax_wave(bv, bi);
+            bi = amax_row_fix(row, w.V, lane, bi, pnan);
             if (lane == 0) toks[s] = bi;
         }
         __syncthreads();

@@ -29,6 +29,7 @@ struct Tunables {
     int beam_parts = 0;           // K2HIP_BEAM_PARTS: 1 = one workgroup per stream in the one-kernel beam search even where two column slabs apply
     int beam_hyp_global = 0;      // K2HIP_BEAM_HYP_GLOBAL: the one-kernel beam search keeps its hypotheses in device memory even when they fit in LDS (the long-utterance form, for its test)
     int decoder_table_mb = 1024;  // K2HIP_DECODER_TABLE_MB: build the all-contexts decoder table when it fits this many MiB (0 = never)
+    int beam_trace = 0;           // K2HIP_BEAM_TRACE: the modified beam search records its per-frame selection (k2hip_debug.h: k2hip_debug_beam_trace)
     int test_greedy_timeout = 0;  // K2HIP_TEST_GREEDY_TIMEOUT: test hook -- every parts > 1 search reports an exchange timeout, so the one-part retry runs
     int pipe_mode = 0;            // K2HIP_PIPE_MODE: 1 = every pipeline slot owns a stream
     int max_streams = 0;          // K2HIP_MAX_STREAMS: slots of the streaming state pool (0 = 256)
@@ -355,6 +356,7 @@ struct BeamLoopArgs {
     // two column slabs per stream (beam <= 4, 256 < V <= 512): workgroup 2 b + p sweeps chunk p and the two exchange their 4 x 256
     // logits per frame as tagged granules xg[b][frame parity][slab][4][256]; null = one workgroup per stream
     unsigned long long* xg;
+    int* trace = nullptr;   // debug tap [B][Tp][2 K + 1] (beam_step_body) or null
 };
 struct GreedyLaunch {
     bool valid = false;  // a launch with inter-workgroup waits (parts > 1 / two beam slabs) that can be repeated without them
@@ -396,6 +398,7 @@ struct BeamArgs {
     float* scores;       // [B] log_prob of the best hypothesis (may be null)
     int max_tokens;
     int* overflow;
+    int* trace = nullptr;  // debug tap [B][Tp][2 beam + 1] or null (k2hip_debug.h: k2hip_debug_beam_trace)
 };
 void beam_search(const Ctx& ctx, const DecJoinW& w, const BeamArgs& a);
 

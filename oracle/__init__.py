@@ -71,6 +71,7 @@ def lib():
         L.k2o_encoder_out_dim.argtypes = [C.c_void_p]
         L.k2o_ctc_greedy.argtypes = [fp, C.c_int, C.c_int, C.c_int, ip, lp, ip, ip, C.c_int, ip]
         L.k2o_modified_beam_search.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, C.c_int, lp, ip, ip, C.c_int, fp, fp]
+        L.k2o_modified_beam_search_trace.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, C.c_int, lp, ip, ip, C.c_int, fp, fp, ip]
         _lib = L
     return _lib
 
@@ -221,8 +222,10 @@ class Oracle:
         self._chk(self._L.k2o_ctc_greedy(_fp(lp_), B, Tp, V, _ip(fo), _lp(tok), _ip(ts), _ip(n), Tp + 1, _ip(tb)))
         return [(tok[b, : n[b]].tolist(), ts[b, : n[b]].tolist()) for b in range(B)], tb
 
-    def modified_beam_search(self, enc_out: np.ndarray, beam: int = 4, want_margins=False, want_scores=False):
-        """icefall modified_beam_search per stream (k2_oracle_beam.c); returns [(tokens, timestamps)] (+ margins [B,T'+1])."""
+    def modified_beam_search(self, enc_out: np.ndarray, beam: int = 4, want_margins=False, want_scores=False, want_trace=False):
+        """icefall modified_beam_search per stream (k2_oracle_beam.c); returns [(tokens, timestamps)] (+ margins [B,T'+1])
+        (+ scores [B]) (+ trace: dict(idx [B,T',2 beam] flat candidate indexes in rank order, val [B,T',2 beam] their scores,
+        n [B,T'] surviving hypotheses per frame) -- the per-frame tap tests/parity.py localises a divergence with)."""
         e = np.ascontiguousarray(enc_out, dtype=np.float32)
         B, Tp, _ = e.shape
         mt = Tp + 1
@@ -231,13 +234,18 @@ class Oracle:
         n = np.zeros(B, np.int32)
         sc = np.zeros(B, np.float32)
         mg = np.zeros((B, Tp + 1), np.float32)
-        self._chk(self._L.k2o_modified_beam_search(self._m, _fp(e), B, Tp, beam, _lp(tok), _ip(ts), _ip(n), mt, _fp(sc), _fp(mg)))
+        tr = np.zeros((B, Tp, 4 * beam + 1), np.int32)
+        self._chk(self._L.k2o_modified_beam_search_trace(self._m, _fp(e), B, Tp, beam, _lp(tok), _ip(ts), _ip(n), mt, _fp(sc), _fp(mg),
+                                                         _ip(tr) if want_trace else None))
         res = [(tok[b, : n[b]].tolist(), ts[b, : n[b]].tolist()) for b in range(B)]
         out = (res,)
         if want_margins:
             out += (mg,)
         if want_scores:
             out += (sc,)
+        if want_trace:
+            out += (dict(idx=tr[:, :, : 2 * beam].copy(), val=tr[:, :, 2 * beam: 4 * beam].copy().view(np.float32), n=tr[:, :, 4 * beam].copy(),
+                         beam=beam),)
         return out if len(out) > 1 else res
 
     def recognize_batch(self, feats):

@@ -91,6 +91,11 @@ int k2o_greedy_single(const k2o_model* m, const float* enc_out, int Tp,
  * margins [B,T'+1] (optional): per-frame beam-boundary score gap, final best-vs-second gap. */
 int k2o_modified_beam_search(const k2o_model* m, const float* enc_out, int B, int Tp, int beam, int64_t* tokens,
                              int32_t* timestamps, int32_t* n_tokens, int max_tokens, float* scores, float* margins);
+/* the same with a per-frame tap: trace [B][T'][4*beam + 1] int32 words = the frame's 2*beam best candidates (flat index = slot * V +
+ * token, then their scores as float bits) and the number of surviving hypotheses; see k2_oracle_beam.c */
+int k2o_modified_beam_search_trace(const k2o_model* m, const float* enc_out, int B, int Tp, int beam, int64_t* tokens,
+                                   int32_t* timestamps, int32_t* n_tokens, int max_tokens, float* scores, float* margins,
+                                   int32_t* trace);
 
 /* CTC greedy search (OfflineRecognizer.cs:305-424, OnlineRecognizer.cs:220-313) over log_probs [B,T',V]:
  * first-index argmax, drop blanks and repeats; frame_offsets / num_trailing_blank may be NULL */

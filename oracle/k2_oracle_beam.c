@@ -34,9 +34,17 @@ static float logaddexp_f(float a, float b) {
 }
 
 /* margins (optional): [Tp+1] -- per frame the gap between the beam-th and (beam+1)-th candidate score (INF if
- * fewer candidates), and in [Tp] the gap between the best and second-best length-normalised final scores */
-int k2o_modified_beam_search(const k2o_model* m, const float* enc_out, int B, int Tp, int beam, int64_t* tokens,
-                             int32_t* timestamps, int32_t* n_tokens, int max_tokens, float* scores, float* margins) {
+ * fewer candidates), and in [Tp] the gap between the best and second-best length-normalised final scores.
+ * trace (optional): [B][Tp][4*beam + 1] int32 words -- the per-frame tap the GPU search is localised against
+ * (tests/parity.py assert_beam_match): the 2*beam best candidates of the frame in (score desc, flat index asc)
+ * order, flat index = hypothesis slot * V + token (-1 where the frame has fewer candidates) in words [0, 2 beam),
+ * their scores (float bits) in words [2 beam, 4 beam), and in the last word the number of hypotheses that survive
+ * the frame (after HypothesisList.add's merges).  Two searches with equal histories up to frame t-1 hold the same
+ * hypotheses in the same slots, so the first frame whose first `beam` flat indexes (or survivor count) differ is
+ * the frame at which the searches part, and the scores say by what margin the oracle decided there. */
+int k2o_modified_beam_search_trace(const k2o_model* m, const float* enc_out, int B, int Tp, int beam, int64_t* tokens,
+                                   int32_t* timestamps, int32_t* n_tokens, int max_tokens, float* scores, float* margins,
+                                   int32_t* trace) {
     const int J = m->J, V = m->V, ctx = m->ctx, blank = 0, unk = 2;
     if (beam < 1 || beam > 16) return fail("beam search: beam %d out of range [1,16]", beam);
     if (ctx != 2) return fail("beam search: context_size %d != 2", ctx);
@@ -76,10 +84,11 @@ int k2o_modified_beam_search(const k2o_model* m, const float* enc_out, int B, in
             }
             /* top `beam` of nA*V by (value desc, flat index asc), plus the runner-up for the margin */
             int nc = nA * V, want = beam < nc ? beam : nc;
-            int top[17];
-            float topv[17];
+            const int ext = trace ? 2 * beam : want + 1;   /* how many candidates to rank */
+            int top[33];
+            float topv[33];
             int nt = 0;
-            for (int r = 0; r < want + 1 && r < nc; r++) {
+            for (int r = 0; r < ext && r < nc; r++) {
                 int bi = -1;
                 float bv = -INFINITY;
                 for (int i = 0; i < nc; i++) {
@@ -113,6 +122,15 @@ int k2o_modified_beam_search(const k2o_model* m, const float* enc_out, int B, in
                 if (real) { d->ys[d->n++] = tok; d->ts[d->nts++] = t; }
                 d->lp = topv[r];
             }
+            if (trace) {
+                int32_t* tr = trace + ((size_t)b * Tp + t) * (4 * beam + 1);
+                for (int r = 0; r < 2 * beam; r++) {
+                    tr[r] = r < nt ? top[r] : -1;
+                    float v = r < nt ? topv[r] : -INFINITY;
+                    memcpy(&tr[2 * beam + r], &v, sizeof(float));
+                }
+                tr[4 * beam] = nN;
+            }
             beam_hyp* tmp = A; A = N; N = tmp;
             nA = nN;
         }
@@ -140,4 +158,9 @@ int k2o_modified_beam_search(const k2o_model* m, const float* enc_out, int B, in
         free(A); free(N); free(dec); free(cur); free(lg); free(yin);
     }
     return rc;
+}
+
+int k2o_modified_beam_search(const k2o_model* m, const float* enc_out, int B, int Tp, int beam, int64_t* tokens,
+                             int32_t* timestamps, int32_t* n_tokens, int max_tokens, float* scores, float* margins) {
+    return k2o_modified_beam_search_trace(m, enc_out, B, Tp, beam, tokens, timestamps, n_tokens, max_tokens, scores, margins, NULL);
 }

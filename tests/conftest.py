@@ -19,6 +19,10 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     terminalreporter.write_line(f"parity: {parity.COMPARED[0]} streams compared token-exactly, {len(parity.EXCUSED)} excused")
     for e in parity.EXCUSED:
         terminalreporter.write_line(f"  excused: {e}")
+    if parity.NEAR_TIES:
+        terminalreporter.write_line(f"parity: {len(parity.NEAR_TIES)} beam-search streams differ on a LOCALISED near-tie (what, stream, frame, oracle gap at that frame):")
+        for e in parity.NEAR_TIES:
+            terminalreporter.write_line(f"  near-tie: {e}")
 
 
 def pytest_sessionfinish(session, exitstatus):

@@ -16,7 +16,8 @@ from k2transducerasr_amd.k2w import write_k2w
 V, DD, J = 8, 4, 8
 
 
-def write_kat_model(path):
+def write_kat_model(path, bias=None):
+    """bias: joiner.output_linear.bias (default zeros) -- the NaN-rule tests put NaNs there (a NaN logit at a chosen index)"""
     meta = make_zipformer2_meta(encoder_dims=[16], num_encoder_layers=[1], feedforward_dims=[16], num_heads=[1],
                                 cnn_module_kernels=[3], downsampling_factors=[1], joiner_dim=J, decoder_dim=DD,
                                 vocab_size=V, comment="greedy-kat")
@@ -34,7 +35,30 @@ def write_kat_model(path):
         ("joiner.decoder_proj.weight", dproj),
         ("joiner.decoder_proj.bias", np.zeros(J, np.float32)),
         ("joiner.output_linear.weight", np.eye(V, J, dtype=np.float32)),
-        ("joiner.output_linear.bias", np.zeros(V, np.float32)),
+        ("joiner.output_linear.bias", np.zeros(V, np.float32) if bias is None else np.asarray(bias, np.float32)),
+    ]
+    write_k2w(path, meta, tensors)
+    return meta
+
+
+def write_wide_model(path, vocab, joiner_dim=64, decoder_dim=8, nan_at=(), seed=3):
+    """A decoder / joiner with random weights and a vocabulary wide enough for the search kernels' column slabs and passes
+    (no encoder tensors: only the operator-level search entries are used); output bias NaN at the indexes `nan_at`."""
+    rng = np.random.default_rng(seed)
+    meta = make_zipformer2_meta(encoder_dims=[16], num_encoder_layers=[1], feedforward_dims=[16], num_heads=[1],
+                                cnn_module_kernels=[3], downsampling_factors=[1], joiner_dim=joiner_dim, decoder_dim=decoder_dim,
+                                vocab_size=vocab, comment="wide-kat")
+    bias = (rng.standard_normal(vocab) * 0.5).astype(np.float32)
+    bias[0] = 5.2           # blank wins a good share of the frames
+    for p in nan_at:
+        bias[p] = np.nan
+    tensors = [
+        ("decoder.embedding.weight", rng.standard_normal((vocab, decoder_dim)).astype(np.float32)),
+        ("decoder.conv.weight", (rng.standard_normal((decoder_dim, 4, 2)) * 0.5).astype(np.float32)),
+        ("joiner.decoder_proj.weight", (rng.standard_normal((joiner_dim, decoder_dim)) * 0.3).astype(np.float32)),
+        ("joiner.decoder_proj.bias", np.zeros(joiner_dim, np.float32)),
+        ("joiner.output_linear.weight", (rng.standard_normal((vocab, joiner_dim)) * 0.3).astype(np.float32)),
+        ("joiner.output_linear.bias", bias),
     ]
     write_k2w(path, meta, tensors)
     return meta

@@ -175,6 +175,7 @@ void Engine::wait_ticket(int ticket, int64_t* tokens, int32_t* ts, int32_t* n_to
 float Engine::debug_gemm(int, int, int, int, bool, int, int, float* e) { if (e) *e = 0.f; return 0.f; }
 void Engine::decoder_table_check(int, unsigned, long long* rows, long long* mismatched) { *rows = 0; *mismatched = 0; }
 void Engine::debug_gemm_trace(int, int, int, int, bool, int, unsigned long long*, int64_t, int* a, int* b) { *a = 0; *b = 0; }
+void Engine::debug_gemm_host(const float*, const float*, const float*, const float*, float*, int, int, int, int, int, int, int) {}
 void* Engine::dev_alloc(int64_t bytes) { return malloc((size_t)std::max<int64_t>(bytes, 1)); }
 void Engine::dev_free(void* p) { free(p); }
 void Engine::dev_upload(void* dst, const void* src, int64_t bytes) { memcpy(dst, src, (size_t)bytes); }

@@ -9,10 +9,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "k2hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(k2hip_[a-z0-9_]+)\s*\(", src)))
+HEADERS = ("k2hip.h", "k2hip_debug.h")   # the boundary, and the test / tuning hooks kept apart from it
+
+
+def declared_symbols(headers=HEADERS):
+    syms = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        syms |= set(re.findall(r"\b(k2hip_[a-z0-9_]+)\s*\(", src))
+    return sorted(syms)
 
 
 def test_header_declares_the_expected_surface():
@@ -29,7 +35,24 @@ def test_library_exports_every_declared_symbol():
     load_library()
     lib = ctypes.CDLL(library_path())
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
-    assert not missing, f"declared in include/k2hip.h but not exported: {missing}"
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+
+
+def test_library_exports_nothing_the_headers_do_not_declare():
+    """The dynamic symbol table is the C ABI and nothing else: no undeclared hook, no C++ symbol of the engine's types
+    (csrc/exports.map), and no debug hook hiding in the boundary header."""
+    import shutil
+    import subprocess
+    from k2transducerasr_amd import library_path
+    nm = shutil.which("nm")
+    if not nm:
+        pytest.skip("no nm")
+    out = subprocess.run([nm, "-D", "--defined-only", library_path()], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    extra = sorted(exported - set(declared_symbols()))
+    assert not extra, f"exported but declared in neither header: {extra}"
+    boundary_debug = [s for s in declared_symbols(("k2hip.h",)) if s.startswith("k2hip_debug_") and s != "k2hip_debug_set_switch"]
+    assert not boundary_debug, boundary_debug
 
 
 def test_every_header_entry_cites_the_reference():
@@ -99,8 +122,9 @@ def test_header_is_plain_c_and_a_c_host_links(tmp_path):
     gcc = shutil.which("gcc")
     if not gcc:
         pytest.skip("no gcc")
-    hdr = os.path.join(root, "include", "k2hip.h")
-    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    for h in HEADERS:
+        hdr = os.path.join(root, "include", h)
+        subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
     src = tmp_path / "host.c"
     src.write_text('#include "k2hip.h"\n#include <stdio.h>\nint main(void) { printf("%s\\n", k2hip_version()); return k2hip_last_error() == 0; }\n')
     lib = os.path.join(root, "k2transducerasr_amd")

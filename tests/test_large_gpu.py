@@ -266,6 +266,54 @@ def test_full_size_beam4_matches_oracle(hip_large, oracle_large):
         hip_large.device_free(ptr)
 
 
+def _beam_two_levels(hip, ora, utts, beam, what, tol):
+    """One batch through the modified beam search at two levels, every differing stream localised by the per-frame taps:
+    (operator) the engine's search on the ORACLE's encoder_out -- only joiner + search differ; (fused) samples -> tokens, where
+    the engine's own encoder (5e-4 from the oracle's) feeds the search.  Returns (exact_operator, exact_fused, hidden) with
+    hidden = streams whose results agree although the searches parted on some frame."""
+    from k2transducerasr_amd import set_switch
+    from parity import assert_beam_match, hidden_beam_divergences
+    B = len(utts)
+    feats = [ora.fbank(u) for u in utts]
+    enc_o = ora.encoder(ora.pad_sequence(feats).reshape(B, -1, 80))
+    want, mg, tr_w = ora.modified_beam_search(enc_o, beam, want_margins=True, want_trace=True)
+    set_switch("K2HIP_BEAM_TRACE", 1)
+    try:
+        got_op = hip.beam_search(enc_o, beam)
+        tr_op = hip.beam_trace()
+        ex_op = assert_beam_match(got_op, want, mg, tol=tol, what=f"{what} (operator level)", allow_tie=True, trace_got=tr_op, trace_want=tr_w)
+        hip.set_decoding_method("modified_beam_search", beam)
+        try:
+            got_f = hip.offline_greedy_from_samples(utts)
+            tr_f = hip.beam_trace()
+        finally:
+            hip.set_decoding_method("greedy_search")
+        ex_f = assert_beam_match(got_f, want, mg, tol=tol, what=f"{what} (fused)", allow_tie=True, trace_got=tr_f, trace_want=tr_w)
+        hidden = hidden_beam_divergences(got_f, want, tr_f, tr_w)
+        assert all(gap < tol for _, _, gap in hidden), hidden     # a search that parts from the oracle does so on a near-tie, whatever the result
+    finally:
+        set_switch("K2HIP_BEAM_TRACE", 0)
+    return ex_op, ex_f, hidden
+
+
+def test_full_size_beam4_fresh_audio_every_divergence_localised(hip_large, oracle_large):
+    """configs[2] shard on audio NO earlier run has seen: the utterance seeds come from the clock (K2HIP_SOAK_SEED pins them; the seed is
+    printed, so a failure can be replayed).  Beam search has no reference behaviour, so the oracle is the only truth; on fresh audio
+    ~5 % of the streams meet a frame whose candidates are closer than the two encoders agree, and such a stream may end differently.
+    This test accepts that ONLY where the two per-frame taps localise it: the first frame at which the selections differ, and the
+    oracle's own scores of the candidates in question at THAT frame within 1e-3 (tests/parity.py localise_beam); on the oracle's own
+    encoder_out the engine's search must match outright."""
+    import os
+    import time
+    from k2transducerasr_amd.synth import synth_utterance
+    seed = int(os.environ.get("K2HIP_SOAK_SEED", "0")) or (int(time.time()) % 1_000_000) * 64 + 100_000
+    print(f"fresh-audio beam test: first utterance seed {seed} (K2HIP_SOAK_SEED={seed} replays it)")
+    utts = [synth_utterance(seed + b, 10.0) for b in range(32)]
+    ex_op, ex_f, hidden = _beam_two_levels(hip_large, oracle_large, utts, 4, f"configs[2] fresh audio, seed {seed}", 1e-3)
+    print(f"fresh-audio beam test: operator level {ex_op}/32 exact, fused {ex_f}/32 exact, {len(hidden)} equal results over parted searches")
+    assert ex_op == 32, "on the oracle's encoder_out only the joiner's summation order differs: the searches must agree"
+
+
 def test_search_exchange_timeout_is_retried_with_one_part(hip_large):
     """The vocabulary-parallel search (two column-slab workgroups per stream here) spins on its sibling with a bounded wait; on a
     shared GPU the siblings may not be resident together.  A timeout is not an error any more: the engine repeats the search

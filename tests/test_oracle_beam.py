@@ -102,3 +102,74 @@ def test_beam_merges_equal_sequences(kat_oracle):
     assert ys == [5]
     assert res[0] == (ys, ts)
     assert abs(lp - float(sc[0])) < 1e-5
+
+
+def _as_engine_tap(tr):
+    """an oracle tap cut down to what the engine's tap holds (the `beam` selected candidates)"""
+    K = tr["beam"]
+    return dict(idx=tr["idx"][:, :, :K], val=tr["val"][:, :, :K], n=tr["n"], beam=K)
+
+
+def test_trace_tap_is_consistent_with_the_search(oracle_tiny, enc_tiny):
+    """The per-frame tap the divergence localiser relies on: ranked (score desc, flat index asc), the first `beam` entries are the
+    frame's selection, the margin is the gap between entries beam-1 and beam, survivors <= selection size; tracing changes nothing."""
+    beam = 4
+    res, mg, tr = oracle_tiny.modified_beam_search(enc_tiny, beam, want_margins=True, want_trace=True)
+    assert res == oracle_tiny.modified_beam_search(enc_tiny, beam)
+    idx, val, n = tr["idx"], tr["val"], tr["n"]
+    B, Tp, E = idx.shape
+    assert E == 2 * beam and n.shape == (B, Tp)
+    V = oracle_tiny.vocab_size
+    for b in range(B):
+        for t in range(Tp):
+            live = idx[b, t] >= 0
+            v = val[b, t][live]
+            assert (np.diff(v) <= 0).all()
+            ties = np.nonzero(np.diff(v) == 0)[0]
+            assert all(idx[b, t, i] < idx[b, t, i + 1] for i in ties)
+            assert 1 <= n[b, t] <= min(beam, live.sum())
+            assert (idx[b, t][live] // V < (1 if t == 0 else n[b, t - 1])).all()     # slots of the previous frame's survivors
+            if live.sum() > beam:
+                assert mg[b, t] == pytest.approx(val[b, t, beam - 1] - val[b, t, beam], abs=0)
+    assert (n[:, 0] >= 1).all() and (idx[:, 0, :beam] < V).all()       # frame 0 expands the single start hypothesis
+
+
+def test_divergence_localiser(oracle_tiny, enc_tiny):
+    """tests/parity.py localise_beam / assert_beam_match on two oracle runs: equal inputs -> no divergence; a perturbed encoder_out
+    plays the engine -- every stream whose result changes must be localised to a frame at which the unperturbed oracle's own scores
+    of the candidates in question are closer than the perturbation can move them, and a gross perturbation must be REJECTED."""
+    import parity
+    beam = 4
+    want, mg, tr_w = oracle_tiny.modified_beam_search(enc_tiny, beam, want_margins=True, want_trace=True)
+    same = _as_engine_tap(tr_w)
+    for b in range(len(want)):
+        assert parity.localise_beam(same, tr_w, b) == (None, None)
+    rng = np.random.default_rng(5)
+    found = 0
+    for trial in range(40):
+        noisy = enc_tiny + rng.standard_normal(enc_tiny.shape).astype(np.float32) * 2e-3
+        got, tr_g = oracle_tiny.modified_beam_search(noisy, beam, want_trace=True)
+        tap = _as_engine_tap(tr_g)
+        for b in range(len(want)):
+            t, gap = parity.localise_beam(tap, tr_w, b)
+            if t is None:
+                if got[b] != want[b]:            # the searches agree on every frame: only the final pick can differ
+                    assert mg[b, -1] < 0.1
+                continue
+            found += 1
+            assert 0 <= t < enc_tiny.shape[1] and gap < 0.1, (trial, b, t, gap)    # 2e-3 of input noise moves scores by far less than 0.1
+            # the localised frame is the FIRST differing one
+            assert (tap["idx"][b, :t] == tr_w["idx"][b, :t, :beam]).all()
+    assert found > 0, "the perturbation never moved a selection: the test does not exercise the localiser"
+    # a gross perturbation: streams differ, and the localiser must refuse to call it a near-tie
+    gross = enc_tiny[::-1].copy()
+    got, tr_g = oracle_tiny.modified_beam_search(gross, beam, want_trace=True)
+    if got != want:
+        n_before = len(parity.NEAR_TIES)
+        with pytest.raises(AssertionError):
+            parity.assert_beam_match(got, want, mg, tol=1e-3, what="gross", allow_tie=True, trace_got=_as_engine_tap(tr_g), trace_want=tr_w)
+        del parity.NEAR_TIES[n_before:]
+        parity.COMPARED[0] -= len(want)
+    with pytest.raises(AssertionError):          # no taps, no excuse
+        parity.assert_beam_match([([1], [0])], [([2], [0])], np.zeros((1, 3)), allow_tie=True)
+    parity.COMPARED[0] -= 1

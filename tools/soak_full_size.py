@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
-"""Dev tool (GPU): the headline shapes with OTHER audio than the tests use -- zipformer2-large-en, batches of 32 x 10 s (and a ragged
-one), greedy search and modified beam search (beam 4, the two-slab one-kernel form) through the fused samples -> tokens entry, every
-stream against the CPU oracle (tests/parity.py criteria; near-ties are reported, not failed).
+"""Dev tool (GPU): the headline shapes with OTHER audio than the tests use -- zipformer2-large-en, batches of 32 x 10 s (every other
+one ragged), greedy search and modified beam search (beam 4) against the CPU oracle.
+
+Greedy: the fused samples -> tokens entry, tests/parity.py criteria (a divergence must start on a frame whose own top-2 gap is a tie).
+Beam search, at TWO levels, every differing stream LOCALISED by the per-frame taps of both sides (tests/parity.py localise_beam):
+  operator level -- the engine's search on the oracle's encoder_out (only joiner + search differ);
+  fused          -- samples -> tokens (the engine's own encoder, 5e-4 from the oracle's, feeds the search).
+A miss is accepted only if the searches part on a frame at which the oracle's own scores of the candidates in question differ by less
+than 1e-3; anything else raises.  Also counted: streams with EQUAL results whose searches nevertheless parted (the dropped hypothesis
+was not the winner), and how many streams the four-launch form of the search decides differently from the one-kernel form.
 usage: soak_full_size.py [batches] [first-utterance-seed]"""
 import os
 import sys
@@ -15,15 +22,18 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import k2transducerasr_amd as pkg  # noqa: E402
 from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model  # noqa: E402
 from oracle import Oracle  # noqa: E402
-from parity import assert_beam_match, assert_tokens_match  # noqa: E402
+import parity  # noqa: E402
+from parity import assert_beam_match, assert_tokens_match, hidden_beam_divergences  # noqa: E402
 
+TOL = 1e-3
 batches = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
 path = os.path.join(tempfile.mkdtemp(), "large.k2w")
 write_synthetic_model(path, "zipformer2-large-en")
 hip, ora = pkg.Model(path, 0), Oracle(path)
 rng = np.random.default_rng(seed0)
-g_exact = g_tot = b_exact = b_tot = forms_differ = 0
+g_exact = op_exact = f_exact = tot = forms_differ = hidden_n = 0
+pkg.set_switch("K2HIP_BEAM_TRACE", 1)
 for k in range(batches):
     B = 32
     secs = [10.0] * B if k % 2 == 0 else [float(rng.uniform(2.0, 10.0)) for _ in range(B)]   # every other batch ragged
@@ -35,18 +45,27 @@ for k in range(batches):
     _, mg = ora.greedy_batch(enc, want_margins=True)
     hip.set_decoding_method("greedy_search")
     g_exact += assert_tokens_match(hip.offline_greedy_from_samples(utts), want, mg, what=f"batch {k} greedy", allow_tie=True)
-    g_tot += B
-    bwant, bmg = ora.modified_beam_search(enc, 4, want_margins=True)
+    bwant, bmg, tr_w = ora.modified_beam_search(enc, 4, want_margins=True, want_trace=True)
+    got_op = hip.beam_search(enc, 4)
+    op_exact += assert_beam_match(got_op, bwant, bmg, tol=TOL, what=f"batch {k} beam 4 operator level", allow_tie=True,
+                                  trace_got=hip.beam_trace(), trace_want=tr_w)
     hip.set_decoding_method("modified_beam_search", 4)
     got = hip.offline_greedy_from_samples(utts)
-    # (the beam's decisions compare SUMS of up to 253 log-probabilities: 2 x the per-logit tolerance for the excuse)
-    b_exact += assert_beam_match(got, bwant, bmg, tol=2e-3, what=f"batch {k} beam 4", allow_tie=True)
+    tr_f = hip.beam_trace()
+    f_exact += assert_beam_match(got, bwant, bmg, tol=TOL, what=f"batch {k} beam 4 fused", allow_tie=True, trace_got=tr_f, trace_want=tr_w)
+    hid = hidden_beam_divergences(got, bwant, tr_f, tr_w)
+    assert all(g < TOL for _, _, g in hid), hid
+    hidden_n += len(hid)
     pkg.set_switch("K2HIP_BEAM_LAUNCHES", 1)   # the four-launches-per-frame form on the same batch: how many streams it decides differently
     try:
         alt = hip.offline_greedy_from_samples(utts)
     finally:
         pkg.set_switch("K2HIP_BEAM_LAUNCHES", 0)
-    forms_differ += sum(1 for x, y in zip(got, alt) if x != y)
-    b_tot += B
-    print(f"batch {k} ({'ragged' if k % 2 else '32 x 10 s'}): greedy {g_exact}/{g_tot}, beam 4 {b_exact}/{b_tot} streams exact so far ({forms_differ} decided differently by the launch form)", flush=True)
+    forms_differ += sum(1 for a, b in zip(got, alt) if a != b)
+    tot += B
+    print(f"batch {k} ({'ragged' if k % 2 else '32 x 10 s'}): greedy {g_exact}/{tot}; beam 4 operator level {op_exact}/{tot}, fused {f_exact}/{tot} "
+          f"streams exact so far; {hidden_n} equal results over parted searches; {forms_differ} decided differently by the launch form", flush=True)
+print(f"every miss localised to a frame whose own oracle gap is < {TOL}:")
+for e in parity.NEAR_TIES:
+    print("  near-tie (what, stream, frame, gap):", e)
 print("soak ok")
