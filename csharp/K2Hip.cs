@@ -51,6 +51,24 @@ namespace K2TransducerAsr.Hip
         [DllImport(Lib)] internal static extern int k2hip_online_stream_get_hyp(IntPtr stream, long[] hyp2);
 
         [DllImport(Lib)] internal static extern int k2hip_model_meta(IntPtr model, string key, byte[] buf, int cap);
+        [DllImport(Lib)] internal static extern int k2hip_set_decoding_method(IntPtr model, string method, int beam);
+
+        // Is this "encoder file" a .k2w weights container (the engine's format) rather than an ONNX file?  Decided by the file's
+        // magic, not by its name, so a renamed container still routes here and an ONNX file never does.  (k2w.py: the file starts
+        // with the ASCII bytes "K2W1".)
+        internal static bool IsK2w(string path)
+        {
+            if (string.IsNullOrEmpty(path) || !System.IO.File.Exists(path)) return false;
+            try
+            {
+                using (var f = System.IO.File.OpenRead(path))
+                {
+                    var magic = new byte[4];
+                    return f.Read(magic, 0, 4) == 4 && magic[0] == (byte)'K' && magic[1] == (byte)'2' && magic[2] == (byte)'W' && magic[3] == (byte)'1';
+                }
+            }
+            catch (System.IO.IOException) { return false; }
+        }
 
         // CustomMetadataMap[key] of the weights container; null when the key is absent (k2hip_model_meta -> K2HIP_ERR_INVALID)
         internal static string Meta(IntPtr model, string key)

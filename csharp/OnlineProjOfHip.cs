@@ -1,6 +1,6 @@
-// IOnlineProj on the MI355X engine: the operator a maintainer selects next to OnlineRecognizer.cs:26-44 when the UNCHANGED
-// ForwardBatchGreedySearch loop (OnlineRecognizer.cs:85-219) is to run against GPU operators.  (The faster route replaces the
-// loop itself: OnlineRecognizer.Hip.patch.cs.)  Lives inside the K2TransducerAsr assembly because the operator methods of
+// IOnlineProj on the MI355X engine: the operator OnlineRecognizer.InitHip (csharp/OnlineRecognizer.Hip.cs) selects for
+// decodingMethod "greedy_search_operators", when the UNCHANGED ForwardBatchGreedySearch loop (OnlineRecognizer.cs:85-219) is to
+// run against GPU operators.  (The faster route replaces the loop itself: OnlineRecognizer.Hip.cs.)  Lives inside the K2TransducerAsr assembly because the operator methods of
 // IOnlineProj are `internal` (IOnlineProj.cs:65-71).  Source only (no dotnet toolchain in the build image); the same call sequence
 // is exercised through ctypes by tests/test_online_gpu.py::test_operator_level_online_proj_runs_the_reference_loop.
 //
@@ -29,6 +29,7 @@ namespace K2TransducerAsr
     internal class OnlineProjOfHip : IOnlineProj, IDisposable
     {
         private IntPtr _model;
+        private readonly bool _ownsModel;
         private K2HipModelInfo _info;
         private OnlineCustomMetadata _customMetadata = new OnlineCustomMetadata();
         private readonly ConditionalWeakTable<float[], HipOnlineState> _states = new ConditionalWeakTable<float[], HipOnlineState>();
@@ -37,6 +38,20 @@ namespace K2TransducerAsr
         public OnlineProjOfHip(string k2wPath, int device = 0)
         {
             K2Hip.Check(K2Hip.k2hip_model_create(k2wPath, null, device, out _model), "OnlineProjOfHip: model load failed");
+            _ownsModel = true;
+            Init();
+        }
+
+        // over a model the recognizer already holds (OnlineRecognizer.InitHip); the recognizer disposes of it
+        internal OnlineProjOfHip(HipOnlineModel model)
+        {
+            _model = model.Handle;
+            _ownsModel = false;
+            Init();
+        }
+
+        private void Init()
+        {
             K2Hip.Check(K2Hip.k2hip_model_get_info(_model, out _info), "OnlineProjOfHip: model info failed");
             K2Hip.Check(K2Hip.k2hip_online_chunk_info(_model, out _chunkLength, out _shiftLength, out _framesPerChunk),
                         "OnlineProjOfHip: not a streaming model");
@@ -129,7 +144,8 @@ namespace K2TransducerAsr
 
         public void Dispose()
         {
-            if (_model != IntPtr.Zero) { K2Hip.k2hip_model_destroy(_model); _model = IntPtr.Zero; }
+            if (_model != IntPtr.Zero && _ownsModel) K2Hip.k2hip_model_destroy(_model);
+            _model = IntPtr.Zero;
         }
         void IOnlineProj.Dispose() => Dispose();
     }

@@ -167,14 +167,45 @@ void Model::parse_config() {
         return it == meta_.end() ? d : (float)atof(it->second.c_str());
     };
     Config& c = cfg_;
-    c.model_type = get("model_type", "");
+    // ---- Model_type as the reference derives it ------------------------------------------------------------------------------
+    // OfflineModel.cs:51-63: Model_type = encoder metadata "model_type" (or ""); a `comment` whose LOWER-CASED text contains both
+    // "ctc" and "zipformer2" overrides it with "zipformer2ctc" (icefall's CTC exports carry model_type "zipformer2" and say "ctc" only
+    // in the comment).  OnlineModel.cs:96-106: the same test WITHOUT the lower-casing, and the result is model_type + "ctc".
+    // OfflineRecognizer.cs:38-53 then routes "zipformer2ctc" to the CTC operator and EVERYTHING else -- unknown and empty strings
+    // included (:50-52) -- to the transducer operator; OnlineRecognizer.cs:26-44 has no default case (an unknown type leaves
+    // _onlineProj null and the first GetResults dereferences it).  The reference's operator is graph-agnostic (the ONNX file is the
+    // graph); here the type also names the encoder graph, so the transducer default is resolved from the architecture keys the
+    // container carries.  The derived value is written back: k2hip_model_meta("model_type") is what CustomMetadata.Model_type holds.
+    const bool streaming_file = get("streaming", "0") == "1";
+    std::string mt = get("model_type", "");
+    {
+        std::string comment = get("comment", "");
+        if (!streaming_file)
+            for (auto& ch : comment) ch = (char)tolower((unsigned char)ch);
+        if (!comment.empty() && comment.find("ctc") != std::string::npos && comment.find("zipformer2") != std::string::npos) {
+            if (!streaming_file) mt = "zipformer2ctc";
+            else if (mt.size() < 3 || mt.compare(mt.size() - 3, 3, "ctc") != 0) mt += "ctc";   // (the reference would make "...ctcctc" of a type that already says ctc and then find no operator for it)
+        }
+    }
+    const bool known = mt == "zipformer2" || mt == "zipformer2ctc" || mt == "zipformer" || mt == "conformer" || mt == "lstm";
+    if (!known) {
+        if (streaming_file)
+            failf(K2HIP_ERR_UNSUPPORTED, "model_type '%s' has no streaming operator (OnlineRecognizer.cs:26-44 knows zipformer, zipformer2, zipformer2ctc, lstm, conformer and has no default case)",
+                  mt.c_str());
+        // OfflineRecognizer.cs:50-52: the transducer operator; which graph, the architecture keys say
+        const char* graph = meta_.count("rnn_hidden_size") ? "lstm" : meta_.count("attention_dims") ? "zipformer" : meta_.count("query_head_dims") ? "zipformer2" : csv_ints(get("encoder_dims", "")).size() == 1 ? "conformer" : nullptr;
+        if (!graph)
+            failf(K2HIP_ERR_UNSUPPORTED, "model_type '%s' routes to the transducer operator (OfflineRecognizer.cs:50-52) but the container's metadata does not say which encoder graph it holds (have: zipformer2, zipformer, conformer, lstm)",
+                  mt.c_str());
+        meta_["model_type_as_given"] = mt;
+        mt = graph;
+    }
+    meta_["model_type"] = mt;
+    c.model_type = mt;
     c.conformer = c.model_type == "conformer";
     c.ctc = c.model_type == "zipformer2ctc";
     c.lstm = c.model_type == "lstm";
     c.zip1 = c.model_type == "zipformer";
-    if (c.model_type != "zipformer2" && !c.conformer && !c.ctc && !c.lstm && !c.zip1)
-        failf(K2HIP_ERR_UNSUPPORTED, "model_type '%s' is not supported (have: zipformer2, zipformer2ctc, zipformer, conformer, lstm)",
-              c.model_type.c_str());
     auto fill = [&](const char* k, int* dst) {
         auto v = csv_ints(get(k, ""));
         if ((int)v.size() > kMaxStacks) failf(K2HIP_ERR_INVALID, "metadata %s has too many entries", k);

@@ -282,12 +282,27 @@ int errors(const char* path) {
     return 0;
 }
 
+// k2hip_model_create + k2hip_model_meta(key): how csrc/model.cpp derives CustomMetadata values from a container's metadata map
+// (prints "<value>" or "ERR <code> <message>")
+int meta(const char* path, const char* key) {
+    k2hip_model_t* m = nullptr;
+    int32_t rc = k2hip_model_create(path, nullptr, 0, &m);
+    if (rc) { printf("ERR %d %s\n", rc, k2hip_last_error()); return 0; }
+    char buf[512];
+    rc = k2hip_model_meta(m, key, buf, sizeof buf);
+    if (rc) printf("ERR %d %s\n", rc, k2hip_last_error());
+    else printf("%s\n", buf);
+    k2hip_model_destroy(m);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
+    if (argc >= 4 && !strcmp(argv[1], "meta")) return meta(argv[2], argv[3]);
     if (argc >= 5 && !strcmp(argv[1], "online")) return online(argv[2], strtoull(argv[3], nullptr, 10), atoi(argv[4]));
     if (argc >= 5 && !strcmp(argv[1], "offline")) return offline(argv[2], strtoull(argv[3], nullptr, 10), atoi(argv[4]));
     if (argc >= 3 && !strcmp(argv[1], "errors")) return errors(argv[2]);
-    fprintf(stderr, "usage: san_api_driver online|offline <model.k2w> <seed> <rounds> | errors <streaming.k2w>\n");
+    fprintf(stderr, "usage: san_api_driver online|offline <model.k2w> <seed> <rounds> | errors <streaming.k2w> | meta <model.k2w> <key>\n");
     return 2;
 }

@@ -137,3 +137,55 @@ def test_offline_stream_and_pipeline_paths(api_driver, tiny_model_path):
     second wait refused, decoder / joiner operators (OfflineStream.cs:43-68, OfflineRecognizer.cs:77-91)."""
     out = run(api_driver, "offline", tiny_model_path, "7", "60")
     assert out.startswith("offline ok: 60 rounds")
+
+
+def test_model_type_is_derived_as_the_reference_derives_it(api_driver, tiny_model_path, streaming_tiny_path, tmp_path):
+    """CustomMetadata.Model_type as OfflineModel.cs:51-63 / OnlineModel.cs:96-106 compute it and OfflineRecognizer.cs:38-53 /
+    OnlineRecognizer.cs:26-44 route it, through the real csrc/model.cpp (k2hip_model_create + k2hip_model_meta):
+      * offline: a comment whose lower-cased text holds "ctc" and "zipformer2" makes a model_type "zipformer2" container a
+        zipformer2ctc one (how icefall's CTC exports look); case-insensitive;
+      * online: the same test is case-SENSITIVE and appends "ctc" to the type;
+      * offline: an unknown or empty model_type routes to the transducer operator (:50-52) -- the graph comes from the architecture keys;
+      * online: no default case -- an unknown type is refused with the reason."""
+    from k2transducerasr_amd.k2w import read_k2w, write_k2w
+    from k2transducerasr_amd.synth import write_synthetic_model
+
+    def variant(src, name, **changes):
+        meta, tensors = read_k2w(src)
+        for k, v in changes.items():
+            if v is None:
+                meta.pop(k, None)
+            else:
+                meta[k] = v
+        p = str(tmp_path / f"{name}.k2w")
+        write_k2w(p, meta, tensors.items())
+        return p
+
+    ctc_src = str(tmp_path / "ctc.k2w")
+    write_synthetic_model(ctc_src, "zipformer2-ctc-tiny-test")
+    ctc_stream_src = str(tmp_path / "ctc_stream.k2w")
+    write_synthetic_model(ctc_stream_src, "zipformer2-ctc-streaming-tiny-test")
+    mt = lambda p: run(api_driver, "meta", p, "model_type")   # noqa: E731
+    # offline CTC export: model_type zipformer2, the comment says ctc
+    assert mt(variant(ctc_src, "a", model_type="zipformer2", comment="streaming ctc zipformer2")) == "zipformer2ctc"
+    assert mt(variant(ctc_src, "b", model_type="zipformer2", comment="CTC head, Zipformer2 encoder")) == "zipformer2ctc"     # ToLower (:59)
+    assert mt(variant(ctc_src, "c", model_type="", comment="zipformer2 + ctc")) == "zipformer2ctc"
+    # the comment does not say both words: the transducer type stands
+    assert mt(variant(tiny_model_path, "d", model_type="zipformer2", comment="zipformer2 transducer")) == "zipformer2"
+    assert mt(variant(tiny_model_path, "e", model_type="zipformer2", comment="ctc only")) == "zipformer2"
+    # unknown / empty / absent model_type: OfflineRecognizer.cs:50-52's default operator; the graph from the architecture keys
+    for i, given in enumerate(["", "zipformer2_v9", None]):
+        p = variant(tiny_model_path, f"f{i}", model_type=given, comment="")
+        assert mt(p) == "zipformer2"
+        if given:
+            assert run(api_driver, "meta", p, "model_type_as_given") == given
+    conf = str(tmp_path / "conf.k2w")
+    write_synthetic_model(conf, "conformer-tiny-test")
+    assert mt(variant(conf, "g", model_type="", comment="")) == "conformer"
+    # online: case-sensitive (OnlineModel.cs:103), model_type + "ctc"
+    assert mt(variant(ctc_stream_src, "h", model_type="zipformer2", comment="streaming ctc zipformer2")) == "zipformer2ctc"
+    assert mt(variant(streaming_tiny_path, "i", model_type="zipformer2", comment="Streaming CTC Zipformer2")) == "zipformer2"     # no ToLower online
+    assert mt(variant(ctc_stream_src, "j", model_type="zipformer2ctc", comment="")) == "zipformer2ctc"
+    # online: OnlineRecognizer.cs:26-44 has no default case
+    out = mt(variant(streaming_tiny_path, "k", model_type="", comment=""))
+    assert out.startswith("ERR -6") and "no default case" in out
