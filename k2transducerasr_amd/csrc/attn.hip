@@ -473,7 +473,9 @@ __global__ __launch_bounds__(256) void k_attn_av_out(const float* __restrict__ a
 //      16-column tile, the weight row of a lane as float4 (keys contiguous), the ring values as scalars (L2);
 //   C. x[T, D] += ctx . wout^T + bias: the column tiles of this slice over the four waves, K = Hc walked in 64-deep trips.
 // Every slice of a stream repeats 0 and A (identical values: benign), as in k_attn_av_out.
-template <int NS, int NT>  // NS = 64-key steps (all of a tile's loads are issued before its first MFMA), NT = threads
+// MULTI: more than NS steps of keys (KL > 256, e.g. left_context_len 256 + the chunk): trips of NS steps each, a trip's loads issued
+// together, the accumulators carried across trips
+template <int NS, int NT, bool MULTI = false>  // NS = 64-key steps (all of a tile's loads are issued before its first MFMA), NT = threads
 __global__ __launch_bounds__(NT) void k_nonlin_av_out(const float* __restrict__ aw, const float* __restrict__ hid, int ldh,
                                                       const float* __restrict__ wout, const float* __restrict__ bias,
                                                       float* __restrict__ x, int B, int T, int KL, int Tp, int Hc, int D,
@@ -503,18 +505,21 @@ __global__ __launch_bounds__(NT) void k_nonlin_av_out(const float* __restrict__ 
     for (int ct = wave; ct * 16 < Hc; ct += NWV) {
         const bool cok = ct * 16 + n < Hc;  // (Hc % 16 != 0: the last tile is partial)
         const float* vb = rb + (long long)(4 * kq) * Hc + (cok ? ct * 16 + n : 0);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const int trips = MULTI ? (KL + 64 * NS - 1) / (64 * NS) : 1;
+        for (int tr = 0; tr < trips; tr++) {
+        const int k0 = 64 * NS * tr;
         float4 a4[NS][4];
         float bv[NS][4][4];
 #pragma unroll
         for (int s = 0; s < NS; s++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                const int kb = 64 * s + 16 * g + 4 * kq;
-                a4[s][g] = kb < Tp ? *reinterpret_cast<const float4*>(arow + 64 * s + 16 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int kb = k0 + 64 * s + 16 * g + 4 * kq;
+                a4[s][g] = kb < Tp ? *reinterpret_cast<const float4*>(arow + k0 + 64 * s + 16 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int m = 0; m < 4; m++) bv[s][g][m] = (cok && kb + m < KL) ? vb[(long long)(64 * s + 16 * g + m) * Hc] : 0.f;
+                for (int m = 0; m < 4; m++) bv[s][g][m] = (cok && kb + m < KL) ? vb[(long long)(k0 + 64 * s + 16 * g + m) * Hc] : 0.f;
             }
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < NS; s++)
 #pragma unroll
@@ -531,6 +536,7 @@ __global__ __launch_bounds__(NT) void k_nonlin_av_out(const float* __restrict__ 
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s][g].w, bv[s][g][3], acc0, 0, 0, 0);
                 }
             }
+        }
         // C layout: col = lane & 15, row = 4 * (lane >> 4) + e; the gate y of (row, col) multiplies here; rows >= T hold zeros
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -677,6 +683,12 @@ void nonlin_av_out_ring(const Ctx& ctx, const float* aw, const RingRef& cache, c
     K2_REQUIRE(Hc % 4 == 0 && D % 16 == 0 && Tp % 4 == 0 && Tp >= KL && T <= 16 && ldh % 4 == 0 && ldh >= 3 * Hc,
                "nonlin_av_out_ring: shape Hc=%d D=%d T=%d KL=%d unsupported", Hc, D, T, KL);
     ctx.add_flops(0.0, 2.0 * B * (double)T * Hc * (KL + D), 0);
+    // (every shape check sits in front of the dry return: a call sizes its arena with a dry pass before its first launch, so a shape
+    // the kernel cannot take is refused before any layer has advanced a cache in place)
+    const size_t lds = sizeof(float) * 16 * (((Hc + 15) & ~15) + 4);
+    K2_REQUIRE(lds <= 64 * 1024, "nonlin_av_out_ring: Hc=%d too wide", Hc);
+    const int ns = (KL + 63) / 64;
+    K2_REQUIRE(ns >= 1, "nonlin_av_out_ring: no keys");
     if (ctx.dry) return;
     const int ntile = D / 16;
     int cs = std::max(1, std::min(4, 512 / std::max(1, B)));
@@ -684,10 +696,6 @@ void nonlin_av_out_ring(const Ctx& ctx, const float* aw, const RingRef& cache, c
     if (!wout) cs = 1;  // context rows only: nothing to slice
     const int tiles_per_z = cdiv(ntile, cs);
     cs = cdiv(ntile, tiles_per_z);
-    const size_t lds = sizeof(float) * 16 * (((Hc + 15) & ~15) + 4);
-    K2_REQUIRE(lds <= 64 * 1024, "nonlin_av_out_ring: Hc=%d too wide", Hc);
-    const int ns = (KL + 63) / 64;
-    K2_REQUIRE(ns >= 1 && ns <= 4, "nonlin_av_out_ring: %d keys unsupported (<= 256)", KL);
     // 16-column tiles of the context over the waves: 16 waves when there are that many tiles (the 50 / 25 Hz stacks), else 8
     const bool wide = (Hc + 15) / 16 > 8;
 #define K2_NONLIN_LAUNCH(NS_, NT_)                                                                                                   \
@@ -697,7 +705,11 @@ void nonlin_av_out_ring(const Ctx& ctx, const float* aw, const RingRef& cache, c
         case 1: if (wide) K2_NONLIN_LAUNCH(1, 1024); else K2_NONLIN_LAUNCH(1, 512); break;
         case 2: if (wide) K2_NONLIN_LAUNCH(2, 1024); else K2_NONLIN_LAUNCH(2, 512); break;
         case 3: if (wide) K2_NONLIN_LAUNCH(3, 1024); else K2_NONLIN_LAUNCH(3, 512); break;
-        default: K2_NONLIN_LAUNCH(4, 512); break;  // (193 .. 256 keys: 16 waves would spill)
+        case 4: K2_NONLIN_LAUNCH(4, 512); break;  // (193 .. 256 keys: 16 waves would spill)
+        default:                                   // > 256 keys (left_context_len >= 256): trips of 4 steps
+            hipLaunchKernelGGL((k_nonlin_av_out<4, 512, true>), dim3(1, B, cs), dim3(512), lds, ctx.stream, aw, hid, ldh, wout, bias, x, B, T, KL,
+                               Tp, Hc, D, tiles_per_z, cache);
+            break;
     }
 #undef K2_NONLIN_LAUNCH
     K2_HIP(hipGetLastError());

@@ -225,6 +225,33 @@ def test_left_context_shorter_than_chunk(tmp_path_factory):
                 np.testing.assert_allclose(h.state(l, kind), o.state(l, kind), atol=2e-4, rtol=0, err_msg=f"layer {l} {kind}")
 
 
+def test_left_context_256_and_longer(tmp_path_factory):
+    """left_context_len 256 on the first stack: keys = 256 + 16 = 272 per chunk, more than the 256 the fused NonlinAttention kernel
+    (k_nonlin_av_out) takes in one trip of loads -- an exported model with such a left context must decode (trips of 4 x 64 keys),
+    not be refused on its first chunk after earlier layers have already moved their caches.  The other stacks follow at their rates (128 / 64 / 128)."""
+    from k2transducerasr_amd import OnlineRecognizer
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    from oracle.online import OnlineOracle
+    p = str(tmp_path_factory.mktemp("longleft") / "m.k2w")
+    write_synthetic_model(p, "zipformer2-streaming-tiny-test", meta_overrides={"left_context_len": "256,128,64,128"})
+    rec, ora = OnlineRecognizer(p), OnlineOracle(p)
+    feats = [ora.fbank(synth_utterance(95 + u, 1.4)) for u in range(2)]
+    hs = [rec.create_online_stream() for _ in feats]
+    os_ = [ora.create_stream() for _ in feats]
+    for h, f in zip(hs, feats):
+        h.add_features(f)
+    T, S = rec.chunk_length, rec.shift_length
+    for k in range((feats[0].shape[0] - T) // S + 1):
+        rec.get_results(hs)
+        ora.step(os_, [f[k * S : k * S + T] for f in feats])
+        for h, o in zip(hs, os_):
+            assert h.tokens == o.tokens and h.timestamps == o.timestamps
+    for h, o in zip(hs, os_):
+        for l in range(o.num_layers):
+            for kind in KINDS:
+                np.testing.assert_allclose(h.state(l, kind), o.state(l, kind), atol=2e-4, rtol=0, err_msg=f"layer {l} {kind}")
+
+
 def test_streaming_128_concurrent_slots_zh(tmp_path_factory):
     """BASELINE configs[3] at its own size: 128 concurrent streams of the zipformer-multi-zh-hans streaming architecture in one
     GetResults call per chunk (pool growth past its first allocation, 128-row launches, every slot live).  Streams 0 and 77 are
