@@ -97,6 +97,7 @@ class Arena {
     int64_t mark() const { return off_; }
     void rewind(int64_t m) { off_ = m; }
     int64_t capacity() const { return cap_; }
+    const void* base() const { return base_; }
     int64_t high_water() const { return high_; }
 
   private:

@@ -49,6 +49,7 @@ Engine::~Engine() {
         if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
         sl.arena.release();
     }
+    graphs_clear();
     if (stream2_) (void)hipStreamDestroy(stream2_);
     for (auto& kv : pe_cache_) (void)hipFree(kv.second);
     for (auto& kv : pp_cache_) (void)hipFree(kv.second);
@@ -302,8 +303,8 @@ const float* Engine::pos_proj_cached(const Ctx& c, int layer, const float* pe, i
     const size_t bytes = sizeof(float) * (size_t)rows * ncols;
     if (pp_cache_bytes_ + bytes > ((size_t)1 << 30)) {  // many distinct utterance lengths: start over (stream-ordered frees)
         K2_HIP(hipDeviceSynchronize());
+        graphs_clear();   // instantiated graphs hold these pointers
         for (auto& kv : pp_cache_) (void)hipFree(kv.second);
-    for (auto& kv : sinus_cache_) (void)hipFree(kv.second);
         pp_cache_.clear();
         pp_cache_bytes_ = 0;
     }
@@ -573,6 +574,23 @@ float* Engine::encoder_forward(const Ctx& c, const float* x, int B, int T, int* 
 // The decoder outputs of the two contexts every offline greedy search starts from are constants of the model: computed once (by the
 // search kernel's own routine), then shared by the t0 pre-pass and every search workgroup (a 70 us single-workgroup launch per
 // batch, and two decoder passes at the head of every search workgroup before).
+void Engine::graphs_clear() {
+    for (auto& kv : graphs_)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    graphs_.clear();
+}
+
+// the encoder pass of the fused entries: one chain of ~400 launches whose every argument follows from (model, B, T, arena) -- replayed
+// as a hipGraph once the same shape has been seen twice (Engine::graphed)
+float* Engine::encoder_forward_graphed(const Ctx& c, const float* d_x, int B, int T, int* Tp) {
+    GraphKey gk;
+    gk.kind = 2; gk.B = B; gk.T = T;
+    gk.p0 = d_x;
+    float* enc = nullptr;
+    graphed(c, gk, [&](const Ctx& g) { enc = encoder_forward(g, d_x, B, T, Tp, -1, nullptr, nullptr, nullptr); });
+    return enc;
+}
+
 const float* Engine::decoder_start(const Ctx& c) {
     if (c.dry) return d_dec_start_;
     if (!d_dec_start_) {
@@ -1042,7 +1060,7 @@ void Engine::offline_greedy_samples_dev(const float* samples_dev, int64_t n_each
         pad_logfloor_dense(c, d_feats, n_fl, d_x, B, L);
         if (!c.dry) K2_HIP(hipEventRecord(ev_[2], c.stream));
         int Tp = 0;
-        float* enc = encoder_forward(c, d_x, B, T, &Tp, -1, nullptr, nullptr, nullptr);
+        float* enc = encoder_forward_graphed(c, d_x, B, T, &Tp);
         if (!c.dry) K2_HIP(hipEventRecord(ev_[3], c.stream));
         greedy_device(c, enc, B, Tp, false, d_tok, d_ts, d_n, max_tokens, d_ovf);
         if (!c.dry) K2_HIP(hipEventRecord(ev_[4], c.stream));
@@ -1151,7 +1169,7 @@ int Engine::submit_impl(const float* samples_dev, const float* samples_host, int
             fbank(c, a);
             pad_logfloor_dense(c, d_feats, n_fl, d_x, B, L);
             int Tp = 0;
-            float* enc = encoder_forward(c, d_x, B, T, &Tp, -1, nullptr, nullptr, nullptr);
+            float* enc = encoder_forward_graphed(c, d_x, B, T, &Tp);
             Ctx cd = c;
             cd.stream = s2;
             cd.instrument = false;

@@ -489,27 +489,35 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
             K2_HIP(hipEventRecord(ev_[0], c.stream));
             K2_HIP(hipMemcpyAsync(d_in, stage, (size_t)in_bytes, hipMemcpyHostToDevice, c.stream));
         }
+        // everything between the upload and the download is the same chain of launches for every tick with this many streams
+        // (slots, ring heads, processed lengths and contexts are DATA in the uploaded block): replayed as a hipGraph
+        GraphKey gk;
+        gk.kind = 1; gk.B = B; gk.T = from_fifo ? 1 : 0; gk.extra = tunables().search_rounds;
+        gk.p0 = online_pool_; gk.p1 = online_fifo_;
+        const int launches_before = graph_launches_;
+        auto chain = [&](const Ctx& c) {
+        const bool ev_ok = !c.dry && !c.capturing;
         if (from_fifo) fifo_gather(c, online_fifo_, kFifoFrames, cf.feat, d_slots, d_heads, d_x, B, T);
         logfloor_inplace(c, d_x, (long long)B * T * cf.feat);  // online PadSequence (PadHelper.cs:9-13,58)
         if (cf.lstm || cf.conformer || cf.zip1) {
             int tc = Tp;
             float* enc = cf.lstm ? lstm_chunk(c, d_x, d_slots, B) : cf.zip1 ? zip1_chunk(c, d_x, d_slots, B, &tc) : conformer_chunk(c, d_x, d_slots, d_plen, B, &tc);
             K2_REQUIRE(tc == Tp, "internal: chunk yields %d frames, expected %d", tc, Tp);
-            if (!c.dry) K2_HIP(hipEventRecord(ev_[3], c.stream));
+            if (ev_ok) K2_HIP(hipEventRecord(ev_[3], c.stream));
             GreedyArgs a;
             a.enc = enc; a.B = B; a.Tp = Tp; a.t0 = nullptr; a.skip1 = 1; a.max_sym = INT_MAX;
             a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = Tp; a.overflow = d_ovf; a.init_ctx = d_hyp;
             if (tunables().search_rounds == 0) greedy_loop(c, decjoin(), a);
             else greedy_rounds(c, decjoin(), model_->w("joiner.output_linear.weight"), a);
-            if (!c.dry) K2_HIP(hipEventRecord(ev_[4], c.stream));
+            if (ev_ok) K2_HIP(hipEventRecord(ev_[4], c.stream));
             return;
         }
         float* enc = online_encoder_zip2(c, d_x, d_slots, d_plen, d_chunks, B);
-        if (!c.dry) K2_HIP(hipEventRecord(ev_[3], c.stream));
+        if (ev_ok) K2_HIP(hipEventRecord(ev_[3], c.stream));
         if (cf.ctc) {
             // OnlineRecognizer.ForwardBatchGreedySearchCTC (:220-313): per-chunk CTC collapse, prev_id reset per chunk
             ctc_device(c, enc, B, Tp, d_tok, d_ts, d_n, Tp, d_ovf);
-            if (!c.dry) K2_HIP(hipEventRecord(ev_[4], c.stream));
+            if (ev_ok) K2_HIP(hipEventRecord(ev_[4], c.stream));
             return;
         }
         // OnlineRecognizer.cs:135-202: decoder on the streams' hyps, T' joiner steps, skip {blank, unk, 1}
@@ -518,7 +526,15 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
         a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = Tp; a.overflow = d_ovf; a.init_ctx = d_hyp;
         if (tunables().search_rounds == 0) greedy_loop(c, decjoin(), a);
             else greedy_rounds(c, decjoin(), model_->w("joiner.output_linear.weight"), a);
-        if (!c.dry) K2_HIP(hipEventRecord(ev_[4], c.stream));
+        if (ev_ok) K2_HIP(hipEventRecord(ev_[4], c.stream));
+        };
+        // (the persistent search kernel notes its launch for the one-part retry: a host-side effect a replay would skip)
+        if (tunables().search_rounds != 0) graphed(c, gk, chain);
+        else chain(c);
+        if (!c.dry && graph_launches_ != launches_before) {   // a replayed tick has no stamps inside: the whole step counts as encoder time
+            K2_HIP(hipEventRecord(ev_[3], c.stream));
+            K2_HIP(hipEventRecord(ev_[4], c.stream));
+        }
     });
     finish_tokens(d_tok, d_ts, d_n, d_ovf, B, Tp, tokens, ts, n_tokens);
     auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, ev_[a], ev_[b]); return ms; };

@@ -1,0 +1,81 @@
+"""hipGraph replay of the encoder passes (Engine::graphed): the first call with a shape is enqueued eagerly, the second is captured,
+later ones replay the instance.  A replay must be the same computation -- same tokens, same encoder output bits -- as the eager
+chain, for the offline batch entries (synchronous and pipelined) and for the streaming tick, and a changed shape / pool must not
+hit a stale instance."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def graph_launches(model):
+    from k2transducerasr_amd import load_library
+    L = load_library()
+    L.k2hip_debug_graph_launches.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    n = C.c_int32(0)
+    assert L.k2hip_debug_graph_launches(model.handle, C.byref(n)) == 0
+    return n.value
+
+
+def test_offline_replays_equal_the_eager_chain(tiny_model_path, oracle_tiny):
+    from k2transducerasr_amd import Model, set_switch
+    from k2transducerasr_amd.synth import synth_utterance
+    m = Model(tiny_model_path, 0)
+    a = np.stack([synth_utterance(50 + u, 1.2) for u in range(4)])
+    b = np.stack([synth_utterance(60 + u, 0.9) for u in range(3)])     # another shape in between
+    pa, pb = m.device_alloc(a.nbytes), m.device_alloc(b.nbytes)
+    m.device_upload(pa, a)
+    m.device_upload(pb, b)
+    set_switch("K2HIP_NO_GRAPHS", 1)
+    try:
+        want_a = m.offline_greedy_from_samples_dev(pa, a.shape[1], 4)
+        want_b = m.offline_greedy_from_samples_dev(pb, b.shape[1], 3)
+    finally:
+        set_switch("K2HIP_NO_GRAPHS", 0)
+    assert graph_launches(m) == 0
+    feats = [oracle_tiny.fbank(u) for u in a]
+    assert want_a == oracle_tiny.recognize_batch(feats)
+    n0 = graph_launches(m)
+    for k in range(5):          # eager, captured + launched, replayed ...
+        assert m.offline_greedy_from_samples_dev(pa, a.shape[1], 4) == want_a, k
+        assert m.offline_greedy_from_samples_dev(pb, b.shape[1], 3) == want_b, k
+    assert graph_launches(m) - n0 >= 6, "the encoder passes were not replayed from graphs"
+    # the pipelined entries: each slot has its own arena, hence its own instance
+    n1 = graph_launches(m)
+    for k in range(4):
+        t1 = m.offline_submit_samples_dev(pa, a.shape[1], 4)
+        t2 = m.offline_submit_samples_dev(pa, a.shape[1], 4)
+        assert m.offline_wait(t1) == want_a and m.offline_wait(t2) == want_a, k
+    assert graph_launches(m) > n1
+    m.device_free(pa)
+    m.device_free(pb)
+    m.close()
+
+
+def test_streaming_ticks_replay_and_follow_the_oracle(tmp_path):
+    """ticks with the same number of ready streams replay one instance; the streams' slots, ring heads and contexts are data, so the
+    instance serves whichever streams are ready -- tokens and caches stay on the oracle's, chunk by chunk"""
+    from k2transducerasr_amd import OnlineRecognizer
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    from oracle.online import OnlineOracle
+    p = str(tmp_path / "s.k2w")
+    write_synthetic_model(p, "zipformer2-streaming-tiny-test")
+    rec, ora = OnlineRecognizer(p), OnlineOracle(p)
+    feats = [ora.fbank(synth_utterance(70 + u, 2.6)) for u in range(3)]
+    hs = [rec.create_online_stream() for _ in feats]
+    os_ = [ora.create_stream() for _ in feats]
+    for h, f in zip(hs, feats):
+        h.add_features(f)
+    T, S = rec.chunk_length, rec.shift_length
+    nchunks = (feats[0].shape[0] - T) // S + 1
+    assert nchunks >= 6
+    for k in range(nchunks):
+        rec.get_results(hs)
+        ora.step(os_, [f[k * S: k * S + T] for f in feats])
+        for h, o in zip(hs, os_):
+            assert h.tokens == o.tokens and h.timestamps == o.timestamps, k
+    assert graph_launches(rec.model) >= nchunks - 2
+    for h, o in zip(hs, os_):
+        np.testing.assert_allclose(h.state(0, "key"), o.state(0, "key"), atol=2e-4, rtol=0)
