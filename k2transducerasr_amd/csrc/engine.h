@@ -119,6 +119,7 @@ class Engine {
     int beam() const { return beam_; }
     const std::vector<int>& last_trail() const { return last_trail_; }
     const std::vector<int>& last_any() const { return last_any_; }
+    int graph_launches() const { return graph_launches_; }   // hipGraph replays since the model was created (k2hip_debug_graph_launches)
     const std::vector<float>& last_scores() const { return last_scores_; }
     // K2HIP_BEAM_TRACE: [B][Tp][2 beam + 1] words of the last synchronous beam search (BeamArgs::trace), and its B / Tp / beam
     const std::vector<int>& last_beam_trace(int* B, int* Tp, int* K) const {
@@ -207,9 +208,9 @@ class Engine {
     struct GraphKey {
         int kind = 0, B = 0, T = 0, extra = 0;
         const void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *stream = nullptr;
-        int64_t cap = 0;
+        int64_t cap = 0, off = 0;   // the arena's capacity and the offset the chain starts at: every pointer it takes follows from them
         bool operator<(const GraphKey& o) const {
-            return std::tie(kind, B, T, extra, p0, p1, p2, stream, cap) < std::tie(o.kind, o.B, o.T, o.extra, o.p0, o.p1, o.p2, o.stream, o.cap);
+            return std::tie(kind, B, T, extra, p0, p1, p2, stream, cap, off) < std::tie(o.kind, o.B, o.T, o.extra, o.p0, o.p1, o.p2, o.stream, o.cap, o.off);
         }
     };
     struct GraphEntry {
@@ -221,7 +222,7 @@ class Engine {
     void graphed(const Ctx& c, GraphKey key, F&& enqueue);
     void graphs_clear();
     float* encoder_forward_graphed(const Ctx& c, const float* d_x, int B, int T, int* Tp);
-    int graph_launches() const { return graph_launches_; }
+
     int submit_impl(const float* samples_dev, const float* samples_host, int64_t n_each, int B, int max_tokens);
     void finish_tokens(const long long* d_tok, const int* d_ts, const int* d_n, const int* d_ovf, int B, int max_tokens,
                        int64_t* tokens, int32_t* ts, int32_t* n_tokens);
@@ -321,6 +322,7 @@ void Engine::graphed(const Ctx& c, GraphKey key, F&& enqueue) {
     key.stream = c.stream;
     key.p2 = key.p2 ? key.p2 : c.arena->base();
     key.cap = c.arena->capacity();
+    key.off = c.arena->mark();
     auto it = graphs_.find(key);
     if (it == graphs_.end()) {
         if (graphs_.size() >= 24) {   // shapes come and go (ragged batches): drop the least recently used instance
