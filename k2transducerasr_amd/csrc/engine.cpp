@@ -580,12 +580,16 @@ void Engine::graphs_clear() {
     graphs_.clear();
 }
 
-// the encoder pass of the fused entries: one chain of ~400 launches whose every argument follows from (model, B, T, arena) -- replayed
-// as a hipGraph once the same shape has been seen twice (Engine::graphed)
+// the encoder pass of the fused entries: one chain of ~400 launches whose every argument follows from (model, B, T, arena) -- under
+// K2HIP_GRAPH_OFFLINE replayed as a hipGraph once the same shape has been seen twice (Engine::graphed).  Off by default: measured
+// on the headline batch it is 0.1 ms SLOWER (13.87 against 13.76 ms) -- a dependent launch costs 2.8 us eagerly and 1.7 us from a
+// graph when the kernels are empty, but behind a 20 - 80 us kernel the next launch's enqueue is already hidden
+// (tools/probes/graph_chain_probe.hip: 33.04 against 32.78 us per step).  The streaming tick (10 us kernels) keeps its graph.
 float* Engine::encoder_forward_graphed(const Ctx& c, const float* d_x, int B, int T, int* Tp) {
     GraphKey gk;
     gk.kind = 2; gk.B = B; gk.T = T;
     gk.p0 = d_x;
+    if (!tunables().graph_offline) return encoder_forward(c, d_x, B, T, Tp, -1, nullptr, nullptr, nullptr);
     float* enc = nullptr;
     graphed(c, gk, [&](const Ctx& g) { enc = encoder_forward(g, d_x, B, T, Tp, -1, nullptr, nullptr, nullptr); });
     return enc;

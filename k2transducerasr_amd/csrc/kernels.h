@@ -30,7 +30,9 @@ struct Tunables {
     int beam_hyp_global = 0;      // K2HIP_BEAM_HYP_GLOBAL: the one-kernel beam search keeps its hypotheses in device memory even when they fit in LDS (the long-utterance form, for its test)
     int decoder_table_mb = 1024;  // K2HIP_DECODER_TABLE_MB: build the all-contexts decoder table when it fits this many MiB (0 = never)
     int beam_trace = 0;           // K2HIP_BEAM_TRACE: the modified beam search records its per-frame selection (k2hip_debug.h: k2hip_debug_beam_trace)
-    int no_graphs = 0;            // K2HIP_NO_GRAPHS: every launch enqueued eagerly (no hipGraph replay of the encoder passes)
+    int no_graphs = 0;            // K2HIP_NO_GRAPHS: every launch enqueued eagerly (no hipGraph replay of the streaming tick)
+    int graph_offline = 0;        // K2HIP_GRAPH_OFFLINE: 1 = the offline batch entries replay their encoder pass from a hipGraph too (measured:
+                                  // 13.87 against 13.76 ms per headline batch -- launches of 20 - 80 us hide their own enqueue cost; off by default)
     int test_greedy_timeout = 0;  // K2HIP_TEST_GREEDY_TIMEOUT: test hook -- every parts > 1 search reports an exchange timeout, so the one-part retry runs
     int pipe_mode = 0;            // K2HIP_PIPE_MODE: 1 = every pipeline slot owns a stream
     int max_streams = 0;          // K2HIP_MAX_STREAMS: slots of the streaming state pool (0 = 256)

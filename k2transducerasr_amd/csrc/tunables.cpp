@@ -41,6 +41,7 @@ const Entry kEntries[] = {
     {"K2HIP_BEAM_PARTS", &Tunables::beam_parts, false},
     {"K2HIP_BEAM_TRACE", &Tunables::beam_trace, true},
     {"K2HIP_NO_GRAPHS", &Tunables::no_graphs, true},
+    {"K2HIP_GRAPH_OFFLINE", &Tunables::graph_offline, false},
     {"K2HIP_TEST_GREEDY_TIMEOUT", &Tunables::test_greedy_timeout, true},
     {"K2HIP_SEARCH_ROUNDS", &Tunables::search_rounds, false},
     {"K2HIP_PIPE_MODE", &Tunables::pipe_mode, false},
