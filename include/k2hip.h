@@ -19,6 +19,12 @@
  *     serialised by an internal mutex, different handles run concurrently.
  *   - there is NO CPU fallback: every compute entry point needs a gfx950 device
  *     and fails with K2HIP_ERR_NO_DEVICE otherwise.
+ *   - memory: a handle holds, on its device, the model's weights (the .k2w file's size), a grow-only arena per pipeline slot
+ *     (~1.1 GB each for 32 x 10 s of zipformer2-large), the streaming state pool (1.85 MB per stream for the medium model) and --
+ *     for vocabularies up to ~700 -- the decoder's output for EVERY two-token context, (V + 1) * V * joiner_dim floats (0.5 GB at
+ *     V = 500, J = 512), built inside k2hip_model_create (~3 ms of GPU time).  N handles on one GPU hold N copies.  The environment
+ *     variable K2HIP_DECODER_TABLE_MB caps the table (default 1024; 0 = never build it: the searches then run the decoder after
+ *     every emission, ~1.7x slower per search, same tokens).
  */
 #ifndef K2HIP_H
 #define K2HIP_H
@@ -103,7 +109,8 @@ int32_t k2hip_model_get_info(const k2hip_model_t* model, k2hip_model_info* info)
 int32_t k2hip_model_meta(const k2hip_model_t* model, const char* key, char* buf, int32_t cap);
 int32_t k2hip_set_instrument(k2hip_model_t* model, int32_t on);
 /* per-launch table of the last instrumented call: rows of 8 floats (M, N, K, batch, act, has_residual, kind, microseconds);
- * kind: 0 plain, 1 conv gather, 2 [K,N] operand, +16 = LDS-DMA kernel.  rows == NULL only queries n_rows. */
+ * kind & 3: 0 plain, 1 conv gather, 2 [K,N] operand; +16 LDS-DMA kernel, +32 skinny kernel, +64 ring kernel, +128 pipelined kernel
+ * with its tile in the bits above (BM / 32 in bits 8-11, BN / 32 in bits 12-15).  rows == NULL only queries n_rows. */
 int32_t k2hip_get_gemm_profile(k2hip_model_t* model, float* rows, int32_t cap_rows, int32_t* n_rows);
 int32_t k2hip_get_timing(const k2hip_model_t* model, k2hip_timing* timing);
 

@@ -690,22 +690,31 @@ int32_t k2hip_online_step(k2hip_model_t* model, k2hip_online_stream_t* const* st
         if (idx.empty()) return;   // :113-116
         // the new frames' host copy is collected after the step (one wait for the device per tick); whatever way this call ends -- an
         // allocation failure below included -- the outstanding download is collected before the streams' Speech can move
+        // If the collection itself fails (the device work behind the download did), the streams whose Speech was extended with
+        // placeholder frames for it are poisoned: their FIFOs hold zeros where audio should be, and a later step must not decode them.
         struct GatherFinisher {
             Engine& e;
+            std::vector<k2hip_online_stream*> owners;   // the streams whose frames the outstanding download carries
             bool armed = false;
             void finish() {
                 if (!armed) return;
                 armed = false;
-                EngineLock lk(e);
-                e.fbank_gather_finish();
+                try {
+                    EngineLock lk(e);
+                    e.fbank_gather_finish();
+                } catch (...) {
+                    for (k2hip_online_stream* s : owners) s->poisoned = true;
+                    throw;
+                }
             }
             ~GatherFinisher() {
-                try { finish(); } catch (...) {}
+                try { finish(); } catch (...) {}   // (already unwinding, or the caller is done: the streams are poisoned, the error of record is the first one)
             }
         } fb{e};
         {   // the deferred fbank of the streams that decode now: one batched launch when they are at the same position
             std::vector<k2hip_online_stream*> ready(idx.size());
             for (size_t r = 0; r < idx.size(); r++) ready[r] = streams[idx[r]];
+            fb.owners = ready;
             fb.armed = online_materialize(ready.data(), (int)ready.size(), true);
         }
         const int R = (int)idx.size(), Tp = e.online_frames_per_chunk();

@@ -699,6 +699,12 @@ void beam_relaunch_one_slab(hipStream_t stream, const GreedyLaunch& rec) {
     BeamLoopArgs la = rec.ba;
     la.xg = nullptr;
     K2_HIP(hipMemsetAsync(la.overflow, 0, sizeof(int), stream));
+    if (tunables().test_greedy_timeout) {   // (as greedy_relaunch_one_part: the caller must get the REPEAT's output)
+        K2_HIP(hipMemsetAsync(la.tokens, 0xEE, sizeof(long long) * (size_t)rec.a.B * la.max_tokens, stream));
+        K2_HIP(hipMemsetAsync(la.timestamps, 0xEE, sizeof(int) * (size_t)rec.a.B * la.max_tokens, stream));
+        K2_HIP(hipMemsetAsync(la.n_tokens, 0xEE, sizeof(int) * (size_t)rec.a.B, stream));
+        if (la.scores) K2_HIP(hipMemsetAsync(la.scores, 0xEE, sizeof(float) * (size_t)rec.a.B, stream));
+    }
     hipLaunchKernelGGL(k_beam_loop<1>, dim3(rec.a.B), dim3(GT), rec.beam_lds, stream, rec.w, la);
     K2_HIP(hipGetLastError());
 }

@@ -35,6 +35,10 @@ Engine::Engine(const std::string& weights, const char* overrides, int device) : 
         K2_HIP(hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming));
     }
     for (auto& e : ev_) K2_HIP(hipEventCreate(&e));
+    // The search tables (groups = 1 decoders: the per-token conv contributions; small vocabularies: the all-contexts decoder table,
+    // 0.5 GB at V = 500 -- k2hip.h "memory") are built HERE, not inside the first search call: their hipMalloc + build + stream
+    // synchronisation would otherwise sit under the engine lock in the first decode or the first pipelined submit.
+    if (!model_->cfg().ctc) (void)decjoin();
 }
 
 Engine::~Engine() {
@@ -828,9 +832,15 @@ void Engine::fbank_host_gather(const float* const* head, const int64_t* n_head, 
     for (int g = 0; g < G; g++) memcpy(dst[g], pin + nb_in + (size_t)g * per_out, per_out);
 }
 
+// Collect the outstanding download of fbank_host_gather(defer).  Throws if the device work behind it failed: the frames are then
+// lost (the destinations keep the zero frames api.cpp reserved for them) and the CALLER must poison the streams that own them --
+// nothing may decode those zeros later as if they were audio.  Either way nothing stays outstanding.
 void Engine::fbank_gather_finish() {
     if (!fb_pending_.active) return;
-    fb_pending_.active = false;
+    struct Done {
+        bool& active;
+        ~Done() { active = false; }
+    } done{fb_pending_.active};
     K2_HIP(hipStreamSynchronize(stream_));   // (returns at once after the step's own synchronisation)
     for (size_t g = 0; g < fb_pending_.dst.size(); g++) memcpy(fb_pending_.dst[g], fb_pending_.src + g * fb_pending_.per_out, fb_pending_.per_out);
 }

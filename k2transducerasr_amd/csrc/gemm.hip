@@ -1479,7 +1479,8 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         }
         launch_pipe_idx(ctx, b, best);
         K2_HIP(hipGetLastError());
-        if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 128;
+        // (+128: the pipelined kernel; its tile in bits 8.. so that a profile can be grouped by instantiation: BM / 32, BN / 32)
+        if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 128 + 256 * (kPipe[best].BM / 32) + 4096 * (kPipe[best].BN / 32);
         if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
         return;
     }

@@ -1052,6 +1052,13 @@ void greedy_relaunch_one_part(hipStream_t stream, const GreedyLaunch& rec) {
     const size_t lds = sizeof(float) * ((size_t)w.J * GF + 8 * APAD + kPsumFloats + 3 * (size_t)w.J + 3 * (size_t)w.DD + GF + 8 +
                                        2 * kMaxParts * GF + 4);
     K2_HIP(hipMemsetAsync(a.overflow, 0, sizeof(int), stream));
+    if (tunables().test_greedy_timeout) {
+        // the test hook raises the timeout flag behind a search that FINISHED: wipe what it wrote, so that the tokens the caller gets
+        // can only be the repeat's (a repeat that wrote nothing would otherwise pass on the first launch's output)
+        K2_HIP(hipMemsetAsync(a.tokens, 0xEE, sizeof(long long) * (size_t)a.B * a.max_tokens, stream));
+        K2_HIP(hipMemsetAsync(a.timestamps, 0xEE, sizeof(int) * (size_t)a.B * a.max_tokens, stream));
+        K2_HIP(hipMemsetAsync(a.n_tokens, 0xEE, sizeof(int) * (size_t)a.B, stream));
+    }
     hipLaunchKernelGGL(k_greedy, dim3(a.B), dim3(GT), lds, stream, w, a);
     K2_HIP(hipGetLastError());
 }

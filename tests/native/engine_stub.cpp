@@ -29,12 +29,14 @@ namespace k2hip {
 namespace {
 // test hook of the stand-in: the next online_step / online_encoder throws (a "device failure"), see san_api_driver.cpp
 int g_fail_next_step = 0;
+int g_fail_next_gather_finish = 0;   // the next collection of a deferred fbank download fails (fbank_gather_finish)
 unsigned mix(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
 }  // namespace
 extern "C" void k2hip_stub_fail_next_step(int n) { g_fail_next_step = n; }
+extern "C" void k2hip_stub_fail_next_gather_finish(int n) { g_fail_next_gather_finish = n; }
 
 Engine::Engine(const std::string& weights, const char* overrides, int device) : device_(device) {
     model_.reset(new Model(weights, overrides));   // real host-side parse + validation; no upload
@@ -76,7 +78,12 @@ void Engine::fbank_host_gather(const float* const* head, const int64_t* n_head, 
         fake_frames(cat.data(), n, model_->cfg().fbank, model_->cfg().feat, dst[g], nf);
     }
 }
-void Engine::fbank_gather_finish() {}
+void Engine::fbank_gather_finish() {
+    if (g_fail_next_gather_finish > 0) {
+        g_fail_next_gather_finish--;
+        failf(K2HIP_ERR_HIP, "stub: the deferred fbank download failed");
+    }
+}
 void Engine::pad_host(const float* const* speech, const int64_t* n_floats, int B, int tail, float* out, int64_t cap, int64_t* Lout) {
     int64_t mx = 0;
     for (int b = 0; b < B; b++) mx = std::max(mx, n_floats[b]);

@@ -1,0 +1,147 @@
+/*
+ * multi_handle_host.c -- the shape of the reference-side host on a multi-GPU node, in C: N model handles opened and driven
+ * from N host threads (one per GPU; fewer GPUs than threads: the handles share devices), each decoding its own contiguous
+ * shard of one utterance list as the GetResults batches shard.py's shard_range / batches_of define, results concatenated in
+ * handle order -- and the same list through ONE handle, which must give the same tokens and timestamps, utterance for
+ * utterance (a shard is decoded exactly as the reference would decode it as its own batches: OfflineRecognizer.cs:189-303
+ * pads and switches context per batch, never across batches).  No collective, no shared state but the result arrays.
+ *
+ * usage: multi_handle_host <model.k2w> <samples.f32> <n_utts> <n_samples_each> <batch> <n_handles> <beam (0 = greedy)> <out.bin>
+ *   samples.f32: n_utts x n_samples_each little-endian floats.
+ *   out.bin: int32 n_utts, int32 max_tokens, then per utterance int32 n, int64 tokens[max_tokens], int32 timestamps[max_tokens]
+ * exit code 0 = the two decodes agree.  Built by tests/test_multi_handle_gpu.py: gcc -std=c99 -pthread ... -lk2hip.
+ */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "k2hip.h"
+
+typedef struct {
+    const char* model_path;
+    const float* samples;
+    long n_each;
+    int total, batch, world, rank, beam, device, max_tokens;
+    int64_t* tokens;   /* [total][max_tokens], shared: every thread writes its own shard's rows */
+    int32_t* ts;
+    int32_t* n_tok;
+    int rc;
+    char err[512];
+} job_t;
+
+/* shard.py shard_range: contiguous, sizes differ by at most one */
+static void shard_range(int n, int world, int rank, int* lo, int* hi) {
+    const int base = n / world, rem = n % world;
+    *lo = rank * base + (rank < rem ? rank : rem);
+    *hi = *lo + base + (rank < rem ? 1 : 0);
+}
+
+static void* run(void* arg) {
+    job_t* j = (job_t*)arg;
+    k2hip_model_t* m = NULL;
+    j->rc = k2hip_model_create(j->model_path, NULL, j->device, &m);
+    if (j->rc) { snprintf(j->err, sizeof j->err, "model_create: %s", k2hip_last_error()); return NULL; }
+    if (j->beam > 0 && (j->rc = k2hip_set_decoding_method(m, "modified_beam_search", j->beam))) {
+        snprintf(j->err, sizeof j->err, "set_decoding_method: %s", k2hip_last_error());
+        k2hip_model_destroy(m);
+        return NULL;
+    }
+    int lo, hi;
+    shard_range(j->total, j->world, j->rank, &lo, &hi);
+    const float** ptrs = (const float**)malloc(sizeof(float*) * (size_t)j->batch);
+    int64_t* lens = (int64_t*)malloc(sizeof(int64_t) * (size_t)j->batch);
+    for (int a = lo; a < hi && !j->rc; a += j->batch) {   /* shard.py batches_of */
+        const int cnt = hi - a < j->batch ? hi - a : j->batch;
+        for (int i = 0; i < cnt; i++) {
+            ptrs[i] = j->samples + (size_t)(a + i) * (size_t)j->n_each;
+            lens[i] = j->n_each;
+        }
+        j->rc = k2hip_offline_greedy_from_samples(m, ptrs, lens, cnt, j->tokens + (size_t)a * j->max_tokens, j->ts + (size_t)a * j->max_tokens,
+                                                  j->n_tok + a, j->max_tokens);
+        if (j->rc) snprintf(j->err, sizeof j->err, "batch at utterance %d: %s", a, k2hip_last_error());
+    }
+    free(ptrs);
+    free(lens);
+    k2hip_model_destroy(m);
+    return NULL;
+}
+
+static int decode(const char* path, const float* samples, long n_each, int total, int batch, int world, int beam, int ndev, int max_tokens,
+                  int64_t* tokens, int32_t* ts, int32_t* n_tok) {
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)world);
+    job_t* jobs = (job_t*)calloc((size_t)world, sizeof(job_t));
+    for (int r = 0; r < world; r++) {
+        job_t* j = &jobs[r];
+        j->model_path = path; j->samples = samples; j->n_each = n_each; j->total = total; j->batch = batch; j->world = world; j->rank = r;
+        j->beam = beam; j->device = r % ndev; j->max_tokens = max_tokens; j->tokens = tokens; j->ts = ts; j->n_tok = n_tok;
+        if (pthread_create(&th[r], NULL, run, j)) { fprintf(stderr, "pthread_create failed\n"); return 1; }
+    }
+    int rc = 0;
+    for (int r = 0; r < world; r++) {
+        pthread_join(th[r], NULL);
+        if (jobs[r].rc) { fprintf(stderr, "handle %d (device %d): %s\n", r, jobs[r].device, jobs[r].err); rc = 1; }
+    }
+    free(th);
+    free(jobs);
+    return rc;
+}
+
+int main(int argc, char** argv) {
+    if (argc != 9) {
+        fprintf(stderr, "usage: %s <model.k2w> <samples.f32> <n_utts> <n_samples_each> <batch> <n_handles> <beam> <out.bin>\n", argv[0]);
+        return 2;
+    }
+    const char* path = argv[1];
+    const int total = atoi(argv[3]), batch = atoi(argv[5]), beam = atoi(argv[7]);
+    const long n_each = atol(argv[4]);
+    int world = atoi(argv[6]);
+    const int ndev = k2hip_device_count();
+    if (ndev <= 0) { fprintf(stderr, "no HIP device\n"); return 3; }
+    if (world > 8) world = 8;
+    if (world < 1 || total < world || batch < 1 || n_each < 400) { fprintf(stderr, "bad arguments\n"); return 2; }
+    const size_t nfl = (size_t)total * (size_t)n_each;
+    float* samples = (float*)malloc(sizeof(float) * nfl);
+    FILE* f = fopen(argv[2], "rb");
+    if (!f || fread(samples, sizeof(float), nfl, f) != nfl) { fprintf(stderr, "cannot read %zu floats from %s\n", nfl, argv[2]); return 2; }
+    fclose(f);
+    /* max_tokens: frames of encoder_out for these utterances (a greedy / beam result cannot be longer) */
+    k2hip_model_t* probe = NULL;
+    if (k2hip_model_create(path, NULL, 0, &probe)) { fprintf(stderr, "model_create: %s\n", k2hip_last_error()); return 1; }
+    const int T = (int)k2hip_fbank_num_frames(probe, n_each) + 19;
+    const int max_tokens = k2hip_encoder_out_frames(probe, T);
+    k2hip_model_destroy(probe);
+    if (max_tokens <= 0) { fprintf(stderr, "utterances too short\n"); return 2; }
+    const size_t cells = (size_t)total * (size_t)max_tokens;
+    int64_t* tokN = (int64_t*)calloc(cells, sizeof(int64_t));
+    int64_t* tok1 = (int64_t*)calloc(cells, sizeof(int64_t));
+    int32_t* tsN = (int32_t*)calloc(cells, sizeof(int32_t));
+    int32_t* ts1 = (int32_t*)calloc(cells, sizeof(int32_t));
+    int32_t* nN = (int32_t*)calloc((size_t)total, sizeof(int32_t));
+    int32_t* n1 = (int32_t*)calloc((size_t)total, sizeof(int32_t));
+    if (decode(path, samples, n_each, total, batch, world, beam, ndev, max_tokens, tokN, tsN, nN)) return 1;
+    if (decode(path, samples, n_each, total, batch, 1, beam, ndev, max_tokens, tok1, ts1, n1)) return 1;
+    int bad = 0;
+    long emitted = 0;
+    for (int u = 0; u < total; u++) {
+        emitted += nN[u];
+        if (nN[u] != n1[u] || memcmp(tokN + (size_t)u * max_tokens, tok1 + (size_t)u * max_tokens, sizeof(int64_t) * (size_t)nN[u]) ||
+            memcmp(tsN + (size_t)u * max_tokens, ts1 + (size_t)u * max_tokens, sizeof(int32_t) * (size_t)nN[u])) {
+            if (bad < 5) fprintf(stderr, "utterance %d: %d handles and one handle disagree (%d vs %d tokens)\n", u, world, nN[u], n1[u]);
+            bad++;
+        }
+    }
+    f = fopen(argv[8], "wb");
+    if (!f) { fprintf(stderr, "cannot write %s\n", argv[8]); return 2; }
+    const int32_t hdr[2] = {total, max_tokens};
+    fwrite(hdr, sizeof(int32_t), 2, f);
+    for (int u = 0; u < total; u++) {
+        fwrite(&nN[u], sizeof(int32_t), 1, f);
+        fwrite(tokN + (size_t)u * max_tokens, sizeof(int64_t), (size_t)max_tokens, f);
+        fwrite(tsN + (size_t)u * max_tokens, sizeof(int32_t), (size_t)max_tokens, f);
+    }
+    fclose(f);
+    printf("%d utterances, %d handles on %d device(s), batches of %d, %s: %ld tokens, %d utterances differ from the one-handle decode\n", total, world,
+           ndev, batch, beam > 0 ? "modified beam search" : "greedy search", emitted, bad);
+    return bad ? 1 : 0;
+}

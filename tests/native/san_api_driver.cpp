@@ -17,6 +17,7 @@
 #include "../../include/k2hip.h"
 
 extern "C" void k2hip_stub_fail_next_step(int n);
+extern "C" void k2hip_stub_fail_next_gather_finish(int n);
 extern "C" int32_t k2hip_debug_poison_stream(k2hip_online_stream_t* s);
 extern "C" int32_t k2hip_debug_stream_mirrored(const k2hip_online_stream_t* s, int32_t* ok);
 
@@ -249,6 +250,26 @@ int errors(const char* path) {
     k2hip_online_stream_t* one[1] = {a};
     OK(k2hip_online_step(m, one, 1, dec, nn));
     CHECK(dec[0] == 1);
+    // the deferred fbank download fails AFTER a step that succeeded (samples were queued: their frames were to be collected behind the
+    // step): the stream's FIFO holds placeholder zeros where audio should be -- it must refuse further steps, not decode silence
+    {
+        OK(k2hip_online_stream_reset(a));
+        std::vector<float> pcm((size_t)(T - 1) * 160 + 400 + 160 * (size_t)S, 0.25f);   // a chunk and a shift's worth of samples
+        OK(k2hip_online_stream_accept_samples(a, pcm.data(), (int64_t)pcm.size()));
+        k2hip_stub_fail_next_gather_finish(1);
+        const int32_t rc = k2hip_online_step(m, one, 1, dec, nn);
+        fprintf(stderr, "deferred-download failure: step returned %d\n", rc);
+        if (rc == K2HIP_ERR_HIP) {   // (the stand-in only defers when the engine would: one batched launch covering every ready stream)
+            CHECK(k2hip_online_stream_num_tokens(a) == 2);                         // nothing host-side moved
+            CHECK(k2hip_online_step(m, one, 1, dec, nn) == K2HIP_ERR_INVALID);     // poisoned
+            CHECK(strstr(k2hip_last_error(), "reset it first") != nullptr);
+        } else {
+            CHECK(rc == K2HIP_OK);
+            k2hip_stub_fail_next_gather_finish(0);
+        }
+        OK(k2hip_online_stream_reset(a));
+        OK(k2hip_online_stream_accept_features(a, f.data(), T));
+    }
     // the FIFO mirror: a block larger than the device ring is not mirrored, and is again once it fits
     OK(k2hip_online_stream_reset(b));
     std::vector<float> big((size_t)700 * 80, 3.f);
