@@ -22,7 +22,7 @@ typedef struct {
     const char* model_path;
     const float* samples;
     long n_each;
-    int total, batch, world, rank, beam, device, max_tokens;
+    int total, batch, world, rank, nranks, beam, device, max_tokens;   /* this handle decodes the shards rank .. rank + nranks - 1 */
     int64_t* tokens;   /* [total][max_tokens], shared: every thread writes its own shard's rows */
     int32_t* ts;
     int32_t* n_tok;
@@ -47,11 +47,12 @@ static void* run(void* arg) {
         k2hip_model_destroy(m);
         return NULL;
     }
-    int lo, hi;
-    shard_range(j->total, j->world, j->rank, &lo, &hi);
     const float** ptrs = (const float**)malloc(sizeof(float*) * (size_t)j->batch);
     int64_t* lens = (int64_t*)malloc(sizeof(int64_t) * (size_t)j->batch);
-    for (int a = lo; a < hi && !j->rc; a += j->batch) {   /* shard.py batches_of */
+    for (int r = j->rank; r < j->rank + j->nranks && !j->rc; r++) {
+    int lo, hi;
+    shard_range(j->total, j->world, r, &lo, &hi);
+    for (int a = lo; a < hi && !j->rc; a += j->batch) {   /* shard.py batches_of: a batch never crosses a shard boundary */
         const int cnt = hi - a < j->batch ? hi - a : j->batch;
         for (int i = 0; i < cnt; i++) {
             ptrs[i] = j->samples + (size_t)(a + i) * (size_t)j->n_each;
@@ -61,24 +62,28 @@ static void* run(void* arg) {
                                                   j->n_tok + a, j->max_tokens);
         if (j->rc) snprintf(j->err, sizeof j->err, "batch at utterance %d: %s", a, k2hip_last_error());
     }
+    }
     free(ptrs);
     free(lens);
     k2hip_model_destroy(m);
     return NULL;
 }
 
-static int decode(const char* path, const float* samples, long n_each, int total, int batch, int world, int beam, int ndev, int max_tokens,
-                  int64_t* tokens, int32_t* ts, int32_t* n_tok) {
-    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)world);
-    job_t* jobs = (job_t*)calloc((size_t)world, sizeof(job_t));
-    for (int r = 0; r < world; r++) {
+/* threads = world: one handle and one thread per shard; threads = 1: ONE handle walks the same shards' batches one after the other
+ * (the batch list is the same -- the reference's results depend on what shares a GetResults batch, so that is what must not change) */
+static int decode(const char* path, const float* samples, long n_each, int total, int batch, int world, int threads, int beam, int ndev,
+                  int max_tokens, int64_t* tokens, int32_t* ts, int32_t* n_tok) {
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+    job_t* jobs = (job_t*)calloc((size_t)threads, sizeof(job_t));
+    for (int r = 0; r < threads; r++) {
         job_t* j = &jobs[r];
-        j->model_path = path; j->samples = samples; j->n_each = n_each; j->total = total; j->batch = batch; j->world = world; j->rank = r;
+        j->model_path = path; j->samples = samples; j->n_each = n_each; j->total = total; j->batch = batch; j->world = world;
+        j->rank = threads == 1 ? 0 : r; j->nranks = threads == 1 ? world : 1;
         j->beam = beam; j->device = r % ndev; j->max_tokens = max_tokens; j->tokens = tokens; j->ts = ts; j->n_tok = n_tok;
         if (pthread_create(&th[r], NULL, run, j)) { fprintf(stderr, "pthread_create failed\n"); return 1; }
     }
     int rc = 0;
-    for (int r = 0; r < world; r++) {
+    for (int r = 0; r < threads; r++) {
         pthread_join(th[r], NULL);
         if (jobs[r].rc) { fprintf(stderr, "handle %d (device %d): %s\n", r, jobs[r].device, jobs[r].err); rc = 1; }
     }
@@ -119,8 +124,8 @@ int main(int argc, char** argv) {
     int32_t* ts1 = (int32_t*)calloc(cells, sizeof(int32_t));
     int32_t* nN = (int32_t*)calloc((size_t)total, sizeof(int32_t));
     int32_t* n1 = (int32_t*)calloc((size_t)total, sizeof(int32_t));
-    if (decode(path, samples, n_each, total, batch, world, beam, ndev, max_tokens, tokN, tsN, nN)) return 1;
-    if (decode(path, samples, n_each, total, batch, 1, beam, ndev, max_tokens, tok1, ts1, n1)) return 1;
+    if (decode(path, samples, n_each, total, batch, world, world, beam, ndev, max_tokens, tokN, tsN, nN)) return 1;
+    if (decode(path, samples, n_each, total, batch, world, 1, beam, ndev, max_tokens, tok1, ts1, n1)) return 1;
     int bad = 0;
     long emitted = 0;
     for (int u = 0; u < total; u++) {
