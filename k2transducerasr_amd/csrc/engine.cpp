@@ -13,6 +13,7 @@ constexpr int kTailFrames = 19;  // PadHelper.cs:17
 Engine::Engine(const std::string& weights, const char* overrides, int device) : device_(device) {
     // the container is parsed and validated on the host first: a missing / truncated / mismatched file is K2HIP_ERR_IO
     // whether or not a GPU is present
+    tunables_init_from_env();   // (first: the model's load-time repacks read switches too)
     model_.reset(new Model(weights, overrides));
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
@@ -169,6 +170,10 @@ DecJoinW Engine::decjoin() {
     w.out_kn = model_->w("joiner.output_linear.weight#kn");
     w.out_b = model_->w("joiner.output_linear.bias");
     w.V = c.V; w.Vp = c.Vp; w.DD = c.DD; w.J = c.J; w.ctx = c.ctx;
+    if (model_->has("joiner.output_linear.weight#h16") && tunables().screen_min_v > 0) {
+        w.out_h16 = model_->w("joiner.output_linear.weight#h16");
+        w.out_eps = model_->w("joiner.output_linear.weight#eps");
+    }
     if (w.cpg > 4) {
         if (!d_ptab_) {  // one-off: P[tap] = emb . conv_tap^T on the MFMA GEMM
             K2_HIP(hipMalloc(&d_ptab_, sizeof(float) * 2 * (size_t)c.V * c.DD));

@@ -425,7 +425,154 @@ __device__ __forceinline__ unsigned long long load_granule(const unsigned long l
     return __hip_atomic_load((gu64*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// LDS: actT[J][GF] | psum[8][GF][256] | dec_a[J] | dec_b[J] | dec_own[J] | h[3*DD] (h | stacked embeddings) | fin[GF]
+// ---- large vocabularies: the round's sweep as an f16 SCREEN + an exact f32 re-check of the few columns that can win ------------
+// A round's three f32 passes over a 1.4 MB slab (V = 5537, 8 parts) are 70 % of that search.  Only the argmax of each frame's logits
+// is wanted, so the slab is first swept in f16 on v_mfma_f32_16x16x32_f16 (half the bytes, 1/16 of the matrix instructions, no k
+// split, no exchange of partial sums through LDS): l~[f][v] with |l~ - l| <= eps[v], a bound fixed at load time (model.cpp) for
+// the f32 logit l the passes would compute.  A column can only hold frame f's maximum if l~ + eps >= max_u (l~_u - eps_u); those
+// candidates -- a handful -- are recomputed EXACTLY as the passes compute them (the k slices' fma chains in k order, the slices
+// summed in the passes' tree, + bias: bit-identical values), and the later-wins argmax over them is the argmax over the slab.
+// Non-finite screen values (a NaN sample upstream, a NaN / Inf / f16-overflowing weight: the reference's NaN rule needs every column)
+// or more than kScreenCand candidates send the round to the f32 passes.  Per round and part: 708 KB of L2 traffic instead of 1.4 MB
+// x the three passes' MFMA-issue time.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+constexpr int kScreenCand = 64;          // (frame, column) pairs re-checked per round and part: one per (pair, k slice) thread
+constexpr int kScreenMaxCols = 1536;     // scr[GF][cols] + the lists below live in the psum area (kPsumFloats)
+constexpr int kScreenSteps = 16;         // J <= 512
+static_assert(GF * kScreenMaxCols + 64 + 8 + kScreenCand + kScreenCand * 8 <= kPsumFloats, "screen: LDS layout");
+
+// actH: the round's activations as f16 A fragments [J / 32][64 lanes][8] (rows >= GF of the 16-row tile stay zero).
+// Returns true (workgroup-uniform) when the screen decided the round: then lane 0 of wave f < nf holds frame f's (bestv, besti) over
+// the part's columns [4 cg0, 4 cg1); false: nothing was decided, run the f32 passes.
+// (a real call: inlined, the four instantiations' loop-invariant addresses stay live across the whole search loop and the kernel spills)
+template <int NS>   // NS = J / 32 K steps: a compile-time constant, so that the tile loop is straight-line code with counted waits
+__device__ __noinline__ bool screen_round(const DecJoinW& w, const float* actT, const _Float16* actH, float* area, int cg0, int cg1, int nf,
+                                             float& bestv, int& besti) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: the tile loop's tests stay scalar)
+    const int c_lo = 4 * cg0, c_hi = min(4 * cg1, w.V), ncols = c_hi - c_lo, kper = w.J >> 3;
+    float* scr = area;                                              // [GF][ncols]: upper bounds l~ + eps (-inf outside the slab)
+    float* wlb = area + GF * kScreenMaxCols;                        // [8 waves][GF]: the waves' largest lower bounds l~ - eps
+    int* ctl = reinterpret_cast<int*>(wlb + 64);                    // [0] candidate count, [1] non-finite flag
+    int* cand = ctl + 8;                                            // [kScreenCand]: frame | local column << 3
+    float* part = reinterpret_cast<float*>(cand + kScreenCand);     // [kScreenCand][8 slices]
+    if (tid < 2) ctl[tid] = 0;
+    // ---- the screen: wave = every 8th 16-column tile; the A fragments (the activations) are re-read from LDS per tile -- held in
+    // registers they are 64 VGPRs on top of the B ring's 64 and the kernel spills
+    typedef __attribute__((address_space(3))) const h16x8 lh16x8;   // (LDS, not flat: a flat load's wait also drains the global loads in flight)
+    lh16x8* afr = (lh16x8*)actH + lane;
+    const int t0 = c_lo >> 4, t1 = (c_hi + 15) >> 4;
+    typedef __attribute__((address_space(1))) const h16x8 gh16x8;   // (global, not flat: flat loads count on lgkmcnt too)
+    gh16x8* wh = (gh16x8*)w.out_h16;
+    float lbmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    bool bad = false;
+    // B fragments: a ring of one register set -- step s of the NEXT tile is requested as soon as step s of this tile has been
+    // used, so a wave keeps a whole tile (16 KB at J = 512) in flight without a second set (two sets spilled: 256 VGPRs + scratch)
+    // (no test inside the loop: the wave's last tile re-requests itself; a conditional load costs the counted waits)
+    h16x8 bfr[NS];
+    auto tile = [&](int t) {
+        const int tn = min(t + GT / 64, t1 - 1);
+        gh16x8* wn = wh + ((size_t)tn * NS) * 64 + lane;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        constexpr int AG = NS >= 4 ? 4 : NS;   // A fragments per LDS round trip
+#pragma unroll
+        for (int s0 = 0; s0 < NS; s0 += AG) {
+            h16x8 ag[AG];
+#pragma unroll
+            for (int q = 0; q < AG; q++) ag[q] = afr[(s0 + q) * 64];
+#pragma unroll
+            for (int q = 0; q < AG; q++) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ag[q], bfr[s0 + q], acc, 0, 0, 0);
+                bfr[s0 + q] = wn[(s0 + q) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (keeps the reloads behind their MFMAs: hoisted, they need a second register set)
+        }
+        // C/D: column = lane & 15, row (frame) = 4 (lane >> 4) + i: frames 0 .. 7 sit in lanes 0 .. 31
+        const int col = 16 * t + (lane & 15);
+        if (lane < 32 && col >= c_lo && col < c_hi) {
+            const float bv = w.out_b[col], e = w.out_eps[col];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int f = 4 * (lane >> 4) + i;
+                const float v = acc[i] + bv;
+                bad = bad || !(fabsf(v) <= 3.0e38f) || !(e <= 3.0e38f);
+                scr[f * ncols + (col - c_lo)] = v + e;
+                lbmax[i] = fmaxf(lbmax[i], v - e);
+            }
+        }
+    };
+    {
+        gh16x8* w0 = wh + ((size_t)min(t0 + wave, t1 - 1) * NS) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < NS; s++) bfr[s] = w0[s * 64];
+    }
+#pragma unroll 1
+    for (int t = t0 + wave; t < t1; t += GT / 64) tile(t);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {   // the row of 16 lanes that shares frames 4 (lane >> 4) + i
+        float v = lbmax[i];
+        v = fmaxf(v, dpp_f<0xB1>(v));
+        v = fmaxf(v, dpp_f<0x4E>(v));
+        v = fmaxf(v, dpp_f<0x141>(v));
+        v = fmaxf(v, dpp_f<0x140>(v));
+        if ((lane & 15) == 0 && lane < 32) wlb[wave * GF + 4 * (lane >> 4) + i] = v;
+    }
+    if (__any(bad) && lane == 0) ctl[1] = 1;
+    __syncthreads();
+    // ---- candidates: every (frame, column) whose upper bound reaches the frame's largest lower bound
+    for (int idx = tid; idx < nf * ncols; idx += GT) {
+        const int f = idx / ncols, c = idx - f * ncols;
+        float tau = wlb[f];
+#pragma unroll
+        for (int q = 1; q < GT / 64; q++) tau = fmaxf(tau, wlb[q * GF + f]);
+        if (scr[f * ncols + c] >= tau) {
+            const int slot = atomicAdd(&ctl[0], 1);
+            if (slot < kScreenCand) cand[slot] = f | (c << 3);
+        }
+    }
+    __syncthreads();
+    const int P = ctl[0];
+    const bool give_up = ctl[1] || P > kScreenCand || P <= 0;   // (uniform: read from LDS behind the barrier)
+    if (give_up) {
+        __syncthreads();   // everyone has read the verdict before the f32 passes reuse this area for their partial sums
+        return false;
+    }
+    // ---- the candidates' logits exactly as the f32 passes form them: thread = (pair, k slice), the slice's fma chain in k order
+    {
+        const int p = tid >> 3, s = tid & 7;
+        if (p < P) {
+            const int f = cand[p] & 7, col = c_lo + (cand[p] >> 3);
+            const float* wp = w.out_kn + (long long)(s * kper) * w.Vp + col;
+            const float* ap = actT + (s * kper) * GF + s * APAD + f;
+            float acc = 0.f;
+            for (int kb = 0; kb < kper; kb += 16) {
+                float wv[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) wv[i] = wp[(long long)min(kb + i, kper - 1) * w.Vp];
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    if (kb + i < kper) acc = fmaf(ap[(kb + i) * GF], wv[i], acc);
+            }
+            part[p * 8 + s] = acc;
+        }
+    }
+    __syncthreads();
+    bestv = -INFINITY;
+    besti = -1;
+    if (lane < P && (cand[lane] & 7) == wave) {   // wave f: frame f's candidates, one per lane
+        const float* ps = part + lane * 8;
+        const int col = c_lo + (cand[lane] >> 3);
+        bestv = (((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]))) + w.out_b[col];
+        besti = col;
+    }
+    amax_wave(bestv, besti);   // finite values: the total order (later index wins ties) is the reference's scan
+    return true;
+}
+
+// LDS: actT[J][GF] | psum[8][GF][256] | dec_a[J] | dec_b[J] | dec_own[J] | h[3*DD] (h | stacked embeddings) | fin[GF] | exchange scratch |
+// actH (large vocabularies: the activations as f16 MFMA fragments, J x 32 bytes)
+// SCREEN: the instantiation for large vocabularies (w.out_h16 set) -- kept apart so that the screen's 128 fragment registers do
+// not weigh on the small-vocabulary kernel's allocation (172 VGPRs, no scratch)
+template <bool SCREEN>
 __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* actT = sm;
@@ -439,6 +586,7 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
     float* pv = reinterpret_cast<float*>(fin + GF + 8);
     int* pi = reinterpret_cast<int*>(pv + kMaxParts * GF);
     int* xf = pi + kMaxParts * GF;  // [0] = exchange timed out
+    _Float16* actH = reinterpret_cast<_Float16*>(xf + 4);   // (only allocated when the screen is on: greedy_lds_bytes)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = a.parts, b = blockIdx.x / G, part = blockIdx.x - b * G;
@@ -450,6 +598,15 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
     // this part's slab of column groups (whole 8-wide wave chunks)
     const int cper = ((ncg + G - 1) / G + 7) & ~7;
     const int cg0 = part * cper, cg1 = min(ncg, cg0 + cper);
+
+    // the f16 screen (screen_round): large vocabularies whose slab fits the psum area
+    const int nks = w.J >> 5;
+    const bool screen = SCREEN && w.out_h16 != nullptr && (w.J & 31) == 0 && (nks == 16 || nks == 8 || nks == 4 || nks == 2) &&
+                        4 * (cg1 - cg0) <= kScreenMaxCols && cg1 > cg0;
+    if (screen) {
+        for (int i = tid; i < w.J * 16; i += GT) reinterpret_cast<unsigned*>(actH)[i] = 0u;   // rows 8 .. 15 of the A tile stay zero
+        __syncthreads();
+    }
 
     long long y0 = -1, y1 = K2HIP_BLANK_ID;
     int n_tok = 0, t = 0;
@@ -479,10 +636,14 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
             for (int f = 0; f < GF; f++) e[f] = enc[(long long)min(t + f, a.Tp - 1) * w.J + k];   // (unconditional, clamped; dropped below when f >= nf)
             const float da = dec_a[k], db = a.t0 ? dec_b[k] : 0.f, dn = dec_own[k];
             float* dst = actT + k * GF + (k / kper) * APAD;
+            // (screen) element j = k & 7 of lane f + 16 ((k & 31) >> 3) of K step k >> 5
+            _Float16* dh = actH + (((size_t)(k >> 5) * 64 + 16 * ((k & 31) >> 3)) * 8 + (k & 7));
 #pragma unroll
             for (int f = 0; f < GF; f++) {
                 const float d = own ? dn : ((t + f) > t0 ? db : da);
-                dst[f] = f < nf ? tanhf(e[f] + d) : 0.f;
+                const float v = f < nf ? tanhf(e[f] + d) : 0.f;
+                dst[f] = v;
+                if (screen) dh[f * 8] = (_Float16)v;
             }
         }
         __syncthreads();
@@ -494,7 +655,17 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
         float bestv = -INFINITY;
         int besti = -1;
         const bool one_pass = cg1 - cg0 <= 64;
-        for (int cgb = cg0; cgb < cg1; cgb += 64) {
+        bool screened = false;
+        if constexpr (SCREEN) if (screen) {
+            switch (nks) {
+                case 16: screened = screen_round<16>(w, actT, actH, psum, cg0, cg1, nf, bestv, besti); break;
+                case 8: screened = screen_round<8>(w, actT, actH, psum, cg0, cg1, nf, bestv, besti); break;
+                case 4: screened = screen_round<4>(w, actT, actH, psum, cg0, cg1, nf, bestv, besti); break;
+                default: screened = screen_round<2>(w, actT, actH, psum, cg0, cg1, nf, bestv, besti); break;
+            }
+        }
+        if (screened && cg0 < cg1) __syncthreads();   // (the passes below are skipped: nothing else reads the psum area this round)
+        for (int cgb = cg0; cgb < (screened ? cg0 : cg1); cgb += 64) {
             const int cg = cgb + lane;
             const bool valid = cg < cg1;
             f32x4 c[2][4];
@@ -537,7 +708,7 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
             }
             if (cgb + 64 < cg1) __syncthreads();   // psum is rewritten by the next pass
         }
-        if (one_pass) rmax_wave(bestv, besti);
+        if (one_pass && !screened) rmax_wave(bestv, besti);
         if (lane == 0) {
             fin[wave] = rmax_index(besti);
             if (G > 1) {  // publish this slab's candidate for frame `wave` (round parity buffer)
@@ -993,6 +1164,11 @@ void first_emit_frame(const Ctx& ctx, const int* tok, int B, int Tp, int skip1, 
     hipLaunchKernelGGL(k_first_emit, dim3(1), dim3(1024), 0, ctx.stream, tok, B, Tp, skip1, t0);
     K2_HIP(hipGetLastError());
 }
+static size_t greedy_lds_bytes(const DecJoinW& w) {
+    return sizeof(float) * ((size_t)w.J * GF + 8 * APAD + kPsumFloats + 3 * (size_t)w.J + 3 * (size_t)w.DD + GF + 8 + 2 * kMaxParts * GF + 4) +
+           (w.out_h16 ? (size_t)w.J * 32 : 0);   // + actH
+}
+
 void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     if (a0.B <= 0) return;
     GreedyArgs a = a0;
@@ -1019,15 +1195,17 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     if (ctx.dry) return;
     K2_REQUIRE(w.J % 8 == 0, "greedy: joiner_dim %d must be a multiple of 8", w.J);
     K2_REQUIRE(w.DD % 4 == 0 && 8 * w.DD <= w.J * GF, "greedy: decoder_dim %d too wide for the LDS scratch", w.DD);
-    size_t lds = sizeof(float) * ((size_t)w.J * GF + 8 * APAD + kPsumFloats + 3 * (size_t)w.J + 3 * (size_t)w.DD + GF + 8 +
-                                 2 * kMaxParts * GF + 4);
+    const size_t lds = greedy_lds_bytes(w);
     K2_REQUIRE(lds <= 150 * 1024, "greedy: vocab %d / joiner %d need %zu B of LDS", w.V, w.J, lds);
     static LdsAttrOnce lds_attr;
-    lds_attr.ensure(k_greedy, 150 * 1024);
+    static LdsAttrOnce lds_attr_s;
+    lds_attr.ensure(k_greedy<false>, 150 * 1024);
+    lds_attr_s.ensure(k_greedy<true>, 150 * 1024);
     if (parts > 1) {
         K2_HIP(hipMemsetAsync(a.gran, 0, sizeof(unsigned long long) * (gran_words + gran2_words), ctx.stream));
     }
-    hipLaunchKernelGGL(k_greedy, dim3(a.B * parts), dim3(GT), lds, ctx.stream, w, a);
+    if (w.out_h16) hipLaunchKernelGGL(k_greedy<true>, dim3(a.B * parts), dim3(GT), lds, ctx.stream, w, a);
+    else hipLaunchKernelGGL(k_greedy<false>, dim3(a.B * parts), dim3(GT), lds, ctx.stream, w, a);
     K2_HIP(hipGetLastError());
     if (ctx.greedy_rec) {
         ctx.greedy_rec->valid = parts > 1;
@@ -1049,8 +1227,7 @@ void greedy_relaunch_one_part(hipStream_t stream, const GreedyLaunch& rec) {
     a.gran = nullptr;
     a.gran2 = nullptr;
     const DecJoinW& w = rec.w;
-    const size_t lds = sizeof(float) * ((size_t)w.J * GF + 8 * APAD + kPsumFloats + 3 * (size_t)w.J + 3 * (size_t)w.DD + GF + 8 +
-                                       2 * kMaxParts * GF + 4);
+    const size_t lds = greedy_lds_bytes(w);
     K2_HIP(hipMemsetAsync(a.overflow, 0, sizeof(int), stream));
     if (tunables().test_greedy_timeout) {
         // the test hook raises the timeout flag behind a search that FINISHED: wipe what it wrote, so that the tokens the caller gets
@@ -1059,7 +1236,8 @@ void greedy_relaunch_one_part(hipStream_t stream, const GreedyLaunch& rec) {
         K2_HIP(hipMemsetAsync(a.timestamps, 0xEE, sizeof(int) * (size_t)a.B * a.max_tokens, stream));
         K2_HIP(hipMemsetAsync(a.n_tokens, 0xEE, sizeof(int) * (size_t)a.B, stream));
     }
-    hipLaunchKernelGGL(k_greedy, dim3(a.B), dim3(GT), lds, stream, w, a);
+    if (w.out_h16) hipLaunchKernelGGL(k_greedy<true>, dim3(a.B), dim3(GT), lds, stream, w, a);
+    else hipLaunchKernelGGL(k_greedy<false>, dim3(a.B), dim3(GT), lds, stream, w, a);
     K2_HIP(hipGetLastError());
 }
 

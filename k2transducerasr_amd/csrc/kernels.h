@@ -30,6 +30,8 @@ struct Tunables {
     int beam_hyp_global = 0;      // K2HIP_BEAM_HYP_GLOBAL: the one-kernel beam search keeps its hypotheses in device memory even when they fit in LDS (the long-utterance form, for its test)
     int decoder_table_mb = 1024;  // K2HIP_DECODER_TABLE_MB: build the all-contexts decoder table when it fits this many MiB (0 = never)
     int beam_trace = 0;           // K2HIP_BEAM_TRACE: the modified beam search records its per-frame selection (k2hip_debug.h: k2hip_debug_beam_trace)
+    int screen_min_v = 1024;      // K2HIP_SCREEN_MIN_V: vocabularies of at least this size get the f16 screening pass in the greedy search
+                                  // (greedy.hip screen_round: exact tokens, ~2.5x fewer bytes per round); 0 = never
     int no_graphs = 0;            // K2HIP_NO_GRAPHS: every launch enqueued eagerly (no hipGraph replay of the streaming tick)
     int graph_offline = 0;        // K2HIP_GRAPH_OFFLINE: 1 = the offline batch entries replay their encoder pass from a hipGraph too (measured:
                                   // 13.87 against 13.76 ms per headline batch -- launches of 20 - 80 us hide their own enqueue cost; off by default)
@@ -294,6 +296,10 @@ struct DecJoinW {
     // small vocabularies only: decoder(y0, y1) of EVERY context, row (y0 + 1) V + y1 of [(V + 1) V][J], y0 = -1 .. V-1 (decoder_table);
     // the search kernels then read a row where they would run the decoder
     const float* dec_table = nullptr;
+    // large vocabularies only (model.cpp add_repacks): output_linear as f16 in MFMA fragment order + the per-column bound on
+    // |f16 product - f32 logit| -- the greedy search's screening pass (greedy.hip screen_round); null = every round sweeps in f32
+    const void* out_h16 = nullptr;
+    const float* out_eps = nullptr;
     int V, Vp, DD, J, ctx;
 };
 void decoder(const Ctx& ctx, const DecJoinW& w, const long long* y, int N, float* dec_out);

@@ -1,4 +1,5 @@
 #include "model.h"
+#include "kernels.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -308,6 +309,24 @@ void Model::parse_config() {
     K2_REQUIRE(f.padded == 512 && f.frame_len <= 512, "fbank kernel is built for a 512-point FFT (got %d)", f.padded);
 }
 
+// float -> IEEE binary16 bits, round to nearest even (overflow -> inf, NaN kept)
+static uint16_t f32_to_f16_rne(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));   // inf / NaN
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                      // >= 65520 rounds to inf
+    if (x < 0x33000001u) return (uint16_t)sign;                                                   // < 2^-25 (+ tie at 2^-25 -> even 0) rounds to zero
+    int e = (int)(x >> 23) - 127;
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;   // 24-bit significand
+    int shift = e < -14 ? (13 + (-14 - e)) : 13;  // bits dropped (subnormal results drop more)
+    uint32_t q = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1))) q++;
+    if (e < -14) return (uint16_t)(sign | q);     // subnormal (q may carry into the smallest normal: the encoding is continuous)
+    return (uint16_t)(sign | (((uint32_t)(e + 15) << 10) + (q - 0x400u)));   // q in [0x400, 0x800]: a carry bumps the exponent
+}
+
 void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>& extra,
                         std::vector<std::pair<std::string, std::vector<int64_t>>>& shapes) {
     const Config& c = cfg_;
@@ -513,6 +532,39 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
         for (int n = 0; n < c.V; n++)
             for (int k = 0; k < c.J; k++) v[(size_t)k * c.Vp + n] = t.host[(size_t)n * c.J + k];
         push("joiner.output_linear.weight#kn", std::move(v), {c.J, c.Vp});
+        // Large vocabularies: an f16 copy for the search's SCREENING pass (greedy.hip screen_round) and, per column, a rigorous bound
+        // on how far the f16 product can be from the f32 logit the search kernels compute.  Layout: 16-column tiles x 32-deep K steps
+        // in v_mfma_f32_16x16x32_f16's B-fragment order -- element j of lane l of (tile t, step s) is W[16 t + (l & 15)][32 s +
+        // 8 (l >> 4) + j] -- so a wave's load instruction reads 1 KB in one piece.
+        //   a_k = tanh(..) in [-1, 1]; a~, w~ = fp16(a), fp16(w):  |x~ - x| <= 2^-11 |x| + 2^-25  (round to nearest, subnormals)
+        //   |sum a~ w~ - sum a w| <= c (2^-10 + 2^-20) + J 2^-24,  c = sum_k |w_k|
+        //   either accumulation (f32, any order) adds at most (J + 8) 2^-24 c (1 + 2^-10), the bias add one ulp of the result
+        const int screen_min_v = tunables().screen_min_v;
+        if (screen_min_v > 0 && c.V >= screen_min_v && (c.J == 512 || c.J == 256 || c.J == 128 || c.J == 64) && has("joiner.output_linear.bias")) {
+            const int nt = (int)(align_up(c.Vp, 16) / 16), ns = c.J / 32;
+            std::vector<float> hv((size_t)nt * ns * 64 * 8 / 2, 0.f);   // two halfs per float slot
+            uint16_t* h = reinterpret_cast<uint16_t*>(hv.data());
+            std::vector<float> eps((size_t)nt * 16, 0.f);
+            const float* bias = tensor("joiner.output_linear.bias").host;
+            for (int n = 0; n < c.V; n++) {
+                double cs = 0.0;
+                bool finite = true;
+                for (int k = 0; k < c.J; k++) {
+                    const float wv = t.host[(size_t)n * c.J + k];
+                    cs += std::fabs((double)wv);
+                    finite = finite && std::isfinite(wv) && std::fabs(wv) < 65504.0f;
+                    const int tt = n >> 4, s = k >> 5, l = (n & 15) + 16 * ((k & 31) >> 3), j = k & 7;
+                    h[(((size_t)tt * ns + s) * 64 + l) * 8 + j] = f32_to_f16_rne(wv);
+                }
+                const double bound = cs * (std::ldexp(1.0, -10) + std::ldexp(1.0, -20) + 2.2 * (c.J + 8) * std::ldexp(1.0, -24)) +
+                                     (std::fabs((double)bias[n]) + 1.0) * std::ldexp(1.0, -20) + c.J * std::ldexp(1.0, -24);
+                // (a column with a NaN / Inf / f16-overflowing weight gets an infinite bound: it is always a candidate, the candidate
+                // list overflows or the screen sees a non-finite value, and the round falls back to the full f32 sweep)
+                eps[n] = (finite && std::isfinite(bound)) ? std::nextafter((float)(bound * 1.01), INFINITY) : INFINITY;
+            }
+            push("joiner.output_linear.weight#h16", std::move(hv), {nt, ns, 64, 4});
+            push("joiner.output_linear.weight#eps", std::move(eps), {nt * 16});
+        }
     }
     if (has("joiner.decoder_proj.weight")) {   // joiner.decoder_proj [J,DD] -> k-major [DD][J]
         const Tensor& t = tensor("joiner.decoder_proj.weight");

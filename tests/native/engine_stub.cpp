@@ -39,6 +39,7 @@ extern "C" void k2hip_stub_fail_next_step(int n) { g_fail_next_step = n; }
 extern "C" void k2hip_stub_fail_next_gather_finish(int n) { g_fail_next_gather_finish = n; }
 
 Engine::Engine(const std::string& weights, const char* overrides, int device) : device_(device) {
+    tunables_init_from_env();
     model_.reset(new Model(weights, overrides));   // real host-side parse + validation; no upload
     if (device != 0) failf(K2HIP_ERR_NO_DEVICE, "device %d out of range (have 1)", device);
     tunables_init_from_env();
