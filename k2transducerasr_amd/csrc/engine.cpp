@@ -173,6 +173,7 @@ DecJoinW Engine::decjoin() {
     if (model_->has("joiner.output_linear.weight#h16") && tunables().screen_min_v > 0) {
         w.out_h16 = model_->w("joiner.output_linear.weight#h16");
         w.out_eps = model_->w("joiner.output_linear.weight#eps");
+        w.out_vj = model_->w("joiner.output_linear.weight");
     }
     if (w.cpg > 4) {
         if (!d_ptab_) {  // one-off: P[tap] = emb . conv_tap^T on the MFMA GEMM

@@ -447,14 +447,27 @@ static_assert(GF * kScreenMaxCols + 64 + 8 + kScreenCand + kScreenCand * 8 <= kP
 // (a real call: inlined, the four instantiations' loop-invariant addresses stay live across the whole search loop and the kernel spills)
 template <int NS>   // NS = J / 32 K steps: a compile-time constant, so that the tile loop is straight-line code with counted waits
 __device__ __noinline__ bool screen_round(const DecJoinW& w, const float* actT, const _Float16* actH, float* area, int cg0, int cg1, int nf,
-                                             float& bestv, int& besti) {
+                                             float& bestv, int& besti, unsigned long long* st) {
+    unsigned long long tprev = st ? __builtin_amdgcn_s_memrealtime() : 0;
+    auto stamp = [&](int slot) {   // (wave-uniform: st is a kernel argument)
+        if (st) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (threadIdx.x == 0) st[slot] += now - tprev;
+            tprev = now;
+        }
+    };
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: the tile loop's tests stay scalar)
-    const int c_lo = 4 * cg0, c_hi = min(4 * cg1, w.V), ncols = c_hi - c_lo, kper = w.J >> 3;
-    float* scr = area;                                              // [GF][ncols]: upper bounds l~ + eps (-inf outside the slab)
-    float* wlb = area + GF * kScreenMaxCols;                        // [8 waves][GF]: the waves' largest lower bounds l~ - eps
-    int* ctl = reinterpret_cast<int*>(wlb + 64);                    // [0] candidate count, [1] non-finite flag
-    int* cand = ctl + 8;                                            // [kScreenCand]: frame | local column << 3
-    float* part = reinterpret_cast<float*>(cand + kScreenCand);     // [kScreenCand][8 slices]
+    const int c_lo = 4 * cg0, c_hi = min(4 * cg1, w.V), ncols = c_hi - c_lo;
+    // (this is a real call: the LDS pointers arrive as generic pointers -- cast back, or every access is a flat instruction whose
+    // wait also drains the global loads in flight)
+    typedef __attribute__((address_space(3))) float lfloat;
+    typedef __attribute__((address_space(3))) int lint;
+    lfloat* scr = (lfloat*)area;                                    // [GF][ncols]: upper bounds l~ + eps (-inf outside the slab)
+    lfloat* wlb = scr + GF * kScreenMaxCols;                        // [8 waves][GF]: the waves' largest lower bounds l~ - eps
+    lint* ctl = (lint*)(wlb + 64);                                  // [0] candidate count, [1] non-finite flag
+    lint* cand = ctl + 8;                                           // [kScreenCand]: frame | local column << 3
+    lfloat* part = (lfloat*)(cand + kScreenCand);                   // [kScreenCand][8 slices]
+    const lfloat* actL = (const lfloat*)actT;
     if (tid < 2) ctl[tid] = 0;
     // ---- the screen: wave = every 8th 16-column tile; the A fragments (the activations) are re-read from LDS per tile -- held in
     // registers they are 64 VGPRs on top of the B ring's 64 and the kernel spills
@@ -465,6 +478,12 @@ __device__ __noinline__ bool screen_round(const DecJoinW& w, const float* actT, 
     gh16x8* wh = (gh16x8*)w.out_h16;
     float lbmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     bool bad = false;
+    // bias and bound of the lane's column: requested one tile ahead, like the B fragments (fetched behind the MFMAs they were a
+    // dependent global round trip per tile)
+    const float* bias_g = w.out_b;
+    const float* eps_g = w.out_eps;
+    auto colof = [&](int t) { return min(16 * t + (lane & 15), w.V - 1); };
+    float bvn = bias_g[colof(min(t0 + wave, t1 - 1))], en = eps_g[colof(min(t0 + wave, t1 - 1))];
     // B fragments: a ring of one register set -- step s of the NEXT tile is requested as soon as step s of this tile has been
     // used, so a wave keeps a whole tile (16 KB at J = 512) in flight without a second set (two sets spilled: 256 VGPRs + scratch)
     // (no test inside the loop: the wave's last tile re-requests itself; a conditional load costs the counted waits)
@@ -472,6 +491,7 @@ __device__ __noinline__ bool screen_round(const DecJoinW& w, const float* actT, 
     auto tile = [&](int t) {
         const int tn = min(t + GT / 64, t1 - 1);
         gh16x8* wn = wh + ((size_t)tn * NS) * 64 + lane;
+        const float bv = bvn, e = en;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         constexpr int AG = NS >= 4 ? 4 : NS;   // A fragments per LDS round trip
 #pragma unroll
@@ -486,10 +506,11 @@ __device__ __noinline__ bool screen_round(const DecJoinW& w, const float* actT, 
             }
             __builtin_amdgcn_sched_barrier(0);   // (keeps the reloads behind their MFMAs: hoisted, they need a second register set)
         }
+        bvn = bias_g[colof(tn)];
+        en = eps_g[colof(tn)];
         // C/D: column = lane & 15, row (frame) = 4 (lane >> 4) + i: frames 0 .. 7 sit in lanes 0 .. 31
         const int col = 16 * t + (lane & 15);
         if (lane < 32 && col >= c_lo && col < c_hi) {
-            const float bv = w.out_b[col], e = w.out_eps[col];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int f = 4 * (lane >> 4) + i;
@@ -518,18 +539,32 @@ __device__ __noinline__ bool screen_round(const DecJoinW& w, const float* actT, 
     }
     if (__any(bad) && lane == 0) ctl[1] = 1;
     __syncthreads();
+    stamp(2);
     // ---- candidates: every (frame, column) whose upper bound reaches the frame's largest lower bound
-    for (int idx = tid; idx < nf * ncols; idx += GT) {
-        const int f = idx / ncols, c = idx - f * ncols;
-        float tau = wlb[f];
+    {
+        // the eight thresholds first (independent reads), then a thread per column over the frames: as one loop over (frame, column)
+        // with the threshold re-read per element this was a chain of ~70 dependent LDS round trips (2.4 us of the round)
+        float tau[GF];
 #pragma unroll
-        for (int q = 1; q < GT / 64; q++) tau = fmaxf(tau, wlb[q * GF + f]);
-        if (scr[f * ncols + c] >= tau) {
-            const int slot = atomicAdd(&ctl[0], 1);
-            if (slot < kScreenCand) cand[slot] = f | (c << 3);
+        for (int f = 0; f < GF; f++) tau[f] = wlb[f];
+#pragma unroll
+        for (int q = 1; q < GT / 64; q++)
+#pragma unroll
+            for (int f = 0; f < GF; f++) tau[f] = fmaxf(tau[f], wlb[q * GF + f]);
+        for (int c = tid; c < ncols; c += GT) {
+            float ub[GF];
+#pragma unroll
+            for (int f = 0; f < GF; f++) ub[f] = f < nf ? scr[f * ncols + c] : -INFINITY;
+#pragma unroll
+            for (int f = 0; f < GF; f++)
+                if (f < nf && ub[f] >= tau[f]) {
+                    const int slot = atomicAdd((int*)&ctl[0], 1);
+                    if (slot < kScreenCand) cand[slot] = f | (c << 3);
+                }
         }
     }
     __syncthreads();
+    stamp(3);
     const int P = ctl[0];
     const bool give_up = ctl[1] || P > kScreenCand || P <= 0;   // (uniform: read from LDS behind the barrier)
     if (give_up) {
@@ -540,17 +575,22 @@ __device__ __noinline__ bool screen_round(const DecJoinW& w, const float* actT, 
     {
         const int p = tid >> 3, s = tid & 7;
         if (p < P) {
+            // the column's weights from the [V][J] layout: the slice is KP contiguous floats, all requested before the chain starts
+            // (from the k-major matrix every weight was its own 64-byte sector, fetched in four dependent groups: ~8 us per round)
+            constexpr int KP = 4 * NS;   // = kper = J / 8
             const int f = cand[p] & 7, col = c_lo + (cand[p] >> 3);
-            const float* wp = w.out_kn + (long long)(s * kper) * w.Vp + col;
-            const float* ap = actT + (s * kper) * GF + s * APAD + f;
+            const float4* wp = reinterpret_cast<const float4*>(w.out_vj + (long long)col * w.J + s * KP);
+            const lfloat* ap = actL + (s * KP) * GF + s * APAD + f;
+            float4 wv[KP / 4];
+#pragma unroll
+            for (int i = 0; i < KP / 4; i++) wv[i] = wp[i];
             float acc = 0.f;
-            for (int kb = 0; kb < kper; kb += 16) {
-                float wv[16];
 #pragma unroll
-                for (int i = 0; i < 16; i++) wv[i] = wp[(long long)min(kb + i, kper - 1) * w.Vp];
-#pragma unroll
-                for (int i = 0; i < 16; i++)
-                    if (kb + i < kper) acc = fmaf(ap[(kb + i) * GF], wv[i], acc);
+            for (int i = 0; i < KP / 4; i++) {
+                acc = fmaf(ap[(4 * i + 0) * GF], wv[i].x, acc);
+                acc = fmaf(ap[(4 * i + 1) * GF], wv[i].y, acc);
+                acc = fmaf(ap[(4 * i + 2) * GF], wv[i].z, acc);
+                acc = fmaf(ap[(4 * i + 3) * GF], wv[i].w, acc);
             }
             part[p * 8 + s] = acc;
         }
@@ -559,12 +599,13 @@ __device__ __noinline__ bool screen_round(const DecJoinW& w, const float* actT, 
     bestv = -INFINITY;
     besti = -1;
     if (lane < P && (cand[lane] & 7) == wave) {   // wave f: frame f's candidates, one per lane
-        const float* ps = part + lane * 8;
+        const lfloat* ps = part + lane * 8;
         const int col = c_lo + (cand[lane] >> 3);
         bestv = (((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]))) + w.out_b[col];
         besti = col;
     }
     amax_wave(bestv, besti);   // finite values: the total order (later index wins ties) is the reference's scan
+    stamp(4);
     return true;
 }
 
@@ -625,8 +666,21 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
         if (a.t0) decoder_context(w, K2HIP_BLANK_ID, K2HIP_BLANK_ID, h, actT, dec_b);
     }
 
+    unsigned long long* st = (a.stamps && blockIdx.x == 0) ? a.stamps : nullptr;
+    unsigned long long tprev = 0;
+    auto stamp = [&](int slot) {
+        if (st) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0) st[slot] += now - tprev;
+            tprev = now;
+        }
+    };
     while (t < a.Tp && n_tok < a.max_sym) {
         const int nf = min(GF, a.Tp - t);
+        if (st) {
+            tprev = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0) st[0] += 1;
+        }
         // activations of the next GF frames under the current context
         // thread = joiner channel k, the GF frames' encoder values requested together (one frame per iteration of a flat
         // index loop was a chain of J GF / GT = 8 dependent global-load latencies per round, ~12 us of a ~55 us round)
@@ -647,6 +701,7 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
             }
         }
         __syncthreads();
+        stamp(1);
         // The sweep (mfma_sweep_rows): wave = k slice (J / 8 rows), lane = 4 columns -- a pass covers 256 columns of the slab and a
         // wave's load instruction reads 1 KB of one weight row.
         // wave f, after the passes: the reference's scan (rmax_*) of frame f's logits over this part's slab.  Lanes hold consecutive
@@ -658,13 +713,14 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
         bool screened = false;
         if constexpr (SCREEN) if (screen) {
             switch (nks) {
-                case 16: screened = screen_round<16>(w, actT, actH, psum, cg0, cg1, nf, bestv, besti); break;
-                case 8: screened = screen_round<8>(w, actT, actH, psum, cg0, cg1, nf, bestv, besti); break;
-                case 4: screened = screen_round<4>(w, actT, actH, psum, cg0, cg1, nf, bestv, besti); break;
-                default: screened = screen_round<2>(w, actT, actH, psum, cg0, cg1, nf, bestv, besti); break;
+                case 16: screened = screen_round<16>(w, actT, actH, psum, cg0, cg1, nf, bestv, besti, st); break;
+                case 8: screened = screen_round<8>(w, actT, actH, psum, cg0, cg1, nf, bestv, besti, st); break;
+                case 4: screened = screen_round<4>(w, actT, actH, psum, cg0, cg1, nf, bestv, besti, st); break;
+                default: screened = screen_round<2>(w, actT, actH, psum, cg0, cg1, nf, bestv, besti, st); break;
             }
         }
         if (screened && cg0 < cg1) __syncthreads();   // (the passes below are skipped: nothing else reads the psum area this round)
+        if (st) tprev = __builtin_amdgcn_s_memrealtime();
         for (int cgb = cg0; cgb < (screened ? cg0 : cg1); cgb += 64) {
             const int cg = cgb + lane;
             const bool valid = cg < cg1;
@@ -709,6 +765,7 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
             if (cgb + 64 < cg1) __syncthreads();   // psum is rewritten by the next pass
         }
         if (one_pass && !screened) rmax_wave(bestv, besti);
+        stamp(5);
         if (lane == 0) {
             fin[wave] = rmax_index(besti);
             if (G > 1) {  // publish this slab's candidate for frame `wave` (round parity buffer)
@@ -761,6 +818,7 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
             }
         }
         __syncthreads();
+        stamp(6);
         // accept frames in order up to and including the first emission
         int adv = nf;
         bool emitted = false;
@@ -840,6 +898,7 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
         } else {
             __syncthreads();  // actT / fin are rewritten by the next round
         }
+        stamp(7);
     }
     if (tid == 0 && part == 0) a.n_tokens[b] = n_tok < a.max_tokens ? n_tok : a.max_tokens;
 }
@@ -1204,8 +1263,24 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     if (parts > 1) {
         K2_HIP(hipMemsetAsync(a.gran, 0, sizeof(unsigned long long) * (gran_words + gran2_words), ctx.stream));
     }
+    static unsigned long long* d_stamps = nullptr;
+    if (tunables().greedy_stamps) {
+        if (!d_stamps) K2_HIP(hipMalloc(&d_stamps, 8 * sizeof(unsigned long long)));
+        K2_HIP(hipMemsetAsync(d_stamps, 0, 8 * sizeof(unsigned long long), ctx.stream));
+        a.stamps = d_stamps;
+    }
     if (w.out_h16) hipLaunchKernelGGL(k_greedy<true>, dim3(a.B * parts), dim3(GT), lds, ctx.stream, w, a);
     else hipLaunchKernelGGL(k_greedy<false>, dim3(a.B * parts), dim3(GT), lds, ctx.stream, w, a);
+    if (a.stamps) {   // tuning: synchronous report of workgroup 0's round
+        unsigned long long h[8];
+        K2_HIP(hipStreamSynchronize(ctx.stream));
+        K2_HIP(hipMemcpy(h, d_stamps, sizeof h, hipMemcpyDeviceToHost));
+        const double r = h[0] ? (double)h[0] : 1.0;
+        fprintf(stderr, "[k_greedy stamps] %llu rounds, %d parts; us per round: activations %.2f, screen tiles %.2f, candidate scan %.2f, re-check %.2f, "
+                        "sweep passes %.2f, publish + exchange %.2f, decision + decoder %.2f\n", h[0], parts, h[1] / r / 100.0, h[2] / r / 100.0, h[3] / r / 100.0,
+                h[4] / r / 100.0, h[5] / r / 100.0, h[6] / r / 100.0, h[7] / r / 100.0);
+        a.stamps = nullptr;
+    }
     K2_HIP(hipGetLastError());
     if (ctx.greedy_rec) {
         ctx.greedy_rec->valid = parts > 1;

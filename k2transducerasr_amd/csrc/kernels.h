@@ -32,6 +32,7 @@ struct Tunables {
     int beam_trace = 0;           // K2HIP_BEAM_TRACE: the modified beam search records its per-frame selection (k2hip_debug.h: k2hip_debug_beam_trace)
     int screen_min_v = 1024;      // K2HIP_SCREEN_MIN_V: vocabularies of at least this size get the f16 screening pass in the greedy search
                                   // (greedy.hip screen_round: exact tokens, ~2.5x fewer bytes per round); 0 = never
+    int greedy_stamps = 0;        // K2HIP_GREEDY_STAMPS: tuning -- the persistent search reports where a round's time goes (stderr, synchronous)
     int no_graphs = 0;            // K2HIP_NO_GRAPHS: every launch enqueued eagerly (no hipGraph replay of the streaming tick)
     int graph_offline = 0;        // K2HIP_GRAPH_OFFLINE: 1 = the offline batch entries replay their encoder pass from a hipGraph too (measured:
                                   // 13.87 against 13.76 ms per headline batch -- launches of 20 - 80 us hide their own enqueue cost; off by default)
@@ -300,6 +301,7 @@ struct DecJoinW {
     // |f16 product - f32 logit| -- the greedy search's screening pass (greedy.hip screen_round); null = every round sweeps in f32
     const void* out_h16 = nullptr;
     const float* out_eps = nullptr;
+    const float* out_vj = nullptr;   // output_linear in its torch layout [V][J]: a candidate column's weights in one 2 KB piece (the re-check)
     int V, Vp, DD, J, ctx;
 };
 void decoder(const Ctx& ctx, const DecJoinW& w, const long long* y, int N, float* dec_out);
@@ -343,6 +345,10 @@ struct GreedyArgs {
     // decoder outputs of the two start contexts [-1, blank] and [blank, blank] ([2][J], from decoder_start_contexts): constants of
     // the model, so every workgroup of every batch loads them instead of running the decoder twice (null: computed in the kernel)
     const float* dec_init = nullptr;
+    // tuning only (K2HIP_GREEDY_STAMPS): workgroup 0 accumulates s_memrealtime (100 MHz) differences per phase of a round here --
+    // [0] rounds, [1] activations, [2] screen tiles, [3] candidate scan, [4] re-check, [5] sweep passes, [6] publish + exchange,
+    // [7] decision + decoder update
+    unsigned long long* stamps = nullptr;
 };
 void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a);
 // The vocabulary-parallel search waits on its sibling workgroups (bounded spins; a timeout raises *overflow = 2).  All B x parts

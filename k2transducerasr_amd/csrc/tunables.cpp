@@ -41,6 +41,7 @@ const Entry kEntries[] = {
     {"K2HIP_BEAM_PARTS", &Tunables::beam_parts, false},
     {"K2HIP_BEAM_TRACE", &Tunables::beam_trace, true},
     {"K2HIP_SCREEN_MIN_V", &Tunables::screen_min_v, false},
+    {"K2HIP_GREEDY_STAMPS", &Tunables::greedy_stamps, true},
     {"K2HIP_NO_GRAPHS", &Tunables::no_graphs, true},
     {"K2HIP_GRAPH_OFFLINE", &Tunables::graph_offline, false},
     {"K2HIP_TEST_GREEDY_TIMEOUT", &Tunables::test_greedy_timeout, true},
