@@ -56,6 +56,10 @@ void tunables_init_from_env() {
     g_init = true;
     for (const Entry& e : kEntries)
         if (const char* v = getenv(e.env)) g_t.*(e.field) = e.flag ? 1 : atoi(v);
+    // Under rocprofv3 (it announces itself with ROCP_TOOL_LIBRARIES) every launch stays eager: the profiler's kernel tracer of ROCm 7.2
+    // segfaults inside the HIP runtime when a stream it traces is captured into / replayed from a hipGraph (seen on
+    // bench_streaming.py; profiles/README.md).  A profile then shows the eager chain, which is the same kernels.
+    if (getenv("ROCP_TOOL_LIBRARIES") && !getenv("K2HIP_GRAPHS_UNDER_PROFILER")) g_t.no_graphs = 1;
 }
 
 const Tunables& tunables() { return g_t; }
