@@ -371,3 +371,36 @@ def test_search_as_rounds_equals_persistent_kernel(hip_tiny, oracle_tiny, utts, 
     assert rounds[1:3] == persistent[1:3]
     for name, case in sorted(CASES.items()):
         assert rounds[3][name] == case["batch"] == persistent[3][name], name
+
+
+def test_large_vocabulary_screened_search_end_to_end(tmp_path):
+    """A vocabulary of 3000 behind the tiny encoder: the persistent search runs its large-vocabulary form (k_greedy<true>: per round an
+    f16 screening sweep with load-time error bounds, then the exact f32 re-check of the columns that can win; greedy.hip screen_round)
+    over several column slabs per stream.  Ragged batches from samples against the oracle, the same batches with the screen switched
+    off (every round sweeps in f32), and one slab per stream (2 .. 3 passes of 1536 columns would not fit the screen's LDS area:
+    that form keeps the f32 passes) -- all three must give the oracle's tokens."""
+    from k2transducerasr_amd import Model, set_switch
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    from oracle import Oracle
+    p = str(tmp_path / "wide.k2w")
+    write_synthetic_model(p, "zipformer2-tiny-test", blank_bias=2.4, meta_overrides={"vocab_size": "3000"})
+    hip, ora = Model(p, 0), Oracle(p)
+    rng = np.random.default_rng(77)
+    emitted = frames = 0
+    for case in range(6):
+        B = int(rng.integers(1, 7))
+        utts = [synth_utterance(900 + 8 * case + b, float(rng.uniform(0.4, 2.2))) for b in range(B)]
+        feats = [ora.fbank(u) for u in utts]
+        want = ora.recognize_batch(feats)
+        _, mg = ora.greedy_batch(ora.encoder(ora.pad_sequence(feats).reshape(B, -1, 80)), want_margins=True)
+        assert_tokens_match(hip.offline_greedy_from_samples(utts), want, mg, what=f"screened search, case {case}")
+        emitted += sum(len(t) for t, _ in want)
+        frames += mg.size
+        for switch, value in (("K2HIP_SCREEN_MIN_V", 0), ("K2HIP_GREEDY_ONE_PART", 1)):
+            set_switch(switch, value)
+            try:
+                assert_tokens_match(hip.offline_greedy_from_samples(utts), want, mg, what=f"{switch}={value}, case {case}")
+            finally:
+                set_switch(switch, 1024 if switch == "K2HIP_SCREEN_MIN_V" else 0)
+    assert 0.03 * frames < emitted < 0.7 * frames, (emitted, frames)     # blank wins many frames and loses some: both branches of the loop run
+    hip.close()

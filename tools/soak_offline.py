@@ -18,12 +18,17 @@ from parity import assert_beam_match, assert_tokens_match  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-presets = ["zipformer2-tiny-test", "zipformer-tiny-test", "conformer-tiny-test", "lstm-tiny-test", "lstm-tiny-split-test"]
+# (preset, metadata overrides, blank bias): the last entry has a vocabulary wide enough for the f16-screened search (k_greedy<true>)
+presets = [("zipformer2-tiny-test", None, None), ("zipformer-tiny-test", None, None), ("conformer-tiny-test", None, None), ("lstm-tiny-test", None, None),
+           ("lstm-tiny-split-test", None, None), ("zipformer2-tiny-test", {"vocab_size": "3000"}, 2.4)]
 tmp = tempfile.mkdtemp()
+pkg.set_switch("K2HIP_BEAM_TRACE", 1)
 lens_pool = [400, 401, 559, 560, 1999, 3200, 4801, 8000, 12345, 16000, 20001, 31999]
-for preset in presets:
-    path = os.path.join(tmp, preset + ".k2w")
-    write_synthetic_model(path, preset)
+for preset, overrides, bias in presets:
+    path = os.path.join(tmp, preset + ("-wide" if overrides else "") + ".k2w")
+    write_synthetic_model(path, preset, blank_bias=bias, meta_overrides=overrides)
+    if overrides:
+        preset += " " + str(overrides)
     hip, ora = pkg.Model(path, 0), Oracle(path)
     rng = np.random.default_rng(seed)
     exact = tot = skipped = bexact = btot = 0
@@ -44,8 +49,10 @@ for preset in presets:
         if preset == "zipformer2-tiny-test":   # the modified beam search (one kernel per batch on this vocabulary) on the same encoder output
             enc = ora.encoder(x)
             beam = int(rng.choice([2, 4, 8]))
-            bwant, bmg = ora.modified_beam_search(enc, beam, want_margins=True)
-            bexact += assert_beam_match(hip.beam_search(enc, beam), bwant, bmg, what=f"{preset} case {case} beam {beam}", allow_tie=True)
+            bwant, bmg, btr = ora.modified_beam_search(enc, beam, want_margins=True, want_trace=True)
+            bgot = hip.beam_search(enc, beam)
+            bexact += assert_beam_match(bgot, bwant, bmg, what=f"{preset} case {case} beam {beam}", allow_tie=True, trace_got=hip.beam_trace(),
+                                        trace_want=btr)
             btot += B
     print(f"{preset}: {cases - skipped} batches, {exact}/{tot} streams token-exact (the rest diverge on an oracle near-tie)", flush=True)
     if btot:
