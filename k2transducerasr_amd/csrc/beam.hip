@@ -24,7 +24,7 @@ __global__ void k_beam_init(BeamState s, int B) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * s.K) return;
     int k = i % s.K;
-    s.lp[i] = k == 0 ? 0.0 : -(double)INFINITY;
+    s.lp[i] = k == 0 ? 0.f : -INFINITY;
     s.n[i] = 0;
     s.n[B * s.K + i] = 0;
     s.ctx[2 * i] = K2HIP_BLANK_ID;
@@ -102,26 +102,23 @@ struct HypView {
     int K, cap;
     const int *ys_c, *ts_c, *n_c;
     int *ys_n, *ts_n, *n_n;
-    double* lp;        // [K] in place: every read of it precedes (barrier-separated) tid 0's write.  float64: a hypothesis' score is a sum
-                       // of ~200 float32 log-softmax terms; in float32 (|score| ~ 100, ulp 7.6e-6) different hypotheses' candidates come
-                       // out exactly equal often enough to decide one stream in fifty by a last bit (oracle/k2_oracle_beam.c)
+    float* lp;         // [K] in place: every read of it precedes (barrier-separated) tid 0's write
     long long* ctx;    // [K][2]
     int* nhyp;
     // debug tap (k2hip_debug.h, K2HIP_BEAM_TRACE) or null: this frame's record of this stream, 2 K + 1 words = the selected candidates'
     // flat indexes (slot * V + token) in rank order, their scores (float bits), the number of hypotheses after the merges
     int* trace = nullptr;
 };
-// taken[K] | topi[K] | pad to 8 bytes | topv[K] doubles | candv[K][K] doubles | candi[K][K]
-constexpr int kStepScratchInts = 2 * kMaxBeam + 2 * kMaxBeam + 2 * kMaxBeam * kMaxBeam + kMaxBeam * kMaxBeam + 4;
+constexpr int kStepScratchInts = 4 * kMaxBeam + 4 + 2 * kMaxBeam * kMaxBeam;
 // one workgroup of NT threads per stream; lg: the hypotheses' logits, ldl floats per row; scratch: kStepScratchInts ints of LDS
 template <int NT>
 __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int V, int t, int* scratch) {
     constexpr int BT = NT;
     int* taken = scratch;
-    int* topi = scratch + kMaxBeam;
-    double* topv = reinterpret_cast<double*>(scratch + 2 * kMaxBeam);          // (scratch is 8-byte aligned at both call sites)
-    double* candv = topv + kMaxBeam;
-    int* candi = reinterpret_cast<int*>(candv + kMaxBeam * kMaxBeam);
+    float* topv = reinterpret_cast<float*>(scratch + kMaxBeam);
+    int* topi = scratch + 2 * kMaxBeam;
+    float* candv = reinterpret_cast<float*>(scratch + 4 * kMaxBeam + 4);
+    int* candi = scratch + 4 * kMaxBeam + 4 + kMaxBeam * kMaxBeam;
     const int tid = threadIdx.x, K = hv.K;
     const int nA = *hv.nhyp;
     // ---- one wave per hypothesis (4 waves, K <= 8): log_softmax statistics, then the hypothesis' own top `want` candidates by
@@ -149,13 +146,9 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
                     if (lane + 64 * i < V) sm += expf(lv[i] - mx);
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
-                const float lse = logf(sm);
-                const double lpk = hv.lp[k];
-                // the float32 log-softmax terms, in the oracle's order of operations.  Within ONE hypothesis the double scores
-                // (double)term + lp are ordered exactly as the terms (distinct floats stay distinct doubles, equal stay equal), so the
-                // hypothesis' own top `want` is selected on the floats; the candidates go on as doubles
+                const float lse = logf(sm), lpk = hv.lp[k];
 #pragma unroll
-                for (int i = 0; i < NE; i++) lv[i] = lv[i] - mx - lse;
+                for (int i = 0; i < NE; i++) lv[i] = (lv[i] - mx - lse) + lpk;  // the scores, in the oracle's order of operations
                 unsigned used = 0;  // bit i: this lane's element i was already selected
                 for (int r = 0; r < want; r++) {
                     float bv = -INFINITY;
@@ -168,7 +161,7 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
                     }
                     wave_best(bv, bi);
                     if (bi >= 0 && (bi & 63) == lane) used |= 1u << (bi >> 6);
-                    if (lane == 0) { candv[k * kMaxBeam + r] = (double)bv + lpk; candi[k * kMaxBeam + r] = bi < 0 ? -1 : k * V + bi; }
+                    if (lane == 0) { candv[k * kMaxBeam + r] = bv; candi[k * kMaxBeam + r] = bi < 0 ? -1 : k * V + bi; }
                 }
             }
         };
@@ -184,8 +177,7 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
         for (int v = lane; v < V; v += 64) sm += expf(l[v] - mx);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
-        const float lse = logf(sm);
-        const double lpk = hv.lp[k];
+        const float lse = logf(sm), lpk = hv.lp[k];
         int excl[kMaxBeam];
         for (int r = 0; r < want; r++) {
             float bv = -INFINITY;
@@ -194,12 +186,12 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
                 bool tk = false;
                 for (int q = 0; q < r; q++) tk |= (excl[q] == v);
                 if (tk) continue;
-                const float sc = l[v] - mx - lse;  // the float32 log-softmax term, in the oracle's order of operations
+                const float sc = (l[v] - mx - lse) + lpk;  // the oracle's order of operations
                 if (bi < 0 || sc > bv) { bv = sc; bi = v; }   // ascending v per lane: first maximum wins
             }
             wave_best(bv, bi);
             excl[r] = bi;
-            if (lane == 0) { candv[k * kMaxBeam + r] = (double)bv + lpk; candi[k * kMaxBeam + r] = bi < 0 ? -1 : k * V + bi; }
+            if (lane == 0) { candv[k * kMaxBeam + r] = bv; candi[k * kMaxBeam + r] = bi < 0 ? -1 : k * V + bi; }
         }
     }
     __syncthreads();
@@ -208,16 +200,13 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
         // indexes are unique): every candidate is broadcast in turn with v_readlane and compared by all lanes at once, no dependent
         // rounds (`want` rounds of a wave-wide best, each waiting for the one before, were 2 us of the step).
         const bool has = (lane / kMaxBeam) < nA && (lane % kMaxBeam) < want;
-        const double myv = has ? candv[lane] : -(double)INFINITY;
+        const float myv = has ? candv[lane] : -INFINITY;
         const int myi = has ? candi[lane] : -1;
-        const unsigned long long mybits = __builtin_bit_cast(unsigned long long, myv);
         int rank = 0;
         for (int k = 0; k < nA; k++)
             for (int r = 0; r < want; r++) {
                 const int src = k * kMaxBeam + r;   // (uniform)
-                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mybits, src);
-                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mybits >> 32), src);
-                const double ov = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+                const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), src));
                 const int oi = __builtin_amdgcn_readlane(myi, src);
                 if (oi >= 0 && (ov > myv || (ov == myv && oi < myi))) rank++;
             }
@@ -257,12 +246,12 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
         // One thread resolves the merges in insertion order.  Everything it needs is read up front (independent LDS loads) and kept in
         // registers -- fully unrolled, selects instead of indexed arrays: as a loop over LDS this was a chain of ~40 dependent
         // accesses, 2 us of the step.
-        double tv[kMaxBeam], lpn[kMaxBeam];
+        float tv[kMaxBeam], lpn[kMaxBeam];
         unsigned eqm[kMaxBeam];   // bit q of eqm[r]: candidates r and q < r spell the same sequence
 #pragma unroll
         for (int r = 0; r < kMaxBeam; r++) {
-            tv[r] = r < want ? topv[r] : -(double)INFINITY;
-            lpn[r] = -(double)INFINITY;
+            tv[r] = r < want ? topv[r] : -INFINITY;
+            lpn[r] = -INFINITY;
             eqm[r] = 0;
 #pragma unroll
             for (int q = 0; q < r; q++)
@@ -286,14 +275,14 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
                 }
                 slot_of[r] = sl;
                 // slot assignment in insertion order; merged scores accumulate in candidate order (logaddexp)
-                double cur = -(double)INFINITY;
+                float cur = -INFINITY;
 #pragma unroll
                 for (int q = 0; q < kMaxBeam; q++)
                     if (q == sl) cur = lpn[q];
-                double nv = tv[r];
+                float nv = tv[r];
                 if (found >= 0) {
-                    const double mx = fmax(cur, tv[r]);
-                    nv = (isinf(mx) && mx < 0) ? mx : mx + log1p(exp(-fabs(cur - tv[r])));
+                    const float mx = fmaxf(cur, tv[r]);
+                    nv = (isinf(mx) && mx < 0) ? mx : mx + log1pf(expf(-fabsf(cur - tv[r])));
                 } else {
                     nN++;
                 }
@@ -307,7 +296,7 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
         for (int q = 0; q < kMaxBeam; q++)
             if (q < nN) hv.lp[q] = lpn[q];
         for (int k = nN; k < K; k++) {
-            hv.lp[k] = -(double)INFINITY;
+            hv.lp[k] = -INFINITY;
             // empty slots still go through the batched decoder launch: give them a valid context
             hv.ctx[2 * k] = K2HIP_BLANK_ID;
             hv.ctx[2 * k + 1] = K2HIP_BLANK_ID;
@@ -318,7 +307,7 @@ __device__ void beam_step_body(const HypView& hv, const float* lg, int ldl, int 
     }
     if (hv.trace && tid < K) {
         hv.trace[tid] = tid < want ? topi[tid] : -1;
-        hv.trace[K + tid] = __float_as_int(tid < want ? (float)topv[tid] : -INFINITY);
+        hv.trace[K + tid] = __float_as_int(tid < want ? topv[tid] : -INFINITY);
     }
     __syncthreads();
     for (int r = wave; r < want; r += BT / 64) {   // a wave per surviving candidate (distinct destination slots)
@@ -388,9 +377,9 @@ __device__ __forceinline__ void bstore_granule(unsigned long long* g, unsigned e
 __device__ __forceinline__ unsigned long long bload_granule(const unsigned long long* g) {
     return __hip_atomic_load((bgu64*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// LDS (floats): actT[J GF] | psum | lg[GF][Vp] | ctx[2 GF] (long long) | lp[GF] (double) | n[2][GF] | nhyp, pad | scratch | ys[2][K][cap] | ts[2][K][cap]
+// LDS (floats): actT[J GF] | psum | lg[GF][Vp] | ctx[2 GF] (long long) | lp[GF] | n[2][GF] | nhyp, pad | scratch | ys[2][K][cap] | ts[2][K][cap]
 __host__ __device__ inline size_t beam_loop_lds_floats(int J, int Vp, int K, int cap, bool hyp_in_lds) {
-    return (size_t)J * GF + kPsumFloats + (size_t)GF * Vp + 4 * GF + 2 * GF + 2 * GF + 4 + kStepScratchInts + 4 + (hyp_in_lds ? 4 * (size_t)K * cap : 0);
+    return (size_t)J * GF + kPsumFloats + (size_t)GF * Vp + 4 * GF + GF + 2 * GF + 4 + kStepScratchInts + 4 + (hyp_in_lds ? 4 * (size_t)K * cap : 0);
 }
 template <int NH>   // NH = 1: beam <= 4, the sweep forms only rows 0..3
 __global__ __launch_bounds__(GT) void k_beam_loop(DecJoinW w, BeamLoopArgs a) {
@@ -399,7 +388,7 @@ __global__ __launch_bounds__(GT) void k_beam_loop(DecJoinW w, BeamLoopArgs a) {
     float* psum = actT + w.J * GF;
     float* lg = psum + kPsumFloats;
     long long* ctx = reinterpret_cast<long long*>(lg + GF * w.Vp);   // (J GF, the psum size and GF Vp are multiples of 4 floats)
-    double* lp = reinterpret_cast<double*>(ctx + 2 * GF);
+    float* lp = reinterpret_cast<float*>(ctx + 2 * GF);
     int* nbuf = reinterpret_cast<int*>(lp + GF);       // [2][GF]
     int* nhyp = nbuf + 2 * GF;
     int* scratch = nhyp + 4;
@@ -411,7 +400,7 @@ __global__ __launch_bounds__(GT) void k_beam_loop(DecJoinW w, BeamLoopArgs a) {
     const int b = a.xg ? blockIdx.x >> 1 : blockIdx.x, slab = a.xg ? blockIdx.x & 1 : 0;
     const float* enc = a.enc + (long long)b * a.Tp * w.J;
     if (tid < GF) {   // k_beam_init
-        lp[tid] = tid == 0 ? 0.0 : -(double)INFINITY;
+        lp[tid] = tid == 0 ? 0.f : -INFINITY;
         nbuf[tid] = 0;
         nbuf[GF + tid] = 0;
         ctx[2 * tid] = K2HIP_BLANK_ID;
@@ -555,9 +544,9 @@ __global__ __launch_bounds__(GT) void k_beam_loop(DecJoinW w, BeamLoopArgs a) {
     const int fin = a.Tp & 1;
     const int* n_f = nbuf + fin * GF;
     int best = 0;
-    double bs = lp[0] / (double)(n_f[0] + 2);
+    float bs = lp[0] / (float)(n_f[0] + 2);
     for (int k = 1; k < *nhyp; k++) {
-        const double v = lp[k] / (double)(n_f[k] + 2);
+        const float v = lp[k] / (float)(n_f[k] + 2);
         if (v > bs) { bs = v; best = k; }
     }
     const int n = n_f[best];
@@ -574,7 +563,7 @@ __global__ __launch_bounds__(GT) void k_beam_loop(DecJoinW w, BeamLoopArgs a) {
     }
     if (tid == 0) {
         a.n_tokens[b] = n;
-        if (a.scores) a.scores[b] = (float)lp[best];
+        if (a.scores) a.scores[b] = lp[best];
     }
 }
 
@@ -585,9 +574,9 @@ __global__ void k_beam_final(BeamState s, int fin, int B, long long* __restrict_
     const long long BK = (long long)B * K;
     const int* n_f = s.n + fin * BK + b * K;
     int best = 0;
-    double bs = s.lp[b * K] / (double)(n_f[0] + 2);
+    float bs = s.lp[b * K] / (float)(n_f[0] + 2);
     for (int k = 1; k < s.nhyp[b]; k++) {
-        double v = s.lp[b * K + k] / (double)(n_f[k] + 2);
+        float v = s.lp[b * K + k] / (float)(n_f[k] + 2);
         if (v > bs) { bs = v; best = k; }
     }
     const int n = n_f[best];
@@ -603,7 +592,7 @@ __global__ void k_beam_final(BeamState s, int fin, int B, long long* __restrict_
     }
     if (threadIdx.x == 0) {
         n_tokens[b] = n;
-        if (scores) scores[b] = (float)s.lp[b * K + best];
+        if (scores) scores[b] = s.lp[b * K + best];
     }
 }
 
@@ -666,7 +655,7 @@ void beam_search(const Ctx& ctx, const DecJoinW& w, const BeamArgs& a) {
     s.ys = ar.take<int>((int64_t)2 * M * cap);
     s.ts = ar.take<int>((int64_t)2 * M * cap);
     s.n = ar.take<int>((int64_t)2 * M);
-    s.lp = ar.take<double>(M);
+    s.lp = ar.take<float>(M);
     s.lp_next = s.lp;  // in place: within k_beam_step every read of a stream's lp / nhyp precedes (barrier-separated) tid 0's write
     s.ctx = ar.take<long long>((int64_t)2 * M);
     s.ctx_next = s.ctx;

@@ -399,7 +399,7 @@ struct BeamState {       // device arrays; hypotheses double-buffered by frame p
     int* ys;             // [2][B][K][cap] tokens without the ctx-blank prefix
     int* ts;             // [2][B][K][cap]
     int* n;              // [2][B][K]
-    double *lp, *lp_next; // [B][K] hypothesis log-probs, float64 sums of float32 log-softmax terms (oracle/k2_oracle_beam.c says why); -inf = empty slot
+    float *lp, *lp_next; // [B][K] hypothesis log-probs (-inf = empty slot)
     long long *ctx, *ctx_next;  // [B][K][2] decoder inputs
     int *nhyp, *nhyp_next;      // [B]
 };

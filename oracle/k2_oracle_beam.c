@@ -17,15 +17,6 @@
  *
  * Tie-breaks the published code leaves to the library are fixed here: top-k is by (score desc, flat index
  * asc); the final argmax keeps the first maximum in insertion order (Python's max()).
- *
- * One deliberate departure from the published ARITHMETIC (round 4): a hypothesis' log_prob is accumulated in float64.  The per-frame
- * term is still float32 as in icefall -- log_softmax(logits) = (x - max) - log(sum exp(x - max)) -- but it is added to a double, the
- * top-k compares doubles, logaddexp and the final length normalisation run in double.  Why: after ~200 frames |log_prob| is ~100 and a
- * float32 sum has a resolution of 7.6e-6 there; two different hypotheses' candidates then come out EXACTLY equal about once in fifty
- * streams, and which one survives is decided by the flat index here and by the last bit of another summation order anywhere else
- * (measured: 3 of 128 streams on the oracle's own encoder_out, all at an oracle gap of 0.0 or one ulp).  With float64 sums the
- * algorithm's decisions no longer hinge on the resolution of its bookkeeping.  The returned score is the double rounded to float.
- *
  * x_lens = T' for every stream on this path (OfflineProjOfTransducer.cs:66-70), so the packed-sequence
  * bookkeeping of the batch form reduces to B independent streams.
  */
@@ -33,13 +24,13 @@ typedef struct {
     int64_t* ys;    /* [cap] incl. the ctx-blank prefix */
     int32_t* ts;    /* [cap] */
     int n, nts;
-    double lp;
+    float lp;
 } beam_hyp;
 
-static double logaddexp_d(double a, double b) {
-    double mx = a > b ? a : b, d = -fabs(a - b);
+static float logaddexp_f(float a, float b) {
+    float mx = a > b ? a : b, d = -fabsf(a - b);
     if (isinf(mx) && mx < 0) return mx;
-    return mx + log1p(exp(d));
+    return mx + log1pf(expf(d));
 }
 
 /* margins (optional): [Tp+1] -- per frame the gap between the beam-th and (beam+1)-th candidate score (INF if
@@ -68,11 +59,10 @@ int k2o_modified_beam_search_trace(const k2o_model* m, const float* enc_out, int
         }
         int nA = 1;
         for (int k = 0; k < ctx; k++) A[0].ys[k] = blank;
-        A[0].n = ctx; A[0].nts = 0; A[0].lp = 0.0;
+        A[0].n = ctx; A[0].nts = 0; A[0].lp = 0.f;
         float* dec = falloc((size_t)beam * J);
         float* cur = falloc((size_t)beam * J);
         float* lg = falloc((size_t)beam * V);
-        double* sc = (double*)malloc(sizeof(double) * (size_t)beam * V);
         int64_t* yin = (int64_t*)malloc(sizeof(int64_t) * beam * ctx);
         float* mg = margins ? margins + (size_t)b * (Tp + 1) : NULL;
         for (int t = 0; t < Tp && !rc; t++) {
@@ -82,7 +72,7 @@ int k2o_modified_beam_search_trace(const k2o_model* m, const float* enc_out, int
             }
             if ((rc = k2o_decoder(m, yin, nA, dec))) break;
             k2o_joiner(m, cur, dec, nA, lg);
-            /* log_softmax in float32 (x - max - log(sum(exp(x - max)))), added to the hypothesis' float64 log_prob */
+            /* log_softmax (float32: x - max - log(sum(exp(x - max)))) + hyp log_prob */
             for (int k = 0; k < nA; k++) {
                 float* l = lg + (size_t)k * V;
                 float mx = l[0];
@@ -90,26 +80,26 @@ int k2o_modified_beam_search_trace(const k2o_model* m, const float* enc_out, int
                 float s = 0.f;
                 for (int v = 0; v < V; v++) s += expf(l[v] - mx);
                 float lse = logf(s);
-                for (int v = 0; v < V; v++) sc[(size_t)k * V + v] = (double)(l[v] - mx - lse) + A[k].lp;
+                for (int v = 0; v < V; v++) l[v] = (l[v] - mx - lse) + A[k].lp;
             }
             /* top `beam` of nA*V by (value desc, flat index asc), plus the runner-up for the margin */
             int nc = nA * V, want = beam < nc ? beam : nc;
             const int ext = trace ? 2 * beam : want + 1;   /* how many candidates to rank */
             int top[33];
-            double topv[33];
+            float topv[33];
             int nt = 0;
             for (int r = 0; r < ext && r < nc; r++) {
                 int bi = -1;
-                double bv = -INFINITY;
+                float bv = -INFINITY;
                 for (int i = 0; i < nc; i++) {
                     int taken = 0;
                     for (int q = 0; q < nt; q++) taken |= (top[q] == i);
                     if (taken) continue;
-                    if (bi < 0 || sc[i] > bv) { bi = i; bv = sc[i]; }
+                    if (bi < 0 || lg[i] > bv) { bi = i; bv = lg[i]; }
                 }
                 top[nt] = bi; topv[nt] = bv; nt++;
             }
-            if (mg) mg[t] = nt > want ? (float)(topv[want - 1] - topv[want]) : INFINITY;
+            if (mg) mg[t] = nt > want ? topv[want - 1] - topv[want] : INFINITY;
             int nN = 0;
             for (int r = 0; r < want; r++) {
                 int hi = top[r] / V, tok = top[r] % V;
@@ -124,7 +114,7 @@ int k2o_modified_beam_search_trace(const k2o_model* m, const float* enc_out, int
                     if (same && real) same = N[q].ys[nn - 1] == tok;
                     if (same) dup = q;
                 }
-                if (dup >= 0) { N[dup].lp = logaddexp_d(N[dup].lp, topv[r]); continue; }
+                if (dup >= 0) { N[dup].lp = logaddexp_f(N[dup].lp, topv[r]); continue; }
                 beam_hyp* d = &N[nN++];
                 memcpy(d->ys, h->ys, sizeof(int64_t) * h->n);
                 memcpy(d->ts, h->ts, sizeof(int32_t) * h->nts);
@@ -136,7 +126,7 @@ int k2o_modified_beam_search_trace(const k2o_model* m, const float* enc_out, int
                 int32_t* tr = trace + ((size_t)b * Tp + t) * (4 * beam + 1);
                 for (int r = 0; r < 2 * beam; r++) {
                     tr[r] = r < nt ? top[r] : -1;
-                    float v = r < nt ? (float)topv[r] : -INFINITY;
+                    float v = r < nt ? topv[r] : -INFINITY;
                     memcpy(&tr[2 * beam + r], &v, sizeof(float));
                 }
                 tr[4 * beam] = nN;
@@ -146,13 +136,13 @@ int k2o_modified_beam_search_trace(const k2o_model* m, const float* enc_out, int
         }
         if (!rc) {
             int best = 0;
-            double bs = A[0].lp / (double)A[0].n, second = -INFINITY;
+            float bs = A[0].lp / (float)A[0].n, second = -INFINITY;
             for (int k = 1; k < nA; k++) {
-                double s = A[k].lp / (double)A[k].n;
+                float s = A[k].lp / (float)A[k].n;
                 if (s > bs) { second = bs; bs = s; best = k; }
                 else if (s > second) second = s;
             }
-            if (mg) mg[Tp] = nA > 1 ? (float)(bs - second) : INFINITY;
+            if (mg) mg[Tp] = nA > 1 ? bs - second : INFINITY;
             int n = A[best].n - ctx;
             if (n > max_tokens) rc = fail("beam search: stream %d has %d tokens > max_tokens %d", b, n, max_tokens);
             else {
@@ -161,11 +151,11 @@ int k2o_modified_beam_search_trace(const k2o_model* m, const float* enc_out, int
                     timestamps[(size_t)b * max_tokens + i] = A[best].ts[i];
                 }
                 n_tokens[b] = n;
-                if (scores) scores[b] = (float)A[best].lp;
+                if (scores) scores[b] = A[best].lp;
             }
         }
         for (int k = 0; k < beam; k++) { free(A[k].ys); free(A[k].ts); free(N[k].ys); free(N[k].ts); }
-        free(A); free(N); free(dec); free(cur); free(lg); free(sc); free(yin);
+        free(A); free(N); free(dec); free(cur); free(lg); free(yin);
     }
     return rc;
 }

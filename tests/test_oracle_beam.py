@@ -13,8 +13,7 @@ def icefall_modified_beam_search(oracle, enc_out, beam=4):
     blank_id, unk_id, context_size = 0, 2, oracle.context_size
     B = {}
     ys0 = [blank_id] * context_size
-    # (log_prob in float64, the per-frame log_softmax in float32: the one departure from icefall's arithmetic, see k2_oracle_beam.c)
-    B[tuple(ys0)] = dict(ys=ys0, log_prob=torch.zeros(1, dtype=torch.float64), timestamp=[])
+    B[tuple(ys0)] = dict(ys=ys0, log_prob=torch.zeros(1, dtype=torch.float32), timestamp=[])
     T = enc_out.shape[0]
     for t in range(T):
         A = list(B.values())
@@ -24,7 +23,7 @@ def icefall_modified_beam_search(oracle, enc_out, beam=4):
         decoder_out = oracle.decoder(decoder_input)
         cur = np.repeat(enc_out[t : t + 1], len(A), 0)
         logits = torch.from_numpy(oracle.joiner(cur, decoder_out))
-        log_probs = logits.log_softmax(dim=-1).to(torch.float64)
+        log_probs = logits.log_softmax(dim=-1)
         log_probs.add_(ys_log_probs)
         vocab_size = log_probs.size(-1)
         log_probs = log_probs.reshape(-1)
@@ -125,11 +124,13 @@ def test_trace_tap_is_consistent_with_the_search(oracle_tiny, enc_tiny):
         for t in range(Tp):
             live = idx[b, t] >= 0
             v = val[b, t][live]
-            assert (np.diff(v) <= 0).all()       # (the tap holds the float64 scores rounded to float32: rounding keeps the order, ties may appear)
+            assert (np.diff(v) <= 0).all()
+            ties = np.nonzero(np.diff(v) == 0)[0]
+            assert all(idx[b, t, i] < idx[b, t, i + 1] for i in ties)
             assert 1 <= n[b, t] <= min(beam, live.sum())
             assert (idx[b, t][live] // V < (1 if t == 0 else n[b, t - 1])).all()     # slots of the previous frame's survivors
             if live.sum() > beam:
-                assert mg[b, t] == pytest.approx(val[b, t, beam - 1] - val[b, t, beam], abs=2e-5)
+                assert mg[b, t] == pytest.approx(val[b, t, beam - 1] - val[b, t, beam], abs=0)
     assert (n[:, 0] >= 1).all() and (idx[:, 0, :beam] < V).all()       # frame 0 expands the single start hypothesis
 
 
