@@ -329,7 +329,11 @@ void Engine::graphed(const Ctx& c, GraphKey key, F&& enqueue) {
             auto old = graphs_.begin();
             for (auto j = graphs_.begin(); j != graphs_.end(); ++j)
                 if (j->second.last_use < old->second.last_use) old = j;
-            if (old->second.exec) (void)hipGraphExecDestroy(old->second.exec);
+            if (old->second.exec) {
+                // (its last replay may still be running on its stream -- the pipelined offline entries do not wait per batch)
+                (void)hipStreamSynchronize(static_cast<hipStream_t>(const_cast<void*>(old->first.stream)));
+                (void)hipGraphExecDestroy(old->second.exec);
+            }
             graphs_.erase(old);
         }
         graphs_[key].last_use = ++graph_clock_;
