@@ -154,7 +154,7 @@ def make_conformer_meta(
         # streaming export (causal convolutions, chunk_forward): the keys OnlineModel.cs:131-166 reads for OnlineProjOfConformer.
         # T = (chunk_size + 2 + right_context) * 4 + 3 input frames per chunk (one embed frame is cut on each side),
         # decode_chunk_len = chunk_size * 4
-        assert right_context == 0, "only right_context = 0 is built"
+        assert right_context >= 0
         meta.update(
             {
                 "streaming": "1",
@@ -322,6 +322,11 @@ CONFORMER_PRESETS = {
     # parity-test model: odd head size, small kernel, decoder conv with groups = 1
     "conformer-streaming-tiny-test": dict(encoder_dim=64, num_encoder_layers=2, feedforward_dim=160, num_heads=4, cnn_module_kernel=7,
                                           joiner_dim=512, decoder_dim=64, vocab_size=41, streaming=True, chunk_size=8, left_context=16),
+    # the same with two frames of right context (OnlineModel.cs:161-165 reads the key): a chunk is chunk_size + 2 encoder frames, the last
+    # two are seen by the attention and the convolution of this step and come again, as the first two, in the next one
+    "conformer-streaming-rc-tiny-test": dict(encoder_dim=64, num_encoder_layers=2, feedforward_dim=160, num_heads=4, cnn_module_kernel=7,
+                                             joiner_dim=512, decoder_dim=64, vocab_size=41, streaming=True, chunk_size=8, left_context=16,
+                                             right_context=2),
     "conformer-tiny-test": dict(encoder_dim=64, num_encoder_layers=2, feedforward_dim=160, num_heads=4, cnn_module_kernel=7,
                                 joiner_dim=512, decoder_dim=64, vocab_size=41),
 }

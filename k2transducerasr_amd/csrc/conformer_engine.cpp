@@ -177,7 +177,7 @@ float* Engine::conformer_forward(const Ctx& c, const float* x, int B, int T, int
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Streaming (OnlineProjOfConformer): Conformer.streaming_forward / chunk_forward with causal convolutions and
-// right_context = 0.  Per stream slot the pool holds cached_attn [L][left][D] (the layers' attention INPUT; keys and values are
+// right_context R >= 0 (R > 0: see conformer_chunk).  Per stream slot the pool holds cached_attn [L][left][D] (the layers' attention INPUT; keys and values are
 // re-projected every chunk) followed by cached_conv [L][K-1][D] (GLU outputs feeding the causal depthwise conv), the shapes of
 // OnlineProjOfConformer.GetEncoderInitStates (:55-82).
 // ---------------------------------------------------------------------------------------------------------------------
@@ -209,12 +209,15 @@ float* Engine::conformer_chunk(const Ctx& c, const float* x, const int* d_slots,
     const Config& cf = m.cfg();
     Arena& ar = *c.arena;
     const int D = cf.dim[0], F = cf.ff[0], H = cf.heads[0], K = cf.kern[0], dk = D / H, L = cf.nlayer[0], left = cf.left[0];
+    // Tc frames go through the layers: chunk_size + right_context (the look-ahead frames are seen by this step's attention and
+    // convolution, stay out of both caches and are cut from the output: they come again as the next chunk's first frames)
+    const int R = cf.right;
     const int T3 = conformer_out_frames(cf.chunk_T), Tc = T3 - 2, KL = left + Tc, KLp = (KL + 3) & ~3, NP = left + 2 * Tc - 1,
-              NPp = (NP + 3) & ~3, M = B * Tc;
-    float* enc = ar.take<float>((int64_t)M * cf.J);
+              NPp = (NP + 3) & ~3, M = B * Tc, Tout = Tc - R;
+    float* enc = ar.take<float>((int64_t)B * Tout * cf.J);
     int t3 = 0;
     float* e = conformer_embed(c, x, B, cf.chunk_T, &t3);
-    K2_REQUIRE(t3 == T3 && Tc > 0, "internal: conformer chunk yields %d frames", t3);
+    K2_REQUIRE(t3 == T3 && Tout > 0, "internal: conformer chunk yields %d frames", t3);
     float* xs = ar.take<float>((int64_t)M * D);
     slice_rows(c, e, xs, B, T3, 1, Tc, D);  // embed[:, 1:-1]: the edge frames saw the conv padding
     const float* pe = c.dry ? nullptr : conformer_pos_emb_left(Tc, left);
@@ -240,8 +243,9 @@ float* Engine::conformer_chunk(const Ctx& c, const float* x, const int* d_slots,
         };
         feed_forward("feed_forward_macaron");
         {
-            // key = [cached_attn ; chunk]; cached_attn <- key[-left:]
-            cat_shift(c, online_pool_, stride, (long long)li * left * D, d_slots, xs, D, cat, B, left, Tc, D);
+            // key = [cached_attn ; chunk]; cached_attn <- key[-left:]  (right_context R: key[-(left + R) : -R])
+            if (R == 0) cat_shift(c, online_pool_, stride, (long long)li * left * D, d_slots, xs, D, cat, B, left, Tc, D);
+            else cat_keep(c, online_pool_, stride, (long long)li * left * D, d_slots, xs, D, cat, B, left, Tc, D, R);
             const float* Win = w("self_attn.in_proj.weight");
             const float* bin = w("self_attn.in_proj.bias");
             linear(c, xs, D, Win, bin, q, D, M, D, D);                                    // q from the chunk
@@ -279,15 +283,22 @@ float* Engine::conformer_chunk(const Ctx& c, const float* x, const int* d_slots,
         {   // causal ConvolutionModule: cache holds the K-1 latest GLU outputs
             linear(c, xs, D, w("conv_module.pointwise_conv1.weight"), w("conv_module.pointwise_conv1.bias"), hid, 2 * D, M, D, 2 * D);
             glu_sigmoid(c, hid, g, M, D);
-            cat_shift(c, online_pool_, stride, (long long)L * left * D + (long long)li * (K - 1) * D, d_slots, g, D, ccat, B, K - 1, Tc, D);
+            if (R == 0) cat_shift(c, online_pool_, stride, (long long)L * left * D + (long long)li * (K - 1) * D, d_slots, g, D, ccat, B, K - 1, Tc, D);
+            else cat_keep(c, online_pool_, stride, (long long)L * left * D + (long long)li * (K - 1) * D, d_slots, g, D, ccat, B, K - 1, Tc, D, R);
             dwconv_valid_dswish(c, ccat, w("conv_module.depthwise_conv.weight#kd"), w("conv_module.depthwise_conv.bias"), g, B, Tc, D, K);
             linear(c, g, D, w("conv_module.pointwise_conv2.weight"), w("conv_module.pointwise_conv2.bias"), xs, D, M, D, D, ACT_NONE, xs, D);
         }
         feed_forward("feed_forward");
         basicnorm(c, xs, w("norm_final.eps"), xs, M, D);
     }
-    linear(c, xs, D, m.w("joiner.encoder_proj.weight"), m.w("joiner.encoder_proj.bias"), enc, cf.J, M, D, cf.J);
-    *Tc_out = Tc;
+    const float* xo = xs;
+    if (R > 0) {   // x = x[:-right_context]
+        float* cut = ar.take<float>((int64_t)B * Tout * D);
+        slice_rows(c, xs, cut, B, Tc, 0, Tout, D);
+        xo = cut;
+    }
+    linear(c, xo, D, m.w("joiner.encoder_proj.weight"), m.w("joiner.encoder_proj.bias"), enc, cf.J, B * Tout, D, cf.J);
+    *Tc_out = Tout;
     return enc;
 }
 

@@ -429,6 +429,10 @@ void cat_shift(const Ctx& ctx, float* pool, long long slot_stride, long long off
 // ring form: the keys of the left context are read from the ring, the chunk's own key rows (columns [32 H, 64 H) of qkp) are
 // written into it first; aw columns are in RING order (column p = the key stored in ring row p), which is also the order the
 // value rings are read in -- a weighted sum does not care.
+// the same with `keep_back` newest rows kept OUT of the cache (streaming Conformer with right_context: states = key[-(L + R) : -R]):
+// cat = [cache ; new rows] first, then cache <- cat[Tc - keep_back .. Tc - keep_back + L) (two launches: the cache is read before it is written)
+void cat_keep(const Ctx& ctx, float* pool, long long slot_stride, long long off, const int* slots, const float* newrows, int ldn, float* cat,
+              int B, int L, int Tc, int width, int keep_back);
 void attn_stream_ring(const Ctx& ctx, const float* qkp, int ld, const RingRef& keys, const float* pp, const long long* plen,
                       float* aw, int B, int Tc, int L, int KLp, int H, int ds, int left50);
 void attn_stream(const Ctx& ctx, const float* qkp, int ld, const float* kcat, const float* pp, const long long* plen,

@@ -263,13 +263,14 @@ void Model::parse_config() {
         c.chunk_T = geti("T", 45);
         c.shift = geti("decode_chunk_len", 32);
         if (c.conformer) {
-            // OnlineProjOfConformer (OnlineModel.cs:131-166): one left_context, T = (chunk_size + 2) * 4 + 3, right_context = 0
+            // OnlineProjOfConformer (OnlineModel.cs:131-166): one left_context, T = (chunk_size + 2 + right_context) * 4 + 3
             c.left[0] = geti("left_context", 64);
             const int chunk = geti("chunk_size", 16);
-            K2_REQUIRE(geti("right_context", 0) == 0, "streaming conformer: only right_context = 0 is built");
-            K2_REQUIRE(c.shift == 4 * chunk && c.chunk_T == (chunk + 2) * 4 + 3 && c.left[0] > 0 && c.left[0] % 4 == 0,
-                       "streaming conformer geometry T=%d, decode_chunk_len=%d, chunk_size=%d, left_context=%d unsupported", c.chunk_T,
-                       c.shift, chunk, c.left[0]);
+            c.right = geti("right_context", 0);
+            K2_REQUIRE(c.right >= 0 && c.right <= 64, "streaming conformer: right_context %d out of range", c.right);
+            K2_REQUIRE(c.shift == 4 * chunk && c.chunk_T == (chunk + 2 + c.right) * 4 + 3 && c.left[0] > 0 && c.left[0] % 4 == 0,
+                       "streaming conformer geometry T=%d, decode_chunk_len=%d, chunk_size=%d, left_context=%d, right_context=%d unsupported",
+                       c.chunk_T, c.shift, chunk, c.left[0], c.right);
         } else if (c.zip1) {
             if (fill("left_context_len", c.left) != c.ns) failf(K2HIP_ERR_INVALID, "metadata left_context_len must have %d entries", c.ns);
             K2_REQUIRE(c.chunk_T == c.shift + 7 && c.shift % 4 == 0, "zipformer streaming geometry T=%d, decode_chunk_len=%d unsupported", c.chunk_T, c.shift);

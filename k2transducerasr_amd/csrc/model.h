@@ -61,6 +61,7 @@ struct Config {
     int conv_cpg = 4;  // decoder conv input channels per group (4: Zipformer recipes; DD: stateless2 decoder, groups = 1)
     bool streaming = false;
     int chunk_T = 0, shift = 0, left[kMaxStacks] = {0};
+    int right = 0;   // streaming Conformer: right_context (OnlineModel.cs:161-165), encoder frames of look-ahead per chunk
     FbankOpts fbank;
 };
 

@@ -437,6 +437,39 @@ void cat_shift(const Ctx& ctx, float* pool, long long slot_stride, long long off
         hipLaunchKernelGGL(k_cat_shift<false>, grid, dim3(256), 0, ctx.stream, pool, slot_stride, off, slots, newrows, ldn, cat, B, L, Tc, width);
     K2_HIP(hipGetLastError());
 }
+namespace {
+// phase 0: cat[b][r] = r < L ? cache[slot b][r] : new[b][r - L];  phase 1: cache[slot b][r] = cat[b][row0 + r], r < L
+template <int PHASE>
+__global__ void k_cat_keep(float* __restrict__ pool, long long slot_stride, long long off, const int* __restrict__ slots,
+                           const float* __restrict__ newrows, int ldn, float* __restrict__ cat, int L, int Tc, int w4, int row0, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % w4) * 4;
+    const long long br = i / w4;
+    const int rows = PHASE == 0 ? L + Tc : L;
+    const int r = (int)(br % rows), b = (int)(br / rows);
+    float* cache = pool + (long long)slots[b] * slot_stride + off;
+    float* ct = cat + (long long)b * (L + Tc) * (w4 * 4);
+    if (PHASE == 0) {
+        const float4 v = r < L ? *reinterpret_cast<const float4*>(cache + (long long)r * (w4 * 4) + c)
+                               : *reinterpret_cast<const float4*>(newrows + ((long long)b * Tc + (r - L)) * ldn + c);
+        *reinterpret_cast<float4*>(ct + (long long)r * (w4 * 4) + c) = v;
+    } else {
+        *reinterpret_cast<float4*>(cache + (long long)r * (w4 * 4) + c) = *reinterpret_cast<const float4*>(ct + (long long)(row0 + r) * (w4 * 4) + c);
+    }
+}
+}  // namespace
+void cat_keep(const Ctx& ctx, float* pool, long long slot_stride, long long off, const int* slots, const float* newrows, int ldn, float* cat,
+              int B, int L, int Tc, int width, int keep_back) {
+    K2_REQUIRE(width % 4 == 0 && ldn % 4 == 0 && keep_back >= 0 && keep_back <= Tc, "cat_keep: width %d / ld %d / keep_back %d", width, ldn, keep_back);
+    if (ctx.dry) return;
+    const int w4 = width / 4;
+    const long long n0 = (long long)B * (L + Tc) * w4, n1 = (long long)B * L * w4;
+    hipLaunchKernelGGL(k_cat_keep<0>, dim3(nb(n0, 256)), dim3(256), 0, ctx.stream, pool, slot_stride, off, slots, newrows, ldn, cat, L, Tc, w4, 0, n0);
+    hipLaunchKernelGGL(k_cat_keep<1>, dim3(nb(n1, 256)), dim3(256), 0, ctx.stream, pool, slot_stride, off, slots, newrows, ldn, cat, L, Tc, w4,
+                       Tc - keep_back, n1);
+    K2_HIP(hipGetLastError());
+}
 void attn_stream_ring(const Ctx& ctx, const float* qkp, int ld, const RingRef& keys, const float* pp, const long long* plen, float* aw, int B,
                       int Tc, int L, int KLp, int H, int ds, int left50) {
     ctx.add_flops(0.0, 2.0 * 36 * (double)Tc * (L + Tc) * B * H, 0);

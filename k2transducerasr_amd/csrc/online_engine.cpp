@@ -184,7 +184,7 @@ void Engine::online_read_state(int slot, int layer, int kind, long long chunks_d
 int Engine::online_frames_per_chunk() const {
     const Config& c = model_->cfg();
     if (c.lstm) return lstm_out_frames(c.chunk_T);
-    if (c.conformer) return conformer_out_frames(c.chunk_T) - 2;
+    if (c.conformer) return conformer_out_frames(c.chunk_T) - 2 - c.right;
     if (c.zip1) return ((c.chunk_T - 7) / 2 + 1) / 2;
     return (c.shift / 2 + 1) / 2;
 }

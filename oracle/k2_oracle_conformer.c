@@ -270,7 +270,10 @@ static int conformer_forward(const k2o_model* m, const float* xin, int B, int T,
  * attention (keys / values are re-projected every chunk) -- and cached_conv [K-1, D] -- the GLU output feeding the causal
  * depthwise conv (OnlineProjOfConformer.cs:55-82 gives the shapes).  One chunk = T input frames -> embed -> drop one frame on
  * each side -> chunk_size frames; keys = [cached_attn ; chunk]; rel-pos table for left + chunk; the oldest
- * (left - processed_lens) cache slots are masked with -inf.  right_context = 0 only.
+ * (left - processed_lens) cache slots are masked with -inf.  right_context R > 0 (OnlineModel.cs:161-165 reads the key): the chunk
+ * carries R more encoder frames, which this step's attention and convolution see; the caches keep the rows in FRONT of them
+ * (states[0] = key[-(left + R) : -R], the conv cache likewise) and the R frames are cut from the output -- they come again as
+ * the next chunk's first frames.
  * ---------------------------------------------------------------------------------------------------------------------- */
 static float* conformer_pos_emb_left(int Tc, int left, int D) {
     const int n2 = left + 2 * Tc - 1;
@@ -288,7 +291,7 @@ static float* conformer_pos_emb_left(int Tc, int left, int D) {
 }
 
 /* x [Tc, D] in place; attn_cache [left, D], conv_cache [K-1, D] updated */
-static void conformer_layer_stream(const k2o_model* m, int li, float* x, const float* pe, int Tc, int left, int64_t processed,
+static void conformer_layer_stream(const k2o_model* m, int li, float* x, const float* pe, int Tc, int left, int right, int64_t processed,
                                    float* attn_cache, float* conv_cache) {
     const int D = m->dim[0], H = m->heads[0], K = m->kern[0], dk = D / H, KL = left + Tc;
     char pfx[64];
@@ -298,7 +301,7 @@ static void conformer_layer_stream(const k2o_model* m, int li, float* x, const f
         float* key = falloc((size_t)KL * D);
         memcpy(key, attn_cache, sizeof(float) * (size_t)left * D);
         memcpy(key + (size_t)left * D, x, sizeof(float) * (size_t)Tc * D);
-        memcpy(attn_cache, key + (size_t)Tc * D, sizeof(float) * (size_t)left * D);   /* states[0] = key[-left:] */
+        memcpy(attn_cache, key + (size_t)(Tc - right) * D, sizeof(float) * (size_t)left * D);   /* states[0] = key[-(left + right) : -right] (key[-left:] for right = 0) */
         const float* wt = WT(m, 3 * D, D, "%sself_attn.in_proj.weight", pfx);           /* [D, 3D] */
         const float* bias = W(m, "%sself_attn.in_proj.bias", pfx);
         float* q = falloc((size_t)Tc * 3 * D);   /* only the first D columns are used */
@@ -359,7 +362,7 @@ static void conformer_layer_stream(const k2o_model* m, int li, float* x, const f
         for (int t = 0; t < Tc; t++)
             for (int d = 0; d < D; d++)
                 g[(size_t)(lo + t) * D + d] = x2[(size_t)t * 2 * D + d] * (1.0f / (1.0f + expf(-x2[(size_t)t * 2 * D + D + d])));
-        memcpy(conv_cache, g + (size_t)Tc * D, sizeof(float) * (size_t)lo * D);   /* cache = x[-lorder:] */
+        memcpy(conv_cache, g + (size_t)(Tc - right) * D, sizeof(float) * (size_t)lo * D);   /* cache = x[-(lorder + right) : -right] (x[-lorder:] for right = 0) */
         const float* dw = W(m, "%sconv_module.depthwise_conv.weight", pfx);
         const float* db = W(m, "%sconv_module.depthwise_conv.bias", pfx);
         float* y = falloc((size_t)Tc * D);
@@ -379,20 +382,21 @@ static void conformer_layer_stream(const k2o_model* m, int li, float* x, const f
 }
 
 /* one chunk for one stream: xin [T, 80] -> enc_out [chunk_size, J]; caches [L][left][D], [L][K-1][D] */
-static int conformer_stream_chunk(const k2o_model* m, const float* xin, int T, int left, int64_t processed, float* attn_caches,
+static int conformer_stream_chunk(const k2o_model* m, const float* xin, int T, int left, int right, int64_t processed, float* attn_caches,
                                   float* conv_caches, float* enc_out) {
     int T3;
     float* e = conformer_embed(m, xin, 1, T, &T3);
-    if (!e || T3 < 3) { free(e); return fail("conformer chunk of %d frames is too short", T); }
+    if (!e || T3 < 3 + right) { free(e); return fail("conformer chunk of %d frames is too short", T); }
     const int D = m->dim[0], Tc = T3 - 2, K = m->kern[0];
     float* x = falloc((size_t)Tc * D);
     memcpy(x, e + D, sizeof(float) * (size_t)Tc * D);   /* embed[:, 1:-1] */
     free(e);
     float* pe = conformer_pos_emb_left(Tc, left, D);
     for (int li = 0; li < m->nlayer[0]; li++)
-        conformer_layer_stream(m, li, x, pe, Tc, left, processed, attn_caches + (size_t)li * left * D, conv_caches + (size_t)li * (K - 1) * D);
+        conformer_layer_stream(m, li, x, pe, Tc, left, right, processed, attn_caches + (size_t)li * left * D, conv_caches + (size_t)li * (K - 1) * D);
     free(pe);
-    linear(enc_out, m->J, x, D, WT(m, m->J, D, "joiner.encoder_proj.weight"), W(m, "joiner.encoder_proj.bias"), Tc, D, m->J);
+    /* x = x[:-right_context]: the right-context frames are not output */
+    linear(enc_out, m->J, x, D, WT(m, m->J, D, "joiner.encoder_proj.weight"), W(m, "joiner.encoder_proj.bias"), Tc - right, D, m->J);
     free(x);
-    return Tc;
+    return Tc - right;
 }

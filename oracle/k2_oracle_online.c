@@ -491,7 +491,8 @@ int k2o_online_encoder_chunk(const k2o_model* m, k2o_online_stream* s, const flo
     if (m->zip1) return z1_stream_chunk(m, s, x, enc_out);
     if (m->conformer) {   /* model semantics: new processed_lens = processed_lens + chunk frames */
         const int left = meta_int(m, "left_context", 64);
-        int tc = conformer_stream_chunk(m, x, k2o_online_chunk_length(m), left, s->processed_len, s->conf_attn, s->conf_conv, enc_out);
+        int tc = conformer_stream_chunk(m, x, k2o_online_chunk_length(m), left, meta_int(m, "right_context", 0), s->processed_len, s->conf_attn,
+                                        s->conf_conv, enc_out);
         if (tc > 0) s->processed_len += tc;
         return tc;
     }

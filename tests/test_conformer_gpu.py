@@ -242,3 +242,43 @@ def test_fused_and_gemm_attention_scores_agree(tmp_path_factory, utts):
         np.testing.assert_allclose(strip32, want, atol=ACT_TOL, rtol=0, err_msg=f"fused, 32-row strips T={T}")
         np.testing.assert_allclose(strip32, fused, atol=1e-5, rtol=0, err_msg=f"16- against 32-row strips T={T}")
         np.testing.assert_allclose(gemm, want, atol=ACT_TOL, rtol=0, err_msg=f"gemm T={T}")
+
+
+def test_streaming_conformer_with_right_context_matches_oracle(tmp_path):
+    """right_context = 2 (OnlineModel.cs:161-165 reads the key; round 3 refused such a model): 51-frame chunks, 8 output frames, a
+    shift of 32 -- the two look-ahead encoder frames are seen by this step's attention and convolution, stay out of both caches
+    (states = key[-(left + R) : -R]) and are cut from the output.  Tokens, timestamps, Hyp and every cache against the oracle chunk
+    by chunk (whose chunk function is held to an independent torch twin on the CPU, tests/test_oracle_conformer.py), including a step
+    with one stream alone (the processed_lens quirk)."""
+    from k2transducerasr_amd import OnlineRecognizer
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    from oracle.online import OnlineOracle
+    p = str(tmp_path / "conformer_stream_rc.k2w")
+    write_synthetic_model(p, "conformer-streaming-rc-tiny-test")
+    oo = OnlineOracle(p)
+    rec = OnlineRecognizer(p)
+    assert (rec.chunk_length, rec.shift_length, rec.frames_per_chunk) == (51, 32, 8)
+    utts = [synth_utterance(64 + u, 2.4) for u in range(3)]
+    feats = [oo.fbank(u) for u in utts]
+    hs = [rec.create_online_stream() for _ in utts]
+    os_ = [oo.create_stream() for _ in utts]
+    for h, f in zip(hs, feats):
+        h.add_features(f)
+    pos, n = 0, 0
+    while pos + 51 <= feats[0].shape[0]:
+        if n == 2:
+            oo.step(os_[:1], [feats[0][pos: pos + 51]])
+            rec.get_results(hs[:1])
+            oo.step(os_[1:], [f[pos: pos + 51] for f in feats[1:]])
+            rec.get_results(hs[1:])
+        else:
+            oo.step(os_, [f[pos: pos + 51] for f in feats])
+            rec.get_results(hs)
+        for h, o in zip(hs, os_):
+            assert h.tokens == o.tokens and h.timestamps == o.timestamps and h.processed_len == o.processed_len, n
+            for l in range(2):
+                np.testing.assert_allclose(h.state(l, "conf_attn"), o.lstm_state(l, "h"), atol=2e-4, rtol=0, err_msg=f"chunk {n} layer {l} cached_attn")
+                np.testing.assert_allclose(h.state(l, "conf_conv"), o.lstm_state(l, "c"), atol=2e-4, rtol=0, err_msg=f"chunk {n} layer {l} cached_conv")
+        pos += 32
+        n += 1
+    assert n >= 4 and sum(len(h.tokens) for h in hs) > 6

@@ -100,6 +100,51 @@ def test_streaming_conformer_matches_twin(cstream_path, utts):
     assert n >= 3
 
 
+def test_streaming_conformer_with_right_context_matches_twin(tmp_path, utts):
+    """right_context = 2 (OnlineModel.cs:161-165 reads the key): T = (8 + 2 + 2) * 4 + 3 = 51 frames per chunk, still 8 output frames
+    and a shift of 32; the two extra encoder frames are seen by this step's attention and convolution, kept OUT of both caches and cut
+    from the output.  Oracle against the independent torch twin: outputs and every cache, chunk by chunk; and the overlap must
+    matter -- the outputs differ from the right_context = 0 model's on the same audio."""
+    import torch
+    from k2transducerasr_amd.synth import write_synthetic_model
+    from oracle.online import OnlineOracle
+    from torch_twin_conformer import ConformerStreamTwin
+    p = str(tmp_path / "rc.k2w")
+    write_synthetic_model(p, "conformer-streaming-rc-tiny-test")
+    meta, tensors = read_k2w(p)
+    assert meta["right_context"] == "2"
+    tw = ConformerStreamTwin(meta, tensors)
+    oo = OnlineOracle(p)
+    assert (oo.chunk_length, oo.shift_length, oo.frames_per_chunk) == (51, 32, 8)
+    f = oo.fbank(utts[0])
+    s = oo.create_stream()
+    st = tw.init_states(1)
+    pl = torch.tensor([2])
+    pos = n = 0
+    outs = []
+    while pos + 51 <= f.shape[0]:
+        x = f[pos: pos + 51]
+        a = oo.encoder_chunk(s, x)
+        b, st, pl = tw.chunk(x[None], st, pl)
+        assert a.shape == (8, 512) and b.shape == (1, 8, 512)
+        np.testing.assert_allclose(a, b[0], atol=5e-5, rtol=0)
+        for l in range(2):
+            np.testing.assert_allclose(s.lstm_state(l, "h").reshape(16, 64), st[0][l, :, 0].numpy(), atol=5e-5, rtol=0)   # cached_attn
+            np.testing.assert_allclose(s.lstm_state(l, "c").reshape(6, 64), st[1][l, :, 0].numpy(), atol=5e-5, rtol=0)    # cached_conv
+        assert s.processed_len == int(pl[0]) == 2 + 8 * (n + 1)
+        outs.append(a)
+        pos += 32
+        n += 1
+    assert n >= 3
+    # the same weights without the right context see less: different outputs
+    p0 = str(tmp_path / "rc0.k2w")
+    write_synthetic_model(p0, "conformer-streaming-tiny-test")
+    o0 = OnlineOracle(p0)
+    s0 = o0.create_stream()
+    a0 = o0.encoder_chunk(s0, f[:43])
+    assert np.abs(a0 - outs[0]).max() > 1e-3
+
+
 def test_streaming_conformer_step_reproduces_the_processed_lens_bug(cstream_path, utts):
     """OnlineProjOfConformer.unstack_states (:229) stores the BATCH SIZE as processed_lens instead of the model's output, so
     after a step with B streams only the newest B left-context frames stay unmasked."""

@@ -163,6 +163,7 @@ class ConformerStreamTwin(ConformerTwin):
     def __init__(self, meta, tensors):
         super().__init__(meta, tensors)
         self.left = int(meta["left_context"])
+        self.right = int(meta.get("right_context", "0"))
 
     def init_states(self, N=1):
         return [torch.zeros(self.L, self.left, N, self.D), torch.zeros(self.L, self.K - 1, N, self.D)]
@@ -193,14 +194,16 @@ class ConformerStreamTwin(ConformerTwin):
         x = x.permute(1, 2, 0)
         x = F.glu(F.conv1d(x, w[p + "pointwise_conv1.weight"], w[p + "pointwise_conv1.bias"]), dim=1)
         x = torch.cat([cache.permute(1, 2, 0), x], dim=2)
-        cache = x.permute(2, 0, 1)[-(self.K - 1):, ...]
+        cache = x.permute(2, 0, 1)   # (lorder + T, B, D)
+        cache = cache[-(self.K - 1 + self.right): -self.right, ...] if self.right > 0 else cache[-(self.K - 1):, ...]
         x = F.conv1d(x, w[p + "depthwise_conv.weight"], w[p + "depthwise_conv.bias"], groups=self.D)   # causal: no padding
         x = F.conv1d(double_swish(x), w[p + "pointwise_conv2.weight"], w[p + "pointwise_conv2.bias"])
         return x.permute(2, 0, 1), cache
 
     @torch.no_grad()
     def chunk(self, x, states, processed_lens):
-        """Conformer.streaming_forward (simulate_streaming=False, right_context=0): x (N, T, 80) -> (N, chunk, J), new states"""
+        """Conformer.streaming_forward (simulate_streaming=False): x (N, T, 80) -> (N, chunk, J), new states.  right_context > 0: the
+        chunk's last `right` encoder frames are seen by this step and cut from its output; the caches keep what is in front of them."""
         x = torch.as_tensor(x)
         N = x.size(0)
         embed = self.embed(x)[:, 1:-1, :]
@@ -215,12 +218,14 @@ class ConformerStreamTwin(ConformerTwin):
             p = f"encoder.encoder.layers.{i}."
             src = src + self.feed_forward(p + "feed_forward_macaron", src)
             key = torch.cat([states[0][i], src], dim=0)
-            new_attn.append(key[-self.left:, ...])
+            new_attn.append(key[-(self.left + self.right): -self.right, ...] if self.right > 0 else key[-self.left:, ...])
             src = src + self.attn_chunk(p + "self_attn.", src, key, pos_emb, mask)
             conv, cc = self.conv_chunk(p + "conv_module.", src, states[1][i])
             new_conv.append(cc)
             src = src + conv
             src = src + self.feed_forward(p + "feed_forward", src)
             src = basic_norm(src, self.w[p + "norm_final.eps"])
+        if self.right > 0:
+            src = src[:-self.right, ...]
         out = F.linear(src.permute(1, 0, 2), self.w["joiner.encoder_proj.weight"], self.w["joiner.encoder_proj.bias"])
-        return out.contiguous().numpy(), [torch.stack(new_attn), torch.stack(new_conv)], processed_lens + T
+        return out.contiguous().numpy(), [torch.stack(new_attn), torch.stack(new_conv)], processed_lens + T - self.right
