@@ -17,7 +17,8 @@ from oracle.online import OnlineOracle  # noqa: E402
 
 TOTAL = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-presets = ["zipformer2-streaming-tiny-test", "zipformer-streaming-tiny-test", "conformer-streaming-tiny-test", "zipformer2-ctc-streaming-tiny-test",
+presets = ["zipformer2-streaming-tiny-test", "zipformer-streaming-tiny-test", "conformer-streaming-tiny-test", "conformer-streaming-rc-tiny-test",
+           "zipformer2-ctc-streaming-tiny-test",
            "lstm-tiny-test"]
 tmp = tempfile.mkdtemp()
 for preset in presets:
