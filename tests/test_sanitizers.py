@@ -189,3 +189,23 @@ def test_model_type_is_derived_as_the_reference_derives_it(api_driver, tiny_mode
     # online: OnlineRecognizer.cs:26-44 has no default case
     out = mt(variant(streaming_tiny_path, "k", model_type="", comment=""))
     assert out.startswith("ERR -6") and "no default case" in out
+
+
+def test_large_vocabulary_repack_under_sanitizers(api_driver, tmp_path):
+    """csrc/model.cpp packs an f16 copy of joiner.output_linear in MFMA fragment order and computes the per-column error bounds for
+    vocabularies >= 1024 (the greedy search's screening pass): index arithmetic over (tile, K step, lane, element) and a hand-written
+    float -> half conversion -- run here under ASan + UBSan through the real loader, on a vocabulary that is no multiple of 16 and with
+    weights that overflow f16, are subnormal in f16, and are not finite."""
+    import numpy as np
+    from k2transducerasr_amd.k2w import read_k2w, write_k2w
+    from k2transducerasr_amd.synth import write_synthetic_model
+    p = str(tmp_path / "wide.k2w")
+    write_synthetic_model(p, "zipformer2-tiny-test", meta_overrides={"vocab_size": "1101"})
+    assert run(api_driver, "meta", p, "vocab_size") == "1101"
+    meta, tensors = read_k2w(p)
+    w = tensors["joiner.output_linear.weight"].copy()
+    w[3, 0], w[4, 1], w[5, 2], w[6, 3], w[7, 4] = 1e6, -7e4, 3e-8, np.inf, np.nan
+    tensors["joiner.output_linear.weight"] = w
+    p2 = str(tmp_path / "wide_odd.k2w")
+    write_k2w(p2, meta, tensors.items())
+    assert run(api_driver, "meta", p2, "model_type") == "zipformer2"
