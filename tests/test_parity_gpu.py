@@ -403,4 +403,19 @@ def test_large_vocabulary_screened_search_end_to_end(tmp_path):
             finally:
                 set_switch(switch, 1024 if switch == "K2HIP_SCREEN_MIN_V" else 0)
     assert 0.03 * frames < emitted < 0.7 * frames, (emitted, frames)     # blank wins many frames and loses some: both branches of the loop run
+    # an exchange timeout between the column slabs (forced: the flag is raised behind the search and its outputs are wiped): the
+    # repeat with one workgroup per stream -- whose 3000 columns exceed the screen's LDS area, so it sweeps in f32 -- gives the tokens
+    import ctypes as C
+    from k2transducerasr_amd import load_library
+    L = load_library()
+    L.k2hip_debug_search_retries.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    n0, n1 = C.c_int32(0), C.c_int32(0)
+    assert L.k2hip_debug_search_retries(hip.handle, C.byref(n0)) == 0
+    set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 1)
+    try:
+        assert_tokens_match(hip.offline_greedy_from_samples(utts), want, mg, what="screened search, forced retry")
+    finally:
+        set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 0)
+    assert L.k2hip_debug_search_retries(hip.handle, C.byref(n1)) == 0
+    assert n1.value == n0.value + 1 or B == 1, (n0.value, n1.value)      # (a one-stream batch may run one slab: nothing to time out)
     hip.close()
