@@ -1228,6 +1228,29 @@ static size_t greedy_lds_bytes(const DecJoinW& w) {
            (w.out_h16 ? (size_t)w.J * 32 : 0);   // + actH
 }
 
+// column slabs per stream of the persistent search (see greedy_loop)
+static int greedy_parts(const DecJoinW& w, int B, bool streaming) {
+    const int ncg = w.Vp >> 2, pass = (GT / 64) * 8;
+    const int bc = std::max(B, 1);
+    const int budget = streaming ? device_cu_count() : std::max(device_cu_count() / 4, 1);
+    int parts = std::min({(ncg + pass - 1) / pass, kMaxParts, budget / bc});
+    if (tunables().greedy_parts > 0) parts = std::max(1, std::min({tunables().greedy_parts, kMaxParts, budget / bc}));  // tuning only
+    if (parts < 2 || tunables().greedy_one_part) parts = 1;
+    return parts;
+}
+// would greedy_loop's rounds go through the f16 screen for a batch of B streams?  (The streaming tick picks its search form by this:
+// with the screen the persistent search beats the rounds of joiner GEMMs -- zipformer2-streaming-zh, V = 2000, 128 streams: 4.18
+// against 4.31 ms per tick; without it -- conformer-streaming-zh, V = 5537: two slabs of 2770 columns per stream do not fit the
+// screen's LDS area -- the rounds win, 7.20 against 7.99 ms.)
+bool greedy_loop_screens(const DecJoinW& w, int B, bool streaming) {
+    if (!w.out_h16 || (w.J & 31) != 0) return false;
+    const int nks = w.J >> 5;
+    if (!(nks == 16 || nks == 8 || nks == 4 || nks == 2)) return false;
+    const int parts = greedy_parts(w, B, streaming), ncg = w.Vp >> 2;
+    const int cper = ((ncg + parts - 1) / parts + 7) & ~7;
+    return 4 * cper <= kScreenMaxCols;
+}
+
 void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     if (a0.B <= 0) return;
     GreedyArgs a = a0;
@@ -1236,21 +1259,25 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     // gets no workgroup onto a CU that hosts one: a quarter of the chip.  Measured, pipelined step / search alone: conformer-zh
     // (V = 5537, B = 8) 4 parts 25.7 / 22.6 ms, 6: 21.3 / 18.9, 8: 16.7 / 13.9, 10: 18.1 / 14.2, 12: 17.1 / 11.7, 16: 17.05 / 10.0;
     // zipformer2-large-en (V = 500, B = 32) 1 part 15.13 / 5.45, 2: 14.44 / 3.79, 3: 14.57 / 3.67, 4: 14.56 / 3.35.
-    const int ncg = w.Vp >> 2, pass = (GT / 64) * 8;
-    const int bc = std::max(a.B, 1);
     // co-residency budget: a quarter of the chip's CUs offline, the whole chip for a streaming chunk step (nothing else is in
     // flight; one 150 KB workgroup per CU).  From the device's own CU count (256 on MI355X -> 64 / 256); a GPU shared with other
     // processes can still leave the parts of a stream apart: then the bounded waits time out and the engine repeats the search with
     // one part per stream (greedy_relaunch_one_part).
-    const int budget = a.init_ctx ? device_cu_count() : std::max(device_cu_count() / 4, 1);
-    int parts = std::min({(ncg + pass - 1) / pass, kMaxParts, budget / bc});
-    if (tunables().greedy_parts > 0) parts = std::max(1, std::min({tunables().greedy_parts, kMaxParts, budget / bc}));  // tuning only
-    if (parts < 2 || tunables().greedy_one_part) parts = 1;
+    const int parts = greedy_parts(w, a.B, a.init_ctx != nullptr);
     a.parts = parts;
     // (one block, one memset: the two exchange areas were two fills of ~5 us each in front of the search)
     const size_t gran_words = (size_t)a.B * 2 * parts * GF * 2, gran2_words = (size_t)a.B * 2 * w.J;
     a.gran = parts > 1 ? ctx.arena->take<unsigned long long>((int64_t)(gran_words + gran2_words)) : nullptr;
     a.gran2 = parts > 1 ? a.gran + gran_words : nullptr;
+    // the launch is noted for the one-part repeat BEFORE the dry return: a pass that only walks the arena because its launches are
+    // replayed from a hipGraph (Engine::graphed) must leave the same record (the sizing pass writes null pointers here and is always
+    // followed by a pass with real ones)
+    if (ctx.greedy_rec) {
+        ctx.greedy_rec->valid = parts > 1;
+        ctx.greedy_rec->beam = false;
+        ctx.greedy_rec->w = w;
+        ctx.greedy_rec->a = a;
+    }
     if (ctx.dry) return;
     K2_REQUIRE(w.J % 8 == 0, "greedy: joiner_dim %d must be a multiple of 8", w.J);
     K2_REQUIRE(w.DD % 4 == 0 && 8 * w.DD <= w.J * GF, "greedy: decoder_dim %d too wide for the LDS scratch", w.DD);
@@ -1282,12 +1309,6 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
         a.stamps = nullptr;
     }
     K2_HIP(hipGetLastError());
-    if (ctx.greedy_rec) {
-        ctx.greedy_rec->valid = parts > 1;
-        ctx.greedy_rec->beam = false;
-        ctx.greedy_rec->w = w;
-        ctx.greedy_rec->a = a;
-    }
     if (parts > 1 && tunables().test_greedy_timeout) K2_HIP(hipMemsetD32Async((hipDeviceptr_t)a.overflow, 2, 1, ctx.stream));
 }
 

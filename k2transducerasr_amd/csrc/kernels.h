@@ -351,6 +351,7 @@ struct GreedyArgs {
     unsigned long long* stamps = nullptr;
 };
 void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a);
+bool greedy_loop_screens(const DecJoinW& w, int B, bool streaming);  // would its rounds use the f16 screen (large vocabulary, slab fits)?
 // The vocabulary-parallel search waits on its sibling workgroups (bounded spins; a timeout raises *overflow = 2).  All B x parts
 // workgroups must be resident together for that, which a GPU shared with other processes or models does not promise.  The engine
 // therefore keeps the launch (inputs are read-only, outputs are rewritten from scratch) and, on a timeout, runs it again with ONE

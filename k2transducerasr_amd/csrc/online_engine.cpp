@@ -491,8 +491,11 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
         }
         // everything between the upload and the download is the same chain of launches for every tick with this many streams
         // (slots, ring heads, processed lengths and contexts are DATA in the uploaded block): replayed as a hipGraph
+        // the tick's search: rounds of joiner GEMMs + a per-stream step kernel, or the persistent kernel where its rounds go through
+        // the f16 screen (measured per model: greedy_loop_screens)
+        const bool persistent_search = tunables().search_rounds == 0 || (tunables().search_rounds < 0 && !cf.ctc && greedy_loop_screens(decjoin(), B, true));
         GraphKey gk;
-        gk.kind = 1; gk.B = B; gk.T = from_fifo ? 1 : 0; gk.extra = tunables().search_rounds;
+        gk.kind = 1; gk.B = B; gk.T = from_fifo ? 1 : 0; gk.extra = persistent_search ? 1 : 0;
         gk.p0 = online_pool_; gk.p1 = online_fifo_;
         const int launches_before = graph_launches_;
         auto chain = [&](const Ctx& c) {
@@ -507,7 +510,7 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
             GreedyArgs a;
             a.enc = enc; a.B = B; a.Tp = Tp; a.t0 = nullptr; a.skip1 = 1; a.max_sym = INT_MAX;
             a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = Tp; a.overflow = d_ovf; a.init_ctx = d_hyp;
-            if (tunables().search_rounds == 0) greedy_loop(c, decjoin(), a);
+            if (persistent_search) greedy_loop(c, decjoin(), a);
             else greedy_rounds(c, decjoin(), model_->w("joiner.output_linear.weight"), a);
             if (ev_ok) K2_HIP(hipEventRecord(ev_[4], c.stream));
             return;
@@ -524,12 +527,12 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
         GreedyArgs a;
         a.enc = enc; a.B = B; a.Tp = Tp; a.t0 = nullptr; a.skip1 = 1; a.max_sym = INT_MAX;
         a.tokens = d_tok; a.timestamps = d_ts; a.n_tokens = d_n; a.max_tokens = Tp; a.overflow = d_ovf; a.init_ctx = d_hyp;
-        if (tunables().search_rounds == 0) greedy_loop(c, decjoin(), a);
-            else greedy_rounds(c, decjoin(), model_->w("joiner.output_linear.weight"), a);
+        if (persistent_search) greedy_loop(c, decjoin(), a);
+        else greedy_rounds(c, decjoin(), model_->w("joiner.output_linear.weight"), a);
         if (ev_ok) K2_HIP(hipEventRecord(ev_[4], c.stream));
         };
-        // (the persistent search kernel notes its launch for the one-part retry: a host-side effect a replay would skip)
-        if (tunables().search_rounds != 0) graphed(c, gk, chain);
+        // (the persistent search notes its launch for the one-part retry in the arena walk too; its phase report is synchronous)
+        if (!tunables().greedy_stamps) graphed(c, gk, chain);
         else chain(c);
         if (!c.dry && graph_launches_ != launches_before) {   // a replayed tick has no stamps inside: the whole step counts as encoder time
             K2_HIP(hipEventRecord(ev_[3], c.stream));

@@ -350,21 +350,33 @@ def test_streaming_128_slots_16_streams_against_oracle_zh(tmp_path_factory):
         assert hs[u].tokens == hs[r].tokens and hs[u].timestamps == hs[r].timestamps, u
 
 
-def test_streaming_search_forms_agree(stream_model_path, ora):
-    """The tick's search over the ready streams runs as rounds of joiner GEMMs by default (greedy_rounds) and as one persistent
-    kernel with K2HIP_SEARCH_ROUNDS=0.  Both carry each stream's Hyp context across chunks; tokens, timestamps and Hyp must be
-    the oracle's after every call from either form."""
+@pytest.mark.parametrize("vocab", [0, 3000])
+def test_streaming_search_forms_agree(stream_model_path, ora, tmp_path, vocab):
+    """The tick's search over the ready streams runs as rounds of joiner GEMMs (greedy_rounds; K2HIP_SEARCH_ROUNDS=1, the default for
+    a vocabulary the f16 screen does not cover) or as one persistent kernel (=0; the default where its rounds go through the screen:
+    the 3000-token case, whose ticks then replay a captured graph holding that kernel).  Both carry each stream's Hyp context across
+    chunks; tokens, timestamps and Hyp must be the oracle's after every call from either form, and from the default's own choice."""
     from k2transducerasr_amd import OnlineRecognizer, set_switch
     from k2transducerasr_amd.synth import synth_utterance
+    rc = None
+    if vocab:
+        from k2transducerasr_amd.synth import write_synthetic_model
+        from oracle.online import OnlineOracle
+        stream_model_path = str(tmp_path / "swide.k2w")
+        write_synthetic_model(stream_model_path, "zipformer2-streaming-tiny-test", blank_bias=2.4, meta_overrides={"vocab_size": str(vocab)})
+        ora = OnlineOracle(stream_model_path)
+        rc = OnlineRecognizer(stream_model_path)
     ra, rb = OnlineRecognizer(stream_model_path), OnlineRecognizer(stream_model_path)
     N = 5
     feats = [ora.fbank(synth_utterance(700 + u, 1.0 + 0.3 * (u % 3))) for u in range(N)]
     sa = [ra.create_online_stream() for _ in range(N)]
     sb = [rb.create_online_stream() for _ in range(N)]
+    sc = [rc.create_online_stream() for _ in range(N)] if rc else []
     so = [ora.create_stream() for _ in range(N)]
-    for a, b, f in zip(sa, sb, feats):
-        a.add_features(f)
-        b.add_features(f)
+    for u, f in enumerate(feats):
+        for ss in (sa, sb, sc):
+            if ss:
+                ss[u].add_features(f)
     T, S = ra.chunk_length, ra.shift_length
     pos = [0] * N
     calls = 0
@@ -375,6 +387,11 @@ def test_streaming_search_forms_agree(stream_model_path, ora):
             ra.get_results(sa)
             set_switch("K2HIP_SEARCH_ROUNDS", 0)
             rb.get_results(sb)
+            set_switch("K2HIP_SEARCH_ROUNDS", -1)
+            if rc:
+                rc.get_results(sc)
+                for u in range(N):
+                    assert sc[u].tokens == sa[u].tokens and sc[u].timestamps == sa[u].timestamps and sc[u].hyp == sa[u].hyp, (calls, u)
             if not ready:
                 break
             ora.step([so[u] for u in ready], [feats[u][pos[u] : pos[u] + T] for u in ready])
