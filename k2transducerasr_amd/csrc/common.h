@@ -53,6 +53,13 @@ inline int device_cu_count() {
     return n[dev];
 }
 
+// Blocking copy / fill on the device's utility stream (non-blocking flag), never on the legacy (null) stream: while ANY stream of the
+// process is in stream capture -- another handle's tick being recorded as a hipGraph on another host thread -- the runtime fails a
+// legacy-stream operation with hipErrorStreamCaptureImplicit AND invalidates that capture.  Same arguments as hipMemcpy / hipMemset;
+// like those on a non-blocking engine stream, they order with nothing but the host.  (tunables.cpp)
+hipError_t copy_blocking(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+hipError_t fill_blocking(void* dst, int value, size_t bytes);
+
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

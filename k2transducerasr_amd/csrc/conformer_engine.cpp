@@ -34,7 +34,7 @@ const float* Engine::conformer_pos_emb(int T) {
     }
     float* d = nullptr;
     K2_HIP(hipMalloc(&d, pe.size() * sizeof(float)));
-    K2_HIP(hipMemcpy(d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+    K2_HIP(copy_blocking(d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
     pe_cache_[-T] = d;
     return d;
 }
@@ -198,7 +198,7 @@ const float* Engine::conformer_pos_emb_left(int Tc, int left) {
     }
     float* d = nullptr;
     K2_HIP(hipMalloc(&d, pe.size() * sizeof(float)));
-    K2_HIP(hipMemcpy(d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+    K2_HIP(copy_blocking(d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
     pe_cache_[key] = d;
     return d;
 }

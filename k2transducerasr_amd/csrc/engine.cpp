@@ -55,6 +55,7 @@ Engine::~Engine() {
         sl.arena.release();
     }
     graphs_clear();
+    if (rec_stream_) (void)hipStreamDestroy(rec_stream_);
     if (stream2_) (void)hipStreamDestroy(stream2_);
     for (auto& kv : pe_cache_) (void)hipFree(kv.second);
     for (auto& kv : pp_cache_) (void)hipFree(kv.second);
@@ -152,7 +153,7 @@ const float* Engine::pos_emb(int T) {
     }
     float* d = nullptr;
     K2_HIP(hipMalloc(&d, pe.size() * sizeof(float)));
-    K2_HIP(hipMemcpy(d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+    K2_HIP(copy_blocking(d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
     pe_cache_[T] = d;
     return d;
 }
@@ -241,7 +242,7 @@ void Engine::decoder_table_check(int n_samples, unsigned seed, long long* rows, 
         K2_HIP(hipStreamSynchronize(stream_));
         for (int n = 0; n < N; n++) {
             const long long row = (y[2 * n] + 1) * V + y[2 * n + 1];
-            K2_HIP(hipMemcpy(want.data(), w.dec_table + row * w.J, sizeof(float) * w.J, hipMemcpyDeviceToHost));
+            K2_HIP(copy_blocking(want.data(), w.dec_table + row * w.J, sizeof(float) * w.J, hipMemcpyDeviceToHost));
             for (int k = 0; k < w.J; k++) *mismatched += memcmp(&want[k], &got[(size_t)n * w.J + k], sizeof(float)) != 0;
         }
     } catch (...) {
@@ -312,7 +313,7 @@ const float* Engine::pos_proj_cached(const Ctx& c, int layer, const float* pe, i
     if (it != pp_cache_.end()) return it->second;
     const size_t bytes = sizeof(float) * (size_t)rows * ncols;
     if (pp_cache_bytes_ + bytes > ((size_t)1 << 30)) {  // many distinct utterance lengths: start over (stream-ordered frees)
-        K2_HIP(hipDeviceSynchronize());
+        synchronize();
         graphs_clear();   // instantiated graphs hold these pointers
         for (auto& kv : pp_cache_) (void)hipFree(kv.second);
         pp_cache_.clear();
@@ -734,16 +735,16 @@ void Engine::finish_tokens(const long long* d_tok, const int* d_ts, const int* d
     if (model_->cfg().ctc && d_trail_) {
         last_trail_.resize(B);
         last_any_.resize(B);
-        K2_HIP(hipMemcpy(last_trail_.data(), d_trail_, sizeof(int) * B, hipMemcpyDeviceToHost));
-        K2_HIP(hipMemcpy(last_any_.data(), d_any_, sizeof(int) * B, hipMemcpyDeviceToHost));
+        K2_HIP(copy_blocking(last_trail_.data(), d_trail_, sizeof(int) * B, hipMemcpyDeviceToHost));
+        K2_HIP(copy_blocking(last_any_.data(), d_any_, sizeof(int) * B, hipMemcpyDeviceToHost));
     }
     if (beam_ > 0 && d_scores_) {
         last_scores_.resize(B);
-        K2_HIP(hipMemcpy(last_scores_.data(), d_scores_, sizeof(float) * B, hipMemcpyDeviceToHost));
+        K2_HIP(copy_blocking(last_scores_.data(), d_scores_, sizeof(float) * B, hipMemcpyDeviceToHost));
     }
     if (beam_ > 0 && d_beam_trace_ && B == trace_B_) {
         last_beam_trace_.resize((size_t)trace_B_ * trace_Tp_ * (2 * trace_K_ + 1));
-        K2_HIP(hipMemcpy(last_beam_trace_.data(), d_beam_trace_, sizeof(int) * last_beam_trace_.size(), hipMemcpyDeviceToHost));
+        K2_HIP(copy_blocking(last_beam_trace_.data(), d_beam_trace_, sizeof(int) * last_beam_trace_.size(), hipMemcpyDeviceToHost));
     }
 }
 
@@ -1267,12 +1268,12 @@ float Engine::debug_gemm(int M, int N, int K, int act, bool with_res, int iters,
     K2_HIP(hipMalloc(&C2, sizeof(float) * (size_t)M * N));
     K2_HIP(hipMalloc(&Rb, sizeof(float) * (size_t)M * N));
     K2_HIP(hipMalloc(&b, sizeof(float) * (size_t)N));
-    K2_HIP(hipMemset(W, 0, sizeof(float) * (size_t)N * K));   // (the last 7 / 3 elements below are not covered by the shifted copies)
-    K2_HIP(hipMemset(Rb, 0, sizeof(float) * (size_t)M * N));
-    K2_HIP(hipMemcpy(A, h.data(), sizeof(float) * (size_t)M * K, hipMemcpyHostToDevice));
-    K2_HIP(hipMemcpy(W, h.data() + 7, sizeof(float) * ((size_t)N * K - 7), hipMemcpyHostToDevice));
-    K2_HIP(hipMemcpy(Rb, h.data() + 3, sizeof(float) * ((size_t)M * N - 3), hipMemcpyHostToDevice));
-    K2_HIP(hipMemcpy(b, h.data() + 11, sizeof(float) * (size_t)N, hipMemcpyHostToDevice));
+    K2_HIP(fill_blocking(W, 0, sizeof(float) * (size_t)N * K));   // (the last 7 / 3 elements below are not covered by the shifted copies)
+    K2_HIP(fill_blocking(Rb, 0, sizeof(float) * (size_t)M * N));
+    K2_HIP(copy_blocking(A, h.data(), sizeof(float) * (size_t)M * K, hipMemcpyHostToDevice));
+    K2_HIP(copy_blocking(W, h.data() + 7, sizeof(float) * ((size_t)N * K - 7), hipMemcpyHostToDevice));
+    K2_HIP(copy_blocking(Rb, h.data() + 3, sizeof(float) * ((size_t)M * N - 3), hipMemcpyHostToDevice));
+    K2_HIP(copy_blocking(b, h.data() + 11, sizeof(float) * (size_t)N, hipMemcpyHostToDevice));
     Ctx c = make_ctx(false);
     c.instrument = false;
     c.stats = nullptr;
@@ -1294,8 +1295,8 @@ float Engine::debug_gemm(int M, int N, int K, int act, bool with_res, int iters,
             K2_HIP(hipStreamSynchronize(stream_));
             K2_HIP(hipEventElapsedTime(&ms, ev_[6], ev_[7]));
             std::vector<float> h1((size_t)M * ldo), h2((size_t)M * N);
-            K2_HIP(hipMemcpy(h1.data(), C, sizeof(float) * h1.size(), hipMemcpyDeviceToHost));
-            K2_HIP(hipMemcpy(h2.data(), C2, sizeof(float) * h2.size(), hipMemcpyDeviceToHost));
+            K2_HIP(copy_blocking(h1.data(), C, sizeof(float) * h1.size(), hipMemcpyDeviceToHost));
+            K2_HIP(copy_blocking(h2.data(), C2, sizeof(float) * h2.size(), hipMemcpyDeviceToHost));
             float e = 0;
             for (int m = 0; m < M; m++)
                 for (int col = 0; col < N; col++) {
@@ -1336,8 +1337,8 @@ float Engine::debug_gemm(int M, int N, int K, int act, bool with_res, int iters,
             linear(c, A, K, W, b, C2, N, M, K, N, act, with_res ? Rb : nullptr, N);
             K2_HIP(hipStreamSynchronize(stream_));
             std::vector<float> h1((size_t)M * N), h2((size_t)M * N);
-            K2_HIP(hipMemcpy(h1.data(), C, sizeof(float) * h1.size(), hipMemcpyDeviceToHost));
-            K2_HIP(hipMemcpy(h2.data(), C2, sizeof(float) * h2.size(), hipMemcpyDeviceToHost));
+            K2_HIP(copy_blocking(h1.data(), C, sizeof(float) * h1.size(), hipMemcpyDeviceToHost));
+            K2_HIP(copy_blocking(h2.data(), C2, sizeof(float) * h2.size(), hipMemcpyDeviceToHost));
             float e = 0;
             for (size_t i = 0; i < h1.size(); i++) {
                 const float d = fabsf(h1[i] - h2[i]);
@@ -1369,16 +1370,16 @@ void Engine::debug_gemm_host(const float* hA, const float* hW, const float* hb, 
     K2_HIP(hipMalloc(&d.A, sizeof(float) * (size_t)M * K));
     K2_HIP(hipMalloc(&d.W, sizeof(float) * (size_t)N * K));
     K2_HIP(hipMalloc(&d.C, sizeof(float) * (size_t)M * ldo));
-    K2_HIP(hipMemcpy(d.A, hA, sizeof(float) * (size_t)M * K, hipMemcpyHostToDevice));
-    K2_HIP(hipMemcpy(d.W, hW, sizeof(float) * (size_t)N * K, hipMemcpyHostToDevice));
-    K2_HIP(hipMemset(d.C, 0xff, sizeof(float) * (size_t)M * ldo));   // NaN pattern: an element the kernel never writes fails the comparison
+    K2_HIP(copy_blocking(d.A, hA, sizeof(float) * (size_t)M * K, hipMemcpyHostToDevice));
+    K2_HIP(copy_blocking(d.W, hW, sizeof(float) * (size_t)N * K, hipMemcpyHostToDevice));
+    K2_HIP(fill_blocking(d.C, 0xff, sizeof(float) * (size_t)M * ldo));   // NaN pattern: an element the kernel never writes fails the comparison
     if (hb) {
         K2_HIP(hipMalloc(&d.b, sizeof(float) * (size_t)N));
-        K2_HIP(hipMemcpy(d.b, hb, sizeof(float) * (size_t)N, hipMemcpyHostToDevice));
+        K2_HIP(copy_blocking(d.b, hb, sizeof(float) * (size_t)N, hipMemcpyHostToDevice));
     }
     if (hres) {
         K2_HIP(hipMalloc(&d.R, sizeof(float) * (size_t)M * ldo));
-        K2_HIP(hipMemcpy(d.R, hres, sizeof(float) * (size_t)M * ldo, hipMemcpyHostToDevice));
+        K2_HIP(copy_blocking(d.R, hres, sizeof(float) * (size_t)M * ldo, hipMemcpyHostToDevice));
     }
     Ctx c = make_ctx(false);
     c.instrument = false;
@@ -1389,7 +1390,7 @@ void Engine::debug_gemm_host(const float* hA, const float* hW, const float* hb, 
     debug_force_gemm_cfg(cfg);
     gemm(c, g);
     K2_HIP(hipStreamSynchronize(stream_));
-    K2_HIP(hipMemcpy(hC, d.C, sizeof(float) * (size_t)M * ldo, hipMemcpyDeviceToHost));
+    K2_HIP(copy_blocking(hC, d.C, sizeof(float) * (size_t)M * ldo, hipMemcpyDeviceToHost));
 }
 
 // tuning hook: ONE launch of the ring kernel `cfg` (>= 100) with in-kernel s_memtime stamps; out [n_wg][n_waves][64]
@@ -1405,11 +1406,11 @@ void Engine::debug_gemm_trace(int M, int N, int K, int act, bool with_res, int c
     K2_HIP(hipMalloc(&C, sizeof(float) * (size_t)M * N));
     K2_HIP(hipMalloc(&b, sizeof(float) * (size_t)N));
     K2_HIP(hipMalloc(&dbg, sizeof(unsigned long long) * (size_t)cap));
-    K2_HIP(hipMemset(dbg, 0, sizeof(unsigned long long) * (size_t)cap));
-    K2_HIP(hipMemcpy(A, h.data(), sizeof(float) * (size_t)M * K, hipMemcpyHostToDevice));
-    K2_HIP(hipMemcpy(W, h.data(), sizeof(float) * (size_t)N * K, hipMemcpyHostToDevice));
-    K2_HIP(hipMemcpy(C, h.data(), sizeof(float) * (size_t)M * N, hipMemcpyHostToDevice));
-    K2_HIP(hipMemcpy(b, h.data(), sizeof(float) * (size_t)N, hipMemcpyHostToDevice));
+    K2_HIP(fill_blocking(dbg, 0, sizeof(unsigned long long) * (size_t)cap));
+    K2_HIP(copy_blocking(A, h.data(), sizeof(float) * (size_t)M * K, hipMemcpyHostToDevice));
+    K2_HIP(copy_blocking(W, h.data(), sizeof(float) * (size_t)N * K, hipMemcpyHostToDevice));
+    K2_HIP(copy_blocking(C, h.data(), sizeof(float) * (size_t)M * N, hipMemcpyHostToDevice));
+    K2_HIP(copy_blocking(b, h.data(), sizeof(float) * (size_t)N, hipMemcpyHostToDevice));
     Ctx c = make_ctx(false);
     c.instrument = false;
     c.stats = nullptr;
@@ -1436,7 +1437,7 @@ void Engine::debug_gemm_trace(int M, int N, int K, int act, bool with_res, int c
         g.dbg = dbg;
         gemm(c, g);
         K2_HIP(hipStreamSynchronize(stream_));
-        K2_HIP(hipMemcpy(out, dbg, sizeof(unsigned long long) * (size_t)*n_wg * nw * 64, hipMemcpyDeviceToHost));
+        K2_HIP(copy_blocking(out, dbg, sizeof(unsigned long long) * (size_t)*n_wg * nw * 64, hipMemcpyDeviceToHost));
     } catch (...) {
         debug_force_gemm_cfg(-1);
         (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipFree(b); (void)hipFree(dbg);
@@ -1458,7 +1459,7 @@ void Engine::dev_free(void* p) {
 }
 void Engine::dev_upload(void* dst, const void* src, int64_t bytes) {
     K2_HIP(hipSetDevice(device_));
-    K2_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+    K2_HIP(copy_blocking(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
 }
 void* Engine::host_alloc(int64_t bytes) {
     K2_HIP(hipSetDevice(device_));
@@ -1476,7 +1477,8 @@ void Engine::synchronize() {
     if (stream2_) K2_HIP(hipStreamSynchronize(stream2_));
     for (auto& sl : slots_)
         if (sl.stream) K2_HIP(hipStreamSynchronize(sl.stream));
-    K2_HIP(hipDeviceSynchronize());  // the bench brackets its timed region with this (device-wide, like torch.cuda.synchronize())
+    // every stream this engine enqueues on -- not hipDeviceSynchronize: the work of other handles is not this call's business, and a
+    // device-wide wait from one host thread while another handle records a graph is one more legacy-style operation to trip over
 }
 
 }  // namespace k2hip

@@ -214,13 +214,15 @@ class Engine {
         }
     };
     struct GraphEntry {
-        int state = 0;  // 0 seen once (ran eagerly), 1 ready, 2 not capturable
+        int state = 0;  // 0 seen (ran eagerly), 1 ready, 2 not capturable
+        int failed = 0; // recordings that did not survive (state 2 after the third)
         hipGraphExec_t exec = nullptr;
         unsigned long long last_use = 0;
     };
     template <typename F>
     void graphed(const Ctx& c, GraphKey key, F&& enqueue);
     void graphs_clear();
+    hipStream_t rec_stream_ = nullptr;   // the stream a chain is RECORDED on (graphed): never one that carries work
     float* encoder_forward_graphed(const Ctx& c, const float* d_x, int B, int T, int* Tp);
 
     int submit_impl(const float* samples_dev, const float* samples_host, int64_t n_each, int B, int max_tokens);
@@ -347,18 +349,29 @@ void Engine::graphed(const Ctx& c, GraphKey key, F&& enqueue) {
         return;
     }
     if (e.state == 0) {
+        // Recorded on a stream of its own, replayed on c.stream.  While a recording is open, ANY legacy-stream operation of ANY host
+        // thread (the host application's own hipMemcpy, a framework on the default stream) is refused by the runtime and invalidates
+        // the recording -- and hipStreamEndCapture then leaves the recording stream in its invalidated state for good (ROCm 7.2:
+        // every later launch on it fails with hipErrorStreamCaptureInvalidated).  So the live stream is never the one in capture
+        // mode: a spoiled recording costs a scratch stream, the chain runs eagerly this time (a recording enqueues nothing) and
+        // the next call with this shape records again (three attempts).
         const int64_t mark = c.arena->mark();
-        bool ok = hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (!rec_stream_ && hipStreamCreateWithFlags(&rec_stream_, hipStreamNonBlocking) != hipSuccess) rec_stream_ = nullptr;
+        const int cm = tunables().graph_capture_mode;
+        const hipStreamCaptureMode mode = cm == 1 ? hipStreamCaptureModeRelaxed : cm == 2 ? hipStreamCaptureModeGlobal : hipStreamCaptureModeThreadLocal;
+        bool ok = rec_stream_ && hipStreamBeginCapture(rec_stream_, mode) == hipSuccess;
+        const bool begun = ok;
         hipGraph_t g = nullptr;
         if (ok) {
             Ctx cc = c;
             cc.capturing = true;
+            cc.stream = rec_stream_;
             try {
                 enqueue(cc);
             } catch (...) {
                 ok = false;
             }
-            if (hipStreamEndCapture(c.stream, &g) != hipSuccess || !g) ok = false;
+            if (hipStreamEndCapture(rec_stream_, &g) != hipSuccess || !g) ok = false;
         }
         if (ok && hipGraphInstantiate(&e.exec, g, nullptr, nullptr, 0) != hipSuccess) {
             ok = false;
@@ -366,8 +379,13 @@ void Engine::graphed(const Ctx& c, GraphKey key, F&& enqueue) {
         }
         if (g) (void)hipGraphDestroy(g);
         (void)hipGetLastError();
-        if (!ok) {   // nothing was enqueued (a capture records, it does not run): the eager form, from the same arena position
-            e.state = 2;
+        if (!ok) {   // nothing was enqueued (a recording records, it does not run): the eager form, from the same arena position
+            if (begun || !rec_stream_) {
+                if (rec_stream_) (void)hipStreamDestroy(rec_stream_);
+                rec_stream_ = nullptr;
+                (void)hipGetLastError();
+            }
+            if (++e.failed >= 3) e.state = 2;
             c.arena->rewind(mark);
             enqueue(c);
             return;

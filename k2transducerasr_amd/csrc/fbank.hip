@@ -9,6 +9,8 @@
 // ~1e-4) that would otherwise be the largest difference between two correct
 // implementations of the same front-end.
 #include <cfloat>
+#include <mutex>
+#include <vector>
 
 #include "kernels.h"
 
@@ -86,10 +88,15 @@ __global__ __launch_bounds__(256) void k_fbank(FbankArgs a, const double2* __res
     }
 }
 
+// one table per device, shared by every model handle of the process: built under the lock and published only when its upload has
+// completed (handles opened from several host threads reach this together -- a pointer published before the copy let a neighbour's
+// first fbank read an empty table)
+std::mutex g_tw_mu;
 double2* g_tw[16] = {nullptr};
 
 const double2* twiddles(int device) {
     if (device < 0 || device >= 16) failf(K2HIP_ERR_INVALID, "device index %d out of range", device);
+    std::lock_guard<std::mutex> lk(g_tw_mu);
     if (!g_tw[device]) {
         std::vector<double2> h(NBIN);
         for (int k = 0; k < NBIN; k++) {
@@ -97,8 +104,13 @@ const double2* twiddles(int device) {
             h[k].x = cos(ang);
             h[k].y = sin(ang);
         }
-        K2_HIP(hipMalloc(&g_tw[device], sizeof(double2) * NBIN));
-        K2_HIP(hipMemcpy(g_tw[device], h.data(), sizeof(double2) * NBIN, hipMemcpyHostToDevice));
+        double2* d = nullptr;
+        K2_HIP(hipMalloc(&d, sizeof(double2) * NBIN));
+        if (hipError_t e = copy_blocking(d, h.data(), sizeof(double2) * NBIN, hipMemcpyHostToDevice); e != hipSuccess) {
+            (void)hipFree(d);
+            K2_HIP(e);
+        }
+        g_tw[device] = d;
     }
     return g_tw[device];
 }

@@ -1301,7 +1301,7 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     if (a.stamps) {   // tuning: synchronous report of workgroup 0's round
         unsigned long long h[8];
         K2_HIP(hipStreamSynchronize(ctx.stream));
-        K2_HIP(hipMemcpy(h, d_stamps, sizeof h, hipMemcpyDeviceToHost));
+        K2_HIP(copy_blocking(h, d_stamps, sizeof h, hipMemcpyDeviceToHost));
         const double r = h[0] ? (double)h[0] : 1.0;
         fprintf(stderr, "[k_greedy stamps] %llu rounds, %d parts; us per round: activations %.2f, screen tiles %.2f, candidate scan %.2f, re-check %.2f, "
                         "sweep passes %.2f, publish + exchange %.2f, decision + decoder %.2f\n", h[0], parts, h[1] / r / 100.0, h[2] / r / 100.0, h[3] / r / 100.0,

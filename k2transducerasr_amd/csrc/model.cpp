@@ -75,13 +75,13 @@ void Model::upload(int device) {
     size_t total = (size_t)align_up((int64_t)file_bytes, 256) + extra_bytes;
     blob_.alloc(device_, total);
     void* dev_blob_ = blob_.p;
-    K2_HIP(hipMemcpy(dev_blob_, data, file_bytes, hipMemcpyHostToDevice));
+    K2_HIP(copy_blocking(dev_blob_, data, file_bytes, hipMemcpyHostToDevice));
     for (const K2wTensorRec& r : file_->tensors)
         if (r.dtype == 0) t_[r.name].dev = reinterpret_cast<float*>(static_cast<char*>(dev_blob_) + r.off);
     size_t off = (size_t)align_up((int64_t)file_bytes, 256);
     for (size_t i = 0; i < extra.size(); i++) {
         auto& e = extra[i];
-        K2_HIP(hipMemcpy(static_cast<char*>(dev_blob_) + off, e.second.data(), e.second.size() * 4, hipMemcpyHostToDevice));
+        K2_HIP(copy_blocking(static_cast<char*>(dev_blob_) + off, e.second.data(), e.second.size() * 4, hipMemcpyHostToDevice));
         Tensor t;
         t.dev = reinterpret_cast<float*>(static_cast<char*>(dev_blob_) + off);
         t.ndim = (int)shapes[i].second.size();

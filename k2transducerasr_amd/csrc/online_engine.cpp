@@ -113,8 +113,8 @@ void Engine::online_fifo_write(int slot, int pos, const float* feats, int64_t n_
     K2_HIP(hipSetDevice(device_));
     const int64_t first = std::min<int64_t>(n_frames, kFifoFrames - pos);
     float* base = online_fifo_ + (size_t)slot * kFifoFrames * feat;
-    K2_HIP(hipMemcpy(base + (size_t)pos * feat, feats, sizeof(float) * (size_t)first * feat, hipMemcpyHostToDevice));
-    if (n_frames > first) K2_HIP(hipMemcpy(base, feats + (size_t)first * feat, sizeof(float) * (size_t)(n_frames - first) * feat, hipMemcpyHostToDevice));
+    K2_HIP(copy_blocking(base + (size_t)pos * feat, feats, sizeof(float) * (size_t)first * feat, hipMemcpyHostToDevice));
+    if (n_frames > first) K2_HIP(copy_blocking(base, feats + (size_t)first * feat, sizeof(float) * (size_t)(n_frames - first) * feat, hipMemcpyHostToDevice));
 }
 void Engine::online_free_slot(int slot) {
     if (slot >= 0) free_slots_.push_back(slot);
@@ -169,7 +169,7 @@ void Engine::online_read_state(int slot, int layer, int kind, long long chunks_d
         const int left = cfz.left[si], tc = (online_tc50() + cfz.ds[si] - 1) / cfz.ds[si], kl = left + tc;
         const long long width = cnt / left;
         std::vector<float> ring((size_t)kl * width);
-        K2_HIP(hipMemcpy(ring.data(), online_pool_ + (size_t)slot * lay_.floats_per_stream + off, sizeof(float) * ring.size(), hipMemcpyDeviceToHost));
+        K2_HIP(copy_blocking(ring.data(), online_pool_ + (size_t)slot * lay_.floats_per_stream + off, sizeof(float) * ring.size(), hipMemcpyDeviceToHost));
         // before the first chunk the ring is all zeros and any rotation of it is the reference's zero cache
         const long long head = chunks_done > 0 ? ((chunks_done - 1) * tc) % kl : 0;
         for (int j = 0; j < left; j++) {
@@ -178,7 +178,7 @@ void Engine::online_read_state(int slot, int layer, int kind, long long chunks_d
         }
         return;
     }
-    K2_HIP(hipMemcpy(out, online_pool_ + (size_t)slot * lay_.floats_per_stream + off, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost));
+    K2_HIP(copy_blocking(out, online_pool_ + (size_t)slot * lay_.floats_per_stream + off, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost));
 }
 
 int Engine::online_frames_per_chunk() const {
@@ -210,7 +210,7 @@ const float* Engine::pos_emb_stream(int Tc, int L) {
     }
     float* d = nullptr;
     K2_HIP(hipMalloc(&d, pe.size() * sizeof(float)));
-    K2_HIP(hipMemcpy(d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+    K2_HIP(copy_blocking(d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
     pe_cache_[key] = d;
     return d;
 }

@@ -4,10 +4,49 @@
 // k2hip_debug_set_switch is the test-only way to flip one afterwards.
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "kernels.h"
 
 namespace k2hip {
+
+// see common.h: blocking transfers that stay off the legacy stream
+namespace {
+std::mutex g_util_mu;
+hipStream_t g_util_stream[64] = {};
+hipError_t util_stream(hipStream_t* s) {   // g_util_mu held
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!g_util_stream[dev]) {
+        e = hipStreamCreateWithFlags(&g_util_stream[dev], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    *s = g_util_stream[dev];
+    return hipSuccess;
+}
+}  // namespace
+hipError_t copy_blocking(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    if (bytes == 0) return hipSuccess;
+    std::lock_guard<std::mutex> lk(g_util_mu);
+    hipStream_t s = nullptr;
+    hipError_t e = util_stream(&s);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(dst, src, bytes, kind, s);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(s);
+}
+hipError_t fill_blocking(void* dst, int value, size_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    std::lock_guard<std::mutex> lk(g_util_mu);
+    hipStream_t s = nullptr;
+    hipError_t e = util_stream(&s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(dst, value, bytes, s);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(s);
+}
 
 namespace {
 Tunables g_t;
@@ -43,6 +82,7 @@ const Entry kEntries[] = {
     {"K2HIP_SCREEN_MIN_V", &Tunables::screen_min_v, false},
     {"K2HIP_GREEDY_STAMPS", &Tunables::greedy_stamps, true},
     {"K2HIP_NO_GRAPHS", &Tunables::no_graphs, true},
+    {"K2HIP_GRAPH_CAPTURE_MODE", &Tunables::graph_capture_mode, false},
     {"K2HIP_GRAPH_OFFLINE", &Tunables::graph_offline, false},
     {"K2HIP_TEST_GREEDY_TIMEOUT", &Tunables::test_greedy_timeout, true},
     {"K2HIP_SEARCH_ROUNDS", &Tunables::search_rounds, false},

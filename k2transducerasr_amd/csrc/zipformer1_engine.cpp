@@ -20,7 +20,7 @@ const float* Engine::sinus_pos_emb(int Tc, int left, int D) {
     auto it = sinus_cache_.find(key);
     if (it != sinus_cache_.end()) return it->second;
     if (sinus_cache_.size() > 256) {  // many distinct utterance lengths: start over
-        K2_HIP(hipDeviceSynchronize());
+        synchronize();
         graphs_clear();   // instantiated graphs hold these pointers
         for (auto& kv : sinus_cache_) (void)hipFree(kv.second);
         sinus_cache_.clear();
@@ -38,7 +38,7 @@ const float* Engine::sinus_pos_emb(int Tc, int left, int D) {
     }
     float* d = nullptr;
     K2_HIP(hipMalloc(&d, pe.size() * sizeof(float)));
-    K2_HIP(hipMemcpy(d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+    K2_HIP(copy_blocking(d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
     sinus_cache_[key] = d;
     return d;
 }

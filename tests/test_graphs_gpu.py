@@ -85,3 +85,60 @@ def test_streaming_ticks_replay_and_follow_the_oracle(tmp_path):
     assert graph_launches(rec.model) >= nchunks - 3
     for h, o in zip(hs, os_):
         np.testing.assert_allclose(h.state(0, "key"), o.state(0, "key"), atol=2e-4, rtol=0)
+
+
+def test_foreign_legacy_stream_traffic_while_a_tick_is_recorded(tmp_path):
+    """Another thread of the HOST process (not this library) keeps issuing legacy-stream copies -- what a plain hipMemcpy or a
+    framework on the default stream does.  While a tick is being recorded the runtime fails those copies and invalidates the
+    recording; the tick must then run eagerly from the same arena position and give the same tokens (Engine::graphed: nothing was
+    enqueued by the failed recording), and later ticks must keep working whether or not their recording survived."""
+    import ctypes.util
+    import threading
+
+    from k2transducerasr_amd import OnlineRecognizer
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    p = str(tmp_path / "s.k2w")
+    write_synthetic_model(p, "zipformer2-streaming-tiny-test")
+    waves = [synth_utterance(900 + u, 2.4) for u in range(6)]
+
+    def decode(rec, counts):
+        out = []
+        for n in counts:
+            hs = [rec.create_online_stream() for _ in range(n)]
+            for h, w in zip(hs, waves):
+                h.add_samples(w)
+            while any(rec.get_results(hs)[0]):
+                pass
+            out.append([(list(h.tokens), list(h.timestamps)) for h in hs])
+            for h in hs:
+                h.close()
+        return out
+
+    counts = [3, 5, 2, 6, 4, 3, 5, 2, 6, 4]
+    quiet = OnlineRecognizer(p)
+    want = decode(quiet, counts)
+    assert graph_launches(quiet.model) > 0
+    stop, stats = threading.Event(), {"copies": 0, "refused": 0}
+
+    def foreign():
+        dev, host = C.c_void_p(), (C.c_char * 4096)()
+        assert hip.hipMalloc(C.byref(dev), 4096) == 0
+        while not stop.is_set():
+            rc = hip.hipMemcpy(dev, host, 4096, 1)        # hipMemcpyHostToDevice on the legacy stream
+            stats["copies"] += 1
+            stats["refused"] += rc != 0
+    th = threading.Thread(target=foreign)
+    th.start()
+    try:
+        rec = OnlineRecognizer(p)
+        got = decode(rec, counts)
+    finally:
+        stop.set()
+        th.join()
+    print(f"foreign legacy-stream copies: {stats['copies']}, refused by the runtime during a recording: {stats['refused']}; "
+          f"graph replays {graph_launches(rec.model)} (undisturbed: {graph_launches(quiet.model)})")
+    assert got == want
+    assert stats["copies"] > 100

@@ -70,3 +70,73 @@ def test_n_handles_from_n_threads_equal_one_handle(host_exe, tmp_path, preset, t
         for first, cnt in batches_of(lo, hi, batch)[:1]:
             assert m.offline_greedy_from_samples(list(s[first: first + cnt])) == got[first: first + cnt], (rank, first)
     m.close()
+
+
+def test_streaming_handles_on_host_threads_while_ticks_are_recorded_as_graphs(tmp_path):
+    """Four OnlineRecognizers, four host threads, one GPU.  A streaming tick is recorded as a hipGraph the second time a stream count
+    is seen; while ANY stream of the process records, the HIP runtime fails every legacy-stream operation of every thread
+    (hipErrorStreamCaptureImplicit) and invalidates the recording.  Found by running this shape: a handle's first tick used to upload
+    its positional table with a plain hipMemcpy while a neighbour recorded -- both calls failed.  The library now keeps all of its
+    blocking transfers on a utility stream of its own (csrc/common.h copy_blocking); here every thread walks through changing
+    stream counts (each one: an eager tick, a recorded one, replays), creates and closes streams, reads states and synchronises
+    while the others do the same, and every stream's tokens must equal the same stream decoded by one handle alone."""
+    import threading
+
+    from k2transducerasr_amd import OnlineRecognizer
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    p = str(tmp_path / "s.k2w")
+    write_synthetic_model(p, "zipformer2-streaming-tiny-test")
+    NT, ROUNDS = 4, 5
+    counts = [[3, 5, 2, 6, 4], [4, 2, 6, 3, 5], [5, 6, 3, 2, 4], [2, 4, 5, 6, 3]]
+    ref = OnlineRecognizer(p)
+    waves = {}
+
+    def decode(rec, thread, rnd, with_extras):
+        n = counts[thread][rnd]
+        hs = [rec.create_online_stream() for _ in range(n)]
+        for u, h in enumerate(hs):
+            key = (thread, rnd, u)
+            if key not in waves:
+                waves[key] = synth_utterance(4000 + 97 * thread + 13 * rnd + u, 2.0 + 0.3 * (u % 3))
+            w = waves[key]
+            for pos in range(0, w.size, 1600):
+                h.add_samples(w[pos: pos + 1600])
+        ticks = 0
+        while True:
+            dec, _ = rec.get_results(hs)
+            if not any(dec):
+                break
+            ticks += 1
+            if with_extras and ticks % 2 == 0:
+                hs[0].state(0, "key")              # a blocking device -> host read between ticks
+                rec.model.synchronize()
+        out = [(list(h.tokens), list(h.timestamps)) for h in hs]
+        for h in hs:
+            h.close()
+        return out, ticks
+
+    for t in range(NT):                  # the audio, made once (the threads then only decode)
+        for r in range(ROUNDS):
+            decode(ref, t, r, False)
+    want = {(t, r): decode(ref, t, r, False)[0] for t in range(NT) for r in range(ROUNDS)}
+    recs = [OnlineRecognizer(p) for _ in range(NT)]
+    got, errors = {}, []
+    bar = threading.Barrier(NT)
+
+    def worker(t):
+        try:
+            bar.wait()
+            for r in range(ROUNDS):
+                got[(t, r)], ticks = decode(recs[t], t, r, True)
+                assert ticks >= 3
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(NT)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
+    assert got == want
+    assert sum(len(tok) - 2 for v in want.values() for tok, _ in v) > 0
