@@ -613,7 +613,7 @@ void beam_search(const Ctx& ctx, const DecJoinW& w, const BeamArgs& a) {
             // the offline co-residency budget: the frame's sweep is bound by ONE CU's fetch of the 1 MB matrix, two CUs halve it, and the
             // exchange of the 4 x 256 logits costs less than the half sweep (search alone 5.5 -> 4.45 ms for the headline batch).  The
             // slabs wait for each other (bounded; *overflow = 2 on a timeout): the launch is kept for a repeat with one slab.
-            const bool two = tunables().beam_parts != 1 && K <= 4 && (w.Vp >> 2) <= 128 && (w.Vp >> 2) > 64 && 2 * B <= std::max(device_cu_count() / 4, 2);
+            const bool two = !ctx.one_part && tunables().beam_parts != 1 && K <= 4 && (w.Vp >> 2) <= 128 && (w.Vp >> 2) > 64 && 2 * B <= std::max(device_cu_count() / 4, 2);
             unsigned long long* xg = two ? ar.take<unsigned long long>((int64_t)B * 2 * 2 * 4 * 256) : nullptr;
             // (hypotheses in device memory: every workgroup keeps its own copy, so two slabs need twice the space)
             int* ys_g = hyp_in_lds ? nullptr : ar.take<int>((int64_t)(two ? 2 : 1) * 2 * M * cap);

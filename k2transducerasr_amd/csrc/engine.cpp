@@ -119,6 +119,7 @@ Ctx Engine::make_ctx(bool dry) {
     c.evused = &evused_;
     c.gemm_log = &gemm_log_;
     c.greedy_rec = &last_greedy_;
+    c.one_part = one_part_left_ > 0;
     return c;
 }
 
@@ -699,6 +700,23 @@ void Engine::beam_device(const Ctx& c, const float* enc, int B, int Tp, long lon
     beam_search(c, decjoin(), a);
 }
 
+// Back-off of the parted searches.  A search whose column slabs are not co-resident (other handles or processes on the GPU hold the
+// CUs) spins to its bound, reports the timeout and is repeated with one workgroup per stream -- correct, but the timeout costs
+// milliseconds, every call (four streaming recognizers on one GPU: 12.6 ms per tick against 4.2).  After a timeout the next 64
+// searches of this engine go out with one part per stream straight away; each further timeout doubles the span (up to 8192), a parted
+// search that comes through clears it.
+void Engine::note_search(bool parted, bool timed_out) {
+    if (timed_out) {
+        if (tunables().test_greedy_timeout == 1) return;   // (the tests' forced timeouts want the next search parted again)
+        one_part_span_ = std::min(std::max(2 * one_part_span_, 64), 8192);
+        one_part_left_ = one_part_span_;
+    } else if (one_part_left_ > 0) {
+        one_part_left_--;
+    } else if (parted) {
+        one_part_span_ = 0;
+    }
+}
+
 void Engine::finish_tokens(const long long* d_tok, const int* d_ts, const int* d_n, const int* d_ovf, int B, int max_tokens,
                            int64_t* tokens, int32_t* ts, int32_t* n_tokens) {
     int64_t nb_tok = (int64_t)B * max_tokens * 8, nb_ts = (int64_t)B * max_tokens * 4, nb_n = (int64_t)B * 4;
@@ -722,7 +740,9 @@ void Engine::finish_tokens(const long long* d_tok, const int* d_ts, const int* d
         ovf = *reinterpret_cast<int*>(pin0);
         // exchange timeout of the vocabulary-parallel search (its workgroups were not co-resident: a shared GPU): the same search
         // once more with one workgroup per stream, which waits for nobody
-        if (ovf != 2 || attempt == 1 || !last_greedy_.valid || last_greedy_.a.overflow != d_ovf) break;
+        const bool mine = last_greedy_.valid && last_greedy_.a.overflow == d_ovf;
+        if (attempt == 0) note_search(mine, ovf == 2 && mine);
+        if (ovf != 2 || attempt == 1 || !mine) break;
         greedy_relaunch_one_part(stream_, last_greedy_);
         search_retries_++;
     }
@@ -1233,6 +1253,7 @@ void Engine::wait_ticket(int ticket, int64_t* tokens, int32_t* ts, int32_t* n_to
     const int64_t nb_tok = (int64_t)sl.B * sl.max_tokens * 8, nb_ts = (int64_t)sl.B * sl.max_tokens * 4, nb_n = (int64_t)sl.B * 4;
     char* pin = static_cast<char*>(sl.pin);
     int ovf = *reinterpret_cast<const int*>(pin + nb_tok + nb_ts + nb_n);
+    note_search(sl.greedy.valid && sl.greedy.a.overflow == sl.d_ovf, ovf == 2 && sl.greedy.valid && sl.greedy.a.overflow == sl.d_ovf);
     if (ovf == 2 && sl.greedy.valid && sl.greedy.a.overflow == sl.d_ovf) {
         // exchange timeout (the search's workgroups were not co-resident): once more with one workgroup per stream.  The slot's
         // arena still holds the encoder output and the search's inputs (it is only rebuilt by the slot's next submit).

@@ -252,6 +252,8 @@ class Engine {
         hipStream_t search_stream = nullptr;
     } slots_[kSlots];
     GreedyLaunch last_greedy_;          // the same for the synchronous entries (searches on stream_)
+    void note_search(bool parted, bool timed_out);
+    int one_part_left_ = 0, one_part_span_ = 0;   // searches still to run with one workgroup per stream / the current back-off span
     int search_retries_ = 0;            // one-part retries since the model was created (k2hip_debug_search_retries)
     int next_slot_ = 0;
     hipStream_t stream2_ = nullptr;

@@ -1229,7 +1229,8 @@ static size_t greedy_lds_bytes(const DecJoinW& w) {
 }
 
 // column slabs per stream of the persistent search (see greedy_loop)
-static int greedy_parts(const DecJoinW& w, int B, bool streaming) {
+static int greedy_parts(const DecJoinW& w, int B, bool streaming, bool one_part) {
+    if (one_part) return 1;
     const int ncg = w.Vp >> 2, pass = (GT / 64) * 8;
     const int bc = std::max(B, 1);
     const int budget = streaming ? device_cu_count() : std::max(device_cu_count() / 4, 1);
@@ -1242,11 +1243,11 @@ static int greedy_parts(const DecJoinW& w, int B, bool streaming) {
 // with the screen the persistent search beats the rounds of joiner GEMMs -- zipformer2-streaming-zh, V = 2000, 128 streams: 4.18
 // against 4.31 ms per tick; without it -- conformer-streaming-zh, V = 5537: two slabs of 2770 columns per stream do not fit the
 // screen's LDS area -- the rounds win, 7.20 against 7.99 ms.)
-bool greedy_loop_screens(const DecJoinW& w, int B, bool streaming) {
+bool greedy_loop_screens(const DecJoinW& w, int B, bool streaming, bool one_part) {
     if (!w.out_h16 || (w.J & 31) != 0) return false;
     const int nks = w.J >> 5;
     if (!(nks == 16 || nks == 8 || nks == 4 || nks == 2)) return false;
-    const int parts = greedy_parts(w, B, streaming), ncg = w.Vp >> 2;
+    const int parts = greedy_parts(w, B, streaming, one_part), ncg = w.Vp >> 2;
     const int cper = ((ncg + parts - 1) / parts + 7) & ~7;
     return 4 * cper <= kScreenMaxCols;
 }
@@ -1263,7 +1264,7 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     // flight; one 150 KB workgroup per CU).  From the device's own CU count (256 on MI355X -> 64 / 256); a GPU shared with other
     // processes can still leave the parts of a stream apart: then the bounded waits time out and the engine repeats the search with
     // one part per stream (greedy_relaunch_one_part).
-    const int parts = greedy_parts(w, a.B, a.init_ctx != nullptr);
+    const int parts = greedy_parts(w, a.B, a.init_ctx != nullptr, ctx.one_part);
     a.parts = parts;
     // (one block, one memset: the two exchange areas were two fills of ~5 us each in front of the search)
     const size_t gran_words = (size_t)a.B * 2 * parts * GF * 2, gran2_words = (size_t)a.B * 2 * w.J;

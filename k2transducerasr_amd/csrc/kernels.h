@@ -38,6 +38,7 @@ struct Tunables {
     int graph_offline = 0;        // K2HIP_GRAPH_OFFLINE: 1 = the offline batch entries replay their encoder pass from a hipGraph too (measured:
                                   // 13.87 against 13.76 ms per headline batch -- launches of 20 - 80 us hide their own enqueue cost; off by default)
     int test_greedy_timeout = 0;  // K2HIP_TEST_GREEDY_TIMEOUT: test hook -- every parts > 1 search reports an exchange timeout, so the one-part retry runs
+                                  // (1: without arming the engine's back-off, so that the next search is parted again; 2: as a real one)
     int pipe_mode = 0;            // K2HIP_PIPE_MODE: 1 = every pipeline slot owns a stream
     int max_streams = 0;          // K2HIP_MAX_STREAMS: slots of the streaming state pool (0 = 256)
     int search_rounds = -1;       // K2HIP_SEARCH_ROUNDS: 1 = every multi-stream search as rounds of joiner GEMMs (greedy_rounds),
@@ -67,6 +68,8 @@ struct Ctx {
     hipStream_t stream = nullptr;
     Arena* arena = nullptr;
     bool dry = false;
+    bool one_part = false;    // the engine's searches recently timed out waiting for their other column slabs (a GPU shared with other
+                              // handles or processes): one workgroup per stream until the back-off runs out (Engine::note_search)
     bool capturing = false;   // the stream is capturing a hipGraph (Engine::graphed): no event records, nothing that is not a stream operation
     bool instrument = false;  // bracket each GEMM launch with events
     GemmStats* stats = nullptr;
@@ -352,7 +355,7 @@ struct GreedyArgs {
     unsigned long long* stamps = nullptr;
 };
 void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a);
-bool greedy_loop_screens(const DecJoinW& w, int B, bool streaming);  // would its rounds use the f16 screen (large vocabulary, slab fits)?
+bool greedy_loop_screens(const DecJoinW& w, int B, bool streaming, bool one_part);  // would its rounds use the f16 screen (large vocabulary, slab fits)?
 // The vocabulary-parallel search waits on its sibling workgroups (bounded spins; a timeout raises *overflow = 2).  All B x parts
 // workgroups must be resident together for that, which a GPU shared with other processes or models does not promise.  The engine
 // therefore keeps the launch (inputs are read-only, outputs are rewritten from scratch) and, on a timeout, runs it again with ONE

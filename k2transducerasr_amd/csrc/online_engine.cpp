@@ -493,9 +493,9 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
         // (slots, ring heads, processed lengths and contexts are DATA in the uploaded block): replayed as a hipGraph
         // the tick's search: rounds of joiner GEMMs + a per-stream step kernel, or the persistent kernel where its rounds go through
         // the f16 screen (measured per model: greedy_loop_screens)
-        const bool persistent_search = tunables().search_rounds == 0 || (tunables().search_rounds < 0 && !cf.ctc && greedy_loop_screens(decjoin(), B, true));
+        const bool persistent_search = tunables().search_rounds == 0 || (tunables().search_rounds < 0 && !cf.ctc && greedy_loop_screens(decjoin(), B, true, c.one_part));
         GraphKey gk;
-        gk.kind = 1; gk.B = B; gk.T = from_fifo ? 1 : 0; gk.extra = persistent_search ? 1 : 0;
+        gk.kind = 1; gk.B = B; gk.T = from_fifo ? 1 : 0; gk.extra = (persistent_search ? 1 : 0) | (c.one_part ? 2 : 0);
         gk.p0 = online_pool_; gk.p1 = online_fifo_;
         const int launches_before = graph_launches_;
         auto chain = [&](const Ctx& c) {

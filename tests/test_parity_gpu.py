@@ -419,3 +419,45 @@ def test_large_vocabulary_screened_search_end_to_end(tmp_path):
     assert L.k2hip_debug_search_retries(hip.handle, C.byref(n1)) == 0
     assert n1.value == n0.value + 1 or B == 1, (n0.value, n1.value)      # (a one-stream batch may run one slab: nothing to time out)
     hip.close()
+
+
+def test_search_timeouts_back_off_to_one_workgroup_per_stream(tmp_path):
+    """A parted search whose slabs are not co-resident (other handles or processes hold the CUs) times out and is repeated with one
+    workgroup per stream; paying that timeout on every call made four streaming recognizers on one GPU three times slower than one.
+    After a timeout the engine's next 64 searches go out with one part straight away (no timeout to wait for), then parted searches are
+    tried again; a further timeout doubles the span.  Forced here with the test hook in its "as a real one" form."""
+    import ctypes as C
+    from k2transducerasr_amd import Model, load_library, set_switch
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    from oracle import Oracle
+    p = str(tmp_path / "wide.k2w")
+    write_synthetic_model(p, "zipformer2-tiny-test", blank_bias=2.4, meta_overrides={"vocab_size": "3000"})
+    hip, ora = Model(p, 0), Oracle(p)
+    L = load_library()
+    L.k2hip_debug_search_retries.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+
+    def retries():
+        n = C.c_int32(0)
+        assert L.k2hip_debug_search_retries(hip.handle, C.byref(n)) == 0
+        return n.value
+    utts = [synth_utterance(1200 + b, 0.8 + 0.3 * b) for b in range(3)]
+    want = ora.recognize_batch([ora.fbank(u) for u in utts])
+    n0 = retries()
+    assert hip.offline_greedy_from_samples(utts) == want and retries() == n0          # parted, undisturbed
+    try:
+        set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 2)
+        assert hip.offline_greedy_from_samples(utts) == want and retries() == n0 + 1  # timed out, repeated with one part
+        for _ in range(5):                                                           # backed off: one part, nothing to time out
+            assert hip.offline_greedy_from_samples(utts) == want
+        assert retries() == n0 + 1
+        set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 0)
+        for _ in range(59):                                                          # ... for 64 searches in all
+            assert hip.offline_greedy_from_samples(utts) == want
+        set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 2)                                   # the 65th is parted again -- and times out again
+        assert hip.offline_greedy_from_samples(utts) == want and retries() == n0 + 2
+        for _ in range(100):                                                         # the span doubled: still one part after 64 more
+            assert hip.offline_greedy_from_samples(utts) == want
+        assert retries() == n0 + 2
+    finally:
+        set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 0)
+    hip.close()
