@@ -1,6 +1,7 @@
 // Shared host-side plumbing for libk2hip: error transport across the C ABI,
 // HIP call checking, a grow-only device arena.
 #pragma once
+#include <atomic>
 #include <type_traits>
 #include <hip/hip_runtime.h>
 
@@ -28,29 +29,30 @@ namespace k2hip {
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: a host that opens one model per GPU in ONE process (the C ABI
 // allows it) needs it on every device, so the "done" flag is kept per (call site, device).
 struct LdsAttrOnce {
-    bool done[64] = {false};
+    std::atomic<bool> done[64] = {};   // (handles on several host threads reach a call site together: setting the attribute twice is harmless)
     template <typename F>
     void ensure(F* func, int bytes) {
         int dev = 0;
         K2_HIP(hipGetDevice(&dev));
-        if (dev < 0 || dev >= 64 || done[dev]) return;
+        if (dev < 0 || dev >= 64 || done[dev].load(std::memory_order_acquire)) return;
         K2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(func), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        done[dev] = true;
+        done[dev].store(true, std::memory_order_release);
     }
 };
 
 // compute units of the calling thread's current device (256 on MI355X), cached per device
 inline int device_cu_count() {
-    static int n[64] = {0};
+    static std::atomic<int> n[64] = {};
     int dev = 0;
     K2_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return 256;
-    if (!n[dev]) {
-        int v = 0;
+    int v = n[dev].load(std::memory_order_relaxed);
+    if (!v) {
         K2_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-        n[dev] = v > 0 ? v : 256;
+        v = v > 0 ? v : 256;
+        n[dev].store(v, std::memory_order_relaxed);
     }
-    return n[dev];
+    return v;
 }
 
 // Blocking copy / fill on the device's utility stream (non-blocking flag), never on the legacy (null) stream: while ANY stream of the

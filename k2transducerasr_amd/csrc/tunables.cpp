@@ -92,7 +92,10 @@ const Entry kEntries[] = {
 }  // namespace
 
 void tunables_init_from_env() {
-    if (g_init) return;
+    // once per process, whichever threads open the first handles (two at the same moment raced on the flag: ThreadSanitizer,
+    // tests/native/tsan_api_driver.cpp)
+    static std::once_flag once;
+    std::call_once(once, [] {
     g_init = true;
     for (const Entry& e : kEntries)
         if (const char* v = getenv(e.env)) g_t.*(e.field) = e.flag ? 1 : atoi(v);
@@ -100,6 +103,7 @@ void tunables_init_from_env() {
     // segfaults inside the HIP runtime when a stream it traces is captured into / replayed from a hipGraph (seen on
     // bench_streaming.py; profiles/README.md).  A profile then shows the eager chain, which is the same kernels.
     if (getenv("ROCP_TOOL_LIBRARIES") && !getenv("K2HIP_GRAPHS_UNDER_PROFILER")) g_t.no_graphs = 1;
+    });
 }
 
 const Tunables& tunables() { return g_t; }

@@ -209,3 +209,21 @@ def test_large_vocabulary_repack_under_sanitizers(api_driver, tmp_path):
     p2 = str(tmp_path / "wide_odd.k2w")
     write_k2w(p2, meta, tensors.items())
     assert run(api_driver, "meta", p2, "model_type") == "zipformer2"
+
+
+def test_host_layer_from_several_threads_under_thread_sanitizer(streaming_tiny_path, tiny_model_path):
+    """INTEGRATION.md's threading contract -- calls on one handle serialise on its mutex, different handles run concurrently, any
+    thread may call -- checked by ThreadSanitizer (`make tsan`: csrc/api.cpp + model.cpp + tunables.cpp over the CPU stand-in of the
+    engine, whose counters and free lists are as unsynchronised as the real engine's): six threads with OnlineStreams of their own on
+    ONE shared streaming handle, three with OfflineStreams on ONE shared offline handle, two creating and destroying handles of their
+    own meanwhile; the first two handles of the process are opened from two threads at the same moment (that raced on the switches'
+    read-the-environment-once flag before it became a std::call_once).  Any report fails."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "k2transducerasr_amd", "csrc"), "-s", "tsan"])
+    exe = os.path.join(ROOT, "tests", "native", "k2hip_tsan_api_driver")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1")
+    r = subprocess.run([exe, streaming_tiny_path, tiny_model_path, "6", "1500"], capture_output=True, text=True, env=env, timeout=600)
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    assert r.stdout.startswith("threads ok:")
+    steps = int(r.stdout.split(":")[1].split()[0])
+    assert steps > 500
