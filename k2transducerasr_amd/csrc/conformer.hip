@@ -8,6 +8,9 @@
 // and the rel_shift (icefall does it with as_strided) is folded into the softmax as a gather:
 //   w[i, j] = softmax_j(ac[i, j] + bd[i, T-1-i+j])
 // The softmaxed weights are then the K-contiguous A operand of the value product.
+#include <algorithm>
+#include <vector>
+
 #include "kernels.h"
 
 namespace k2hip {
@@ -417,6 +420,177 @@ __global__ __launch_bounds__(64 * NW) void k_conformer_scores_softmax16(const fl
     }
 }
 
+
+// The 16-row strip again, with the scatter and the operand loads taken off the critical path (round 4).  What the ISA of the kernel
+// above showed: every one of its 8 positional read-modify-writes per key tile sat in a branch of its own (ds_read, wait, add,
+// ds_write: eight exposed LDS round trips per tile), and the loop began with vmcnt(0) on loads issued one scatter earlier.  Here
+//   * a positional tile's element (rl, li) belongs to exactly ONE strip position, column 16 (m - 1) + 1 + li + rl of row rl (the "low
+//     run" and the "high run" of the form above are the two halves of that one formula): the tile is WRITTEN skewed, four plain
+//     ds_write per lane, masked by address (a dump slot per lane) -- no branch, no read;
+//   * the content tile is then added on top: four reads in one batch, one wait, four writes (a wave's LDS operations complete in order,
+//     and a wave only writes the columns of its own run);
+//   * keys and table rows are requested TWO tiles ahead into the register set just consumed (the loop is unrolled by two so that the set
+//     is a compile-time choice).
+// Same MFMAs, same sums (a position receives one content value and one positional value: the order of that one addition does not
+// matter), bit-identical weights.
+template <int NG, int NW>
+__global__ __launch_bounds__(64 * NW) void k_conformer_scores_softmax16s(const float* __restrict__ qu, const float* __restrict__ qv,
+                                                                     const float* __restrict__ kmat, int ldk, const float* __restrict__ pp,
+                                                                     float* __restrict__ aw, int B, int H, int T, int Tp, int D,
+                                                                     int lds_stride, unsigned long long* __restrict__ stamps) {
+    constexpr int DK = 16 * NG;
+    extern __shared__ __attribute__((aligned(16))) float csm[];
+    float* S = csm;                                   // [16][lds_stride] | 64 dump slots
+    // tuning (K2HIP_CONFORMER_STAMPS): per wave s_memtime at entry | queries loaded | tile loop done | barrier passed | end, + s_memrealtime
+    unsigned long long* st = stamps ? stamps + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + (threadIdx.x >> 6)) * 8 : nullptr;
+    if (st && (threadIdx.x & 63) == 0) { st[0] = __builtin_amdgcn_s_memtime(); st[6] = __builtin_amdgcn_s_memrealtime(); }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int i0 = blockIdx.x * 16, b = blockIdx.y, h = blockIdx.z, NP = 2 * T - 1;
+    const long long rowbase = (long long)b * T;
+    const int dump = 16 * lds_stride + lane;
+    float4 fu[NG], fv[NG];
+    {
+        const int row = i0 + li;
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            fu[g] = fv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < T) {
+                fu[g] = *reinterpret_cast<const float4*>(qu + (rowbase + row) * D + h * DK + 16 * g + 4 * kq);
+                fv[g] = *reinterpret_cast<const float4*>(qv + (rowbase + row) * D + h * DK + 16 * g + 4 * kq);
+            }
+        }
+    }
+    const int njt = (T + 15) / 16;
+    auto load_k = [&](int jt, float4* k_) {
+        const int jr = min(jt * 16 + li, T - 1);
+#pragma unroll
+        for (int g = 0; g < NG; g++) k_[g] = *reinterpret_cast<const float4*>(kmat + (rowbase + jr) * ldk + h * DK + 16 * g + 4 * kq);
+    };
+    auto load_p = [&](int nrow, float4* p_) {   // table row nrow (out-of-table rows only meet masked entries)
+        const int nr = min(max(nrow, 0), NP - 1);
+#pragma unroll
+        for (int g = 0; g < NG; g++) p_[g] = *reinterpret_cast<const float4*>(pp + (long long)nr * D + h * DK + 16 * g + 4 * kq);
+    };
+    auto mma = [](const float4& a, const float4& bq, cf32x4 acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc, 0, 0, 0);
+        return acc;
+    };
+    const int tpw = (njt + NW - 1) / NW, jt_beg = wave * tpw, jt_end = min(njt, jt_beg + tpw);
+    if (st && lane == 0) st[1] = __builtin_amdgcn_s_memtime();
+    if (jt_beg < jt_end) {
+        const int col_lo = 16 * jt_beg, col_hi = min(16 * jt_end, T);   // the strip columns this wave owns
+        // positional tile m = jt_beg .. jt_end: table rows base0 + 16 (m - jt_beg) + li
+        const int base0 = T - 1 - i0 - 15 + jt_beg * 16;
+        auto put_pos = [&](const cf32x4& g, int m) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int rl = 4 * kq + e, col = 16 * (m - 1) + 1 + li + rl;
+                S[(col >= col_lo && col < col_hi) ? rl * lds_stride + col : dump] = g[e];
+            }
+        };
+        // (Tried on top of this form and measured slower, all of them fighting the compiler's wait counting rather than the hardware:
+        // separate interior / boundary code paths with addresses as uniform base + fixed per-lane offset -- a third of the vector-ALU
+        // instructions, but vmcnt(0) wherever the paths join: 233 us against 195; the same without branches: the register allocator
+        // rotates the two operand sets through copies at the loop's latch and waits for the loads there, tile loop 67.8k cycles against
+        // 58.6k; the loads as inline asm with hand-counted waits: the copies then read destination registers of loads in flight.)
+        auto step = [&](int jt, float4* K_, float4* P_) {   // key tile jt (operands in K_) and positional tile jt + 1 (in P_)
+            cf32x4 acc = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NG; q++) {
+                acc = mma(fu[q], K_[q], acc);
+                g = mma(fv[q], P_[q], g);
+            }
+            if (jt + 2 < jt_end) {   // (wave-uniform) two tiles ahead, into the registers just consumed
+                load_k(jt + 2, K_);
+                load_p(base0 + (jt + 3 - jt_beg) * 16 + li, P_);
+            }
+            put_pos(g, jt + 1);
+            const int j = jt * 16 + li;
+            int idx[4];
+            float sv[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                idx[e] = j < T ? (4 * kq + e) * lds_stride + j : dump;
+                sv[e] = S[idx[e]];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) S[idx[e]] = sv[e] + acc[e];
+        };
+        float4 k0[NG], k1[NG], p0[NG], p1[NG];
+        load_p(base0 + li, p1);
+        load_k(jt_beg, k0);
+        load_p(base0 + 16 + li, p0);
+        {
+            cf32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NG; q++) g = mma(fv[q], p1[q], g);
+            put_pos(g, jt_beg);
+        }
+        if (jt_beg + 1 < jt_end) {
+            load_k(jt_beg + 1, k1);
+            load_p(base0 + 32 + li, p1);
+        }
+        for (int jt = jt_beg; jt < jt_end; jt += 2) {
+            step(jt, k0, p0);
+            if (jt + 1 < jt_end) step(jt + 1, k1, p1);
+        }
+    }
+    if (st && lane == 0) st[2] = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    if (st && lane == 0) st[3] = __builtin_amdgcn_s_memtime();
+    // row softmax: wave w owns 16 / NW rows; a row's T scores are read ONCE into registers (T <= 64 * 20), four consecutive columns per
+    // lane and instruction (ds_read_b128 / global_store_dwordx4: with three workgroups per CU the phase is bound by the instructions
+    // the SIMD can issue, and this form has a third of them).  Rows are lds_stride = Tp + 4 floats, 16-byte aligned; Tp % 4 == 0.
+    float* out = aw + (((long long)b * H + h) * T) * Tp;
+    const int nu = (Tp + 255) >> 8;   // groups of 256 columns (<= 5)
+    for (int rr = 0; rr < 16 / NW; rr++) {
+        const int rl = wave * (16 / NW) + rr, i = i0 + rl;
+        if (i >= T) break;
+        const float* srow = S + rl * lds_stride;
+        float4 v[5];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            if (u < nu) {
+                const int jj = 4 * lane + 256 * u;
+                const float4 x = *reinterpret_cast<const float4*>(srow + min(jj, lds_stride - 4));
+                v[u].x = jj < T ? x.x : -INFINITY;
+                v[u].y = jj + 1 < T ? x.y : -INFINITY;
+                v[u].z = jj + 2 < T ? x.z : -INFINITY;
+                v[u].w = jj + 3 < T ? x.w : -INFINITY;
+                mx = fmaxf(fmaxf(mx, fmaxf(v[u].x, v[u].y)), fmaxf(v[u].z, v[u].w));
+            }
+        }
+        mx = wave_max_dpp(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            if (u < nu) {   // exp(-inf) = 0 for the masked columns
+                v[u].x = __expf(v[u].x - mx);
+                v[u].y = __expf(v[u].y - mx);
+                v[u].z = __expf(v[u].z - mx);
+                v[u].w = __expf(v[u].w - mx);
+                sum += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.0f / sum;
+        float* orow = out + (long long)i * Tp;
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            const int jj = 4 * lane + 256 * u;
+            if (u < nu && jj < Tp)   // pad columns [T, Tp) get 0
+                *reinterpret_cast<float4*>(orow + jj) = make_float4(v[u].x * inv, v[u].y * inv, v[u].z * inv, v[u].w * inv);
+        }
+    }
+    if (st && lane == 0) { st[4] = __builtin_amdgcn_s_memtime(); st[7] = __builtin_amdgcn_s_memrealtime(); }
+}
+
 }  // namespace
 
 void conformer_softmax_shift_stream(const Ctx& ctx, float* ac, const float* bd, const long long* plen, int B, int H, int Tc, int left,
@@ -481,12 +655,46 @@ template <int NG>
 static bool conformer_scores_launch16(const Ctx& ctx, const float* qu, const float* qv, const float* kmat, int ldk, const float* pp, float* aw,
                                       int B, int H, int T, int Tp, int D) {
     const int lds_stride = Tp + 4;
-    const size_t lds = sizeof(float) * (size_t)16 * lds_stride;
-    static LdsAttrOnce lds_attr;
+    const size_t lds = sizeof(float) * ((size_t)16 * lds_stride + 64);   // + a dump slot per lane (masked positional writes)
+    static LdsAttrOnce lds_attr, lds_attr_v1;
     // (eight waves per strip: 222 against 205 us per launch; four it is)
-    lds_attr.ensure((k_conformer_scores_softmax16<NG, 4>), 96 * 1024);
-    hipLaunchKernelGGL((k_conformer_scores_softmax16<NG, 4>), dim3(cdiv(T, 16), B, H), dim3(256), lds, ctx.stream, qu, qv, kmat, ldk, pp, aw, B, H, T,
-                       Tp, D, lds_stride);
+    if (tunables().conformer_scatter_v1) {   // round 3's loop (read-modify-write scatter, loads one tile ahead), for comparison
+        lds_attr_v1.ensure((k_conformer_scores_softmax16<NG, 4>), 96 * 1024);
+        hipLaunchKernelGGL((k_conformer_scores_softmax16<NG, 4>), dim3(cdiv(T, 16), B, H), dim3(256), lds, ctx.stream, qu, qv, kmat, ldk, pp, aw, B, H,
+                           T, Tp, D, lds_stride);
+    } else {
+        lds_attr.ensure((k_conformer_scores_softmax16s<NG, 4>), 96 * 1024);
+        unsigned long long* d_st = nullptr;
+        const size_t n_st = (size_t)cdiv(T, 16) * B * H * 4 * 8;
+        if (tunables().conformer_stamps) {
+            K2_HIP(hipMalloc(&d_st, n_st * 8));
+            K2_HIP(hipMemsetAsync(d_st, 0, n_st * 8, ctx.stream));
+        }
+        hipLaunchKernelGGL((k_conformer_scores_softmax16s<NG, 4>), dim3(cdiv(T, 16), B, H), dim3(256), lds, ctx.stream, qu, qv, kmat, ldk, pp, aw, B, H,
+                           T, Tp, D, lds_stride, d_st);
+        if (d_st) {   // tuning only: synchronous report (cycles of the slowest wave of each workgroup, averaged; launch span in realtime ticks)
+            std::vector<unsigned long long> h(n_st);
+            K2_HIP(hipStreamSynchronize(ctx.stream));
+            K2_HIP(copy_blocking(h.data(), d_st, n_st * 8, hipMemcpyDeviceToHost));
+            (void)hipFree(d_st);
+            double ph[4] = {0, 0, 0, 0};
+            unsigned long long r0 = ~0ull, r1 = 0;
+            const size_t nwg = n_st / 32;
+            for (size_t w = 0; w < nwg; w++) {
+                double worst[4] = {0, 0, 0, 0};
+                for (int v = 0; v < 4; v++) {
+                    const unsigned long long* q = &h[(w * 4 + v) * 8];
+                    for (int k = 0; k < 4; k++) worst[k] = std::max(worst[k], (double)(q[k + 1] - q[k]));
+                    r0 = std::min(r0, q[6]);
+                    r1 = std::max(r1, q[7]);
+                }
+                for (int k = 0; k < 4; k++) ph[k] += worst[k];
+            }
+            fprintf(stderr, "conformer scores stamps: %zu workgroups; slowest wave per workgroup, mean cycles: queries %.0f | tile loop %.0f | barrier wait %.0f | "
+                            "softmax + write %.0f; launch span %.1f us (100 MHz ticks)\n",
+                    nwg, ph[0] / nwg, ph[1] / nwg, ph[2] / nwg, ph[3] / nwg, (double)(r1 - r0) / 100.0);
+        }
+    }
     K2_HIP(hipGetLastError());
     return true;
 }

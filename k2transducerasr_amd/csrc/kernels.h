@@ -17,6 +17,8 @@ struct Tunables {
     int attn_long = 0;            // K2HIP_ATTN_LONG: two-pass attention scores for every length
     int no_fused_av = 0;          // K2HIP_NO_FUSED_AV: attention apply + out_proj as two GEMMs
     int conformer_strip32 = 0;      // K2HIP_CONFORMER_STRIP32: the fused Conformer scores kernel on 32-row strips (one workgroup per CU), the earlier form
+    int conformer_stamps = 0;       // K2HIP_CONFORMER_STAMPS: tuning -- the 16-row scores kernel reports its phases (stderr, synchronous)
+    int conformer_scatter_v1 = 0;   // K2HIP_CONFORMER_SCATTER_V1: the 16-row scores kernel with round 3's loop (read-modify-write scatter)
     int conformer_gemm_scores = 0;  // K2HIP_CONFORMER_GEMM_SCORES: two batched GEMMs + gather/softmax
     int dw7_simple = 0;           // K2HIP_DW7_SIMPLE: untiled 7x7 depthwise convolution
     int dw1d_tt = 0;              // K2HIP_DW1D_TT: outputs per thread of the depthwise Conv1d (8 / 4 / 2; 0 = by grid size)

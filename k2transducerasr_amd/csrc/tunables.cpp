@@ -67,6 +67,8 @@ const Entry kEntries[] = {
     {"K2HIP_NO_FUSED_AV", &Tunables::no_fused_av, true},
     {"K2HIP_CONFORMER_GEMM_SCORES", &Tunables::conformer_gemm_scores, true},
     {"K2HIP_CONFORMER_STRIP32", &Tunables::conformer_strip32, true},
+    {"K2HIP_CONFORMER_SCATTER_V1", &Tunables::conformer_scatter_v1, true},
+    {"K2HIP_CONFORMER_STAMPS", &Tunables::conformer_stamps, true},
     {"K2HIP_DW7_SIMPLE", &Tunables::dw7_simple, true},
     {"K2HIP_DW7_TILED", &Tunables::dw7_tiled, true},
     {"K2HIP_CAUSAL_CONV_LDS", &Tunables::causal_conv_lds, true},
