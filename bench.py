@@ -156,6 +156,19 @@ def cpu_baseline(weights, n_utts, seconds, beam=0, extra_firsts=()):
     res = run()
     dt = time.time() - t
     extra = [run([synth_utterance(f + i, seconds) for i in range(n_utts)]) for f in extra_firsts]
+    # untimed: the oracle's encoder output and joiner logits of the sample batch, for `oracle_match.max_abs_logit_diff` (the caller runs
+    # the same operator-level chain on the GPU: fbank -> PadSequence -> EncoderProj -> DecoderProj / JoinerProj)
+    logits_ref = None
+    if beam == 0 and ora.meta("model_type") not in ("zipformer2ctc",):
+        try:
+            feats = [ora.fbank(u) for u in utts]
+            enc = ora.encoder(ora.pad_sequence(feats).reshape(len(feats), -1, ora.feature_dim))
+            ys = np.array([[-1, 0], [5, 7]], np.int64)
+            dec = ora.decoder(ys)
+            rows = enc[:, ::4, :].reshape(-1, enc.shape[-1])
+            logits_ref = {"enc": enc, "ys": ys, "logits": [ora.joiner(rows, np.repeat(dec[c : c + 1], rows.shape[0], 0)) for c in range(2)]}
+        except Exception as e:  # noqa: BLE001 -- the record says why the figure is missing
+            logits_ref = {"error": repr(e)}
     return {
         "value": round(n_utts * seconds / dt, 2),
         "unit": "x real-time (audio-sec/wall-sec)",
@@ -163,7 +176,24 @@ def cpu_baseline(weights, n_utts, seconds, beam=0, extra_firsts=()):
         "kind": "port",
         "sample": f"{n_utts} x {seconds:g} s utterances of the same synthetic workload as one batch through oracle/ "
                   f"(C + OpenMP restatement{', modified beam search beam=%d' % beam if beam else ''}; the reference's ONNXRuntime path cannot run here), {dt:.2f} s wall",
-    }, res, extra
+    }, res, extra, logits_ref
+
+
+def logit_diff(model, utts, ref):
+    """max |GPU - oracle| of encoder_out and of the joiner logits on every 4th frame under two decoder contexts, through the operator-level
+    entries (IOfflineProj: k2hip_fbank -> k2hip_pad_sequence -> k2hip_offline_encoder -> k2hip_decoder / k2hip_joiner); north_star: 1e-3."""
+    if not ref or "error" in ref:
+        return {"error": (ref or {}).get("error", "no reference")}
+    feats = [model.fbank(u) for u in utts]
+    enc = model.encoder_proj(model.pad_sequence(feats).reshape(len(feats), -1, model.feature_dim))
+    dec = model.decoder_proj(ref["ys"])
+    rows = enc[:, ::4, :].reshape(-1, enc.shape[-1])
+    worst = 0.0
+    for c in range(2):
+        got = model.joiner_proj(rows, np.repeat(dec[c : c + 1], rows.shape[0], 0))
+        worst = max(worst, float(np.abs(got - ref["logits"][c]).max()))
+    return {"max_abs_logit_diff": round(worst, 7), "max_abs_encoder_out_diff": round(float(np.abs(enc - ref["enc"]).max()), 7),
+            "logit_rows": int(2 * rows.shape[0]), "tolerance": 1e-3}
 
 
 def dominant_kernel(rows):
@@ -486,7 +516,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = args.cpu_utts or my_batches[0][1]
             whole = my_batches[0] == (0, n_cpu)
-            cb, ores, ores_extra = cpu_baseline(weights, n_cpu, secs, args.beam, [r * total for r in range(1, R)] if whole else [])
+            cb, ores, ores_extra, logits_ref = cpu_baseline(weights, n_cpu, secs, args.beam, [r * total for r in range(1, R)] if whole else [])
             out["cpu_baseline"] = cb
             # the oracle's results for the sample against what the timed legs returned for the same batch (outside the timed region);
             # and, untimed, the first batch of every other set the timed steps rotated through
@@ -499,6 +529,11 @@ def main():
                 # greedy: every set must be exact.  Beam search: set 0 must be; on other audio ~1 stream in 20 meets a frame whose candidates
                 # are closer than the two encoders agree (tests/parity.py localises those frame by frame; this line only counts them)
                 bad_match = per_set[0] < n_cpu or (args.beam == 0 and sum(per_set) < n_cpu * len(per_set))
+                if logits_ref is not None:   # north_star: "fp32 logits within 1e-3" -- measured here, next to the token match
+                    from k2transducerasr_amd.synth import synth_utterance as _su
+                    ld = logit_diff(model, [_su(u, secs) for u in range(n_cpu)], logits_ref)
+                    out["oracle_match"]["logits"] = ld
+                    bad_match = bad_match or ld.get("max_abs_logit_diff", 1.0) > 1e-3
             else:
                 out["oracle_match"] = {"streams": 0, "exact": 0, "what": "the CPU sample is not one of the timed batches"}
         if args.dump_results:
