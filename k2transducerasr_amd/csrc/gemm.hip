@@ -1286,6 +1286,7 @@ void launch_mode(const Ctx& ctx, const GemmArgs& a, int cfg) {
         case 3: launch_cfg<64, 64, 32, 32, 64, MODE>(ctx, a); break;    // 4 waves, BK 64
         case 4: launch_cfg<128, 64, 32, 32, 64, MODE>(ctx, a); break;   // 8 waves, BK 64
         case 5: case 7: case 8: case 11: launch_cfg<128, 64, 32, 32, 32, MODE>(ctx, a); break;   // 8 waves (and the fallback of the DMA-only configs)
+        case 12: launch_cfg<128, 32, 32, 32, 32, MODE>(ctx, a); break;  // 4 waves, 32 columns (the second embed convolution: N = 32, 600k rows)
         default: launch_cfg<64, 64, 32, 32, 32, MODE>(ctx, a); break;   // 4 waves
     }
 }
@@ -1302,6 +1303,10 @@ int g_forced_cfg = -1;  // debug_force_gemm_cfg (tuning hook); K2HIP_GEMM_CFG co
 int choose_cfg(const GemmArgs& a) {
     if (g_forced_cfg >= 0) return g_forced_cfg;
     if (tunables().gemm_cfg >= 0) return tunables().gemm_cfg;
+    // N <= 32 with many rows (encoder_embed.conv.4 as an implicit GEMM: 632 736 x 32 x 72 at the headline shape): a 64-column tile
+    // multiplies 32 columns of padding
+    if (a.N <= 32 && a.M >= 4096 && !tunables().gemm_v1) return 12;
+    // (the third embed convolution, 307 040 x 128 x 288, stays on 128x64: one 128-column tile that gathers each A row once is 301 against 284 us)
     if (a.N <= 64) return 2;    // 64x64 tiles, 4 waves
     if (a.M <= 64) return 3;    // a handful of rows (per-frame recurrent products, batched over layers): 64x64 tiles, K step 64
     // few output tiles (streaming chunks: 256..2048 rows): the launch is one latency-bound K sweep per
