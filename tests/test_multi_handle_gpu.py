@@ -132,11 +132,32 @@ def test_streaming_handles_on_host_threads_while_ticks_are_recorded_as_graphs(tm
         except Exception as e:  # noqa: BLE001 -- reported by the main thread
             errors.append((t, repr(e)))
 
+    # ... and one more thread opens and closes handles of its own meanwhile (device allocations, uploads, the decoder table's kernel,
+    # frees, stream destruction -- next to the others' recordings), decoding a round through each
+    stop = threading.Event()
+    lifecycle = {"models": 0}
+
+    def opener():
+        try:
+            while not stop.is_set():
+                r = OnlineRecognizer(p)
+                out, _ = decode(r, 0, 0, False)
+                assert out == want[(0, 0)]
+                r.model.close()
+                lifecycle["models"] += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(("opener", repr(e)))
+
     th = [threading.Thread(target=worker, args=(t,)) for t in range(NT)]
+    op = threading.Thread(target=opener)
+    op.start()
     for x in th:
         x.start()
     for x in th:
         x.join()
+    stop.set()
+    op.join()
     assert not errors, errors
     assert got == want
+    assert lifecycle["models"] >= 1
     assert sum(len(tok) - 2 for v in want.values() for tok, _ in v) > 0
