@@ -1428,6 +1428,10 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         int ring = -1;
         if (a.K % 128 == 0 && g32 <= 256) ring = 16;          // 32x32 tiles, KS 4, 4 stages + L2 prefetch wave
         else if (a.K % 128 == 0 && g6432 <= 256) ring = 17;   // 64x32 tiles, KS 4, 3 stages
+        // K a multiple of 64 but not of 128 (the 256-wide stacks' feed-forward outputs: K = 576 / 960, and K = 192): 32x64 tiles, KS 2 --
+        // round 4, tools/gemm_lab.py streaming-real (gpurun_out/r4c/lab_stream.txt): 1024 x 256 x 960 14.7 against 17.3 us (skinny),
+        // x 576 10.4 against 12.2, 2048 x 192 x 192 6.2 against 7.9 (64x64 tiles)
+        else if (a.K % 64 == 0 && a.K % 128 != 0 && (long long)cdiv(a.M, 32) * cdiv(a.N, 64) <= 256) ring = 12;
         else if (a.K % 64 == 0 && (long long)cdiv(a.M, 64) * cdiv(a.N, 64) >= 96) ring = 8;  // 64x64 tiles, KS 2, 3 stages
         if (ring >= 0) {
             launch_ring_idx(ctx, b, ring);
@@ -1436,6 +1440,15 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
             if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
             return;
         }
+    }
+    // a few hundred rows x <= 96 columns with a long enough K (the streaming value projections of the downsampled stacks: 256 x 96 x 512,
+    // 512 x 48 x 384): 32x32 ring tiles with the K step split four ways, 6.4 / 5.7 against 9.3 / 6.5 us (same lab run)
+    if (skinny16_ok && a.N <= 96 && a.M <= 512 && a.K % 128 == 0 && a.K >= 384 && !(tn.gemm_v1 & 5) && a.res_div == 1 && !a.act_after_res) {
+        launch_ring_idx(ctx, b, 15);
+        K2_HIP(hipGetLastError());
+        if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 64;
+        if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
+        return;
     }
     if (skinny16_ok) {
         if (a.N <= 48) hipLaunchKernelGGL(gemm_f32_mfma_skinny<3>, dim3(cdiv(a.M, 16), 1), dim3(256), 0, ctx.stream, b);
