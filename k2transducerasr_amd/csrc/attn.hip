@@ -311,23 +311,81 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // RING: streaming form -- the stream's values live in a ring of KL rows inside its slot of the state pool (RingRef, kernels.h), aw's
 // columns are in ring order, and the chunk's T new value rows (newrows [B*T, HV]) are written into the ring by this workgroup before
 // it reads them (every column slice of a stream writes the same bytes; nobody reads those rows before its own copy is stored).
-template <bool RING>
+// PROJ (with RING): the value projection itself runs here too -- newrows = xin[b rows] . win^T + bin, the chunk's <= 16 rows of one
+// stream against [HV, D] weights: (HV / 16) x (D / 4) 16x16x4 MFMAs split over the four waves (~1.5 - 4 us) instead of a launch of its
+// own for 256 .. 2048 rows x 48 / 96 columns (8 - 15 us, 32 of them per streaming tick).  Every column slice of a stream computes the same
+// rows (same code, same bits) and writes them into the ring as before.  The projection reads the WHOLE input rows while other slices of
+// the stream already store their output columns, so input and output are different buffers in this form (xin: projection + residual;
+// x: written).
+template <bool RING, bool PROJ = false>
 __global__ __launch_bounds__(256) void k_attn_av_out(const float* __restrict__ aw, const float* __restrict__ v,
                                                      const float* __restrict__ wout, const float* __restrict__ bias,
                                                      float* __restrict__ x, int B, int T, int KL, int Tp, int Tk, int H, int vh,
-                                                     int D, int tiles_per_z, RingRef ring, const float* __restrict__ newrows) {
+                                                     int D, int tiles_per_z, RingRef ring, const float* __restrict__ newrows,
+                                                     const float* __restrict__ xin = nullptr, const float* __restrict__ win = nullptr,
+                                                     const float* __restrict__ bin = nullptr) {
     extern __shared__ float avs[];  // [16][HV + 1]
     const int HV = H * vh, AS = HV + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, i0 = blockIdx.x * 16;
     const int n = lane & 15, kq = lane >> 4;
+    const float* xres = PROJ ? xin : x;   // the residual operand of phase C
     if (RING) {
         float* rb = ring.pool + (long long)ring.slots[b] * ring.slot_stride + ring.off;
         const int head = (int)(((long long)ring.chunks[b] * T) % KL), h4 = HV >> 2;
-        for (int e = tid; e < T * h4; e += 256) {
-            const int r = e / h4, c = (e % h4) * 4;
-            *reinterpret_cast<float4*>(rb + (long long)((head + r) % KL) * HV + c) =
-                *reinterpret_cast<const float4*>(newrows + ((long long)b * T + r) * HV + c);
+        if (PROJ) {
+            // the stream's T input rows -> LDS (behind the context tile, rows of D + 4 floats: conflict-free ds_read_b128 for 16 rows x 4
+            // k groups), one coalesced pass of the whole workgroup; rows past T are zero
+            float* xs = avs + 16 * AS + ((4 - ((16 * AS) & 3)) & 3);
+            const int XS = D + 4, d4 = D >> 2;
+            for (int e = tid; e < 16 * d4; e += 256) {
+                const int r = e / d4, c = (e % d4) * 4;
+                *reinterpret_cast<float4*>(xs + r * XS + c) =
+                    r < T ? *reinterpret_cast<const float4*>(xin + ((long long)b * T + r) * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            __syncthreads();
+            // A: lane (row n, k group kq) holds x[row][k0 + 4 kq ..] (from LDS); B: lane (column n, kq) holds win[column][k0 + 4 kq ..]
+            // (from L2, four 16-deep steps requested at a time); MFMA c of a step takes component c of both (every k once); C: column =
+            // lane & 15, rows 4 kq + e
+            const float* xr = xs + n * XS + 4 * kq;
+            for (int ct = wave; 16 * ct < HV; ct += 4) {
+                const int col = 16 * ct + n;
+                const float* wr = win + (long long)min(col, HV - 1) * D + 4 * kq;
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                for (int k0 = 0; k0 < D; k0 += 64) {   // D % 32 == 0: the last round may hold two steps
+                    float4 w4[4], a4[4];
+                    const int ns = min(4, (D - k0) >> 4);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) w4[q] = q < ns ? *reinterpret_cast<const float4*>(wr + k0 + 16 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) a4[q] = q < ns ? *reinterpret_cast<const float4*>(xr + k0 + 16 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].x, w4[q].x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q + 1].x, w4[q + 1].x, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].y, w4[q].y, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q + 1].y, w4[q + 1].y, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].z, w4[q].z, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q + 1].z, w4[q + 1].z, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].w, w4[q].w, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q + 1].w, w4[q + 1].w, acc1, 0, 0, 0);
+                    }
+                }
+                if (col < HV) {
+                    const float bc = bin[col];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int r = 4 * kq + e;
+                        if (r < T) rb[(long long)((head + r) % KL) * HV + col] = (acc0[e] + acc1[e]) + bc;
+                    }
+                }
+            }
+        } else {
+            for (int e = tid; e < T * h4; e += 256) {
+                const int r = e / h4, c = (e % h4) * 4;
+                *reinterpret_cast<float4*>(rb + (long long)((head + r) % KL) * HV + c) =
+                    *reinterpret_cast<const float4*>(newrows + ((long long)b * T + r) * HV + c);
+            }
         }
         __syncthreads();
         v = rb;  // this stream's ring: rows 0 .. KL-1
@@ -412,7 +470,7 @@ __global__ __launch_bounds__(256) void k_attn_av_out(const float* __restrict__ a
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int i = i0 + 4 * kq + e;
-            dst[e] = i < T ? x[((long long)b * T + i) * D + col] : 0.f;
+            dst[e] = i < T ? xres[((long long)b * T + i) * D + col] : 0.f;
         }
     };
     auto tile = [&](const float4* w, const float* xr, float bv, int ct) {
@@ -676,6 +734,28 @@ bool attn_av_out_ring(const Ctx& ctx, const float* aw, const RingRef& vals, cons
                        tiles_per_z, vals, newrows);
     K2_HIP(hipGetLastError());
     return true;
+}
+
+// the streaming self-attention module behind the attention weights, value projection included (k_attn_av_out<true, true>):
+// xout = xin + out_proj(aw . [ring ; xin . win^T + bin]); xin and xout must be different buffers
+void attn_proj_av_out_ring(const Ctx& ctx, const float* aw, const RingRef& vals, const float* xin, const float* win, const float* bin,
+                           const float* wout, const float* bias, float* xout, int B, int T, int KL, int Tp, int H, int vh, int D) {
+    const int HV = H * vh, Tk = (KL + 63) & ~63;
+    K2_REQUIRE(vh <= 16 && HV % 4 == 0 && HV <= 128 && D % 32 == 0 && Tp % 4 == 0 && Tp >= KL && T <= 16,
+               "attn_proj_av_out_ring: shape H=%d vh=%d D=%d T=%d KL=%d unsupported", H, vh, D, T, KL);
+    K2_REQUIRE(ctx.dry || xin != xout, "attn_proj_av_out_ring: input and output must be different buffers");
+    ctx.add_flops(0.0, 2.0 * B * (double)T * HV * (KL + D) + 2.0 * B * (double)T * HV * D, 0);
+    if (ctx.dry) return;
+    const int strips = B, ntile = D / 16;
+    int cs = std::max(1, std::min(4, 512 / std::max(1, strips)));
+    cs = std::min(cs, ntile);
+    const int tiles_per_z = cdiv(ntile, cs);
+    cs = cdiv(ntile, tiles_per_z);
+    const size_t lds = sizeof(float) * (16 * (HV + 1) + 4 + 16 * (D + 4));   // context tile | the stream's input rows
+    K2_REQUIRE(lds <= 64 * 1024, "attn_proj_av_out_ring: D=%d too wide", D);
+    hipLaunchKernelGGL((k_attn_av_out<true, true>), dim3(1, B, cs), dim3(256), lds, ctx.stream, aw, nullptr, wout, bias, xout, B, T, KL, Tp, Tk, H, vh,
+                       D, tiles_per_z, vals, nullptr, xin, win, bin);
+    K2_HIP(hipGetLastError());
 }
 
 void nonlin_av_out_ring(const Ctx& ctx, const float* aw, const RingRef& cache, const float* hid, int ldh, const float* wout, const float* bias,

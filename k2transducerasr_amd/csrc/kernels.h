@@ -16,6 +16,9 @@ struct Tunables {
     int gemm_v1 = 0;              // K2HIP_GEMM_V1: the earlier LDS-DMA kernels and tile rules (barrier at the top of every K step) instead of gemm_f32_mfma_pipe
     int attn_long = 0;            // K2HIP_ATTN_LONG: two-pass attention scores for every length
     int no_fused_av = 0;          // K2HIP_NO_FUSED_AV: attention apply + out_proj as two GEMMs
+    int fused_vproj_min_t = 4;    // K2HIP_FUSED_VPROJ_MIN_T: ... from this many chunk rows per stream on (a 16-row tile per stream wastes the deepest stack's 2 rows:
+                                  // 128 streams, device time per tick 3.61 ms from 4 rows on, 3.62 from 8, 3.68 from 2, 3.66 never)
+    int no_fused_vproj = 0;       // K2HIP_NO_FUSED_VPROJ: the streaming self-attention modules' value projection as a GEMM launch of its own
     int conformer_strip32 = 0;      // K2HIP_CONFORMER_STRIP32: the fused Conformer scores kernel on 32-row strips (one workgroup per CU), the earlier form
     int conformer_stamps = 0;       // K2HIP_CONFORMER_STAMPS: tuning -- the 16-row scores kernel reports its phases (stderr, synchronous)
     int conformer_scatter_v1 = 0;   // K2HIP_CONFORMER_SCATTER_V1: the 16-row scores kernel with round 3's loop (read-modify-write scatter)
@@ -183,6 +186,8 @@ bool attn_av_out(const Ctx& ctx, const float* aw, const float* v, const float* w
 // rows (newrows [B*T, H*vh]) are written into the ring by the kernel itself before it reads them.  T <= 16 (one row strip).
 bool attn_av_out_ring(const Ctx& ctx, const float* aw, const RingRef& vals, const float* newrows, const float* wout, const float* bias, float* x,
                       int B, int T, int KL, int Tp, int H, int vh, int D);
+void attn_proj_av_out_ring(const Ctx& ctx, const float* aw, const RingRef& vals, const float* xin, const float* win, const float* bin,
+                           const float* wout, const float* bias, float* xout, int B, int T, int KL, int Tp, int H, int vh, int D);
 
 // NonlinAttention.streaming_forward after its in_proj: hid [B*T, ldh] rows = s | x | y (Hc columns each); x * tanh(s) of the chunk's
 // rows goes into the cache ring, then ctx = (aw_head0 . ring) * y.  wout != nullptr: x[B*T, D] += out_proj(ctx) in the same launch

@@ -305,6 +305,9 @@ void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x,
     attn_stream_ring(c, qkp, ldcat, ring(lay_.key[l]), pp, d_plen, aw, B, Tc, L, KLp, H, cf.ds[si], left50);
 
     float* src = ar.take<float>((int64_t)M * D);
+    // the self-attention modules with their value projection inside (attn_proj_av_out_ring) read one buffer and write the other
+    const bool vproj_fused = !tunables().no_fused_vproj && Tc >= tunables().fused_vproj_min_t && D % 32 == 0 && vh <= 16 && HV % 4 == 0 && HV <= 128;
+    float* src_alt = vproj_fused ? ar.take<float>((int64_t)M * D) : nullptr;
     float* hid = ar.take<float>((int64_t)M * std::max({F * 5 / 4, 3 * Hc, 2 * D}));
     float* tmp2 = ar.take<float>((int64_t)M * std::max(D, Hc));
 
@@ -323,6 +326,11 @@ void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x,
         snprintf(b, sizeof b, "self_attn%d.in_proj.bias", k);
         snprintf(cc, sizeof cc, "self_attn%d.out_proj.weight", k);
         snprintf(d, sizeof d, "self_attn%d.out_proj.bias", k);
+        if (vproj_fused) {   // one launch: value projection of the chunk's rows, ring update, attention apply, out_proj, residual
+            attn_proj_av_out_ring(c, aw, ring(cache_off), src, w(a), w(b), w(cc), w(d), src_alt, B, Tc, KL, KLp, H, vh, D);
+            std::swap(src, src_alt);
+            return;
+        }
         linear(c, src, D, w(a), w(b), hid, HV, M, D, HV);
         // fused: chunk rows into the value ring, attention apply over the ring, out_proj, residual
         attn_av_out_ring(c, aw, ring(cache_off), hid, w(cc), w(d), src, B, Tc, KL, KLp, H, vh, D);

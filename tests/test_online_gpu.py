@@ -590,3 +590,50 @@ def test_failed_step_poisons_its_streams_until_reset(rec, ora):
         assert rec.get_results([a])[0] == [1]
         ora.step([o], [f[k * S : k * S + T]])
         assert a.tokens == o.tokens and a.timestamps == o.timestamps
+
+
+def test_value_projection_inside_the_attention_kernel_equals_the_gemm_form(stream_model_path, ora):
+    """The streaming self-attention modules run their value projection inside k_attn_av_out (one launch per module: projection of the
+    chunk's rows, ring update, attention apply, out_proj, residual; input and output in different buffers) where a stream's chunk has at
+    least K2HIP_FUSED_VPROJ_MIN_T rows, and as a GEMM launch of their own below that / with K2HIP_NO_FUSED_VPROJ.  Three recognizers -- every
+    stack fused, none, the default -- step the same streams: tokens, Hyp and every value cache must follow the oracle in all three."""
+    from k2transducerasr_amd import OnlineRecognizer, set_switch
+    from k2transducerasr_amd.synth import synth_utterance
+    recs = [OnlineRecognizer(stream_model_path) for _ in range(3)]
+    forms = [("K2HIP_FUSED_VPROJ_MIN_T", 1, 4), ("K2HIP_NO_FUSED_VPROJ", 1, 0), (None, 0, 0)]
+    N = 4
+    feats = [ora.fbank(synth_utterance(820 + u, 1.2 + 0.25 * u)) for u in range(N)]
+    hs = [[r.create_online_stream() for _ in range(N)] for r in recs]
+    so = [ora.create_stream() for _ in range(N)]
+    for u, f in enumerate(feats):
+        for h in hs:
+            h[u].add_features(f)
+    T, S = recs[0].chunk_length, recs[0].shift_length
+    pos = [0] * N
+    calls = 0
+    while True:
+        ready = [u for u in range(N) if pos[u] + T <= feats[u].shape[0]]
+        for r, h, (sw, on, off) in zip(recs, hs, forms):
+            if sw:
+                set_switch(sw, on)
+            try:
+                r.get_results(h)
+            finally:
+                if sw:
+                    set_switch(sw, off)
+        if not ready:
+            break
+        ora.step([so[u] for u in ready], [feats[u][pos[u] : pos[u] + T] for u in ready])
+        for u in ready:
+            pos[u] += S
+        for u in range(N):
+            for h in hs:
+                assert h[u].tokens == so[u].tokens and h[u].timestamps == so[u].timestamps and h[u].hyp == so[u].hyp, (calls, u)
+        calls += 1
+    for u in range(N):
+        for l in range(recs[0].num_layers):
+            for kind in ("val1", "val2"):
+                want = so[u].state(l, kind)
+                for h in hs:
+                    np.testing.assert_allclose(h[u].state(l, kind), want, atol=5e-4, rtol=0)
+    assert calls >= 3
