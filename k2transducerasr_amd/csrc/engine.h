@@ -206,11 +206,12 @@ class Engine {
     // eagerly and ~1.7 us from a graph (tools/probes/graph_chain_probe.hip): ~385 launches per streaming tick, ~400 per offline batch.
     // Anything that goes wrong while capturing marks the key and falls back to the eager form for good.
     struct GraphKey {
-        int kind = 0, B = 0, T = 0, extra = 0;
+        int kind = 0, B = 0, T = 0, extra = 0, gen = 0;   // gen: tunables_generation() (a test that flips a switch must not replay the old form)
         const void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *stream = nullptr;
         int64_t cap = 0, off = 0;   // the arena's capacity and the offset the chain starts at: every pointer it takes follows from them
         bool operator<(const GraphKey& o) const {
-            return std::tie(kind, B, T, extra, p0, p1, p2, stream, cap, off) < std::tie(o.kind, o.B, o.T, o.extra, o.p0, o.p1, o.p2, o.stream, o.cap, o.off);
+            return std::tie(kind, B, T, extra, gen, p0, p1, p2, stream, cap, off) <
+                   std::tie(o.kind, o.B, o.T, o.extra, o.gen, o.p0, o.p1, o.p2, o.stream, o.cap, o.off);
         }
     };
     struct GraphEntry {
@@ -324,6 +325,7 @@ void Engine::graphed(const Ctx& c, GraphKey key, F&& enqueue) {
         return;
     }
     key.stream = c.stream;
+    key.gen = tunables_generation();
     key.p2 = key.p2 ? key.p2 : c.arena->base();
     key.cap = c.arena->capacity();
     key.off = c.arena->mark();

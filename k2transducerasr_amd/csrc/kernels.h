@@ -53,6 +53,7 @@ struct Tunables {
 void tunables_init_from_env();            // idempotent; called by k2hip_model_create
 const Tunables& tunables();
 bool tunables_set(const char* env_name, int value);  // test hook (k2hip_debug_set_switch)
+int tunables_generation();                           // bumped when tunables_set changes a switch that shapes a chain of launches (part of the graph keys)
 
 struct GemmStats {
     double flops = 0;       // algorithmic, 2*M*N*K per launch

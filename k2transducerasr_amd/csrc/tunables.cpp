@@ -2,6 +2,7 @@
 // both paths) or tuning variants.  The K2HIP_* environment is read exactly ONCE, when the first model of the process is created;
 // after that the launch paths only read this struct (no libc lookups per launch, no behaviour change from a setenv mid-run).
 // k2hip_debug_set_switch is the test-only way to flip one afterwards.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -111,10 +112,18 @@ void tunables_init_from_env() {
 }
 
 const Tunables& tunables() { return g_t; }
+namespace {
+std::atomic<int> g_generation{0};
+}
+int tunables_generation() { return g_generation.load(std::memory_order_relaxed); }
 
 bool tunables_set(const char* env_name, int value) {
     for (const Entry& e : kEntries)
         if (!strcmp(e.env, env_name)) {
+            // a switch that changes what a chain of launches IS makes every recorded graph one of the old form (the switches that
+            // only say whether graphs are used do not)
+            if (g_t.*(e.field) != value && strncmp(env_name, "K2HIP_NO_GRAPHS", 15) && strncmp(env_name, "K2HIP_GRAPH", 11))
+                g_generation.fetch_add(1, std::memory_order_relaxed);
             g_t.*(e.field) = value;
             return true;
         }
