@@ -1306,7 +1306,8 @@ int choose_cfg(const GemmArgs& a) {
     // N <= 32 with many rows (encoder_embed.conv.4 as an implicit GEMM: 632 736 x 32 x 72 at the headline shape): a 64-column tile
     // multiplies 32 columns of padding
     if (a.N <= 32 && a.M >= 4096 && !tunables().gemm_v1) return 12;
-    // (the third embed convolution, 307 040 x 128 x 288, stays on 128x64: one 128-column tile that gathers each A row once is 301 against 284 us)
+    // (the third embed convolution, 307 040 x 128 x 288, stays on 128x64 with K steps of 32: one 128-column tile that gathers each A row once is
+    // 301 against 284 us, K steps of 64 382)
     if (a.N <= 64) return 2;    // 64x64 tiles, 4 waves
     if (a.M <= 64) return 3;    // a handful of rows (per-frame recurrent products, batched over layers): 64x64 tiles, K step 64
     // few output tiles (streaming chunks: 256..2048 rows): the launch is one latency-bound K sweep per

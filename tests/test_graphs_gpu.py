@@ -142,3 +142,36 @@ def test_foreign_legacy_stream_traffic_while_a_tick_is_recorded(tmp_path):
           f"graph replays {graph_launches(rec.model)} (undisturbed: {graph_launches(quiet.model)})")
     assert got == want
     assert stats["copies"] > 100
+
+
+def test_a_flipped_switch_never_replays_the_old_chain(tmp_path):
+    """Recorded graphs are keyed by the generation of the switches: one recognizer whose ticks alternate between the two forms of the
+    self-attention value projection (a different chain of launches, different arena use) must follow the oracle through every tick --
+    a replay of the chain recorded under the other form would not."""
+    from k2transducerasr_amd import OnlineRecognizer, set_switch
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    from oracle.online import OnlineOracle
+    p = str(tmp_path / "s.k2w")
+    write_synthetic_model(p, "zipformer2-streaming-tiny-test")
+    rec, ora = OnlineRecognizer(p), OnlineOracle(p)
+    feats = [ora.fbank(synth_utterance(170 + u, 3.4)) for u in range(3)]
+    hs = [rec.create_online_stream() for _ in feats]
+    os_ = [ora.create_stream() for _ in feats]
+    for h, f in zip(hs, feats):
+        h.add_features(f)
+    T, S = rec.chunk_length, rec.shift_length
+    nchunks = (feats[0].shape[0] - T) // S + 1
+    assert nchunks >= 9
+    try:
+        for k in range(nchunks):
+            set_switch("K2HIP_NO_FUSED_VPROJ", (k // 3) & 1)      # three ticks of one form (eager, recorded, replayed), then the other
+            rec.get_results(hs)
+            ora.step(os_, [f[k * S : k * S + T] for f in feats])
+            for h, o in zip(hs, os_):
+                assert h.tokens == o.tokens and h.timestamps == o.timestamps, k
+    finally:
+        set_switch("K2HIP_NO_FUSED_VPROJ", 0)
+    for h, o in zip(hs, os_):
+        for kind in ("val1", "val2", "conv1"):
+            np.testing.assert_allclose(h.state(0, kind), o.state(0, kind), atol=5e-4, rtol=0)
+    assert graph_launches(rec.model) >= 2
