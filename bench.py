@@ -18,7 +18,7 @@ the data path (RCCL / gloo carry the timing barrier, the max-over-ranks and the 
 of the token lists).  `python bench.py --gpus N` with no WORLD_SIZE in the environment starts the
 N ranks itself (before any GPU call); under torch.distributed.run it is one of the ranks.
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus 1 --steps 20 --warmup 3
     python bench.py --gpus 8 --total-utts 256 --beam 4                              # configs[2]
     python bench.py --gpus 8 --preset conformer-zh --total-utts 64 --batch 8 --seconds 30   # configs[4]
     python bench.py --gpus 2 --dist-backend gloo                                    # rehearsal on one GPU
@@ -63,8 +63,8 @@ def log(*a):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--preset", default=PRESET)
     ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GetResults batch")
     ap.add_argument("--seconds", type=float, default=UTT_SECONDS)
