@@ -637,3 +637,46 @@ def test_value_projection_inside_the_attention_kernel_equals_the_gemm_form(strea
                 for h in hs:
                     np.testing.assert_allclose(h[u].state(l, kind), want, atol=5e-4, rtol=0)
     assert calls >= 3
+
+
+def test_streaming_search_timeout_under_a_replayed_tick_backs_off(tmp_path):
+    """The tick of a large-vocabulary model runs the parted persistent search inside its replayed graph.  A timeout of the slabs' exchange
+    (forced in the hook's "as a real one" form; flipping the hook is a new generation of the switches, so that tick is enqueued eagerly)
+    is noticed when the tick's results come down: the search is repeated with one workgroup per stream from the launch's record, and
+    the engine backs off to the unparted form -- another chain of launches with its own graph key, eager, recorded and replayed in the
+    ticks that follow -- for the next 64 searches.  Tokens, timestamps and Hyp stay on the oracle's through all of it, and the retry
+    counter moves exactly once."""
+    import ctypes as C
+    from k2transducerasr_amd import OnlineRecognizer, load_library, set_switch
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    from oracle.online import OnlineOracle
+    p = str(tmp_path / "swide.k2w")
+    write_synthetic_model(p, "zipformer2-streaming-tiny-test", blank_bias=2.4, meta_overrides={"vocab_size": "3000"})
+    rec, ora = OnlineRecognizer(p), OnlineOracle(p)
+    L = load_library()
+    L.k2hip_debug_search_retries.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+
+    def retries():
+        n = C.c_int32(0)
+        assert L.k2hip_debug_search_retries(rec.model.handle, C.byref(n)) == 0
+        return n.value
+    feats = [ora.fbank(synth_utterance(930 + u, 3.6)) for u in range(3)]
+    hs = [rec.create_online_stream() for _ in feats]
+    os_ = [ora.create_stream() for _ in feats]
+    for h, f in zip(hs, feats):
+        h.add_features(f)
+    T, S = rec.chunk_length, rec.shift_length
+    nchunks = (feats[0].shape[0] - T) // S + 1
+    assert nchunks >= 9
+    n0 = retries()
+    try:
+        for k in range(nchunks):
+            set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 2 if k == 4 else 0)   # ticks 0 - 3: eager, recorded, replayed; tick 4 times out
+            rec.get_results(hs)
+            ora.step(os_, [f[k * S : k * S + T] for f in feats])
+            for h, o in zip(hs, os_):
+                assert h.tokens == o.tokens and h.timestamps == o.timestamps and h.hyp == o.hyp, k
+            assert retries() == n0 + (1 if k >= 4 else 0), k
+    finally:
+        set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 0)
+    assert sum(len(o.tokens) - 2 for o in os_) > 0
