@@ -198,11 +198,15 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, float (&v)[NV],
         if (row0 + ROWS::off(n) < g.M) cp[(long long)ROWS::off(n) * g.ldc] = v[n];
 }
 
-// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so
-// the natural x-fastest order makes every XCD read all of A.  Remap so that each XCD owns a contiguous
-// run of row-major tiles (a band of M): per XCD the L2 then holds A/8 + W instead of A + W/8.
-__device__ __forceinline__ void xcd_tile(int& mb, int& nb) {
-    const int gx = gridDim.x, nwg = gx * gridDim.y;
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so the natural x-fastest order
+// makes every XCD read all of A and all of W.  Remap so that each XCD owns a contiguous run of a linear tile order in which runs are
+// compact blocks: the N tiles are cut into PN panels (1, 2, 4 or 8), a panel is walked row-major, panels follow each other.  PN = 1 is a
+// band of M per XCD (its L2 holds A / 8 + W: the right cut while the rows outweigh the columns); with PN panels an XCD holds ~A PN / 8 +
+// W / PN, and the cut that minimises the fabric traffic PN x A + (8 / PN) x W -- PN M + (8 / PN) N in rows and columns, K cancels -- is
+// taken (round 4: the wide feed-forward GEMMs of the 6.25 / 12.5 Hz stacks used to pull W, the larger operand there, once per XCD).
+// Any (M tiles, N tiles, PN) is a bijection: run boundaries need not coincide with panel boundaries.
+__device__ __forceinline__ void xcd_tile(int& mb, int& nb, int M = 0, int N = 0) {
+    const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy;
     if (gridDim.z != 1 || nwg < 16) {  // batched launches keep the natural order
         mb = blockIdx.y;
         nb = blockIdx.x;
@@ -210,9 +214,30 @@ __device__ __forceinline__ void xcd_tile(int& mb, int& nb) {
     }
     const int orig = blockIdx.x + blockIdx.y * gx;
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    mb = t / gx;
-    nb = t - mb * gx;
+    int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    int pn = 1;
+    if (M > 0 && N > 0) {
+        long long best = (long long)M + 8ll * N;
+        const long long worth = best - best / 8;   // (a cut has to save an eighth of the band form's traffic to be taken)
+#pragma unroll
+        for (int c = 2; c <= 8; c *= 2) {
+            const long long cost = (long long)c * M + (8ll / c) * N;
+            if (cost < best && cost <= worth && gx >= c) {
+                best = cost;
+                pn = c;
+            }
+        }
+    }
+    // panel p holds columns [n0, n0 + w): widths gx / pn, the first gx % pn panels one wider
+    const int wq = gx / pn, wr = gx % pn;
+    int n0 = 0, w = wq + (wr > 0);
+    for (int p = 0; p < pn - 1 && t >= gy * w; p++) {
+        t -= gy * w;
+        n0 += w;
+        w = wq + (p + 1 < wr);
+    }
+    mb = t / w;
+    nb = n0 + (t - mb * w);
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int MODE>
@@ -245,7 +270,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma(Gemm
     const float* __restrict__ R = g.res ? g.res + z0 * g.sR0 + z1 * g.sR1 : nullptr;
 
     int mb_, nb_;
-    xcd_tile(mb_, nb_);
+    xcd_tile(mb_, nb_, g.xcd_panels == 1 ? 0 : g.M, g.N);
     const int m0 = mb_ * BM, n0 = nb_ * BN;
     const int Kp = (g.K + 3) & ~3;
 
@@ -453,7 +478,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_dma(
     float* __restrict__ C = g.C + z0 * g.sC0 + z1 * g.sC1;
     const float* __restrict__ R = g.res ? g.res + z0 * g.sR0 + z1 * g.sR1 : nullptr;
     int mb_, nb_;
-    xcd_tile(mb_, nb_);
+    xcd_tile(mb_, nb_, g.xcd_panels == 1 ? 0 : g.M, g.N);
     const int m0 = mb_ * BM, n0 = nb_ * BN;
     // tuning only (g.dbg != nullptr): lane 0 of every wave stamps s_memtime: entry | prologue issued | per K step: barrier passed
     // (first 40) | loop done | end; [62] = stamps, [60]/[63] = s_memrealtime
@@ -652,7 +677,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
     float* __restrict__ C = g.C;
     const float* __restrict__ R = g.res;
     int mb_, nb_;
-    xcd_tile(mb_, nb_);
+    xcd_tile(mb_, nb_, g.xcd_panels == 1 ? 0 : g.M, g.N);
     const int m0 = mb_ * BM, n0 = nb_ * BN;
     const int nk = g.K / BK;
 
@@ -907,7 +932,7 @@ __global__ __launch_bounds__(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)) void g
     float* __restrict__ C = g.C + z0 * g.sC0 + z1 * g.sC1;
     const float* __restrict__ R = g.res ? g.res + z0 * g.sR0 + z1 * g.sR1 : nullptr;
     int mb_, nb_;
-    xcd_tile(mb_, nb_);
+    xcd_tile(mb_, nb_, g.xcd_panels == 1 ? 0 : g.M, g.N);
     const int m0 = mb_ * BM, n0 = nb_ * BN;
     const int nk = g.K / (BK * KS);
 
@@ -1391,6 +1416,7 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     int cfg = choose_cfg(a);
     GemmArgs b = a;
     b.ablate = g_ablate;
+    b.xcd_panels = tunables().xcd_panels;
     if (ctx.instrument && ctx.gemm_log)
         ctx.gemm_log->push_back({a.M, a.N, a.K, a.nb0 * a.nb1, a.act, a.res != nullptr, a.cv_Fout > 0 ? 1 : (a.w_kn ? 2 : 0), 0.f});
     // (a) N <= 96: few columns; (b) small problems (streaming chunks, beam search: a 128x64 grid would leave most CUs idle and

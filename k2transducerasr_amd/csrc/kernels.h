@@ -15,6 +15,7 @@ struct Tunables {
     int no_glu_epilogue = 0;      // K2HIP_NO_GLU_EPILOGUE: conv modules' GLU in the depthwise kernel (round 1 form) instead of the in_proj GEMM's epilogue
     int gemm_v1 = 0;              // K2HIP_GEMM_V1: the earlier LDS-DMA kernels and tile rules (barrier at the top of every K step) instead of gemm_f32_mfma_pipe
     int attn_long = 0;            // K2HIP_ATTN_LONG: two-pass attention scores for every length
+    int xcd_panels = 0;           // K2HIP_XCD_PANELS: 1 = every GEMM's tiles as bands of M per XCD (rounds 1 - 3); 0 = panels of N where they cut the fabric traffic
     int no_fused_av = 0;          // K2HIP_NO_FUSED_AV: attention apply + out_proj as two GEMMs
     int fused_vproj_min_t = 4;    // K2HIP_FUSED_VPROJ_MIN_T: ... from this many chunk rows per stream on (a 16-row tile per stream wastes the deepest stack's 2 rows:
                                   // 128 streams, device time per tick 3.61 ms from 4 rows on, 3.62 from 8, 3.68 from 2, 3.66 never)
@@ -116,6 +117,7 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0;
     int lda = 0, ldw = 0, ldc = 0, ldr = 0;
     int act = ACT_NONE;
+    int xcd_panels = 0;  // tile order: 0 = N panels per XCD chosen by PN M + (8 / PN) N (gemm.hip xcd_tile); 1 = a band of M per XCD (K2HIP_XCD_PANELS)
     int act_cols = 0;  // > 0: the activation applies to output columns < act_cols only (two Linears of one input fused in one launch)
     int w_kn = 0;
     // batching over blockIdx.z = z0 + nb0 * z1

@@ -67,6 +67,7 @@ const Entry kEntries[] = {
     {"K2HIP_ATTN_LONG", &Tunables::attn_long, true},
     {"K2HIP_NO_FUSED_AV", &Tunables::no_fused_av, true},
     {"K2HIP_NO_FUSED_VPROJ", &Tunables::no_fused_vproj, true},
+    {"K2HIP_XCD_PANELS", &Tunables::xcd_panels, false},
     {"K2HIP_FUSED_VPROJ_MIN_T", &Tunables::fused_vproj_min_t, false},
     {"K2HIP_CONFORMER_GEMM_SCORES", &Tunables::conformer_gemm_scores, true},
     {"K2HIP_CONFORMER_STRIP32", &Tunables::conformer_strip32, true},
