@@ -506,8 +506,8 @@ def main():
                 "all_matrix_flops_per_batch": it["total_flops"],
                 "algorithmic_bytes": algorithmic_bytes(gemm_rows),
                 "algorithmic_bytes_note": "mean per launch over the same launches as `traffic`: A and W read once, C written once, a residual read once (f32); "
-                                          "what `traffic` holds beyond it is W once per XCD (8 private L2s, each owning a band of M and all of W: 7 x ~3 MB), "
-                                          "served by the memory-side cache (DESIGN 4)",
+                                          "what `traffic` holds beyond it is the operands crossing the fabric once per XCD that needs them (8 private L2s: "
+                                          "PN x A + (8 / PN) x W with the tile order's PN panels of N per launch), served by the memory-side cache (DESIGN 4)",
                 "dominant": dominant_kernel(gemm_rows),
             }
             out["stages_ms_one_synchronous_batch"] = {k: round(stages[k], 3) for k in ("total_ms", "fbank_ms", "pad_ms", "encoder_ms", "greedy_ms", "d2h_ms")}
