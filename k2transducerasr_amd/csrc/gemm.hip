@@ -216,7 +216,9 @@ __device__ __forceinline__ void xcd_tile(int& mb, int& nb, int M = 0, int N = 0)
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     int pn = 1;
-    if (M > 0 && N > 0) {
+    // (launches of more than a round of the chip only: on the streaming tick's GEMMs of 100 - 250 workgroups the panels cost 0.06 ms per
+    // tick -- there the next launch reads what this one's XCD just wrote, band by band)
+    if (M > 0 && N > 0 && nwg >= 320) {
         long long best = (long long)M + 8ll * N;
         const long long worth = best - best / 8;   // (a cut has to save an eighth of the band form's traffic to be taken)
 #pragma unroll
