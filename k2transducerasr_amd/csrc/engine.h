@@ -385,7 +385,8 @@ void Engine::graphed(const Ctx& c, GraphKey key, F&& enqueue) {
         (void)hipGetLastError();
         if (!ok) {   // nothing was enqueued (a recording records, it does not run): the eager form, from the same arena position
             if (begun || !rec_stream_) {
-                if (rec_stream_) (void)hipStreamDestroy(rec_stream_);
+                // the spoiled stream is abandoned, not destroyed: whoever spoiled the recording is still issuing legacy-stream
+                // operations, and those walk the runtime's stream list (a destroy next to that walk crashed inside libamdhip64)
                 rec_stream_ = nullptr;
                 (void)hipGetLastError();
             }
