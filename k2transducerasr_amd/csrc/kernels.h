@@ -41,6 +41,10 @@ struct Tunables {
     int greedy_stamps = 0;        // K2HIP_GREEDY_STAMPS: tuning -- the persistent search reports where a round's time goes (stderr, synchronous)
     int no_graphs = 0;            // K2HIP_NO_GRAPHS: every launch enqueued eagerly (no hipGraph replay of the streaming tick)
     int graph_capture_mode = 0;   // K2HIP_GRAPH_CAPTURE_MODE: how a tick is recorded -- 0 thread-local, 1 relaxed, 2 global (hipStreamCaptureMode*)
+    int graph_streaming = 0;      // K2HIP_GRAPH_STREAMING: 1 = the streaming tick's launches replay from a hipGraph (Engine::graphed).  OFF by default
+                                  // since the end of round 4: with ~335 launches per tick and the persistent search, replay and eager enqueue
+                                  // measure the same (4.13 - 4.20 against 4.10 - 4.16 ms per tick, four presets), while a recording in progress
+                                  // makes the runtime refuse every legacy-stream operation of every host thread (INTEGRATION.md "Threading")
     int graph_offline = 0;        // K2HIP_GRAPH_OFFLINE: 1 = the offline batch entries replay their encoder pass from a hipGraph too (measured:
                                   // 13.87 against 13.76 ms per headline batch -- launches of 20 - 80 us hide their own enqueue cost; off by default)
     int test_greedy_timeout = 0;  // K2HIP_TEST_GREEDY_TIMEOUT: test hook -- every parts > 1 search reports an exchange timeout, so the one-part retry runs

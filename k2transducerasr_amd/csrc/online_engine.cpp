@@ -540,7 +540,7 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
         if (ev_ok) K2_HIP(hipEventRecord(ev_[4], c.stream));
         };
         // (the persistent search notes its launch for the one-part retry in the arena walk too; its phase report is synchronous)
-        if (!tunables().greedy_stamps) graphed(c, gk, chain);
+        if (!tunables().greedy_stamps && tunables().graph_streaming) graphed(c, gk, chain);
         else chain(c);
         if (!c.dry && graph_launches_ != launches_before) {   // a replayed tick has no stamps inside: the whole step counts as encoder time
             K2_HIP(hipEventRecord(ev_[3], c.stream));

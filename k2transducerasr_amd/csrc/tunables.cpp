@@ -90,6 +90,7 @@ const Entry kEntries[] = {
     {"K2HIP_NO_GRAPHS", &Tunables::no_graphs, true},
     {"K2HIP_GRAPH_CAPTURE_MODE", &Tunables::graph_capture_mode, false},
     {"K2HIP_GRAPH_OFFLINE", &Tunables::graph_offline, false},
+    {"K2HIP_GRAPH_STREAMING", &Tunables::graph_streaming, false},
     {"K2HIP_TEST_GREEDY_TIMEOUT", &Tunables::test_greedy_timeout, true},
     {"K2HIP_SEARCH_ROUNDS", &Tunables::search_rounds, false},
     {"K2HIP_PIPE_MODE", &Tunables::pipe_mode, false},

@@ -6,6 +6,8 @@ tokens equal those of an undisturbed recognizer; exit code 0 iff they do.  usage
 import ctypes as C
 import os
 import sys
+
+os.environ["K2HIP_GRAPH_STREAMING"] = "1"   # (read when the first model of the process is created) the ticks here replay from graphs
 import threading
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -4,6 +4,8 @@ usage: streaming_threads_child.py <model path to write>"""
 import os
 import sys
 
+os.environ["K2HIP_GRAPH_STREAMING"] = "1"   # (read when the first model of the process is created) the ticks here replay from graphs
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 

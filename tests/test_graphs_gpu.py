@@ -11,6 +11,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def streaming_graphs_on():
+    """the streaming tick's graph replay is opt-in (K2HIP_GRAPH_STREAMING; off by default since it stopped paying): on for this file"""
+    from k2transducerasr_amd import set_switch
+    set_switch("K2HIP_GRAPH_STREAMING", 1)
+    yield
+    set_switch("K2HIP_GRAPH_STREAMING", 0)
+
+
 def graph_launches(model):
     from k2transducerasr_amd import load_library
     L = load_library()

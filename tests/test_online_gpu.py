@@ -354,7 +354,7 @@ def test_streaming_128_slots_16_streams_against_oracle_zh(tmp_path_factory):
 def test_streaming_search_forms_agree(stream_model_path, ora, tmp_path, vocab):
     """The tick's search over the ready streams runs as rounds of joiner GEMMs (greedy_rounds; K2HIP_SEARCH_ROUNDS=1, the default for
     a vocabulary the f16 screen does not cover) or as one persistent kernel (=0; the default where its rounds go through the screen:
-    the 3000-token case, whose ticks then replay a captured graph holding that kernel).  Both carry each stream's Hyp context across
+    the 3000-token case).  Both carry each stream's Hyp context across
     chunks; tokens, timestamps and Hyp must be the oracle's after every call from either form, and from the default's own choice."""
     from k2transducerasr_amd import OnlineRecognizer, set_switch
     from k2transducerasr_amd.synth import synth_utterance
@@ -669,6 +669,7 @@ def test_streaming_search_timeout_under_a_replayed_tick_backs_off(tmp_path):
     nchunks = (feats[0].shape[0] - T) // S + 1
     assert nchunks >= 9
     n0 = retries()
+    set_switch("K2HIP_GRAPH_STREAMING", 1)
     try:
         for k in range(nchunks):
             set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 2 if k == 4 else 0)   # ticks 0 - 3: eager, recorded, replayed; tick 4 times out
@@ -679,4 +680,5 @@ def test_streaming_search_timeout_under_a_replayed_tick_backs_off(tmp_path):
             assert retries() == n0 + (1 if k >= 4 else 0), k
     finally:
         set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 0)
+        set_switch("K2HIP_GRAPH_STREAMING", 0)
     assert sum(len(o.tokens) - 2 for o in os_) > 0
