@@ -78,7 +78,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip the bounded configs[2] / [3] / [4] legs that follow the headline run on one GPU")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal of the N > 1 path on one GPU)")
     ap.add_argument("--beam", type=int, default=0, help="0 = greedy_search (headline metric); K = modified_beam_search with beam K (BASELINE configs[2])")
-    ap.add_argument("--depth", type=int, default=0, help="batches in flight (0: 2; 3 is allowed with --beam, and with K2HIP_PIPE_MODE=2 for the greedy search)")
+    ap.add_argument("--depth", type=int, default=0, help="batches in flight (0: 2; 3 is allowed with --beam)")
     ap.add_argument("--rotate", type=int, default=3,
                     help="distinct sets of utterances the timed steps cycle through (step s decodes set s %% R: other audio, other emission "
                          "pattern and search length from step to step; every set is checked once against the oracle sample)")

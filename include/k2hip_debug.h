@@ -37,13 +37,6 @@ int32_t k2hip_debug_decoder_table_check(k2hip_model_t* model, int32_t n_samples,
  * (oracle/k2_oracle_beam.c) to find the first frame at which the two searches part. */
 int32_t k2hip_debug_beam_trace(k2hip_model_t* model, int32_t* trace, int64_t cap_words, int32_t* B, int32_t* Tprime, int32_t* beam);
 
-/* ---- launch graphs ----------------------------------------------------------------------------- */
-/* An encoder pass is a chain of ~400 dependent launches whose arguments follow from (model, batch shape, arena): the engine enqueues
- * it eagerly the first time it sees a shape, captures it as a hipGraph the second time and replays the instance from then on (offline
- * batches of one shape; streaming ticks with one number of ready streams).  n = replays since the model was created; the switch
- * K2HIP_NO_GRAPHS keeps every launch eager (tests/test_graphs_gpu.py holds the two forms to each other). */
-int32_t k2hip_debug_graph_launches(k2hip_model_t* model, int32_t* n);
-
 /* ---- streaming --------------------------------------------------------------------------------- */
 /* mark a stream as if a chunk step over it had failed on the device (k2hip_online_step's poisoning rule, k2hip.h) */
 int32_t k2hip_debug_poison_stream(k2hip_online_stream_t* s);

@@ -901,15 +901,6 @@ int32_t k2hip_debug_search_retries(k2hip_model_t* model, int32_t* n) {
         *n = model->engine.search_retries();
     });
 }
-// hipGraph replays of encoder passes since the model was created (Engine::graphed; include/k2hip_debug.h)
-int32_t k2hip_debug_graph_launches(k2hip_model_t* model, int32_t* n) {
-    return guard([&] {
-        NEED(model); NEED(n);
-        EngineLock lk(model->engine);
-        *n = model->engine.graph_launches();
-    });
-}
-// K2HIP_BEAM_TRACE: the per-frame selection of the last synchronous modified beam search (include/k2hip_debug.h)
 int32_t k2hip_debug_beam_trace(k2hip_model_t* model, int32_t* trace, int64_t cap_words, int32_t* B, int32_t* Tprime, int32_t* beam) {
     return guard([&] {
         NEED(model); NEED(B); NEED(Tprime); NEED(beam);

@@ -55,10 +55,11 @@ inline int device_cu_count() {
     return v;
 }
 
-// Blocking copy / fill on the device's utility stream (non-blocking flag), never on the legacy (null) stream: while ANY stream of the
-// process is in stream capture -- another handle's tick being recorded as a hipGraph on another host thread -- the runtime fails a
-// legacy-stream operation with hipErrorStreamCaptureImplicit AND invalidates that capture.  Same arguments as hipMemcpy / hipMemset;
-// like those on a non-blocking engine stream, they order with nothing but the host.  (tunables.cpp)
+// Blocking copy / fill on the current device's utility stream (non-blocking flag; one stream and one mutex per device), never on the
+// legacy (null) stream: a legacy-stream operation synchronises with every blocking stream of the device -- the HOST APPLICATION's
+// streams included -- and is refused outright while any stream of the process is being captured into a hipGraph by someone else.
+// Same arguments as hipMemcpy / hipMemset; like those on a non-blocking engine stream, they order with nothing but the host.
+// (tunables.cpp)
 hipError_t copy_blocking(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 hipError_t fill_blocking(void* dst, int value, size_t bytes);
 

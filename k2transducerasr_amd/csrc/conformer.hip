@@ -152,277 +152,24 @@ __global__ void k_dwconv_valid_dswish(const float* __restrict__ cat, const float
 
 
 // ---------------------------------------------------------------------------------------
-// RelPositionMultiheadAttention scores + softmax, fused (offline Conformer): for one (stream, head) and a strip of 32 query rows
+// RelPositionMultiheadAttention scores + softmax, fused (offline Conformer): for one (stream, head) and a strip of 16 query rows
 //   s[i,j] = (q_i + u).k_j + (q_i + v).p[T-1-i+j]          w[i,:] = softmax_j s[i,:]
 // without the two [T, T] / [T, 2T-1] score tensors of the GEMM form (145 + 290 MB per layer at T = 753, written and re-read).
-// Eight waves share the 32 x T strip in LDS; a wave takes key tiles of 32: the content term is 32x32x2 f32 MFMAs as in the Zipformer
-// kernel (K = dk); the positional term of the tile only involves the 63 table rows n = base .. base + 62 (base = T-1-i0-31+j0), so
-// it is two more MFMA tiles G[32, 64] = (q+v) . p[base ..]^T whose elements are ADDED into the strip skewed -- G[r, col] belongs to key
-// j0 + col - 31 + r -- icefall's rel-shift as an LDS scatter (each strip element receives exactly one of them, so the sum is exact and
-// needs no staging tile: the strip is the only LDS, which is what lets eight waves share it).  Then the row softmax and one
-// coalesced write.
-// NG = dk / 8.
+// Four waves share the 16 x T strip in LDS (48 KB at T = 750, so THREE workgroups share a CU and one strip's softmax and write-out
+// run under the others' MFMAs); a wave takes runs of 16-key tiles: the content term is 16x16x4 f32 MFMAs (K = dk); the positional
+// term of a tile only involves the table rows n = base .. base + 30, two 16-wide table tiles G = (q+v) . p[base ..]^T whose elements
+// land in the strip skewed -- G[r, col] belongs to key j0 + col - 15 + r -- icefall's rel-shift through LDS (each strip element
+// receives exactly one of them, so the sum is exact and needs no staging tile: the strip is the only LDS).  Then the row softmax and
+// one coalesced write.  NG = dk / 16.
+// (Rounds 1 - 4 kept two earlier forms beside this one -- 32-row strips with 32x32x2 tiles, one workgroup per CU: 257 us per layer at
+// T = 750; 16-row strips with a read-modify-write scatter: 199 us; this one 185 us -- DESIGN.md "Where the Conformer attention
+// kernel's time goes".  Round 5 removed them: one path per operation in the library.)
 // ---------------------------------------------------------------------------------------
-typedef float cf32x16 __attribute__((ext_vector_type(16)));
-constexpr int CR = 32;       // rows per strip
-
-template <int NG>
-__global__ __launch_bounds__(512) void k_conformer_scores_softmax(const float* __restrict__ qu, const float* __restrict__ qv,
-                                                                  const float* __restrict__ kmat, int ldk, const float* __restrict__ pp,
-                                                                  float* __restrict__ aw, int B, int H, int T, int Tp, int D,
-                                                                  int lds_stride) {
-    constexpr int DK = 8 * NG;
-    extern __shared__ __attribute__((aligned(16))) float csm[];
-    float* S = csm;                                   // [CR][lds_stride]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int i0 = blockIdx.x * CR, b = blockIdx.y, h = blockIdx.z, NP = 2 * T - 1;
-    const long long rowbase = (long long)b * T;
-    // A operands: this lane's query row (strip row li), k chunks 8g + 4lh .. +3
-    float4 fu[NG], fv[NG];
-    {
-        const int row = i0 + li;
-#pragma unroll
-        for (int g = 0; g < NG; g++) {
-            fu[g] = fv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < T) {
-                fu[g] = *reinterpret_cast<const float4*>(qu + (rowbase + row) * D + h * DK + 8 * g + 4 * lh);
-                fv[g] = *reinterpret_cast<const float4*>(qv + (rowbase + row) * D + h * DK + 8 * g + 4 * lh);
-            }
-        }
-    }
-    const int njt = (T + 31) / 32;
-    // A wave takes a RUN of consecutive key tiles.  Tile jt needs the positional products against table rows base + li (the "low" run)
-    // and base + 32 + li (the "high" run), base = T - 1 - i0 - 31 + 32 jt: the high run of tile jt IS the low run of tile jt + 1, so
-    // along a run every positional tile is computed once and used twice -- 2 tiles' worth of MFMAs per key tile instead of 3 (plus one
-    // per run).  The next tile's operands are requested as soon as this tile's MFMAs are issued: they arrive under the scatter below.
-    float4 fk[NG], ph[NG];
-    auto load_k = [&](int jt, float4* k_) {
-        const int jr = min(jt * 32 + li, T - 1);
-#pragma unroll
-        for (int g = 0; g < NG; g++) k_[g] = *reinterpret_cast<const float4*>(kmat + (rowbase + jr) * ldk + h * DK + 8 * g + 4 * lh);
-    };
-    auto load_p = [&](int nrow, float4* p_) {   // table row nrow (out-of-table rows only meet masked entries)
-        const int nr = min(max(nrow, 0), NP - 1);
-#pragma unroll
-        for (int g = 0; g < NG; g++) p_[g] = *reinterpret_cast<const float4*>(pp + (long long)nr * D + h * DK + 8 * g + 4 * lh);
-    };
-    const int tpw = (njt + 7) >> 3, jt_beg = wave * tpw, jt_end = min(njt, jt_beg + tpw);
-    if (jt_beg < jt_end) {
-        cf32x16 acc, glo, ghi;
-        const int base0 = T - 1 - i0 - 31 + jt_beg * 32;
-        load_p(base0 + li, ph);
-        load_k(jt_beg, fk);
-#pragma unroll
-        for (int r = 0; r < 16; r++) glo[r] = 0.f;
-#pragma unroll
-        for (int g = 0; g < NG; g++) {   // the run's first low positional tile
-            glo = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].x, ph[g].x, glo, 0, 0, 0);
-            glo = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].y, ph[g].y, glo, 0, 0, 0);
-            glo = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].z, ph[g].z, glo, 0, 0, 0);
-            glo = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].w, ph[g].w, glo, 0, 0, 0);
-        }
-        load_p(base0 + 32 + li, ph);
-        for (int jt = jt_beg; jt < jt_end; jt++) {
-            const int j0 = jt * 32, j = j0 + li;
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = ghi[r] = 0.f;
-#pragma unroll
-            for (int g = 0; g < NG; g++) {   // content term, and the positional term against the high run of table rows
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[g].x, fk[g].x, acc, 0, 0, 0);
-                ghi = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].x, ph[g].x, ghi, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[g].y, fk[g].y, acc, 0, 0, 0);
-                ghi = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].y, ph[g].y, ghi, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[g].z, fk[g].z, acc, 0, 0, 0);
-                ghi = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].z, ph[g].z, ghi, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[g].w, fk[g].w, acc, 0, 0, 0);
-                ghi = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[g].w, ph[g].w, ghi, 0, 0, 0);
-            }
-            if (jt + 1 < jt_end) {   // (wave-uniform) the next tile's keys and high run, into the registers just consumed
-                load_k(jt + 1, fk);
-                load_p(base0 + (jt + 1 - jt_beg) * 32 + 32 + li, ph);
-            }
-            // C layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  The tile's 32 strip columns belong to
-            // this wave alone; LDS operations of one wave complete in order.
-            if (j < T) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) S[((r & 3) + 8 * (r >> 2) + 4 * lh) * lds_stride + j] = acc[r];
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int c0 = li - 31 + rl, c1 = li + 1 + rl;   // strip column (within the tile) fed by G[rl][li] / G[rl][32 + li]
-                if (c0 >= 0 && j0 + c0 < T) S[rl * lds_stride + j0 + c0] += glo[r];
-                if (c1 < 32 && j0 + c1 < T) S[rl * lds_stride + j0 + c1] += ghi[r];
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 16; r++) glo[r] = ghi[r];   // this tile's high run is the next tile's low run
-        }
-    }
-    __syncthreads();
-    // row softmax: wave w owns rows 4w .. 4w+3; a row's T scores are read ONCE into registers (T <= 64 * 20)
-    float* out = aw + (((long long)b * H + h) * T) * Tp;
-    for (int rr = 0; rr < 4; rr++) {
-        const int rl = wave * 4 + rr, i = i0 + rl;
-        if (i >= T) break;
-        const float* srow = S + rl * lds_stride;
-        float v[20];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < 20; u++) {
-            const int jj = lane + 64 * u;
-            v[u] = jj < T ? srow[jj] : -INFINITY;
-            mx = fmaxf(mx, v[u]);
-        }
-        mx = wave_max_dpp(mx);
-        float sum = 0.f;
-#pragma unroll
-        for (int u = 0; u < 20; u++) {
-            v[u] = lane + 64 * u < T ? __expf(v[u] - mx) : 0.f;
-            sum += v[u];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        const float inv = 1.0f / sum;
-        float* orow = out + (long long)i * Tp;
-#pragma unroll
-        for (int u = 0; u < 20; u++) {
-            const int jj = lane + 64 * u;
-            if (jj < Tp) orow[jj] = v[u] * inv;   // pad columns [T, Tp) get 0
-        }
-    }
-}
-
-// The same computation on 16-row strips and 16 x 16 x 4 tiles: 4 waves, a strip of 16 x T scores (48 KB at T = 750), so THREE
-// workgroups share a CU and one strip's softmax and write-out run under the others' MFMAs (the 32-row form holds 97 KB: one workgroup
-// per CU, its matrix pipe ~55 % busy in the tile loop and idle in the softmax).  Same MFMA work per row; the positional band of a
-// 16-key tile is two 16-wide table tiles, G[r, col] belongs to key j0 + col - 15 + r.  NG = dk / 16.
+constexpr int CR = 32;       // (bound of the in-LDS form: 32 x (Tp + 4) floats must fit, conformer_scores_softmax below)
 typedef float cf32x4 __attribute__((ext_vector_type(4)));
-template <int NG, int NW>   // NW waves per strip
-__global__ __launch_bounds__(64 * NW) void k_conformer_scores_softmax16(const float* __restrict__ qu, const float* __restrict__ qv,
-                                                                    const float* __restrict__ kmat, int ldk, const float* __restrict__ pp,
-                                                                    float* __restrict__ aw, int B, int H, int T, int Tp, int D,
-                                                                    int lds_stride) {
-    constexpr int DK = 16 * NG;
-    extern __shared__ __attribute__((aligned(16))) float csm[];
-    float* S = csm;                                   // [16][lds_stride]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kq = lane >> 4;
-    const int i0 = blockIdx.x * 16, b = blockIdx.y, h = blockIdx.z, NP = 2 * T - 1;
-    const long long rowbase = (long long)b * T;
-    // A operands: this lane's query row (strip row li), k chunks 16g + 4kq .. +3 (MFMA (g, c) takes component c of both operands: every
-    // k of the head's dk is multiplied exactly once)
-    float4 fu[NG], fv[NG];
-    {
-        const int row = i0 + li;
-#pragma unroll
-        for (int g = 0; g < NG; g++) {
-            fu[g] = fv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < T) {
-                fu[g] = *reinterpret_cast<const float4*>(qu + (rowbase + row) * D + h * DK + 16 * g + 4 * kq);
-                fv[g] = *reinterpret_cast<const float4*>(qv + (rowbase + row) * D + h * DK + 16 * g + 4 * kq);
-            }
-        }
-    }
-    const int njt = (T + 15) / 16;
-    float4 fk[NG], ph[NG];
-    auto load_k = [&](int jt, float4* k_) {
-        const int jr = min(jt * 16 + li, T - 1);
-#pragma unroll
-        for (int g = 0; g < NG; g++) k_[g] = *reinterpret_cast<const float4*>(kmat + (rowbase + jr) * ldk + h * DK + 16 * g + 4 * kq);
-    };
-    auto load_p = [&](int nrow, float4* p_) {   // table row nrow (out-of-table rows only meet masked entries)
-        const int nr = min(max(nrow, 0), NP - 1);
-#pragma unroll
-        for (int g = 0; g < NG; g++) p_[g] = *reinterpret_cast<const float4*>(pp + (long long)nr * D + h * DK + 16 * g + 4 * kq);
-    };
-    auto mma = [](const float4& a, const float4& bq, cf32x4 acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc, 0, 0, 0);
-        return acc;
-    };
-    // a wave takes a RUN of consecutive key tiles: the high positional tile of key tile jt is the low one of jt + 1
-    const int tpw = (njt + NW - 1) / NW, jt_beg = wave * tpw, jt_end = min(njt, jt_beg + tpw);
-    if (jt_beg < jt_end) {
-        cf32x4 acc, glo = {0.f, 0.f, 0.f, 0.f}, ghi;
-        const int base0 = T - 1 - i0 - 15 + jt_beg * 16;
-        load_p(base0 + li, ph);
-        load_k(jt_beg, fk);
-#pragma unroll
-        for (int g = 0; g < NG; g++) glo = mma(fv[g], ph[g], glo);   // the run's first low positional tile
-        load_p(base0 + 16 + li, ph);
-        for (int jt = jt_beg; jt < jt_end; jt++) {
-            const int j0 = jt * 16, j = j0 + li;
-            acc = cf32x4{0.f, 0.f, 0.f, 0.f};
-            ghi = cf32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int g = 0; g < NG; g++) {   // content term, and the positional term against the high run of table rows
-                acc = mma(fu[g], fk[g], acc);
-                ghi = mma(fv[g], ph[g], ghi);
-            }
-            if (jt + 1 < jt_end) {   // (wave-uniform) the next tile's keys and high run, into the registers just consumed
-                load_k(jt + 1, fk);
-                load_p(base0 + (jt + 1 - jt_beg) * 16 + 16 + li, ph);
-            }
-            // C layout of 16x16: col = lane & 15, row = 4 * (lane >> 4) + e.  The tile's 16 strip columns belong to this wave alone; LDS
-            // operations of one wave complete in order.
-            if (j < T) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) S[(4 * kq + e) * lds_stride + j] = acc[e];
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int rl = 4 * kq + e;
-                const int c0 = li - 15 + rl, c1 = li + 1 + rl;   // strip column (within the tile) fed by G[rl][li] / G[rl][16 + li]
-                if (c0 >= 0 && j0 + c0 < T) S[rl * lds_stride + j0 + c0] += glo[e];
-                if (c1 < 16 && j0 + c1 < T) S[rl * lds_stride + j0 + c1] += ghi[e];
-            }
-            __builtin_amdgcn_wave_barrier();
-            glo = ghi;   // this tile's high run is the next tile's low run
-        }
-    }
-    __syncthreads();
-    // row softmax: wave w owns 16 / NW rows; a row's T scores are read ONCE into registers (T <= 64 * 20)
-    float* out = aw + (((long long)b * H + h) * T) * Tp;
-    for (int rr = 0; rr < 16 / NW; rr++) {
-        const int rl = wave * (16 / NW) + rr, i = i0 + rl;
-        if (i >= T) break;
-        const float* srow = S + rl * lds_stride;
-        float v[20];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < 20; u++) {
-            const int jj = lane + 64 * u;
-            v[u] = jj < T ? srow[jj] : -INFINITY;
-            mx = fmaxf(mx, v[u]);
-        }
-        mx = wave_max_dpp(mx);
-        float sum = 0.f;
-#pragma unroll
-        for (int u = 0; u < 20; u++) {
-            v[u] = lane + 64 * u < T ? __expf(v[u] - mx) : 0.f;
-            sum += v[u];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        const float inv = 1.0f / sum;
-        float* orow = out + (long long)i * Tp;
-#pragma unroll
-        for (int u = 0; u < 20; u++) {
-            const int jj = lane + 64 * u;
-            if (jj < Tp) orow[jj] = v[u] * inv;   // pad columns [T, Tp) get 0
-        }
-    }
-}
 
-
-// The 16-row strip again, with the scatter and the operand loads taken off the critical path (round 4).  What the ISA of the kernel
-// above showed: every one of its 8 positional read-modify-writes per key tile sat in a branch of its own (ds_read, wait, add,
+// The scatter and the operand loads are off the critical path (round 4).  What the ISA of the read-modify-write form
+// showed: every one of its 8 positional read-modify-writes per key tile sat in a branch of its own (ds_read, wait, add,
 // ds_write: eight exposed LDS round trips per tile), and the loop began with vmcnt(0) on loads issued one scatter earlier.  Here
 //   * a positional tile's element (rl, li) belongs to exactly ONE strip position, column 16 (m - 1) + 1 + li + rl of row rl (the "low
 //     run" and the "high run" of the form above are the two halves of that one formula): the tile is WRITTEN skewed, four plain
@@ -638,31 +385,13 @@ void conformer_softmax_shift(const Ctx& ctx, float* ac, const float* bd, int Z, 
 }
 
 template <int NG>
-static bool conformer_scores_launch(const Ctx& ctx, const float* qu, const float* qv, const float* kmat, int ldk, const float* pp, float* aw, int B,
-                                    int H, int T, int Tp, int D) {
-    const int lds_stride = Tp + 4;
-    const size_t lds = sizeof(float) * (size_t)CR * lds_stride;
-    if (lds > 156 * 1024) return false;  // longer utterances: the GEMM form
-    static LdsAttrOnce lds_attr;
-    lds_attr.ensure(k_conformer_scores_softmax<NG>, 156 * 1024);
-    hipLaunchKernelGGL(k_conformer_scores_softmax<NG>, dim3(cdiv(T, CR), B, H), dim3(512), lds, ctx.stream, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp,
-                       D, lds_stride);
-    K2_HIP(hipGetLastError());
-    return true;
-}
-
-template <int NG>
 static bool conformer_scores_launch16(const Ctx& ctx, const float* qu, const float* qv, const float* kmat, int ldk, const float* pp, float* aw,
                                       int B, int H, int T, int Tp, int D) {
     const int lds_stride = Tp + 4;
     const size_t lds = sizeof(float) * ((size_t)16 * lds_stride + 64);   // + a dump slot per lane (masked positional writes)
-    static LdsAttrOnce lds_attr, lds_attr_v1;
+    static LdsAttrOnce lds_attr;
     // (eight waves per strip: 222 against 205 us per launch; four it is)
-    if (tunables().conformer_scatter_v1) {   // round 3's loop (read-modify-write scatter, loads one tile ahead), for comparison
-        lds_attr_v1.ensure((k_conformer_scores_softmax16<NG, 4>), 96 * 1024);
-        hipLaunchKernelGGL((k_conformer_scores_softmax16<NG, 4>), dim3(cdiv(T, 16), B, H), dim3(256), lds, ctx.stream, qu, qv, kmat, ldk, pp, aw, B, H,
-                           T, Tp, D, lds_stride);
-    } else {
+    {
         lds_attr.ensure((k_conformer_scores_softmax16s<NG, 4>), 96 * 1024);
         unsigned long long* d_st = nullptr;
         const size_t n_st = (size_t)cdiv(T, 16) * B * H * 4 * 8;
@@ -707,16 +436,9 @@ bool conformer_scores_softmax(const Ctx& ctx, const float* qu, const float* qv, 
     if (sizeof(float) * (size_t)CR * (Tp + 4) > 156 * 1024 || Tp > 64 * 20) return false;
     ctx.add_flops(0.0, 2.0 * dk * (double)T * (3.0 * T) * B * H, 0);
     if (ctx.dry) return true;
-    if (!tunables().conformer_strip32) {   // 16-row strips: three workgroups per CU
-        if (dk == 64) return conformer_scores_launch16<4>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
-        if (dk == 32) return conformer_scores_launch16<2>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
-        if (dk == 16) return conformer_scores_launch16<1>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
-    }
-    switch (dk) {
-        case 64: return conformer_scores_launch<8>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
-        case 32: return conformer_scores_launch<4>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
-        default: return conformer_scores_launch<2>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
-    }
+    if (dk == 64) return conformer_scores_launch16<4>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
+    if (dk == 32) return conformer_scores_launch16<2>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
+    return conformer_scores_launch16<1>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
 }
 
 }  // namespace k2hip

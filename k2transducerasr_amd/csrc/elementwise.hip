@@ -603,7 +603,7 @@ void basicnorm(const Ctx& ctx, const float* x, const float* log_eps, float* y, i
 void dwconv7x7(const Ctx& ctx, const float* x, const float* w_kc, const float* b, float* y, int B, int Tin, int T, int tpad,
                int F, int C) {
     ctx.add_flops(0.0, 2.0 * B * T * (double)F * C * 49, 0);
-    if (C % DW7_CG == 0 && F <= 24 && !tunables().dw7_simple && !tunables().dw7_tiled && T >= 48 && (long long)F * C * 4 < (1ll << 31)) {
+    if (C % DW7_CG == 0 && F <= 24 && !tunables().dw7_tiled && T >= 48 && (long long)F * C * 4 < (1ll << 31)) {
         if (ctx.dry) return;
         const int TR = T >= 256 ? 64 : 32;
         size_t lds = sizeof(float) * ((size_t)DW7_RING * (F + 6) * 32 + 49 * 32);
@@ -614,7 +614,7 @@ void dwconv7x7(const Ctx& ctx, const float* x, const float* w_kc, const float* b
         K2_HIP(hipGetLastError());
         return;
     }
-    if (C % DW7_CG == 0 && F <= 24 && !tunables().dw7_simple) {
+    if (C % DW7_CG == 0 && F <= 24) {
         if (ctx.dry) return;
         size_t lds = sizeof(float) * ((size_t)(DW7_TT + 6) * (F + 6) * 32 + 49 * 32);
         hipLaunchKernelGGL(k_dwconv7x7_tiled, dim3(C / DW7_CG, cdiv(T, DW7_TT), B), dim3(192), lds, ctx.stream, x, w_kc, b, y, Tin, T,

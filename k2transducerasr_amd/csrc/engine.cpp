@@ -24,7 +24,6 @@ Engine::Engine(const std::string& weights, const char* overrides, int device) : 
     K2_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     K2_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
     tunables_init_from_env();
-    pipe_mode_ = tunables().pipe_mode;
     for (auto& sl : slots_) {
         // Streams in creation order: encoder, shared search stream, slot 0, slot 1 -- and slot 2's only at its first use (the
         // three-deep pipeline of the beam search).  HIP streams share a handful of hardware queues: with a fifth stream created
@@ -54,8 +53,6 @@ Engine::~Engine() {
         if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
         sl.arena.release();
     }
-    graphs_clear();
-    if (rec_stream_) (void)hipStreamDestroy(rec_stream_);
     if (stream2_) (void)hipStreamDestroy(stream2_);
     for (auto& kv : pe_cache_) (void)hipFree(kv.second);
     for (auto& kv : pp_cache_) (void)hipFree(kv.second);
@@ -110,7 +107,7 @@ void* Engine::pinned(int64_t bytes) {
 
 Ctx Engine::make_ctx(bool dry) {
     Ctx c;
-    c.stream = cur_stream_ ? cur_stream_ : stream_;
+    c.stream = stream_;
     c.arena = cur_arena_;
     c.dry = dry;
     c.instrument = instrument_ && !dry;
@@ -315,7 +312,6 @@ const float* Engine::pos_proj_cached(const Ctx& c, int layer, const float* pe, i
     const size_t bytes = sizeof(float) * (size_t)rows * ncols;
     if (pp_cache_bytes_ + bytes > ((size_t)1 << 30)) {  // many distinct utterance lengths: start over (stream-ordered frees)
         synchronize();
-        graphs_clear();   // instantiated graphs hold these pointers
         for (auto& kv : pp_cache_) (void)hipFree(kv.second);
         pp_cache_.clear();
         pp_cache_bytes_ = 0;
@@ -586,27 +582,6 @@ float* Engine::encoder_forward(const Ctx& c, const float* x, int B, int T, int* 
 // The decoder outputs of the two contexts every offline greedy search starts from are constants of the model: computed once (by the
 // search kernel's own routine), then shared by the t0 pre-pass and every search workgroup (a 70 us single-workgroup launch per
 // batch, and two decoder passes at the head of every search workgroup before).
-void Engine::graphs_clear() {
-    for (auto& kv : graphs_)
-        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-    graphs_.clear();
-}
-
-// the encoder pass of the fused entries: one chain of ~400 launches whose every argument follows from (model, B, T, arena) -- under
-// K2HIP_GRAPH_OFFLINE replayed as a hipGraph once the same shape has been seen twice (Engine::graphed).  Off by default: measured
-// on the headline batch it is 0.1 ms SLOWER (13.87 against 13.76 ms) -- a dependent launch costs 2.8 us eagerly and 1.7 us from a
-// graph when the kernels are empty, but behind a 20 - 80 us kernel the next launch's enqueue is already hidden
-// (tools/probes/graph_chain_probe.hip: 33.04 against 32.78 us per step).  The streaming tick (10 us kernels) keeps its graph.
-float* Engine::encoder_forward_graphed(const Ctx& c, const float* d_x, int B, int T, int* Tp) {
-    GraphKey gk;
-    gk.kind = 2; gk.B = B; gk.T = T;
-    gk.p0 = d_x;
-    if (!tunables().graph_offline) return encoder_forward(c, d_x, B, T, Tp, -1, nullptr, nullptr, nullptr);
-    float* enc = nullptr;
-    graphed(c, gk, [&](const Ctx& g) { enc = encoder_forward(g, d_x, B, T, Tp, -1, nullptr, nullptr, nullptr); });
-    return enc;
-}
-
 const float* Engine::decoder_start(const Ctx& c) {
     if (c.dry) return d_dec_start_;
     if (!d_dec_start_) {
@@ -1101,7 +1076,7 @@ void Engine::offline_greedy_samples_dev(const float* samples_dev, int64_t n_each
         pad_logfloor_dense(c, d_feats, n_fl, d_x, B, L);
         if (!c.dry) K2_HIP(hipEventRecord(ev_[2], c.stream));
         int Tp = 0;
-        float* enc = encoder_forward_graphed(c, d_x, B, T, &Tp);
+        float* enc = encoder_forward(c, d_x, B, T, &Tp, -1, nullptr, nullptr, nullptr);
         if (!c.dry) K2_HIP(hipEventRecord(ev_[3], c.stream));
         greedy_device(c, enc, B, Tp, false, d_tok, d_ts, d_n, max_tokens, d_ovf);
         if (!c.dry) K2_HIP(hipEventRecord(ev_[4], c.stream));
@@ -1155,9 +1130,9 @@ int Engine::submit_impl(const float* samples_dev, const float* samples_host, int
     K2_REQUIRE(cf.ctc || cf.J == 512, "offline loops hard-code a 512-wide encoder_out; joiner_dim is %d", cf.J);
     const int64_t nf = fbank_num_frames(n_each);
     K2_REQUIRE(nf > 0, "offline_submit: %lld samples give no frame", (long long)n_each);
-    // slots in use: all three when every slot's search runs on the slot's own stream (the beam search, or K2HIP_PIPE_MODE=2), else two
-    const bool own = pipe_mode_ == 1;
-    const bool deep = !own && (pipe_mode_ == 2 || (pipe_mode_ == 0 && beam_ > 0 && !cf.ctc));
+    // slots in use: all three when every slot's search runs on the slot's own stream (the beam search), else two.  (Rounds 1 - 4 kept a
+    // third form behind a switch, two whole batches concurrently on two streams: 15.15 against 13.76 ms per headline batch; removed.)
+    const bool deep = beam_ > 0 && !cf.ctc;
     const int nslots = deep ? kSlots : 2;
     int ticket = -1, in_flight = 0;
     for (const auto& x : slots_) in_flight += x.busy;
@@ -1180,8 +1155,7 @@ int Engine::submit_impl(const float* samples_dev, const float* samples_host, int
         sl.pin_cap = nb;
     }
     cur_arena_ = &sl.arena;
-    hipStream_t s2 = (own || deep) ? sl.stream : stream2_;
-    cur_stream_ = own ? sl.stream : nullptr;
+    hipStream_t s2 = deep ? sl.stream : stream2_;
     try {
         run_sized([&](const Ctx& c) {
             Arena& ar = *c.arena;
@@ -1196,12 +1170,10 @@ int Engine::submit_impl(const float* samples_dev, const float* samples_host, int
                 float* d_s = ar.take<float>((int64_t)B * n_each);
                 src = d_s;
                 if (!c.dry) {
-                    hipStream_t cs = own ? c.stream : (deep ? stream2_ : sl.stream);  // deep: the shared search stream is idle -> copies
+                    hipStream_t cs = deep ? stream2_ : sl.stream;  // deep: the shared search stream is idle -> copies
                     K2_HIP(hipMemcpyAsync(d_s, samples_host, sizeof(float) * (size_t)B * n_each, hipMemcpyHostToDevice, cs));
-                    if (!own) {
-                        K2_HIP(hipEventRecord(sl.h2d_done, cs));
-                        K2_HIP(hipStreamWaitEvent(c.stream, sl.h2d_done, 0));
-                    }
+                    K2_HIP(hipEventRecord(sl.h2d_done, cs));
+                    K2_HIP(hipStreamWaitEvent(c.stream, sl.h2d_done, 0));
                 }
             }
             FbankArgs a{src, n_each, n_each, B, nf, d_feats, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift,
@@ -1210,13 +1182,13 @@ int Engine::submit_impl(const float* samples_dev, const float* samples_host, int
             fbank(c, a);
             pad_logfloor_dense(c, d_feats, n_fl, d_x, B, L);
             int Tp = 0;
-            float* enc = encoder_forward_graphed(c, d_x, B, T, &Tp);
+            float* enc = encoder_forward(c, d_x, B, T, &Tp, -1, nullptr, nullptr, nullptr);
             Ctx cd = c;
             cd.stream = s2;
             cd.instrument = false;
             cd.greedy_rec = &sl.greedy;
             sl.greedy.valid = false;
-            if (!c.dry && !own) {
+            if (!c.dry) {
                 K2_HIP(hipEventRecord(sl.enc_done, c.stream));
                 K2_HIP(hipStreamWaitEvent(s2, sl.enc_done, 0));
             }
@@ -1224,11 +1196,9 @@ int Engine::submit_impl(const float* samples_dev, const float* samples_host, int
         });
     } catch (...) {
         cur_arena_ = &arena_;
-        cur_stream_ = nullptr;
         throw;
     }
     cur_arena_ = &arena_;
-    cur_stream_ = nullptr;
     const int64_t nb_tok = (int64_t)B * max_tokens * 8, nb_ts = (int64_t)B * max_tokens * 4, nb_n = (int64_t)B * 4;
     char* pin = static_cast<char*>(sl.pin);
     K2_HIP(hipMemcpyAsync(pin, sl.d_tok, nb_tok, hipMemcpyDeviceToHost, s2));

@@ -111,7 +111,6 @@ class Engine {
                      int64_t* tokens, int32_t* ts, int32_t* n_tokens, const int* fifo_heads = nullptr);
 
     void set_instrument(bool on) { instrument_ = on; }
-    void set_pipe_mode(int m) { pipe_mode_ = m; }
     const std::vector<GemmLaunchRec>& gemm_log() const { return gemm_log_; }
     // decoding method of the batch entry points: 0 = greedy_search (the reference's only method), K >= 1 = modified beam
     // search with beam K (BASELINE.json configs[2]); the single-stream path is always greedy
@@ -119,7 +118,6 @@ class Engine {
     int beam() const { return beam_; }
     const std::vector<int>& last_trail() const { return last_trail_; }
     const std::vector<int>& last_any() const { return last_any_; }
-    int graph_launches() const { return graph_launches_; }   // hipGraph replays since the model was created (k2hip_debug_graph_launches)
     const std::vector<float>& last_scores() const { return last_scores_; }
     // K2HIP_BEAM_TRACE: [B][Tp][2 beam + 1] words of the last synchronous beam search (BeamArgs::trace), and its B / Tp / beam
     const std::vector<int>& last_beam_trace(int* B, int* Tp, int* K) const {
@@ -199,41 +197,11 @@ class Engine {
     // run `body` once dry to size the arena, then for real
     template <typename F>
     void run_sized(F&& body);
-    // A chain of launches that is the same every time it is enqueued with the same key (shapes, arena, pools: every kernel argument is
-    // a function of those) replayed as a hipGraph: the first call with a key runs eagerly (lazy caches fill), the second is captured
-    // from the stream and instantiated, later ones launch the instance -- `enqueue` then only walks the arena (ctx.dry: no launches,
-    // real pointers), so what it returns and what follows it in the arena are unchanged.  A dependent launch costs ~2.8 us enqueued
-    // eagerly and ~1.7 us from a graph (tools/probes/graph_chain_probe.hip): ~385 launches per streaming tick, ~400 per offline batch.
-    // Anything that goes wrong while capturing marks the key and falls back to the eager form for good.
-    struct GraphKey {
-        int kind = 0, B = 0, T = 0, extra = 0, gen = 0;   // gen: tunables_generation() (a test that flips a switch must not replay the old form)
-        const void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *stream = nullptr;
-        int64_t cap = 0, off = 0;   // the arena's capacity and the offset the chain starts at: every pointer it takes follows from them
-        bool operator<(const GraphKey& o) const {
-            return std::tie(kind, B, T, extra, gen, p0, p1, p2, stream, cap, off) <
-                   std::tie(o.kind, o.B, o.T, o.extra, o.gen, o.p0, o.p1, o.p2, o.stream, o.cap, o.off);
-        }
-    };
-    struct GraphEntry {
-        int state = 0;  // 0 seen (ran eagerly), 1 ready, 2 not capturable
-        int failed = 0; // recordings that did not survive (state 2 after the third)
-        hipGraphExec_t exec = nullptr;
-        unsigned long long last_use = 0;
-    };
-    template <typename F>
-    void graphed(const Ctx& c, GraphKey key, F&& enqueue);
-    void graphs_clear();
-    hipStream_t rec_stream_ = nullptr;   // the stream a chain is RECORDED on (graphed): never one that carries work
-    float* encoder_forward_graphed(const Ctx& c, const float* d_x, int B, int T, int* Tp);
-
     int submit_impl(const float* samples_dev, const float* samples_host, int64_t n_each, int B, int max_tokens);
     void finish_tokens(const long long* d_tok, const int* d_ts, const int* d_n, const int* d_ovf, int B, int max_tokens,
                        int64_t* tokens, int32_t* ts, int32_t* n_tokens);
     Ctx make_ctx(bool dry);
 
-    std::map<GraphKey, GraphEntry> graphs_;
-    unsigned long long graph_clock_ = 0;
-    int graph_launches_ = 0;
     std::unique_ptr<Model> model_;
     int device_;
     hipStream_t stream_ = nullptr;
@@ -258,11 +226,9 @@ class Engine {
     int search_retries_ = 0;            // one-part retries since the model was created (k2hip_debug_search_retries)
     int next_slot_ = 0;
     hipStream_t stream2_ = nullptr;
-    hipStream_t cur_stream_ = nullptr;  // stream of the call being built (nullptr = stream_)
     // submit/wait overlap: 0 = search of batch i (stream2) under the encoder of batch i+1 (stream); 1 = every slot owns a
     // stream, so whole batches run concurrently and each other's GEMM prologues / epilogues / tails are filled; 2 = encoders in
     // order on `stream`, every slot's search on the slot's stream (chosen by itself for the beam search)
-    int pipe_mode_ = 0;
     float* online_pool_ = nullptr;
     float* online_fifo_ = nullptr;  // [online_cap_][kFifoFrames][feat]
     int online_cap_ = 0;
@@ -319,94 +285,6 @@ class EngineLock {
 };
 
 template <typename F>
-void Engine::graphed(const Ctx& c, GraphKey key, F&& enqueue) {
-    if (c.dry || c.instrument || c.capturing || tunables().no_graphs) {
-        enqueue(c);
-        return;
-    }
-    key.stream = c.stream;
-    key.gen = tunables_generation();
-    key.p2 = key.p2 ? key.p2 : c.arena->base();
-    key.cap = c.arena->capacity();
-    key.off = c.arena->mark();
-    auto it = graphs_.find(key);
-    if (it == graphs_.end()) {
-        if (graphs_.size() >= 24) {   // shapes come and go (ragged batches): drop the least recently used instance
-            auto old = graphs_.begin();
-            for (auto j = graphs_.begin(); j != graphs_.end(); ++j)
-                if (j->second.last_use < old->second.last_use) old = j;
-            if (old->second.exec) {
-                // (its last replay may still be running on its stream -- the pipelined offline entries do not wait per batch)
-                (void)hipStreamSynchronize(static_cast<hipStream_t>(const_cast<void*>(old->first.stream)));
-                (void)hipGraphExecDestroy(old->second.exec);
-            }
-            graphs_.erase(old);
-        }
-        graphs_[key].last_use = ++graph_clock_;
-        enqueue(c);
-        return;
-    }
-    GraphEntry& e = it->second;
-    e.last_use = ++graph_clock_;
-    if (e.state == 2) {
-        enqueue(c);
-        return;
-    }
-    if (e.state == 0) {
-        // Recorded on a stream of its own, replayed on c.stream.  While a recording is open, ANY legacy-stream operation of ANY host
-        // thread (the host application's own hipMemcpy, a framework on the default stream) is refused by the runtime and invalidates
-        // the recording -- and hipStreamEndCapture then leaves the recording stream in its invalidated state for good (ROCm 7.2:
-        // every later launch on it fails with hipErrorStreamCaptureInvalidated).  So the live stream is never the one in capture
-        // mode: a spoiled recording costs a scratch stream, the chain runs eagerly this time (a recording enqueues nothing) and
-        // the next call with this shape records again (three attempts).
-        const int64_t mark = c.arena->mark();
-        if (!rec_stream_ && hipStreamCreateWithFlags(&rec_stream_, hipStreamNonBlocking) != hipSuccess) rec_stream_ = nullptr;
-        const int cm = tunables().graph_capture_mode;
-        const hipStreamCaptureMode mode = cm == 1 ? hipStreamCaptureModeRelaxed : cm == 2 ? hipStreamCaptureModeGlobal : hipStreamCaptureModeThreadLocal;
-        bool ok = rec_stream_ && hipStreamBeginCapture(rec_stream_, mode) == hipSuccess;
-        const bool begun = ok;
-        hipGraph_t g = nullptr;
-        if (ok) {
-            Ctx cc = c;
-            cc.capturing = true;
-            cc.stream = rec_stream_;
-            try {
-                enqueue(cc);
-            } catch (...) {
-                ok = false;
-            }
-            if (hipStreamEndCapture(rec_stream_, &g) != hipSuccess || !g) ok = false;
-        }
-        if (ok && hipGraphInstantiate(&e.exec, g, nullptr, nullptr, 0) != hipSuccess) {
-            ok = false;
-            e.exec = nullptr;
-        }
-        if (g) (void)hipGraphDestroy(g);
-        (void)hipGetLastError();
-        if (!ok) {   // nothing was enqueued (a recording records, it does not run): the eager form, from the same arena position
-            if (begun || !rec_stream_) {
-                // the spoiled stream is abandoned, not destroyed: whoever spoiled the recording is still issuing legacy-stream
-                // operations, and those walk the runtime's stream list (a destroy next to that walk crashed inside libamdhip64)
-                rec_stream_ = nullptr;
-                (void)hipGetLastError();
-            }
-            if (++e.failed >= 3) e.state = 2;
-            c.arena->rewind(mark);
-            enqueue(c);
-            return;
-        }
-        e.state = 1;
-    } else {
-        Ctx r = c;   // walk the arena only
-        r.dry = true;
-        r.stats = nullptr;
-        enqueue(r);
-    }
-    K2_HIP(hipGraphLaunch(e.exec, c.stream));
-    graph_launches_++;
-}
-
-template <typename F>
 void Engine::run_sized(F&& body) {
     K2_HIP(hipSetDevice(device_));
     stats_ = GemmStats();
@@ -424,7 +302,7 @@ void Engine::run_sized(F&& body) {
     int64_t need = cur_arena_->high_water();
     cur_arena_->reset();
     if (need > cur_arena_->capacity()) {
-        K2_HIP(hipStreamSynchronize(cur_stream_ ? cur_stream_ : stream_));
+        K2_HIP(hipStreamSynchronize(stream_));
         cur_arena_->reserve(need + need / 8);
     }
     Ctx c = make_ctx(false);
@@ -432,7 +310,7 @@ void Engine::run_sized(F&& body) {
     gemm_log_.clear();
     body(c);
     if (instrument_) {
-        K2_HIP(hipStreamSynchronize(cur_stream_ ? cur_stream_ : stream_));
+        K2_HIP(hipStreamSynchronize(stream_));
         for (int i = 0; i + 1 < evused_; i += 2) {
             float ms = 0;
             K2_HIP(hipEventElapsedTime(&ms, evpool_[i], evpool_[i + 1]));

@@ -1281,7 +1281,8 @@ struct RingCfg { int BM, BN, KS, NST, LW, PF; };
     X(10, 64, 64, 4, 2, 0, 0) X(11, 64, 64, 4, 2, 0, 1) X(12, 32, 64, 2, 3, 0, 0) X(13, 32, 64, 4, 3, 0, 0) X(14, 32, 64, 4, 3, 0, 1)  \
     X(15, 32, 32, 4, 3, 0, 0) X(16, 32, 32, 4, 4, 0, 1) X(17, 64, 32, 4, 3, 0, 0) X(18, 128, 128, 1, 2, 0, 0) X(19, 128, 128, 1, 2, 0, 1) \
     X(20, 64, 128, 1, 3, 0, 0) X(21, 64, 128, 1, 3, 0, 1) X(22, 64, 96, 1, 3, 0, 0) X(23, 64, 96, 1, 3, 0, 1) X(24, 128, 96, 1, 2, 0, 1) \
-    X(25, 128, 64, 1, 3, 2, 0) X(26, 128, 64, 1, 3, 2, 1) X(27, 128, 64, 2, 2, 0, 1)
+    X(25, 128, 64, 1, 3, 2, 0) X(26, 128, 64, 1, 3, 2, 1) X(27, 128, 64, 2, 2, 0, 1) X(28, 64, 96, 2, 3, 0, 0) X(29, 64, 96, 2, 2, 0, 0) \
+    X(30, 64, 96, 2, 2, 0, 1) X(31, 128, 96, 1, 3, 0, 0) X(32, 128, 96, 1, 3, 0, 1)
 #define X(i, bm, bn, ks, nst, lw, pf) {bm, bn, ks, nst, lw, pf},
 const RingCfg kRing[] = {K2_RING_TABLE(X)};
 #undef X
@@ -1332,7 +1333,7 @@ int choose_cfg(const GemmArgs& a) {
     if (tunables().gemm_cfg >= 0) return tunables().gemm_cfg;
     // N <= 32 with many rows (encoder_embed.conv.4 as an implicit GEMM: 632 736 x 32 x 72 at the headline shape): a 64-column tile
     // multiplies 32 columns of padding
-    if (a.N <= 32 && a.M >= 4096 && !tunables().gemm_v1) return 12;
+    if (a.N <= 32 && a.M >= 4096) return 12;
     // (the third embed convolution, 307 040 x 128 x 288, stays on 128x64 with K steps of 32: one 128-column tile that gathers each A row once is
     // 301 against 284 us, K steps of 64 382)
     if (a.N <= 64) return 2;    // 64x64 tiles, 4 waves
@@ -1441,18 +1442,18 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         return;
     }
     const Tunables& tn = tunables();
-    const bool no_skinny = tn.gemm_no_skinny != 0, forced = g_forced_cfg >= 0 || tn.gemm_cfg >= 0, use_dma = g_use_dma && !tn.gemm_no_dma;
+    const bool forced = g_forced_cfg >= 0 || tn.gemm_cfg >= 0, use_dma = g_use_dma != 0;
     const bool plain = a.cv_Fout == 0 && !a.w_kn && a.nb0 * a.nb1 == 1 && a.K % 64 == 0 && a.K >= 64;
     // (16-row workgroups re-read the weight chunk M/16 times: with many rows and a short K the 64x64 tiles are better)
     const bool few_tiles = (long long)cdiv(a.M, 128) * cdiv(a.N, 64) < 144 && a.M <= 4096 && !(a.M >= 2048 && a.K <= 256 && a.N > 272);
-    const bool skinny_ok = !forced && !no_skinny && plain && !a.mul && ((a.N <= 96 && a.M >= 512) || few_tiles);
+    const bool skinny_ok = !forced && plain && !a.mul && ((a.N <= 96 && a.M >= 512) || few_tiles);
     const bool skinny16_ok = skinny_ok && !a.glu;  // the 16-column C/D layout of gemm_f32_mfma_skinny has no lane pair 16 apart
     // Small problems with more than a handful of columns (the streaming chunk step: 256 .. 2048 rows): small ring tiles with the
     // K step split over four (two) wave groups of the workgroup put 4 - 8 waves on ~200 CUs and walk K in K / 128 (K / 64) steps
     // through coalesced LDS-DMA tiles, where the 16-row skinny kernel re-reads the weight chunk M / 16 times straight into
     // fragment layout (half-used cache lines; it is bound by the texture-address path, not by latency).  Choice by grid size,
     // from tools/gemm_lab.py streaming (gpurun_out/lab_str1.txt): 17 % less GEMM time over the chunk step's shapes.
-    if (skinny_ok && few_tiles && a.N > 96 && !(tn.gemm_v1 & 5) && a.res_div == 1 && !a.act_after_res) {
+    if (skinny_ok && few_tiles && a.N > 96 && a.res_div == 1 && !a.act_after_res) {
         const long long g32 = (long long)cdiv(a.M, 32) * cdiv(a.N, 32), g6432 = (long long)cdiv(a.M, 64) * cdiv(a.N, 32);
         int ring = -1;
         if (a.K % 128 == 0 && g32 <= 256) ring = 16;          // 32x32 tiles, KS 4, 4 stages + L2 prefetch wave
@@ -1472,7 +1473,7 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     }
     // a few hundred rows x <= 96 columns with a long enough K (the streaming value projections of the downsampled stacks: 256 x 96 x 512,
     // 512 x 48 x 384): 32x32 ring tiles with the K step split four ways, 6.4 / 5.7 against 9.3 / 6.5 us (same lab run)
-    if (skinny16_ok && a.N <= 96 && a.M <= 512 && a.K % 128 == 0 && a.K >= 384 && !(tn.gemm_v1 & 5) && a.res_div == 1 && !a.act_after_res) {
+    if (skinny16_ok && a.N <= 96 && a.M <= 512 && a.K % 128 == 0 && a.K >= 384 && a.res_div == 1 && !a.act_after_res) {
         launch_ring_idx(ctx, b, 15);
         K2_HIP(hipGetLastError());
         if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 64;
@@ -1509,7 +1510,7 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     // for their extra operand traffic.  Examples it reproduces: 4064 x 512 -> 128x64 (256 tiles, one round); 4064 x 1152,
     // 2048 x 2560 / 2080 -> 64x64 (1152 / 1280 / 1056 tiles: 4.5 / 5 / 4.1 rounds of 4096 instead of 2.25 / 2.5 / 2.1 -> 3 of 8192);
     // 4064 x 1024 / 1920, 2048 x 2048 -> 128x128; 16160 x 192 -> 64x64 or 128x32 (3 rounds of 4096 instead of 2 of 8192).
-    if (dma_ok && use_dma && !forced && !(tn.gemm_v1 & 3) && a.nb0 * a.nb1 == 1 && a.K >= 64 && a.M >= 256 &&
+    if (dma_ok && use_dma && !forced && a.nb0 * a.nb1 == 1 && a.K >= 64 && a.M >= 256 &&
         (long long)a.M * a.lda < (1ll << 29) && (long long)a.N * a.ldw < (1ll << 29)) {
         struct Cand { int idx, bm, bn; double fixed_steps, penalty; };
         static const Cand cands[] = {{8, 128, 128, 3.5, 0.0}, {1, 128, 64, 3.3, 0.02}, {5, 64, 64, 4.0, 0.12}, {13, 128, 32, 5.5, 0.08}};
@@ -1531,21 +1532,6 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
         return;
     }
-    // (K2HIP_GEMM_V1: the round-1 / round-2 tile rules below)
-    if (dma_ok && use_dma && !forced && a.nb0 * a.nb1 == 1 && a.M >= 1024) {
-        const long long t96 = a.N % 96 == 0 ? (long long)cdiv(a.M, 128) * (a.N / 96) : 0;
-        const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128);
-        int ring = -1;
-        if (t96 >= 218 && t96 <= 256) ring = 24;                                                    // 128x96, 2 stages + L2 prefetch wave
-        else if (a.K >= 512 && a.N >= 500 && t128 * 100 >= cdiv(t128, 256) * 256 * 85) ring = 18;   // 128x128, 2 stages
-        if (ring >= 0) {
-            launch_ring_idx(ctx, b, ring);
-            K2_HIP(hipGetLastError());
-            if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 64;
-            if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
-            return;
-        }
-    }
     // (batched launches too -- the Conformer's per-(head, stream) score products -- as long as the tile choice is one of the DMA kernel's)
     if (dma_ok && use_dma && (cfg == 5 || cfg == 0 || (cfg >= 7 && cfg <= 11))) {
         if (cfg == 11) launch_dma<64, 96, 32, 32, 2>(ctx, b);        // 64x96 tiles (6 waves): N % 96 == 0 outputs that 128x64 quantises badly
@@ -1553,8 +1539,7 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         else if (cfg == 10) launch_dma<64, 64, 32, 32, 3>(ctx, b);   // tuning: 64x64 tiles, 3 stages
         else if (cfg == 7) launch_dma<128, 64, 32, 32, 2>(ctx, b);  // tuning: 2 stages, 3 workgroups per CU
         else if (cfg == 8) launch_dma<128, 64, 32, 32, 4>(ctx, b);  // tuning: 4 stages, 1 workgroup per CU
-        else if (cfg == 5 && !tn.gemm_nst3) launch_dma<128, 64, 32, 32, 2>(ctx, b);  // 2 stages: 3 workgroups per CU
-        else if (cfg == 5) launch_dma<128, 64, 32, 32>(ctx, b);
+        else if (cfg == 5) launch_dma<128, 64, 32, 32, 2>(ctx, b);  // 2 stages: 3 workgroups per CU
         else launch_dma<128, 128, 64, 32>(ctx, b);
         K2_HIP(hipGetLastError());
         if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 16;

@@ -468,7 +468,8 @@ __device__ __noinline__ bool screen_round(const DecJoinW& w, const float* actT, 
     lint* cand = ctl + 8;                                           // [kScreenCand]: frame | local column << 3
     lfloat* part = (lfloat*)(cand + kScreenCand);                   // [kScreenCand][8 slices]
     const lfloat* actL = (const lfloat*)actT;
-    if (tid < 2) ctl[tid] = 0;
+    // (ctl[0 .. 1] were zeroed by the caller IN FRONT of the barrier that precedes this call: zeroed here, a wave that finished its tile
+    // sweep early could raise the non-finite flag before wave 0's late store cleared it again)
     // ---- the screen: wave = every 8th 16-column tile; the A fragments (the activations) are re-read from LDS per tile -- held in
     // registers they are 64 VGPRs on top of the B ring's 64 and the kernel spills
     typedef __attribute__((address_space(3))) const h16x8 lh16x8;   // (LDS, not flat: a flat load's wait also drains the global loads in flight)
@@ -645,7 +646,8 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
     const bool screen = SCREEN && w.out_h16 != nullptr && (w.J & 31) == 0 && (nks == 16 || nks == 8 || nks == 4 || nks == 2) &&
                         4 * (cg1 - cg0) <= kScreenMaxCols && cg1 > cg0;
     if (screen) {
-        for (int i = tid; i < w.J * 16; i += GT) reinterpret_cast<unsigned*>(actH)[i] = 0u;   // rows 8 .. 15 of the A tile stay zero
+        // (J x 32 bytes = J x 8 words: exactly what greedy_lds_bytes allots -- actH is the last region of the dynamic LDS)
+        for (int i = tid; i < w.J * 8; i += GT) reinterpret_cast<unsigned*>(actH)[i] = 0u;   // rows 8 .. 15 of the A tile stay zero
         __syncthreads();
     }
 
@@ -700,6 +702,10 @@ __global__ __launch_bounds__(GT) void k_greedy(DecJoinW w, GreedyArgs a) {
                 if (screen) dh[f * 8] = (_Float16)v;
             }
         }
+        // the screen's candidate count and non-finite flag (screen_round's ctl, behind scr and wlb in the psum area): every thread has
+        // left the previous round's reads of them (barriers behind both of its exits), and the barrier below orders this store in front
+        // of every wave's `ctl[1] = 1`
+        if (screen && tid < 2) reinterpret_cast<int*>(psum + GF * kScreenMaxCols + 64)[tid] = 0;
         __syncthreads();
         stamp(1);
         // The sweep (mfma_sweep_rows): wave = k slice (J / 8 rows), lane = 4 columns -- a pass covers 256 columns of the slab and a
@@ -1270,8 +1276,7 @@ void greedy_loop(const Ctx& ctx, const DecJoinW& w, const GreedyArgs& a0) {
     const size_t gran_words = (size_t)a.B * 2 * parts * GF * 2, gran2_words = (size_t)a.B * 2 * w.J;
     a.gran = parts > 1 ? ctx.arena->take<unsigned long long>((int64_t)(gran_words + gran2_words)) : nullptr;
     a.gran2 = parts > 1 ? a.gran + gran_words : nullptr;
-    // the launch is noted for the one-part repeat BEFORE the dry return: a pass that only walks the arena because its launches are
-    // replayed from a hipGraph (Engine::graphed) must leave the same record (the sizing pass writes null pointers here and is always
+    // the launch is noted for the one-part repeat BEFORE the dry return (the sizing pass writes null pointers here and is always
     // followed by a pass with real ones)
     if (ctx.greedy_rec) {
         ctx.greedy_rec->valid = parts > 1;

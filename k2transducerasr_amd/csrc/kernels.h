@@ -6,59 +6,53 @@
 
 namespace k2hip {
 
-// Development switches (tunables.cpp): the K2HIP_* environment read once at the first model creation.
+// Switches of the library (tunables.cpp): the K2HIP_* environment read once at the first model creation.  The shipped build keeps
+// ONE path per operation plus the cross-check pairs the parity tests compare (an alternative kernel for the same math, a forced
+// fallback, a size limit); the tuning probes exist only in a -DK2HIP_DEV build (make DEV=1), where K2HIP_DEV_SWITCH fields become
+// ordinary members -- here they are compile-time constants and the code behind them folds away.
+#ifdef K2HIP_DEV
+#define K2HIP_DEV_SWITCH(name, def) int name = def
+#else
+#define K2HIP_DEV_SWITCH(name, def) static constexpr int name = def
+#endif
 struct Tunables {
-    int gemm_cfg = -1;            // K2HIP_GEMM_CFG: force one tile configuration (tuning)
-    int gemm_no_dma = 0;          // K2HIP_GEMM_NO_DMA: register-staged kernels only
-    int gemm_no_skinny = 0;       // K2HIP_GEMM_NO_SKINNY
-    int gemm_nst3 = 0;            // K2HIP_GEMM_NST3: three-stage ring for the 128x64 LDS-DMA kernel
-    int no_glu_epilogue = 0;      // K2HIP_NO_GLU_EPILOGUE: conv modules' GLU in the depthwise kernel (round 1 form) instead of the in_proj GEMM's epilogue
-    int gemm_v1 = 0;              // K2HIP_GEMM_V1: the earlier LDS-DMA kernels and tile rules (barrier at the top of every K step) instead of gemm_f32_mfma_pipe
-    int attn_long = 0;            // K2HIP_ATTN_LONG: two-pass attention scores for every length
-    int xcd_panels = 0;           // K2HIP_XCD_PANELS: 1 = every GEMM's tiles as bands of M per XCD (rounds 1 - 3); 0 = panels of N where they cut the fabric traffic
+    // ---- cross-check pairs and forced fallbacks (tests/)
+    int no_glu_epilogue = 0;      // K2HIP_NO_GLU_EPILOGUE: conv modules' GLU in the depthwise kernel instead of the in_proj GEMM's epilogue
+    int attn_long = 0;            // K2HIP_ATTN_LONG: two-pass attention scores for every length (the long-utterance form)
     int no_fused_av = 0;          // K2HIP_NO_FUSED_AV: attention apply + out_proj as two GEMMs
-    int fused_vproj_min_t = 4;    // K2HIP_FUSED_VPROJ_MIN_T: ... from this many chunk rows per stream on (a 16-row tile per stream wastes the deepest stack's 2 rows:
-                                  // 128 streams, device time per tick 3.61 ms from 4 rows on, 3.62 from 8, 3.68 from 2, 3.66 never)
-    int no_fused_vproj = 0;       // K2HIP_NO_FUSED_VPROJ: the streaming self-attention modules' value projection as a GEMM launch of its own
-    int conformer_strip32 = 0;      // K2HIP_CONFORMER_STRIP32: the fused Conformer scores kernel on 32-row strips (one workgroup per CU), the earlier form
-    int conformer_stamps = 0;       // K2HIP_CONFORMER_STAMPS: tuning -- the 16-row scores kernel reports its phases (stderr, synchronous)
-    int conformer_scatter_v1 = 0;   // K2HIP_CONFORMER_SCATTER_V1: the 16-row scores kernel with round 3's loop (read-modify-write scatter)
-    int conformer_gemm_scores = 0;  // K2HIP_CONFORMER_GEMM_SCORES: two batched GEMMs + gather/softmax
-    int dw7_simple = 0;           // K2HIP_DW7_SIMPLE: untiled 7x7 depthwise convolution
-    int dw1d_tt = 0;              // K2HIP_DW1D_TT: outputs per thread of the depthwise Conv1d (8 / 4 / 2; 0 = by grid size)
-    int causal_conv_lds = 0;      // K2HIP_CAUSAL_CONV_LDS: the streaming conv modules' depthwise kernel with its column in LDS (any chunk length)
-    int dw7_tiled = 0;            // K2HIP_DW7_TILED: the one-shot LDS-tiled form also for long inputs (default: the sliding LDS-DMA form)
+    int fused_vproj_min_t = 4;    // K2HIP_FUSED_VPROJ_MIN_T: the streaming self-attention's value projection inside k_attn_av_out from this many
+                                  // chunk rows per stream on (128 streams, device time per tick 3.61 ms from 4 rows on, 3.62 from 8, 3.68 from 2)
+    int no_fused_vproj = 0;       // K2HIP_NO_FUSED_VPROJ: ... as a GEMM launch of its own
+    int no_fused_conv = 0;        // K2HIP_NO_FUSED_CONV: the streaming conv modules' GLU + chunk-causal depthwise conv as a launch of its own
+                                  // instead of inside the in_proj GEMM's epilogue (round 5)
+    int conformer_gemm_scores = 0;  // K2HIP_CONFORMER_GEMM_SCORES: two batched GEMMs + gather/softmax (the long-utterance form)
+    int dw7_tiled = 0;            // K2HIP_DW7_TILED: the one-shot LDS-tiled 7x7 depthwise conv also for long inputs (default: the sliding LDS-DMA form)
     int lstm_seq = 0;             // K2HIP_LSTM_SEQ: layer-by-layer LSTM instead of the layer wavefront
     int greedy_one_part = 0;      // K2HIP_GREEDY_ONE_PART: one workgroup per stream in the search
     int greedy_parts = 0;         // K2HIP_GREEDY_PARTS: vocabulary slabs per stream (0 = automatic)
-    int beam_launches = 0;        // K2HIP_BEAM_LAUNCHES: the modified beam search as 4 launches per frame even when the one-kernel form applies
+    int beam_launches = 0;        // K2HIP_BEAM_LAUNCHES: the modified beam search as 4 launches per frame (the large-vocabulary form) even when the one-kernel form applies
     int beam_parts = 0;           // K2HIP_BEAM_PARTS: 1 = one workgroup per stream in the one-kernel beam search even where two column slabs apply
-    int beam_hyp_global = 0;      // K2HIP_BEAM_HYP_GLOBAL: the one-kernel beam search keeps its hypotheses in device memory even when they fit in LDS (the long-utterance form, for its test)
-    int decoder_table_mb = 1024;  // K2HIP_DECODER_TABLE_MB: build the all-contexts decoder table when it fits this many MiB (0 = never)
+    int beam_hyp_global = 0;      // K2HIP_BEAM_HYP_GLOBAL: the one-kernel beam search keeps its hypotheses in device memory even when they fit in LDS (the long-utterance form)
     int beam_trace = 0;           // K2HIP_BEAM_TRACE: the modified beam search records its per-frame selection (k2hip_debug.h: k2hip_debug_beam_trace)
-    int screen_min_v = 1024;      // K2HIP_SCREEN_MIN_V: vocabularies of at least this size get the f16 screening pass in the greedy search
-                                  // (greedy.hip screen_round: exact tokens, ~2.5x fewer bytes per round); 0 = never
-    int greedy_stamps = 0;        // K2HIP_GREEDY_STAMPS: tuning -- the persistent search reports where a round's time goes (stderr, synchronous)
-    int no_graphs = 0;            // K2HIP_NO_GRAPHS: every launch enqueued eagerly (no hipGraph replay of the streaming tick)
-    int graph_capture_mode = 0;   // K2HIP_GRAPH_CAPTURE_MODE: how a tick is recorded -- 0 thread-local, 1 relaxed, 2 global (hipStreamCaptureMode*)
-    int graph_streaming = 0;      // K2HIP_GRAPH_STREAMING: 1 = the streaming tick's launches replay from a hipGraph (Engine::graphed).  OFF by default
-                                  // since the end of round 4: with ~335 launches per tick and the persistent search, replay and eager enqueue
-                                  // measure the same (4.13 - 4.20 against 4.10 - 4.16 ms per tick, four presets), while a recording in progress
-                                  // makes the runtime refuse every legacy-stream operation of every host thread (INTEGRATION.md "Threading")
-    int graph_offline = 0;        // K2HIP_GRAPH_OFFLINE: 1 = the offline batch entries replay their encoder pass from a hipGraph too (measured:
-                                  // 13.87 against 13.76 ms per headline batch -- launches of 20 - 80 us hide their own enqueue cost; off by default)
+    int search_rounds = -1;       // K2HIP_SEARCH_ROUNDS: 1 = every multi-stream search as rounds of joiner GEMMs (greedy_rounds),
+                                  // 0 = always the persistent kernel (k_greedy), -1 = measured default
     int test_greedy_timeout = 0;  // K2HIP_TEST_GREEDY_TIMEOUT: test hook -- every parts > 1 search reports an exchange timeout, so the one-part retry runs
                                   // (1: without arming the engine's back-off, so that the next search is parted again; 2: as a real one)
-    int pipe_mode = 0;            // K2HIP_PIPE_MODE: 1 = every pipeline slot owns a stream
+    // ---- limits
+    int decoder_table_mb = 1024;  // K2HIP_DECODER_TABLE_MB: build the all-contexts decoder table when it fits this many MiB (0 = never)
+    int screen_min_v = 1024;      // K2HIP_SCREEN_MIN_V: vocabularies of at least this size get the f16 screening pass in the greedy search
+                                  // (greedy.hip screen_round: exact tokens, ~2.5x fewer bytes per round); 0 = never
     int max_streams = 0;          // K2HIP_MAX_STREAMS: slots of the streaming state pool (0 = 256)
-    int search_rounds = -1;       // K2HIP_SEARCH_ROUNDS: 1 = every multi-stream search as rounds of joiner GEMMs (greedy_rounds),
-                                  // 0 = always the persistent kernel (k_greedy), -1 = measured default: rounds for the streaming
-                                  // tick (0.58 -> 0.45 ms at 128 streams), persistent for the offline batch (17.00 vs 17.10 ms)
+    // ---- tuning probes (-DK2HIP_DEV builds only)
+    K2HIP_DEV_SWITCH(gemm_cfg, -1);         // K2HIP_GEMM_CFG: force one tile configuration
+    K2HIP_DEV_SWITCH(xcd_panels, 0);        // K2HIP_XCD_PANELS: 1 = every GEMM's tiles as bands of M per XCD (rounds 1 - 3)
+    K2HIP_DEV_SWITCH(dw1d_tt, 0);           // K2HIP_DW1D_TT: outputs per thread of the depthwise Conv1d (8 / 4 / 2; 0 = by grid size)
+    K2HIP_DEV_SWITCH(greedy_stamps, 0);     // K2HIP_GREEDY_STAMPS: the persistent search reports where a round's time goes (stderr, synchronous)
+    K2HIP_DEV_SWITCH(conformer_stamps, 0);  // K2HIP_CONFORMER_STAMPS: the Conformer scores kernel reports its phases (stderr, synchronous)
 };
 void tunables_init_from_env();            // idempotent; called by k2hip_model_create
 const Tunables& tunables();
 bool tunables_set(const char* env_name, int value);  // test hook (k2hip_debug_set_switch)
-int tunables_generation();                           // bumped when tunables_set changes a switch that shapes a chain of launches (part of the graph keys)
 
 struct GemmStats {
     double flops = 0;       // algorithmic, 2*M*N*K per launch
@@ -81,7 +75,6 @@ struct Ctx {
     bool dry = false;
     bool one_part = false;    // the engine's searches recently timed out waiting for their other column slabs (a GPU shared with other
                               // handles or processes): one workgroup per stream until the back-off runs out (Engine::note_search)
-    bool capturing = false;   // the stream is capturing a hipGraph (Engine::graphed): no event records, nothing that is not a stream operation
     bool instrument = false;  // bracket each GEMM launch with events
     GemmStats* stats = nullptr;
     // instrumented runs: each GEMM launch records a (start, stop) pair from this pool

@@ -493,7 +493,7 @@ void glu_causal_conv(const Ctx& ctx, const float* x2, float* pool, long long slo
     if (ctx.dry) return;
     size_t lds = sizeof(float) * (K / 2 + Tc) * 64;
     const dim3 grid(cdiv(D, 64), B);
-    if (!tunables().causal_conv_lds) {
+    {   // the lane's column in registers for the (K, Tc) pairs of the model zoo; any other pair: the LDS form below
 #define K2_GCR(KT, TC)                                                                                                              \
     if (K == KT && Tc == TC) {                                                                                                      \
         hipLaunchKernelGGL((k_glu_causal_conv_reg<KT, TC>), grid, dim3(64), 0, ctx.stream, x2, pool, slot_stride, off, slots, wc, bc, ww, bw, \

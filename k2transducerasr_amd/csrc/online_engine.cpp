@@ -497,17 +497,10 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
             K2_HIP(hipEventRecord(ev_[0], c.stream));
             K2_HIP(hipMemcpyAsync(d_in, stage, (size_t)in_bytes, hipMemcpyHostToDevice, c.stream));
         }
-        // everything between the upload and the download is the same chain of launches for every tick with this many streams
-        // (slots, ring heads, processed lengths and contexts are DATA in the uploaded block): replayed as a hipGraph
         // the tick's search: rounds of joiner GEMMs + a per-stream step kernel, or the persistent kernel where its rounds go through
         // the f16 screen (measured per model: greedy_loop_screens)
         const bool persistent_search = tunables().search_rounds == 0 || (tunables().search_rounds < 0 && !cf.ctc && greedy_loop_screens(decjoin(), B, true, c.one_part));
-        GraphKey gk;
-        gk.kind = 1; gk.B = B; gk.T = from_fifo ? 1 : 0; gk.extra = (persistent_search ? 1 : 0) | (c.one_part ? 2 : 0);
-        gk.p0 = online_pool_; gk.p1 = online_fifo_;
-        const int launches_before = graph_launches_;
-        auto chain = [&](const Ctx& c) {
-        const bool ev_ok = !c.dry && !c.capturing;
+        const bool ev_ok = !c.dry;
         if (from_fifo) fifo_gather(c, online_fifo_, kFifoFrames, cf.feat, d_slots, d_heads, d_x, B, T);
         logfloor_inplace(c, d_x, (long long)B * T * cf.feat);  // online PadSequence (PadHelper.cs:9-13,58)
         if (cf.lstm || cf.conformer || cf.zip1) {
@@ -538,14 +531,6 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
         if (persistent_search) greedy_loop(c, decjoin(), a);
         else greedy_rounds(c, decjoin(), model_->w("joiner.output_linear.weight"), a);
         if (ev_ok) K2_HIP(hipEventRecord(ev_[4], c.stream));
-        };
-        // (the persistent search notes its launch for the one-part retry in the arena walk too; its phase report is synchronous)
-        if (!tunables().greedy_stamps && tunables().graph_streaming) graphed(c, gk, chain);
-        else chain(c);
-        if (!c.dry && graph_launches_ != launches_before) {   // a replayed tick has no stamps inside: the whole step counts as encoder time
-            K2_HIP(hipEventRecord(ev_[3], c.stream));
-            K2_HIP(hipEventRecord(ev_[4], c.stream));
-        }
     });
     finish_tokens(d_tok, d_ts, d_n, d_ovf, B, Tp, tokens, ts, n_tokens);
     auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, ev_[a], ev_[b]); return ms; };

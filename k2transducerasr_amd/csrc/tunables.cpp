@@ -2,7 +2,6 @@
 // both paths) or tuning variants.  The K2HIP_* environment is read exactly ONCE, when the first model of the process is created;
 // after that the launch paths only read this struct (no libc lookups per launch, no behaviour change from a setenv mid-run).
 // k2hip_debug_set_switch is the test-only way to flip one afterwards.
-#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -11,17 +10,21 @@
 
 namespace k2hip {
 
-// see common.h: blocking transfers that stay off the legacy stream
+// see common.h: blocking transfers on a per-device utility stream.  One mutex and one stream PER DEVICE: handles on different GPUs
+// (one host thread each, INTEGRATION.md "More than one GPU") never wait for each other's copies -- a model upload on device 3 does
+// not stall a streaming tick on device 0.
 namespace {
-std::mutex g_util_mu;
-hipStream_t g_util_stream[64] = {};
-hipError_t util_stream(hipStream_t* s) {   // g_util_mu held
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
+constexpr int kMaxDev = 64;
+std::mutex g_util_mu[kMaxDev];
+hipStream_t g_util_stream[kMaxDev] = {};
+hipError_t util_device(int* dev) {
+    hipError_t e = hipGetDevice(dev);
     if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    return (*dev < 0 || *dev >= kMaxDev) ? hipErrorInvalidDevice : hipSuccess;
+}
+hipError_t util_stream(int dev, hipStream_t* s) {   // g_util_mu[dev] held
     if (!g_util_stream[dev]) {
-        e = hipStreamCreateWithFlags(&g_util_stream[dev], hipStreamNonBlocking);
+        hipError_t e = hipStreamCreateWithFlags(&g_util_stream[dev], hipStreamNonBlocking);
         if (e != hipSuccess) return e;
     }
     *s = g_util_stream[dev];
@@ -30,9 +33,12 @@ hipError_t util_stream(hipStream_t* s) {   // g_util_mu held
 }  // namespace
 hipError_t copy_blocking(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
     if (bytes == 0) return hipSuccess;
-    std::lock_guard<std::mutex> lk(g_util_mu);
+    int dev = 0;
+    hipError_t e = util_device(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_util_mu[dev]);
     hipStream_t s = nullptr;
-    hipError_t e = util_stream(&s);
+    e = util_stream(dev, &s);
     if (e != hipSuccess) return e;
     e = hipMemcpyAsync(dst, src, bytes, kind, s);
     if (e != hipSuccess) return e;
@@ -40,9 +46,12 @@ hipError_t copy_blocking(void* dst, const void* src, size_t bytes, hipMemcpyKind
 }
 hipError_t fill_blocking(void* dst, int value, size_t bytes) {
     if (bytes == 0) return hipSuccess;
-    std::lock_guard<std::mutex> lk(g_util_mu);
+    int dev = 0;
+    hipError_t e = util_device(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_util_mu[dev]);
     hipStream_t s = nullptr;
-    hipError_t e = util_stream(&s);
+    e = util_stream(dev, &s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(dst, value, bytes, s);
     if (e != hipSuccess) return e;
@@ -58,25 +67,14 @@ struct Entry {
     bool flag;  // presence of the variable means 1
 };
 const Entry kEntries[] = {
-    {"K2HIP_GEMM_CFG", &Tunables::gemm_cfg, false},
-    {"K2HIP_GEMM_NO_DMA", &Tunables::gemm_no_dma, true},
-    {"K2HIP_GEMM_NO_SKINNY", &Tunables::gemm_no_skinny, true},
-    {"K2HIP_GEMM_NST3", &Tunables::gemm_nst3, true},
-    {"K2HIP_GEMM_V1", &Tunables::gemm_v1, false},  // 1: everything older; 2: only the pipelined kernel off; 4: only the small ring tiles off
     {"K2HIP_NO_GLU_EPILOGUE", &Tunables::no_glu_epilogue, true},
     {"K2HIP_ATTN_LONG", &Tunables::attn_long, true},
     {"K2HIP_NO_FUSED_AV", &Tunables::no_fused_av, true},
     {"K2HIP_NO_FUSED_VPROJ", &Tunables::no_fused_vproj, true},
-    {"K2HIP_XCD_PANELS", &Tunables::xcd_panels, false},
     {"K2HIP_FUSED_VPROJ_MIN_T", &Tunables::fused_vproj_min_t, false},
+    {"K2HIP_NO_FUSED_CONV", &Tunables::no_fused_conv, true},
     {"K2HIP_CONFORMER_GEMM_SCORES", &Tunables::conformer_gemm_scores, true},
-    {"K2HIP_CONFORMER_STRIP32", &Tunables::conformer_strip32, true},
-    {"K2HIP_CONFORMER_SCATTER_V1", &Tunables::conformer_scatter_v1, true},
-    {"K2HIP_CONFORMER_STAMPS", &Tunables::conformer_stamps, true},
-    {"K2HIP_DW7_SIMPLE", &Tunables::dw7_simple, true},
     {"K2HIP_DW7_TILED", &Tunables::dw7_tiled, true},
-    {"K2HIP_CAUSAL_CONV_LDS", &Tunables::causal_conv_lds, true},
-    {"K2HIP_DW1D_TT", &Tunables::dw1d_tt, false},
     {"K2HIP_LSTM_SEQ", &Tunables::lstm_seq, true},
     {"K2HIP_GREEDY_ONE_PART", &Tunables::greedy_one_part, true},
     {"K2HIP_GREEDY_PARTS", &Tunables::greedy_parts, false},
@@ -86,15 +84,16 @@ const Entry kEntries[] = {
     {"K2HIP_BEAM_PARTS", &Tunables::beam_parts, false},
     {"K2HIP_BEAM_TRACE", &Tunables::beam_trace, true},
     {"K2HIP_SCREEN_MIN_V", &Tunables::screen_min_v, false},
-    {"K2HIP_GREEDY_STAMPS", &Tunables::greedy_stamps, true},
-    {"K2HIP_NO_GRAPHS", &Tunables::no_graphs, true},
-    {"K2HIP_GRAPH_CAPTURE_MODE", &Tunables::graph_capture_mode, false},
-    {"K2HIP_GRAPH_OFFLINE", &Tunables::graph_offline, false},
-    {"K2HIP_GRAPH_STREAMING", &Tunables::graph_streaming, false},
     {"K2HIP_TEST_GREEDY_TIMEOUT", &Tunables::test_greedy_timeout, true},
     {"K2HIP_SEARCH_ROUNDS", &Tunables::search_rounds, false},
-    {"K2HIP_PIPE_MODE", &Tunables::pipe_mode, false},
     {"K2HIP_MAX_STREAMS", &Tunables::max_streams, false},
+#ifdef K2HIP_DEV   // tuning probes: a -DK2HIP_DEV build only (make DEV=1)
+    {"K2HIP_GEMM_CFG", &Tunables::gemm_cfg, false},
+    {"K2HIP_XCD_PANELS", &Tunables::xcd_panels, false},
+    {"K2HIP_DW1D_TT", &Tunables::dw1d_tt, false},
+    {"K2HIP_GREEDY_STAMPS", &Tunables::greedy_stamps, true},
+    {"K2HIP_CONFORMER_STAMPS", &Tunables::conformer_stamps, true},
+#endif
 };
 }  // namespace
 
@@ -106,26 +105,13 @@ void tunables_init_from_env() {
     g_init = true;
     for (const Entry& e : kEntries)
         if (const char* v = getenv(e.env)) g_t.*(e.field) = e.flag ? 1 : atoi(v);
-    // Under rocprofv3 (it announces itself with ROCP_TOOL_LIBRARIES) every launch stays eager: the profiler's kernel tracer of ROCm 7.2
-    // segfaults inside the HIP runtime when a stream it traces is captured into / replayed from a hipGraph (seen on
-    // bench_streaming.py; profiles/README.md).  A profile then shows the eager chain, which is the same kernels.
-    if (getenv("ROCP_TOOL_LIBRARIES") && !getenv("K2HIP_GRAPHS_UNDER_PROFILER")) g_t.no_graphs = 1;
     });
 }
 
 const Tunables& tunables() { return g_t; }
-namespace {
-std::atomic<int> g_generation{0};
-}
-int tunables_generation() { return g_generation.load(std::memory_order_relaxed); }
-
 bool tunables_set(const char* env_name, int value) {
     for (const Entry& e : kEntries)
         if (!strcmp(e.env, env_name)) {
-            // a switch that changes what a chain of launches IS makes every recorded graph one of the old form (the switches that
-            // only say whether graphs are used do not)
-            if (g_t.*(e.field) != value && strncmp(env_name, "K2HIP_NO_GRAPHS", 15) && strncmp(env_name, "K2HIP_GRAPH", 11))
-                g_generation.fetch_add(1, std::memory_order_relaxed);
             g_t.*(e.field) = value;
             return true;
         }

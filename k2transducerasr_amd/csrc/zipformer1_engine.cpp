@@ -21,7 +21,6 @@ const float* Engine::sinus_pos_emb(int Tc, int left, int D) {
     if (it != sinus_cache_.end()) return it->second;
     if (sinus_cache_.size() > 256) {  // many distinct utterance lengths: start over
         synchronize();
-        graphs_clear();   // instantiated graphs hold these pointers
         for (auto& kv : sinus_cache_) (void)hipFree(kv.second);
         sinus_cache_.clear();
     }

@@ -1,10 +1,8 @@
-"""Child process of tests/test_multi_handle_gpu.py::test_streaming_handles_on_host_threads_while_ticks_are_recorded_as_graphs (TEST
+"""Child process of tests/test_multi_handle_gpu.py::test_streaming_handles_on_host_threads (TEST
 INFRASTRUCTURE): the scenario itself; exit code 0 iff every stream of every thread equals the one-handle decode.
 usage: streaming_threads_child.py <model path to write>"""
 import os
 import sys
-
-os.environ["K2HIP_GRAPH_STREAMING"] = "1"   # (read when the first model of the process is created) the ticks here replay from graphs
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 

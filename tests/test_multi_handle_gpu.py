@@ -72,16 +72,13 @@ def test_n_handles_from_n_threads_equal_one_handle(host_exe, tmp_path, preset, t
     m.close()
 
 
-def test_streaming_handles_on_host_threads_while_ticks_are_recorded_as_graphs(tmp_path):
-    """Four OnlineRecognizers, four host threads, one GPU.  A streaming tick is recorded as a hipGraph the second time a stream count
-    is seen; while ANY stream of the process records, the HIP runtime fails every legacy-stream operation of every thread
-    (hipErrorStreamCaptureImplicit) and invalidates the recording.  Found by running this shape: a handle's first tick used to upload
-    its positional table with a plain hipMemcpy while a neighbour recorded -- both calls failed.  The library now keeps all of its
-    blocking transfers on a utility stream of its own (csrc/common.h copy_blocking); here every thread walks through changing
-    stream counts (each one: an eager tick, a recorded one, replays), creates and closes streams, reads states and synchronises
-    while the others do the same, and every stream's tokens must equal the same stream decoded by one handle alone."""
+def test_streaming_handles_on_host_threads(tmp_path):
+    """Four OnlineRecognizers, four host threads, one GPU.  The library keeps all of its blocking transfers on a utility stream of its
+    own per device (csrc/common.h copy_blocking; found in round 4 by running this shape); here every thread walks through changing
+    stream counts, creates and closes streams, reads states and synchronises while the others do the same, and every stream's tokens
+    must equal the same stream decoded by one handle alone."""
     # the scenario lives in tests/streaming_threads_child.py and runs as a child process: a fault of the runtime under five threads of
-    # captures, allocations and frees would otherwise end the whole test session instead of failing this test
+    # allocations and frees would otherwise end the whole test session instead of failing this test
     import sys
     child = os.path.join(ROOT, "tests", "streaming_threads_child.py")
     r = subprocess.run([sys.executable, child, str(tmp_path / "s.k2w")], capture_output=True, text=True, timeout=900,
@@ -89,3 +86,18 @@ def test_streaming_handles_on_host_threads_while_ticks_are_recorded_as_graphs(tm
     print(r.stdout.strip())
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     assert r.stdout.strip().startswith("threads ok:")
+
+
+def test_foreign_legacy_stream_traffic_beside_the_ticks(tmp_path):
+    """Another thread of the HOST process (not this library) keeps issuing legacy-stream copies -- what a plain hipMemcpy or a
+    framework on the default stream does -- while a recognizer decodes through changing stream counts.  The library's streams are
+    non-blocking and it never captures one (the hipGraph replay of rounds 3 - 4 made the runtime refuse such copies while a tick was
+    being recorded; it measured equal to eager enqueue and was removed in round 5), so: no copy is refused, the tokens equal an
+    undisturbed recognizer's, and a crash of the child is a FAILURE, not a skip."""
+    import sys
+    child = os.path.join(ROOT, "tests", "foreign_legacy_child.py")
+    r = subprocess.run([sys.executable, child, str(tmp_path / "s.k2w")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    print(r.stdout.strip())
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    assert "tokens equal: True" in r.stdout and "refused by the runtime: 0" in r.stdout

@@ -639,12 +639,10 @@ def test_value_projection_inside_the_attention_kernel_equals_the_gemm_form(strea
     assert calls >= 3
 
 
-def test_streaming_search_timeout_under_a_replayed_tick_backs_off(tmp_path):
-    """The tick of a large-vocabulary model runs the parted persistent search inside its replayed graph.  A timeout of the slabs' exchange
-    (forced in the hook's "as a real one" form; flipping the hook is a new generation of the switches, so that tick is enqueued eagerly)
-    is noticed when the tick's results come down: the search is repeated with one workgroup per stream from the launch's record, and
-    the engine backs off to the unparted form -- another chain of launches with its own graph key, eager, recorded and replayed in the
-    ticks that follow -- for the next 64 searches.  Tokens, timestamps and Hyp stay on the oracle's through all of it, and the retry
+def test_streaming_search_timeout_backs_off(tmp_path):
+    """The tick of a large-vocabulary model runs the parted persistent search.  A timeout of the slabs' exchange (forced in the hook's
+    "as a real one" form) is noticed when the tick's results come down: the search is repeated with one workgroup per stream from the
+    launch's record, and the engine backs off to the unparted form for the next 64 searches.  Tokens, timestamps and Hyp stay on the oracle's through all of it, and the retry
     counter moves exactly once."""
     import ctypes as C
     from k2transducerasr_amd import OnlineRecognizer, load_library, set_switch
@@ -669,10 +667,9 @@ def test_streaming_search_timeout_under_a_replayed_tick_backs_off(tmp_path):
     nchunks = (feats[0].shape[0] - T) // S + 1
     assert nchunks >= 9
     n0 = retries()
-    set_switch("K2HIP_GRAPH_STREAMING", 1)
     try:
         for k in range(nchunks):
-            set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 2 if k == 4 else 0)   # ticks 0 - 3: eager, recorded, replayed; tick 4 times out
+            set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 2 if k == 4 else 0)   # tick 4 times out
             rec.get_results(hs)
             ora.step(os_, [f[k * S : k * S + T] for f in feats])
             for h, o in zip(hs, os_):
@@ -680,5 +677,4 @@ def test_streaming_search_timeout_under_a_replayed_tick_backs_off(tmp_path):
             assert retries() == n0 + (1 if k >= 4 else 0), k
     finally:
         set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 0)
-        set_switch("K2HIP_GRAPH_STREAMING", 0)
     assert sum(len(o.tokens) - 2 for o in os_) > 0

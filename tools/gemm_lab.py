@@ -90,6 +90,9 @@ if which in ("streaming", "all"):
     for M, D, F, H, nl in ((2048, 192, 512, 4, 2), (1024, 256, 768, 4, 4), (512, 384, 1024, 4, 6), (256, 512, 1536, 8, 4)):
         shapes += [(s[:5], s[5] * nl) for s in layer_shapes(M, D, F, H)]
 cfgs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [-1, 100, 101, 103, 104]
+if len(sys.argv) > 3:  # "MxN,MxN": only these output shapes
+    keep = {tuple(int(v) for v in t.split("x")) for t in sys.argv[3].split(",")}
+    shapes = [s for s in shapes if (s[0][0], s[0][1]) in keep]
 
 
 
