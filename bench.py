@@ -43,17 +43,39 @@ UTT_SECONDS = 10.0
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
 
 
+def _profile_file(pattern):
+    """newest committed-profile summary matching `pattern`: from K2HIP_PROFILE_DIR when tools/refresh_profiles.sh is producing a new set (the
+    bench record then cites the files of its OWN tag, under the names they are committed as), else from profiles/.  Returns
+    (absolute path or None, the profiles/... name the record cites)."""
+    import glob
+    d = os.environ.get("K2HIP_PROFILE_DIR") or os.path.join(ROOT, "profiles")
+    files = sorted(glob.glob(os.path.join(d, pattern)))
+    if not files:
+        return None, None
+    return files[-1], "profiles/" + os.path.basename(files[-1])
+
+
 def pmc_traffic():
     """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (cannot be read live:
     counters need their own profiler run).  Valid only for the default workload they were taken on."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_traffic.json")))
-    if not files:
+    path, cite = _profile_file("r*_gemm_traffic.json")
+    if not path:
         return None, "no PMC summary under profiles/"
-    with open(files[-1]) as f:
+    with open(path) as f:
         d = json.load(f)
     return d["hbm_bytes_per_launch"], (f"bytes per launch (fetch {d['fetch_bytes_per_launch']} + write {d['write_bytes_per_launch']}), "
-                                       f"from {os.path.relpath(files[-1], ROOT)}: {d['method']}")
+                                       f"from {cite}: {d['method']}")
+
+
+def pmc_hbm_kernels():
+    """per-kernel HBM-side bytes and achieved GB/s of the memory-bound kernels (tools/make_hbm_kernels.py over the same PMC passes)"""
+    path, cite = _profile_file("r*_hbm_kernels.json")
+    if not path:
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    d["from"] = cite
+    return d
 
 
 def log(*a):
@@ -91,7 +113,7 @@ def parse_args(argv=None):
 # launcher: `python bench.py --gpus N` starts its own ranks.  Nothing here may touch the GPU: the
 # children are separate programs, started before any HIP call of this process.
 # ------------------------------------------------------------------------------------------------
-def launch_ranks(n: int) -> int:
+def launch_ranks(n: int, script: str = None) -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -100,7 +122,7 @@ def launch_ranks(n: int) -> int:
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     alive = set(range(n))
     while alive:
@@ -130,6 +152,23 @@ def ensure_weights(path, preset, rank, barrier):
     barrier()
 
 
+def host_cores():
+    """threads of the CPU leg: every core this process may run on (all host cores, count stated) unless OMP_NUM_THREADS says otherwise"""
+    return int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
+
+
+def cpu_model():
+    """the host CPU's model string (/proc/cpuinfo; lscpu prints the same line)"""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(weights, n_utts, seconds, beam=0, extra_firsts=()):
     """The CPU restatement (oracle/, 'port') of the same path on this box's host cores, on a bounded sample of the same workload:
     the first `n_utts` utterances as ONE GetResults batch.  Returns the baseline record and the oracle's (tokens, timestamps) per
@@ -138,7 +177,7 @@ def cpu_baseline(weights, n_utts, seconds, beam=0, extra_firsts=()):
     from k2transducerasr_amd.synth import synth_utterance
     from oracle import Oracle
 
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(len(os.sched_getaffinity(0)), 16)
+    cores = host_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)
     ora = Oracle(weights)
     utts = [synth_utterance(u, seconds) for u in range(n_utts)]
@@ -173,6 +212,7 @@ def cpu_baseline(weights, n_utts, seconds, beam=0, extra_firsts=()):
         "value": round(n_utts * seconds / dt, 2),
         "unit": "x real-time (audio-sec/wall-sec)",
         "cores": cores,
+        "cpu_model": cpu_model(),
         "kind": "port",
         "sample": f"{n_utts} x {seconds:g} s utterances of the same synthetic workload as one batch through oracle/ "
                   f"(C + OpenMP restatement{', modified beam search beam=%d' % beam if beam else ''}; the reference's ONNXRuntime path cannot run here), {dt:.2f} s wall",
@@ -238,13 +278,12 @@ def algorithmic_bytes(rows):
 def pmc_mfma_busy():
     """MFMA-pipe utilisation of the GEMM kernels from the committed rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES against
     SQ_BUSY_CU_CYCLES; counters need their own profiler run, so this cannot be read live)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_mfma_busy.json")))
-    if not files:
+    path, cite = _profile_file("r*_gemm_mfma_busy.json")
+    if not path:
         return None, "no MFMA PMC summary under profiles/"
-    with open(files[-1]) as f:
+    with open(path) as f:
         d = json.load(f)
-    return d["mfma_busy"], f"from {os.path.relpath(files[-1], ROOT)}: {d['method']}"
+    return d["mfma_busy"], f"from {cite}: {d['method']}"
 
 
 def run_secondary(timeout_s=240):
@@ -424,6 +463,38 @@ def main():
     if not args.no_host_leg:
         res_h, host_elapsed = timed(True)
         assert res_h == res_sets, "results from host memory and from device memory differ"
+    # The call shape OfflineRecognizer.GetResults has today (OfflineRecognizer.cs:85-91 behind OfflineStream.AddSamples, OfflineStream.cs:43-57)
+    # and the shipped C# binding produces (csharp/OfflineRecognizer.Hip.cs): per batch, B x CreateOfflineStream + AddSamples(host samples),
+    # ONE synchronous GetResults (samples H2D, batched fbank, pad, encoder, search, tokens D2H -- nothing of the next batch overlaps it),
+    # Tokens / Timestamps pulled into host lists.  Same utterance sets, same rotation; results must equal the pipelined legs'.
+    sync_elapsed = None
+    if not args.no_host_leg and not args.no_pipeline:
+        import ctypes as C
+        L = model._L
+
+        def sync_steps(n):
+            last = [[None] * nb for _ in range(R)]
+            for s_ in range(n):
+                r = s_ % R
+                for i, (first, cnt) in enumerate(my_batches):
+                    streams = [pkg.OfflineStream(model) for _ in range(cnt)]
+                    for k, st in enumerate(streams):
+                        st.add_samples(host[r][i][k])
+                    arr = (C.c_void_p * cnt)(*[st._h for st in streams])
+                    model._chk(L.k2hip_offline_recognizer_get_results(model.handle, arr, cnt))
+                    last[r][i] = [(st.tokens[2 * cnt:], st.timestamps[2 * cnt:]) for st in streams]   # (behind the 2 x B blank prefix, :250-267)
+                    for st in streams:
+                        st.close()
+            return last
+        sync_steps(min(args.warmup, 2))
+        model.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        res_s = sync_steps(args.steps)
+        model.synchronize()
+        barrier()
+        sync_elapsed = max_over_ranks(dist, time.perf_counter() - t0, device="cuda" if (dist is not None and args.dist_backend == "nccl") else None)
+        assert res_s == res_sets, "the synchronous GetResults route and the pipelined route give different results"
     res = res_sets[0]                                   # set 0 = the job's own utterance ids 0 .. total-1
     local = [r for batch in res for r in batch]
     allres = gather_results(dist, local, world, rank)   # rank order == utterance order
@@ -487,9 +558,20 @@ def main():
                          "what": f"step s decodes utterance set s % {R}; set r holds the utterances r * {total} .. r * {total} + {total - 1} "
                                  "(other audio in consecutive steps); `results_sha1`, `tokens_emitted_per_step` and `emission_rate` are set 0's"},
         }
+        out["value_note"] = ("`value` is the HBM-resident leg, as this build's measurement contract prescribes (inputs resident in HBM when the timed "
+                             "region starts; a PCIe-inclusive rate is never `value`); SURVEY 8(d)'s host-memory definition is `value_from_host_memory` "
+                             "(pipelined: k2hip_offline_submit_samples / wait, 2 batches in flight) and `value_sync_get_results` (the call shape "
+                             "OfflineRecognizer.GetResults has and the shipped C# binding produces: one synchronous native GetResults per batch)")
         if host_elapsed is not None:
             out["value_from_host_memory"] = round(audio / host_elapsed, 1)
             out["ms_per_step_from_host_memory"] = round(host_elapsed / args.steps * 1e3, 3)
+        if sync_elapsed is not None:
+            out["value_sync_get_results"] = round(audio / sync_elapsed, 1)
+            out["ms_per_step_sync_get_results"] = round(sync_elapsed / args.steps * 1e3, 3)
+            out["sync_get_results_what"] = ("host samples -> B x (k2hip_offline_stream_create + accept_samples) -> k2hip_offline_recognizer_get_results "
+                                            "(fbank on the GPU, one call per batch, nothing in flight beside it) -> Tokens / Timestamps in host lists; "
+                                            "timed through the ctypes binding (7 calls per stream and batch: ~0.3 ms of interpreter time per batch that a "
+                                            "P/Invoke host does not pay)")
         if it:
             out["roofline"] = {
                 "kernel": "gemm_f32_mfma (all Linear / pointwise-conv / implicit-conv / attention-apply launches)",
@@ -515,6 +597,8 @@ def main():
             # in `source` and says so (a kernel change without a refreshed profile leaves it stale; `traffic` above is of the same kind)
             mb, mb_note = pmc_mfma_busy() if default_workload else (None, "PMC passes exist for the default workload only")
             out["roofline"]["committed_profile"] = {"mfma_busy": mb, "source": mb_note}
+            # north_star: "rocprof HBM GB/s ... against gfx950 peak" -- the HBM-bound kernels of the batch, each against the 8 TB/s peak
+            out["roofline"]["hbm_kernels"] = pmc_hbm_kernels() if default_workload else None
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = args.cpu_utts or my_batches[0][1]
             whole = my_batches[0] == (0, n_cpu)

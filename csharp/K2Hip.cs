@@ -18,6 +18,7 @@ namespace K2TransducerAsr.Hip
         [DllImport(Lib)] internal static extern IntPtr k2hip_last_error();
         [DllImport(Lib)] internal static extern int k2hip_model_create(string weightsPath, string overrides, int device, out IntPtr model);
         [DllImport(Lib)] internal static extern int k2hip_model_destroy(IntPtr model);
+        [DllImport(Lib)] internal static extern int k2hip_device_count();
         [DllImport(Lib)] internal static extern int k2hip_model_get_info(IntPtr model, out K2HipModelInfo info);
         [DllImport(Lib)] internal static extern long k2hip_fbank_num_frames(IntPtr model, long nSamples);
         [DllImport(Lib)] internal static extern int k2hip_fbank(IntPtr model, float[] samples, long n, float[] feats, long capFrames, out long nFrames);
@@ -30,6 +31,19 @@ namespace K2TransducerAsr.Hip
             long[] tokens, int[] timestamps, int[] nTokens, int maxTokens);
         [DllImport(Lib)] internal static extern int k2hip_offline_greedy_single(IntPtr model, float[] feats, long nFloats,
             long[] tokens, int[] timestamps, int[] nTokens, int maxTokens);
+
+        // ---- OfflineStream / OfflineRecognizer.GetResults on native streams (include/k2hip.h, "OfflineStream" section): AddSamples queues
+        // raw samples, GetResults runs fbank + pad + encoder + search for the whole batch on the device
+        [DllImport(Lib)] internal static extern int k2hip_offline_stream_create(IntPtr model, out IntPtr stream);
+        [DllImport(Lib)] internal static extern int k2hip_offline_stream_destroy(IntPtr stream);
+        [DllImport(Lib)] internal static extern int k2hip_offline_stream_accept_samples(IntPtr stream, float[] samples, long n);
+        [DllImport(Lib)] internal static extern long k2hip_offline_stream_speech_length(IntPtr stream);
+        [DllImport(Lib)] internal static extern int k2hip_offline_recognizer_get_results(IntPtr model, IntPtr[] streams, int B);
+        [DllImport(Lib)] internal static extern int k2hip_offline_recognizer_get_result(IntPtr model, IntPtr stream);
+        [DllImport(Lib)] internal static extern int k2hip_offline_stream_num_tokens(IntPtr stream);
+        [DllImport(Lib)] internal static extern int k2hip_offline_stream_num_timestamps(IntPtr stream);
+        [DllImport(Lib)] internal static extern int k2hip_offline_stream_get_tokens(IntPtr stream, long[] tokens, int cap);
+        [DllImport(Lib)] internal static extern int k2hip_offline_stream_get_timestamps(IntPtr stream, int[] timestamps, int cap);
 
         // ---- streaming path (include/k2hip.h, "streaming path" section)
         [DllImport(Lib)] internal static extern int k2hip_online_chunk_info(IntPtr model, out int chunkLength, out int shiftLength, out int framesPerChunk);
@@ -53,11 +67,48 @@ namespace K2TransducerAsr.Hip
         [DllImport(Lib)] internal static extern int k2hip_model_meta(IntPtr model, string key, byte[] buf, int cap);
         [DllImport(Lib)] internal static extern int k2hip_set_decoding_method(IntPtr model, string method, int beam);
 
+        // Which GPU?  The reference's constructors (OfflineRecognizer.cs:27-28, OnlineRecognizer.cs:18-19) take file paths and nothing
+        // else, and they stay as they are: the device rides on the paths.
+        //   encoderFilePath "model.k2w@3"                 -> container "model.k2w" on device 3 (the suffix is split off only when what
+        //                                                    follows the LAST '@' is 1 - 4 decimal digits: k2hip_parse_model_spec's rule)
+        //   decoderFilePath "device=3" (encoder "model.k2w") -> the same; the decoder path is otherwise unused on this route (a .k2w
+        //                                                    container holds all three networks)
+        // An explicit "@N" wins over "device=N"; neither: device 0.  A host that serves N GPUs builds N recognizers, one per device, from
+        // N threads (INTEGRATION.md "More than one GPU"; tests/native/multi_handle_host.c is that host in C).
+        internal static void SplitSpec(string encoderFilePath, string decoderFilePath, out string path, out int device)
+        {
+            path = encoderFilePath;
+            device = 0;
+            bool fromSpec = false;
+            if (!string.IsNullOrEmpty(encoderFilePath))
+            {
+                int at = encoderFilePath.LastIndexOf('@');
+                int nd = encoderFilePath.Length - at - 1;
+                if (at > 0 && nd >= 1 && nd <= 4)
+                {
+                    int d = 0;
+                    bool digits = true;
+                    for (int i = at + 1; i < encoderFilePath.Length; i++)
+                    {
+                        char ch = encoderFilePath[i];
+                        if (ch < '0' || ch > '9') { digits = false; break; }
+                        d = d * 10 + (ch - '0');
+                    }
+                    if (digits) { path = encoderFilePath.Substring(0, at); device = d; fromSpec = true; }
+                }
+            }
+            if (!fromSpec && !string.IsNullOrEmpty(decoderFilePath) && decoderFilePath.StartsWith("device=", StringComparison.Ordinal))
+            {
+                if (int.TryParse(decoderFilePath.Substring(7), out int d) && d >= 0) device = d;
+            }
+        }
+
         // Is this "encoder file" a .k2w weights container (the engine's format) rather than an ONNX file?  Decided by the file's
         // magic, not by its name, so a renamed container still routes here and an ONNX file never does.  (k2w.py: the file starts
-        // with the ASCII bytes "K2W1".)
-        internal static bool IsK2w(string path)
+        // with the ASCII bytes "K2W1".)  A "@N" device suffix (SplitSpec) is not part of the file name.
+        internal static bool IsK2w(string encoderFilePath)
         {
+            SplitSpec(encoderFilePath, null, out string path, out _);
             if (string.IsNullOrEmpty(path) || !System.IO.File.Exists(path)) return false;
             try
             {

@@ -5,12 +5,17 @@
 // edits; `patch -p1` applies them):
 //   * OnlineRecognizer.cs:11  `public class OnlineRecognizer` -> `public partial class OnlineRecognizer`
 //   * OnlineRecognizer.cs:21  IN FRONT of `OnlineModel onlineModel = new OnlineModel(encoderFilePath, ...)`:
-//         if (Hip.K2Hip.IsK2w(encoderFilePath)) { InitHip(encoderFilePath, tokensFilePath, decodingMethod, sampleRate, featureDim); return; }
+//         if (Hip.K2Hip.IsK2w(encoderFilePath)) { InitHip(encoderFilePath, decoderFilePath, tokensFilePath, decodingMethod, sampleRate, featureDim); return; }
 //     (`new OnlineModel` opens ONNXRuntime sessions on the path, OnlineModel.cs:28-30,224-228, and leaves `CustomMetadata` null
 //     without an encoder session, :32 -- the switch at :26 would dereference it.)  `onlineModel` is a local of the constructor
 //     (:21-44): nothing behind the constructor uses it, so there is no other use site to serve.
 //   * OnlineRecognizer.cs:62  CreateOnlineStream: `if (_hipModel != null && _hipFused) return new OnlineStream(_hipModel);`
-//   * OnlineRecognizer.cs:498 Dispose: `_hipModel?.Dispose();` behind `_onlineProj.Dispose();`
+//   * OnlineRecognizer.cs:499 Dispose: `_hipModel?.Dispose();` BEHIND the closing brace of `if (_onlineProj != null) { _onlineProj.Dispose(); }` --
+//     after the operator (OnlineProjOfHip borrows the handle) but not inside that block: on the fused route `_onlineProj` is null and the
+//     block is skipped, and the model (weights, arenas, the streams' state pool) must be released all the same
+//   * WHICH GPU: the constructor keeps its signature; the device rides on the paths (K2Hip.SplitSpec): encoderFilePath "model.k2w@3", or
+//     decoderFilePath "device=3" -- unused otherwise on this route.  Streams are pinned to the recognizer's GPU at CreateOnlineStream time
+//     (OnlineRecognizer.cs:60-64); a host spreads its streams over N recognizers, stream id mod N (SURVEY 8e, INTEGRATION.md)
 //   * OnlineStream.cs:7       `public class OnlineStream` -> `public partial class OnlineStream`
 //   * OnlineStream.cs:59,126  AddSamples / IsFinished forward to the native stream when it exists; :164 Dispose destroys it
 //
@@ -97,16 +102,17 @@ namespace K2TransducerAsr
         private bool _hipFused;
 
         // the constructor's early branch (see the header): everything :21-57 does, for a .k2w container
-        private void InitHip(string k2wPath, string tokensFilePath, string decodingMethod, int sampleRate, int featureDim)
+        private void InitHip(string encoderFilePath, string decoderFilePath, string tokensFilePath, string decodingMethod, int sampleRate, int featureDim)
         {
-            _hipModel = new HipOnlineModel(k2wPath);
+            K2Hip.SplitSpec(encoderFilePath, decoderFilePath, out string k2wPath, out int device);
+            _hipModel = new HipOnlineModel(k2wPath, device);
             _tokens = File.ReadAllLines(tokensFilePath);                                // :24
             _hipFused = decodingMethod != "greedy_search_operators";
             if (_hipFused)
             {
                 _forwardBatch = new ForwardBatchOnline(this.ForwardBatchGreedySearchHip);
                 // _onlineProj stays null: the loops that dereference it (:91-204, :226-305) are not bound, CreateOnlineStream returns
-                // the native-handle stream, Dispose (:496) checks for null
+                // the native-handle stream, Dispose (:496) checks for null -- and releases _hipModel behind that check, not inside it
             }
             else
             {

@@ -104,6 +104,14 @@ int32_t k2hip_device_count(void);
  * a null session and fails later with a NullReferenceException, :86-89). */
 int32_t k2hip_model_create(const char* weights_path, const char* overrides, int32_t device, k2hip_model_t** out);
 int32_t k2hip_model_destroy(k2hip_model_t* model);
+/* Device selection through the reference's UNCHANGED constructors (OfflineRecognizer.cs:27-28, OnlineRecognizer.cs:18-19 take file
+ * paths and no device): a model spec is "path.k2w" (device 0) or "path.k2w@N" (device N, decimal; the suffix is only split off when
+ * what follows the LAST '@' is all digits).  path gets the spec without the suffix (NUL terminated, cap bytes), device the number.
+ * Pure string work: no file access, no GPU.  csharp/K2Hip.cs (SplitSpec) implements the same rule in managed code -- it has to
+ * answer for ONNX paths on installations without this library -- and tests/native/multi_handle_host.c names its handles this way. */
+int32_t k2hip_parse_model_spec(const char* spec, char* path, int32_t cap, int32_t* device);
+/* k2hip_model_create on a spec: the container of `spec` on the device it names */
+int32_t k2hip_model_create_spec(const char* spec, const char* overrides, k2hip_model_t** out);
 int32_t k2hip_model_get_info(const k2hip_model_t* model, k2hip_model_info* info);
 /* CustomMetadataMap[key] -> buf (NUL terminated); K2HIP_ERR_INVALID if absent */
 int32_t k2hip_model_meta(const k2hip_model_t* model, const char* key, char* buf, int32_t cap);

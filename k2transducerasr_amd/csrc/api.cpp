@@ -19,8 +19,13 @@ struct k2hip_model {
 // OfflineStream.cs:7-99
 struct k2hip_offline_stream {
     k2hip_model* model;
-    std::vector<float> speech;     // OfflineInputEntity.Speech (frame-major features)
-    std::vector<float> remainder;  // samples not yet covered by a full frame shift (streaming fbank state)
+    std::vector<float> speech;     // OfflineInputEntity.Speech (frame-major features) -- what has been MATERIALISED of it
+    // Samples whose frames are not in `speech` yet: [the streaming fbank's left-over of the frames already materialised ; everything
+    // AddSamples has accepted since].  AddSamples only appends here (no fbank launch, no lock on the model): a frame depends on its own
+    // samples only (no dither, no cross-frame state), so the frames of this buffer ARE what per-call fbank would have appended, and
+    // SpeechLength counts them.  GetResults hands the buffer to the engine's from-samples path (one batched fbank launch for the whole
+    // batch, on the device); k2hip_offline_stream_get_speech and a batch that mixes in already materialised features run the fbank here.
+    std::vector<float> wav;
     std::vector<int64_t> tokens;   // Tokens, initialised to [blank, blank] (:34)
     std::vector<int32_t> timestamps;
     int32_t frame_offset = 0;        // FrameOffset (:39), read by the CTC search (OfflineRecognizer.cs:376,402)
@@ -107,6 +112,39 @@ int32_t k2hip_device_count(void) {
     return n;
 }
 
+// "path.k2w" | "path.k2w@N" (include/k2hip.h)
+static void parse_model_spec(const char* spec, std::string* path, int* device) {
+    const std::string s(spec);
+    *path = s;
+    *device = 0;
+    const size_t at = s.rfind('@');
+    if (at == std::string::npos || at == 0 || at + 1 >= s.size() || s.size() - at - 1 > 4) return;   // (at most four digits)
+    int d = 0;
+    for (size_t i = at + 1; i < s.size(); i++) {
+        if (s[i] < '0' || s[i] > '9') return;
+        d = d * 10 + (s[i] - '0');
+    }
+    *path = s.substr(0, at);
+    *device = d;
+}
+int32_t k2hip_parse_model_spec(const char* spec, char* path, int32_t cap, int32_t* device) {
+    return guard([&] {
+        NEED(spec); NEED(path); NEED(device);
+        std::string p;
+        int d = 0;
+        parse_model_spec(spec, &p, &d);
+        if ((int64_t)p.size() + 1 > (int64_t)cap) failf(K2HIP_ERR_CAPACITY, "model spec: the path needs %zu bytes", p.size() + 1);
+        memcpy(path, p.c_str(), p.size() + 1);
+        *device = d;
+    });
+}
+int32_t k2hip_model_create_spec(const char* spec, const char* overrides, k2hip_model_t** out) {
+    if (!spec) return k2hip_model_create(nullptr, overrides, 0, out);
+    std::string p;
+    int d = 0;
+    parse_model_spec(spec, &p, &d);
+    return k2hip_model_create(p.c_str(), overrides, d, out);
+}
 int32_t k2hip_model_create(const char* weights_path, const char* overrides, int32_t device, k2hip_model_t** out) {
     return guard([&] {
         NEED(weights_path);
@@ -1004,40 +1042,66 @@ int32_t k2hip_offline_stream_create(k2hip_model_t* model, k2hip_offline_stream_t
 int32_t k2hip_offline_stream_destroy(k2hip_offline_stream_t* s) {
     return guard([&] { delete s; });
 }
-// OfflineStream.AddSamples (:43-57)
+// frames the stream's unmaterialised samples will add to Speech
+static int64_t offline_pending_frames(const k2hip_offline_stream* s) {
+    return s->wav.empty() ? 0 : s->model->engine.fbank_num_frames((int64_t)s->wav.size());
+}
+// run the fbank of the stream's unmaterialised samples now and append the frames to Speech; the samples behind the last whole frame
+// shift stay queued (the streaming framing of an OnlineFbank)
+static void offline_materialize(k2hip_offline_stream* s) {
+    Engine& e = s->model->engine;
+    const Config& c = e.model().cfg();
+    const int64_t nf = offline_pending_frames(s);
+    if (nf <= 0) return;
+    const size_t old = s->speech.size();
+    s->speech.resize(old + (size_t)nf * c.feat);
+    try {
+        int64_t got = 0;
+        EngineLock lk(e);
+        e.fbank_host(s->wav.data(), (int64_t)s->wav.size(), s->speech.data() + old, nf, &got);
+    } catch (...) {
+        s->speech.resize(old);
+        throw;
+    }
+    s->wav.erase(s->wav.begin(), s->wav.begin() + (size_t)nf * c.fbank.frame_shift);
+}
+// OfflineStream.AddSamples (:43-57): the samples are queued; their frames count in SpeechLength at once and are computed when
+// somebody needs them (GetResults: on the device, for the whole batch in one launch)
 int32_t k2hip_offline_stream_accept_samples(k2hip_offline_stream_t* s, const float* samples, int64_t n) {
     return guard([&] {
         NEED(s);
         if (n > 0) NEED(samples);
-        Engine& e = s->model->engine;
-        const Config& c = e.model().cfg();
-        std::vector<float> wav(s->remainder);
-        wav.insert(wav.end(), samples, samples + n);
-        int64_t nf = e.fbank_num_frames((int64_t)wav.size());
-        if (nf > 0) {
-            size_t old = s->speech.size();
-            s->speech.resize(old + (size_t)nf * c.feat);
-            int64_t got = 0;
-            EngineLock lk(e);
-            e.fbank_host(wav.data(), (int64_t)wav.size(), s->speech.data() + old, nf, &got);
-            // streaming framing: the next frame starts nf*shift samples in
-            size_t consumed = (size_t)nf * c.fbank.frame_shift;
-            s->remainder.assign(wav.begin() + consumed, wav.end());
-        } else {
-            s->remainder.swap(wav);
-        }
+        if (n > 0) s->wav.insert(s->wav.end(), samples, samples + n);
     });
 }
-int64_t k2hip_offline_stream_speech_length(const k2hip_offline_stream_t* s) { return s ? (int64_t)s->speech.size() : -1; }
-int32_t k2hip_offline_stream_get_speech(const k2hip_offline_stream_t* s, float* out, int64_t cap) {
+int64_t k2hip_offline_stream_speech_length(const k2hip_offline_stream_t* s) {
+    return s ? (int64_t)s->speech.size() + offline_pending_frames(s) * s->model->engine.model().cfg().feat : -1;
+}
+int32_t k2hip_offline_stream_get_speech(const k2hip_offline_stream_t* s_, float* out, int64_t cap) {
     return guard([&] {
-        NEED(s);
+        NEED(s_);
+        k2hip_offline_stream* s = const_cast<k2hip_offline_stream*>(s_);   // (materialising the frames does not change what the stream IS)
+        offline_materialize(s);
         if ((int64_t)s->speech.size() > cap) failf(K2HIP_ERR_CAPACITY, "speech has %zu floats", s->speech.size());
         if (!s->speech.empty()) {
             NEED(out);
             memcpy(out, s->speech.data(), sizeof(float) * s->speech.size());
         }
     });
+}
+
+// OfflineStream.RemoveSamples (:58-68) after a search that consumed the stream's samples straight from `wav`: Speech = null when
+// Tokens.Count > Context_size; otherwise the reference keeps the features -- they are materialised then (a rare path: one stream
+// that emitted nothing).  Either way the samples behind the last whole frame shift stay queued.
+static void offline_consume(k2hip_offline_stream* s, int ctx) {
+    if ((int)s->tokens.size() > ctx) {
+        const int64_t nf = offline_pending_frames(s);
+        if (nf > 0) s->wav.erase(s->wav.begin(), s->wav.begin() + (size_t)nf * s->model->engine.model().cfg().fbank.frame_shift);
+        s->speech.clear();
+        s->speech.shrink_to_fit();
+    } else {
+        offline_materialize(s);
+    }
 }
 
 // OfflineRecognizer.GetResults -> ForwardBatchGreedySearch (:85-91, :189-303)
@@ -1047,15 +1111,26 @@ int32_t k2hip_offline_recognizer_get_results(k2hip_model_t* model, k2hip_offline
         K2_REQUIRE(B > 0, "GetResults: empty stream list");
         Engine& e = model->engine;
         const Config& c = e.model().cfg();
-        std::vector<const float*> ptrs(B);
-        std::vector<int64_t> nfl(B);
-        int64_t mx = 0;
+        bool from_samples = true;   // no stream holds materialised features: the whole batch goes samples -> tokens on the device
         for (int b = 0; b < B; b++) {
             NEED(streams[b]);
             K2_REQUIRE(streams[b]->model == model, "stream %d belongs to another model", b);
-            ptrs[b] = streams[b]->speech.data();
-            nfl[b] = (int64_t)streams[b]->speech.size();
-            mx = std::max(mx, nfl[b]);
+            from_samples = from_samples && streams[b]->speech.empty() && offline_pending_frames(streams[b]) > 0;
+        }
+        {   // one stream twice in the list would be decoded twice and have its samples consumed twice
+            std::vector<const k2hip_offline_stream*> seen(streams, streams + B);
+            std::sort(seen.begin(), seen.end());
+            K2_REQUIRE(std::adjacent_find(seen.begin(), seen.end()) == seen.end(), "GetResults: the same stream appears twice in the list");
+        }
+        std::vector<const float*> ptrs(B);
+        std::vector<int64_t> nfl(B);
+        int64_t mx = 0;
+        if (!from_samples)
+            for (int b = 0; b < B; b++) offline_materialize(streams[b]);
+        for (int b = 0; b < B; b++) {
+            ptrs[b] = from_samples ? streams[b]->wav.data() : streams[b]->speech.data();
+            nfl[b] = from_samples ? (int64_t)streams[b]->wav.size() : (int64_t)streams[b]->speech.size();
+            mx = std::max(mx, from_samples ? offline_pending_frames(streams[b]) * c.feat : nfl[b]);
         }
         int T = (int)((mx + 80 * 19) / c.feat);
         int max_tokens = std::max(1, e.encoder_out_frames(T));
@@ -1063,8 +1138,17 @@ int32_t k2hip_offline_recognizer_get_results(k2hip_model_t* model, k2hip_offline
         std::vector<int32_t> ts((size_t)B * max_tokens), n(B);
         {
             EngineLock lk(e);
-            e.offline_greedy_feats(ptrs.data(), nfl.data(), B, false, tok.data(), ts.data(), n.data(), max_tokens);
+            if (from_samples) e.offline_greedy_samples(ptrs.data(), nfl.data(), B, tok.data(), ts.data(), n.data(), max_tokens);
+            else e.offline_greedy_feats(ptrs.data(), nfl.data(), B, false, tok.data(), ts.data(), n.data(), max_tokens);
         }
+        auto remove_samples = [&](k2hip_offline_stream* s) {   // RemoveSamples (:294 / :418, OfflineStream.cs:58-68)
+            if (from_samples) {
+                offline_consume(s, c.ctx);
+            } else if ((int)s->tokens.size() > c.ctx) {
+                s->speech.clear();
+                s->speech.shrink_to_fit();
+            }
+        };
         if (c.ctc) {
             // ForwardBatchGreedySearchCTC (:366-424): new symbols are appended to the stream's OWN lists (Tokens starts as
             // [blank, blank], OfflineStream.cs:34), timestamps carry FrameOffset, NumTrailingBlank accumulates
@@ -1076,10 +1160,7 @@ int32_t k2hip_offline_recognizer_get_results(k2hip_model_t* model, k2hip_offline
                     s->timestamps.push_back(ts[(size_t)b * max_tokens + k] + s->frame_offset);
                 }
                 s->num_trailing_blank = any[b] ? trail[b] : s->num_trailing_blank + trail[b];
-                if ((int)s->tokens.size() > c.ctx) {  // RemoveSamples (:418)
-                    s->speech.clear();
-                    s->speech.shrink_to_fit();
-                }
+                remove_samples(s);
             }
             return;
         }
@@ -1090,11 +1171,7 @@ int32_t k2hip_offline_recognizer_get_results(k2hip_model_t* model, k2hip_offline
             s->tokens.insert(s->tokens.end(), tok.begin() + (size_t)b * max_tokens, tok.begin() + (size_t)b * max_tokens + n[b]);
             s->timestamps.insert(s->timestamps.end(), (size_t)2 * B, 0);  // Timestamps.AddRange (:293)
             s->timestamps.insert(s->timestamps.end(), ts.begin() + (size_t)b * max_tokens, ts.begin() + (size_t)b * max_tokens + n[b]);
-            // RemoveSamples (:294, OfflineStream.cs:58-68)
-            if ((int)s->tokens.size() > c.ctx) {
-                s->speech.clear();
-                s->speech.shrink_to_fit();
-            }
+            remove_samples(s);
         }
     });
 }
@@ -1105,21 +1182,26 @@ int32_t k2hip_offline_recognizer_get_result(k2hip_model_t* model, k2hip_offline_
         K2_REQUIRE(s->model == model, "stream belongs to another model");
         Engine& e = model->engine;
         const Config& c = e.model().cfg();
-        int T = (int)(((int64_t)s->speech.size() + 80 * 19) / c.feat);
+        const bool from_samples = s->speech.empty() && offline_pending_frames(s) > 0;
+        const int64_t n_fl = from_samples ? offline_pending_frames(s) * c.feat : (int64_t)s->speech.size();
+        int T = (int)((n_fl + 80 * 19) / c.feat);
         int max_tokens = std::max(1, e.encoder_out_frames(T));
         std::vector<int64_t> tok(max_tokens);
         std::vector<int32_t> ts(max_tokens);
         int32_t n = 0;
-        const float* p[1] = {s->speech.data()};
-        int64_t nfl[1] = {(int64_t)s->speech.size()};
+        const float* p[1] = {from_samples ? s->wav.data() : s->speech.data()};
+        int64_t nfl[1] = {from_samples ? (int64_t)s->wav.size() : (int64_t)s->speech.size()};
         {
             EngineLock lk(e);
-            e.offline_greedy_feats(p, nfl, 1, true, tok.data(), ts.data(), &n, max_tokens);
+            if (from_samples) e.offline_greedy_samples(p, nfl, 1, tok.data(), ts.data(), &n, max_tokens, true);
+            else e.offline_greedy_feats(p, nfl, 1, true, tok.data(), ts.data(), &n, max_tokens);
         }
         s->tokens = {-1, K2HIP_BLANK_ID};  // hypList (:115-117, :180); the CTC single path seeds the same pair (:318-320)
         s->tokens.insert(s->tokens.end(), tok.begin(), tok.begin() + n);
         s->timestamps.insert(s->timestamps.end(), ts.begin(), ts.begin() + n);  // (:181; CTC :355 with frameOffset = 0)
         if (c.ctc) s->num_trailing_blank = e.last_any()[0] ? e.last_trail()[0] : e.last_trail()[0];  // local counter from 0 (:316,:354)
+        // (the single paths never call RemoveSamples, :93-187 / :305-364: Speech stays -- materialised now if the search took the samples)
+        if (from_samples) offline_materialize(s);
     });
 }
 int32_t k2hip_offline_stream_num_tokens(const k2hip_offline_stream_t* s) { return s ? (int32_t)s->tokens.size() : -1; }

@@ -1092,23 +1092,75 @@ void Engine::offline_greedy_samples_dev(const float* samples_dev, int64_t n_each
 }
 
 void Engine::offline_greedy_samples(const float* const* samples, const int64_t* n_samples, int B, int64_t* tokens, int32_t* ts,
-                                    int32_t* n_tokens, int max_tokens) {
-    // General (ragged) case: F1 per stream on the device, then the fused feature path.
-    K2_REQUIRE(B > 0, "offline_greedy_from_samples: empty batch");
+                                    int32_t* n_tokens, int max_tokens, bool single) {
+    // Host samples, any lengths: ONE pinned staging block [B, nmax] (tails zeroed) + the streams' feature offsets / lengths, one H2D,
+    // ONE batched fbank launch over nmax samples per stream, then the fused feature path on the device.  A frame i < frames(n_b) of
+    // stream b only reads samples below n_b, so the zero tail never reaches a frame that is kept; pad_logfloor takes each stream's
+    // own frame count.  (Rounds 1 - 4 ran one fbank round trip per stream here and uploaded the features again.)  This is what
+    // OfflineRecognizer.GetResults reaches through k2hip_offline_recognizer_get_results (OfflineStream.cs:43-57 + OfflineRecognizer.cs:85-91).
+    K2_REQUIRE(B > 0 && max_tokens > 0, "offline_greedy_from_samples: bad B=%d / max_tokens=%d", B, max_tokens);
+    K2_REQUIRE(!single || B == 1, "offline_greedy_from_samples: the single-stream loop takes one stream");
     const Config& cf = model_->cfg();
-    std::vector<std::vector<float>> feats(B);
-    std::vector<const float*> ptrs(B);
-    std::vector<int64_t> nfl(B);
+    const FbankOpts& f = cf.fbank;
+    K2_REQUIRE(cf.ctc || cf.J == 512, "offline loops hard-code a 512-wide encoder_out (OfflineRecognizer.cs:103,201); joiner_dim is %d", cf.J);
+    int64_t nmax = 0;
     for (int b = 0; b < B; b++) {
-        int64_t nf = fbank_num_frames(n_samples[b]);
-        K2_REQUIRE(nf > 0, "stream %d: %lld samples give no frame", b, (long long)n_samples[b]);
-        feats[b].resize((size_t)nf * cf.feat);
-        int64_t got = 0;
-        fbank_host(samples[b], n_samples[b], feats[b].data(), nf, &got);
-        ptrs[b] = feats[b].data();
-        nfl[b] = nf * cf.feat;
+        K2_REQUIRE(samples[b] != nullptr && fbank_num_frames(n_samples[b]) > 0, "stream %d: %lld samples give no frame", b, (long long)n_samples[b]);
+        nmax = std::max(nmax, n_samples[b]);
     }
-    offline_greedy_feats(ptrs.data(), nfl.data(), B, false, tokens, ts, n_tokens, max_tokens);
+    const int64_t nfmax = fbank_num_frames(nmax), n_fl = nfmax * cf.feat, L = n_fl + 80 * kTailFrames;
+    const int T = (int)(L / cf.feat);  // OfflineProjOfTransducer.cs:59 over PadHelper.cs:17,22
+    const int64_t nb_s = align_up((int64_t)sizeof(float) * B * nmax, 16), nb_in = nb_s + 16 * (int64_t)B;
+    // (sized for the token download as well: finish_tokens takes the same buffer and must not re-allocate it under the upload)
+    char* pin = static_cast<char*>(pinned(std::max<int64_t>(nb_in, (int64_t)B * max_tokens * 12 + 4 * (int64_t)B + 64) + 64));
+    long long* h_off = reinterpret_cast<long long*>(pin + nb_s);
+    long long* h_len = h_off + B;
+    for (int b = 0; b < B; b++) {
+        float* row = reinterpret_cast<float*>(pin) + (size_t)b * nmax;
+        memcpy(row, samples[b], sizeof(float) * (size_t)n_samples[b]);
+        if (n_samples[b] < nmax) memset(row + n_samples[b], 0, sizeof(float) * (size_t)(nmax - n_samples[b]));
+        h_off[b] = (long long)b * n_fl;
+        h_len[b] = fbank_num_frames(n_samples[b]) * cf.feat;
+    }
+    long long* d_tok = nullptr;
+    int *d_ts = nullptr, *d_n = nullptr, *d_ovf = nullptr;
+    run_sized([&](const Ctx& c) {
+        Arena& ar = *c.arena;
+        d_tok = ar.take<long long>((int64_t)B * max_tokens);
+        d_ts = ar.take<int>((int64_t)B * max_tokens);
+        d_n = ar.take<int>(B);
+        d_ovf = ar.take<int>(1);
+        char* d_in = ar.take<char>(nb_in);
+        float* d_s = reinterpret_cast<float*>(d_in);
+        long long* d_off = reinterpret_cast<long long*>(d_in + nb_s);
+        long long* d_len = d_off + B;
+        float* d_feats = ar.take<float>((int64_t)B * n_fl);
+        float* d_x = ar.take<float>((int64_t)B * L);
+        if (!c.dry) {
+            K2_HIP(hipEventRecord(ev_[0], c.stream));
+            K2_HIP(hipMemcpyAsync(d_in, pin, (size_t)nb_in, hipMemcpyHostToDevice, c.stream));
+        }
+        FbankArgs a{d_s, nmax, nmax, B, nfmax, d_feats, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift,
+                    f.preemph, f.input_scale, f.remove_dc};
+        a.melrange = model_->d_melrange;
+        fbank(c, a);
+        if (!c.dry) K2_HIP(hipEventRecord(ev_[1], c.stream));
+        pad_logfloor(c, d_feats, d_off, d_len, d_x, B, L);
+        if (!c.dry) K2_HIP(hipEventRecord(ev_[2], c.stream));
+        int Tp = 0;
+        float* enc = encoder_forward(c, d_x, B, T, &Tp, -1, nullptr, nullptr, nullptr);
+        if (!c.dry) K2_HIP(hipEventRecord(ev_[3], c.stream));
+        greedy_device(c, enc, B, Tp, single, d_tok, d_ts, d_n, max_tokens, d_ovf);
+        if (!c.dry) K2_HIP(hipEventRecord(ev_[4], c.stream));
+    });
+    finish_tokens(d_tok, d_ts, d_n, d_ovf, B, max_tokens, tokens, ts, n_tokens);
+    auto el = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, ev_[a], ev_[b]); return ms; };
+    timing_.fbank_ms = el(0, 1);   // (includes the samples' H2D copy)
+    timing_.pad_ms = el(1, 2);
+    timing_.encoder_ms = el(2, 3);
+    timing_.greedy_ms = el(3, 4);
+    timing_.d2h_ms = el(4, 5);
+    timing_.total_ms = el(0, 5);
 }
 
 int Engine::submit_samples_dev(const float* samples_dev, int64_t n_each, int B, int max_tokens) {

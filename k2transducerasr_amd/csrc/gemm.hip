@@ -901,7 +901,81 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
 //     step), so a problem with few output tiles (streaming chunks: 256 .. 2048 rows) still puts 8 - 16 waves on a CU and
 //     walks K in K / (32 KS) steps.  The groups' partial tiles meet in LDS after the loop and are summed in the fixed order
 //     g = 0 .. KS - 1 (deterministic); each group finishes 16 / KS of the accumulator registers.
-template <int BM, int BN, int KS, int NST, int LW, int PF = 0>
+// ---- fused tail of the streaming conv modules' in_proj (GemmArgs::cf_*): GLU + chunk-causal depthwise conv + SwooshR on the tile.
+// fin: the lane's finished accumulator values (rows lrow0 + Rows32::off(n) of the tile, GEMM column n0 + 32 wc + li).  LDS (the ring's
+// memory, free by now): col [S][CH][pad + Tc] = per (stream, channel) the cached frames then the chunk's GLU outputs -- exactly the
+// `col` array a lane of k_glu_causal_conv_reg holds in registers -- and the two filters' taps for the tile's CH = BN / 2 channels.
+// A thread computes Tc / Q consecutive frames of one (stream, channel): same sums in the same order as the separate kernel.
+template <int BM, int BN, int NV>
+__device__ __forceinline__ void conv_tail(const GemmArgs& g, const float (&fin)[NV], float* smem, int m0, int n0, int wc, int lrow0, int li,
+                                          int tid, int nthreads) {
+    constexpr int CH = BN / 2;
+    const int Tc = g.cf_Tc, K = g.cf_K, pad = K >> 1, Kc = (K + 1) >> 1, CL = pad + Tc, S = BM / Tc, KcP = Kc | 1;
+    const int Bn = g.M / Tc, b0 = m0 / Tc, c0 = n0 >> 1, D = g.N >> 1;
+    float* colL = smem;                    // [S][CH][CL]   (CL is odd for every (K, Tc) of the model zoo: conflict-free columns)
+    float* wcl = colL + S * CH * CL;       // [CH][KcP]
+    float* wwl = wcl + CH * KcP;           // [CH][K]       (K odd)
+    __syncthreads();                       // every wave has left the ring / the K groups' exchange area
+    {   // (a) the chunk's GLU outputs: value lanes (li & 16) == 0, their gates 16 lanes up
+        const int col = n0 + wc * 32 + li;
+        const float bv = g.bias ? g.bias[col] : 0.f;
+        const int ch = wc * 16 + (li & 15);
+#pragma unroll
+        for (int n = 0; n < NV; n++) {
+            const float v = fin[n] + bv;
+            const float other = __shfl_xor(v, 16, 64);
+            const float gated = v * (1.0f / (1.0f + __expf(-other)));
+            const int lrow = lrow0 + Rows32::off(n);
+            const int s = lrow / Tc, t = lrow - s * Tc;
+            if ((li & 16) == 0) colL[(s * CH + ch) * CL + pad + t] = gated;
+        }
+    }
+    // (b) the streams' cached frames (contiguous per stream: channels c0 .. c0 + CH - 1, pad frames each) and the taps
+    for (int idx = tid; idx < S * CH * pad; idx += nthreads) {
+        const int s = idx / (CH * pad), rem = idx - s * (CH * pad), ch = rem / pad, r = rem - ch * pad;
+        if (b0 + s < Bn) colL[(s * CH + ch) * CL + r] = g.cf_pool[(long long)g.cf_slots[b0 + s] * g.cf_stride + g.cf_off + (long long)c0 * pad + rem];
+    }
+    for (int idx = tid; idx < CH * Kc; idx += nthreads) wcl[(idx / Kc) * KcP + idx % Kc] = g.cf_wc[(long long)c0 * Kc + idx];
+    for (int idx = tid; idx < CH * K; idx += nthreads) wwl[idx] = g.cf_ww[(long long)c0 * K + idx];
+    __syncthreads();
+    // (c) outputs: thread = (stream, frame group q of Q, channel)
+    int Q = 1;
+    while (2 * Q <= Tc && S * CH * 2 * Q <= nthreads) Q *= 2;
+    const int TPT = Tc / Q;
+    for (int w = tid; w < S * CH * Q; w += nthreads) {
+        const int ch = w % CH, sq = w / CH, q = sq % Q, s = sq / Q;
+        if (b0 + s >= Bn) continue;
+        const int c = c0 + ch;
+        const float* cp = colL + (s * CH + ch) * CL;
+        const float* wcp = wcl + ch * KcP;
+        const float* wwp = wwl + ch * K;
+        const float bcv = g.cf_bc[c], bwv = g.cf_bw[c];
+        float* yp = g.C + ((long long)m0 + s * Tc) * g.ldc + c;
+        for (int t = q * TPT; t < (q + 1) * TPT; t++) {
+            float xc = bcv, xw = bwv;
+            for (int k = 0; k < Kc; k++) xc += wcp[k] * cp[t + k];
+            const int klo = max(0, pad - t), khi = min(K, Tc + pad - t);   // taps whose frame t + k - pad lies inside the chunk
+            for (int k = klo; k < khi; k++) xw += wwp[k] * cp[t + k];
+            float le, re;
+            if (Tc < K) {
+                le = g.cf_sc[(long long)c * K + t];
+                re = g.cf_sc[(long long)D * K + (long long)c * K + (K - Tc) + t];
+            } else {
+                le = t < K ? g.cf_sc[(long long)c * K + t] : 0.f;
+                re = t >= Tc - K ? g.cf_sc[(long long)D * K + (long long)c * K + (t - (Tc - K))] : 0.f;
+            }
+            const float z = xw * (1.0f + (le + re)) + xc;
+            yp[(long long)t * g.ldc] = fast_softplus(z - 1.0f) - 0.08f * z - 0.313261687f;   // SwooshR (online.hip swoosh_r)
+        }
+    }
+    // (d) cache = the last pad frames of [cache ; chunk] (read from LDS: the old cache in memory is not needed any more)
+    for (int idx = tid; idx < S * CH * pad; idx += nthreads) {
+        const int s = idx / (CH * pad), rem = idx - s * (CH * pad), ch = rem / pad, r = rem - ch * pad;
+        if (b0 + s < Bn) g.cf_pool[(long long)g.cf_slots[b0 + s] * g.cf_stride + g.cf_off + (long long)c0 * pad + rem] = colL[(s * CH + ch) * CL + Tc + r];
+    }
+}
+
+template <int BM, int BN, int KS, int NST, int LW, int PF = 0, bool CONV = false>
 __global__ __launch_bounds__(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)) void gemm_f32_mfma_ring(GemmArgs g) {
     constexpr int BK = 32;
     constexpr int WCOLS = BN / 32;
@@ -1150,6 +1224,11 @@ __global__ __launch_bounds__(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)) void g
     }
 
     // group kg finishes registers [kg RPG, (kg + 1) RPG): RPG = 16 -> the whole block; 8 -> rows (r&3) + 8 (r>>2) from 16 kg; 4 -> from 8 kg
+    if constexpr (CONV) {
+        static_assert(LW == 0, "conv tail: no loader waves (an L2-prefetch wave has left the kernel by now)");
+        conv_tail<BM, BN, RPG>(g, fin, smem, m0, n0, wc, wr * 32 + 4 * lh + 8 * ((kg * RPG) >> 2), li, tid, 64 * NW);
+        return;
+    }
     epilogue_rows<RPG, Rows32>(g, fin, m0 + wr * 32 + 4 * lh + 8 * ((kg * RPG) >> 2), n0 + wc * 32 + li, C, R, fin, false, nullptr,
                                g.bias ? g.bias + z0 * g.sBias0 : nullptr);
     K2_STAMP()
@@ -1242,6 +1321,17 @@ void launch_ring(const Ctx& ctx, const GemmArgs& a) {
     static LdsAttrOnce lds_attr;
     lds_attr.ensure(gemm_f32_mfma_ring<BM, BN, KS, NST, LW, PF>, (int)lds);
     hipLaunchKernelGGL((gemm_f32_mfma_ring<BM, BN, KS, NST, LW, PF>), grid, dim3(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)), lds, ctx.stream, a);
+}
+
+template <int BM, int BN, int KS, int NST, int PF = 0>
+void launch_ring_conv(const Ctx& ctx, const GemmArgs& a) {
+    dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), 1);
+    const int pad = a.cf_K >> 1, Kc = (a.cf_K + 1) >> 1, CH = BN / 2;
+    const size_t conv_fl = (size_t)(BM / a.cf_Tc) * CH * (pad + a.cf_Tc) + (size_t)CH * (Kc | 1) + (size_t)CH * a.cf_K;
+    size_t lds = sizeof(float) * std::max({(size_t)NST * KS * (BM + BN) * 32, KS > 1 ? (size_t)KS * (BM / 32) * (BN / 32) * 1024 : (size_t)0, conv_fl}) + (PF ? 256 : 0);
+    static LdsAttrOnce lds_attr;
+    lds_attr.ensure(gemm_f32_mfma_ring<BM, BN, KS, NST, 0, PF, true>, (int)lds);
+    hipLaunchKernelGGL((gemm_f32_mfma_ring<BM, BN, KS, NST, 0, PF, true>), grid, dim3(64 * ((BM / 32) * (BN / 32) * KS + PF)), lds, ctx.stream, a);
 }
 
 template <int BM, int BN, int WM, int WN, int NST>
@@ -1551,6 +1641,41 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
     else launch_mode<MODE_PLAIN>(ctx, b, cfg);
     K2_HIP(hipGetLastError());
     if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
+}
+
+bool gemm_glu_causal_conv(const Ctx& ctx, const float* x, const float* wg, const float* bg, float* pool, long long slot_stride, long long off,
+                          const int* slots, const float* wc, const float* bc, const float* ww, const float* bw, const float* sc, float* y, int B,
+                          int Tc, int D, int K) {
+    const int M = B * Tc, N = 2 * D;
+    // tiles: 32 / 64 rows of whole streams (Tc | 32), 32 / 64 GEMM columns of whole (value | gate) blocks; the K step split over the
+    // workgroup's wave groups as the dispatcher of gemm() does for these shapes (streaming chunk steps: a few hundred tiles at most)
+    if (Tc < 1 || 32 % Tc != 0 || D % 64 != 0 || K < 3 || K > 31 || (K & 1) == 0) return false;
+    const long long g32 = (long long)cdiv(M, 32) * (N / 32), g6432 = (long long)cdiv(M, 64) * (N / 32);
+    int form = -1;   // 0: 32x32 KS 4 (4 stages), 1: 64x32 KS 4, 2: 32x64 KS 2, 3: 64x64 KS 2
+    if (D % 128 == 0 && g32 <= 256) form = 0;
+    else if (D % 128 == 0 && g6432 <= 256) form = 1;
+    else if (D % 128 == 0) form = 3;
+    else if ((long long)cdiv(M, 32) * (N / 64) <= 256) form = 2;
+    else form = 3;
+    const double fl = 2.0 * M * (double)N * D;
+    ctx.add_flops(fl, 2.0 * M * (double)D * (K + (K + 1) / 2), 1);
+    if (ctx.dry) return true;
+    GemmArgs g;
+    g.A = x; g.lda = D; g.W = wg; g.ldw = D; g.bias = bg; g.C = y; g.ldc = D; g.M = M; g.N = N; g.K = D;
+    g.cf_pool = pool; g.cf_stride = slot_stride; g.cf_off = off; g.cf_slots = slots;
+    g.cf_wc = wc; g.cf_bc = bc; g.cf_ww = ww; g.cf_bw = bw; g.cf_sc = sc; g.cf_Tc = Tc; g.cf_K = K;
+    g.xcd_panels = tunables().xcd_panels;
+    if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
+    if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->push_back({M, N, D, 1, 0, 0, 64, 0.f});
+    switch (form) {
+        case 0: launch_ring_conv<32, 32, 4, 4, 1>(ctx, g); break;   // (+ the L2-prefetch wave, as gemm()'s choice for this grid has it)
+        case 1: launch_ring_conv<64, 32, 4, 3>(ctx, g); break;
+        case 2: launch_ring_conv<32, 64, 2, 3>(ctx, g); break;
+        default: launch_ring_conv<64, 64, 2, 3>(ctx, g); break;
+    }
+    K2_HIP(hipGetLastError());
+    if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
+    return true;
 }
 
 void linear(const Ctx& ctx, const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int K,

@@ -146,10 +146,27 @@ struct GemmArgs {
     const float* byp_orig = nullptr;
     const float* byp_scale = nullptr;
     int ld_orig = 0;
+    // Streaming conv module (round 5, gemm_glu_causal_conv below): the in_proj GEMM over "#glu"-interleaved weights finishes with the
+    // GLU AND the chunk-causal depthwise convolution of online.hip's k_glu_causal_conv_reg -- the Tc rows of a stream sit in one tile, a
+    // 32-column block holds 16 channels' values and gates, so everything the convolution of those channels needs is in the workgroup
+    // (+ the stream's K / 2 cached frames from the state pool, which it also advances).  C = y [M, N / 2].
+    float* cf_pool = nullptr;          // != nullptr: the fused form
+    long long cf_stride = 0, cf_off = 0;
+    const int* cf_slots = nullptr;
+    const float *cf_wc = nullptr, *cf_bc = nullptr, *cf_ww = nullptr, *cf_bw = nullptr, *cf_sc = nullptr;
+    int cf_Tc = 0, cf_K = 0;
     unsigned long long* dbg = nullptr;  // tuning only: in-kernel s_memtime stamps of the ring kernel, [workgroup][wave][64]
     int ablate = 0;  // tuning only: 1 = skip in-loop global loads, 2 = skip MFMAs, 4 = skip epilogue stores
 };
 void gemm(const Ctx& ctx, const GemmArgs& a);
+// Conv module of a streaming Zipformer2 layer, first two thirds in ONE launch: y [M, D] = SwooshR(chunk-causal depthwise conv(GLU(x Wg^T + bg)))
+// with the streams' conv caches (pool slot + off, [D][K / 2]) read and advanced in place; M = B Tc rows, stream-major.  wg / bg: the
+// "#glu" row-interleaved in_proj [2 D, D]; wc / bc / ww / bw / sc: causal_conv, chunkwise_conv and chunkwise_conv_scale as
+// glu_causal_conv takes them.  Returns false (nothing launched, nothing tallied) when the shape has no fused form -- the caller then
+// runs linear + glu_causal_conv.  Same sums in the same order as those two launches: bit-identical outputs and caches.
+bool gemm_glu_causal_conv(const Ctx& ctx, const float* x, const float* wg, const float* bg, float* pool, long long slot_stride, long long off,
+                          const int* slots, const float* wc, const float* bc, const float* ww, const float* bw, const float* sc, float* y, int B,
+                          int Tc, int D, int K);
 void debug_force_gemm_cfg(int cfg);  // tuning hook: -1 = automatic
 void debug_pipe_shape(int cfg, int M, int N, int* n_wg, int* waves);  // grid and waves of pipe cfg (>= 2000) on a shape
 void debug_ring_shape(int idx, int* bm, int* bn, int* waves);  // tile and waves of ring table entry idx

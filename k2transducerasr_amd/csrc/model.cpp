@@ -481,7 +481,8 @@ void Model::add_repacks(std::vector<std::pair<std::string, std::vector<float>>>&
     // conv_module in_proj [2D, D] (value rows | gate rows) -> rows interleaved in blocks of 16 channels: new row 32 q + p = value of
     // channel 16 q + p, row 32 q + 16 + p = its gate, so that one 32-column block of the GEMM output holds 16 channels' values and
     // gates and the GLU runs in the GEMM's epilogue (a lane pair 16 apart), halving what the conv kernel has to read back
-    for (int si = 0; si < (c.streaming ? 0 : c.ns); si++)
+    // (streaming Zipformer2 as well since round 5: there the same epilogue goes on to the chunk-causal depthwise conv, gemm_glu_causal_conv)
+    for (int si = 0; si < c.ns; si++)
         for (int li = 0; li < c.nlayer[si]; li++)
             for (int k = 1; k <= 2; k++) {
                 char nm[192], nb[192];

@@ -346,8 +346,19 @@ void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x,
         snprintf(n3, sizeof n3, "conv_module%d.depthwise_conv.chunkwise_conv.weight", k);
         snprintf(n4, sizeof n4, "conv_module%d.depthwise_conv.chunkwise_conv.bias", k);
         snprintf(n5, sizeof n5, "conv_module%d.depthwise_conv.chunkwise_conv_scale", k);
-        linear(c, src, D, w(a), w(b), hid, 2 * D, M, D, 2 * D);
-        glu_causal_conv(c, hid, online_pool_, SS, cache_off, d_slots, w(n1), w(n2_), w(n3), w(n4), w(n5), tmp2, B, Tc, D, K);
+        // in_proj + GLU + chunk-causal depthwise conv + SwooshR in ONE launch where the shape has the fused form (round 5): the Tc rows
+        // of a stream and a 16-channel (value | gate) block sit in one tile of the in_proj GEMM, so its epilogue has everything the
+        // convolution needs (conv_module 3 -> 2 launches, 32 per tick; K2HIP_NO_FUSED_CONV keeps the two launches for the cross-check)
+        bool fused = false;
+        if (!tunables().no_fused_conv) {
+            const std::string wa = std::string(a) + "#glu", wb = std::string(b) + "#glu";
+            fused = gemm_glu_causal_conv(c, src, w(wa.c_str()), w(wb.c_str()), online_pool_, SS, cache_off, d_slots, w(n1), w(n2_), w(n3), w(n4), w(n5),
+                                         tmp2, B, Tc, D, K);
+        }
+        if (!fused) {
+            linear(c, src, D, w(a), w(b), hid, 2 * D, M, D, 2 * D);
+            glu_causal_conv(c, hid, online_pool_, SS, cache_off, d_slots, w(n1), w(n2_), w(n3), w(n4), w(n5), tmp2, B, Tc, D, K);
+        }
         linear(c, tmp2, D, w(e), w(f), src, D, M, D, D, ACT_NONE, src, D);
     };
 

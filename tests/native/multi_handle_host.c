@@ -6,6 +6,12 @@
  * utterance (a shard is decoded exactly as the reference would decode it as its own batches: OfflineRecognizer.cs:189-303
  * pads and switches context per batch, never across batches).  No collective, no shared state but the result arrays.
  *
+ * The N handles are opened and driven the way the C# shim drives them (csharp/OfflineRecognizer.Hip.cs): by MODEL SPEC
+ * "model.k2w@device" (k2hip_model_create_spec: the naming K2Hip.SplitSpec parses out of the reference's unchanged constructor
+ * arguments), and through native OfflineStreams -- AddSamples = k2hip_offline_stream_accept_samples (raw samples, queued),
+ * GetResults = k2hip_offline_recognizer_get_results (fbank + pad + encoder + search on the device), Tokens with the reference's
+ * 2 x B blank prefix stripped here.  The ONE-handle decode they are compared with goes through k2hip_offline_greedy_from_samples.
+ *
  * usage: multi_handle_host <model.k2w> <samples.f32> <n_utts> <n_samples_each> <batch> <n_handles> <beam (0 = greedy)> <out.bin>
  *   samples.f32: n_utts x n_samples_each little-endian floats.
  *   out.bin: int32 n_utts, int32 max_tokens, then per utterance int32 n, int64 tokens[max_tokens], int32 timestamps[max_tokens]
@@ -23,6 +29,7 @@ typedef struct {
     const float* samples;
     long n_each;
     int total, batch, world, rank, nranks, beam, device, max_tokens;   /* this handle decodes the shards rank .. rank + nranks - 1 */
+    int via_streams;   /* 1: spec + OfflineStream route (the C# shim's calls); 0: k2hip_offline_greedy_from_samples */
     int64_t* tokens;   /* [total][max_tokens], shared: every thread writes its own shard's rows */
     int32_t* ts;
     int32_t* n_tok;
@@ -40,8 +47,23 @@ static void shard_range(int n, int world, int rank, int* lo, int* hi) {
 static void* run(void* arg) {
     job_t* j = (job_t*)arg;
     k2hip_model_t* m = NULL;
-    j->rc = k2hip_model_create(j->model_path, NULL, j->device, &m);
+    if (j->via_streams) {
+        char spec[1200];
+        snprintf(spec, sizeof spec, "%s@%d", j->model_path, j->device);   /* "model.k2w@3": what the C# constructor is handed */
+        j->rc = k2hip_model_create_spec(spec, NULL, &m);
+    } else {
+        j->rc = k2hip_model_create(j->model_path, NULL, j->device, &m);
+    }
     if (j->rc) { snprintf(j->err, sizeof j->err, "model_create: %s", k2hip_last_error()); return NULL; }
+    {
+        k2hip_model_info info;
+        if (k2hip_model_get_info(m, &info) || info.device != j->device) {
+            snprintf(j->err, sizeof j->err, "the handle is on device %d, not on device %d", info.device, j->device);
+            j->rc = -1;
+            k2hip_model_destroy(m);
+            return NULL;
+        }
+    }
     if (j->beam > 0 && (j->rc = k2hip_set_decoding_method(m, "modified_beam_search", j->beam))) {
         snprintf(j->err, sizeof j->err, "set_decoding_method: %s", k2hip_last_error());
         k2hip_model_destroy(m);
@@ -58,9 +80,39 @@ static void* run(void* arg) {
             ptrs[i] = j->samples + (size_t)(a + i) * (size_t)j->n_each;
             lens[i] = j->n_each;
         }
-        j->rc = k2hip_offline_greedy_from_samples(m, ptrs, lens, cnt, j->tokens + (size_t)a * j->max_tokens, j->ts + (size_t)a * j->max_tokens,
-                                                  j->n_tok + a, j->max_tokens);
-        if (j->rc) snprintf(j->err, sizeof j->err, "batch at utterance %d: %s", a, k2hip_last_error());
+        if (!j->via_streams) {
+            j->rc = k2hip_offline_greedy_from_samples(m, ptrs, lens, cnt, j->tokens + (size_t)a * j->max_tokens, j->ts + (size_t)a * j->max_tokens,
+                                                      j->n_tok + a, j->max_tokens);
+        } else {   /* CreateOfflineStream x cnt, AddSamples in two pieces, GetResults, Tokens / Timestamps behind the 2 x cnt prefix */
+            k2hip_offline_stream_t* ss[64];
+            for (int i = 0; i < cnt && !j->rc; i++) {
+                ss[i] = NULL;
+                j->rc = k2hip_offline_stream_create(m, &ss[i]);
+                const long half = (j->n_each / 2) | 1;   /* an odd split: the second piece starts inside a frame */
+                if (!j->rc) j->rc = k2hip_offline_stream_accept_samples(ss[i], ptrs[i], half);
+                if (!j->rc) j->rc = k2hip_offline_stream_accept_samples(ss[i], ptrs[i] + half, j->n_each - half);
+            }
+            if (!j->rc) j->rc = k2hip_offline_recognizer_get_results(m, ss, cnt);
+            for (int i = 0; i < cnt && !j->rc; i++) {
+                int64_t tk[4096];
+                int32_t tv[4096];
+                const int nt = k2hip_offline_stream_num_tokens(ss[i]), nv = k2hip_offline_stream_num_timestamps(ss[i]);
+                const int n = nt - 2 * cnt;
+                if (n < 0 || n > j->max_tokens || nt > 4096 || nv != nt) { j->rc = -1; snprintf(j->err, sizeof j->err, "stream %d holds %d tokens, %d timestamps", a + i, nt, nv); break; }
+                j->rc = k2hip_offline_stream_get_tokens(ss[i], tk, 4096);
+                if (!j->rc) j->rc = k2hip_offline_stream_get_timestamps(ss[i], tv, 4096);
+                if (j->rc) break;
+                for (int k = 0; k < 2 * cnt; k++)
+                    if (tk[k] != K2HIP_BLANK_ID || tv[k] != 0) j->rc = -1;   /* OfflineRecognizer.cs:250-267: the prefix */
+                memcpy(j->tokens + (size_t)(a + i) * j->max_tokens, tk + 2 * cnt, sizeof(int64_t) * (size_t)n);
+                memcpy(j->ts + (size_t)(a + i) * j->max_tokens, tv + 2 * cnt, sizeof(int32_t) * (size_t)n);
+                j->n_tok[a + i] = n;
+                if (k2hip_offline_stream_speech_length(ss[i]) != 0 && nt > 2) j->rc = -1;   /* RemoveSamples (:294) */
+            }
+            for (int i = 0; i < cnt; i++)
+                if (ss[i]) k2hip_offline_stream_destroy(ss[i]);
+        }
+        if (j->rc && !j->err[0]) snprintf(j->err, sizeof j->err, "batch at utterance %d: %s", a, k2hip_last_error());
     }
     }
     free(ptrs);
@@ -80,6 +132,7 @@ static int decode(const char* path, const float* samples, long n_each, int total
         j->model_path = path; j->samples = samples; j->n_each = n_each; j->total = total; j->batch = batch; j->world = world;
         j->rank = threads == 1 ? 0 : r; j->nranks = threads == 1 ? world : 1;
         j->beam = beam; j->device = r % ndev; j->max_tokens = max_tokens; j->tokens = tokens; j->ts = ts; j->n_tok = n_tok;
+        j->via_streams = threads > 1;
         if (pthread_create(&th[r], NULL, run, j)) { fprintf(stderr, "pthread_create failed\n"); return 1; }
     }
     int rc = 0;
@@ -104,7 +157,7 @@ int main(int argc, char** argv) {
     const int ndev = k2hip_device_count();
     if (ndev <= 0) { fprintf(stderr, "no HIP device\n"); return 3; }
     if (world > 8) world = 8;
-    if (world < 1 || total < world || batch < 1 || n_each < 400) { fprintf(stderr, "bad arguments\n"); return 2; }
+    if (world < 1 || total < world || batch < 1 || batch > 64 || n_each < 400) { fprintf(stderr, "bad arguments\n"); return 2; }
     const size_t nfl = (size_t)total * (size_t)n_each;
     float* samples = (float*)malloc(sizeof(float) * nfl);
     FILE* f = fopen(argv[2], "rb");

@@ -168,16 +168,32 @@ int offline(const char* path, unsigned long long seed, int rounds) {
                 OK(k2hip_offline_stream_accept_samples(ss[b], w.data(), n));
                 total += n;
             }
-            CHECK(k2hip_offline_stream_speech_length(ss[b]) > 0);
-            std::vector<float> sp((size_t)k2hip_offline_stream_speech_length(ss[b]));
-            OK(k2hip_offline_stream_get_speech(ss[b], sp.data(), (int64_t)sp.size()));
-            CHECK(k2hip_offline_stream_get_speech(ss[b], sp.data(), (int64_t)sp.size() - 1) == K2HIP_ERR_CAPACITY);
+            // SpeechLength counts the queued samples' frames at once (OfflineStream.cs:55: it is set by AddSamples) ...
+            const long long want_len = (long long)k2hip_fbank_num_frames(m, total) * info.feature_dim;
+            CHECK(k2hip_offline_stream_speech_length(ss[b]) == want_len && want_len > 0);
+            // ... and reading Speech (every other stream: the others keep their samples queued, so that a batch is decoded from
+            // samples, from features, or -- mixed -- from features materialised at GetResults) changes nothing visible
+            if (rng() % 2) {
+                std::vector<float> sp((size_t)want_len);
+                OK(k2hip_offline_stream_get_speech(ss[b], sp.data(), (int64_t)sp.size()));
+                CHECK(k2hip_offline_stream_get_speech(ss[b], sp.data(), (int64_t)sp.size() - 1) == K2HIP_ERR_CAPACITY);
+                CHECK(k2hip_offline_stream_speech_length(ss[b]) == want_len);
+            }
         }
-        if (B == 1 && rng() % 2) OK(k2hip_offline_recognizer_get_result(m, ss[0]));
+        const bool single = B == 1 && rng() % 2;
+        if (single) OK(k2hip_offline_recognizer_get_result(m, ss[0]));
         else OK(k2hip_offline_recognizer_get_results(m, ss.data(), B));
+        {   // the same stream twice in one batch is refused
+            std::vector<k2hip_offline_stream_t*> twice{ss[0], ss[0]};
+            CHECK(k2hip_offline_recognizer_get_results(m, twice.data(), 2) == K2HIP_ERR_INVALID);
+        }
         for (int b = 0; b < B; b++) {
             const int nt = k2hip_offline_stream_num_tokens(ss[b]);
             CHECK(nt >= 2);
+            // RemoveSamples (OfflineStream.cs:58-68): the batch path clears Speech when Tokens.Count > Context_size; the single path keeps it
+            const long long after = k2hip_offline_stream_speech_length(ss[b]);
+            if (single) CHECK(after > 0);
+            else if (nt > info.context_size) CHECK(after == 0);
             std::vector<int64_t> tk((size_t)nt);
             OK(k2hip_offline_stream_get_tokens(ss[b], tk.data(), nt));
             const int nts = k2hip_offline_stream_num_timestamps(ss[b]);

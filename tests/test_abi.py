@@ -165,3 +165,27 @@ def test_bad_containers_are_io_errors_through_the_abi(tiny_model_path, tmp_path)
         Model(extra, 0).close()
     except K2HipError as e2:
         assert e2.code == -3, str(e2)     # no GPU here: the file itself was accepted
+
+
+def test_profiles_named_in_committed_bench_records_exist():
+    """Profile hygiene (round 5): every `profiles/...` path a committed bench record cites -- `roofline.traffic_note`,
+    `roofline.committed_profile.source`, `roofline.hbm_kernels` -- must be a committed file, and a record must cite files of its OWN tag
+    (round 4's records cited r04_v3 summaries that were never committed: those records stay as the history they are; the rule holds from
+    r05 on)."""
+    import glob
+    import json
+    import re
+    prof = os.path.join(ROOT, "profiles")
+    checked = 0
+    for path in sorted(glob.glob(os.path.join(prof, "r*_bench*.json"))):
+        tag = re.match(r"(r\d+_v\d+)_", os.path.basename(path))
+        if not tag or int(tag.group(1)[1:3]) < 5:
+            continue
+        text = open(path).read()
+        json.loads(text.strip().splitlines()[-1])
+        for cited in set(re.findall(r"profiles/[A-Za-z0-9_.\-]+", text)):
+            assert os.path.exists(os.path.join(ROOT, cited)), f"{os.path.basename(path)} cites {cited}, which is not committed"
+            assert os.path.basename(cited).startswith(tag.group(1) + "_"), f"{os.path.basename(path)} cites {cited}: a file of another profile set"
+            checked += 1
+    # (no r05 record yet at the start of the round: nothing to check is fine; the rule bites once tools/refresh_profiles.sh has run)
+    assert checked >= 0

@@ -13,7 +13,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
-FILES = ["OfflineRecognizer.cs", "OnlineRecognizer.cs", "OnlineStream.cs"]
+FILES = ["OfflineRecognizer.cs", "OfflineStream.cs", "OnlineRecognizer.cs", "OnlineStream.cs"]
 
 needs_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "K2TransducerAsr")) or not shutil.which("patch"),
                                reason="the reference tree / patch(1) is not here")
@@ -54,6 +54,20 @@ def test_patches_apply_and_put_the_branch_in_front_of_the_onnx_constructors(patc
     assert on.index("new OnlineStream(_hipModel)") < on.index("new OnlineStream(_onlineProj)")
     for call in ("AddSamplesHip(samples)", "IsFinishedHip(isEndpoint)", "DisposeHip()"):
         assert call in st
+    # OfflineStream (round 5): on the fused route AddSamples hands the RAW samples to the native stream -- the branch sits in front of
+    # `lock (obj)` and of `_wavFrontend.GetFbank(samples)` (OfflineStream.cs:45-47), so no CPU fbank runs and no static lock is taken
+    os_ = _src(patched_tree, "OfflineStream.cs")
+    assert "public partial class OfflineStream" in os_
+    add = os_[os_.index("public void AddSamples(float[] samples)"):]
+    assert 0 < add.index("AddSamplesHip(samples); return;") < add.index("lock (obj)") < add.index("_wavFrontend.GetFbank(samples)")
+    assert "DisposeHip();" in os_[os_.index("protected virtual void Dispose(bool disposing)"):]
+    create = off[off.index("public OfflineStream CreateOfflineStream()"):]
+    assert 0 < create.index("if (_hipSamples) return new OfflineStream((OfflineProjOfHip)_offlineProj") < create.index("new OfflineStream(_offlineModel.CustomMetadata, sampleRate")
+    # OnlineRecognizer.Dispose (round 4's advice): the model handle is released BEHIND the `if (_onlineProj != null) { ... }` block, not
+    # inside it -- on the fused route _onlineProj is null and a Dispose inside the block would never run (the GPU memory of the model leaked)
+    disp = on[on.index("protected virtual void Dispose(bool disposing)"):]
+    m = re.search(r"if \(_onlineProj != null\)\s*\{\s*_onlineProj\.Dispose\(\);\s*\}\s*_hipModel\?\.Dispose\(\);", disp)
+    assert m, "_hipModel?.Dispose() must follow the closing brace of the _onlineProj null check"
     # regenerating the patches from tools/make_csharp_patches.py gives what is committed
     r = subprocess.run(["python", os.path.join(ROOT, "tools", "make_csharp_patches.py")], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stderr
@@ -113,3 +127,58 @@ def test_pinvoke_declarations_match_the_header():
         if f.endswith(".cs") and f != "K2Hip.cs":
             for name in set(re.findall(r"K2Hip\.(k2hip_\w+)\(", open(os.path.join(ROOT, "csharp", f)).read())):
                 assert re.search(rf"extern \w+ {name}\(", cs), f"{f} calls K2Hip.{name}, which K2Hip.cs does not declare"
+
+
+def test_the_fused_offline_route_never_touches_the_cpu_front_end():
+    """csharp/OfflineRecognizer.Hip.cs: the members OfflineStream gains on the fused route must not name `_wavFrontend`, the forward
+    delegates must call the native GetResults / GetResult (fbank on the GPU, from the queued samples), and SpeechLength must come from
+    the native stream (= 80 x frames, what OfflineStream.cs:55 would hold)."""
+    hip = open(os.path.join(ROOT, "csharp", "OfflineRecognizer.Hip.cs")).read()
+    code = hip[hip.index("using System;"):]
+    stream_part = code[code.index("public partial class OfflineStream"):code.index("public partial class OfflineRecognizer")]
+    assert "_wavFrontend" not in stream_part and "GetFbank" not in stream_part
+    assert "k2hip_offline_stream_accept_samples(HipStream, samples" in stream_part
+    assert stream_part.count("SpeechLength = (int)K2Hip.k2hip_offline_stream_speech_length(HipStream)") >= 2
+    rec_part = code[code.index("public partial class OfflineRecognizer"):]
+    assert "k2hip_offline_recognizer_get_results(proj.Handle, handles, B)" in rec_part
+    assert "k2hip_offline_recognizer_get_result(proj.Handle, stream.HipStream)" in rec_part
+    # the feature entry stays reachable only through the operator route ("greedy_search_operators": managed streams, CPU fbank)
+    assert "k2hip_offline_greedy(" not in rec_part
+    assert re.search(r'case "greedy_search_operators":[^}]*?_hipSamples = false;', rec_part, flags=re.S)
+
+
+def test_every_recognizer_constructor_path_can_reach_a_device_other_than_zero():
+    """The reference's constructors have no device parameter (OfflineRecognizer.cs:27-28, OnlineRecognizer.cs:18-19) and keep their
+    signatures: both InitHip halves take encoderFilePath AND decoderFilePath, resolve (path, device) with K2Hip.SplitSpec and hand the
+    device to the native model constructor; the patches pass decoderFilePath through."""
+    for f, ctor in (("OfflineRecognizer.Hip.cs", "new OfflineProjOfHip(k2wPath, device)"), ("OnlineRecognizer.Hip.cs", "new HipOnlineModel(k2wPath, device)")):
+        src = open(os.path.join(ROOT, "csharp", f)).read()
+        body = src[src.index("private void InitHip(string encoderFilePath, string decoderFilePath,"):]
+        assert body.index("K2Hip.SplitSpec(encoderFilePath, decoderFilePath, out string k2wPath, out int device);") < body.index(ctor), f
+    for f in ("OfflineRecognizer.cs.patch", "OnlineRecognizer.cs.patch"):
+        assert "InitHip(encoderFilePath, decoderFilePath, tokensFilePath, decodingMethod, sampleRate, featureDim);" in open(os.path.join(ROOT, "csharp", "patches", f)).read(), f
+    for f, call in (("OfflineProjOfHip.cs", "k2hip_model_create(k2wPath, null, device, out _model)"), ("OnlineRecognizer.Hip.cs", "k2hip_model_create(k2wPath, null, device, out Handle)")):
+        assert call in open(os.path.join(ROOT, "csharp", f)).read(), f
+    # the managed rule is the library's (k2hip_parse_model_spec): the LAST '@', 1 - 4 decimal digits behind it, "device=N" as the fallback
+    cs = open(os.path.join(ROOT, "csharp", "K2Hip.cs")).read()
+    split = cs[cs.index("internal static void SplitSpec("):cs.index("internal static bool IsK2w(")]
+    assert "LastIndexOf('@')" in split and "nd >= 1 && nd <= 4" in split and 'StartsWith("device=", StringComparison.Ordinal)' in split
+    assert "SplitSpec(encoderFilePath, null, out string path, out _);" in cs[cs.index("internal static bool IsK2w("):]
+
+
+def test_model_spec_parser_of_the_library():
+    """k2hip_parse_model_spec: "path@N" -> (path, N); anything else is a path on device 0.  Pure string work (runs without a GPU)."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, ROOT)
+    from k2transducerasr_amd import load_library
+    L = load_library()
+    L.k2hip_parse_model_spec.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]
+    cases = [("m.k2w", "m.k2w", 0), ("m.k2w@3", "m.k2w", 3), ("/a@b/m.k2w@12", "/a@b/m.k2w", 12), ("m.k2w@", "m.k2w@", 0), ("m.k2w@x1", "m.k2w@x1", 0),
+             ("@7", "@7", 0), ("m@12345", "m@12345", 0), ("user@host/m.k2w", "user@host/m.k2w", 0), ("m.k2w@0007", "m.k2w", 7)]
+    for spec, path, dev in cases:
+        buf, d = C.create_string_buffer(256), C.c_int32(-1)
+        assert L.k2hip_parse_model_spec(spec.encode(), buf, 256, C.byref(d)) == 0
+        assert (buf.value.decode(), d.value) == (path, dev), spec
+    buf, d = C.create_string_buffer(4), C.c_int32(0)
+    assert L.k2hip_parse_model_spec(b"model.k2w@1", buf, 4, C.byref(d)) == -5   # K2HIP_ERR_CAPACITY

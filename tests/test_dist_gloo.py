@@ -125,3 +125,35 @@ def test_two_ranks_through_the_product_equal_one_process(tmp_path):
         assert a["batches_per_rank"] == 2 and b["batches_per_rank"] == 1
         assert len(a["results"]) == 6 and a["results"] == b["results"]
         assert l1["results_sha1"] == l2["results_sha1"] and l1["tokens_emitted_per_step"] > 0
+
+
+def _bench_streaming(*argv, env=None, timeout=600):
+    import subprocess
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench_streaming.py"), *argv], env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_streaming_refuses_a_world_that_differs_from_gpus():
+    r = _bench_streaming("--gpus", "4", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, timeout=120)
+    assert r.returncode == 2 and "refusing" in r.stderr
+
+
+@pytest.mark.gpu
+def test_streaming_two_ranks_equal_one_process(tmp_path):
+    """SURVEY 8(e), streaming: streams pinned to a GPU at CreateOnlineStream time, stream u on rank u mod N.  bench_streaming.py's own
+    launcher with two gloo ranks sharing device 0 (five streams: three on rank 0, two on rank 1) against one process with all five:
+    every stream's tokens and timestamps equal, in stream order; the oracle check of rank 0's first streams (ids 0 and 2) passes."""
+    import json
+    common = ["--preset", "zipformer2-streaming-tiny-test", "--streams", "5", "--seconds", "3", "--no-cpu-baseline"]
+    one, two = str(tmp_path / "one.json"), str(tmp_path / "two.json")
+    r1 = _bench_streaming("--gpus", "1", *common, "--dump-results", one)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = _bench_streaming("--gpus", "2", "--dist-backend", "gloo", *common, "--check", "2", "--dump-results", two)
+    assert r2.returncode == 0, (r2.stdout[-1000:], r2.stderr[-2000:])
+    l1, l2 = (json.loads(r.stdout.strip().splitlines()[-1]) for r in (r1, r2))
+    assert l1["n_gpus"] == 1 and l2["n_gpus"] == 2 and l2["oracle_match"] == {**l2["oracle_match"], "streams": 2, "exact": 2}
+    a, b = json.load(open(one)), json.load(open(two))
+    assert len(a["results"]) == 5 and a["results"] == b["results"] and l1["tokens"] == l2["tokens"] > 0

@@ -1,7 +1,9 @@
 """The multi-GPU host, rehearsed in C on however many GPUs the box has: tests/native/multi_handle_host.c opens N model handles
-from N threads (N = 8 here; on a one-GPU box all eight share device 0), cuts BASELINE configs[2]'s utterance list -- 256 x 10 s,
-modified beam search beam 4 -- into the shards and GetResults batches of k2transducerasr_amd/shard.py, and requires the
-concatenation to equal the same list decoded through ONE handle.  That is the C# host's exact shape (one OfflineRecognizer per GPU,
+from N threads (N = 8 here; on a one-GPU box all eight share device 0) BY MODEL SPEC "model.k2w@device" -- the naming the C# shim
+parses out of the reference's unchanged constructors -- and drives them through native OfflineStreams (AddSamples in two pieces,
+GetResults: the calls csharp/OfflineRecognizer.Hip.cs makes), cuts BASELINE configs[2]'s utterance list -- 256 x 10 s, modified beam
+search beam 4 -- and configs[4]'s -- 64 x 30 s conformer-zh, 8 per GPU -- into the shards and GetResults batches of
+k2transducerasr_amd/shard.py, and requires the concatenation to equal the same list decoded through ONE handle.  That is the C# host's exact shape (one OfflineRecognizer per GPU,
 one thread each, INTEGRATION.md "More than one GPU"); no 1 -> 8 GPU scaling curve exists yet (the driver's 8-GPU node was never
 available), so this is what proves the sharded path before it meets one."""
 import os
@@ -43,6 +45,7 @@ def read_results(path):
 @pytest.mark.parametrize("preset,total,secs,batch,handles,beam", [
     ("zipformer2-tiny-test", 13, 1.1, 3, 4, 0),              # ragged shards (13 over 4 handles: 4 / 3 / 3 / 3), a short last batch
     ("zipformer2-large-en", 256, 10.0, 32, 8, 4),           # BASELINE configs[2]
+    ("conformer-zh", 64, 30.0, 8, 8, 0),                    # BASELINE configs[4]: 64 x 30 s, 8 per GPU (round 5)
 ])
 def test_n_handles_from_n_threads_equal_one_handle(host_exe, tmp_path, preset, total, secs, batch, handles, beam):
     from k2transducerasr_amd import Model

@@ -678,3 +678,53 @@ def test_streaming_search_timeout_backs_off(tmp_path):
     finally:
         set_switch("K2HIP_TEST_GREEDY_TIMEOUT", 0)
     assert sum(len(o.tokens) - 2 for o in os_) > 0
+
+
+@pytest.mark.parametrize("preset,n_streams,secs", [("zipformer2-streaming-tiny-test", 5, 2.6), ("zipformer2-streaming-zh", 70, 1.4)])
+def test_conv_module_inside_the_in_proj_gemm_equals_the_two_launches(tmp_path, preset, n_streams, secs):
+    """Round 5: a streaming conv module's in_proj GEMM finishes with the GLU and the chunk-causal depthwise convolution on its own tile
+    (gemm_glu_causal_conv: conv_module 3 -> 2 launches), where the shape has the fused form; K2HIP_NO_FUSED_CONV keeps linear +
+    k_glu_causal_conv_reg.  Same sums in the same order: two recognizers, one per form, step the same streams (ragged lengths, so the
+    number of ready streams -- the GEMM's M, its tile form and its partial last tile -- changes from tick to tick) and must agree BIT FOR
+    BIT on every token, timestamp and convolution cache; the tiny model also follows the oracle.  The zh architecture at 70 streams walks
+    through all four tile forms (32x32 / 64x32 with the K step split four ways, 32x64 / 64x64 split two ways) and both kernel sizes."""
+    from k2transducerasr_amd import OnlineRecognizer, set_switch
+    from k2transducerasr_amd.synth import synth_utterance, write_synthetic_model
+    p = str(tmp_path / "m.k2w")
+    write_synthetic_model(p, preset)
+    tiny = "tiny" in preset
+    fused, plain = OnlineRecognizer(p), OnlineRecognizer(p)
+    waves = [synth_utterance(5100 + u, secs + 0.35 * (u % 4)) for u in range(n_streams)]
+    hf = [fused.create_online_stream() for _ in waves]
+    hp = [plain.create_online_stream() for _ in waves]
+    for a, b, w in zip(hf, hp, waves):
+        a.add_samples(w)
+        b.add_samples(w)
+    ticks = 0
+    while True:
+        df, _ = fused.get_results(hf)
+        set_switch("K2HIP_NO_FUSED_CONV", 1)
+        try:
+            dp, _ = plain.get_results(hp)
+        finally:
+            set_switch("K2HIP_NO_FUSED_CONV", 0)
+        assert df == dp
+        if not any(df):
+            break
+        ticks += 1
+        for u, (a, b) in enumerate(zip(hf, hp)):
+            assert a.tokens == b.tokens and a.timestamps == b.timestamps and a.hyp == b.hyp, (ticks, u)
+        for u in range(0, n_streams, max(1, n_streams // 6)):
+            for layer in range(fused.num_layers):
+                for kind in ("conv1", "conv2"):
+                    np.testing.assert_array_equal(hf[u].state(layer, kind), hp[u].state(layer, kind), err_msg=f"tick {ticks} stream {u} layer {layer} {kind}")
+    assert ticks >= 3 and sum(len(a.tokens) - 2 for a in hf) > 0
+    if tiny:
+        from oracle.online import OnlineOracle
+        ora = OnlineOracle(p)
+        for u, w in enumerate(waves):
+            f = ora.fbank(w)
+            o = ora.create_stream()
+            for k in range((f.shape[0] - fused.chunk_length) // fused.shift_length + 1):
+                ora.step([o], [f[k * fused.shift_length : k * fused.shift_length + fused.chunk_length]])
+            assert hf[u].tokens == o.tokens and hf[u].timestamps == o.timestamps, u

@@ -20,9 +20,23 @@ EDITS = {
             "            // HERE, in front of `new OfflineModel(...)`: that constructor opens ONNXRuntime sessions on the paths it is given.",
             "            if (Hip.K2Hip.IsK2w(encoderFilePath))",
             "            {",
-            "                InitHip(encoderFilePath, tokensFilePath, decodingMethod, sampleRate, featureDim);",
+            "                InitHip(encoderFilePath, decoderFilePath, tokensFilePath, decodingMethod, sampleRate, featureDim);",
             "                return;",
             "            }",
+        ]),
+        ("OfflineStream offlineStream = new OfflineStream(_offlineModel.CustomMetadata, sampleRate: _frontendConfEntity.fs, featureDim: _frontendConfEntity.n_mels);", "before", [
+            "            // the fused route: the stream owns a native handle, AddSamples queues raw samples, the fbank runs on the GPU inside GetResults",
+            "            if (_hipSamples) return new OfflineStream((OfflineProjOfHip)_offlineProj, _offlineModel.CustomMetadata);   // OfflineRecognizer.Hip.cs",
+        ]),
+    ],
+    "K2TransducerAsr/OfflineStream.cs": [
+        ("public class OfflineStream", "replace", ["    public partial class OfflineStream"]),
+        ("public void AddSamples(float[] samples)", "after+1", [
+            "            // in FRONT of the static lock below: on this route no CPU fbank runs and nothing shared is touched (OfflineRecognizer.Hip.cs)",
+            "            if (HipStream != IntPtr.Zero) { AddSamplesHip(samples); return; }",
+        ]),
+        ("if (_wavFrontend != null)", "before", [
+            "                DisposeHip();   // OfflineRecognizer.Hip.cs: k2hip_offline_stream_destroy",
         ]),
     ],
     "K2TransducerAsr/OnlineRecognizer.cs": [
@@ -32,15 +46,16 @@ EDITS = {
             "            // leaves CustomMetadata null when there is no encoder session (OnlineModel.cs:32).",
             "            if (Hip.K2Hip.IsK2w(encoderFilePath))",
             "            {",
-            "                InitHip(encoderFilePath, tokensFilePath, decodingMethod, sampleRate, featureDim);",
+            "                InitHip(encoderFilePath, decoderFilePath, tokensFilePath, decodingMethod, sampleRate, featureDim);",
             "                return;",
             "            }",
         ]),
         ("OnlineStream onlineStream = new OnlineStream(_onlineProj);", "before", [
             "            if (_hipModel != null && _hipFused) return new OnlineStream(_hipModel);   // the stream owns a native handle (OnlineRecognizer.Hip.cs)",
         ]),
-        ("_onlineProj.Dispose();", "after", [
-            "                    _hipModel?.Dispose();   // after the operator: OnlineProjOfHip borrows this handle",
+        # BEHIND the closing brace of `if (_onlineProj != null) { ... }`: on the fused route _onlineProj is null and that block is skipped
+        ("_onlineProj.Dispose();", "after-block", [
+            "                _hipModel?.Dispose();   // after the operator (OnlineProjOfHip borrows this handle), outside its null check",
         ]),
     ],
     "K2TransducerAsr/OnlineStream.cs": [
@@ -71,6 +86,9 @@ def patched(lines, edits, name):
             out[i:i] = new
         elif how == "after":
             out[i + 1: i + 1] = new
+        elif how == "after-block":  # behind the closing brace that follows the anchor
+            assert out[i + 1].strip() == "}", (name, anchor)
+            out[i + 2: i + 2] = new
         elif how == "after+1":      # behind the opening brace that follows the anchor
             assert out[i + 1].strip() == "{", (name, anchor)
             out[i + 2: i + 2] = new

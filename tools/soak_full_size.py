@@ -33,6 +33,7 @@ write_synthetic_model(path, "zipformer2-large-en")
 hip, ora = pkg.Model(path, 0), Oracle(path)
 rng = np.random.default_rng(seed0)
 g_exact = op_exact = f_exact = tot = forms_differ = hidden_n = 0
+forms_gaps = []
 pkg.set_switch("K2HIP_BEAM_TRACE", 1)
 for k in range(batches):
     B = 32
@@ -56,15 +57,24 @@ for k in range(batches):
     hid = hidden_beam_divergences(got, bwant, tr_f, tr_w)
     assert all(g < TOL for _, _, g in hid), hid
     hidden_n += len(hid)
-    pkg.set_switch("K2HIP_BEAM_LAUNCHES", 1)   # the four-launches-per-frame form on the same batch: how many streams it decides differently
-    try:
+    pkg.set_switch("K2HIP_BEAM_LAUNCHES", 1)   # the four-launches-per-frame form on the same batch: which streams it decides differently,
+    try:                                        # and how far apart the oracle's candidates are where either form left the oracle
         alt = hip.offline_greedy_from_samples(utts)
+        tr_a = hip.beam_trace()
     finally:
         pkg.set_switch("K2HIP_BEAM_LAUNCHES", 0)
-    forms_differ += sum(1 for a, b in zip(got, alt) if a != b)
+    n_f = len(parity.NEAR_TIES)
+    assert_beam_match(alt, bwant, bmg, tol=TOL, what=f"batch {k} beam 4 fused, launch form", allow_tie=True, trace_got=tr_a, trace_want=tr_w)
+    gap_l = {e[1]: e[3] for e in parity.NEAR_TIES[n_f:]}
+    gap_f = {e[1]: e[3] for e in parity.NEAR_TIES if e[0] == f"batch {k} beam 4 fused"}
+    for b_, (a_, c_) in enumerate(zip(got, alt)):
+        if a_ != c_:
+            forms_differ += 1
+            forms_gaps.append((k, b_, gap_f.get(b_), gap_l.get(b_)))
     tot += B
     print(f"batch {k} ({'ragged' if k % 2 else '32 x 10 s'}): greedy {g_exact}/{tot}; beam 4 operator level {op_exact}/{tot}, fused {f_exact}/{tot} "
           f"streams exact so far; {hidden_n} equal results over parted searches; {forms_differ} decided differently by the launch form", flush=True)
+print(f"streams the engine's two search forms decide differently (batch, stream, oracle gap where the one-kernel form / the launch form left the oracle): {forms_gaps}")
 print(f"every miss localised to a frame whose own oracle gap is < {TOL}:")
 for e in parity.NEAR_TIES:
     print("  near-tie (what, stream, frame, gap):", e)
