@@ -153,8 +153,25 @@ def ensure_weights(path, preset, rank, barrier):
 
 
 def host_cores():
-    """threads of the CPU leg: every core this process may run on (all host cores, count stated) unless OMP_NUM_THREADS says otherwise"""
-    return int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
+    """threads of the CPU leg: every core this process may USE (all host cores, count stated) unless OMP_NUM_THREADS says
+    otherwise -- the affinity mask, cut to the cgroup's CPU quota where one is set, and to the GPU box's CPU share of 16 cores per visible
+    GPU (a one-GPU lease of a many-core host shows the host's whole mask: 200 OpenMP threads spinning on a 16-core share do not finish)"""
+    if int(os.environ.get("OMP_NUM_THREADS", "0")) > 0:
+        return int(os.environ["OMP_NUM_THREADS"])
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    try:
+        import k2transducerasr_amd as pkg
+        n_gpu = max(1, pkg.load_library().k2hip_device_count())
+    except Exception:  # noqa: BLE001 -- no library / no GPU: the CPU container
+        n_gpu = 1
+    return max(1, min(n, 16 * n_gpu))
 
 
 def cpu_model():
@@ -458,9 +475,11 @@ def main():
         el = time.perf_counter() - t0
         return r, max_over_ranks(dist, el, device="cuda" if (dist is not None and args.dist_backend == "nccl") else None)
 
+    log(f"[bench] rank {rank}: timed leg, samples resident in HBM")
     res_sets, elapsed = timed(False)
     host_elapsed = None
     if not args.no_host_leg:
+        log(f"[bench] rank {rank}: timed leg, samples in host memory (pipelined)")
         res_h, host_elapsed = timed(True)
         assert res_h == res_sets, "results from host memory and from device memory differ"
     # The call shape OfflineRecognizer.GetResults has today (OfflineRecognizer.cs:85-91 behind OfflineStream.AddSamples, OfflineStream.cs:43-57)
@@ -486,6 +505,7 @@ def main():
                     for st in streams:
                         st.close()
             return last
+        log(f"[bench] rank {rank}: timed leg, synchronous GetResults from host samples")
         sync_steps(min(args.warmup, 2))
         model.synchronize()
         barrier()
@@ -602,6 +622,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = args.cpu_utts or my_batches[0][1]
             whole = my_batches[0] == (0, n_cpu)
+            log(f"[bench] CPU restatement on {host_cores()} host threads ({cpu_model()})")
             cb, ores, ores_extra, logits_ref = cpu_baseline(weights, n_cpu, secs, args.beam, [r * total for r in range(1, R)] if whole else [])
             out["cpu_baseline"] = cb
             # the oracle's results for the sample against what the timed legs returned for the same batch (outside the timed region);

@@ -3,6 +3,7 @@
 // OfflineRecognizer.cs:77-91,289-296).
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <new>
 
 #include "text.h"
@@ -13,6 +14,12 @@ using namespace k2hip;
 
 struct k2hip_model {
     Engine engine;
+    // Sample buffers of destroyed OfflineStreams, handed to the next streams (a GetResults batch is B x create / AddSamples / destroy
+    // of ~640 KB each: a fresh std::vector per stream pays a first-touch page fault per 4 KB -- ~1 ms per 32 x 10 s batch on the host
+    // thread that drives the GPU).  At most kPoolMax buffers are kept.
+    static constexpr size_t kPoolMax = 128;
+    std::mutex wav_mu;
+    std::vector<std::vector<float>> wav_pool;
     k2hip_model(const char* path, const char* ov, int dev) : engine(path, ov, dev) {}
 };
 
@@ -1040,7 +1047,16 @@ int32_t k2hip_offline_stream_create(k2hip_model_t* model, k2hip_offline_stream_t
     });
 }
 int32_t k2hip_offline_stream_destroy(k2hip_offline_stream_t* s) {
-    return guard([&] { delete s; });
+    return guard([&] {
+        if (s && s->wav.capacity() > 0) {   // the buffer goes back to the model's pool (touched pages: no first-touch faults next time)
+            std::lock_guard<std::mutex> lk(s->model->wav_mu);
+            if (s->model->wav_pool.size() < k2hip_model::kPoolMax) {
+                s->wav.clear();
+                s->model->wav_pool.push_back(std::move(s->wav));
+            }
+        }
+        delete s;
+    });
 }
 // frames the stream's unmaterialised samples will add to Speech
 static int64_t offline_pending_frames(const k2hip_offline_stream* s) {
@@ -1071,7 +1087,18 @@ int32_t k2hip_offline_stream_accept_samples(k2hip_offline_stream_t* s, const flo
     return guard([&] {
         NEED(s);
         if (n > 0) NEED(samples);
-        if (n > 0) s->wav.insert(s->wav.end(), samples, samples + n);
+        if (n <= 0) return;
+        if (s->wav.capacity() == 0) {   // first samples of the stream: a buffer of the model's pool that is large enough, if there is one
+            std::lock_guard<std::mutex> lk(s->model->wav_mu);
+            auto& pool = s->model->wav_pool;
+            for (size_t i = pool.size(); i-- > 0;)
+                if (pool[i].capacity() >= (size_t)n) {
+                    s->wav = std::move(pool[i]);
+                    pool.erase(pool.begin() + (long)i);
+                    break;
+                }
+        }
+        s->wav.insert(s->wav.end(), samples, samples + n);
     });
 }
 int64_t k2hip_offline_stream_speech_length(const k2hip_offline_stream_t* s) {

@@ -1,4 +1,6 @@
 #include <cstring>
+#include <thread>
+
 #include "engine.h"
 
 #include <climits>
@@ -1115,10 +1117,26 @@ void Engine::offline_greedy_samples(const float* const* samples, const int64_t* 
     char* pin = static_cast<char*>(pinned(std::max<int64_t>(nb_in, (int64_t)B * max_tokens * 12 + 4 * (int64_t)B + 64) + 64));
     long long* h_off = reinterpret_cast<long long*>(pin + nb_s);
     long long* h_len = h_off + B;
+    auto stage = [&](int b_lo, int b_hi) {
+        for (int b = b_lo; b < b_hi; b++) {
+            float* row = reinterpret_cast<float*>(pin) + (size_t)b * nmax;
+            memcpy(row, samples[b], sizeof(float) * (size_t)n_samples[b]);
+            if (n_samples[b] < nmax) memset(row + n_samples[b], 0, sizeof(float) * (size_t)(nmax - n_samples[b]));
+        }
+    };
+    // 20 MB for a 32 x 10 s batch: one host thread copies it in ~2 ms (a seventh of the whole call); four do it in ~0.5 ms
+    const int64_t stage_bytes = (int64_t)sizeof(float) * B * nmax;
+    const int helpers = stage_bytes >= (4 << 20) ? std::min(3, B - 1) : 0;
+    if (helpers > 0) {
+        std::vector<std::thread> th;
+        const int per = (B + helpers) / (helpers + 1);
+        for (int h = 1; h <= helpers; h++) th.emplace_back(stage, std::min(B, h * per), std::min(B, (h + 1) * per));
+        stage(0, std::min(B, per));
+        for (auto& t : th) t.join();
+    } else {
+        stage(0, B);
+    }
     for (int b = 0; b < B; b++) {
-        float* row = reinterpret_cast<float*>(pin) + (size_t)b * nmax;
-        memcpy(row, samples[b], sizeof(float) * (size_t)n_samples[b]);
-        if (n_samples[b] < nmax) memset(row + n_samples[b], 0, sizeof(float) * (size_t)(nmax - n_samples[b]));
         h_off[b] = (long long)b * n_fl;
         h_len[b] = fbank_num_frames(n_samples[b]) * cf.feat;
     }

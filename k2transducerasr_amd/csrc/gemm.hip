@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -903,77 +904,193 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
 //     g = 0 .. KS - 1 (deterministic); each group finishes 16 / KS of the accumulator registers.
 // ---- fused tail of the streaming conv modules' in_proj (GemmArgs::cf_*): GLU + chunk-causal depthwise conv + SwooshR on the tile.
 // fin: the lane's finished accumulator values (rows lrow0 + Rows32::off(n) of the tile, GEMM column n0 + 32 wc + li).  LDS (the ring's
-// memory, free by now): col [S][CH][pad + Tc] = per (stream, channel) the cached frames then the chunk's GLU outputs -- exactly the
-// `col` array a lane of k_glu_causal_conv_reg holds in registers -- and the two filters' taps for the tile's CH = BN / 2 channels.
-// A thread computes Tc / Q consecutive frames of one (stream, channel): same sums in the same order as the separate kernel.
-template <int BM, int BN, int NV>
-__device__ __forceinline__ void conv_tail(const GemmArgs& g, const float (&fin)[NV], float* smem, int m0, int n0, int wc, int lrow0, int li,
-                                          int tid, int nthreads) {
-    constexpr int CH = BN / 2;
-    const int Tc = g.cf_Tc, K = g.cf_K, pad = K >> 1, Kc = (K + 1) >> 1, CL = pad + Tc, S = BM / Tc, KcP = Kc | 1;
-    const int Bn = g.M / Tc, b0 = m0 / Tc, c0 = n0 >> 1, D = g.N >> 1;
+// memory, free by now): col [S][CH][CL] = per (stream, channel) the cached frames then the chunk's GLU outputs -- exactly the `col` array
+// a lane of k_glu_causal_conv_reg holds in registers -- and the two filters' taps for the tile's CH = BN / 2 channels.
+// A thread computes TPT consecutive frames of one (stream, channel) from REGISTERS: its TPT + K - 1 column values and its channel's taps
+// are read from LDS once (the first version read two LDS words per FMA: 47 x 2 per output, LDS-bound at ~3 us per tile).  Same sums in
+// the same order as the separate kernel.  Tc, CH and TPT are powers of two (shifts; an integer division costs ~40 instructions).
+// What the tail needs from memory, requested BEFORE the K loop so that its latencies (the streams' slot indexes, then their cached
+// frames; the taps; the scale rows) lie under the GEMM instead of behind it -- three dependent round trips were ~2.5 us of a 12 us launch.
+template <int BM, int BN, int NTHR>
+struct ConvPre {
+    static constexpr int CH = BN / 2, lgCH = CH == 16 ? 4 : 5, TPT0 = BM * CH / NTHR;
+    static_assert((CH == 16 || CH == 32) && (TPT0 == 2 || TPT0 == 4), "conv tail: tile form");
+    float cv[8], wv[4], uv[4], le[TPT0], re[TPT0], bias, bcv, bwv;
+    int slot, lgTc, pad, Kc, npc, lgTPS, cs, cr;
+    bool live, full;   // full: every thread owns TPT0 frames of one (stream, channel) (Tc >= TPT0): le / re / bcv / bwv are prefetched
+    // independent loads (before the DMA prologue): slot index, taps, biases, scale rows
+    __device__ __forceinline__ void first(const GemmArgs& g, int tid, int m0, int n0, int col) {
+        const int Tc = g.cf_Tc, K = g.cf_K, D = g.N >> 1, c0 = n0 >> 1;
+        lgTc = 31 - __builtin_clz(Tc);
+        pad = K >> 1;
+        Kc = (K + 1) >> 1;
+        npc = CH * pad;
+        const int lgS = (BM == 64 ? 6 : 5) - lgTc;
+        lgTPS = (NTHR == 512 ? 9 : 8) - lgS;
+        cs = tid >> lgTPS;
+        cr = tid & ((1 << lgTPS) - 1);
+        const int b0 = m0 >> lgTc, Bn = g.M >> lgTc;
+        live = b0 + cs < Bn;
+        slot = live ? g.cf_slots[b0 + cs] : 0;
+        bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = tid + u * NTHR;
+            wv[u] = idx < CH * Kc ? g.cf_wc[(long long)c0 * Kc + idx] : 0.f;
+            uv[u] = idx < CH * K ? g.cf_ww[(long long)c0 * K + idx] : 0.f;
+        }
+        full = Tc >= TPT0;
+        if (full) {   // this thread's outputs: (stream, frame group q, channel) as conv_outputs<K, TPT0> maps them
+            const int lgQ = lgTc - (TPT0 == 2 ? 1 : 2), ch = tid & (CH - 1), q = (tid >> lgCH) & ((1 << lgQ) - 1), c = c0 + ch, tq = q * TPT0;
+            bcv = g.cf_bc[c];
+            bwv = g.cf_bw[c];
+#pragma unroll
+            for (int i = 0; i < TPT0; i++) {
+                const int t = tq + i, il = min(t, K - 1), ir = min(max(t - (Tc - K), 0), K - 1);
+                const float lv = g.cf_sc[(long long)c * K + il], rv = g.cf_sc[(long long)D * K + (long long)c * K + ir];
+                le[i] = t < K ? lv : 0.f;
+                re[i] = t >= Tc - K ? rv : 0.f;
+            }
+        }
+    }
+    // the streams' cached frames (the slot index has arrived by now: behind the prologue's first barrier)
+    __device__ __forceinline__ void second(const GemmArgs& g, int n0) {
+        const float* cbase = g.cf_pool + (long long)slot * g.cf_stride + g.cf_off + (long long)(n0 >> 1) * pad;
+#pragma unroll
+        for (int u = 0; u < 8; u++) cv[u] = (live && cr + (u << lgTPS) < npc) ? cbase[cr + (u << lgTPS)] : 0.f;
+    }
+};
+
+template <int KT, int TPT, typename PRE>
+__device__ __forceinline__ void conv_outputs(const GemmArgs& g, const PRE& pre, bool use_pre, const float* colL, const float* wcl, const float* wwl, int CL,
+                                             int KcP, int lgTc, int lgCH, int S, int Bn, int b0, int c0, int m0, int D, int tid, int nthreads) {
+    constexpr int K = KT, pad = K >> 1, Kc = (K + 1) >> 1;
+    const int Tc = 1 << lgTc, CH = 1 << lgCH, lgQ = lgTc - (TPT == 1 ? 0 : TPT == 2 ? 1 : TPT == 4 ? 2 : 3), Q = 1 << lgQ;
+    for (int w = tid; w < (S << (lgCH + lgQ)); w += nthreads) {
+        const int ch = w & (CH - 1), sq = w >> lgCH, q = sq & (Q - 1), s = sq >> lgQ;
+        if (b0 + s >= Bn) continue;
+        const int c = c0 + ch, tq = q * TPT;
+        const float* cp = colL + ((s << lgCH) + ch) * CL + tq;
+        float col[TPT + K - 1], wc[Kc], ww[K];
+#pragma unroll
+        for (int j = 0; j < TPT + K - 1; j++) col[j] = tq + j < CL ? cp[j] : 0.f;   // (frames past the chunk: only ever met by masked taps)
+#pragma unroll
+        for (int k = 0; k < Kc; k++) wc[k] = wcl[ch * KcP + k];
+#pragma unroll
+        for (int k = 0; k < K; k++) ww[k] = wwl[ch * K + k];
+        // chunkwise_conv_scale (k_glu_causal_conv_reg's le / re) and the two biases: prefetched before the K loop where the thread's
+        // outputs were known then (use_pre), else unconditional loads from clamped indexes, all in flight together
+        float le[TPT], re[TPT], bcv, bwv;
+        if (use_pre) {
+            bcv = pre.bcv;
+            bwv = pre.bwv;
+#pragma unroll
+            for (int i = 0; i < TPT; i++) {
+                le[i] = pre.le[i < PRE::TPT0 ? i : 0];
+                re[i] = pre.re[i < PRE::TPT0 ? i : 0];
+            }
+        } else {
+            bcv = g.cf_bc[c];
+            bwv = g.cf_bw[c];
+#pragma unroll
+            for (int i = 0; i < TPT; i++) {
+                const int t = tq + i, il = min(t, K - 1), ir = min(max(t - (Tc - K), 0), K - 1);
+                const float lv = g.cf_sc[(long long)c * K + il], rv = g.cf_sc[(long long)D * K + (long long)c * K + ir];
+                le[i] = t < K ? lv : 0.f;
+                re[i] = t >= Tc - K ? rv : 0.f;
+            }
+        }
+        float* yp = g.C + ((long long)m0 + (s << lgTc) + tq) * g.ldc + c;
+#pragma unroll
+        for (int i = 0; i < TPT; i++) {
+            const int t = tq + i;
+            float xc = bcv, xw = bwv;
+#pragma unroll
+            for (int k = 0; k < Kc; k++) xc += wc[k] * col[i + k];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int tt = t + k - pad;   // chunkwise conv: zero padding outside the chunk
+                if (tt >= 0 && tt < Tc) xw += ww[k] * col[i + k];
+            }
+            const float z = xw * (1.0f + (le[i] + re[i])) + xc;
+            yp[(long long)i * g.ldc] = fast_softplus(z - 1.0f) - 0.08f * z - 0.313261687f;   // SwooshR (online.hip swoosh_r)
+        }
+    }
+}
+
+template <int BM, int BN, int NV, int NTHR>
+__device__ __forceinline__ void conv_tail(const GemmArgs& g, const ConvPre<BM, BN, NTHR>& pre, const float (&fin)[NV], float* smem, int m0, int n0, int wc,
+                                          int lrow0, int li, int tid) {
+    constexpr int CH = BN / 2, lgCH = CH == 16 ? 4 : 5, TPT0 = ConvPre<BM, BN, NTHR>::TPT0;
+    const int Tc = g.cf_Tc, lgTc = pre.lgTc, K = g.cf_K, pad = pre.pad, Kc = pre.Kc, CL = pad + Tc, S = BM >> lgTc, KcP = Kc | 1;
+    const int Bn = g.M >> lgTc, b0 = m0 >> lgTc, c0 = n0 >> 1, D = g.N >> 1;
     float* colL = smem;                    // [S][CH][CL]   (CL is odd for every (K, Tc) of the model zoo: conflict-free columns)
     float* wcl = colL + S * CH * CL;       // [CH][KcP]
     float* wwl = wcl + CH * KcP;           // [CH][K]       (K odd)
     __syncthreads();                       // every wave has left the ring / the K groups' exchange area
     {   // (a) the chunk's GLU outputs: value lanes (li & 16) == 0, their gates 16 lanes up
-        const int col = n0 + wc * 32 + li;
-        const float bv = g.bias ? g.bias[col] : 0.f;
         const int ch = wc * 16 + (li & 15);
 #pragma unroll
         for (int n = 0; n < NV; n++) {
-            const float v = fin[n] + bv;
+            const float v = fin[n] + pre.bias;
             const float other = __shfl_xor(v, 16, 64);
             const float gated = v * (1.0f / (1.0f + __expf(-other)));
             const int lrow = lrow0 + Rows32::off(n);
-            const int s = lrow / Tc, t = lrow - s * Tc;
+            const int s = lrow >> lgTc, t = lrow & (Tc - 1);
             if ((li & 16) == 0) colL[(s * CH + ch) * CL + pad + t] = gated;
         }
     }
-    // (b) the streams' cached frames (contiguous per stream: channels c0 .. c0 + CH - 1, pad frames each) and the taps
-    for (int idx = tid; idx < S * CH * pad; idx += nthreads) {
-        const int s = idx / (CH * pad), rem = idx - s * (CH * pad), ch = rem / pad, r = rem - ch * pad;
-        if (b0 + s < Bn) colL[(s * CH + ch) * CL + r] = g.cf_pool[(long long)g.cf_slots[b0 + s] * g.cf_stride + g.cf_off + (long long)c0 * pad + rem];
-    }
-    for (int idx = tid; idx < CH * Kc; idx += nthreads) wcl[(idx / Kc) * KcP + idx % Kc] = g.cf_wc[(long long)c0 * Kc + idx];
-    for (int idx = tid; idx < CH * K; idx += nthreads) wwl[idx] = g.cf_ww[(long long)c0 * K + idx];
-    __syncthreads();
-    // (c) outputs: thread = (stream, frame group q of Q, channel)
-    int Q = 1;
-    while (2 * Q <= Tc && S * CH * 2 * Q <= nthreads) Q *= 2;
-    const int TPT = Tc / Q;
-    for (int w = tid; w < S * CH * Q; w += nthreads) {
-        const int ch = w % CH, sq = w / CH, q = sq % Q, s = sq / Q;
-        if (b0 + s >= Bn) continue;
-        const int c = c0 + ch;
-        const float* cp = colL + (s * CH + ch) * CL;
-        const float* wcp = wcl + ch * KcP;
-        const float* wwp = wwl + ch * K;
-        const float bcv = g.cf_bc[c], bwv = g.cf_bw[c];
-        float* yp = g.C + ((long long)m0 + s * Tc) * g.ldc + c;
-        for (int t = q * TPT; t < (q + 1) * TPT; t++) {
-            float xc = bcv, xw = bwv;
-            for (int k = 0; k < Kc; k++) xc += wcp[k] * cp[t + k];
-            const int klo = max(0, pad - t), khi = min(K, Tc + pad - t);   // taps whose frame t + k - pad lies inside the chunk
-            for (int k = klo; k < khi; k++) xw += wwp[k] * cp[t + k];
-            float le, re;
-            if (Tc < K) {
-                le = g.cf_sc[(long long)c * K + t];
-                re = g.cf_sc[(long long)D * K + (long long)c * K + (K - Tc) + t];
-            } else {
-                le = t < K ? g.cf_sc[(long long)c * K + t] : 0.f;
-                re = t >= Tc - K ? g.cf_sc[(long long)D * K + (long long)c * K + (t - (Tc - K))] : 0.f;
-            }
-            const float z = xw * (1.0f + (le + re)) + xc;
-            yp[(long long)t * g.ldc] = fast_softplus(z - 1.0f) - 0.08f * z - 0.313261687f;   // SwooshR (online.hip swoosh_r)
+    // (b) the streams' cached frames (contiguous per stream: channels c0 .. c0 + CH - 1, pad frames each) and the taps, out of the
+    // registers ConvPre filled before the K loop: thread = (stream cs, element cr) with TPS = NTHR / S threads per stream, <= 8 elements each
+    const int npc = pre.npc, TPS = 1 << pre.lgTPS, cs = pre.cs, cr = pre.cr;
+    const bool live = pre.live;
+    const float inv_pad = 1.0f / (float)pad;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int rem = cr + u * TPS;
+        if (live && rem < npc) {
+            const int ch = __float2int_rz(((float)rem + 0.5f) * inv_pad), r = rem - ch * pad;   // (exact: rem < 512, pad in {3, 7, 15})
+            colL[(cs * CH + ch) * CL + r] = pre.cv[u];
         }
     }
+    {
+        const int lgKc = 31 - __builtin_clz(Kc);   // (K + 1) / 2 is 4, 8 or 16
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = tid + u * NTHR;
+            if (idx < CH * Kc) wcl[(idx >> lgKc) * KcP + (idx & (Kc - 1))] = pre.wv[u];
+            if (idx < CH * K) wwl[idx] = pre.uv[u];
+        }
+    }
+    __syncthreads();
+    // (c) outputs
+#define K2_CONV_OUT(KT_, TPT_, PRE_) conv_outputs<KT_, TPT_>(g, pre, PRE_, colL, wcl, wwl, CL, KcP, lgTc, lgCH, S, Bn, b0, c0, m0, D, tid, NTHR)
+    if (pre.full) {
+        switch (K) {
+            case 31: K2_CONV_OUT(31, TPT0, true); break;
+            case 15: K2_CONV_OUT(15, TPT0, true); break;
+            default: K2_CONV_OUT(7, TPT0, true); break;
+        }
+    } else {   // chunks of fewer frames than a thread's share (Tc = 2 against 4): two frames per thread, two passes over the threads
+        switch (K) {
+            case 31: K2_CONV_OUT(31, 2, false); break;
+            case 15: K2_CONV_OUT(15, 2, false); break;
+            default: K2_CONV_OUT(7, 2, false); break;
+        }
+    }
+#undef K2_CONV_OUT
     // (d) cache = the last pad frames of [cache ; chunk] (read from LDS: the old cache in memory is not needed any more)
-    for (int idx = tid; idx < S * CH * pad; idx += nthreads) {
-        const int s = idx / (CH * pad), rem = idx - s * (CH * pad), ch = rem / pad, r = rem - ch * pad;
-        if (b0 + s < Bn) g.cf_pool[(long long)g.cf_slots[b0 + s] * g.cf_stride + g.cf_off + (long long)c0 * pad + rem] = colL[(s * CH + ch) * CL + Tc + r];
+    float* cbase = g.cf_pool + (long long)pre.slot * g.cf_stride + g.cf_off + (long long)c0 * pad;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int rem = cr + u * TPS;
+        if (live && rem < npc) {
+            const int ch = __float2int_rz(((float)rem + 0.5f) * inv_pad), r = rem - ch * pad;
+            cbase[rem] = colL[(cs * CH + ch) * CL + Tc + r];
+        }
     }
 }
+struct ConvPreNone {};
 
 template <int BM, int BN, int KS, int NST, int LW, int PF = 0, bool CONV = false>
 __global__ __launch_bounds__(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)) void gemm_f32_mfma_ring(GemmArgs g) {
@@ -1011,6 +1128,11 @@ __global__ __launch_bounds__(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)) void g
     xcd_tile(mb_, nb_, g.xcd_panels == 1 ? 0 : g.M, g.N);
     const int m0 = mb_ * BM, n0 = nb_ * BN;
     const int nk = g.K / (BK * KS);
+    // (CONV: what the fused conv tail needs from memory goes out first, see ConvPre)
+    typename std::conditional<CONV, ConvPre<BM, BN, 64 * NW>, ConvPreNone>::type cpre;
+    if constexpr (CONV) {
+        if (!loader && !(PF > 0 && wave == NW + LW)) cpre.first(g, tid, m0, n0, n0 + wc * 32 + li);
+    }
 
     // tuning only (g.dbg != nullptr): lane 0 of every wave stamps s_memtime at the phases of the pipeline
     unsigned long long* stamp = g.dbg ? g.dbg + ((size_t)(blockIdx.x + blockIdx.y * gridDim.x) * (NW + LW + PF) + wave) * 64 : nullptr;
@@ -1172,6 +1294,7 @@ __global__ __launch_bounds__(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)) void g
         if (nk >= NST) K2_RING_WAIT(NST - 1) else K2_RING_WAIT(0)
     }
     __builtin_amdgcn_s_barrier();
+    if constexpr (CONV) cpre.second(g, n0);   // (its slot index was requested in front of the prologue's DMAs)
 #pragma unroll
     for (int gk = 0; gk < 4; gk++) K2_RING_READ(0, 0, gk)
 
@@ -1226,7 +1349,7 @@ __global__ __launch_bounds__(64 * ((BM / 32) * (BN / 32) * KS + LW + PF)) void g
     // group kg finishes registers [kg RPG, (kg + 1) RPG): RPG = 16 -> the whole block; 8 -> rows (r&3) + 8 (r>>2) from 16 kg; 4 -> from 8 kg
     if constexpr (CONV) {
         static_assert(LW == 0, "conv tail: no loader waves (an L2-prefetch wave has left the kernel by now)");
-        conv_tail<BM, BN, RPG>(g, fin, smem, m0, n0, wc, wr * 32 + 4 * lh + 8 * ((kg * RPG) >> 2), li, tid, 64 * NW);
+        conv_tail<BM, BN, RPG, 64 * NW>(g, cpre, fin, smem, m0, n0, wc, wr * 32 + 4 * lh + 8 * ((kg * RPG) >> 2), li, tid);
         return;
     }
     epilogue_rows<RPG, Rows32>(g, fin, m0 + wr * 32 + 4 * lh + 8 * ((kg * RPG) >> 2), n0 + wc * 32 + li, C, R, fin, false, nullptr,
@@ -1649,7 +1772,7 @@ bool gemm_glu_causal_conv(const Ctx& ctx, const float* x, const float* wg, const
     const int M = B * Tc, N = 2 * D;
     // tiles: 32 / 64 rows of whole streams (Tc | 32), 32 / 64 GEMM columns of whole (value | gate) blocks; the K step split over the
     // workgroup's wave groups as the dispatcher of gemm() does for these shapes (streaming chunk steps: a few hundred tiles at most)
-    if (Tc < 1 || 32 % Tc != 0 || D % 64 != 0 || K < 3 || K > 31 || (K & 1) == 0) return false;
+    if (Tc < 2 || 32 % Tc != 0 || D % 64 != 0 || (K != 31 && K != 15 && K != 7)) return false;
     const long long g32 = (long long)cdiv(M, 32) * (N / 32), g6432 = (long long)cdiv(M, 64) * (N / 32);
     int form = -1;   // 0: 32x32 KS 4 (4 stages), 1: 64x32 KS 4, 2: 32x64 KS 2, 3: 64x64 KS 2
     if (D % 128 == 0 && g32 <= 256) form = 0;
@@ -1657,6 +1780,10 @@ bool gemm_glu_causal_conv(const Ctx& ctx, const float* x, const float* wg, const
     else if (D % 128 == 0) form = 3;
     else if ((long long)cdiv(M, 32) * (N / 64) <= 256) form = 2;
     else form = 3;
+    {   // the tail's cache staging holds at most 8 elements per thread (conv_tail): tile's streams x channels x cached frames
+        const int bm = (form == 1 || form == 3) ? 64 : 32, ch = (form >= 2) ? 32 : 16, nthr = (bm / 32) * (ch / 16) * (form >= 2 ? 2 : 4) * 64;
+        if ((long long)(bm / Tc) * ch * (K >> 1) > 8ll * nthr) return false;
+    }
     const double fl = 2.0 * M * (double)N * D;
     ctx.add_flops(fl, 2.0 * M * (double)D * (K + (K + 1) / 2), 1);
     if (ctx.dry) return true;

@@ -163,7 +163,8 @@ void gemm(const Ctx& ctx, const GemmArgs& a);
 // with the streams' conv caches (pool slot + off, [D][K / 2]) read and advanced in place; M = B Tc rows, stream-major.  wg / bg: the
 // "#glu" row-interleaved in_proj [2 D, D]; wc / bc / ww / bw / sc: causal_conv, chunkwise_conv and chunkwise_conv_scale as
 // glu_causal_conv takes them.  Returns false (nothing launched, nothing tallied) when the shape has no fused form -- the caller then
-// runs linear + glu_causal_conv.  Same sums in the same order as those two launches: bit-identical outputs and caches.
+// runs linear + glu_causal_conv.  The convolution's sums are formed in k_glu_causal_conv_reg's order; the in_proj product in the order of
+// this launch's tile form (the dispatcher's own choice for most of these shapes): equal to the two launches up to float rounding.
 bool gemm_glu_causal_conv(const Ctx& ctx, const float* x, const float* wg, const float* bg, float* pool, long long slot_stride, long long off,
                           const int* slots, const float* wc, const float* bc, const float* ww, const float* bw, const float* sc, float* y, int B,
                           int Tc, int D, int K);
