@@ -260,7 +260,9 @@ def dominant_kernel(rows):
     for r in rows:
         M, N, K, bat, _, _, kind, us = (float(x) for x in r)
         kind = int(kind)
-        if kind & 128:
+        if kind & (1 << 20):
+            name = f"gemm_f32_mfma_p16<{32 * ((kind >> 8) & 15)}, {32 * ((kind >> 12) & 15)}>"
+        elif kind & 128:
             name = f"gemm_f32_mfma_pipe<{32 * ((kind >> 8) & 15)}, {32 * ((kind >> 12) & 15)}>"
         elif kind & 64:
             name = "gemm_f32_mfma_ring"

@@ -118,7 +118,7 @@ int32_t k2hip_model_meta(const k2hip_model_t* model, const char* key, char* buf,
 int32_t k2hip_set_instrument(k2hip_model_t* model, int32_t on);
 /* per-launch table of the last instrumented call: rows of 8 floats (M, N, K, batch, act, has_residual, kind, microseconds);
  * kind & 3: 0 plain, 1 conv gather, 2 [K,N] operand; +16 LDS-DMA kernel, +32 skinny kernel, +64 ring kernel, +128 pipelined kernel
- * with its tile in the bits above (BM / 32 in bits 8-11, BN / 32 in bits 12-15).  rows == NULL only queries n_rows. */
+ * with its tile in the bits above (BM / 32 in bits 8-11, BN / 32 in bits 12-15; + 2^20: its 16x16x4-tile form).  rows == NULL only queries n_rows. */
 int32_t k2hip_get_gemm_profile(k2hip_model_t* model, float* rows, int32_t cap_rows, int32_t* n_rows);
 int32_t k2hip_get_timing(const k2hip_model_t* model, k2hip_timing* timing);
 

@@ -760,8 +760,11 @@ static void glu_dwconv1d_any(const Ctx& ctx, const float* x2, const float* w_kd,
     // tall strips (k_glu_dwconv1d_tall): 128 frames per workgroup where that still gives every CU a workgroup, 64 otherwise; the
     // 256-channel form for kernels longer than 32 taps, short inputs and forced thread shapes (K2HIP_DW1D_TT, dev builds)
     if (K <= 32 && D % 64 == 0 && T >= 48 && !tunables().dw1d_tt) {
+        // 128-frame strips only where they still number two workgroups per CU (one strip's staging then runs under another's taps: with
+        // ONE 128-frame workgroup per CU the launch is a serial stage -> compute -> store chain, 11.6 us against 9.0 for the 16-frame form
+        // although it moves half the bytes -- measured, profiles/r05_v1)
         const long long g128 = (long long)(D / 64) * cdiv(T, 128) * B;
-        if (g128 >= 224 && T > 64) launch_dw1d_tall<DSWISH, GLU, 8>(ctx, x2, w_kd, b, y, B, T, D, K);
+        if (g128 >= 512) launch_dw1d_tall<DSWISH, GLU, 8>(ctx, x2, w_kd, b, y, B, T, D, K);
         else launch_dw1d_tall<DSWISH, GLU, 4>(ctx, x2, w_kd, b, y, B, T, D, K);
         return;
     }

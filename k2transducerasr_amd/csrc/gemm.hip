@@ -890,6 +890,197 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_pipe
 }
 
 // ---------------------------------------------------------------------------------------
+// The pipelined kernel on 16x16x4 MFMA tiles (round 5): the same stage image, swizzle, LDS-DMA and vector-ALU-free K loop as
+// gemm_f32_mfma_pipe above, with wave tiles of WM x WN = (16 MT) x (16 NT) built from v_mfma_f32_16x16x4_f32 (exact f32 products, the
+// same 64 flop / cycle / SIMD as the 32x32x2 shape).  Why a second shape: a 32 x 32 block per wave makes every workgroup tile a multiple
+// of 32 x 32 PER WAVE, and the launches that quantise badly on 256 CUs need tiles in between -- 2048 x 768 (the 6.25 Hz stack: 30
+// launches, 1.44 ms of the batch) is 192 tiles of 128 x 64 (a quarter of the chip idle) or 256 tiles of 64 x 96, and 64 x 96 in 32 x 32
+// blocks is six waves on four SIMDs (two of them carry twice the work: no gain, measured in rounds 1 and 5) while in 16 x 16 blocks it is
+// four waves of 32 x 48, one per SIMD, all equal.  Fragments: lane (i = lane & 15, kq = lane >> 4) reads chunk 4 g + kq of row i of a
+// 16-k group g as one ds_read_b128 and feeds component e to MFMA step e, for A and for W alike (the k order inside a group is a
+// permutation, identical on both sides); rows 16 apart share the XOR swizzle, so a wave tile's blocks are immediate offsets of one
+// address per (stage, group), and the 16 lanes of a row block hit all 64 banks once.  C/D: lane (n, q) holds rows 4 q + e of column n
+// (epilogue_rows<4, Rows16>; no gated epilogue: that pairs lanes 16 columns apart).
+template <int BM, int BN, int WM, int WN, int NST>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_f32_mfma_p16(GemmArgs g) {
+    constexpr int BK = 32;
+    constexpr int MT = WM / 16, NT = WN / 16;
+    constexpr int WCOLS = BN / WN;
+    constexpr int NW = (BM / WM) * (BN / WN);
+    constexpr int NINST = (BM + BN) / 8;
+    constexpr int IPW = NINST / NW;
+    constexpr int STAGE = (BM + BN) * BK;
+    constexpr int DPE = (IPW + 3) / 4;
+    static_assert(NST == 3, "p16: three stages");
+    static_assert(NINST % NW == 0, "p16: every wave issues the same number of DMA instructions");
+    static_assert(MT >= 1 && NT >= 1 && MT * NT <= 12, "p16: wave tile");
+
+    if (g.skip_if_zero && *g.skip_if_zero == 0) return;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [NST][STAGE]: A rows then W rows
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WCOLS, wc = wave % WCOLS;
+    const int li = lane & 15, kq = lane >> 4;
+    float* __restrict__ C = g.C;
+    const float* __restrict__ R = g.res;
+    int mb_, nb_;
+    xcd_tile(mb_, nb_, g.xcd_panels == 1 ? 0 : g.M, g.N);
+    const int m0 = mb_ * BM, n0 = nb_ * BN;
+    const int nk = g.K / BK;
+
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    unsigned voff[IPW];
+    unsigned long long sb[IPW];
+    unsigned mq[IPW];
+#pragma unroll
+    for (int q = 0; q < IPW; q++) {
+        const int inst = wave + q * NW;  // wave-uniform
+        const int slot = inst * 64 + lane;
+        const int r = slot >> 3, cp = slot & 7;
+        const int c = cp ^ ((r >> 1) & 7);
+        const bool is_a = inst < BM / 8;
+        const long long row = is_a ? min(m0 + r, g.M - 1) : min(n0 + (r - BM), g.N - 1);
+        voff[q] = (unsigned)((row * (is_a ? g.lda : g.ldw) + 4 * c) * 4);
+        const unsigned long long base = (unsigned long long)(is_a ? g.A : g.W);
+        sb[q] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
+        mq[q] = __builtin_amdgcn_readfirstlane(lds_base + inst * 1024);
+    }
+#define K2_P16_DMA(ST_, KT_, q_)                                                                                           \
+    {                                                                                                                      \
+        const unsigned long long src_ = sb[q_] + (unsigned long long)(KT_) * (BK * 4);                                    \
+        asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                    \
+                     :                                                                                                     \
+                     : "v"(voff[q_]), "s"(src_), "s"(mq[q_]), "n"((ST_) * STAGE * 4)                                       \
+                     : "memory", "m0", "scc");                                                                             \
+    }
+#define K2_P16_READ(SET_, ST_, G_)                                                                                         \
+    {                                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < MT; i++) fa[SET_][i] = *reinterpret_cast<const f32x4*>(ra[ST_][G_] + i * 16 * BK); \
+        _Pragma("unroll") for (int j = 0; j < NT; j++) fb[SET_][j] = *reinterpret_cast<const f32x4*>(rb[ST_][G_] + j * 16 * BK); \
+    }
+// one K step = two 16-k groups.  Group 0 out of set 0 (its fragments were read during the previous step's group 1), group 1 out of set 1
+// (read behind group 0's first MFMAs); behind group 0: the wait for step KT_+1's DMA + the step's one barrier; behind group 1's first
+// MFMAs: the next step's group 0 into set 0; the DMA of step KT_+NST-1 spread over group 1's MFMA slots.
+#define K2_P16_STEP(ST_, KT_, HAS_NEXT_, DO_ISSUE_, WAIT_)                                                                 \
+    _Pragma("unroll") for (int gk = 0; gk < 2; gk++) {                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                                    \
+            _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++)                  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[gk][i][e], fb[gk][j][e], acc[i][j], 0, 0, 0);          \
+            if (e == 0) {                                                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                                         \
+                if (gk == 0) K2_P16_READ(1, ST_, 1)                                                                        \
+                if (gk == 1 && (HAS_NEXT_)) K2_P16_READ(0, ((ST_) + 1) % NST, 0)                                           \
+                __builtin_amdgcn_sched_barrier(0);                                                                         \
+            }                                                                                                              \
+            if (gk == 1 && (DO_ISSUE_)) {                                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                                         \
+                _Pragma("unroll") for (int q = e * DPE; q < (e + 1) * DPE && q < IPW; q++)                                 \
+                    K2_P16_DMA(((ST_) + NST - 1) % NST, (KT_) + NST - 1, q)                                                \
+                __builtin_amdgcn_sched_barrier(0);                                                                         \
+            }                                                                                                              \
+        }                                                                                                                  \
+        if (gk == 0 && (HAS_NEXT_)) { /* step KT_+1 has landed for everyone; everyone has left step KT_-1's stage */       \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            WAIT_                                                                                                          \
+            __builtin_amdgcn_s_barrier();                                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+        }                                                                                                                  \
+    }
+#define K2_P16_WAIT_STEADY asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 3) * IPW) : "memory");
+#define K2_P16_WAIT_DRAIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- prologue: K steps 0 .. NST-2 in flight
+#pragma unroll
+    for (int p = 0; p < NST - 1; p++)
+        if (p < nk) {
+#pragma unroll
+            for (int q = 0; q < IPW; q++) {
+                if (p == 0) K2_P16_DMA(0, 0, q)
+                if (p == 1) K2_P16_DMA(1, 1, q)
+            }
+        }
+    const int arow = wr * WM + li, brow = wc * WN + li;
+    const int swa = (arow >> 1) & 7, swb = ((BM + brow) >> 1) & 7;
+    const float* ra[NST][2];
+    const float* rb[NST][2];
+#pragma unroll
+    for (int st = 0; st < NST; st++)
+#pragma unroll
+        for (int gg = 0; gg < 2; gg++) {
+            ra[st][gg] = smem + st * STAGE + arow * BK + (((4 * gg + kq) ^ swa) << 2);
+            rb[st][gg] = smem + st * STAGE + (BM + brow) * BK + (((4 * gg + kq) ^ swb) << 2);
+        }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 fa[2][MT], fb[2][NT];
+    if (nk >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * IPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    K2_P16_READ(0, 0, 0)
+    // residual and bias: behind the prologue's DMAs and the first barrier (vmcnt retires in issue order: the loop's counted waits cover
+    // these loads conservatively, as in gemm_f32_mfma_pipe)
+    float rres[MT][NT][4];
+    if (R) {
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int col = min(n0 + wc * WN + j * 16 + li, g.N - 1);
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int row = min(m0 + wr * WM + i * 16 + 4 * kq + e, g.M - 1);
+                    rres[i][j][e] = R[(long long)row * g.ldr + col];
+                }
+        }
+    }
+    float bias_pre[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) bias_pre[j] = g.bias ? g.bias[min(n0 + wc * WN + j * 16 + li, g.N - 1)] : 0.f;
+
+    int kt = 0;
+    const int nsteady = nk - (NST - 1);
+    for (; kt + NST <= nsteady; kt += NST) {
+        K2_P16_STEP(0, kt, true, true, K2_P16_WAIT_STEADY)
+        K2_P16_STEP(1, kt + 1, true, true, K2_P16_WAIT_STEADY)
+        K2_P16_STEP(2, kt + 2, true, true, K2_P16_WAIT_STEADY)
+    }
+#define K2_P16_S(j_) K2_P16_STEP((j_) % NST, kt + (j_), true, true, K2_P16_WAIT_STEADY)
+#define K2_P16_T(j_) K2_P16_STEP((j_) % NST, kt + (j_), true, false, K2_P16_WAIT_DRAIN)
+#define K2_P16_L(j_) K2_P16_STEP((j_) % NST, kt + (j_), false, false, K2_P16_WAIT_DRAIN)
+    const int rs = nsteady - kt;
+    switch (rs) {
+        case 0: K2_P16_T(0) K2_P16_L(1) break;
+        case 1: K2_P16_S(0) K2_P16_T(1) K2_P16_L(2) break;
+        default: K2_P16_S(0) K2_P16_S(1) K2_P16_T(2) K2_P16_L(3) break;
+    }
+#undef K2_P16_S
+#undef K2_P16_T
+#undef K2_P16_L
+#undef K2_P16_WAIT_DRAIN
+#undef K2_P16_WAIT_STEADY
+#undef K2_P16_STEP
+#undef K2_P16_READ
+#undef K2_P16_DMA
+
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            float vals[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) vals[e] = acc[i][j][e];
+            epilogue_rows<4, Rows16>(g, vals, m0 + wr * WM + i * 16 + 4 * kq, n0 + wc * WN + j * 16 + li, C, nullptr, rres[i][j], R != nullptr, nullptr,
+                                     g.bias, true, bias_pre[j]);
+        }
+}
+
+// ---------------------------------------------------------------------------------------
 // Ring variant of the LDS-DMA kernel (plain Linear, K % (32 KS) == 0).  Same tile image and swizzle as above; what changes is
 // the pipeline and the K split:
 //   * the fragments of a K tile are read from LDS into a SECOND register set while the MFMAs of the previous tile run, so
@@ -956,8 +1147,10 @@ struct ConvPre {
     // the streams' cached frames (the slot index has arrived by now: behind the prologue's first barrier)
     __device__ __forceinline__ void second(const GemmArgs& g, int n0) {
         const float* cbase = g.cf_pool + (long long)slot * g.cf_stride + g.cf_off + (long long)(n0 >> 1) * pad;
+        const int nper = (npc + (1 << lgTPS) - 1) >> lgTPS;   // elements per thread, workgroup-uniform (<= 8): the unrolled slots behind it are skipped
 #pragma unroll
-        for (int u = 0; u < 8; u++) cv[u] = (live && cr + (u << lgTPS) < npc) ? cbase[cr + (u << lgTPS)] : 0.f;
+        for (int u = 0; u < 8; u++)
+            if (u < nper) cv[u] = (live && cr + (u << lgTPS) < npc) ? cbase[cr + (u << lgTPS)] : 0.f;
     }
 };
 
@@ -971,13 +1164,12 @@ __device__ __forceinline__ void conv_outputs(const GemmArgs& g, const PRE& pre, 
         if (b0 + s >= Bn) continue;
         const int c = c0 + ch, tq = q * TPT;
         const float* cp = colL + ((s << lgCH) + ch) * CL + tq;
-        float col[TPT + K - 1], wc[Kc], ww[K];
+        // causal_conv: all (K + 1) / 2 taps are live -- the TPT + Kc - 1 column values and the taps in registers, unrolled
+        float col[TPT + Kc - 1], wc[Kc];
 #pragma unroll
-        for (int j = 0; j < TPT + K - 1; j++) col[j] = tq + j < CL ? cp[j] : 0.f;   // (frames past the chunk: only ever met by masked taps)
+        for (int j = 0; j < TPT + Kc - 1; j++) col[j] = cp[j];   // (tq + j <= Tc - 1 + Kc - 1 = CL - 1: inside the column)
 #pragma unroll
         for (int k = 0; k < Kc; k++) wc[k] = wcl[ch * KcP + k];
-#pragma unroll
-        for (int k = 0; k < K; k++) ww[k] = wwl[ch * K + k];
         // chunkwise_conv_scale (k_glu_causal_conv_reg's le / re) and the two biases: prefetched before the K loop where the thread's
         // outputs were known then (use_pre), else unconditional loads from clamped indexes, all in flight together
         float le[TPT], re[TPT], bcv, bwv;
@@ -1001,18 +1193,31 @@ __device__ __forceinline__ void conv_outputs(const GemmArgs& g, const PRE& pre, 
             }
         }
         float* yp = g.C + ((long long)m0 + (s << lgTc) + tq) * g.ldc + c;
+        // chunkwise_conv: of its K taps only those whose frame t + k - pad lies inside the chunk are live (8 of 31 at Tc = 8); with the
+        // frame index a run-time value a tap loop cannot drop the others at compile time (it cost ~3.5 instructions per dead tap: the
+        // tail was ~600 instructions per thread, ~2.7 us at two waves per SIMD) -- so the loop runs over the chunk's FRAMES tt, tap
+        // k = tt - t + pad read from LDS: ascending tt is ascending k, the sum is formed in k_glu_causal_conv_reg's order.
+        float xw[TPT];
+#pragma unroll
+        for (int i = 0; i < TPT; i++) xw[i] = bwv;
+        {
+            const float* xcol = colL + ((s << lgCH) + ch) * CL + pad;     // the chunk's frames 0 .. Tc - 1 of this (stream, channel)
+            const float* wrow = wwl + ch * K + pad - tq;                  // tap of output i at frame tt: wrow[tt - i]
+            for (int tt = 0; tt < Tc; tt++) {
+                const float xv = xcol[tt];
+#pragma unroll
+                for (int i = 0; i < TPT; i++) {
+                    const int k = tt - i + pad - tq;                      // (a uniform bound test per output: |tt - t| <= pad)
+                    if (k >= 0 && k < K) xw[i] += wrow[tt - i] * xv;
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TPT; i++) {
-            const int t = tq + i;
-            float xc = bcv, xw = bwv;
+            float xc = bcv;
 #pragma unroll
             for (int k = 0; k < Kc; k++) xc += wc[k] * col[i + k];
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                const int tt = t + k - pad;   // chunkwise conv: zero padding outside the chunk
-                if (tt >= 0 && tt < Tc) xw += ww[k] * col[i + k];
-            }
-            const float z = xw * (1.0f + (le[i] + re[i])) + xc;
+            const float z = xw[i] * (1.0f + (le[i] + re[i])) + xc;
             yp[(long long)i * g.ldc] = fast_softplus(z - 1.0f) - 0.08f * z - 0.313261687f;   // SwooshR (online.hip swoosh_r)
         }
     }
@@ -1045,10 +1250,11 @@ __device__ __forceinline__ void conv_tail(const GemmArgs& g, const ConvPre<BM, B
     const int npc = pre.npc, TPS = 1 << pre.lgTPS, cs = pre.cs, cr = pre.cr;
     const bool live = pre.live;
     const float inv_pad = 1.0f / (float)pad;
+    const int nper = (npc + TPS - 1) >> pre.lgTPS;   // (uniform: unrolled slots past it are skipped, not predicated)
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         const int rem = cr + u * TPS;
-        if (live && rem < npc) {
+        if (u < nper && live && rem < npc) {
             const int ch = __float2int_rz(((float)rem + 0.5f) * inv_pad), r = rem - ch * pad;   // (exact: rem < 512, pad in {3, 7, 15})
             colL[(cs * CH + ch) * CL + r] = pre.cv[u];
         }
@@ -1084,7 +1290,7 @@ __device__ __forceinline__ void conv_tail(const GemmArgs& g, const ConvPre<BM, B
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         const int rem = cr + u * TPS;
-        if (live && rem < npc) {
+        if (u < nper && live && rem < npc) {
             const int ch = __float2int_rz(((float)rem + 0.5f) * inv_pad), r = rem - ch * pad;
             cbase[rem] = colL[(cs * CH + ch) * CL + Tc + r];
         }
@@ -1486,6 +1692,28 @@ bool launch_pipe_idx(const Ctx& ctx, const GemmArgs& a, int idx) {
     return true;
 }
 
+template <int BM, int BN, int WM, int WN, int NST>
+void launch_p16(const Ctx& ctx, const GemmArgs& a) {
+    dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), 1);
+    size_t lds = sizeof(float) * NST * (BM + BN) * 32;
+    static LdsAttrOnce lds_attr;
+    lds_attr.ensure(gemm_f32_mfma_p16<BM, BN, WM, WN, NST>, (int)lds);
+    K2_REQUIRE((long long)a.M * a.lda < (1ll << 29) && (long long)a.N * a.ldw < (1ll << 29), "p16: operand too large for 31-bit lane byte offsets");
+    K2_REQUIRE(a.K % 32 == 0 && a.K >= 32 * (NST - 1) && !a.glu, "p16: K %d too short for %d stages, or a gated epilogue", a.K, NST);
+    hipLaunchKernelGGL((gemm_f32_mfma_p16<BM, BN, WM, WN, NST>), grid, dim3(64 * (BM / WM) * (BN / WN)), lds, ctx.stream, a);
+}
+// tuning table of the 16x16x4 pipelined kernel: k2hip_debug_gemm cfg = 3000 + index
+bool launch_p16_idx(const Ctx& ctx, const GemmArgs& a, int idx) {
+    switch (idx) {
+        case 0: launch_p16<64, 96, 32, 48, 3>(ctx, a); break;     // 4 waves of 32 x 48
+        case 1: launch_p16<128, 96, 64, 48, 3>(ctx, a); break;    // 4 waves of 64 x 48
+        case 2: launch_p16<64, 192, 32, 96, 3>(ctx, a); break;    // 4 waves of 32 x 96
+        case 3: launch_p16<32, 96, 16, 48, 3>(ctx, a); break;     // 4 waves of 16 x 48
+        default: return false;
+    }
+    return true;
+}
+
 // tuning table of the ring kernel: k2hip_debug_gemm cfg = 100 + index
 struct RingCfg { int BM, BN, KS, NST, LW, PF; };
 #define K2_RING_TABLE(X)                                                                                        \
@@ -1582,6 +1810,7 @@ void debug_ring_shape(int idx, int* bm, int* bn, int* waves) {
 }
 int g_forced_ring = -1;
 int g_forced_pipe = -1;
+int g_forced_p16 = -1;
 void debug_pipe_shape(int cfg, int M, int N, int* n_wg, int* waves) {
     const int idx = (cfg - 2000) % 100;
     K2_REQUIRE(idx >= 0 && idx < (int)(sizeof(kPipe) / sizeof(kPipe[0])), "no pipe cfg %d", idx);
@@ -1591,6 +1820,15 @@ void debug_pipe_shape(int cfg, int M, int N, int* n_wg, int* waves) {
 void debug_force_gemm_cfg(int cfg) {
     const int dma_default = 1;
     g_forced_pipe = -1;
+    g_forced_p16 = -1;
+    if (cfg >= 3000) {  // 16x16x4 pipelined kernel table
+        g_forced_p16 = cfg - 3000;
+        g_forced_ring = -1;
+        g_forced_cfg = -1;
+        g_ablate = 0;
+        g_use_dma = dma_default;
+        return;
+    }
     if (cfg >= 2000) {  // pipelined kernel table
         g_forced_pipe = cfg - 2000;
         g_forced_ring = -1;
@@ -1637,6 +1875,14 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         ctx.gemm_log->push_back({a.M, a.N, a.K, a.nb0 * a.nb1, a.act, a.res != nullptr, a.cv_Fout > 0 ? 1 : (a.w_kn ? 2 : 0), 0.f});
     // (a) N <= 96: few columns; (b) small problems (streaming chunks, beam search: a 128x64 grid would leave most CUs idle and
     // every workgroup would walk K serially): the same kernel over column chunks of 96
+    if (g_forced_p16 >= 0) {  // tuning hook
+        K2_REQUIRE(a.cv_Fout == 0 && !a.w_kn && !a.mul && a.res_div == 1 && !a.act_after_res && !a.glu && a.K % 32 == 0 && a.K >= 64 && a.nb0 * a.nb1 == 1,
+                   "p16 cfg %d does not fit this GEMM", g_forced_p16);
+        K2_REQUIRE(launch_p16_idx(ctx, b, g_forced_p16), "no p16 cfg %d", g_forced_p16);
+        K2_HIP(hipGetLastError());
+        if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
+        return;
+    }
     if (g_forced_pipe >= 0) {  // tuning hook
         K2_REQUIRE(a.cv_Fout == 0 && !a.w_kn && !a.mul && a.res_div == 1 && !a.act_after_res && a.K % 32 == 0 && a.K >= 64 && a.nb0 * a.nb1 == 1,
                    "pipe cfg %d does not fit this GEMM", g_forced_pipe);
@@ -1736,6 +1982,23 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
             if (best < 0 || cost < best_cost) {
                 best = c.idx;
                 best_cost = cost;
+            }
+        }
+        // The 16x16x4 form's 64 x 96 tile (gemm_f32_mfma_p16, round 5) where N is a multiple of 96 and the same model prefers it: the
+        // launches that quantise badly in 32 x 32 blocks -- 2048 x 768 is 256 tiles of 64 x 96 against 192 of 128 x 64 (tools/gemm_lab.py,
+        // gpurun_out/r5j/lab_p16.txt: 69.3 against 83.5 us at K = 2560, 57.2 / 67.8 at 2048, 44.7 / 52.5 at 1536, 25.7 / 29.0 at 768;
+        // 4064 x 1152 x 512 47.4 / 48.3; it loses where 128 x 64 already divides the output: 8096 x 768 x 256 40.7 / 36.3, which the model
+        // reproduces).  One wave per SIMD on a single-round grid, so its prologue and tail are fully exposed: six fixed steps.
+        if (a.N % 96 == 0 && !a.glu && a.M >= 1024) {
+            const long long tiles = (long long)cdiv(a.M, 64) * (a.N / 96);
+            const double cost = (double)cdiv(tiles, 256) * 64 * 96 * (nk + 6.0) * 1.10;
+            if (tiles >= 128 && cost < best_cost) {
+                launch_p16_idx(ctx, b, 0);
+                K2_HIP(hipGetLastError());
+                // (+128 + 2048: the pipelined kernel on 16x16x4 tiles; BM / 32 = 2 in bits 8-11, BN / 32 = 3 in bits 12-15)
+                if (ctx.instrument && ctx.gemm_log) ctx.gemm_log->back().kind += 128 + 256 * 2 + 4096 * 3 + (1 << 20);
+                if (ctx.instrument) K2_HIP(hipEventRecord(ctx.next_event(), ctx.stream));
+                return;
             }
         }
         launch_pipe_idx(ctx, b, best);

@@ -101,7 +101,12 @@ _tab3 = _src[_src.index("#define K2_PIPE_TABLE(X)") : _src.index("const PipeCfg 
 PIPE = [tuple(int(v) for v in t[1:]) for t in sorted((tuple(int(x) for x in t) for t in re.findall(r"X\((\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\)", _tab3)))]
 
 
+P16 = [(64, 96, 32, 48), (128, 96, 64, 48), (64, 192, 32, 96), (32, 96, 16, 48)]   # gemm.hip launch_p16_idx
+
+
 def name(c):
+    if c >= 3000:
+        return "q%dx%d.%dx%d" % P16[c - 3000]
     if c >= 2000:
         return "p%dx%d.%dx%d.%d" % PIPE[c - 2000]
     return "auto" if c < 0 else f"c{c}" if c < 100 else "r%dx%d.%d.%d.%d%s" % (RING[c - 100][:5] + ("p" if RING[c - 100][5] else "",))

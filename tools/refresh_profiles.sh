@@ -1,7 +1,7 @@
 #!/bin/bash
 # Re-create the rocprofv3 summaries under profiles/ (run on the GPU box from the repo root: bash tools/refresh_profiles.sh r01_v5).
-# Batches in the offline run (--no-secondary: headline legs only): (2 warm-up + 8 timed) x 2 legs (HBM-resident, host memory) + 1 synchronous + 1 instrumented
-# + 1 operator-level encoder pass for oracle_match.logits = 23;
+# Batches in the offline run (--no-secondary: headline legs only): (2 warm-up + 8 timed) x 3 legs (HBM-resident, host memory pipelined, host memory
+# synchronous GetResults) + 1 synchronous + 1 instrumented + 1 operator-level encoder pass for oracle_match.logits = 33;
 # chunk steps in the streaming run: 64 warm-up + 64 timed + 1 instrumented = 129 (the divisors of tools/summarize_stats.py below).
 # Every rocprofv3 run puts python3 directly after `--` and collects counters in their own passes (kernel-trace only).
 set -e -o pipefail
@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_beam4 -- python
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_conformer_zh -- python3 $R/bench.py --preset conformer-zh --batch 8 --seconds 30 --steps 8 --warmup 2 --no-host-leg --no-cpu-baseline --no-secondary > /dev/null 2> $O/stats_conformer_zh.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_streaming -- python3 $R/bench_streaming.py --streams 128 --seconds 20 --no-cpu-baseline > /dev/null 2> $O/stats_streaming.err
 cd $R
-python3 tools/summarize_stats.py $(ls $O/stats/*/*_kernel_stats.csv | head -1) 23 $O/${TAG}_offline_kernel_stats.csv > /dev/null
+python3 tools/summarize_stats.py $(ls $O/stats/*/*_kernel_stats.csv | head -1) 33 $O/${TAG}_offline_kernel_stats.csv > /dev/null
 python3 tools/summarize_stats.py $(ls $O/stats_streaming/*/*_kernel_stats.csv | head -1) 129 $O/${TAG}_streaming_kernel_stats.csv > /dev/null
 python3 tools/summarize_pmc.py $O/pmc_fetch FETCH_SIZE $O/${TAG}_pmc_fetch_summary.csv > /dev/null
 python3 tools/summarize_pmc.py $O/pmc_write WRITE_SIZE $O/${TAG}_pmc_write_summary.csv > /dev/null
