@@ -485,84 +485,6 @@ __global__ __launch_bounds__(256) void k_glu_dwconv1d(const float* __restrict__ 
     }
 }
 
-// ---- the same convolution on TALL strips (round 5): one workgroup = TR = 16 RT output frames x 64 channels of one stream, so the
-//  K - 1 halo frames are staged once per TR frames instead of once per 16 / 32: at K = 31 the strip is 158 (94) staged frames for 128
-//  (64) outputs, 1.23x (1.47x) the input, where the 256-channel form stages 2.9x (16-frame workgroups, what the batch's shapes mostly
-//  ran) or 1.94x (32-frame ones) -- that kernel moved 40 MB per launch for 16.6 MB of input + output (profiles/r04: 2.6 TB/s of HBM-side
-//  traffic, memory-bound).  64 channels keep the workgroup count (D / 64 x T / TR x B) at or above one per CU for every stack of the
-//  batch.  thread = (row group of RT frames, channel quad); a wave's load / LDS instruction covers 4 rows x 256 B.
-//  Same taps in the same order per output as k_glu_dwconv1d: bit-identical results.
-template <bool DSWISH, bool GLU, int RT>
-__global__ __launch_bounds__(256) void k_glu_dwconv1d_tall(const float* __restrict__ x2, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, float* __restrict__ y, int B, int T,
-                                                           int D, int K) {
-    constexpr int TR = 16 * RT, LDR = 64 + 4;   // (row stride 68 floats: the four rows of a wave instruction fall into different banks)
-    extern __shared__ __attribute__((aligned(16))) float sx[];  // [TR + K - 1][LDR]
-    const int tid = threadIdx.x, quad = tid & 15, rg = tid >> 4;
-    const int c = blockIdx.x * 64 + quad * 4;
-    const int t0 = blockIdx.y * TR, b = blockIdx.z;
-    const int half = K >> 1, nrows = TR + K - 1;
-    const bool cok = c < D;
-    float4 wp[32];
-#pragma unroll
-    for (int q = 0; q < 32; q++)
-        wp[q] = (cok && q < K) ? *reinterpret_cast<const float4*>(w + q * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    // staging: 16 rows per pass over the workgroup, four passes (eight 16-byte loads with the gate) in flight per lane
-    for (int r0 = rg; r0 < nrows; r0 += 64) {
-        float4 a[4], sg[4];
-        bool ok[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int r = r0 + 16 * i, u = t0 - half + r;
-            ok[i] = cok && r < nrows && u >= 0 && u < T;
-            if (ok[i]) {
-                const float* row = x2 + ((long long)b * T + u) * (GLU ? 2 * D : D);
-                a[i] = *reinterpret_cast<const float4*>(row + c);
-                if (GLU) sg[i] = *reinterpret_cast<const float4*>(row + D + c);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int r = r0 + 16 * i;
-            if (r < nrows) {
-                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok[i]) g = GLU ? make_float4(a[i].x * sigm(sg[i].x), a[i].y * sigm(sg[i].y), a[i].z * sigm(sg[i].z), a[i].w * sigm(sg[i].w)) : a[i];
-                *reinterpret_cast<float4*>(sx + r * LDR + quad * 4) = g;
-            }
-        }
-    }
-    __syncthreads();
-    if (!cok) return;
-    f32x2 alo[RT], ahi[RT];
-    const float4 bv = *reinterpret_cast<const float4*>(bias + c);
-#pragma unroll
-    for (int i = 0; i < RT; i++) {
-        alo[i] = f32x2{bv.x, bv.y};
-        ahi[i] = f32x2{bv.z, bv.w};
-    }
-    const float* base = sx + (rg * RT) * LDR + quad * 4;
-#pragma unroll
-    for (int q = 0; q < 32; q++) {
-        if (q < K) {
-            const f32x2 wlo{wp[q].x, wp[q].y}, whi{wp[q].z, wp[q].w};
-#pragma unroll
-            for (int i = 0; i < RT; i++) {
-                const float4 xv = *reinterpret_cast<const float4*>(base + (i + q) * LDR);
-                alo[i] = __builtin_elementwise_fma(wlo, f32x2{xv.x, xv.y}, alo[i]);
-                ahi[i] = __builtin_elementwise_fma(whi, f32x2{xv.z, xv.w}, ahi[i]);
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < RT; i++) {
-        const int t = t0 + rg * RT + i;
-        if (t < T)
-            *reinterpret_cast<float4*>(y + ((long long)b * T + t) * D + c) =
-                DSWISH ? make_float4(dswish(alo[i].x), dswish(alo[i].y), dswish(ahi[i].x), dswish(ahi[i].y))
-                       : make_float4(swoosh_r(alo[i].x), swoosh_r(alo[i].y), swoosh_r(ahi[i].x), swoosh_r(ahi[i].y));
-    }
-}
-
 // ---- SimpleDownsample: softmax(bias)-weighted sum of ds frames, last frame repeated
 // x rows are Din4 float4 wide: a narrower (wider) input is zero-extended (truncated) to D4 on the fly (convert_channels)
 __global__ void k_downsample(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ y, int B,
@@ -744,30 +666,16 @@ static void launch_dw1d(const Ctx& ctx, const float* x, const float* w_kd, const
     hipLaunchKernelGGL((k_glu_dwconv1d<DSWISH, GLU, TT>), grid, dim3(256), lds, ctx.stream, x, w_kd, b, y, B, T, D, K);
     K2_HIP(hipGetLastError());
 }
-template <bool DSWISH, bool GLU, int RT>
-static void launch_dw1d_tall(const Ctx& ctx, const float* x, const float* w_kd, const float* b, float* y, int B, int T, int D, int K) {
-    size_t lds = sizeof(float) * (size_t)(16 * RT + K - 1) * 68;
-    dim3 grid(cdiv(D, 64), cdiv(T, 16 * RT), B);
-    hipLaunchKernelGGL((k_glu_dwconv1d_tall<DSWISH, GLU, RT>), grid, dim3(256), lds, ctx.stream, x, w_kd, b, y, B, T, D, K);
-    K2_HIP(hipGetLastError());
-}
 template <bool DSWISH, bool GLU>
 static void glu_dwconv1d_any(const Ctx& ctx, const float* x2, const float* w_kd, const float* b, float* y, int B, int T, int D,
                              int K) {
     K2_REQUIRE(D % 4 == 0, "dwconv1d: D=%d", D);
     ctx.add_flops(0.0, 2.0 * B * T * (double)D * K, 0);
     if (ctx.dry) return;
-    // tall strips (k_glu_dwconv1d_tall): 128 frames per workgroup where that still gives every CU a workgroup, 64 otherwise; the
-    // 256-channel form for kernels longer than 32 taps, short inputs and forced thread shapes (K2HIP_DW1D_TT, dev builds)
-    if (K <= 32 && D % 64 == 0 && T >= 48 && !tunables().dw1d_tt) {
-        // 128-frame strips only where they still number two workgroups per CU (one strip's staging then runs under another's taps: with
-        // ONE 128-frame workgroup per CU the launch is a serial stage -> compute -> store chain, 11.6 us against 9.0 for the 16-frame form
-        // although it moves half the bytes -- measured, profiles/r05_v1)
-        const long long g128 = (long long)(D / 64) * cdiv(T, 128) * B;
-        if (g128 >= 512) launch_dw1d_tall<DSWISH, GLU, 8>(ctx, x2, w_kd, b, y, B, T, D, K);
-        else launch_dw1d_tall<DSWISH, GLU, 4>(ctx, x2, w_kd, b, y, B, T, D, K);
-        return;
-    }
+    // (Round 5 built the same convolution on tall strips -- 64 channels x 128 / 64 frames per workgroup, 1.23x / 1.47x staged input
+    // instead of this kernel's 2.9x on 16-frame workgroups -- and measured it slower: 11.6 us per launch at one 128-frame workgroup per
+    // CU, 10.0 us at two 64-frame ones, against 9.0 here (profiles/r05_v1 / r05_v2_offline_kernel_stats.csv).  The input was written by
+    // the in_proj GEMM a launch earlier and sits in L2 / the memory-side cache: the launch is not bound by the bytes it re-reads.  Removed.)
     switch (dw1d_tt(B, T, D)) {
         case 8: launch_dw1d<DSWISH, GLU, 8>(ctx, x2, w_kd, b, y, B, T, D, K); break;
         case 4: launch_dw1d<DSWISH, GLU, 4>(ctx, x2, w_kd, b, y, B, T, D, K); break;

@@ -211,6 +211,49 @@ def test_stream_api_mirrors_reference_bookkeeping(tiny_model_path, oracle_tiny, 
     assert s.speech_length == f.size
 
 
+def test_get_results_from_queued_samples_equals_the_feature_route(tiny_model_path, oracle_tiny, utts):
+    """Round 5: AddSamples on a native OfflineStream only queues the raw samples (what the C# shim's fused route calls: no fbank per call,
+    SpeechLength counts the queued samples' frames at once); GetResults then runs fbank + pad + encoder + search for the whole RAGGED
+    batch on the device in one pass (k2hip_offline_recognizer_get_results -> Engine::offline_greedy_samples).  Tokens, timestamps and the
+    stream bookkeeping must equal the oracle's / the feature route's: (a) nobody reads Speech before GetResults -- the batch goes samples ->
+    tokens; (b) one stream's Speech is read first -- that batch is decoded from features materialised at GetResults; (c) a second
+    utterance on the same streams (samples left over behind the last whole frame shift stay queued, as an OnlineFbank keeps them)."""
+    from k2transducerasr_amd import OfflineRecognizer
+    rec = OfflineRecognizer(tiny_model_path)
+    B = len(utts)
+    feats = _feats(oracle_tiny, utts)
+    want = oracle_tiny.recognize_batch(feats)
+    for read_one in (False, True):
+        streams = [rec.create_offline_stream() for _ in utts]
+        for k, (s, u) in enumerate(zip(streams, utts)):
+            cut = 3001 + 517 * k                      # an odd split: the second piece starts inside a frame
+            s.add_samples(u[:cut])
+            s.add_samples(u[cut:])
+            assert s.speech_length == feats[k].size   # OfflineStream.cs:55, before anything was computed
+        if read_one:
+            np.testing.assert_allclose(streams[1].speech.reshape(-1, 80), feats[1], atol=2e-5, rtol=0)
+        res = rec.get_results(streams)
+        for (tok, ts), (wt, wts), s in zip(res, want, streams):
+            assert tok == [0] * (2 * B) + wt and ts == [0] * (2 * B) + wts
+            assert s.speech_length == 0               # RemoveSamples :294
+        if not read_one:
+            # (c) the next utterance on the same streams: what is decoded is fbank([left-over samples ; new samples])
+            tails = [u[(f.shape[0] * 160):] for u, f in zip(utts, feats)]
+            nxt = [np.concatenate([t, u[::-1].copy()]) for t, u in zip(tails, utts)]
+            f2 = [oracle_tiny.fbank(x) for x in nxt]
+            for s, u in zip(streams, utts):
+                s.add_samples(u[::-1].copy())
+            for s, f in zip(streams, f2):
+                assert s.speech_length == f.size
+            want2 = oracle_tiny.recognize_batch(f2)
+            res2 = rec.get_results(streams)
+            for (tok, ts), (wt, wts), (_, ts1) in zip(res2, want2, res):
+                assert tok == [0] * (2 * B) + wt
+                assert ts == ts1 + [0] * (2 * B) + wts    # Timestamps.AddRange (:293): the list keeps growing across calls
+        for s in streams:
+            s.close()
+
+
 def test_errors_are_reported_not_thrown(hip_tiny):
     from k2transducerasr_amd import K2HipError, Model
     with pytest.raises(K2HipError) as e:
