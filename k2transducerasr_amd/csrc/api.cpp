@@ -12,14 +12,64 @@
 
 using namespace k2hip;
 
+// The sample queue of an OfflineStream: a float array in PINNED host memory (Engine::host_alloc), which the GPU reads in place -- the
+// batch's GetResults gathers the streams' samples straight out of these buffers (no staging copy on the host, no separate upload).
+struct PinVec {
+    Engine* e = nullptr;
+    float* p = nullptr;
+    size_t n = 0, cap = 0;
+    PinVec() = default;
+    PinVec(const PinVec&) = delete;
+    PinVec& operator=(const PinVec&) = delete;
+    PinVec(PinVec&& o) noexcept : e(o.e), p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    PinVec& operator=(PinVec&& o) noexcept {
+        if (this != &o) {
+            release();
+            e = o.e; p = o.p; n = o.n; cap = o.cap;
+            o.p = nullptr; o.n = o.cap = 0;
+        }
+        return *this;
+    }
+    ~PinVec() { release(); }
+    void release() noexcept {
+        if (p && e) {
+            try { e->host_free(p); } catch (...) {}
+        }
+        p = nullptr;
+        n = cap = 0;
+    }
+    const float* data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    size_t capacity() const { return cap; }
+    void clear() { n = 0; }
+    void append(Engine& eng, const float* src, size_t cnt) {
+        if (n + cnt > cap) {   // (a stream normally gets ONE AddSamples call, and its buffer comes from the pool: growth is the rare path)
+            const size_t want = std::max(n + cnt, cap + cap / 2);
+            const size_t ncap = (want + 65535) & ~(size_t)65535;
+            float* q = static_cast<float*>(eng.host_alloc((int64_t)(ncap * sizeof(float))));
+            if (n) memcpy(q, p, n * sizeof(float));
+            if (p) eng.host_free(p);
+            e = &eng; p = q; cap = ncap;
+        }
+        memcpy(p + n, src, cnt * sizeof(float));
+        n += cnt;
+    }
+    void erase_front(size_t cnt) {
+        if (cnt >= n) { n = 0; return; }
+        memmove(p, p + cnt, (n - cnt) * sizeof(float));
+        n -= cnt;
+    }
+};
+
 struct k2hip_model {
     Engine engine;
     // Sample buffers of destroyed OfflineStreams, handed to the next streams (a GetResults batch is B x create / AddSamples / destroy
-    // of ~640 KB each: a fresh std::vector per stream pays a first-touch page fault per 4 KB -- ~1 ms per 32 x 10 s batch on the host
-    // thread that drives the GPU).  At most kPoolMax buffers are kept.
+    // of ~640 KB each: pinned allocations cost a system call and a page-table update each, and fresh pages a first-touch fault per 4 KB
+    // -- ~1 ms per 32 x 10 s batch on the host thread that drives the GPU).  At most kPoolMax buffers are kept.
     static constexpr size_t kPoolMax = 128;
     std::mutex wav_mu;
-    std::vector<std::vector<float>> wav_pool;
+    std::vector<PinVec> wav_pool;   // (declared behind `engine`: released first)
     k2hip_model(const char* path, const char* ov, int dev) : engine(path, ov, dev) {}
 };
 
@@ -32,7 +82,7 @@ struct k2hip_offline_stream {
     // samples only (no dither, no cross-frame state), so the frames of this buffer ARE what per-call fbank would have appended, and
     // SpeechLength counts them.  GetResults hands the buffer to the engine's from-samples path (one batched fbank launch for the whole
     // batch, on the device); k2hip_offline_stream_get_speech and a batch that mixes in already materialised features run the fbank here.
-    std::vector<float> wav;
+    PinVec wav;
     std::vector<int64_t> tokens;   // Tokens, initialised to [blank, blank] (:34)
     std::vector<int32_t> timestamps;
     int32_t frame_offset = 0;        // FrameOffset (:39), read by the CTC search (OfflineRecognizer.cs:376,402)
@@ -1079,7 +1129,7 @@ static void offline_materialize(k2hip_offline_stream* s) {
         s->speech.resize(old);
         throw;
     }
-    s->wav.erase(s->wav.begin(), s->wav.begin() + (size_t)nf * c.fbank.frame_shift);
+    s->wav.erase_front((size_t)nf * c.fbank.frame_shift);
 }
 // OfflineStream.AddSamples (:43-57): the samples are queued; their frames count in SpeechLength at once and are computed when
 // somebody needs them (GetResults: on the device, for the whole batch in one launch)
@@ -1098,7 +1148,7 @@ int32_t k2hip_offline_stream_accept_samples(k2hip_offline_stream_t* s, const flo
                     break;
                 }
         }
-        s->wav.insert(s->wav.end(), samples, samples + n);
+        s->wav.append(s->model->engine, samples, (size_t)n);
     });
 }
 int64_t k2hip_offline_stream_speech_length(const k2hip_offline_stream_t* s) {
@@ -1123,7 +1173,7 @@ int32_t k2hip_offline_stream_get_speech(const k2hip_offline_stream_t* s_, float*
 static void offline_consume(k2hip_offline_stream* s, int ctx) {
     if ((int)s->tokens.size() > ctx) {
         const int64_t nf = offline_pending_frames(s);
-        if (nf > 0) s->wav.erase(s->wav.begin(), s->wav.begin() + (size_t)nf * s->model->engine.model().cfg().fbank.frame_shift);
+        if (nf > 0) s->wav.erase_front((size_t)nf * s->model->engine.model().cfg().fbank.frame_shift);
         s->speech.clear();
         s->speech.shrink_to_fit();
     } else {
@@ -1165,7 +1215,7 @@ int32_t k2hip_offline_recognizer_get_results(k2hip_model_t* model, k2hip_offline
         std::vector<int32_t> ts((size_t)B * max_tokens), n(B);
         {
             EngineLock lk(e);
-            if (from_samples) e.offline_greedy_samples(ptrs.data(), nfl.data(), B, tok.data(), ts.data(), n.data(), max_tokens);
+            if (from_samples) e.offline_greedy_samples(ptrs.data(), nfl.data(), B, tok.data(), ts.data(), n.data(), max_tokens, false, /*pinned_src=*/true);
             else e.offline_greedy_feats(ptrs.data(), nfl.data(), B, false, tok.data(), ts.data(), n.data(), max_tokens);
         }
         auto remove_samples = [&](k2hip_offline_stream* s) {   // RemoveSamples (:294 / :418, OfflineStream.cs:58-68)
@@ -1220,7 +1270,7 @@ int32_t k2hip_offline_recognizer_get_result(k2hip_model_t* model, k2hip_offline_
         int64_t nfl[1] = {from_samples ? (int64_t)s->wav.size() : (int64_t)s->speech.size()};
         {
             EngineLock lk(e);
-            if (from_samples) e.offline_greedy_samples(p, nfl, 1, tok.data(), ts.data(), &n, max_tokens, true);
+            if (from_samples) e.offline_greedy_samples(p, nfl, 1, tok.data(), ts.data(), &n, max_tokens, true, /*pinned_src=*/true);
             else e.offline_greedy_feats(p, nfl, 1, true, tok.data(), ts.data(), &n, max_tokens);
         }
         s->tokens = {-1, K2HIP_BLANK_ID};  // hypList (:115-117, :180); the CTC single path seeds the same pair (:318-320)

@@ -1094,12 +1094,15 @@ void Engine::offline_greedy_samples_dev(const float* samples_dev, int64_t n_each
 }
 
 void Engine::offline_greedy_samples(const float* const* samples, const int64_t* n_samples, int B, int64_t* tokens, int32_t* ts,
-                                    int32_t* n_tokens, int max_tokens, bool single) {
+                                    int32_t* n_tokens, int max_tokens, bool single, bool pinned_src) {
     // Host samples, any lengths: ONE pinned staging block [B, nmax] (tails zeroed) + the streams' feature offsets / lengths, one H2D,
     // ONE batched fbank launch over nmax samples per stream, then the fused feature path on the device.  A frame i < frames(n_b) of
     // stream b only reads samples below n_b, so the zero tail never reaches a frame that is kept; pad_logfloor takes each stream's
     // own frame count.  (Rounds 1 - 4 ran one fbank round trip per stream here and uploaded the features again.)  This is what
     // OfflineRecognizer.GetResults reaches through k2hip_offline_recognizer_get_results (OfflineStream.cs:43-57 + OfflineRecognizer.cs:85-91).
+    // pinned_src: the sample arrays live in pinned host memory (the native OfflineStreams' queues, Engine::host_alloc): no staging block --
+    // only the table of pointers and lengths is uploaded, and a gather kernel reads the samples in place over PCIe into the dense [B, nmax]
+    // device block (tails zeroed there): the host's 20 MB staging copy and the separate upload of a 32 x 10 s batch become one pass.
     K2_REQUIRE(B > 0 && max_tokens > 0, "offline_greedy_from_samples: bad B=%d / max_tokens=%d", B, max_tokens);
     K2_REQUIRE(!single || B == 1, "offline_greedy_from_samples: the single-stream loop takes one stream");
     const Config& cf = model_->cfg();
@@ -1112,29 +1115,42 @@ void Engine::offline_greedy_samples(const float* const* samples, const int64_t* 
     }
     const int64_t nfmax = fbank_num_frames(nmax), n_fl = nfmax * cf.feat, L = n_fl + 80 * kTailFrames;
     const int T = (int)(L / cf.feat);  // OfflineProjOfTransducer.cs:59 over PadHelper.cs:17,22
-    const int64_t nb_s = align_up((int64_t)sizeof(float) * B * nmax, 16), nb_in = nb_s + 16 * (int64_t)B;
+    const int64_t nb_s = align_up((int64_t)sizeof(float) * B * nmax, 16);
+    // the host block: [samples (not with pinned_src)] | feature offsets | feature lengths | [sample pointers | sample counts]
+    const int64_t hb_s = pinned_src ? 0 : nb_s, hb_in = hb_s + 32 * (int64_t)B;
     // (sized for the token download as well: finish_tokens takes the same buffer and must not re-allocate it under the upload)
-    char* pin = static_cast<char*>(pinned(std::max<int64_t>(nb_in, (int64_t)B * max_tokens * 12 + 4 * (int64_t)B + 64) + 64));
-    long long* h_off = reinterpret_cast<long long*>(pin + nb_s);
+    char* pin = static_cast<char*>(pinned(std::max<int64_t>(hb_in, (int64_t)B * max_tokens * 12 + 4 * (int64_t)B + 64) + 64));
+    long long* h_off = reinterpret_cast<long long*>(pin + hb_s);
     long long* h_len = h_off + B;
-    auto stage = [&](int b_lo, int b_hi) {
-        for (int b = b_lo; b < b_hi; b++) {
-            float* row = reinterpret_cast<float*>(pin) + (size_t)b * nmax;
-            memcpy(row, samples[b], sizeof(float) * (size_t)n_samples[b]);
-            if (n_samples[b] < nmax) memset(row + n_samples[b], 0, sizeof(float) * (size_t)(nmax - n_samples[b]));
+    const float** h_ptr = reinterpret_cast<const float**>(h_len + B);
+    long long* h_cnt = reinterpret_cast<long long*>(h_ptr + B);
+    if (pinned_src) {
+        for (int b = 0; b < B; b++) {
+            void* dp = nullptr;   // (the device's address of the pinned array: the same value on this platform, asked for all the same)
+            K2_HIP(hipHostGetDevicePointer(&dp, const_cast<float*>(samples[b]), 0));
+            h_ptr[b] = static_cast<const float*>(dp);
+            h_cnt[b] = n_samples[b];
         }
-    };
-    // 20 MB for a 32 x 10 s batch: one host thread copies it in ~2 ms (a seventh of the whole call); four do it in ~0.5 ms
-    const int64_t stage_bytes = (int64_t)sizeof(float) * B * nmax;
-    const int helpers = stage_bytes >= (4 << 20) ? std::min(3, B - 1) : 0;
-    if (helpers > 0) {
-        std::vector<std::thread> th;
-        const int per = (B + helpers) / (helpers + 1);
-        for (int h = 1; h <= helpers; h++) th.emplace_back(stage, std::min(B, h * per), std::min(B, (h + 1) * per));
-        stage(0, std::min(B, per));
-        for (auto& t : th) t.join();
     } else {
-        stage(0, B);
+        auto stage = [&](int b_lo, int b_hi) {
+            for (int b = b_lo; b < b_hi; b++) {
+                float* row = reinterpret_cast<float*>(pin) + (size_t)b * nmax;
+                memcpy(row, samples[b], sizeof(float) * (size_t)n_samples[b]);
+                if (n_samples[b] < nmax) memset(row + n_samples[b], 0, sizeof(float) * (size_t)(nmax - n_samples[b]));
+            }
+        };
+        // 20 MB for a 32 x 10 s batch: one host thread copies it in ~2 ms (a seventh of the whole call); four do it in ~0.5 ms
+        const int64_t stage_bytes = (int64_t)sizeof(float) * B * nmax;
+        const int helpers = stage_bytes >= (4 << 20) ? std::min(3, B - 1) : 0;
+        if (helpers > 0) {
+            std::vector<std::thread> th;
+            const int per = (B + helpers) / (helpers + 1);
+            for (int h = 1; h <= helpers; h++) th.emplace_back(stage, std::min(B, h * per), std::min(B, (h + 1) * per));
+            stage(0, std::min(B, per));
+            for (auto& t : th) t.join();
+        } else {
+            stage(0, B);
+        }
     }
     for (int b = 0; b < B; b++) {
         h_off[b] = (long long)b * n_fl;
@@ -1148,16 +1164,20 @@ void Engine::offline_greedy_samples(const float* const* samples, const int64_t* 
         d_ts = ar.take<int>((int64_t)B * max_tokens);
         d_n = ar.take<int>(B);
         d_ovf = ar.take<int>(1);
-        char* d_in = ar.take<char>(nb_in);
+        char* d_in = ar.take<char>(nb_s + 32 * (int64_t)B);
         float* d_s = reinterpret_cast<float*>(d_in);
         long long* d_off = reinterpret_cast<long long*>(d_in + nb_s);
         long long* d_len = d_off + B;
+        const float* const* d_ptr = reinterpret_cast<const float* const*>(d_len + B);
+        const long long* d_cnt = reinterpret_cast<const long long*>(d_ptr + B);
         float* d_feats = ar.take<float>((int64_t)B * n_fl);
         float* d_x = ar.take<float>((int64_t)B * L);
         if (!c.dry) {
             K2_HIP(hipEventRecord(ev_[0], c.stream));
-            K2_HIP(hipMemcpyAsync(d_in, pin, (size_t)nb_in, hipMemcpyHostToDevice, c.stream));
+            if (pinned_src) K2_HIP(hipMemcpyAsync(d_in + nb_s, pin, (size_t)(32 * (int64_t)B), hipMemcpyHostToDevice, c.stream));
+            else K2_HIP(hipMemcpyAsync(d_in, pin, (size_t)(nb_s + 16 * (int64_t)B), hipMemcpyHostToDevice, c.stream));
         }
+        if (pinned_src) gather_samples(c, d_ptr, d_cnt, d_s, B, nmax);
         FbankArgs a{d_s, nmax, nmax, B, nfmax, d_feats, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift,
                     f.preemph, f.input_scale, f.remove_dc};
         a.melrange = model_->d_melrange;

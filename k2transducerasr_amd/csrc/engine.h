@@ -77,7 +77,7 @@ class Engine {
     void offline_greedy_feats(const float* const* feats, const int64_t* n_floats, int B, bool single, int64_t* tokens,
                               int32_t* ts, int32_t* n_tokens, int max_tokens);
     void offline_greedy_samples(const float* const* samples, const int64_t* n_samples, int B, int64_t* tokens,
-                                int32_t* ts, int32_t* n_tokens, int max_tokens, bool single = false);
+                                int32_t* ts, int32_t* n_tokens, int max_tokens, bool single = false, bool pinned_src = false);
     void offline_greedy_samples_dev(const float* samples_dev, int64_t n_each, int B, int64_t* tokens, int32_t* ts,
                                     int32_t* n_tokens, int max_tokens);
 

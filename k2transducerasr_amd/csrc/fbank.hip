@@ -130,4 +130,32 @@ void fbank(const Ctx& ctx, const FbankArgs& a) {
     K2_HIP(hipGetLastError());
 }
 
+// The native OfflineStreams' sample queues (pinned host memory) -> the dense [B, nmax] block the batched fbank reads.  One float4 per
+// thread and trip; the reads are coalesced 16 B per lane out of host memory, the grid is sized so that enough of them are in flight
+// for the link (a 32 x 10 s batch: 20 MB).
+__global__ __launch_bounds__(256) void k_gather_samples(const float* const* __restrict__ src, const long long* __restrict__ n,
+                                                        float* __restrict__ dst, long long nmax) {
+    const int b = blockIdx.y;
+    const float* s = src[b];
+    const long long cnt = n[b];
+    float* d = dst + (long long)b * nmax;
+    const bool al = ((reinterpret_cast<unsigned long long>(s) | reinterpret_cast<unsigned long long>(d)) & 15) == 0;
+    for (long long i4 = (long long)blockIdx.x * 256 + threadIdx.x; 4 * i4 < nmax; i4 += (long long)gridDim.x * 256) {
+        const long long i = 4 * i4;
+        if (al && i + 3 < cnt && i + 3 < nmax) {
+            *reinterpret_cast<float4*>(d + i) = *reinterpret_cast<const float4*>(s + i);
+        } else {
+            for (int k = 0; k < 4 && i + k < nmax; k++) d[i + k] = i + k < cnt ? s[i + k] : 0.f;
+        }
+    }
+}
+
+void gather_samples(const Ctx& ctx, const float* const* src, const long long* n, float* dst, int B, long long nmax) {
+    if (ctx.dry) return;
+    K2_REQUIRE(B > 0 && nmax > 0, "gather_samples: empty batch");
+    const int gx = (int)std::min<long long>(cdiv((int)std::min<long long>((nmax + 3) / 4, 1 << 30), 256), 64);   // 64 x B workgroups, ~10 trips each at 10 s
+    hipLaunchKernelGGL(k_gather_samples, dim3(gx, B), dim3(256), 0, ctx.stream, src, n, dst, nmax);
+    K2_HIP(hipGetLastError());
+}
+
 }  // namespace k2hip

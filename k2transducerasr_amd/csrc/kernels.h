@@ -310,6 +310,8 @@ struct FbankArgs {
     const float* melrange = nullptr;  // [num_bins][2] extent of each mel filter's non-zero weights (model table)
 };
 void fbank(const Ctx& ctx, const FbankArgs& a);
+// dst[b][0 .. nmax) = src[b][0 .. n[b]) followed by zeros; src[b] may be pinned host memory (read in place over PCIe), 16 B aligned
+void gather_samples(const Ctx& ctx, const float* const* src, const long long* n, float* dst, int B, long long nmax);
 
 // ---- decoder / joiner / greedy ----------------------------------------------------
 struct DecJoinW {

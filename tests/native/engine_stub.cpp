@@ -150,7 +150,7 @@ void Engine::offline_greedy_feats(const float* const* feats, const int64_t* n_fl
     fake_search(B, encoder_out_frames((int)(mx / model_->cfg().feat) + 19), tokens, ts, n_tokens, max_tokens);
 }
 void Engine::offline_greedy_samples(const float* const* samples, const int64_t* n_samples, int B, int64_t* tokens, int32_t* ts, int32_t* n_tokens,
-                                    int max_tokens, bool) {
+                                    int max_tokens, bool, bool) {
     int64_t mx = 0;
     volatile float sink = 0.f;
     for (int b = 0; b < B; b++) {
