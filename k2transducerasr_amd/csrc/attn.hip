@@ -47,6 +47,16 @@ __global__ __launch_bounds__(512, 4) void k_attn_scores_softmax(const float* __r
             if (row < T) fq[g] = *reinterpret_cast<const float4*>(base + (long long)row * ld + qoff + 8 * g + 4 * lh);
         }
     }
+    const int njt = (T + 31) / 32;
+    // the next key tile's fragments are requested before this tile's MFMAs and positional adds
+    float4 fkn[NG];
+    auto load_keys = [&](int jt) {
+        if (jt >= njt) return;                 // (wave-uniform)
+        const int j = min(jt * 32 + li, T - 1);   // (a key past T reads key T-1: its column is never written)
+#pragma unroll
+        for (int g = 0; g < NG; g++) fkn[g] = *reinterpret_cast<const float4*>(base + (long long)j * ld + koff + 8 * g + 4 * lh);
+    };
+    load_keys(wave);   // (requested in front of the window staging: one memory latency for both)
     // the positional rows this workgroup can touch, n = T-1-i+j for its rows i and every key j: one window of <= T+R-1
     // consecutive rows of pp (16 B each for this head) -> LDS, so the per-element gather below is an LDS read
     float4* PW = reinterpret_cast<float4*>(S + R * lds_stride);
@@ -57,18 +67,6 @@ __global__ __launch_bounds__(512, 4) void k_attn_scores_softmax(const float* __r
     if (tid < R) PR[tid] = i0 + tid < T ? *reinterpret_cast<const float4*>(base + (long long)(i0 + tid) * ld + poff) : make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
-    const int njt = (T + 31) / 32;
-    // the next key tile's fragments are requested before this tile's MFMAs and positional adds
-    float4 fkn[NG];
-    auto load_keys = [&](int jt) {
-        const int j = jt * 32 + li;
-#pragma unroll
-        for (int g = 0; g < NG; g++) {
-            fkn[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (jt < njt && j < T) fkn[g] = *reinterpret_cast<const float4*>(base + (long long)j * ld + koff + 8 * g + 4 * lh);
-        }
-    };
-    load_keys(wave);
     for (int jt = wave; jt < njt; jt += 8) {
         int j = jt * 32 + li;  // this lane's key (as B-operand column and as accumulator column)
         float4 fk[NG];
@@ -86,17 +84,24 @@ __global__ __launch_bounds__(512, 4) void k_attn_scores_softmax(const float* __r
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fq[g].w, fk[g].w, acc, 0, 0, 0);
         }
         if (j < T) {
+            // rel-shift in gather form: relative index n = T-1-i+j in [0, 2T-2].  No condition on the row (a row past T reads the window
+            // entry of row T-1 and is never used): under `if (i < T)` every one of the 16 window reads sat in its own block behind its
+            // own LDS wait.  Eight reads per wait now (round 5: 75.5 -> 73.6 us per launch at T = 505 -- the phase is bound by MFMA +
+            // vector issue at two workgroups per CU, not by these round trips; DESIGN "Round 5")
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                int i = i0 + rl;
-                float s = acc[r];
-                if (i < T) {
-                    // rel-shift in gather form: relative index n = T-1-i+j in [0, 2T-2]
-                    const float4 e = PW[T - 1 - i + j - nlo], pq = PR[rl];
-                    s += pq.x * e.x + pq.y * e.y + pq.z * e.z + pq.w * e.w;
+            for (int r0 = 0; r0 < 16; r0 += 8) {
+                float4 e[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int rl = ((r0 + r) & 3) + 8 * ((r0 + r) >> 2) + 4 * lh;
+                    e[r] = PW[T - 1 - min(i0 + rl, T - 1) + j - nlo];
                 }
-                S[rl * lds_stride + j] = s;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int rl = ((r0 + r) & 3) + 8 * ((r0 + r) >> 2) + 4 * lh;
+                    const float4 pq = PR[rl];
+                    S[rl * lds_stride + j] = acc[r0 + r] + (pq.x * e[r].x + pq.y * e[r].y + pq.z * e[r].z + pq.w * e[r].w);
+                }
             }
         }
     }
