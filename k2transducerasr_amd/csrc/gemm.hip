@@ -1991,7 +1991,9 @@ void gemm(const Ctx& ctx, const GemmArgs& a) {
         // reproduces).  One wave per SIMD on a single-round grid, so its prologue and tail are fully exposed: six fixed steps.
         if (a.N % 96 == 0 && !a.glu && a.M >= 1024) {
             const long long tiles = (long long)cdiv(a.M, 64) * (a.N / 96);
-            const double cost = (double)cdiv(tiles, 256) * 64 * 96 * (nk + 6.0) * 1.10;
+            // (a long K loop amortises the form's extra operand traffic: 16160 x 192 x 2432 is 126.8 us on it against 134.8 on 128 x 32,
+            // gpurun_out/r5q/lab_p16_all.txt -- 6 % over the other tiles from 64 K steps, 10 % below)
+            const double cost = (double)cdiv(tiles, 256) * 64 * 96 * (nk + 6.0) * (nk >= 64 ? 1.06 : 1.10);
             if (tiles >= 128 && cost < best_cost) {
                 launch_p16_idx(ctx, b, 0);
                 K2_HIP(hipGetLastError());
