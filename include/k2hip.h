@@ -228,10 +228,13 @@ int32_t k2hip_device_upload(k2hip_model_t* model, void* dev_dst, const void* hos
 int32_t k2hip_synchronize(k2hip_model_t* model);
 
 /* ---- OfflineStream (OfflineStream.cs:7-99): per-utterance feature buffer.
- * accept_samples = AddSamples (:43-57): runs the streaming fbank on the new
- * samples (left-over samples shorter than a frame shift are carried to the next
- * call, as an OnlineFbank does; InputFinished is never called by the reference,
- * SURVEY Q16) and APPENDS the frames to Speech. */
+ * accept_samples = AddSamples (:43-57).  What a caller can observe is the reference's: speech_length counts the frames of
+ * the streaming fbank over everything accepted so far (left-over samples shorter than a frame shift are carried to the
+ * next call, as an OnlineFbank does; InputFinished is never called by the reference), get_speech returns them.
+ * WHEN they are computed is not: the call only copies the samples into the stream's queue (no fbank launch, no lock on the
+ * model); k2hip_offline_recognizer_get_results computes the whole batch's frames in one launch on the device, get_speech
+ * computes this stream's.  The queue lives in PINNED host memory (~4 bytes per sample; the buffers of destroyed streams are
+ * kept per model, at most 128 of them, and handed to the next streams), which the device reads in place. */
 int32_t k2hip_offline_stream_create(k2hip_model_t* model, k2hip_offline_stream_t** out);
 int32_t k2hip_offline_stream_destroy(k2hip_offline_stream_t* s);
 int32_t k2hip_offline_stream_accept_samples(k2hip_offline_stream_t* s, const float* samples, int64_t n);
