@@ -679,13 +679,17 @@ void Engine::beam_device(const Ctx& c, const float* enc, int B, int Tp, long lon
 
 // Back-off of the parted searches.  A search whose column slabs are not co-resident (other handles or processes on the GPU hold the
 // CUs) spins to its bound, reports the timeout and is repeated with one workgroup per stream -- correct, but the timeout costs
-// milliseconds, every call (four streaming recognizers on one GPU: 12.6 ms per tick against 4.2).  After a timeout the next 64
+// milliseconds, every call (four streaming recognizers on one GPU: 12.6 ms per tick against 4.2).  After a timeout the next 4
 // searches of this engine go out with one part per stream straight away; each further timeout doubles the span (up to 8192), a parted
 // search that comes through clears it.
 void Engine::note_search(bool parted, bool timed_out) {
     if (timed_out) {
         if (tunables().test_greedy_timeout == 1) return;   // (the tests' forced timeouts want the next search parted again)
-        one_part_span_ = std::min(std::max(2 * one_part_span_, 64), 8192);
+        // exponential back-off from FOUR searches (round 5; 64 before): one timeout while the process warms up -- arenas growing under
+        // the first batches, the search kernel's partner slab placed late -- put a whole 20-step run on the one-slab form (the beam-4
+        // leg read 16.6 - 16.9 ms per batch in such runs and 14.4 - 14.9 in the others); a GPU that stays contended still reaches
+        // 64 after four more timeouts and 8192 after eleven
+        one_part_span_ = std::min(std::max(2 * one_part_span_, 4), 8192);
         one_part_left_ = one_part_span_;
     } else if (one_part_left_ > 0) {
         one_part_left_--;

@@ -642,7 +642,7 @@ def test_value_projection_inside_the_attention_kernel_equals_the_gemm_form(strea
 def test_streaming_search_timeout_backs_off(tmp_path):
     """The tick of a large-vocabulary model runs the parted persistent search.  A timeout of the slabs' exchange (forced in the hook's
     "as a real one" form) is noticed when the tick's results come down: the search is repeated with one workgroup per stream from the
-    launch's record, and the engine backs off to the unparted form for the next 64 searches.  Tokens, timestamps and Hyp stay on the oracle's through all of it, and the retry
+    launch's record, and the engine backs off to the unparted form for the next searches (four after a first timeout, doubling while they repeat).  Tokens, timestamps and Hyp stay on the oracle's through all of it, and the retry
     counter moves exactly once."""
     import ctypes as C
     from k2transducerasr_amd import OnlineRecognizer, load_library, set_switch
