@@ -163,7 +163,9 @@ int offline(const char* path, unsigned long long seed, int rounds) {
             long long total = 0;
             const int pieces = 1 + (int)(rng() % 3);
             for (int p = 0; p < pieces; p++) {
-                const long long n = 400 + (long long)(rng() % 20000);
+                // (one piece in eight is long enough to outgrow the stream's pinned queue -- 64 K samples at first, pooled buffers larger:
+                // the queue is then re-allocated with its contents)
+                const long long n = 400 + (long long)(rng() % (rng() % 8 == 0 ? 150000 : 20000));
                 std::vector<float> w((size_t)n, 0.25f);
                 OK(k2hip_offline_stream_accept_samples(ss[b], w.data(), n));
                 total += n;

@@ -211,6 +211,32 @@ def test_stream_api_mirrors_reference_bookkeeping(tiny_model_path, oracle_tiny, 
     assert s.speech_length == f.size
 
 
+def test_sample_queues_grow_and_are_reused_across_streams(tiny_model_path, oracle_tiny):
+    """The native OfflineStreams' sample queues are pinned host buffers that GetResults reads in place: (a) a queue that outgrows its
+    buffer (a short first piece: 64 K samples of capacity, then a long second piece) is re-allocated with its contents; (b) the buffers
+    of destroyed streams go back to the model's pool and are handed to later streams of OTHER lengths -- a short utterance in a long
+    stream's buffer, a longer one than anything pooled.  Every round's tokens and timestamps equal the oracle's on the same audio."""
+    from k2transducerasr_amd import OfflineRecognizer
+    from k2transducerasr_amd.synth import synth_utterance
+    rec = OfflineRecognizer(tiny_model_path)
+    rounds = [[5.5, 0.9, 4.6], [0.7, 5.0], [6.5, 1.2, 0.8, 5.9]]      # seconds; 64 K samples = 4.1 s
+    for r, secs in enumerate(rounds):
+        us = [synth_utterance(4200 + 10 * r + k, s) for k, s in enumerate(secs)]
+        feats = [oracle_tiny.fbank(u) for u in us]
+        want = oracle_tiny.recognize_batch(feats)
+        streams = [rec.create_offline_stream() for _ in us]
+        for s, u, f in zip(streams, us, feats):
+            s.add_samples(u[:1000])          # takes a pooled buffer (or a fresh 64 K one) ...
+            s.add_samples(u[1000:])          # ... which a long utterance outgrows here
+            assert s.speech_length == f.size
+        res = rec.get_results(streams)
+        B = len(us)
+        for (tok, ts), (wt, wts) in zip(res, want):
+            assert tok == [0] * (2 * B) + wt and ts == [0] * (2 * B) + wts, r
+        for s in streams:
+            s.close()
+
+
 def test_get_results_from_queued_samples_equals_the_feature_route(tiny_model_path, oracle_tiny, utts):
     """Round 5: AddSamples on a native OfflineStream only queues the raw samples (what the C# shim's fused route calls: no fbank per call,
     SpeechLength counts the queued samples' frames at once); GetResults then runs fbank + pad + encoder + search for the whole RAGGED
