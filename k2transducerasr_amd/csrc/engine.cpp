@@ -1109,6 +1109,7 @@ void Engine::offline_greedy_samples(const float* const* samples, const int64_t* 
     // device block (tails zeroed there): the host's 20 MB staging copy and the separate upload of a 32 x 10 s batch become one pass.
     K2_REQUIRE(B > 0 && max_tokens > 0, "offline_greedy_from_samples: bad B=%d / max_tokens=%d", B, max_tokens);
     K2_REQUIRE(!single || B == 1, "offline_greedy_from_samples: the single-stream loop takes one stream");
+    K2_HIP(hipSetDevice(device_));   // (the pinned queues' device addresses are asked for below, before run_sized sets it)
     const Config& cf = model_->cfg();
     const FbankOpts& f = cf.fbank;
     K2_REQUIRE(cf.ctc || cf.J == 512, "offline loops hard-code a 512-wide encoder_out (OfflineRecognizer.cs:103,201); joiner_dim is %d", cf.J);
