@@ -49,8 +49,11 @@ struct PinVec {
             const size_t ncap = (want + 65535) & ~(size_t)65535;
             float* q = static_cast<float*>(eng.host_alloc((int64_t)(ncap * sizeof(float))));
             if (n) memcpy(q, p, n * sizeof(float));
-            if (p) eng.host_free(p);
+            float* old = p;
             e = &eng; p = q; cap = ncap;
+            if (old) {
+                try { eng.host_free(old); } catch (...) {}   // (the queue is consistent either way)
+            }
         }
         memcpy(p + n, src, cnt * sizeof(float));
         n += cnt;

@@ -1120,7 +1120,10 @@ void Engine::offline_greedy_samples(const float* const* samples, const int64_t* 
     }
     const int64_t nfmax = fbank_num_frames(nmax), n_fl = nfmax * cf.feat, L = n_fl + 80 * kTailFrames;
     const int T = (int)(L / cf.feat);  // OfflineProjOfTransducer.cs:59 over PadHelper.cs:17,22
-    const int64_t nb_s = align_up((int64_t)sizeof(float) * B * nmax, 16);
+    // rows of the dense sample block are `ns` floats apart: nmax rounded up to 4, so that every row starts on 16 bytes for any lengths (the
+    // gather moves float4; a row that did not would take its scalar path -- four 4-byte reads per lane over PCIe)
+    const int64_t ns = (nmax + 3) & ~(int64_t)3;
+    const int64_t nb_s = align_up((int64_t)sizeof(float) * B * ns, 16);
     // the host block: [samples (not with pinned_src)] | feature offsets | feature lengths | [sample pointers | sample counts]
     const int64_t hb_s = pinned_src ? 0 : nb_s, hb_in = hb_s + 32 * (int64_t)B;
     // (sized for the token download as well: finish_tokens takes the same buffer and must not re-allocate it under the upload)
@@ -1139,13 +1142,13 @@ void Engine::offline_greedy_samples(const float* const* samples, const int64_t* 
     } else {
         auto stage = [&](int b_lo, int b_hi) {
             for (int b = b_lo; b < b_hi; b++) {
-                float* row = reinterpret_cast<float*>(pin) + (size_t)b * nmax;
+                float* row = reinterpret_cast<float*>(pin) + (size_t)b * ns;
                 memcpy(row, samples[b], sizeof(float) * (size_t)n_samples[b]);
-                if (n_samples[b] < nmax) memset(row + n_samples[b], 0, sizeof(float) * (size_t)(nmax - n_samples[b]));
+                if (n_samples[b] < ns) memset(row + n_samples[b], 0, sizeof(float) * (size_t)(ns - n_samples[b]));
             }
         };
         // 20 MB for a 32 x 10 s batch: one host thread copies it in ~2 ms (a seventh of the whole call); four do it in ~0.5 ms
-        const int64_t stage_bytes = (int64_t)sizeof(float) * B * nmax;
+        const int64_t stage_bytes = (int64_t)sizeof(float) * B * ns;
         const int helpers = stage_bytes >= (4 << 20) ? std::min(3, B - 1) : 0;
         if (helpers > 0) {
             std::vector<std::thread> th;
@@ -1182,8 +1185,8 @@ void Engine::offline_greedy_samples(const float* const* samples, const int64_t* 
             if (pinned_src) K2_HIP(hipMemcpyAsync(d_in + nb_s, pin, (size_t)(32 * (int64_t)B), hipMemcpyHostToDevice, c.stream));
             else K2_HIP(hipMemcpyAsync(d_in, pin, (size_t)(nb_s + 16 * (int64_t)B), hipMemcpyHostToDevice, c.stream));
         }
-        if (pinned_src) gather_samples(c, d_ptr, d_cnt, d_s, B, nmax);
-        FbankArgs a{d_s, nmax, nmax, B, nfmax, d_feats, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift,
+        if (pinned_src) gather_samples(c, d_ptr, d_cnt, d_s, B, ns);
+        FbankArgs a{d_s, nmax, ns, B, nfmax, d_feats, model_->d_window, model_->d_melw, f.frame_len, f.frame_shift,
                     f.preemph, f.input_scale, f.remove_dc};
         a.melrange = model_->d_melrange;
         fbank(c, a);
