@@ -548,6 +548,39 @@ __global__ void k_upsample_combine(const float* __restrict__ orig, const float* 
     reinterpret_cast<float4*>(y)[i] = make_float4(o.x + (u.x - o.x) * s.x, o.y + (u.y - o.y) * s.y,
                                                   o.z + (u.z - o.z) * s.z, o.w + (u.w - o.w) * s.w);
 }
+// One stack's out_combiner and the NEXT stack's SimpleDownsample in one pass (both stacks downsampled: four of the six stack seams of
+// Zipformer2): thread (b, t2, q) forms the ds2 combined frames of its group -- y[b, t, q] = orig + (upsample(xd) - orig) * scale, the
+// expression of k_upsample_combine -- writes them, and sums them with the next stack's softmax(bias2) weights into xd2[b, t2, q], in
+// k_downsample's order (the last frame repeated past T; y is D4 float4 wide, xd2 D2_4: zero-extended / truncated like convert_channels).
+__global__ void k_upsample_combine_downsample(const float* __restrict__ orig, const float* __restrict__ xd, const float* __restrict__ scale,
+                                              float* __restrict__ y, const float* __restrict__ bias2, float* __restrict__ xd2, int B, int T,
+                                              int Td, int D4, int ds, int Do4, int Td2, int D2_4, int ds2) {
+    const int W4 = max(D4, D2_4);
+    long long n = (long long)B * Td2 * W4;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float wgt[16], mx = -INFINITY, sum = 0.f;
+    for (int k = 0; k < ds2; k++) mx = fmaxf(mx, bias2[k]);
+    for (int k = 0; k < ds2; k++) { wgt[k] = expf(bias2[k] - mx); sum += wgt[k]; }
+    for (int k = 0; k < ds2; k++) wgt[k] /= sum;
+    const int q = (int)(i % W4);
+    const long long bt = i / W4;
+    const int t2 = (int)(bt % Td2), b = (int)(bt / Td2);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < D4) {
+        const float4 sc = reinterpret_cast<const float4*>(scale)[q];
+        for (int k = 0; k < ds2; k++) {
+            const int t = t2 * ds2 + k, tt = min(t, T - 1);
+            const long long row = (long long)b * T + tt;
+            const float4 o = q < Do4 ? reinterpret_cast<const float4*>(orig)[row * Do4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 u = reinterpret_cast<const float4*>(xd)[((long long)b * Td + tt / ds) * D4 + q];
+            const float4 v = make_float4(o.x + (u.x - o.x) * sc.x, o.y + (u.y - o.y) * sc.y, o.z + (u.z - o.z) * sc.z, o.w + (u.w - o.w) * sc.w);
+            if (t < T) reinterpret_cast<float4*>(y)[row * D4 + q] = v;
+            s.x += v.x * wgt[k]; s.y += v.y * wgt[k]; s.z += v.z * wgt[k]; s.w += v.w * wgt[k];
+        }
+    }
+    if (q < D2_4) reinterpret_cast<float4*>(xd2)[((long long)b * Td2 + t2) * D2_4 + q] = s;
+}
 // convert_num_channels: truncate / zero-pad
 __global__ void k_convert_channels(const float* __restrict__ x, float* __restrict__ y, long long M, int Din4, int Dout4) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -707,6 +740,14 @@ void upsample_combine(const Ctx& ctx, const float* orig, const float* xd, const 
                       int Td, int D, int ds, int Dorig) {
     long long n = (long long)B * T * (D / 4);
     LAUNCH(k_upsample_combine, dim3(nblocks(n, 256)), dim3(256), orig, xd, scale, y, B, T, Td, D / 4, ds, (Dorig > 0 ? Dorig : D) / 4);
+}
+void upsample_combine_downsample(const Ctx& ctx, const float* orig, const float* xd, const float* scale, float* y, const float* bias2,
+                                 float* xd2, int B, int T, int Td, int D, int ds, int Dorig, int D2, int ds2) {
+    K2_REQUIRE(ds2 >= 1 && ds2 <= 16 && D % 4 == 0 && D2 % 4 == 0, "upsample_combine_downsample: ds2=%d D=%d D2=%d unsupported", ds2, D, D2);
+    const int Td2 = (T + ds2 - 1) / ds2;
+    long long n = (long long)B * Td2 * (std::max(D, D2) / 4);
+    LAUNCH(k_upsample_combine_downsample, dim3(nblocks(n, 256)), dim3(256), orig, xd, scale, y, bias2, xd2, B, T, Td, D / 4, ds,
+           (Dorig > 0 ? Dorig : D) / 4, Td2, D2 / 4, ds2);
 }
 void convert_channels(const Ctx& ctx, const float* x, float* y, int M, int Din, int Dout) {
     long long n = (long long)M * (Dout / 4);

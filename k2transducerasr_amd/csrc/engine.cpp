@@ -484,6 +484,7 @@ float* Engine::encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, 
     float* outputs[kMaxStacks] = {nullptr};
     float* x = x0;
     int Dcur = cf.dim[0];
+    float *pre_y = nullptr, *pre_xd = nullptr;
     for (int si = 0; si < cf.ns; si++) {
         const int D = cf.dim[si], ds = cf.ds[si];
         // the stack's input is the previous output zero-extended / truncated to D channels (convert_channels): a stack that runs at
@@ -502,13 +503,28 @@ float* Engine::encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, 
             x = xi;
         } else {
             const int Td = (T50 + ds - 1) / ds;
-            float* y = ar.take<float>((int64_t)M * D);
+            // Round 5: where the NEXT stack is downsampled too, this stack's out_combiner and that stack's SimpleDownsample are one
+            // launch (upsample_combine_downsample): its two outputs -- the next stack's `y` is not one of them, only reserved here -- are
+            // taken in front of this stack's mark, so that they outlive the rewind.
+            float* y = pre_y ? pre_y : ar.take<float>((int64_t)M * D);
+            float* xd_ready = pre_xd;   // this stack's downsampled input, if the previous stack's combiner produced it
+            pre_y = pre_xd = nullptr;
+            const bool fuse_next = si + 1 < cf.ns && cf.ds[si + 1] > 1;
+            const int D2 = fuse_next ? cf.dim[si + 1] : 0, ds2 = fuse_next ? cf.ds[si + 1] : 1;
+            if (fuse_next) {
+                pre_y = ar.take<float>((int64_t)M * D2);
+                pre_xd = ar.take<float>((int64_t)B * ((T50 + ds2 - 1) / ds2) * D2);
+            }
             int64_t mark = ar.mark();
-            float* xd = ar.take<float>((int64_t)B * Td * D);
-            downsample(c, x, m.wf("encoder.encoders.%d.downsample.bias", si), xd, B, T50, D, ds, Din);
+            float* xd = xd_ready ? xd_ready : ar.take<float>((int64_t)B * Td * D);
+            if (!xd_ready) downsample(c, x, m.wf("encoder.encoders.%d.downsample.bias", si), xd, B, T50, D, ds, Din);
             const float* pe = c.dry ? nullptr : pos_emb(Td);
             for (int li = 0; li < cf.nlayer[si]; li++) encoder_layer(c, si, li, xd, pe, B, Td);
-            upsample_combine(c, x, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y, B, T50, Td, D, ds, Din);
+            if (fuse_next)
+                upsample_combine_downsample(c, x, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y,
+                                            m.wf("encoder.encoders.%d.downsample.bias", si + 1), pre_xd, B, T50, Td, D, ds, Din, D2, ds2);
+            else
+                upsample_combine(c, x, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y, B, T50, Td, D, ds, Din);
             ar.rewind(mark);
             x = y;
         }

@@ -284,6 +284,9 @@ bool conformer_scores_softmax(const Ctx& ctx, const float* qu, const float* qv, 
 void downsample(const Ctx& ctx, const float* x, const float* bias, float* y, int B, int T, int D, int ds, int Din = 0);
 void upsample_combine(const Ctx& ctx, const float* orig, const float* xd, const float* scale, float* y, int B, int T,
                       int Td, int D, int ds, int Dorig = 0);
+// the same and the NEXT stack's downsample of its result in one launch: y as above, xd2[b, t2, :D2] = sum_k softmax(bias2)_k y[b, ds2 t2 + k, :]
+void upsample_combine_downsample(const Ctx& ctx, const float* orig, const float* xd, const float* scale, float* y, const float* bias2,
+                                 float* xd2, int B, int T, int Td, int D, int ds, int Dorig, int D2, int ds2);
 void convert_channels(const Ctx& ctx, const float* x, float* y, int M, int Din, int Dout);
 // Zipformer2._get_full_dim_output without the concatenated tensor: columns [col1[i-1], col1[i]) of the full-width row live in src[i]
 // (row width ld[i]); downsample_full = that gather + SimpleDownsample(ds) in one launch
@@ -451,10 +454,10 @@ struct BeamArgs {
 void beam_search(const Ctx& ctx, const DecJoinW& w, const BeamArgs& a);
 
 // ---- streaming (online.hip): device-resident per-stream caches indexed by slot ------------------
-void convnext_cat(const Ctx& ctx, const float* a3, const float* pool, long long slot_stride, long long embed_off,
-                  const int* slots, float* cat, int B, int T3, int F, int C);
-void convnext_cache_update(const Ctx& ctx, const float* a3, float* pool, long long slot_stride, long long embed_off,
-                           const int* slots, int B, int T3, int Tc, int F, int C);
+// ConvNeXt.streaming_forward's data movement in one launch: cat[b] = [cached_left_pad ; x], the cache advanced to x's frames Tc-3 .. Tc-1,
+// byp[b] = x[b, :Tc] (the bypass operand)
+void convnext_cat(const Ctx& ctx, const float* a3, float* pool, long long slot_stride, long long embed_off, const int* slots, float* cat,
+                  float* byp, int B, int T3, int Tc, int F, int C);
 // tanh_gated: the new rows are formed as x[width + c] * tanh(x[c]) from rows of >= 2*width floats (NonlinAttention's gated input)
 void cat_shift(const Ctx& ctx, float* pool, long long slot_stride, long long off, const int* slots, const float* newrows,
                int ldn, float* cat, int B, int L, int Tc, int width, bool tanh_gated = false);
@@ -476,6 +479,7 @@ void glu_causal_conv(const Ctx& ctx, const float* x2, float* pool, long long slo
 //   fifo_append: frames [g][0 .. nf) of `src` go to ring rows (pos[g] + i) % cap of slot slots[g] (pos[g] < 0: skipped)
 //   fifo_gather: x[b][t] = ring row (head[b] + t) % cap of slot slots[b], t < T  -- the chunk input of a step, no host round trip
 void fifo_append(const Ctx& ctx, float* fifo, int cap, int feat, const float* src, const int* slots, const int* pos, int G, int nf);
+// (the gathered frames pass the online PadSequence's floor of genuine zeros on the way: PadHelper.cs:9-13,58)
 void fifo_gather(const Ctx& ctx, const float* fifo, int cap, int feat, const int* slots, const int* head, float* x, int B, int T);
 void zero_floats(const Ctx& ctx, float* p, long long n);
 // ---- streaming Zipformer v1 (zipformer1.hip; OnlineProjOfZipformer) ------------------------------

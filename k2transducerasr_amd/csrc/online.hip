@@ -18,10 +18,14 @@ __device__ __forceinline__ float fast_softplus(float z) { return z > 15.f ? z : 
 __device__ __forceinline__ float swoosh_r(float v) { return fast_softplus(v - 1.0f) - 0.08f * v - 0.313261687f; }
 __device__ __forceinline__ float sigm(float s) { return 1.0f / (1.0f + __expf(-s)); }
 
-// ConvNeXt.streaming_forward: cat[b] = [cached_left_pad (3 frames) ; x (T3 frames)], NHWC
-__global__ void k_convnext_cat(const float* __restrict__ a3, const float* __restrict__ pool, long long slot_stride,
-                               long long embed_off, const int* __restrict__ slots, float* __restrict__ cat, int B, int T3,
-                               int F, int C) {
+// ConvNeXt.streaming_forward in one pass over x (round 5; three launches before: this one, the cache update, a 2-D copy):
+//   cat[b] = [cached_left_pad (3 frames) ; x (T3 frames)], NHWC
+//   cached_left_pad <- cat[:, :, Tc:Tc+3] = x frames Tc-3 .. Tc-1   (a cache element is read -- into cat -- and rewritten by the SAME
+//                                                                    thread, in that order: nobody else touches it)
+//   byp[b] = x[b, :Tc]                                               (the module's bypass operand)
+__global__ void k_convnext_cat(const float* __restrict__ a3, float* __restrict__ pool, long long slot_stride,
+                               long long embed_off, const int* __restrict__ slots, float* __restrict__ cat, float* __restrict__ byp, int B,
+                               int T3, int Tc, int F, int C) {
     long long n = (long long)B * (T3 + 3) * F * C;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -31,23 +35,15 @@ __global__ void k_convnext_cat(const float* __restrict__ a3, const float* __rest
     long long bt = p / F;
     int t = (int)(bt % (T3 + 3)), b = (int)(bt / (T3 + 3));
     float v;
-    if (t < 3) v = pool[(long long)slots[b] * slot_stride + embed_off + ((long long)c * 3 + t) * F + f];
-    else v = a3[(((long long)b * T3 + (t - 3)) * F + f) * C + c];
+    if (t < 3) {
+        float* cp = pool + (long long)slots[b] * slot_stride + embed_off + ((long long)c * 3 + t) * F + f;
+        v = *cp;
+        *cp = a3[(((long long)b * T3 + (Tc - 3 + t)) * F + f) * C + c];
+    } else {
+        v = a3[(((long long)b * T3 + (t - 3)) * F + f) * C + c];
+        if (t - 3 < Tc) byp[(((long long)b * Tc + (t - 3)) * F + f) * C + c] = v;
+    }
     cat[i] = v;
-}
-// cached_left_pad <- cat[:, :, Tc:Tc+3] = x frames Tc-3 .. Tc-1
-__global__ void k_convnext_cache(const float* __restrict__ a3, float* __restrict__ pool, long long slot_stride,
-                                 long long embed_off, const int* __restrict__ slots, int B, int T3, int Tc, int F, int C) {
-    long long n = (long long)B * C * 3 * F;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int f = (int)(i % F);
-    long long p = i / F;
-    int t = (int)(p % 3);
-    p /= 3;
-    int c = (int)(p % C), b = (int)(p / C);
-    pool[(long long)slots[b] * slot_stride + embed_off + ((long long)c * 3 + t) * F + f] =
-        a3[(((long long)b * T3 + (Tc - 3 + t)) * F + f) * C + c];
 }
 
 // cat[b] = [cache[slot_b] (L rows) ; new[b] (Tc rows)] and cache[slot_b] <- cat[b][Tc:], in ONE pass: a thread owns the rows
@@ -391,8 +387,13 @@ __global__ void k_fifo_gather(const float* __restrict__ fifo, int cap, int f4, c
     const long long n = (long long)T * f4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int t = (int)(i / f4), q = (int)(i % f4);
-        reinterpret_cast<float4*>(x)[((long long)b * T + t) * f4 + q] =
-            reinterpret_cast<const float4*>(fifo)[((long long)slots[b] * cap + (h + t) % cap) * f4 + q];
+        float4 v = reinterpret_cast<const float4*>(fifo)[((long long)slots[b] * cap + (h + t) % cap) * f4 + q];
+        // the online PadSequence's floor of genuine zeros (PadHelper.cs:9-13,58; k_logfloor) on the way through: one launch fewer per tick
+        v.x = v.x == 0.0f ? -23.025850929940457F : v.x;
+        v.y = v.y == 0.0f ? -23.025850929940457F : v.y;
+        v.z = v.z == 0.0f ? -23.025850929940457F : v.z;
+        v.w = v.w == 0.0f ? -23.025850929940457F : v.w;
+        reinterpret_cast<float4*>(x)[((long long)b * T + t) * f4 + q] = v;
     }
 }
 
@@ -412,18 +413,13 @@ inline int nb(long long n, int per) { return (int)((n + per - 1) / per); }
 
 }  // namespace
 
-void convnext_cat(const Ctx& ctx, const float* a3, const float* pool, long long slot_stride, long long embed_off,
-                  const int* slots, float* cat, int B, int T3, int F, int C) {
+void convnext_cat(const Ctx& ctx, const float* a3, float* pool, long long slot_stride, long long embed_off, const int* slots, float* cat,
+                  float* byp, int B, int T3, int Tc, int F, int C) {
+    K2_REQUIRE(Tc >= 3 && Tc <= T3, "convnext_cat: chunk of %d frames out of %d", Tc, T3);
     if (ctx.dry) return;
     long long n = (long long)B * (T3 + 3) * F * C;
-    hipLaunchKernelGGL(k_convnext_cat, dim3(nb(n, 256)), dim3(256), 0, ctx.stream, a3, pool, slot_stride, embed_off, slots, cat, B, T3, F, C);
-    K2_HIP(hipGetLastError());
-}
-void convnext_cache_update(const Ctx& ctx, const float* a3, float* pool, long long slot_stride, long long embed_off,
-                           const int* slots, int B, int T3, int Tc, int F, int C) {
-    if (ctx.dry) return;
-    long long n = (long long)B * C * 3 * F;
-    hipLaunchKernelGGL(k_convnext_cache, dim3(nb(n, 256)), dim3(256), 0, ctx.stream, a3, pool, slot_stride, embed_off, slots, B, T3, Tc, F, C);
+    hipLaunchKernelGGL(k_convnext_cat, dim3(nb(n, 256)), dim3(256), 0, ctx.stream, a3, pool, slot_stride, embed_off, slots, cat, byp, B, T3, Tc,
+                       F, C);
     K2_HIP(hipGetLastError());
 }
 void cat_shift(const Ctx& ctx, float* pool, long long slot_stride, long long off, const int* slots, const float* newrows,

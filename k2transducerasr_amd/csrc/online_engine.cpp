@@ -246,16 +246,12 @@ float* Engine::encoder_embed_stream(const Ctx& c, const float* x, const int* d_s
     }
     // ConvNeXt.streaming_forward: [cache(3) ; a3(T3)] -> valid 7-tap time conv -> Tc frames
     float* cat = ar.take<float>((int64_t)B * (T3 + 3) * F3 * 128);
-    convnext_cat(c, a3, online_pool_, lay_.floats_per_stream, lay_.embed, d_slots, cat, B, T3, F3, 128);
-    convnext_cache_update(c, a3, online_pool_, lay_.floats_per_stream, lay_.embed, d_slots, B, T3, Tc, F3, 128);
     const int npix = B * Tc * F3;
+    float* byp = ar.take<float>((int64_t)npix * 128);  // bypass = x[:, :, :Tc]
+    convnext_cat(c, a3, online_pool_, lay_.floats_per_stream, lay_.embed, d_slots, cat, byp, B, T3, Tc, F3, 128);
     float* dw = ar.take<float>((int64_t)npix * 128);
     dwconv7x7(c, cat, m.w("encoder_embed.convnext.depthwise_conv.weight#kc"), m.w("encoder_embed.convnext.depthwise_conv.bias"), dw, B,
               T3 + 3, Tc, 0, F3, 128);
-    float* byp = ar.take<float>((int64_t)npix * 128);  // bypass = x[:, :, :Tc]
-    if (!c.dry)
-        K2_HIP(hipMemcpy2DAsync(byp, sizeof(float) * (size_t)Tc * F3 * 128, a3, sizeof(float) * (size_t)T3 * F3 * 128,
-                                sizeof(float) * (size_t)Tc * F3 * 128, B, hipMemcpyDeviceToDevice, c.stream));
     float* hid = ar.take<float>((int64_t)npix * 384);
     linear(c, dw, 128, m.w("encoder_embed.convnext.pointwise_conv1.weight"), m.w("encoder_embed.convnext.pointwise_conv1.bias"), hid, 384,
            npix, 128, 384, ACT_SWOOSH_L);
@@ -400,6 +396,7 @@ float* Engine::online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_
     const int M = B * Tc;
     float* outputs[kMaxStacks] = {nullptr};
     int Dcur = cf.dim[0], l = 0;
+    float *pre_y = nullptr, *pre_xd = nullptr;
     for (int si = 0; si < cf.ns; si++) {
         const int D = cf.dim[si], ds = cf.ds[si], L = cf.left[si];
         // the stack's input is the previous output zero-extended / truncated to D channels (convert_channels): a stack that runs at
@@ -418,13 +415,26 @@ float* Engine::online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_
             x = xi;
         } else {
             const int Td = (Tc + ds - 1) / ds;
-            float* y = ar.take<float>((int64_t)M * D);
+            // (as in the offline stacks: this stack's out_combiner + the next stack's downsample in one launch where both are downsampled)
+            float* y = pre_y ? pre_y : ar.take<float>((int64_t)M * D);
+            float* xd_ready = pre_xd;
+            pre_y = pre_xd = nullptr;
+            const bool fuse_next = si + 1 < cf.ns && cf.ds[si + 1] > 1;
+            const int D2 = fuse_next ? cf.dim[si + 1] : 0, ds2 = fuse_next ? cf.ds[si + 1] : 1;
+            if (fuse_next) {
+                pre_y = ar.take<float>((int64_t)M * D2);
+                pre_xd = ar.take<float>((int64_t)B * ((Tc + ds2 - 1) / ds2) * D2);
+            }
             int64_t mark = ar.mark();
-            float* xd = ar.take<float>((int64_t)B * Td * D);
-            downsample(c, x, m.wf("encoder.encoders.%d.downsample.bias", si), xd, B, Tc, D, ds, Din);
+            float* xd = xd_ready ? xd_ready : ar.take<float>((int64_t)B * Td * D);
+            if (!xd_ready) downsample(c, x, m.wf("encoder.encoders.%d.downsample.bias", si), xd, B, Tc, D, ds, Din);
             const float* pe = c.dry ? nullptr : pos_emb_stream(Td, L);
             for (int li = 0; li < cf.nlayer[si]; li++, l++) encoder_layer_stream(c, si, li, l, xd, pe, d_slots, d_plen, d_chunks, B, Td, L);
-            upsample_combine(c, x, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y, B, Tc, Td, D, ds, Din);
+            if (fuse_next)
+                upsample_combine_downsample(c, x, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y,
+                                            m.wf("encoder.encoders.%d.downsample.bias", si + 1), pre_xd, B, Tc, Td, D, ds, Din, D2, ds2);
+            else
+                upsample_combine(c, x, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y, B, Tc, Td, D, ds, Din);
             ar.rewind(mark);
             x = y;
         }
@@ -512,8 +522,9 @@ void Engine::online_step(const int* slots, const float* const* chunks, const lon
         // the f16 screen (measured per model: greedy_loop_screens)
         const bool persistent_search = tunables().search_rounds == 0 || (tunables().search_rounds < 0 && !cf.ctc && greedy_loop_screens(decjoin(), B, true, c.one_part));
         const bool ev_ok = !c.dry;
+        // online PadSequence (PadHelper.cs:9-13,58): the floor of genuine zeros runs inside the gather when the chunks come from the FIFO
         if (from_fifo) fifo_gather(c, online_fifo_, kFifoFrames, cf.feat, d_slots, d_heads, d_x, B, T);
-        logfloor_inplace(c, d_x, (long long)B * T * cf.feat);  // online PadSequence (PadHelper.cs:9-13,58)
+        else logfloor_inplace(c, d_x, (long long)B * T * cf.feat);
         if (cf.lstm || cf.conformer || cf.zip1) {
             int tc = Tp;
             float* enc = cf.lstm ? lstm_chunk(c, d_x, d_slots, B) : cf.zip1 ? zip1_chunk(c, d_x, d_slots, B, &tc) : conformer_chunk(c, d_x, d_slots, d_plen, B, &tc);
