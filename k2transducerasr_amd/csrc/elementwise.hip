@@ -526,9 +526,20 @@ __global__ void k_downsample_full(FullDimSegs segs, const float* __restrict__ bi
     const float* src = segs.src[sg];
     const int ld4 = segs.ld[sg] >> 2;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool lazy = sg == 0 && segs.lz_orig != nullptr;   // the last stack's out_combiner on the fly (FullDimSegs)
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lazy) sc = reinterpret_cast<const float4*>(segs.lz_scale)[q];
+    const int Do4 = segs.lz_Do >> 2;
     for (int k = 0; k < ds; k++) {
         int tt = min(t * ds + k, T - 1);
-        float4 v = reinterpret_cast<const float4*>(src)[((long long)b * T + tt) * ld4 + q];
+        float4 v;
+        if (lazy) {
+            const float4 o = q < Do4 ? reinterpret_cast<const float4*>(segs.lz_orig)[((long long)b * T + tt) * Do4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 u = reinterpret_cast<const float4*>(segs.lz_xd)[((long long)b * segs.lz_Td + tt / segs.lz_ds) * ld4 + q];
+            v = make_float4(o.x + (u.x - o.x) * sc.x, o.y + (u.y - o.y) * sc.y, o.z + (u.z - o.z) * sc.z, o.w + (u.w - o.w) * sc.w);
+        } else {
+            v = reinterpret_cast<const float4*>(src)[((long long)b * T + tt) * ld4 + q];
+        }
         s.x += v.x * wgt[k]; s.y += v.y * wgt[k]; s.z += v.z * wgt[k]; s.w += v.w * wgt[k];
     }
     reinterpret_cast<float4*>(y)[i] = s;

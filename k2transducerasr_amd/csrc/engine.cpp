@@ -485,6 +485,7 @@ float* Engine::encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, 
     float* x = x0;
     int Dcur = cf.dim[0];
     float *pre_y = nullptr, *pre_xd = nullptr;
+    FullDimSegs lz;   // (only its lz_* fields are used)
     for (int si = 0; si < cf.ns; si++) {
         const int D = cf.dim[si], ds = cf.ds[si];
         // the stack's input is the previous output zero-extended / truncated to D channels (convert_channels): a stack that runs at
@@ -520,12 +521,17 @@ float* Engine::encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, 
             if (!xd_ready) downsample(c, x, m.wf("encoder.encoders.%d.downsample.bias", si), xd, B, T50, D, ds, Din);
             const float* pe = c.dry ? nullptr : pos_emb(Td);
             for (int li = 0; li < cf.nlayer[si]; li++) encoder_layer(c, si, li, xd, pe, B, Td);
+            // the LAST stack's out_combiner runs inside the final downsample (FullDimSegs::lz_*): its output tensor is never written
+            const bool lazy = segs_out != nullptr && si == cf.ns - 1 && tap != 1 + si;
             if (fuse_next)
                 upsample_combine_downsample(c, x, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y,
                                             m.wf("encoder.encoders.%d.downsample.bias", si + 1), pre_xd, B, T50, Td, D, ds, Din, D2, ds2);
-            else
+            else if (lazy) {
+                lz.lz_orig = x; lz.lz_xd = xd; lz.lz_scale = c.dry ? nullptr : m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si);
+                lz.lz_Td = Td; lz.lz_ds = ds; lz.lz_Do = Din;
+            } else
                 upsample_combine(c, x, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y, B, T50, Td, D, ds, Din);
-            ar.rewind(mark);
+            if (!lazy) ar.rewind(mark);   // (lazy: xd is read by the final downsample -- it stays allocated)
             x = y;
         }
         outputs[si] = x;
@@ -538,6 +544,8 @@ float* Engine::encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, 
     }
     if (segs_out) {  // the caller gathers the columns itself (downsample_full): no concatenated tensor
         *segs_out = full_dim_segments(cf, outputs);
+        segs_out->lz_orig = c.dry ? nullptr : lz.lz_orig; segs_out->lz_xd = lz.lz_xd; segs_out->lz_scale = lz.lz_scale;
+        segs_out->lz_Td = lz.lz_Td; segs_out->lz_ds = lz.lz_ds; segs_out->lz_Do = lz.lz_Do;
         return nullptr;
     }
     // _get_full_dim_output

@@ -293,6 +293,12 @@ void convert_channels(const Ctx& ctx, const float* x, float* y, int M, int Din, 
 struct FullDimSegs {
     const float* src[8];
     int ld[8], col1[8], n = 0;
+    // segment 0 (the last stack's output) formed on the fly instead of read, when that stack is downsampled: its out_combiner
+    // orig + (upsample(xd) - orig) * scale (k_upsample_combine's expression) -- the tensor itself is never written
+    const float* lz_orig = nullptr;   // [B*T, lz_Do] (zero-extended / truncated to the stack's width)
+    const float* lz_xd = nullptr;     // [B*lz_Td, ld[0]]
+    const float* lz_scale = nullptr;
+    int lz_Td = 0, lz_ds = 1, lz_Do = 0;
 };
 void downsample_full(const Ctx& ctx, const FullDimSegs& segs, const float* bias, float* y, int B, int T, int D, int ds);
 void copy_cols(const Ctx& ctx, const float* x, int ldx, int xcol0, float* y, int ldy, int ycol0, int M, int n);

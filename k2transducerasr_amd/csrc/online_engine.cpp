@@ -397,6 +397,7 @@ float* Engine::online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_
     float* outputs[kMaxStacks] = {nullptr};
     int Dcur = cf.dim[0], l = 0;
     float *pre_y = nullptr, *pre_xd = nullptr;
+    FullDimSegs lz;   // (only its lz_* fields are used)
     for (int si = 0; si < cf.ns; si++) {
         const int D = cf.dim[si], ds = cf.ds[si], L = cf.left[si];
         // the stack's input is the previous output zero-extended / truncated to D channels (convert_channels): a stack that runs at
@@ -430,12 +431,16 @@ float* Engine::online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_
             if (!xd_ready) downsample(c, x, m.wf("encoder.encoders.%d.downsample.bias", si), xd, B, Tc, D, ds, Din);
             const float* pe = c.dry ? nullptr : pos_emb_stream(Td, L);
             for (int li = 0; li < cf.nlayer[si]; li++, l++) encoder_layer_stream(c, si, li, l, xd, pe, d_slots, d_plen, d_chunks, B, Td, L);
+            const bool lazy = si == cf.ns - 1;   // the last stack's out_combiner runs inside the final downsample (FullDimSegs::lz_*)
             if (fuse_next)
                 upsample_combine_downsample(c, x, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y,
                                             m.wf("encoder.encoders.%d.downsample.bias", si + 1), pre_xd, B, Tc, Td, D, ds, Din, D2, ds2);
-            else
+            else if (lazy) {
+                lz.lz_orig = x; lz.lz_xd = xd; lz.lz_scale = m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si);
+                lz.lz_Td = Td; lz.lz_ds = ds; lz.lz_Do = Din;
+            } else
                 upsample_combine(c, x, xd, m.wf("encoder.encoders.%d.out_combiner.bypass_scale", si), y, B, Tc, Td, D, ds, Din);
-            ar.rewind(mark);
+            if (!lazy) ar.rewind(mark);   // (lazy: xd is read by the final downsample -- it stays allocated)
             x = y;
         }
         outputs[si] = x;
@@ -456,6 +461,8 @@ float* Engine::online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_
                 cur = d;
             }
         }
+        segs.lz_orig = c.dry ? nullptr : lz.lz_orig; segs.lz_xd = lz.lz_xd; segs.lz_scale = lz.lz_scale;
+        segs.lz_Td = lz.lz_Td; segs.lz_ds = lz.lz_ds; segs.lz_Do = lz.lz_Do;
         downsample_full(c, segs, m.w("encoder.downsample_output.bias"), dsd, B, Tc, Dmax, 2);
     }
     float* enc = ar.take<float>((int64_t)B * Tp * cf.enc_dim());
