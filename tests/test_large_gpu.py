@@ -329,8 +329,12 @@ def test_full_size_beam4_fresh_audio_every_divergence_localised(hip_large, oracl
     Round 5, the gate at what was MEASURED (profiles/r04_soak_full_size_10_batches.txt: operator level 311 / 320, fused 305 / 320, largest
     localised gap 1.2e-4): operator level >= 30 / 32 and fused >= 29 / 32 -- or, on a batch with more near-ties than that, every
     localised gap <= 2e-4; and the engine's two forms of the search (one kernel per batch, four launches per frame) must decide every
-    stream alike unless the oracle's own candidates TIE there (gap 0.0: two float32 scores equal to the last bit, ordered by flat index in
-    the oracle and by the joiner's summation order here) -- a form-dependent result at a gap > 0 would be a search-kernel bug."""
+    stream alike unless the oracle's own candidates are a near-tie there, by the same 2e-4: the two forms sum the joiner's products in
+    different orders (a sweep on the matrix pipe in the one-kernel form, a GEMM in the launch form), and at |score| ~ 100 a gap of
+    6.1e-5 is eight float32 steps.  (The round's first version of this gate demanded an EXACT tie, gap 0.0; the round's own soak --
+    profiles/r05_soak_full_size_10_batches.txt: 7 of 320 streams decided differently by the forms, 4 of them at 6.1e-5, 3 at 0.0 --
+    and this test's clock-seeded audio then showed that bar failing one run in three on rounding alone.)  A form-dependent result at a
+    gap beyond the near-tie bound would be a search-kernel bug."""
     import os
     import time
     from k2transducerasr_amd.synth import synth_utterance
@@ -343,8 +347,8 @@ def test_full_size_beam4_fresh_audio_every_divergence_localised(hip_large, oracl
     assert (ex_op >= 30 and ex_f >= 29) or max(gaps, default=0.0) <= 2e-4, \
         f"operator level {ex_op}/32, fused {ex_f}/32 with a localised gap of {max(gaps, default=0.0):.3g}: misses this frequent at gaps this wide are not near-ties"
     for b, gf, gl in forms:
-        assert max(g for g in (gf, gl, 0.0) if g is not None) == 0.0, \
-            f"stream {b}: the engine's two search forms disagree where the oracle's candidates are {gf} / {gl} apart (not a tie)"
+        assert max(g for g in (gf, gl, 0.0) if g is not None) <= 2e-4, \
+            f"stream {b}: the engine's two search forms disagree where the oracle's candidates are {gf} / {gl} apart (not a near-tie)"
 
 
 def test_search_exchange_timeout_is_retried_with_one_part(hip_large):
