@@ -332,7 +332,8 @@ def test_full_size_beam4_fresh_audio_every_divergence_localised(hip_large, oracl
     stream alike unless the oracle's own candidates are a near-tie there, by the same 2e-4: the two forms sum the joiner's products in
     different orders (a sweep on the matrix pipe in the one-kernel form, a GEMM in the launch form), and at |score| ~ 100 a gap of
     6.1e-5 is eight float32 steps.  (The round's first version of this gate demanded an EXACT tie, gap 0.0; the round's own soak --
-    profiles/r05_soak_full_size_10_batches.txt: 7 of 320 streams decided differently by the forms, 4 of them at 6.1e-5, 3 at 0.0 --
+    tools/soak_full_size.py on two sets of seeds: 7 of 320 streams decided differently by the forms, 4 of them at 6.1e-5, 3 at 0.0;
+    3 of 320 in profiles/r05_soak_full_size_10_batches.txt, one at 6.1e-5 --
     and this test's clock-seeded audio then showed that bar failing one run in three on rounding alone.)  A form-dependent result at a
     gap beyond the near-tie bound would be a search-kernel bug."""
     import os
