@@ -311,6 +311,73 @@ __global__ void k_biasnorm(const float* __restrict__ x, const float* __restrict_
     }
 }
 
+// The last layer of a stack that runs at the input rate, in front of a downsampled stack: BiasNorm + bypass (k_biasnorm<true>'s
+// arithmetic, row by row) AND the next stack's SimpleDownsample of the result (k_downsample's weighted sum, same order) in one launch.
+// One wave per (stream, downsampled frame): it walks the group's ds2 rows, writes each (y may be `orig`: a row is read whole before it
+// is written), and keeps the running sum in registers; a frame past T repeats the last row from registers (never re-read: it has been
+// overwritten in place).  xd2 rows are D2 wide: zero-extended (truncated) like convert_channels.
+__global__ void k_biasnorm_bypass_downsample(const float* __restrict__ x, const float* __restrict__ orig, const float* __restrict__ nbias,
+                                             const float* __restrict__ log_scale, const float* __restrict__ bscale, float* __restrict__ y,
+                                             const float* __restrict__ bias2, float* __restrict__ xd2, int B, int T, int D, int ds2, int D2) {
+    const int Td2 = (T + ds2 - 1) / ds2;
+    const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= B * Td2) return;
+    const int lane = threadIdx.x & 63, b = g / Td2, t2 = g - b * Td2;
+    float wgt[16], mx = -INFINITY, sum = 0.f;
+    for (int k = 0; k < ds2; k++) mx = fmaxf(mx, bias2[k]);
+    for (int k = 0; k < ds2; k++) { wgt[k] = expf(bias2[k] - mx); sum += wgt[k]; }
+    for (int k = 0; k < ds2; k++) wgt[k] /= sum;
+    const int nq = D >> 2, nq2 = D2 >> 2;
+    const float es = expf(log_scale[0]);
+    float4 acc[4], last[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[j] = last[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < ds2; k++) {
+        const int t = t2 * ds2 + k;
+        if (t < T) {
+            const long long row = (long long)b * T + t;
+            const float* xr = x + row * D;
+            float4 v[4];
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int q = lane + 64 * j;
+                if (q < nq) {
+                    v[j] = *reinterpret_cast<const float4*>(xr + 4 * q);
+                    const float4 bq = *reinterpret_cast<const float4*>(nbias + 4 * q);
+                    const float a0 = v[j].x - bq.x, a1 = v[j].y - bq.y, a2 = v[j].z - bq.z, a3 = v[j].w - bq.w;
+                    s += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float sc = (1.0f / sqrtf(s / (float)D)) * es;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int q = lane + 64 * j;
+                if (q < nq) {
+                    float4 o = make_float4(v[j].x * sc, v[j].y * sc, v[j].z * sc, v[j].w * sc);
+                    const float4 gq = *reinterpret_cast<const float4*>(orig + row * D + 4 * q);
+                    const float4 bs = *reinterpret_cast<const float4*>(bscale + 4 * q);
+                    o.x = gq.x + (o.x - gq.x) * bs.x; o.y = gq.y + (o.y - gq.y) * bs.y;
+                    o.z = gq.z + (o.z - gq.z) * bs.z; o.w = gq.w + (o.w - gq.w) * bs.w;
+                    *reinterpret_cast<float4*>(y + row * D + 4 * q) = o;
+                    last[j] = o;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            acc[j].x += last[j].x * wgt[k]; acc[j].y += last[j].y * wgt[k]; acc[j].z += last[j].z * wgt[k]; acc[j].w += last[j].w * wgt[k];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int q = lane + 64 * j;
+        if (q < nq2) *reinterpret_cast<float4*>(xd2 + ((long long)b * Td2 + t2) * D2 + 4 * q) = q < nq ? acc[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 // ---- BasicNorm (Conformer): y = x * (mean(x^2) + exp(log_eps))^-0.5, one wave per row
 __global__ void k_basicnorm(const float* __restrict__ x, const float* __restrict__ log_eps, float* __restrict__ y, int M, int D) {
     int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -677,6 +744,13 @@ void biasnorm_bypass(const Ctx& ctx, const float* x, const float* orig, const fl
                      const float* scale, float* y, int M, int D) {
     K2_REQUIRE(D % 4 == 0 && D <= 1024, "biasnorm: D=%d unsupported", D);
     LAUNCH((k_biasnorm<true>), dim3(nblocks(M, 4)), dim3(256), x, orig, nbias, log_scale, scale, y, M, D);
+}
+void biasnorm_bypass_downsample(const Ctx& ctx, const float* x, const float* orig, const float* nbias, const float* log_scale, const float* scale,
+                                float* y, const float* bias2, float* xd2, int B, int T, int D, int ds2, int D2) {
+    K2_REQUIRE(D % 4 == 0 && D <= 1024 && D2 % 4 == 0 && D2 <= 1024 && ds2 >= 1 && ds2 <= 16, "biasnorm + downsample: D=%d D2=%d ds=%d unsupported", D, D2, ds2);
+    const int Td2 = (T + ds2 - 1) / ds2;
+    LAUNCH(k_biasnorm_bypass_downsample, dim3(nblocks((long long)B * Td2, 4)), dim3(256), x, orig, nbias, log_scale, scale, y, bias2, xd2, B, T, D,
+           ds2, D2);
 }
 void bypass(const Ctx& ctx, const float* orig, const float* x, const float* scale, float* y, int M, int D) {
     long long n4 = (long long)M * D / 4;

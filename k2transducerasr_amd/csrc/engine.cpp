@@ -333,7 +333,7 @@ const float* Engine::pos_proj_cached(const Ctx& c, int layer, const float* pe, i
 // ---------------------------------------------------------------------------
 // Zipformer2EncoderLayer.forward (inference), in place on x [B*T, D]
 // ---------------------------------------------------------------------------
-void Engine::encoder_layer(const Ctx& c, int si, int li, float* x, const float* pe, int B, int T) {
+void Engine::encoder_layer(const Ctx& c, int si, int li, float* x, const float* pe, int B, int T, const LayerTail* tail) {
     const Model& m = *model_;
     const Config& cf = m.cfg();
     const int D = cf.dim[si], F = cf.ff[si], H = cf.heads[si], vh = cf.vhd[si], K = cf.kern[si];
@@ -453,7 +453,11 @@ void Engine::encoder_layer(const Ctx& c, int si, int li, float* x, const float* 
     self_attn(2);
     conv_module(2);
     feed_forward(3, F * 5 / 4, src, src);
-    biasnorm_bypass(c, src, x, w("norm.bias"), w("norm.log_scale"), w("bypass.bypass_scale"), x, M, D);
+    if (tail && tail->bias2)   // the stack's last layer in front of a downsampled stack: that stack's downsample in the same launch
+        biasnorm_bypass_downsample(c, src, x, w("norm.bias"), w("norm.log_scale"), w("bypass.bypass_scale"), x, tail->bias2, tail->xd2, B, T, D,
+                                   tail->ds2, tail->D2);
+    else
+        biasnorm_bypass(c, src, x, w("norm.bias"), w("norm.log_scale"), w("bypass.bypass_scale"), x, M, D);
     ar.rewind(mark);
 }
 
@@ -500,7 +504,16 @@ float* Engine::encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, 
                 convert_channels(c, x, xi, M, Din, D);
             }
             const float* pe = c.dry ? nullptr : pos_emb(T50);
-            for (int li = 0; li < cf.nlayer[si]; li++) encoder_layer(c, si, li, xi, pe, B, T50);
+            // in front of a downsampled stack the last layer's BiasNorm launch forms that stack's input as well (LayerTail)
+            LayerTail tail;
+            if (si + 1 < cf.ns && cf.ds[si + 1] > 1 && cf.nlayer[si] > 0) {
+                tail.D2 = cf.dim[si + 1]; tail.ds2 = cf.ds[si + 1];
+                pre_y = ar.take<float>((int64_t)M * tail.D2);
+                pre_xd = ar.take<float>((int64_t)B * ((T50 + tail.ds2 - 1) / tail.ds2) * tail.D2);
+                tail.xd2 = pre_xd;
+                tail.bias2 = m.wf("encoder.encoders.%d.downsample.bias", si + 1);
+            }
+            for (int li = 0; li < cf.nlayer[si]; li++) encoder_layer(c, si, li, xi, pe, B, T50, li == cf.nlayer[si] - 1 ? &tail : nullptr);
             x = xi;
         } else {
             const int Td = (T50 + ds - 1) / ds;

@@ -142,7 +142,7 @@ class Engine {
   private:
     // device-side building blocks; all take a Ctx (dry run = sizing only)
     float* encoder_embed(const Ctx& c, const float* x, int B, int T, int* T50);
-    void encoder_layer(const Ctx& c, int si, int li, float* x, const float* pe, int B, int T);
+    void encoder_layer(const Ctx& c, int si, int li, float* x, const float* pe, int B, int T, const LayerTail* tail = nullptr);
     float* encoder_stacks(const Ctx& c, float* x0, int B, int T50, int tap, float** tap_ptr, int* tap_dim, bool* tapped, FullDimSegs* segs_out = nullptr);
     float* encoder_forward(const Ctx& c, const float* x, int B, int T, int* Tp, int tap, float** tap_ptr, int* tap_rows,
                            int* tap_dim);
@@ -186,7 +186,7 @@ class Engine {
     void online_ensure_pool();
     float* encoder_embed_stream(const Ctx& c, const float* x, const int* d_slots, int B, int T, int* Tc);
     void encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x, const float* pe, const int* d_slots,
-                              const long long* d_plen, const int* d_chunks, int B, int Tc, int L);
+                              const long long* d_plen, const int* d_chunks, int B, int Tc, int L, const LayerTail* tail = nullptr);
     std::mutex cache_mu_;  // pos_proj / pos_emb / decjoin tables are built lazily
     float* online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_slots, const long long* d_plen, const int* d_chunks, int B);
     DecJoinW decjoin();

@@ -230,6 +230,16 @@ void biasnorm(const Ctx& ctx, const float* x, const float* bias, const float* lo
 // y = orig + (biasnorm(x) - orig) * scale     (layer tail: norm + bypass)
 void biasnorm_bypass(const Ctx& ctx, const float* x, const float* orig, const float* nbias, const float* log_scale,
                      const float* scale, float* y, int M, int D);
+// the same for the last layer of an input-rate stack in front of a downsampled one, and that stack's SimpleDownsample of the result
+// (xd2 [B * ceil(T / ds2), D2]) in the same launch
+void biasnorm_bypass_downsample(const Ctx& ctx, const float* x, const float* orig, const float* nbias, const float* log_scale, const float* scale,
+                                float* y, const float* bias2, float* xd2, int B, int T, int D, int ds2, int D2);
+// what a layer's last launch also has to produce when it is that layer (null bias2: nothing)
+struct LayerTail {
+    const float* bias2 = nullptr;
+    float* xd2 = nullptr;
+    int ds2 = 1, D2 = 0;
+};
 void bypass(const Ctx& ctx, const float* orig, const float* x, const float* scale, float* y, int M, int D);
 void glu_sigmoid(const Ctx& ctx, const float* x, float* y, int M, int D);          // y = x[:, :D] * sigmoid(x[:, D:])
 void tanh_gate(const Ctx& ctx, const float* x, float* y, int M, int Hc);           // y = x[:, Hc:2Hc] * tanh(x[:, :Hc])

@@ -267,7 +267,7 @@ float* Engine::encoder_embed_stream(const Ctx& c, const float* x, const int* d_s
 
 // Zipformer2EncoderLayer.streaming_forward, in place on x [B*Tc, D]; l = global layer index
 void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x, const float* pe, const int* d_slots,
-                                  const long long* d_plen, const int* d_chunks, int B, int Tc, int L) {
+                                  const long long* d_plen, const int* d_chunks, int B, int Tc, int L, const LayerTail* tail) {
     const Model& m = *model_;
     const Config& cf = m.cfg();
     const int D = cf.dim[si], F = cf.ff[si], H = cf.heads[si], vh = cf.vhd[si], K = cf.kern[si], qh = cf.qhd[si], ph = cf.phd[si];
@@ -380,7 +380,11 @@ void Engine::encoder_layer_stream(const Ctx& c, int si, int li, int l, float* x,
     self_attn(2, lay_.val2[l]);
     conv_module(2, lay_.conv2[l]);
     feed_forward(3, F * 5 / 4, src, src);
-    biasnorm_bypass(c, src, x, w("norm.bias"), w("norm.log_scale"), w("bypass.bypass_scale"), x, M, D);
+    if (tail && tail->bias2)   // the stack's last layer in front of a downsampled stack: that stack's downsample in the same launch
+        biasnorm_bypass_downsample(c, src, x, w("norm.bias"), w("norm.log_scale"), w("bypass.bypass_scale"), x, tail->bias2, tail->xd2, B, Tc, D,
+                                   tail->ds2, tail->D2);
+    else
+        biasnorm_bypass(c, src, x, w("norm.bias"), w("norm.log_scale"), w("bypass.bypass_scale"), x, M, D);
     ar.rewind(mark);
 }
 
@@ -412,7 +416,17 @@ float* Engine::online_encoder_zip2(const Ctx& c, const float* d_x, const int* d_
                 convert_channels(c, x, xi, M, Din, D);
             }
             const float* pe = c.dry ? nullptr : pos_emb_stream(Tc, L);
-            for (int li = 0; li < cf.nlayer[si]; li++, l++) encoder_layer_stream(c, si, li, l, xi, pe, d_slots, d_plen, d_chunks, B, Tc, L);
+            // in front of a downsampled stack the last layer's BiasNorm launch forms that stack's input as well (LayerTail)
+            LayerTail tail;
+            if (si + 1 < cf.ns && cf.ds[si + 1] > 1 && cf.nlayer[si] > 0) {
+                tail.D2 = cf.dim[si + 1]; tail.ds2 = cf.ds[si + 1];
+                pre_y = ar.take<float>((int64_t)M * tail.D2);
+                pre_xd = ar.take<float>((int64_t)B * ((Tc + tail.ds2 - 1) / tail.ds2) * tail.D2);
+                tail.xd2 = pre_xd;
+                tail.bias2 = m.wf("encoder.encoders.%d.downsample.bias", si + 1);
+            }
+            for (int li = 0; li < cf.nlayer[si]; li++, l++)
+                encoder_layer_stream(c, si, li, l, xi, pe, d_slots, d_plen, d_chunks, B, Tc, L, li == cf.nlayer[si] - 1 ? &tail : nullptr);
             x = xi;
         } else {
             const int Td = (Tc + ds - 1) / ds;
