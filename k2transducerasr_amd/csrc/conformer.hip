@@ -184,7 +184,10 @@ template <int NG, int NW>
 __global__ __launch_bounds__(64 * NW) void k_conformer_scores_softmax16s(const float* __restrict__ qu, const float* __restrict__ qv,
                                                                      const float* __restrict__ kmat, int ldk, const float* __restrict__ pp,
                                                                      float* __restrict__ aw, int B, int H, int T, int Tp, int D,
-                                                                     int lds_stride, unsigned long long* __restrict__ stamps) {
+                                                                     int lds_stride, unsigned long long* __restrict__ stamps, int ldq,
+                                                                     const float* __restrict__ bu, const float* __restrict__ bv, float scaling) {
+    // bu != null: `qu` is the in_proj output's q block (rows ldq floats apart) and the two query operands are formed here, as
+    // k_conformer_qprep forms them (q * scaling + pos_bias_u / pos_bias_v) -- that launch and its two [M, D] tensors are gone (round 5)
     constexpr int DK = 16 * NG;
     extern __shared__ __attribute__((aligned(16))) float csm[];
     float* S = csm;                                   // [16][lds_stride] | 64 dump slots
@@ -203,8 +206,17 @@ __global__ __launch_bounds__(64 * NW) void k_conformer_scores_softmax16s(const f
         for (int g = 0; g < NG; g++) {
             fu[g] = fv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < T) {
-                fu[g] = *reinterpret_cast<const float4*>(qu + (rowbase + row) * D + h * DK + 16 * g + 4 * kq);
-                fv[g] = *reinterpret_cast<const float4*>(qv + (rowbase + row) * D + h * DK + 16 * g + 4 * kq);
+                if (bu) {
+                    float4 q = *reinterpret_cast<const float4*>(qu + (rowbase + row) * ldq + h * DK + 16 * g + 4 * kq);
+                    const float4 u = *reinterpret_cast<const float4*>(bu + h * DK + 16 * g + 4 * kq);
+                    const float4 v = *reinterpret_cast<const float4*>(bv + h * DK + 16 * g + 4 * kq);
+                    q.x *= scaling; q.y *= scaling; q.z *= scaling; q.w *= scaling;
+                    fu[g] = make_float4(q.x + u.x, q.y + u.y, q.z + u.z, q.w + u.w);
+                    fv[g] = make_float4(q.x + v.x, q.y + v.y, q.z + v.z, q.w + v.w);
+                } else {
+                    fu[g] = *reinterpret_cast<const float4*>(qu + (rowbase + row) * D + h * DK + 16 * g + 4 * kq);
+                    fv[g] = *reinterpret_cast<const float4*>(qv + (rowbase + row) * D + h * DK + 16 * g + 4 * kq);
+                }
             }
         }
     }
@@ -386,7 +398,7 @@ void conformer_softmax_shift(const Ctx& ctx, float* ac, const float* bd, int Z, 
 
 template <int NG>
 static bool conformer_scores_launch16(const Ctx& ctx, const float* qu, const float* qv, const float* kmat, int ldk, const float* pp, float* aw,
-                                      int B, int H, int T, int Tp, int D) {
+                                      int B, int H, int T, int Tp, int D, int ldq, const float* bu, const float* bv, float scaling) {
     const int lds_stride = Tp + 4;
     const size_t lds = sizeof(float) * ((size_t)16 * lds_stride + 64);   // + a dump slot per lane (masked positional writes)
     static LdsAttrOnce lds_attr;
@@ -400,7 +412,7 @@ static bool conformer_scores_launch16(const Ctx& ctx, const float* qu, const flo
             K2_HIP(hipMemsetAsync(d_st, 0, n_st * 8, ctx.stream));
         }
         hipLaunchKernelGGL((k_conformer_scores_softmax16s<NG, 4>), dim3(cdiv(T, 16), B, H), dim3(256), lds, ctx.stream, qu, qv, kmat, ldk, pp, aw, B, H,
-                           T, Tp, D, lds_stride, d_st);
+                           T, Tp, D, lds_stride, d_st, ldq, bu, bv, scaling);
         if (d_st) {   // tuning only: synchronous report (cycles of the slowest wave of each workgroup, averaged; launch span in realtime ticks)
             std::vector<unsigned long long> h(n_st);
             K2_HIP(hipStreamSynchronize(ctx.stream));
@@ -428,17 +440,20 @@ static bool conformer_scores_launch16(const Ctx& ctx, const float* qu, const flo
     return true;
 }
 
-// fused scores + softmax of the offline Conformer attention; returns false (nothing launched) when the shape does not fit
+// fused scores + softmax of the offline Conformer attention; returns false (nothing launched) when the shape does not fit.
+// bias_u != null: `qu` is the q block of the in_proj output (rows ldq floats apart, qv unused) and the kernel forms q * scaling + bias_u /
+// bias_v itself (no conformer_qprep launch in front)
 bool conformer_scores_softmax(const Ctx& ctx, const float* qu, const float* qv, const float* kmat, int ldk, const float* pp, float* aw, int B, int H,
-                              int T, int Tp, int D) {
+                              int T, int Tp, int D, int ldq, const float* bias_u, const float* bias_v, float scaling) {
     const int dk = D / H;
     if (tunables().conformer_gemm_scores || Tp % 4 != 0 || D % 4 != 0 || ldk % 4 != 0 || (dk != 16 && dk != 32 && dk != 64)) return false;
+    if (bias_u && (ldq % 4 != 0 || !bias_v)) return false;
     if (sizeof(float) * (size_t)CR * (Tp + 4) > 156 * 1024 || Tp > 64 * 20) return false;
     ctx.add_flops(0.0, 2.0 * dk * (double)T * (3.0 * T) * B * H, 0);
     if (ctx.dry) return true;
-    if (dk == 64) return conformer_scores_launch16<4>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
-    if (dk == 32) return conformer_scores_launch16<2>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
-    return conformer_scores_launch16<1>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D);
+    if (dk == 64) return conformer_scores_launch16<4>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D, ldq, bias_u, bias_v, scaling);
+    if (dk == 32) return conformer_scores_launch16<2>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D, ldq, bias_u, bias_v, scaling);
+    return conformer_scores_launch16<1>(ctx, qu, qv, kmat, ldk, pp, aw, B, H, T, Tp, D, ldq, bias_u, bias_v, scaling);
 }
 
 }  // namespace k2hip

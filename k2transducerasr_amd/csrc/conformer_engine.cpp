@@ -103,12 +103,15 @@ void Engine::conformer_layer(const Ctx& c, int li, float* x, const float* pe, in
         const float* pp = pos_proj_cached(c, 3000 + li, pe, D, w("self_attn.linear_pos.weight"), NP, D);
         float* qu = ar.take<float>((int64_t)M * D);
         float* qv = ar.take<float>((int64_t)M * D);
-        conformer_qprep(c, qkv, w("self_attn.pos_bias_u"), w("self_attn.pos_bias_v"), qu, qv, M, D, 1.0f / sqrtf((float)dk));
         float* ac = ar.take<float>((int64_t)B * H * T * Tp);
         float* bd = ar.take<float>((int64_t)B * H * T * NPp);
-        // scores + softmax in one kernel (no [T,T] / [T,2T-1] score tensors); the GEMM form below is the fallback for shapes it does
-        // not cover (very long utterances, unusual head sizes)
-        if (!conformer_scores_softmax(c, qu, qv, qkv + D, 3 * D, pp, ac, B, H, T, Tp, D)) {
+        // scores + softmax in one kernel (no [T,T] / [T,2T-1] score tensors), the two query operands q * scaling + pos_bias_u / _v formed
+        // on its way in (round 5: k_conformer_qprep was a launch of its own per layer); the GEMM form below is the fallback for shapes it
+        // does not cover (very long utterances, unusual head sizes)
+        const float scaling = 1.0f / sqrtf((float)dk);
+        if (!conformer_scores_softmax(c, qkv, nullptr, qkv + D, 3 * D, pp, ac, B, H, T, Tp, D, 3 * D, w("self_attn.pos_bias_u"), w("self_attn.pos_bias_v"),
+                                      scaling)) {
+            conformer_qprep(c, qkv, w("self_attn.pos_bias_u"), w("self_attn.pos_bias_v"), qu, qv, M, D, scaling);
             {   // ac[b,h] = qu[b,:,h] . k[b,:,h]^T      z = h + H*b
                 GemmArgs g;
                 g.A = qu; g.lda = D; g.sA0 = dk; g.sA1 = (long long)T * D;

@@ -289,7 +289,7 @@ void conformer_softmax_shift(const Ctx& ctx, float* ac, const float* bd, int Z, 
 // fused form: aw[b*H+h][i][:] = softmax_j((q+u)_i.k_j + (q+v)_i.p[T-1-i+j]) straight from qu / qv [B*T, D], k rows (row stride ldk) and the
 // projected positional table pp [2T-1, D]; false = shape not covered (caller takes the GEMM + conformer_softmax_shift form)
 bool conformer_scores_softmax(const Ctx& ctx, const float* qu, const float* qv, const float* kmat, int ldk, const float* pp, float* aw, int B, int H,
-                              int T, int Tp, int D);
+                              int T, int Tp, int D, int ldq = 0, const float* bias_u = nullptr, const float* bias_v = nullptr, float scaling = 1.0f);
 // Din / Dorig > 0: the input rows are that wide and are zero-extended / truncated to D on the fly (convert_channels folded in)
 void downsample(const Ctx& ctx, const float* x, const float* bias, float* y, int B, int T, int D, int ds, int Din = 0);
 void upsample_combine(const Ctx& ctx, const float* orig, const float* xd, const float* scale, float* y, int B, int T,
