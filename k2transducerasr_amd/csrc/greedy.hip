@@ -438,7 +438,6 @@ __device__ __forceinline__ unsigned long long load_granule(const unsigned long l
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 constexpr int kScreenCand = 64;          // (frame, column) pairs re-checked per round and part: one per (pair, k slice) thread
 constexpr int kScreenMaxCols = 1536;     // scr[GF][cols] + the lists below live in the psum area (kPsumFloats)
-constexpr int kScreenSteps = 16;         // J <= 512
 static_assert(GF * kScreenMaxCols + 64 + 8 + kScreenCand + kScreenCand * 8 <= kPsumFloats, "screen: LDS layout");
 
 // actH: the round's activations as f16 A fragments [J / 32][64 lanes][8] (rows >= GF of the 16-row tile stay zero).
